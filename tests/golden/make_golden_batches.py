@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Generate seeded golden batches with the PYTHON oracle (oracle/plume_oracle.py, itself pinned to the
+reference's KATs).  Output: tests/golden/golden_batches.json — inputs and expected outputs only.
+
+    python tests/golden/make_golden_batches.py        (~1-2 min on 8 cores)
+
+Batches (BASELINE.md §3 synthetic generator, seed 0x504C554D45):
+  sign_v1 / sign_v2   : items 0..63    sk, r, msg -> pk, h, nullifier, c, s, r_point, hashed_to_curve_r, status, u0,u1,q0,q1
+  verify_v1 / verify_v2: items 0..255  signatures of the same generator with 1/16 corrupted -> expected ok
+  edge                : hand-built edge cases (ragged / empty messages, identity points, non-canonical and
+                        off-curve inputs, zero / >= n scalars, swapped fields) -> expected ok from the oracle
+"""
+import json
+import sys
+from multiprocessing import Pool
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import plume_oracle as O  # noqa: E402
+
+N_SIGN, N_VERIFY = 64, 256
+
+
+def hx(b):
+    return b.hex()
+
+
+def sign_item(args):
+    ver, i = args
+    sk, r, msg = O.synth_sk(i), O.synth_r(i), O.synth_msg(i)
+    sig = O.sign(ver, sk, r, msg)
+    _, (u0, u1, q0, q1) = O.hash_to_curve_bytes(msg + O.sec1_compress(sig["pk"]), want_intermediates=True)
+    return dict(i=i, sk=hx(sk.to_bytes(32, "big")), r=hx(r.to_bytes(32, "big")), msg=hx(msg),
+                pk=hx(O.pt_bytes(sig["pk"])), h=hx(O.pt_bytes(sig["h"])), nullifier=hx(O.pt_bytes(sig["nullifier"])),
+                c=hx(sig["c"].to_bytes(32, "big")), s=hx(sig["s"].to_bytes(32, "big")),
+                r_point=hx(O.pt_bytes(sig["r_point"])), hashed_to_curve_r=hx(O.pt_bytes(sig["hashed_to_curve_r"])),
+                status=sig["status"], u0=hx(u0.to_bytes(32, "big")), u1=hx(u1.to_bytes(32, "big")),
+                q0=hx(O.pt_bytes(q0)), q1=hx(O.pt_bytes(q1)))
+
+
+def corrupt(ver, i, it, prev_nul):
+    """items with i mod 16 == 5 are corrupted by kind (i div 16) mod 4."""
+    it = dict(it)
+    if i % 16 != 5:
+        return it
+    kind = (i // 16) % 4
+    if kind == 0:
+        b = bytearray.fromhex(it["s"]); b[31] ^= 1; it["s"] = b.hex()
+    elif kind == 1:
+        b = bytearray.fromhex(it["c"]); b[31] ^= 1; it["c"] = b.hex()
+    elif kind == 2:
+        it["nullifier"] = prev_nul
+    elif ver == 1:
+        it["r_point"], it["hashed_to_curve_r"] = it["hashed_to_curve_r"], it["r_point"]
+    else:
+        b = bytearray.fromhex(it["msg"]); b[0] ^= 1; it["msg"] = b.hex()
+    return it
+
+
+def verify_item(args):
+    ver, it = args
+    P = O.pt_from_bytes
+    kw = {}
+    if ver == 1:
+        kw = dict(r_point=P(bytes.fromhex(it["r_point"])), hashed_to_curve_r=P(bytes.fromhex(it["hashed_to_curve_r"])))
+    ok = O.verify(ver, bytes.fromhex(it["msg"]), P(bytes.fromhex(it["pk"])), P(bytes.fromhex(it["nullifier"])),
+                  int(it["c"], 16), int(it["s"], 16), **kw)
+    keep = ["msg", "pk", "nullifier", "c", "s"] + (["r_point", "hashed_to_curve_r"] if ver == 1 else [])
+    out = {k: it[k] for k in keep}
+    out["ok"] = int(ok)
+    if "note" in it:
+        out["note"] = it["note"]
+    return out
+
+
+def edge_cases():
+    """(version, item) pairs; all derived from two honest signatures."""
+    out = []
+    base = {}
+    for ver in (1, 2):
+        sk, r = O.synth_sk(1000 + ver), O.synth_r(1000 + ver)
+        for mlen in (0, 1, 29, 31, 33, 55, 56, 63, 64, 65, 87, 88, 119, 120, 151, 152, 200, 300):
+            msg = (O.blk("edge", mlen) * 10)[:mlen]
+            sig = O.sign(ver, sk, r, msg)
+            it = dict(msg=hx(msg), pk=hx(O.pt_bytes(sig["pk"])), nullifier=hx(O.pt_bytes(sig["nullifier"])),
+                      c=hx(sig["c"].to_bytes(32, "big")), s=hx(sig["s"].to_bytes(32, "big")),
+                      r_point=hx(O.pt_bytes(sig["r_point"])), hashed_to_curve_r=hx(O.pt_bytes(sig["hashed_to_curve_r"])),
+                      note=f"honest, |m|={mlen}")
+            out.append((ver, it))
+            if mlen == 29:
+                base[ver] = it
+
+        def var(note, **kw):
+            it = dict(base[ver]); it.update(kw); it["note"] = note
+            out.append((ver, it))
+
+        b = base[ver]
+        zero32, zero64 = "00" * 32, "00" * 64
+        n_hex = O.N.to_bytes(32, "big").hex()
+        p_hex = O.P.to_bytes(32, "big").hex()
+        var("c = 0", c=zero32)
+        var("s = 0", s=zero32)
+        var("c = n", c=n_hex)
+        var("s = n", s=n_hex)
+        var("c + n (non-canonical alias of a valid c)", c=((int(b["c"], 16) + O.N) % 2**256).to_bytes(32, "big").hex() if int(b["c"], 16) + O.N < 2**256 else n_hex)
+        var("s = n-1", s=(O.N - 1).to_bytes(32, "big").hex())
+        var("c = n-1", c=(O.N - 1).to_bytes(32, "big").hex())
+        var("pk = identity", pk=zero64)
+        var("nullifier = identity", nullifier=zero64)
+        var("pk.x += p (non-canonical)", pk=((int(b["pk"][:64], 16) + O.P) % 2**256).to_bytes(32, "big").hex() + b["pk"][64:] if int(b["pk"][:64], 16) + O.P < 2**256 else p_hex + b["pk"][64:])
+        var("pk.x = p", pk=p_hex + b["pk"][64:])
+        var("pk off curve (y ^ 1)", pk=b["pk"][:126] + f"{int(b['pk'][126:], 16) ^ 1:02x}")
+        var("nullifier off curve", nullifier=b["nullifier"][:126] + f"{int(b['nullifier'][126:], 16) ^ 1:02x}")
+        var("pk negated (on curve, wrong)", pk=b["pk"][:64] + (O.P - int(b["pk"][64:], 16)).to_bytes(32, "big").hex())
+        var("nullifier negated", nullifier=b["nullifier"][:64] + (O.P - int(b["nullifier"][64:], 16)).to_bytes(32, "big").hex())
+        var("pk = G", pk=hx(O.pt_bytes(O.G)))
+        var("nullifier = G", nullifier=hx(O.pt_bytes(O.G)))
+        var("nullifier = pk", nullifier=b["pk"])
+        var("message truncated", msg=b["msg"][:-2])
+        var("message extended", msg=b["msg"] + "00")
+        if ver == 1:
+            var("r_point = identity", r_point=zero64)
+            var("hashed_to_curve_r = identity", hashed_to_curve_r=zero64)
+            var("r_point off curve", r_point=b["r_point"][:126] + f"{int(b['r_point'][126:], 16) ^ 1:02x}")
+            var("r_point negated", r_point=b["r_point"][:64] + (O.P - int(b["r_point"][64:], 16)).to_bytes(32, "big").hex())
+            var("hashed_to_curve_r negated", hashed_to_curve_r=b["hashed_to_curve_r"][:64] + (O.P - int(b["hashed_to_curve_r"][64:], 16)).to_bytes(32, "big").hex())
+            var("r_point.y = p (non-canonical)", r_point=b["r_point"][:64] + p_hex)
+        # sk = 0 forgery that the reference ACCEPTS (pk = nullifier = identity; encodings shrink to 00)
+        msg = b"identity forgery"
+        r0 = O.synth_r(77)
+        R = O.pt_mul(r0, O.G)
+        h = O.hash_to_curve(msg, None)
+        hr = O.pt_mul(r0, h)
+        c0 = int.from_bytes(O.c_hash(ver, None, h, None, R, hr), "big") % O.N
+        out.append((ver, dict(msg=hx(msg), pk=zero64, nullifier=zero64, c=hx(c0.to_bytes(32, "big")), s=hx(r0.to_bytes(32, "big")),
+                              r_point=hx(O.pt_bytes(R)), hashed_to_curve_r=hx(O.pt_bytes(hr)), note="sk=0 forgery: pk=nul=identity (reference accepts)")))
+        # sk = 1: pk = G, nullifier = H  (tables of both bases coincide: exercises P+P / P-P paths in double-base loops)
+        sig = O.sign(ver, 1, r0, msg)
+        out.append((ver, dict(msg=hx(msg), pk=hx(O.pt_bytes(sig["pk"])), nullifier=hx(O.pt_bytes(sig["nullifier"])),
+                              c=hx(sig["c"].to_bytes(32, "big")), s=hx(sig["s"].to_bytes(32, "big")),
+                              r_point=hx(O.pt_bytes(sig["r_point"])), hashed_to_curve_r=hx(O.pt_bytes(sig["hashed_to_curve_r"])), note="sk=1 (pk=G, nul=H)")))
+        # r = sk: R = pk, Hr = nullifier
+        skx = O.synth_sk(5)
+        sig = O.sign(ver, skx, skx, msg)
+        out.append((ver, dict(msg=hx(msg), pk=hx(O.pt_bytes(sig["pk"])), nullifier=hx(O.pt_bytes(sig["nullifier"])),
+                              c=hx(sig["c"].to_bytes(32, "big")), s=hx(sig["s"].to_bytes(32, "big")),
+                              r_point=hx(O.pt_bytes(sig["r_point"])), hashed_to_curve_r=hx(O.pt_bytes(sig["hashed_to_curve_r"])), note="r=sk (R=pk, Hr=nul)")))
+        # sk = n-1: pk = -G
+        sig = O.sign(ver, O.N - 1, r0, msg)
+        out.append((ver, dict(msg=hx(msg), pk=hx(O.pt_bytes(sig["pk"])), nullifier=hx(O.pt_bytes(sig["nullifier"])),
+                              c=hx(sig["c"].to_bytes(32, "big")), s=hx(sig["s"].to_bytes(32, "big")),
+                              r_point=hx(O.pt_bytes(sig["r_point"])), hashed_to_curve_r=hx(O.pt_bytes(sig["hashed_to_curve_r"])), note="sk=n-1 (pk=-G)")))
+        # small scalars: s small via r = 1 - sk*c is not constructible without fixing c; use tiny r and sk instead
+        sig = O.sign(ver, 2, 3, msg)
+        out.append((ver, dict(msg=hx(msg), pk=hx(O.pt_bytes(sig["pk"])), nullifier=hx(O.pt_bytes(sig["nullifier"])),
+                              c=hx(sig["c"].to_bytes(32, "big")), s=hx(sig["s"].to_bytes(32, "big")),
+                              r_point=hx(O.pt_bytes(sig["r_point"])), hashed_to_curve_r=hx(O.pt_bytes(sig["hashed_to_curve_r"])), note="sk=2, r=3")))
+    return out
+
+
+def main():
+    out = {"_generated_by": "tests/golden/make_golden_batches.py", "seed": O.SEED}
+    with Pool(8) as pool:
+        for ver in (1, 2):
+            signed = pool.map(sign_item, [(ver, i) for i in range(N_VERIFY)])
+            out[f"sign_v{ver}"] = signed[:N_SIGN]
+            items = []
+            for i, it in enumerate(signed):
+                items.append(corrupt(ver, i, it, signed[i - 1]["nullifier"] if i else None))
+            ver_out = pool.map(verify_item, [(ver, it) for it in items])
+            for i, v in enumerate(ver_out):
+                assert v["ok"] == (0 if i % 16 == 5 else 1), (ver, i, v["ok"])
+            out[f"verify_v{ver}"] = ver_out
+        edges = edge_cases()
+        res = pool.map(verify_item, edges)
+        out["edge"] = [dict(version=v, **r) for (v, _), r in zip(edges, res)]
+    p = Path(__file__).with_name("golden_batches.json")
+    p.write_text(json.dumps(out, indent=0, separators=(",", ":")) + "\n")
+    print("wrote", p, p.stat().st_size, "bytes;",
+          "edge accepted:", [(e["version"], e["note"]) for e in out["edge"] if e["ok"] and not e["note"].startswith("honest")])
+
+
+if __name__ == "__main__":
+    main()
