@@ -1,0 +1,119 @@
+"""ctypes binding of tests/devsim/libplume_devsim.so: the product's device headers compiled for the host (test-only)."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+_DIR = ROOT / "tests" / "devsim"
+_SO = _DIR / "libplume_devsim.so"
+_lib = None
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        srcs = [_DIR / "devsim.cpp"] + list((ROOT / "zk-nullifier-sig_amd" / "csrc").glob("*.h"))
+        if not _SO.exists() or _SO.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
+            subprocess.check_call(["make", "-s", "-C", str(_DIR)])
+        _lib = C.CDLL(str(_SO))
+    return _lib
+
+
+def _p(a, t=u8p):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def to_limbs(vals):
+    """list of ints (< 2^256) -> uint32 array [n, 8] little-endian limbs"""
+    return np.array([[(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)] for v in vals], dtype=np.uint32)
+
+
+def from_limbs(a):
+    return [sum(int(a[r, i]) << (32 * i) for i in range(a.shape[1])) for r in range(a.shape[0])]
+
+
+def fe_op(op, a, b=None):
+    A = to_limbs(a)
+    Bm = to_limbs(b if b is not None else [0] * len(a))
+    out = np.zeros_like(A)
+    lib().ds_fe_op(C.c_int(op), C.c_size_t(len(a)), _p(A, u32p), _p(Bm, u32p), _p(out, u32p))
+    return from_limbs(out)
+
+
+def sc_op(op, a, b=None):
+    A = to_limbs(a)
+    Bm = to_limbs(b if b is not None else [0] * len(a))
+    out = np.zeros_like(A)
+    lib().ds_sc_op(C.c_int(op), C.c_size_t(len(a)), _p(A, u32p), _p(Bm, u32p), _p(out, u32p))
+    return from_limbs(out)
+
+
+def glv(ks):
+    K = to_limbs(ks)
+    out = np.zeros((len(ks), 10), dtype=np.uint32)
+    dig = np.zeros((len(ks), 66), dtype=np.int8)
+    lib().ds_glv(C.c_size_t(len(ks)), _p(K, u32p), _p(out, u32p), dig.ctypes.data_as(C.POINTER(C.c_int8)))
+    res = []
+    for r in range(len(ks)):
+        m1 = sum(int(out[r, i]) << (32 * i) for i in range(4))
+        m2 = sum(int(out[r, 5 + i]) << (32 * i) for i in range(4))
+        res.append((m1, int(out[r, 4]), m2, int(out[r, 9]), dig[r, :33].tolist(), dig[r, 33:].tolist()))
+    return res
+
+
+def sha256(data: bytes):
+    out = (C.c_uint8 * 32)()
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+    lib().ds_sha256(buf, C.c_uint32(len(data)), out)
+    return bytes(out)
+
+
+def _aligned(a):
+    """device code assumes 4-byte aligned records (HBM allocations are); numpy allocations are 16+ aligned"""
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a)
+    assert a.ctypes.data % 4 == 0
+    return a
+
+
+def verify_batch(version, msgs_buf, msg_off, pk, nul, c, s, r_point=None, hr=None, L=3):
+    n = len(msg_off) - 1
+    ok = np.full(n, 0xEE, dtype=np.uint8)
+    pk, nul, c, s, r_point, hr = map(_aligned, (pk, nul, c, s, r_point, hr))
+    rc = lib().ds_verify_batch(C.c_int(version), C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), _p(pk), _p(nul),
+                               _p(c), _p(s), _p(r_point), _p(hr), _p(ok), C.c_int(L))
+    assert rc == 0
+    return ok
+
+
+def sign_batch(version, msgs_buf, msg_off, sk, r, pk_in=None, L=3):
+    n = len(msg_off) - 1
+    o = {k: np.zeros((n, w), dtype=np.uint8) for k, w in
+         [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64), ("h", 64)]}
+    status = np.zeros(n, dtype=np.uint8)
+    sk, r, pk_in = map(_aligned, (sk, r, pk_in))
+    rc = lib().ds_sign_batch(C.c_int(version), C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), _p(sk), _p(r), _p(pk_in),
+                             _p(o["pk"]), _p(o["nullifier"]), _p(o["c"]), _p(o["s"]), _p(o["r_point"]), _p(o["hashed_to_curve_r"]), _p(o["h"]),
+                             _p(status), C.c_int(L))
+    assert rc == 0
+    o["status"] = status
+    return o
+
+
+def h2c_batch(msgs_buf, msg_off, pk):
+    n = len(msg_off) - 1
+    h = np.zeros((n, 64), dtype=np.uint8)
+    lib().ds_h2c_batch(C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), _p(_aligned(pk)), _p(h))
+    return h
+
+
+def point_mul(k: bytes, p: bytes):
+    out = (C.c_uint8 * 64)()
+    ok = lib().ds_point_mul((C.c_uint8 * 32).from_buffer_copy(k), (C.c_uint8 * 64).from_buffer_copy(p), out)
+    return bytes(out) if ok else None

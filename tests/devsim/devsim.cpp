@@ -1,0 +1,159 @@
+// Device-code simulation harness — TEST INFRASTRUCTURE ONLY (never linked into the product library).
+// Compiles the product's device headers (zk-nullifier-sig_amd/csrc/plume_*.h) as plain host C++ and drives the
+// per-lane stage bodies with the same index mapping the HIP kernels use, so the exact device arithmetic and
+// pipeline logic can be checked against the oracle in a container without a GPU.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "plume_stages.h"
+
+using namespace plume;
+
+static void fe_from_le_words(fe& r, const uint32_t* w) { for (int i = 0; i < 8; i++) r.v[i] = w[i]; }
+
+extern "C" {
+
+// op: 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 inv, 6 pow_c1, 7 normalize, 8 mul_small(b[0]), 9 is_zero->out[0], 10 eq->out[0], 11 is_odd->out[0]
+// operands/outputs: 8 little-endian 32-bit limbs; count elements
+void ds_fe_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    for (size_t i = 0; i < count; i++) {
+        fe x, y, r = fe_zero();
+        fe_from_le_words(x, a + 8 * i);
+        fe_from_le_words(y, b + 8 * i);
+        switch (op) {
+            case 0: fe_mul(r, x, y); break;
+            case 1: fe_sqr(r, x); break;
+            case 2: fe_add(r, x, y); break;
+            case 3: fe_sub(r, x, y); break;
+            case 4: fe_neg(r, x); break;
+            case 5: fe_inv(r, x); break;
+            case 6: fe_pow_c1(r, x); break;
+            case 7: r = x; fe_normalize(r); break;
+            case 8: fe_mul_small(r, x, y.v[0]); break;
+            case 9: r.v[0] = fe_is_zero(x); break;
+            case 10: r.v[0] = fe_eq(x, y); break;
+            case 11: r.v[0] = fe_is_odd(x); break;
+        }
+        for (int k = 0; k < 8; k++) out[8 * i + k] = r.v[k];
+    }
+}
+// op: 0 mul, 1 add, 2 neg, 3 reduce of 512-bit a|b (a low)
+void ds_sc_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    for (size_t i = 0; i < count; i++) {
+        sc x, y, r;
+        for (int k = 0; k < 8; k++) { x.v[k] = a[8 * i + k]; y.v[k] = b[8 * i + k]; r.v[k] = 0; }
+        if (op == 0) sc_mul(r, x, y);
+        else if (op == 1) sc_add(r, x, y);
+        else if (op == 2) sc_neg(r, x);
+        else { uint32_t t[16]; for (int k = 0; k < 8; k++) { t[k] = x.v[k]; t[8 + k] = y.v[k]; } sc_reduce_wide(r, t); }
+        for (int k = 0; k < 8; k++) out[8 * i + k] = r.v[k];
+    }
+}
+// k (8 limbs) -> m1[4], neg1, m2[4], neg2 (10 words) and 66 digits (int8)
+void ds_glv(size_t count, const uint32_t* k, uint32_t* out, int8_t* digits) {
+    for (size_t i = 0; i < count; i++) {
+        sc x; for (int j = 0; j < 8; j++) x.v[j] = k[8 * i + j];
+        glv_half h1, h2;
+        glv_split(h1, h2, x);
+        for (int j = 0; j < 4; j++) { out[10 * i + j] = h1.m[j]; out[10 * i + 5 + j] = h2.m[j]; }
+        out[10 * i + 4] = h1.neg; out[10 * i + 9] = h2.neg;
+        booth_store(digits + 66 * i, 1, h1, false);
+        booth_store(digits + 66 * i + 33, 1, h2, false);
+    }
+}
+void ds_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
+    uint32_t st[8];
+    sha256_init(st);
+    sha256_absorb_pad(st, 0u, len, [&](uint32_t pos) -> uint32_t { return data[pos]; });
+    for (int i = 0; i < 8; i++) { out[4 * i] = st[i] >> 24; out[4 * i + 1] = st[i] >> 16; out[4 * i + 2] = st[i] >> 8; out[4 * i + 3] = st[i]; }
+}
+
+static void build_gtab(std::vector<uint32_t>& gtab) {
+    gtab.assign(PLUME_TAB_WORDS, 0);
+    std::vector<uint32_t> bases(24, 0);
+    jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
+    st_jac_soa(bases.data(), 1, 0, g);
+    uint8_t flag = 0;
+    table_build(gtab.data(), bases.data(), &flag, 1, 0, 1);
+}
+
+// simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)
+static const uint32_t B = 8;
+
+int ds_verify_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
+                    const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L) {
+    if (version != 1 && version != 2) return -1;
+    std::vector<uint32_t> gtab; build_gtab(gtab);
+    std::vector<uint32_t> bases(24 * 3 * (size_t)n), tab((size_t)3 * n * PLUME_TAB_WORDS), res(24 * 2 * (size_t)n);
+    std::vector<uint8_t> jobflags(3 * (size_t)n), itemflags(n), resinf(2 * (size_t)n);
+    VerifyArgs a;
+    a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok;
+    a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data(); a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data();
+    a.gtab = gtab.data();
+    for (uint32_t i = 0; i < n; i++) verify_ingest_h2c(a, i);
+    const size_t nj = 3 * (size_t)n;
+    for (size_t j0 = 0; j0 < nj; j0 += L) table_build(a.tab, a.bases, a.jobflags, nj, j0, (int)((nj - j0) < (size_t)L ? (nj - j0) : L));
+    std::vector<int8_t> dig(4 * PLUME_NDIG * B);
+    for (uint32_t eq = 0; eq < 2; eq++)
+        for (uint32_t i = 0; i < n; i++) verify_msm(a, i, eq, a.gtab, dig.data() + (i % B), B);
+    for (uint32_t i = 0; i < n; i++) verify_finalize(a, i);
+    return 0;
+}
+
+int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,
+                  uint8_t* pk, uint8_t* nul, uint8_t* c, uint8_t* s, uint8_t* rpt, uint8_t* hr, uint8_t* h_out, uint8_t* status, int L) {
+    if (version != 1 && version != 2) return -1;
+    std::vector<uint32_t> gtab; build_gtab(gtab);
+    std::vector<uint32_t> gres(24 * 2 * (size_t)n), hres(24 * 2 * (size_t)n), bases(24 * (size_t)n), pkaff(16 * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
+    std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(n), itemflags(n);
+    SignArgs a;
+    a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.sk = sk; a.r = r; a.pk_in = pk_in;
+    a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
+    a.gres = gres.data(); a.gresinf = gresinf.data(); a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
+    a.pkaff = pkaff.data(); a.tab = tab.data(); a.hres = hres.data(); a.hresinf = hresinf.data(); a.gtab = gtab.data();
+    std::vector<int8_t> dig(4 * PLUME_NDIG * B);
+    for (uint32_t w = 0; w < 2; w++)
+        for (uint32_t i = 0; i < n; i++) sign_gmul(a, i, w, a.gtab, dig.data() + (i % B), B);
+    for (uint32_t i = 0; i < n; i++) sign_h2c(a, i);
+    for (size_t j0 = 0; j0 < n; j0 += L) table_build(a.tab, a.bases, a.jobflags, n, j0, (int)((n - j0) < (size_t)L ? (n - j0) : L));
+    for (uint32_t w = 0; w < 2; w++)
+        for (uint32_t i = 0; i < n; i++) sign_hmul(a, i, w, dig.data() + (i % B), B);
+    for (uint32_t i = 0; i < n; i++) sign_final(a, i);
+    return 0;
+}
+
+int ds_h2c_batch(uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out) {
+    H2cArgs a; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.h_out = h_out;
+    for (uint32_t i = 0; i < n; i++) h2c_only(a, i);
+    return 0;
+}
+
+// k*P through the device table + msm path (single base, affine 64-byte BE in/out); returns 0 for invalid input
+int ds_point_mul(const uint8_t k_be[32], const uint8_t p_be[64], uint8_t out[64]) {
+    fe x, y;
+    alignas(16) uint8_t pb[64], kb[32];
+    memcpy(pb, p_be, 64); memcpy(kb, k_be, 32);
+    uint32_t f = load_affine_be(x, y, pb);
+    if (f == PLUME_JOB_INVALID) return 0;
+    alignas(16) uint8_t ob[64];
+    if (f == PLUME_JOB_INF) { memset(out, 0, 64); return 1; }
+    std::vector<uint32_t> bases(24), tab(PLUME_TAB_WORDS);
+    jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
+    st_jac_soa(bases.data(), 1, 0, p);
+    uint8_t flag = 0;
+    table_build(tab.data(), bases.data(), &flag, 1, 0, 1);
+    sc k; sc_from_be_aligned(k, kb);
+    while (!sc_lt_n(k)) sc_cond_sub_n(k);
+    glv_half h1, h2; glv_split(h1, h2, k);
+    std::vector<int8_t> dig(2 * PLUME_NDIG);
+    booth_store(dig.data(), 1, h1, false); booth_store(dig.data() + PLUME_NDIG, 1, h2, false);
+    jac acc; msm_run(acc, tab.data(), nullptr, 2, dig.data(), 1);
+    fe ox = fe_zero(), oy = fe_zero();
+    if (!acc.inf) { fe zi, zi2; fe_inv(zi, acc.z); fe_sqr(zi2, zi); fe_mul(ox, acc.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(oy, acc.y, zi2); }
+    store_affine_be(ob, ox, oy, acc.inf != 0);
+    memcpy(out, ob, 64);
+    return 1;
+}
+}

@@ -1,0 +1,186 @@
+"""The product's DEVICE code (zk-nullifier-sig_amd/csrc/plume_*.h), compiled for the host, against the oracles.
+No GPU needed: these pin the exact limb arithmetic, recoding, tables and pipeline logic that the HIP kernels run."""
+import hashlib
+import json
+import random
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import plume_oracle as O
+from tests import _devsim as D
+from tests import _oracle_c as OC
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "golden_batches.json").read_text())
+P, N = O.P, O.N
+PC = 2**32 + 977
+EDGE_FE = [0, 1, 2, PC - 1, PC, PC + 1, P - 2, P - 1, P, P + 1, P + PC - 1, 2**256 - PC, 2**256 - PC + 1, 2**256 - 2, 2**256 - 1,
+           2**255, 2**128, 2**128 - 1, (1 << 224) - 1, 0xFFFFFFFF, 0xFFFFFFFF00000000, int("f" * 56 + "0" * 8, 16)]
+
+
+def fe_cases(rng, nrand=300):
+    vals = list(EDGE_FE) + [rng.randrange(2**256) for _ in range(nrand)] + [rng.randrange(P) for _ in range(nrand)]
+    a, b = [], []
+    for x in EDGE_FE:
+        for y in EDGE_FE:
+            a.append(x); b.append(y)
+    for _ in range(nrand * 2):
+        a.append(rng.choice(vals)); b.append(rng.choice(vals))
+    return a, b
+
+
+def test_fe_arith():
+    rng = random.Random(1)
+    a, b = fe_cases(rng)
+    for op, fn in [(0, lambda x, y: x * y), (2, lambda x, y: x + y), (3, lambda x, y: x - y)]:
+        got = D.fe_op(op, a, b)
+        for x, y, g in zip(a, b, got):
+            assert g < 2**256 and g % P == fn(x, y) % P, (op, hex(x), hex(y), hex(g))
+    got = D.fe_op(1, a)
+    assert all(g % P == x * x % P for x, g in zip(a, got))
+    got = D.fe_op(4, a)
+    assert all(g % P == (-x) % P for x, g in zip(a, got))
+    got = D.fe_op(7, a)
+    assert all(g == x % P for x, g in zip(a, got))
+    ks = [1, 2, 3, 4, 8, 11, 1771, 65535, 2**20 - 1]
+    for k in ks:
+        got = D.fe_op(8, a, [k] * len(a))
+        assert all(g % P == x * k % P for x, g in zip(a, got)), k
+    assert [g for g in D.fe_op(9, a)] == [int(x % P == 0) for x in a]
+    assert [g for g in D.fe_op(10, a, b)] == [int((x - y) % P == 0) for x, y in zip(a, b)]
+    assert [g for g in D.fe_op(11, a)] == [(x % P) & 1 for x in a]
+
+
+def test_fe_inv_pow():
+    rng = random.Random(2)
+    a = [1, 2, P - 1, P + 1, 2**256 - 1, PC] + [rng.randrange(1, 2**256) for _ in range(40)]
+    a = [x for x in a if x % P]
+    assert [g % P for g in D.fe_op(5, a)] == [pow(x, P - 2, P) for x in a]
+    assert [g % P for g in D.fe_op(6, a)] == [pow(x, (P - 3) // 4, P) for x in a]
+    assert D.fe_op(5, [0, P])[0] % P == 0
+
+
+def test_sc_arith():
+    rng = random.Random(3)
+    edge = [0, 1, 2, N - 1, N - 2, (N - 1) // 2, 2**128, 2**255 % N, 2**256 - N]
+    a = edge * len(edge) + [rng.randrange(N) for _ in range(300)]
+    b = [y for y in edge for _ in edge] + [rng.randrange(N) for _ in range(300)]
+    assert D.sc_op(0, a, b) == [x * y % N for x, y in zip(a, b)]
+    assert D.sc_op(1, a, b) == [(x + y) % N for x, y in zip(a, b)]
+    assert D.sc_op(2, a) == [(-x) % N for x in a]
+    wide_lo = [rng.randrange(2**256) for _ in range(200)] + [2**256 - 1, 0, 2**256 - 1]
+    wide_hi = [rng.randrange(2**256) for _ in range(200)] + [2**256 - 1, 2**256 - 1, 0]
+    assert D.sc_op(3, wide_lo, wide_hi) == [(lo + (hi << 256)) % N for lo, hi in zip(wide_lo, wide_hi)]
+
+
+def test_glv_and_booth():
+    rng = random.Random(4)
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    ks = [0, 1, 2, N - 1, N - 2, lam, lam + 1, N - lam, (N - 1) // 2, (N + 1) // 2, 2**128, 2**128 - 1, 2**255 % N] + [rng.randrange(N) for _ in range(2000)]
+    for k, (m1, n1, m2, n2, d1, d2) in zip(ks, D.glv(ks)):
+        assert m1 < 2**128 and m2 < 2**128
+        k1 = -m1 if n1 else m1
+        k2 = -m2 if n2 else m2
+        assert (k1 + k2 * lam) % N == k
+        for m, neg, d in ((m1, n1, d1), (m2, n2, d2)):
+            assert all(-8 <= x <= 8 for x in d)
+            assert sum(x * 16**i for i, x in enumerate(d)) == (-m if neg else m)
+
+
+def test_sha256_generic():
+    for n in (0, 1, 3, 55, 56, 57, 63, 64, 65, 119, 120, 121, 198, 99, 500):
+        d = bytes((i * 13 + n) & 0xFF for i in range(n))
+        assert D.sha256(d) == hashlib.sha256(d).digest(), n
+
+
+def test_point_mul_matches_oracle():
+    rng = random.Random(5)
+    g = O.pt_bytes(O.G)
+    pts = [g, O.pt_bytes(O.pt_mul(rng.randrange(N), O.G)), O.pt_bytes(O.pt_mul(7, O.G))]
+    ks = [0, 1, 2, 3, 7, 8, 9, 15, 16, 17, N - 1, N - 2, N, 2**128, 2**128 - 1, 2**255, 2**256 - 1] + [rng.randrange(N) for _ in range(12)]
+    for p in pts:
+        for k in ks:
+            kb = k.to_bytes(32, "big")
+            assert D.point_mul(kb, p) == OC.point_mul(kb, p), (k, p.hex())
+    assert D.point_mul((5).to_bytes(32, "big"), bytes(64)) == bytes(64)
+    bad = bytearray(g); bad[63] ^= 1
+    assert D.point_mul((5).to_bytes(32, "big"), bytes(bad)) is None
+
+
+def test_h2c_kats(kats):
+    v = kats["plume_vector"]
+    msgs = [v["msg_utf8"].encode(), b"", b"x" * 300]
+    mb, off = OC.pack_msgs(msgs)
+    pk = np.frombuffer(bytes.fromhex(v["pk_x"] + v["pk_y"]) * 3, dtype=np.uint8).reshape(3, 64).copy()
+    h = D.h2c_batch(mb, off, pk)
+    assert h[0].tobytes().hex() == v["h_x"] + v["h_y"]
+    assert np.array_equal(h, OC.hash_to_curve_batch(mb, off, pk))
+    # raw-bytes mode: RFC 9380 J.8.1 "", "abc", and the literal 62-byte preimage of the TS test
+    raw = [b"", b"abc", bytes.fromhex(kats["h2c_preimage"]["preimage_hex"])]
+    mb, off = OC.pack_msgs(raw)
+    h = D.h2c_batch(mb, off, None)
+    assert h[0].tobytes().hex() == kats["rfc9380_empty"]["p_x"] + kats["rfc9380_empty"]["p_y"]
+    assert h[1].tobytes().hex() == kats["h2c_abc"]["x"] + kats["h2c_abc"]["y"]
+    assert h[2].tobytes().hex() == kats["h2c_preimage"]["x"] + kats["h2c_preimage"]["y"]
+    # identity pk: encoding is the single byte 00
+    mb, off = OC.pack_msgs([b"edge"])
+    z = np.zeros((1, 64), dtype=np.uint8)
+    assert D.h2c_batch(mb, off, z)[0].tobytes() == O.pt_bytes(O.hash_to_curve(b"edge", None))
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+@pytest.mark.parametrize("L", [1, 3, 7])
+def test_golden_verify(ver, L):
+    items = GOLD[f"verify_v{ver}"][: (256 if L == 3 else 48)]
+    mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+    ok = D.verify_batch(ver, mb, off, OC.arr(items, "pk", 64), OC.arr(items, "nullifier", 64), OC.arr(items, "c", 32), OC.arr(items, "s", 32),
+                        OC.arr(items, "r_point", 64) if ver == 1 else None, OC.arr(items, "hashed_to_curve_r", 64) if ver == 1 else None, L=L)
+    assert list(ok) == [it["ok"] for it in items]
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_golden_edge(ver):
+    items = [e for e in GOLD["edge"] if e["version"] == ver]
+    mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+    ok = D.verify_batch(ver, mb, off, OC.arr(items, "pk", 64), OC.arr(items, "nullifier", 64), OC.arr(items, "c", 32), OC.arr(items, "s", 32),
+                        OC.arr(items, "r_point", 64) if ver == 1 else None, OC.arr(items, "hashed_to_curve_r", 64) if ver == 1 else None)
+    bad = [(it["note"], int(o), it["ok"]) for it, o in zip(items, ok) if int(o) != it["ok"]]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_golden_sign(ver, kats):
+    items = GOLD[f"sign_v{ver}"]
+    mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+    o = D.sign_batch(ver, mb, off, OC.arr(items, "sk", 32), OC.arr(items, "r", 32))
+    for key, w in [("pk", 64), ("h", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]:
+        assert np.array_equal(o[key], OC.arr(items, key, w)), key
+    assert list(o["status"]) == [it["status"] for it in items]
+    # arkworks-shaped (pk supplied) gives identical outputs (BASELINE config 5)
+    o2 = D.sign_batch(ver, mb, off, OC.arr(items, "sk", 32), OC.arr(items, "r", 32), pk_in=OC.arr(items, "pk", 64))
+    for k in o:
+        assert np.array_equal(o[k], o2[k]), k
+    # the reference's fixed vector (BASELINE config 1)
+    v = kats["plume_vector"]
+    mb, off = OC.pack_msgs([v["msg_utf8"].encode()])
+    o = D.sign_batch(ver, mb, off, np.frombuffer(bytes.fromhex(v["sk"]), dtype=np.uint8).reshape(1, 32).copy(),
+                     np.frombuffer(bytes.fromhex(v["r"]), dtype=np.uint8).reshape(1, 32).copy())
+    assert o["c"][0].tobytes().hex() == v[f"c_v{ver}"] and o["s"][0].tobytes().hex() == v[f"s_v{ver}"]
+    assert o["nullifier"][0].tobytes().hex() == v["nullifier_x"] + v["nullifier_y"]
+
+
+def test_sign_edge_status():
+    """out-of-range scalars and ragged messages: device sign path == C oracle, including status bits"""
+    rng = random.Random(9)
+    sks = [0, N, N + 5, 1, N - 1, 2**256 - 1, rng.randrange(1, N), rng.randrange(1, N)]
+    rs = [rng.randrange(1, N), rng.randrange(1, N), 0, N - 1, 1, 7, N, rng.randrange(1, N)]
+    msgs = [bytes(rng.randrange(256) for _ in range(l)) for l in (0, 1, 32, 55, 56, 64, 100, 257)]
+    mb, off = OC.pack_msgs(msgs)
+    sk = np.frombuffer(b"".join(x.to_bytes(32, "big") for x in sks), dtype=np.uint8).reshape(-1, 32).copy()
+    r = np.frombuffer(b"".join(x.to_bytes(32, "big") for x in rs), dtype=np.uint8).reshape(-1, 32).copy()
+    for ver in (1, 2):
+        a = D.sign_batch(ver, mb, off, sk, r)
+        b = OC.sign_batch(ver, mb, off, sk, r)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (ver, k)

@@ -1,0 +1,268 @@
+// secp256k1 group law, GLV split, signed fixed-window recoding, per-lane window tables and the multi-scalar
+// loop for the PLUME hot path (the reference's `ProjectivePoint * Scalar` and point subtraction:
+// rust-k256/src/lib.rs:101,109; randomizedsigner.rs:51,53,67,70 — there done by the k256 crate).
+//
+// Design (SIMT-first, not a port of k256/libsecp): one scalar multiplication "task" per lane; because every
+// lane of a wavefront must execute the same instruction stream, recoding is a FIXED signed window (Booth,
+// w = 4, digits in [-8, 8]) rather than wNAF — all lanes add at the same positions, a zero digit just idles
+// its lane for one slot.  The endomorphism split (k = k1 + k2*lambda, |k_i| < 2^128) halves the doubling chain
+// to 128 for all four half-scalars of a double-base task.  Tables hold the eight AFFINE multiples 1P..8P plus
+// beta*x for the lambda half; they are produced by `table_build` with one field inversion per lane shared by
+// all tables the lane builds (Montgomery's trick through HBM scratch).
+#pragma once
+#include "plume_field.h"
+
+namespace plume {
+
+struct jac {
+    fe x, y, z;
+    uint32_t inf;
+};
+
+PLUME_HD fe fe_beta() { return fe_set(0x7AE96A2Bu, 0x657C0710u, 0x6E64479Eu, 0xAC3434E9u, 0x9CF04975u, 0x12F58995u, 0xC1396C28u, 0x719501EEu); }
+PLUME_HD fe fe_gx() { return fe_set(0x79BE667Eu, 0xF9DCBBACu, 0x55A06295u, 0xCE870B07u, 0x029BFCDBu, 0x2DCE28D9u, 0x59F2815Bu, 0x16F81798u); }  // curves/mod.rs:52
+PLUME_HD fe fe_gy() { return fe_set(0x483ADA77u, 0x26A3C465u, 0x5DA4FBFCu, 0x0E1108A8u, 0xFD17B448u, 0xA6855419u, 0x9C47D08Fu, 0xFB10D4B8u); }  // curves/mod.rs:57
+
+// y^2 == x^3 + 7 (curves/mod.rs:36-39)
+PLUME_HD bool affine_on_curve(const fe& x, const fe& y) {
+    fe l, r;
+    fe_sqr(l, y);
+    fe_sqr(r, x); fe_mul(r, r, x);
+    fe seven = fe_small(7);
+    fe_add(r, r, seven);
+    return fe_eq(l, r);
+}
+
+// 2P, a = 0:  S = 4XY^2, M = 3X^2, X' = M^2 - 2S, Y' = M(S - X') - 8Y^4, Z' = 2YZ   (3M + 4S)
+// valid for every non-infinity point (the curve has no 2-torsion); the inf flag just rides along.
+PLUME_HD void jac_dbl(jac& p) {
+    fe y2, s, m, t, x3, y4;
+    fe_sqr(y2, p.y);
+    fe_mul(s, p.x, y2); fe_dbl(s, s); fe_dbl(s, s);
+    fe_sqr(m, p.x); fe_dbl(t, m); fe_add(m, t, m);
+    fe_mul(p.z, p.y, p.z); fe_dbl(p.z, p.z);
+    fe_sqr(x3, m); fe_sub(x3, x3, s); fe_sub(x3, x3, s);
+    fe_sqr(y4, y2); fe_dbl(y4, y4); fe_dbl(y4, y4); fe_dbl(y4, y4);
+    fe_sub(t, s, x3); fe_mul(t, m, t); fe_sub(p.y, t, y4);
+    p.x = x3;
+}
+PLUME_HD_NOINLINE void jac_dbl_cold(jac& p) { jac_dbl(p); }
+
+// p += (qx, qy) affine, q != infinity.  8M + 3S; all exceptional cases handled (p infinite, p == q, p == -q).
+PLUME_HD void jac_madd(jac& p, const fe& qx, const fe& qy) {
+    if (p.inf) {
+        p.x = qx; p.y = qy; p.z = fe_small(1); p.inf = 0;
+        return;
+    }
+    fe z1z1, u2, s2, h, r, hh, hhh, v, t;
+    fe_sqr(z1z1, p.z);
+    fe_mul(u2, qx, z1z1);
+    fe_mul(s2, p.z, z1z1); fe_mul(s2, s2, qy);
+    fe_sub(h, u2, p.x);
+    fe_sub(r, s2, p.y);
+    if (fe_is_zero(h)) {
+        if (fe_is_zero(r)) { jac_dbl_cold(p); } else { p.inf = 1; }
+        return;
+    }
+    fe_sqr(hh, h); fe_mul(hhh, hh, h); fe_mul(v, p.x, hh);
+    fe_mul(p.z, p.z, h);
+    fe_sqr(t, r); fe_sub(t, t, hhh); fe_sub(t, t, v); fe_sub(p.x, t, v);
+    fe_sub(t, v, p.x); fe_mul(t, r, t);
+    fe_mul(hhh, p.y, hhh);
+    fe_sub(p.y, t, hhh);
+}
+
+// p += q, both Jacobian.  12M + 4S; all exceptional cases handled.
+PLUME_HD void jac_add(jac& p, const jac& q) {
+    if (q.inf) return;
+    if (p.inf) { p = q; return; }
+    fe z1z1, z2z2, u1, u2, s1, s2, h, r, hh, hhh, v, t;
+    fe_sqr(z1z1, p.z); fe_sqr(z2z2, q.z);
+    fe_mul(u1, p.x, z2z2); fe_mul(u2, q.x, z1z1);
+    fe_mul(s1, q.z, z2z2); fe_mul(s1, s1, p.y);
+    fe_mul(s2, p.z, z1z1); fe_mul(s2, s2, q.y);
+    fe_sub(h, u2, u1);
+    fe_sub(r, s2, s1);
+    if (fe_is_zero(h)) {
+        if (fe_is_zero(r)) { jac_dbl_cold(p); } else { p.inf = 1; }
+        return;
+    }
+    fe_sqr(hh, h); fe_mul(hhh, hh, h); fe_mul(v, u1, hh);
+    fe_mul(p.z, p.z, q.z); fe_mul(p.z, p.z, h);
+    fe_sqr(t, r); fe_sub(t, t, hhh); fe_sub(t, t, v); fe_sub(p.x, t, v);
+    fe_sub(t, v, p.x); fe_mul(t, r, t);
+    fe_mul(hhh, s1, hhh);
+    fe_sub(p.y, t, hhh);
+}
+
+// Jacobian p == affine (ax, ay)?  (ProjectivePoint == AffinePoint, rust-k256/src/lib.rs:117,122); a_inf = the affine side is the identity
+PLUME_HD bool jac_eq_affine(const jac& p, const fe& ax, const fe& ay, bool a_inf) {
+    if (p.inf || a_inf) return p.inf && a_inf;
+    fe z2, z3, t;
+    fe_sqr(z2, p.z); fe_mul(z3, z2, p.z);
+    fe_mul(t, ax, z2);
+    if (!fe_eq(t, p.x)) return false;
+    fe_mul(t, ay, z3);
+    return fe_eq(t, p.y);
+}
+
+// ------------------------------------------------------------------------------------------------ GLV split
+// k = k1 + k2*lambda (mod n) with |k1|, |k2| < 2^128; returns magnitudes (4 limbs each) and signs.
+// Constants: the standard secp256k1 endomorphism lattice basis (lambda^3 = 1 mod n, beta^3 = 1 mod p,
+// lambda*(x, y) = (beta*x, y)); checked against the oracle's plain double-and-add in tests/test_devsim.py.
+struct glv_half {
+    uint32_t m[4];
+    uint32_t neg;
+};
+PLUME_HD void glv_split(glv_half& h1, glv_half& h2, const sc& k) {
+    const uint32_t g1[8] = {0x45DBB031u, 0xE893209Au, 0x71E8CA7Fu, 0x3DAA8A14u, 0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u};
+    const uint32_t g2[8] = {0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu, 0x0ABFE4C4u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u};
+    const uint32_t mb1[4] = {0x0ABFE4C3u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u};
+    const uint32_t mb2[8] = {0x3DB1562Cu, 0xD765CDA8u, 0x0774346Du, 0x8A280AC5u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    sc lam; { const uint32_t l[8] = {0x1B23BD72u, 0xDF02967Cu, 0x20816678u, 0x122E22EAu, 0x8812645Au, 0xA5261C02u, 0xC05C30E0u, 0x5363AD4Cu};
+              PLUME_UNROLL for (int i = 0; i < 8; i++) lam.v[i] = l[i]; }
+    uint32_t t[16], c1[4], c2[4];
+    uint32_t c;
+    mul_limbs<8, 8>(t, k.v, g1);            // c1 = round(k*g1 / 2^384)
+    c = t[11] >> 31;
+    PLUME_UNROLL for (int i = 0; i < 4; i++) c1[i] = addc(t[12 + i], 0u, c);
+    mul_limbs<8, 8>(t, k.v, g2);            // c2 = round(k*g2 / 2^384)
+    c = t[11] >> 31;
+    PLUME_UNROLL for (int i = 0; i < 4; i++) c2[i] = addc(t[12 + i], 0u, c);
+    // k2 = c1*(-b1) + c2*(-b2)  (mod n)
+    uint32_t p1[8], p2[12], w[16];
+    mul_limbs<4, 4>(p1, c1, mb1);
+    mul_limbs<4, 8>(p2, c2, mb2);
+    c = 0;
+    PLUME_UNROLL for (int i = 0; i < 12; i++) w[i] = addc(p2[i], i < 8 ? p1[i] : 0u, c);
+    w[12] = c; w[13] = 0; w[14] = 0; w[15] = 0;
+    sc k2, k1, tmp;
+    sc_reduce_wide(k2, w);
+    sc_mul(tmp, k2, lam);
+    sc_neg(tmp, tmp);
+    sc_add(k1, k, tmp);                     // k1 = k - k2*lambda
+    // |k_i| < 2^128: a "negative" residue is >= n - 2^128, i.e. has non-zero high limbs
+    sc n1, n2;
+    sc_neg(n1, k1); sc_neg(n2, k2);
+    h1.neg = (k1.v[4] | k1.v[5] | k1.v[6] | k1.v[7]) != 0;
+    h2.neg = (k2.v[4] | k2.v[5] | k2.v[6] | k2.v[7]) != 0;
+    PLUME_UNROLL for (int i = 0; i < 4; i++) { h1.m[i] = h1.neg ? n1.v[i] : k1.v[i]; h2.m[i] = h2.neg ? n2.v[i] : k2.v[i]; }
+}
+
+// Booth recoding, w = 4: m = sum d_i 16^i, d_i in [-8, 8], i = 0..32.  d_i = k_{4i-1} + k_{4i} + 2k_{4i+1} + 4k_{4i+2} - 8k_{4i+3}.
+#define PLUME_NDIG 33
+PLUME_HD int booth_digit(const uint32_t m[4], int i) {
+    // u = bits [4i-1, 4i+3] of m (bit -1 = 0); i is a compile-time constant after unrolling
+    int lo = 4 * i - 1;
+    uint32_t u;
+    if (lo < 0) {
+        u = (m[0] << 1) & 0x1F;
+    } else {
+        int wi = lo >> 5, sh = lo & 31;
+        uint32_t a = wi < 4 ? m[wi] : 0u, b = (wi + 1) < 4 ? m[wi + 1] : 0u;
+        u = (sh == 0 ? a : ((a >> sh) | (sh > 27 ? (b << (32 - sh)) : 0u))) & 0x1F;
+    }
+    return (int)(u & 1) + (int)((u >> 1) & 7) - (int)((u >> 4) << 3);
+}
+// writes the 33 signed digits of one half-scalar to dig[i*stride], sign applied
+PLUME_HD void booth_store(int8_t* dig, uint32_t stride, const glv_half& h, bool flip) {
+    bool neg = (h.neg != 0) != flip;
+    PLUME_UNROLL for (int i = 0; i < PLUME_NDIG; i++) {
+        int d = booth_digit(h.m, i);
+        dig[(uint32_t)i * stride] = (int8_t)(neg ? -d : d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ window tables
+// One table = 8 entries x 32 words (128 B): [x(8) | y(8) | beta*x(8) | scratch(8)], entry e holds (e+1)*P.
+// Words are little-endian limbs of weakly reduced field elements.
+#define PLUME_TAB_ENTRIES 8
+#define PLUME_TAB_ENTRY_WORDS 32
+#define PLUME_TAB_WORDS (PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
+
+PLUME_HD void ld_fe(fe& r, const uint32_t* p) { PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = p[i]; }
+PLUME_HD void st_fe(uint32_t* p, const fe& a) { PLUME_UNROLL for (int i = 0; i < 8; i++) p[i] = a.v[i]; }
+// strided (SoA) field element: word w of element j lives at base[w*stride + j]
+PLUME_HD void ld_fe_soa(fe& r, const uint32_t* base, size_t stride, size_t j) { PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = base[(size_t)i * stride + j]; }
+PLUME_HD void st_fe_soa(uint32_t* base, size_t stride, size_t j, const fe& a) { PLUME_UNROLL for (int i = 0; i < 8; i++) base[(size_t)i * stride + j] = a.v[i]; }
+// Jacobian point SoA: x words 0..7, y 8..15, z 16..23
+PLUME_HD void ld_jac_soa(jac& p, const uint32_t* base, size_t stride, size_t j) {
+    ld_fe_soa(p.x, base, stride, j); ld_fe_soa(p.y, base + 8 * stride, stride, j); ld_fe_soa(p.z, base + 16 * stride, stride, j);
+}
+PLUME_HD void st_jac_soa(uint32_t* base, size_t stride, size_t j, const jac& p) {
+    st_fe_soa(base, stride, j, p.x); st_fe_soa(base + 8 * stride, stride, j, p.y); st_fe_soa(base + 16 * stride, stride, j, p.z);
+}
+
+#define PLUME_JOB_OK 0u
+#define PLUME_JOB_INF 1u      // base is the identity: its slots are skipped
+#define PLUME_JOB_INVALID 2u  // base failed validation: a dummy (G) table is built, the item is rejected elsewhere
+
+// Build the tables of jobs [j0, j0+cnt) (cnt <= L, one lane).  Bases are Jacobian SoA (stride = njobs).
+// Pass 1 writes (X_k, Y_k, Z_k, running product before Z_k) for k = 1..8 of every job; one inversion of the
+// total product; pass 2 walks back, peels off each 1/Z_k, and overwrites the entry with affine (x, y, beta*x).
+PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt) {
+    fe acc = fe_small(1);
+    PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
+        size_t job = j0 + (size_t)jj;
+        jac b;
+        ld_jac_soa(b, bases, njobs, job);
+        b.inf = 0;
+        if (jobflags[job] != PLUME_JOB_OK) { b.x = fe_gx(); b.y = fe_gy(); b.z = fe_small(1); }
+        jac cur = b;
+        uint32_t* e = tab + job * PLUME_TAB_WORDS;
+        PLUME_NOUNROLL for (int k = 0; k < PLUME_TAB_ENTRIES; k++) {
+            if (k == 1) jac_dbl(cur);
+            else if (k > 1) jac_add(cur, b);
+            st_fe(e + 0, cur.x); st_fe(e + 8, cur.y); st_fe(e + 16, cur.z); st_fe(e + 24, acc);
+            fe_mul(acc, acc, cur.z);
+            e += PLUME_TAB_ENTRY_WORDS;
+        }
+    }
+    fe inv;
+    fe_inv(inv, acc);
+    const fe beta = fe_beta();
+    PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
+        size_t job = j0 + (size_t)jj;
+        PLUME_NOUNROLL for (int k = PLUME_TAB_ENTRIES - 1; k >= 0; k--) {
+            uint32_t* e = tab + job * PLUME_TAB_WORDS + k * PLUME_TAB_ENTRY_WORDS;
+            fe X, Y, Zk, cprev, zi, zi2;
+            ld_fe(X, e + 0); ld_fe(Y, e + 8); ld_fe(Zk, e + 16); ld_fe(cprev, e + 24);
+            fe_mul(zi, inv, cprev);      // 1/Z_k
+            fe_mul(inv, inv, Zk);        // inverse of the product before Z_k
+            fe_sqr(zi2, zi);
+            fe_mul(X, X, zi2);
+            fe_mul(zi2, zi2, zi); fe_mul(Y, Y, zi2);
+            fe_normalize(X); fe_normalize(Y);
+            fe bx; fe_mul(bx, X, beta);
+            st_fe(e + 0, X); st_fe(e + 8, Y); st_fe(e + 16, bx);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------- multi-scalar loop
+// acc = sum over slots of digit * table point.  Slot s uses table tabs[s >> 1]; odd slots are the lambda
+// halves (beta*x).  dig: digits of slot s, window i at dig[(s*PLUME_NDIG + i)*stride].  A NULL table (or a
+// job flagged INF) contributes nothing.
+PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride) {
+    acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
+    PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
+        if (i != PLUME_NDIG - 1) {
+            PLUME_NOUNROLL for (int d = 0; d < 4; d++) jac_dbl(acc);
+        }
+        PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
+            const uint32_t* tab = (s & 2) ? tab1 : tab0;
+            int d = dig[(uint32_t)(s * PLUME_NDIG + i) * stride];
+            if (d != 0 && tab != nullptr) {
+                int ad = d < 0 ? -d : d;
+                const uint32_t* e = tab + (ad - 1) * PLUME_TAB_ENTRY_WORDS;
+                fe qx, qy;
+                ld_fe(qx, (s & 1) ? e + 16 : e);
+                ld_fe(qy, e + 8);
+                if (d < 0) fe_neg(qy, qy);
+                jac_madd(acc, qx, qy);
+            }
+        }
+    }
+}
+
+}  // namespace plume

@@ -1,0 +1,391 @@
+// secp256k1 base field Fp (p = 2^256 - 2^32 - 977) and scalar field Fn arithmetic for the PLUME hot path.
+// Written for gfx950 (CDNA4): 8 x 32-bit limbs per element held in VGPRs, products through v_mad_u64_u32
+// (32x32+64 -> 64), carries through v_add_co/v_addc_co chains (__builtin_addc).  No MFMA: this is integer VALU.
+//
+// The same header compiles as plain C++ for the host (tests/devsim) so that the exact device arithmetic is
+// unit-tested on the CPU against the oracle; that build is test infrastructure and is never linked into the
+// product library.
+//
+// Reference anchors: p rust-arkworks/src/secp256k1/fields/fq.rs:12, n fields/fr.rs:19 (the reference gets its
+// arithmetic from the un-vendored k256 ~0.13.3 crate, rust-k256/Cargo.toml:18).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define PLUME_HD __host__ __device__ __forceinline__
+#define PLUME_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+#define PLUME_HD inline
+#define PLUME_HD_NOINLINE inline
+#endif
+
+#if defined(__clang__)
+#define PLUME_UNROLL _Pragma("unroll")
+#define PLUME_NOUNROLL _Pragma("unroll 1")
+#else
+#define PLUME_UNROLL
+#define PLUME_NOUNROLL
+#endif
+
+namespace plume {
+
+// ---------------------------------------------------------------------------------------------- carry helpers
+PLUME_HD uint32_t addc(uint32_t a, uint32_t b, uint32_t& c) {
+#if defined(__clang__)
+    unsigned co;
+    uint32_t r = __builtin_addc(a, b, c, &co);
+    c = co;
+    return r;
+#else
+    uint64_t t = (uint64_t)a + b + c;
+    c = (uint32_t)(t >> 32);
+    return (uint32_t)t;
+#endif
+}
+PLUME_HD uint32_t subb(uint32_t a, uint32_t b, uint32_t& bw) {
+#if defined(__clang__)
+    unsigned bo;
+    uint32_t r = __builtin_subc(a, b, bw, &bo);
+    bw = bo;
+    return r;
+#else
+    uint64_t t = (uint64_t)a - b - bw;
+    bw = (uint32_t)(t >> 63);
+    return (uint32_t)t;
+#endif
+}
+PLUME_HD uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+
+// ------------------------------------------------------------------------------------------------------- Fp
+// Invariant: every fe is an arbitrary 256-bit integer v in [0, 2^256) standing for v mod p ("weakly reduced").
+// 2^256 = PC (mod p) with PC = 2^32 + 977, so a carry out of bit 256 folds back as +PC.  Values in [p, 2^256)
+// are legal (non-canonical zero..PC-1); fe_normalize gives the canonical representative where one is needed
+// (comparisons, parity, serialisation).
+struct fe {
+    uint32_t v[8];
+};
+#define PLUME_PC977 977u
+
+PLUME_HD fe fe_zero() { fe r; PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
+PLUME_HD fe fe_small(uint32_t x) { fe r = fe_zero(); r.v[0] = x; return r; }
+PLUME_HD fe fe_set(uint32_t w7, uint32_t w6, uint32_t w5, uint32_t w4, uint32_t w3, uint32_t w2, uint32_t w1, uint32_t w0) {
+    fe r; r.v[0] = w0; r.v[1] = w1; r.v[2] = w2; r.v[3] = w3; r.v[4] = w4; r.v[5] = w5; r.v[6] = w6; r.v[7] = w7; return r;  // big-endian word order, as hex reads
+}
+
+// r += c*PC for a carry bit c in {0,1} out of bit 256, twice (the second can only touch limbs 0..1)
+PLUME_HD void fe_fold_carry(fe& r, uint32_t c) {
+    uint32_t k = 0;
+    r.v[0] = addc(r.v[0], (0u - c) & PLUME_PC977, k);
+    r.v[1] = addc(r.v[1], c, k);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, k);
+    // wrapped again: now r < PC, so adding PC stays below 2^34
+    uint32_t k2 = 0;
+    r.v[0] = addc(r.v[0], (0u - k) & PLUME_PC977, k2);
+    r.v[1] = r.v[1] + k + k2;
+}
+PLUME_HD void fe_add(fe& r, const fe& a, const fe& b) {
+    uint32_t c = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = addc(a.v[i], b.v[i], c);
+    fe_fold_carry(r, c);
+}
+PLUME_HD void fe_sub(fe& r, const fe& a, const fe& b) {
+    uint32_t bw = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = subb(a.v[i], b.v[i], bw);
+    // a - b + 2^256 = a - b + PC (mod p): take PC back out; a second borrow can only touch limbs 0..1
+    uint32_t k = 0;
+    r.v[0] = subb(r.v[0], (0u - bw) & PLUME_PC977, k);
+    r.v[1] = subb(r.v[1], bw, k);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = subb(r.v[i], 0u, k);
+    uint32_t k2 = 0;
+    r.v[0] = subb(r.v[0], (0u - k) & PLUME_PC977, k2);
+    r.v[1] = r.v[1] - k - k2;
+}
+PLUME_HD void fe_neg(fe& r, const fe& a) { fe z = fe_zero(); fe_sub(r, z, a); }
+PLUME_HD void fe_dbl(fe& r, const fe& a) { fe_add(r, a, a); }
+
+// canonical representative in [0, p)
+PLUME_HD void fe_normalize(fe& a) {
+    fe t;
+    uint32_t c = 0;
+    t.v[0] = addc(a.v[0], PLUME_PC977, c);
+    t.v[1] = addc(a.v[1], 1u, c);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) t.v[i] = addc(a.v[i], 0u, c);
+    // carry <=> a + PC >= 2^256 <=> a >= p
+    PLUME_UNROLL for (int i = 0; i < 8; i++) a.v[i] = c ? t.v[i] : a.v[i];
+}
+PLUME_HD bool fe_is_zero(const fe& a) {  // a == 0 (mod p): a is 0 or p
+    uint32_t z = 0, pp = (a.v[0] ^ 0xFFFFFC2Fu) | (a.v[1] ^ 0xFFFFFFFEu);
+    PLUME_UNROLL for (int i = 0; i < 8; i++) z |= a.v[i];
+    PLUME_UNROLL for (int i = 2; i < 8; i++) pp |= ~a.v[i];
+    return z == 0 || pp == 0;
+}
+PLUME_HD bool fe_eq(const fe& a, const fe& b) { fe d; fe_sub(d, a, b); return fe_is_zero(d); }
+PLUME_HD bool fe_is_odd(const fe& a) { fe t = a; fe_normalize(t); return t.v[0] & 1; }
+PLUME_HD void fe_cmov(fe& r, const fe& a, bool flag) { PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = flag ? a.v[i] : r.v[i]; }
+// true iff the 256-bit integer is < p (canonical encoding check for caller-supplied coordinates)
+PLUME_HD bool fe_is_canonical(const fe& a) {
+    uint32_t c = 0;
+    (void)addc(a.v[0], PLUME_PC977, c);
+    (void)addc(a.v[1], 1u, c);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) (void)addc(a.v[i], 0u, c);
+    return c == 0;
+}
+
+// 256x256 -> 512: row-wise; the 8 products of a row are independent v_mad_u64_u32 (addend = the running limb),
+// their high words ripple through one v_addc chain.  a_i*b_j + t <= 2^64 - 2^32, so nothing overflows.
+PLUME_HD void mul_wide(uint32_t t[16], const uint32_t a[8], const uint32_t b[8]) {
+    PLUME_UNROLL for (int i = 0; i < 16; i++) t[i] = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) {
+        uint64_t p[8];
+        PLUME_UNROLL for (int j = 0; j < 8; j++) p[j] = (uint64_t)a[i] * b[j] + t[i + j];
+        uint32_t c = 0;
+        t[i] = (uint32_t)p[0];
+        PLUME_UNROLL for (int j = 1; j < 8; j++) t[i + j] = addc((uint32_t)p[j], (uint32_t)(p[j - 1] >> 32), c);
+        t[i + 8] = (uint32_t)(p[7] >> 32) + c;
+    }
+}
+// a^2 as 512 bits: off-diagonal products once, doubled, plus the diagonal
+PLUME_HD void sqr_wide(uint32_t t[16], const uint32_t a[8]) {
+    PLUME_UNROLL for (int i = 0; i < 16; i++) t[i] = 0;
+    PLUME_UNROLL for (int i = 0; i < 7; i++) {  // row i: a_i * a_j, j > i, lands at limbs i+j ..
+        uint64_t p[8];
+        PLUME_UNROLL for (int j = i + 1; j < 8; j++) p[j] = (uint64_t)a[i] * a[j] + t[i + j];
+        uint32_t c = 0;
+        t[2 * i + 1] = (uint32_t)p[i + 1];
+        PLUME_UNROLL for (int j = i + 2; j < 8; j++) t[i + j] = addc((uint32_t)p[j], (uint32_t)(p[j - 1] >> 32), c);
+        t[i + 8] = (uint32_t)(p[7] >> 32) + c;
+    }
+    // t = 2*t + sum a_i^2 * 2^(64 i)
+    uint32_t top = 0, c = 0;
+    PLUME_UNROLL for (int i = 0; i < 16; i++) { uint32_t nt = t[i] >> 31; t[i] = (t[i] << 1) | top; top = nt; }
+    PLUME_UNROLL for (int i = 0; i < 8; i++) {
+        uint64_t s = (uint64_t)a[i] * a[i];
+        t[2 * i] = addc(t[2 * i], (uint32_t)s, c);
+        t[2 * i + 1] = addc(t[2 * i + 1], (uint32_t)(s >> 32), c);
+    }
+}
+// 512 -> weakly reduced 256: lo + hi*PC, PC = 2^32 + 977
+PLUME_HD void fe_reduce_wide(fe& r, const uint32_t t[16]) {
+    // u = lo + hi*977  (9 limbs)
+    uint32_t u[10];
+    {
+        uint64_t q[8];
+        PLUME_UNROLL for (int i = 0; i < 8; i++) q[i] = (uint64_t)t[8 + i] * PLUME_PC977 + t[i];
+        uint32_t c = 0;
+        u[0] = (uint32_t)q[0];
+        PLUME_UNROLL for (int i = 1; i < 8; i++) u[i] = addc((uint32_t)q[i], (uint32_t)(q[i - 1] >> 32), c);
+        u[8] = (uint32_t)(q[7] >> 32) + c;  // < 2^11
+    }
+    // u += hi << 32  (10 limbs; top < 2)
+    {
+        uint32_t c = 0;
+        PLUME_UNROLL for (int i = 1; i < 8; i++) u[i] = addc(u[i], t[8 + i - 1], c);
+        u[8] = addc(u[8], t[15], c);
+        u[9] = c;
+    }
+    // fold the part above bit 256: top = u[8] + u[9]*2^32 (< 2^34);  top*PC = top*977 + (top << 32)
+    uint64_t m = (uint64_t)u[8] * PLUME_PC977 + (uint64_t)u[9] * ((uint64_t)PLUME_PC977 << 32);  // < 2^44
+    uint32_t c = 0;
+    r.v[0] = addc(u[0], (uint32_t)m, c);
+    r.v[1] = addc(u[1], (uint32_t)(m >> 32), c);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc(u[i], 0u, c);
+    uint32_t c2 = 0;
+    r.v[1] = addc(r.v[1], u[8], c2);
+    r.v[2] = addc(r.v[2], u[9], c2);
+    PLUME_UNROLL for (int i = 3; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c2);
+    fe_fold_carry(r, c + c2);  // at most one of the two chains can carry out (total < 2^256 + 2^67)
+}
+PLUME_HD void fe_mul(fe& r, const fe& a, const fe& b) {
+    uint32_t t[16];
+    mul_wide(t, a.v, b.v);
+    fe_reduce_wide(r, t);
+}
+PLUME_HD void fe_sqr(fe& r, const fe& a) {
+    uint32_t t[16];
+    sqr_wide(t, a.v);
+    fe_reduce_wide(r, t);
+}
+// r = a * k for a small k (k*2^256 folds as k*PC; k < 2^20)
+PLUME_HD void fe_mul_small(fe& r, const fe& a, uint32_t k) {
+    uint64_t q[8];
+    PLUME_UNROLL for (int i = 0; i < 8; i++) q[i] = (uint64_t)a.v[i] * k;
+    uint32_t c = 0;
+    r.v[0] = (uint32_t)q[0];
+    PLUME_UNROLL for (int i = 1; i < 8; i++) r.v[i] = addc((uint32_t)q[i], (uint32_t)(q[i - 1] >> 32), c);
+    uint32_t top = (uint32_t)(q[7] >> 32) + c;  // < k
+    uint64_t m = (uint64_t)top * PLUME_PC977;   // top*PC = m + (top << 32)
+    uint32_t c1 = 0;
+    r.v[0] = addc(r.v[0], (uint32_t)m, c1);
+    r.v[1] = addc(r.v[1], (uint32_t)(m >> 32), c1);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c1);
+    uint32_t c2 = 0;
+    r.v[1] = addc(r.v[1], top, c2);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c2);
+    fe_fold_carry(r, c1 + c2);
+}
+PLUME_HD void fe_sqr_n(fe& r, const fe& a, int n) {
+    r = a;
+    PLUME_NOUNROLL for (int i = 0; i < n; i++) fe_sqr(r, r);
+}
+// shared prefix of the two exponentiations: x2 = a^(2^2-1), x22 = a^(2^22-1), t = a^((2^223-1)*2^23 + 2^22-1)
+PLUME_HD void fe_pow_prefix(fe& t, fe& x2, const fe& a) {
+    fe x3, x6, x9, x11, x22, x44, x88, x176, x220, x223;
+    fe_sqr(x2, a); fe_mul(x2, x2, a);
+    fe_sqr(x3, x2); fe_mul(x3, x3, a);
+    fe_sqr_n(x6, x3, 3); fe_mul(x6, x6, x3);
+    fe_sqr_n(x9, x6, 3); fe_mul(x9, x9, x3);
+    fe_sqr_n(x11, x9, 2); fe_mul(x11, x11, x2);
+    fe_sqr_n(x22, x11, 11); fe_mul(x22, x22, x11);
+    fe_sqr_n(x44, x22, 22); fe_mul(x44, x44, x22);
+    fe_sqr_n(x88, x44, 44); fe_mul(x88, x88, x44);
+    fe_sqr_n(x176, x88, 88); fe_mul(x176, x176, x88);
+    fe_sqr_n(x220, x176, 44); fe_mul(x220, x220, x44);
+    fe_sqr_n(x223, x220, 3); fe_mul(x223, x223, x3);
+    fe_sqr_n(t, x223, 23); fe_mul(t, t, x22);
+}
+// a^(p-2): 255 squarings + 15 multiplications
+PLUME_HD void fe_inv(fe& r, const fe& a) {
+    fe t, x2;
+    fe_pow_prefix(t, x2, a);
+    fe_sqr_n(t, t, 5); fe_mul(t, t, a);
+    fe_sqr_n(t, t, 3); fe_mul(t, t, x2);
+    fe_sqr_n(t, t, 2); fe_mul(r, t, a);
+}
+// a^((p-3)/4)  (RFC 9380 F.2.1.2 constant c1): 253 squarings + 14 multiplications
+PLUME_HD void fe_pow_c1(fe& r, const fe& a) {
+    fe t, x2;
+    fe_pow_prefix(t, x2, a);
+    fe_sqr_n(t, t, 5); fe_mul(t, t, a);
+    fe_sqr_n(t, t, 3); fe_mul(r, t, x2);
+}
+
+// big-endian 32 bytes <-> fe.  The pointers may be unaligned (caller arrays are byte arrays).
+PLUME_HD void fe_from_be(fe& r, const uint8_t* b) {
+    PLUME_UNROLL for (int i = 0; i < 8; i++) {
+        const uint8_t* q = b + 4 * (7 - i);
+        r.v[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    }
+}
+PLUME_HD void fe_to_be(uint8_t* b, const fe& a) {  // a must be canonical
+    PLUME_UNROLL for (int i = 0; i < 8; i++) {
+        uint8_t* q = b + 4 * (7 - i);
+        q[0] = (uint8_t)(a.v[i] >> 24); q[1] = (uint8_t)(a.v[i] >> 16); q[2] = (uint8_t)(a.v[i] >> 8); q[3] = (uint8_t)a.v[i];
+    }
+}
+// 16-byte-aligned variants (caller arrays of 32/64-byte records in HBM are at least 16-byte aligned)
+PLUME_HD void fe_from_be_aligned(fe& r, const uint8_t* b) {
+    const uint32_t* w = (const uint32_t*)b;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = bswap32(w[7 - i]);
+}
+PLUME_HD void fe_to_be_aligned(uint8_t* b, const fe& a) {
+    uint32_t* w = (uint32_t*)b;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) w[7 - i] = bswap32(a.v[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------- Fn
+// Scalars mod n, 8 x 32-bit limbs, canonical (< n).  Used once or twice per item (range checks, GLV split,
+// s = r + sk*c), so this is written for clarity, not speed.
+struct sc {
+    uint32_t v[8];
+};
+// n = FFFFFFFF FFFFFFFF FFFFFFFF FFFFFFFE BAAEDCE6 AF48A03B BFD25E8C D0364141 (fields/fr.rs:19)
+PLUME_HD uint32_t sc_n(int i) {
+    return i == 0 ? 0xD0364141u : i == 1 ? 0xBFD25E8Cu : i == 2 ? 0xAF48A03Bu : i == 3 ? 0xBAAEDCE6u : i == 4 ? 0xFFFFFFFEu : 0xFFFFFFFFu;
+}
+// NC = 2^256 - n = 1 45512319 50B75FC4 402DA173 2FC9BEBF (129 bits)
+PLUME_HD uint32_t sc_nc(int i) { return i == 0 ? 0x2FC9BEBFu : i == 1 ? 0x402DA173u : i == 2 ? 0x50B75FC4u : i == 3 ? 0x45512319u : i == 4 ? 1u : 0u; }
+
+PLUME_HD bool sc_is_zero(const sc& a) { uint32_t z = 0; PLUME_UNROLL for (int i = 0; i < 8; i++) z |= a.v[i]; return z == 0; }
+PLUME_HD bool sc_lt_n(const sc& a) {  // a < n
+    uint32_t bw = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) (void)subb(a.v[i], sc_n(i), bw);
+    return bw != 0;
+}
+PLUME_HD void sc_cond_sub_n(sc& a) {  // a in [0, 2n) -> [0, n) ... (only one subtraction)
+    sc t; uint32_t bw = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) t.v[i] = subb(a.v[i], sc_n(i), bw);
+    PLUME_UNROLL for (int i = 0; i < 8; i++) a.v[i] = bw ? a.v[i] : t.v[i];
+}
+PLUME_HD void sc_from_be(sc& r, const uint8_t* b) {
+    PLUME_UNROLL for (int i = 0; i < 8; i++) {
+        const uint8_t* q = b + 4 * (7 - i);
+        r.v[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    }
+}
+PLUME_HD void sc_from_be_aligned(sc& r, const uint8_t* b) {
+    const uint32_t* w = (const uint32_t*)b;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = bswap32(w[7 - i]);
+}
+PLUME_HD void sc_to_be_aligned(uint8_t* b, const sc& a) {
+    uint32_t* w = (uint32_t*)b;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) w[7 - i] = bswap32(a.v[i]);
+}
+PLUME_HD void sc_add(sc& r, const sc& a, const sc& b) {  // canonical inputs
+    uint32_t c = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = addc(a.v[i], b.v[i], c);
+    // if carry or r >= n: subtract n  (r + NC mod 2^256 when carry)
+    sc t; uint32_t bw = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) t.v[i] = subb(r.v[i], sc_n(i), bw);
+    bool take = c || !bw;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = take ? t.v[i] : r.v[i];
+}
+PLUME_HD void sc_neg(sc& r, const sc& a) {  // n - a, 0 -> 0
+    uint32_t bw = 0; bool z = sc_is_zero(a);
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = subb(sc_n(i), a.v[i], bw);
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = z ? 0u : r.v[i];
+}
+// generic NxM limb product (small helper for the scalar side)
+template <int NA, int NB>
+PLUME_HD void mul_limbs(uint32_t* t, const uint32_t* a, const uint32_t* b) {
+    PLUME_UNROLL for (int i = 0; i < NA + NB; i++) t[i] = 0;
+    PLUME_UNROLL for (int i = 0; i < NA; i++) {
+        uint32_t carry = 0;
+        PLUME_UNROLL for (int j = 0; j < NB; j++) {
+            uint64_t p = (uint64_t)a[i] * b[j] + t[i + j] + carry;
+            t[i + j] = (uint32_t)p; carry = (uint32_t)(p >> 32);
+        }
+        t[i + NB] = carry;
+    }
+}
+// 512-bit t -> t mod n.  Fold hi*NC three times (512 -> 385 -> 258 -> 256+), then at most two subtractions.
+PLUME_HD void sc_reduce_wide(sc& r, const uint32_t t[16]) {
+    uint32_t nc[5];
+    PLUME_UNROLL for (int i = 0; i < 5; i++) nc[i] = sc_nc(i);
+    // round 1: a = lo(8) + hi(8)*NC(5)  -> 13 limbs + carry -> 14 limbs
+    uint32_t a[14], m[13];
+    mul_limbs<8, 5>(m, t + 8, nc);
+    uint32_t c = 0;
+    PLUME_UNROLL for (int i = 0; i < 13; i++) a[i] = addc(m[i], i < 8 ? t[i] : 0u, c);
+    a[13] = c;
+    // round 2: b = a[0..8) + a[8..14)*NC -> 6+5 = 11 limbs (value < 2^(130+129)) + lo
+    uint32_t m2[11], b[12];
+    mul_limbs<6, 5>(m2, a + 8, nc);
+    c = 0;
+    PLUME_UNROLL for (int i = 0; i < 11; i++) b[i] = addc(m2[i], i < 8 ? a[i] : 0u, c);
+    b[11] = c;
+    // round 3: d = b[0..8) + b[8..12)*NC: b[8..] < 2^4 so the product < 2^133
+    uint32_t m3[9], d[9];
+    mul_limbs<4, 5>(m3, b + 8, nc);
+    c = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) d[i] = addc(m3[i], b[i], c);
+    d[8] = m3[8] + c;  // 0 or 1
+    // d < 2^256 + 2^133: if d[8] then d - 2^256 + NC (< 2^134, no further carry)
+    uint32_t c4 = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = addc(d[i], d[8] ? sc_nc(i) : 0u, c4);
+    sc_cond_sub_n(r);
+    sc_cond_sub_n(r);
+}
+PLUME_HD void sc_mul(sc& r, const sc& a, const sc& b) {
+    uint32_t t[16];
+    mul_limbs<8, 8>(t, a.v, b.v);
+    sc_reduce_wide(r, t);
+}
+// digest (32 bytes BE) -> scalar mod n; *canonical = digest in [1, n-1]  (Scalar::reduce, rust-k256/src/lib.rs:128;
+// NonZeroScalar::from_repr, randomizedsigner.rs:90)
+PLUME_HD void sc_from_digest_words(sc& r, const uint32_t h[8], bool& canonical) {
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = h[7 - i];
+    canonical = sc_lt_n(r) && !sc_is_zero(r);
+    sc_cond_sub_n(r);  // digest < 2^256 < 2n
+}
+
+}  // namespace plume

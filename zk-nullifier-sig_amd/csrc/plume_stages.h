@@ -1,0 +1,414 @@
+// Per-lane bodies of the PLUME batch pipeline.  The __global__ kernels in plume_kernels.hip are thin wrappers
+// that map (blockIdx, threadIdx) to an item / job / task index and call these; tests/devsim calls the same
+// bodies from plain host loops so the exact device logic is checked on the CPU against the oracle.
+//
+// verify (rust-k256/src/lib.rs:93-145), n items:
+//   S1 ingest_h2c   lane = item     validate inputs; H = h2c(m || enc(pk)) (Jacobian); publish the three table
+//                                   jobs of the item: 3i = pk, 3i+1 = H, 3i+2 = nullifier
+//   S2 tables       lane = L jobs   affine window tables 1P..8P (+ beta*x), one inversion per lane
+//   S3 msm          lane = task     task 2i: R' = s*G - c*pk ;  task 2i+1: Hr' = s*H - c*nul   (Jacobian results)
+//   S4 finalize     lane = item     V1: R' == r_point, Hr' == hashed_to_curve_r, c == SHA256(G,pk,H,nul,R,Hr) mod n
+//                                   V2: c == SHA256(nul, R', Hr') mod n
+// sign (rust-k256/src/randomizedsigner.rs:43-112; arkworks flavour rust-arkworks/src/lib.rs:229-278), n items:
+//   G1 sign_gmul    lane = task     task 2i: pk = sk*G ; task 2i+1: R = r*G
+//   G2 sign_h2c     lane = item     pk -> affine (or caller-supplied), H = h2c(m || enc(pk)); table job i = H
+//   S2 tables       (as above, 1 job per item)
+//   G3 sign_hmul    lane = task     task 2i: nullifier = sk*H ; task 2i+1: Hr = r*H
+//   G4 sign_final   lane = item     affine outputs, c = SHA256(..) mod n, s = r + sk*c, status bits
+#pragma once
+#include "plume_h2c.h"
+
+namespace plume {
+
+// ------------------------------------------------------------------------------------------- point ingest
+// 64-byte affine x||y big-endian, all-zero = identity (include/plume_hip.h).  flag: 0 ok, 1 identity, 2 invalid
+PLUME_HD uint32_t load_affine_be(fe& x, fe& y, const uint8_t* p) {
+    fe_from_be_aligned(x, p);
+    fe_from_be_aligned(y, p + 32);
+    uint32_t nz = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) nz |= x.v[i] | y.v[i];
+    if (nz == 0) return PLUME_JOB_INF;
+    if (!fe_is_canonical(x) || !fe_is_canonical(y)) return PLUME_JOB_INVALID;
+    return affine_on_curve(x, y) ? PLUME_JOB_OK : PLUME_JOB_INVALID;
+}
+PLUME_HD void store_affine_be(uint8_t* p, fe x, fe y, bool inf) {
+    fe_normalize(x); fe_normalize(y);
+    if (inf) { x = fe_zero(); y = fe_zero(); }
+    fe_to_be_aligned(p, x);
+    fe_to_be_aligned(p + 32, y);
+}
+// scalar in [1, n-1]?
+PLUME_HD bool load_scalar_be(sc& k, const uint8_t* p) {
+    sc_from_be_aligned(k, p);
+    return !sc_is_zero(k) && sc_lt_n(k);
+}
+
+// --------------------------------------------------------------------------------------------- c-hash
+// One SEC1-compressed operand of the c-hash: canonical x, parity of y, or the identity (encoded as the single byte 00;
+// rust-k256/src/utils.rs:23-25, rust-arkworks/src/lib.rs:112-118)
+struct enc_pt {
+    fe x;
+    uint32_t tag;  // 2 | 3, or 0 for the identity
+};
+PLUME_HD enc_pt enc_of(fe x, const fe& y, bool inf) {
+    enc_pt e;
+    fe_normalize(x);
+    e.x = x;
+    e.tag = inf ? 0u : (2u + (fe_is_odd(y) ? 1u : 0u));
+    return e;
+}
+// SHA256 over npts encodings (order given by the caller).  Fast path: no identity among them -> static layout of
+// 33-byte records; slow path: generic byte stream.
+template <int NPTS>
+PLUME_HD void c_hash(uint32_t out[8], const enc_pt* pts) {
+    bool any_inf = false;
+    PLUME_UNROLL for (int i = 0; i < NPTS; i++) any_inf |= (pts[i].tag == 0);
+    sha256_init(out);
+    if (!any_inf) {
+        constexpr int LEN = 33 * NPTS, NW = ((LEN + 9 + 63) / 64) * 16;
+        uint32_t w[NW];
+        PLUME_UNROLL for (int i = 0; i < NW; i++) w[i] = 0;
+        PLUME_UNROLL for (int i = 0; i < NPTS; i++) {
+            // record i occupies bytes [33i, 33i+33): tag then x big-endian; static shifts after unrolling
+            PLUME_UNROLL for (int k = 0; k < 33; k++) {
+                const int pos = 33 * i + k;
+                uint32_t byte = k == 0 ? pts[i].tag : ((pts[i].x.v[7 - ((k - 1) >> 2)] >> (8 * (3 - ((k - 1) & 3)))) & 0xFF);
+                w[pos >> 2] |= byte << (8 * (3 - (pos & 3)));
+            }
+        }
+        w[LEN >> 2] |= 0x80u << (8 * (3 - (LEN & 3)));
+        w[NW - 1] = LEN * 8;
+        PLUME_UNROLL for (int b = 0; b < NW / 16; b++) sha256_compress(out, w + 16 * b);
+    } else {
+        uint32_t len = 0;
+        PLUME_UNROLL for (int i = 0; i < NPTS; i++) len += pts[i].tag ? 33u : 1u;
+        sha256_absorb_pad(out, 0u, len, [&](uint32_t pos) -> uint32_t {
+            uint32_t v = 0, base = 0;
+            PLUME_UNROLL for (int i = 0; i < NPTS; i++) {
+                uint32_t l = pts[i].tag ? 33u : 1u;
+                if (pos >= base && pos < base + l) v = (pos == base) ? pts[i].tag : be_byte_of_limbs(pts[i].x.v, pos - base - 1);
+                base += l;
+            }
+            return v;
+        });
+    }
+}
+
+// ===================================================================================================== verify
+struct VerifyArgs {
+    int version;       // 1 | 2
+    uint32_t n;
+    // caller arrays (device memory): SoA of big-endian records
+    const uint8_t* msgs; const uint64_t* msg_off;
+    const uint8_t *pk, *nul, *c, *s, *rpt, *hr;
+    uint8_t* ok;
+    // scratch (device memory)
+    uint32_t* bases;      // 24 x (3n) words, Jacobian SoA, job j = word-row w at bases[w*3n + j]
+    uint8_t* jobflags;    // 3n
+    uint8_t* itemflags;   // n : 1 = rejected at ingest (bad scalar / invalid point)
+    uint32_t* tab;        // 3n tables of PLUME_TAB_WORDS
+    uint32_t* res;        // 24 x (2n) words, Jacobian SoA of R' (task 2i) and Hr' (task 2i+1)
+    uint8_t* resinf;      // 2n
+    const uint32_t* gtab; // table of G (PLUME_TAB_WORDS)
+};
+
+PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
+    const size_t nj = 3 * (size_t)a.n;
+    fe pkx, pky, nx, ny;
+    uint32_t fpk = load_affine_be(pkx, pky, a.pk + 64 * (size_t)i);
+    uint32_t fnul = load_affine_be(nx, ny, a.nul + 64 * (size_t)i);
+    sc c, s;
+    bool okc = load_scalar_be(c, a.c + 32 * (size_t)i), oks = load_scalar_be(s, a.s + 32 * (size_t)i);
+    bool bad = !okc || !oks || fpk == PLUME_JOB_INVALID || fnul == PLUME_JOB_INVALID;
+    a.itemflags[i] = bad ? 1 : 0;
+    jac h;
+    if (!bad) {
+        const uint64_t o0 = a.msg_off[i], o1 = a.msg_off[i + 1];
+        hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), pkx, 2u + (fe_is_odd(pky) ? 1u : 0u), fpk == PLUME_JOB_INF);
+    } else {
+        h.x = fe_gx(); h.y = fe_gy(); h.z = fe_small(1); h.inf = 0;
+    }
+    jac p; p.inf = 0; p.z = fe_small(1);
+    p.x = pkx; p.y = pky;
+    st_jac_soa(a.bases, nj, 3 * (size_t)i + 0, p); a.jobflags[3 * (size_t)i + 0] = (uint8_t)fpk;
+    st_jac_soa(a.bases, nj, 3 * (size_t)i + 1, h); a.jobflags[3 * (size_t)i + 1] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
+    p.x = nx; p.y = ny;
+    st_jac_soa(a.bases, nj, 3 * (size_t)i + 2, p); a.jobflags[3 * (size_t)i + 2] = (uint8_t)fnul;
+}
+
+// digits of one double-base task a*A + b*B into dig (4 slots x 33): slots 0,1 = a's halves, 2,3 = b's halves
+PLUME_HD void task_digits(int8_t* dig, uint32_t stride, const sc& ka, bool flip_a, const sc& kb, bool flip_b) {
+    glv_half h1, h2;
+    glv_split(h1, h2, ka);
+    booth_store(dig + 0 * PLUME_NDIG * stride, stride, h1, flip_a);
+    booth_store(dig + 1 * PLUME_NDIG * stride, stride, h2, flip_a);
+    glv_split(h1, h2, kb);
+    booth_store(dig + 2 * PLUME_NDIG * stride, stride, h1, flip_b);
+    booth_store(dig + 3 * PLUME_NDIG * stride, stride, h2, flip_b);
+}
+
+// task t = 2*item + eq;  eq 0: s*G - c*pk, eq 1: s*H - c*nul.   dig: this lane's digit area (LDS), element stride
+PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const uint32_t* gtab, int8_t* dig, uint32_t stride) {
+    const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + eq;
+    jac acc;
+    if (a.itemflags[item]) {
+        acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
+    } else {
+        sc c, s;
+        sc_from_be_aligned(c, a.c + 32 * (size_t)item);
+        sc_from_be_aligned(s, a.s + 32 * (size_t)item);
+        task_digits(dig, stride, s, false, c, true);
+        const size_t ja = 3 * (size_t)item + 1, jb = 3 * (size_t)item + (eq ? 2 : 0);
+        const uint32_t* tab0 = eq ? (a.jobflags[ja] == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr) : gtab;
+        const uint32_t* tab1 = a.jobflags[jb] == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
+        msm_run(acc, tab0, tab1, 4, dig, stride);
+    }
+    st_jac_soa(a.res, nt, t, acc);
+    a.resinf[t] = (uint8_t)acc.inf;
+}
+
+PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
+    const size_t nt = 2 * (size_t)a.n;
+    uint8_t ok = 0;
+    if (!a.itemflags[i]) {
+        jac rc, hc;
+        ld_jac_soa(rc, a.res, nt, 2 * (size_t)i); rc.inf = a.resinf[2 * (size_t)i];
+        ld_jac_soa(hc, a.res, nt, 2 * (size_t)i + 1); hc.inf = a.resinf[2 * (size_t)i + 1];
+        fe pkx, pky, nx, ny;
+        uint32_t fpk = load_affine_be(pkx, pky, a.pk + 64 * (size_t)i);
+        uint32_t fnul = load_affine_be(nx, ny, a.nul + 64 * (size_t)i);
+        sc c;
+        sc_from_be_aligned(c, a.c + 32 * (size_t)i);
+        uint32_t dg[8];
+        bool hashed = false;
+        if (a.version == 1) {
+            fe rx, ry, hx, hy;
+            uint32_t fr = load_affine_be(rx, ry, a.rpt + 64 * (size_t)i);
+            uint32_t fh = load_affine_be(hx, hy, a.hr + 64 * (size_t)i);
+            if (fr != PLUME_JOB_INVALID && fh != PLUME_JOB_INVALID &&
+                jac_eq_affine(rc, rx, ry, fr == PLUME_JOB_INF) && jac_eq_affine(hc, hx, hy, fh == PLUME_JOB_INF)) {   // lib.rs:117,122
+                // affine H = entry 0 of H's table (canonical); identity H has no table
+                const size_t jh = 3 * (size_t)i + 1;
+                bool hinf = a.jobflags[jh] == PLUME_JOB_INF;
+                fe Hx, Hy;
+                ld_fe(Hx, a.tab + jh * PLUME_TAB_WORDS); ld_fe(Hy, a.tab + jh * PLUME_TAB_WORDS + 8);
+                enc_pt pts[6];
+                pts[0] = enc_of(fe_gx(), fe_gy(), false);
+                pts[1] = enc_of(pkx, pky, fpk == PLUME_JOB_INF);
+                pts[2] = enc_of(Hx, Hy, hinf);
+                pts[3] = enc_of(nx, ny, fnul == PLUME_JOB_INF);
+                pts[4] = enc_of(rx, ry, fr == PLUME_JOB_INF);
+                pts[5] = enc_of(hx, hy, fh == PLUME_JOB_INF);
+                c_hash<6>(dg, pts);                                                                                  // lib.rs:128-135
+                hashed = true;
+            }
+        } else {
+            // affine R', Hr' with one shared inversion
+            fe zr = rc.inf ? fe_small(1) : rc.z, zh = hc.inf ? fe_small(1) : hc.z, zz, inv, zri, zhi, t;
+            fe_mul(zz, zr, zh);
+            fe_inv(inv, zz);
+            fe_mul(zri, inv, zh); fe_mul(zhi, inv, zr);
+            fe_sqr(t, zri); fe_mul(rc.x, rc.x, t); fe_mul(t, t, zri); fe_mul(rc.y, rc.y, t);
+            fe_sqr(t, zhi); fe_mul(hc.x, hc.x, t); fe_mul(t, t, zhi); fe_mul(hc.y, hc.y, t);
+            enc_pt pts[3];
+            pts[0] = enc_of(nx, ny, fnul == PLUME_JOB_INF);
+            pts[1] = enc_of(rc.x, rc.y, rc.inf != 0);
+            pts[2] = enc_of(hc.x, hc.y, hc.inf != 0);
+            c_hash<3>(dg, pts);                                                                                      // lib.rs:139-143
+            hashed = true;
+        }
+        if (hashed) {
+            sc cc; bool canon;
+            sc_from_digest_words(cc, dg, canon);                                                                     // Scalar::reduce
+            uint32_t diff = 0;
+            PLUME_UNROLL for (int k = 0; k < 8; k++) diff |= cc.v[k] ^ c.v[k];
+            ok = diff == 0 ? 1 : 0;
+        }
+    }
+    a.ok[i] = ok;
+}
+
+// ======================================================================================================= sign
+#define PLUME_ST_C_NOT_CANONICAL 1u  // digest == 0 or >= n (k256 sign panics there, randomizedsigner.rs:90-91; arkworks reduces, lib.rs:257)
+#define PLUME_ST_BAD_SCALAR 2u       // sk or r outside [1, n-1], or a supplied pk that is not a curve point
+#define PLUME_ST_IDENTITY 4u         // H == identity (randomizedsigner.rs:61) or s == 0 (:95)
+
+struct SignArgs {
+    int version;
+    uint32_t n;
+    const uint8_t* msgs; const uint64_t* msg_off;
+    const uint8_t *sk, *r;
+    const uint8_t* pk_in;   // optional (arkworks-shaped sign_with_r: pk supplied, not derived)
+    uint8_t *pk, *nul, *c, *s, *rpt, *hr, *status;
+    uint8_t* h_out;         // optional 64 B/item
+    // scratch
+    uint32_t* gres;  uint8_t* gresinf;   // 2n tasks: sk*G, r*G (Jacobian SoA)
+    uint32_t* bases; uint8_t* jobflags;  // n jobs: H
+    uint8_t* itemflags;                  // n: status bits accumulated across stages
+    uint32_t* pkaff;                     // 16 x n words SoA: affine pk (x, y) for the final stage
+    uint32_t* tab;                       // n tables
+    uint32_t* hres;  uint8_t* hresinf;   // 2n tasks: sk*H, r*H
+    const uint32_t* gtab;
+};
+
+// scalars reduced mod n for the arithmetic, status bit if out of range (the Rust types cannot hold such values)
+PLUME_HD uint32_t load_scalar_reduced(sc& k, const uint8_t* p) {
+    sc_from_be_aligned(k, p);
+    bool ok = !sc_is_zero(k) && sc_lt_n(k);
+    sc_cond_sub_n(k);
+    return ok ? 0u : PLUME_ST_BAD_SCALAR;
+}
+// task t = 2*item + which: which 0 -> sk, 1 -> r;  result = k * (table tab0)
+PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, const uint32_t* tab0, uint32_t* res, uint8_t* resinf, int8_t* dig, uint32_t stride) {
+    const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
+    sc k;
+    (void)load_scalar_reduced(k, (which ? a.r : a.sk) + 32 * (size_t)item);
+    glv_half h1, h2;
+    glv_split(h1, h2, k);
+    booth_store(dig, stride, h1, false);
+    booth_store(dig + PLUME_NDIG * stride, stride, h2, false);
+    jac acc;
+    msm_run(acc, tab0, nullptr, 2, dig, stride);
+    st_jac_soa(res, nt, t, acc);
+    resinf[t] = (uint8_t)acc.inf;
+}
+PLUME_HD void sign_gmul(const SignArgs& a, uint32_t item, uint32_t which, const uint32_t* gtab, int8_t* dig, uint32_t stride) {
+    if (which == 0 && a.pk_in) return;   // pk supplied: sk*G not needed
+    sign_mul(a, item, which, gtab, a.gres, a.gresinf, dig, stride);
+}
+PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
+    const size_t nt = 2 * (size_t)a.n;
+    uint32_t st = 0;
+    sc tmp;
+    st |= load_scalar_reduced(tmp, a.sk + 32 * (size_t)i);
+    st |= load_scalar_reduced(tmp, a.r + 32 * (size_t)i);
+    fe px, py;
+    bool pinf;
+    if (a.pk_in) {
+        uint32_t f = load_affine_be(px, py, a.pk_in + 64 * (size_t)i);
+        if (f == PLUME_JOB_INVALID) { st |= PLUME_ST_BAD_SCALAR; f = PLUME_JOB_INF; }
+        pinf = f == PLUME_JOB_INF;
+    } else {
+        jac p;
+        ld_jac_soa(p, a.gres, nt, 2 * (size_t)i); p.inf = a.gresinf[2 * (size_t)i];
+        pinf = p.inf != 0;
+        fe zi, zi2;
+        fe z = pinf ? fe_small(1) : p.z;
+        fe_inv(zi, z); fe_sqr(zi2, zi);
+        fe_mul(px, p.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(py, p.y, zi2);
+        fe_normalize(px); fe_normalize(py);
+    }
+    if (pinf) { px = fe_zero(); py = fe_zero(); }
+    st_fe_soa(a.pkaff, a.n, i, px); st_fe_soa(a.pkaff + 8 * (size_t)a.n, a.n, i, py);
+    jac h;
+    const uint64_t o0 = a.msg_off[i], o1 = a.msg_off[i + 1];
+    hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), px, 2u + (fe_is_odd(py) ? 1u : 0u), pinf);
+    if (h.inf) st |= PLUME_ST_IDENTITY;
+    st_jac_soa(a.bases, a.n, i, h);
+    a.jobflags[i] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
+    a.itemflags[i] = (uint8_t)(st | (pinf ? 0x80u : 0u));
+}
+PLUME_HD void sign_hmul(const SignArgs& a, uint32_t item, uint32_t which, int8_t* dig, uint32_t stride) {
+    const uint32_t* tab0 = a.jobflags[item] == PLUME_JOB_OK ? a.tab + (size_t)item * PLUME_TAB_WORDS : nullptr;
+    sign_mul(a, item, which, tab0, a.hres, a.hresinf, dig, stride);
+}
+PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
+    const size_t nt = 2 * (size_t)a.n;
+    uint32_t st = a.itemflags[i] & 0x7Fu;
+    bool pinf = (a.itemflags[i] & 0x80u) != 0;
+    jac R, nul, hr;
+    ld_jac_soa(R, a.gres, nt, 2 * (size_t)i + 1); R.inf = a.gresinf[2 * (size_t)i + 1];
+    ld_jac_soa(nul, a.hres, nt, 2 * (size_t)i); nul.inf = a.hresinf[2 * (size_t)i];
+    ld_jac_soa(hr, a.hres, nt, 2 * (size_t)i + 1); hr.inf = a.hresinf[2 * (size_t)i + 1];
+    // three affine conversions, one inversion
+    fe z0 = R.inf ? fe_small(1) : R.z, z1 = nul.inf ? fe_small(1) : nul.z, z2 = hr.inf ? fe_small(1) : hr.z;
+    fe p01, p012, inv, i0, i1, i2, t;
+    fe_mul(p01, z0, z1); fe_mul(p012, p01, z2);
+    fe_inv(inv, p012);
+    fe_mul(i2, inv, p01); fe_mul(inv, inv, z2);   // inv = 1/(z0 z1)
+    fe_mul(i1, inv, z0); fe_mul(i0, inv, z1);
+    fe_sqr(t, i0); fe_mul(R.x, R.x, t); fe_mul(t, t, i0); fe_mul(R.y, R.y, t);
+    fe_sqr(t, i1); fe_mul(nul.x, nul.x, t); fe_mul(t, t, i1); fe_mul(nul.y, nul.y, t);
+    fe_sqr(t, i2); fe_mul(hr.x, hr.x, t); fe_mul(t, t, i2); fe_mul(hr.y, hr.y, t);
+    fe px, py, Hx, Hy;
+    ld_fe_soa(px, a.pkaff, a.n, i); ld_fe_soa(py, a.pkaff + 8 * (size_t)a.n, a.n, i);
+    bool hinf = a.jobflags[i] == PLUME_JOB_INF;
+    ld_fe(Hx, a.tab + (size_t)i * PLUME_TAB_WORDS); ld_fe(Hy, a.tab + (size_t)i * PLUME_TAB_WORDS + 8);
+    uint32_t dg[8];
+    enc_pt e_nul = enc_of(nul.x, nul.y, nul.inf != 0), e_r = enc_of(R.x, R.y, R.inf != 0), e_hr = enc_of(hr.x, hr.y, hr.inf != 0);
+    if (a.version == 1) {
+        enc_pt pts[6] = {enc_of(fe_gx(), fe_gy(), false), enc_of(px, py, pinf), enc_of(Hx, Hy, hinf), e_nul, e_r, e_hr};
+        c_hash<6>(dg, pts);                                                          // randomizedsigner.rs:80-87
+    } else {
+        enc_pt pts[3] = {e_nul, e_r, e_hr};
+        c_hash<3>(dg, pts);
+    }
+    sc c, sk, r, s, tt;
+    bool canon;
+    sc_from_digest_words(c, dg, canon);
+    if (!canon) st |= PLUME_ST_C_NOT_CANONICAL;                                      // :90-91
+    (void)load_scalar_reduced(sk, a.sk + 32 * (size_t)i);
+    (void)load_scalar_reduced(r, a.r + 32 * (size_t)i);
+    sc_mul(tt, c, sk); sc_add(s, r, tt);                                             // :94
+    if (sc_is_zero(s)) st |= PLUME_ST_IDENTITY;                                      // :95
+    if (a.pk) store_affine_be(a.pk + 64 * (size_t)i, px, py, pinf);
+    store_affine_be(a.nul + 64 * (size_t)i, nul.x, nul.y, nul.inf != 0);
+    sc_to_be_aligned(a.c + 32 * (size_t)i, c);
+    sc_to_be_aligned(a.s + 32 * (size_t)i, s);
+    store_affine_be(a.rpt + 64 * (size_t)i, R.x, R.y, R.inf != 0);
+    store_affine_be(a.hr + 64 * (size_t)i, hr.x, hr.y, hr.inf != 0);
+    if (a.h_out) store_affine_be(a.h_out + 64 * (size_t)i, Hx, Hy, hinf);
+    a.status[i] = (uint8_t)st;
+}
+
+// ============================================================================================ h2c only (KAT pinning)
+struct H2cArgs {
+    uint32_t n;
+    const uint8_t* msgs; const uint64_t* msg_off;
+    const uint8_t* pk;   // may be NULL: hash the raw message bytes (no encoding appended)
+    uint8_t* h_out;      // 64 B/item, all-zero for identity or invalid pk
+};
+PLUME_HD void h2c_only(const H2cArgs& a, uint32_t i) {
+    const uint64_t o0 = a.msg_off[i], o1 = a.msg_off[i + 1];
+    jac h;
+    fe x = fe_zero(), y = fe_zero();
+    bool bad = false;
+    if (a.pk) {
+        fe px, py;
+        uint32_t f = load_affine_be(px, py, a.pk + 64 * (size_t)i);
+        bad = f == PLUME_JOB_INVALID;
+        if (!bad) hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), px, 2u + (fe_is_odd(py) ? 1u : 0u), f == PLUME_JOB_INF);
+    } else {
+        // raw: m || <nothing>: reuse the same stream with a zero-length "encoding" by folding it into the message
+        fe u0, u1;
+        {
+            uint32_t b0[8], uni[24], xx[8];
+            const uint8_t* msg = a.msgs + o0; const uint32_t mlen = (uint32_t)(o1 - o0);
+            sha256_init_after_zero_block(b0);
+            sha256_absorb_pad(b0, 64u, mlen + 53u, [&](uint32_t pos) -> uint32_t {
+                if (pos < mlen) return msg[pos];
+                uint32_t k = pos - mlen;
+                if (k < 3) return k == 1 ? 0x60u : 0u;
+                return dst_prime_byte(k - 3);
+            });
+            xmd_bi(uni, b0, 1);
+            PLUME_UNROLL for (int k = 0; k < 8; k++) xx[k] = b0[k] ^ uni[k];
+            xmd_bi(uni + 8, xx, 2);
+            PLUME_UNROLL for (int k = 0; k < 8; k++) xx[k] = b0[k] ^ uni[8 + k];
+            xmd_bi(uni + 16, xx, 3);
+            fe_from_be48_words(u0, uni); fe_from_be48_words(u1, uni + 12);
+        }
+        jac q0, q1; fe xn, xd, yy;
+        sswu_frac(xn, xd, yy, u0); iso3_frac_to_jac(q0, xn, xd, yy);
+        sswu_frac(xn, xd, yy, u1); iso3_frac_to_jac(q1, xn, xd, yy);
+        h = q0; jac_add(h, q1);
+    }
+    if (!bad && !h.inf) {
+        fe zi, zi2;
+        fe_inv(zi, h.z); fe_sqr(zi2, zi);
+        fe_mul(x, h.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y, h.y, zi2);
+    }
+    store_affine_be(a.h_out + 64 * (size_t)i, x, y, bad || h.inf);
+}
+
+}  // namespace plume
