@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — PLUME V1 verifies/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2-batch 20] [--version 1] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the verify pipeline (ingest+h2c -> window tables -> multi-scalar loop -> finalize) over one
+batch of 2^20 synthetic V1 signatures per GPU, inputs already resident in HBM, through the C ABI's device-resident
+entry point (plume_verify_batch_device) on torch's current stream.  Weak scaling: every rank verifies its own
+2^20-item shard (items [rank*2^20, (rank+1)*2^20) of the BASELINE.md §3 generator); the path has no cross-device
+exchange, so the only collectives are the timing barrier and the MAX over ranks.
+
+Extra objects on the line:
+  roofline      dominant kernel (k_verify_msm): algorithmic bytes (353 B/item) / its HIP-event duration
+                vs 8 TB/s — the schema's HBM view, honest and tiny because this path is integer-VALU bound;
+  valu_roofline the meaningful one: accounting MACs (SURVEY.md §8d, 72 per Fp-mult) per second vs the v_mad_u64_u32
+                issue rate measured by a microbenchmark in this same run;
+  cpu_baseline  the plain-C oracle (kind "port": rust-k256 cannot be built here) timed on the host cores, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+sys.path.insert(0, str(ROOT))
+
+BYTES_PER_ITEM = {1: 353, 2: 225}                 # SURVEY.md §8d / BASELINE.md §4 (in + out)
+FPMUL_PER_ITEM = {1: 5460, 2: 5460}               # accounting algorithm, whole verify
+FPMUL_MSM_PER_ITEM = 1900 + 2260                  # the two double-base multiplications (dominant kernel)
+MACS_PER_FPMUL = 72
+HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2-batch", type=int, default=20, help="items per GPU per step = 2^this (BASELINE: 20)")
+    ap.add_argument("--version", type=int, default=1, choices=(1, 2))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def shard_bounds(total: int, rank: int, world: int):
+    """contiguous even split [floor(r*T/W), floor((r+1)*T/W)) — SURVEY.md §8e"""
+    return (total * rank) // world, (total * (rank + 1)) // world
+
+
+def cpu_baseline(version: int):
+    """plain-C oracle on the host cores, bounded sample of the same workload"""
+    import numpy as np  # noqa: F401
+
+    from tests import _oracle_c as OC
+    from tests import synth
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    n = max(1024, min(16384, 256 * threads))
+    b = synth.sign_inputs(n)
+    signed = OC.sign_batch(version, b["msgs"], b["off"], b["sk"], b["r"], nthreads=threads)
+    v = synth.corrupt_for_verify(version, b, signed)
+    args = (version, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
+    t0 = time.perf_counter()
+    ok_mt = OC.verify_batch(*args, nthreads=threads)
+    t_mt = time.perf_counter() - t0
+    n1 = min(n, 1024)
+    a1 = (version, v["msgs"], v["off"][: n1 + 1], v["pk"][:n1], v["nullifier"][:n1], v["c"][:n1], v["s"][:n1],
+          v["r_point"][:n1] if version == 1 else None, v["hashed_to_curve_r"][:n1] if version == 1 else None)
+    t0 = time.perf_counter()
+    OC.verify_batch(*a1, nthreads=1)
+    t_1 = time.perf_counter() - t0
+    assert list(ok_mt) == list(synth.expected_ok(n))
+    return {"value": round(n / t_mt, 1), "unit": "verifies/s", "cores": threads, "kind": "port",
+            "sample": f"first {n} items of the same synthetic V{version} batch, plain-C oracle (4-bit window, no endomorphism), {threads} threads; "
+                      f"single thread: {n1 / t_1:.1f} verifies/s. rust-k256 itself cannot be built here (no rustc/cargo).",
+            "single_thread_value": round(n1 / t_1, 1)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world == 1:
+        # convenience: launched bare with --gpus N -> re-launch under torch.distributed.run as a CHILD (nothing has touched the GPU yet)
+        port = os.environ.get("MASTER_PORT", "29533")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", port,
+               str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import zk_nullifier_sig_amd as plume
+    from tests import synth
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    eng = plume.Engine(local_rank)
+    n = 1 << a.log2_batch
+    ver = a.version
+    eng.set_chunk(max(n, 1 << 20))
+
+    # ---- synthetic shard of this rank, signed on the GPU (setup, untimed), corrupted 1/16 as BASELINE.md §3
+    start, _ = shard_bounds(n * world, rank, world)
+    b = synth.sign_inputs(n, start=start)
+    signed = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    v = synth.corrupt_for_verify(ver, b, signed, start=start)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    d = {k: t(v[k]) for k in ("msgs", "pk", "nullifier", "c", "s")}
+    d["off"] = t(v["off"].view(np.int64))
+    d["r_point"] = t(v["r_point"]) if ver == 1 else None
+    d["hashed_to_curve_r"] = t(v["hashed_to_curve_r"]) if ver == 1 else None
+    ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    msgs_bytes = int(v["off"][-1])
+    expected = torch.from_numpy(synth.expected_ok(n, start)).to(dev)
+
+    def step():
+        eng.verify_batch_device(ver, n, d["msgs"], d["off"], msgs_bytes, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stage_acc = {}
+    for _ in range(a.steps):
+        step()
+        if a.steps <= 64:  # per-stage HIP-event times (events are recorded on the launch stream inside the library)
+            torch.cuda.current_stream().synchronize()
+            for name, ms in eng.last_stage_times():
+                stage_acc[name] = stage_acc.get(name, 0.0) + ms
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert bool((ok == expected).all()), "verify results differ from the expected corruption pattern"
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / a.steps
+        value = n * world * a.steps / elapsed
+        stages = {k: round(vv / a.steps, 4) for k, vv in stage_acc.items()}
+        line = {
+            "metric": f"PLUME V{ver} verifies/sec (secp256k1 + SHA-256), batch 2^{a.log2_batch} per GPU", "value": round(value, 1), "unit": "verifies/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32x8 limbs (v_mad_u64_u32 integer)", "data": "synthetic",
+            "config": {"workload": f"batch 2^{a.log2_batch} PLUME V{ver} verify per GPU, 32-byte messages, 1/16 corrupted, inputs resident in HBM",
+                       "items_per_gpu": n, "global_items_per_step": n * world, "parallelism": f"shard x{world}, no collective"},
+            "stage_ms": stages,
+        }
+        if stages:
+            dom = max(stages, key=stages.get)
+            dom_s = stages[dom] * 1e-3
+            achieved = BYTES_PER_ITEM[ver] * n / dom_s / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                                "note": "path is integer-VALU bound (SURVEY.md §8d); see valu_roofline"}
+            try:
+                mad_rate = eng.microbench(0, 4096)
+                add_rate = eng.microbench(4, 4096)
+                fpmul_rate = eng.microbench(5, 512)
+                fpsqr_rate = eng.microbench(6, 512)
+                step_s = sum(stages.values()) * 1e-3
+                whole = FPMUL_PER_ITEM[ver] * MACS_PER_FPMUL * n / step_s
+                msm = FPMUL_MSM_PER_ITEM * MACS_PER_FPMUL * n / (stages.get("verify_msm", step_s * 1e3) * 1e-3)
+                line["valu_roofline"] = {"bound": "int-valu", "unit": "32-bit MAC/s", "peak_v_mad_u64_u32": round(mad_rate, 1), "peak_v_add_u32": round(add_rate, 1),
+                                         "fp_mul_per_s": round(fpmul_rate, 1), "fp_sqr_per_s": round(fpsqr_rate, 1),
+                                         "achieved_whole_path": round(whole, 1), "frac_whole_path": round(whole / mad_rate, 4),
+                                         "achieved_msm_kernel": round(msm, 1), "frac_msm_kernel": round(msm / mad_rate, 4),
+                                         "accounting": "5460 Fp-mult/verify x 72 MACs (SURVEY.md §8d, frozen in BASELINE.md §4)"}
+            except Exception as e:  # measurement extras must not kill the bench line
+                line["valu_roofline"] = {"error": str(e)}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(ver)
+            except Exception as e:
+                line["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

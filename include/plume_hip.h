@@ -1,0 +1,117 @@
+/* plume_hip.h — C ABI of the MI355X batch PLUME sign/verify engine (libplume_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of plume-sig/zk-nullifier-sig.  The reference has no FFI of
+ * its own: its public Rust API is the boundary.  Each entry point below replaces, for a whole
+ * batch at once, the Rust item named beside it; a `plume_rustcrypto`-compatible façade binds these with
+ * `extern "C"` (INTEGRATION.md shows the stub).
+ *
+ * Data formats (all arrays are structure-of-arrays, caller-owned, never retained after return):
+ *   point   64 bytes  affine x || y, big-endian; all-zero = the identity (k256 AffinePoint::IDENTITY)
+ *   scalar  32 bytes  big-endian
+ *   msgs    packed message bytes + (n+1) u64 offsets: message i = msgs[msg_off[i] .. msg_off[i+1])
+ *   arrays of 32/64-byte records must be 4-byte aligned (16 recommended); msgs may have any alignment
+ *
+ * Return codes: 0 ok, -1 bad argument, -2 HIP runtime error (text via plume_last_error), -3 no usable GPU.
+ * Nothing throws or unwinds across this boundary.  There is NO CPU fallback: without a gfx950 device
+ * plume_init fails with -3.
+ *
+ * Threading: one plume_ctx is used by one host thread at a time; distinct contexts (one per GPU / per process
+ * rank) are independent.  Multi-GPU = one context per device over a contiguous shard of the batch; the path has
+ * no cross-device exchange, so no collective is involved.
+ */
+#ifndef PLUME_HIP_H
+#define PLUME_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plume_ctx plume_ctx;
+
+#define PLUME_OK 0
+#define PLUME_ERR_ARG (-1)
+#define PLUME_ERR_HIP (-2)
+#define PLUME_ERR_NODEV (-3)
+
+/* sign status bits (per item) */
+#define PLUME_STATUS_C_NOT_CANONICAL 1 /* SHA-256 digest was 0 or >= n: k256's sign panics here (rust-k256/src/randomizedsigner.rs:90-91), \
+                                          arkworks' reduces (rust-arkworks/src/lib.rs:257); c is emitted reduced mod n */
+#define PLUME_STATUS_BAD_SCALAR 2      /* sk or r outside [1, n-1] (NonZeroScalar / SecretKey invariant), or a supplied pk not on the curve */
+#define PLUME_STATUS_IDENTITY 4        /* H == identity (randomizedsigner.rs:61) or s == 0 (randomizedsigner.rs:95) */
+
+/* Create a context bound to HIP device `device_id` (>= 0).  Builds the generator's window table on the device. */
+int plume_init(plume_ctx** out, int device_id);
+void plume_destroy(plume_ctx* ctx);
+/* Last error text of this thread (valid until the next failing call on the thread). */
+const char* plume_last_error(void);
+/* Library / build information, e.g. "plume_hip 0.1 gfx950". */
+const char* plume_version(void);
+/* Upper bound on items processed per internal pass (workspace is ~3.7 KB per in-flight item). Default 1<<20. */
+int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
+
+/* ---- PlumeSignature::verify, batched  (rust-k256/src/lib.rs:93-145) -------------------------------------
+ * version 1: V1 (v1specific = Some{r_point, hashed_to_curve_r}); version 2: V2 (r_point, hashed_to_curve_r NULL).
+ * ok[i] = 1 iff the reference's verify() returns true for item i, else 0.  Inputs the Rust types cannot even
+ * represent (c or s outside [1, n-1], coordinates >= p, points off the curve) give ok = 0.
+ * Host-pointer form: copies in, runs, copies ok[] out, returns when done. */
+int plume_verify_batch(plume_ctx* ctx, int version, size_t n,
+                       const uint8_t* msgs, const uint64_t* msg_off,
+                       const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s,
+                       const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
+                       uint8_t* ok);
+
+/* ---- PlumeSigner::try_sign_with_rng / PlumeSignature::sign_v1|sign_v2, batched, nonce supplied -----------
+ * (rust-k256/src/randomizedsigner.rs:43-112, rust-k256/src/lib.rs:149-156; the RNG stays on the host: r[i] is
+ * the 32 bytes the reference would draw, cf. the mock RNG in rust-k256/tests/signing.rs:23-44).
+ * pk_in == NULL : pk = sk*G is derived (plume_rustcrypto shape).
+ * pk_in != NULL : plume_arkworks::sign_with_r shape (rust-arkworks/src/lib.rs:229-278): pk supplied, not recomputed.
+ * Outputs: pk (may be NULL), nullifier, c (= digest mod n), s, r_point, hashed_to_curve_r (always written, V1 and
+ * V2), status[i] bit set as above.  version selects the c-hash (V1: G,pk,H,nul,R,Hr; V2: nul,R,Hr). */
+int plume_sign_batch(plume_ctx* ctx, int version, size_t n,
+                     const uint8_t* msgs, const uint64_t* msg_off,
+                     const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,
+                     uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s,
+                     uint8_t* r_point, uint8_t* hashed_to_curve_r, uint8_t* status);
+
+/* ---- hash_to_curve(m, pk), batched  (rust-k256/src/utils.rs:11-20) ----------------------------------------
+ * h_out[i] = h2c(msg_i || SEC1c(pk_i)) with DST rust-k256/src/lib.rs:61.  pk == NULL hashes the raw message
+ * bytes (Secp256k1::hash_from_bytes(&[msg], &[DST]); rust-k256/tests/verification.rs:148-156) for KAT pinning. */
+int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n,
+                              const uint8_t* msgs, const uint64_t* msg_off,
+                              const uint8_t* pk, uint8_t* h_out);
+
+/* ---- device-resident forms -------------------------------------------------------------------------------
+ * Same semantics, but every data pointer is a DEVICE pointer on the context's GPU and the work is enqueued on
+ * `stream` (a hipStream_t passed as void*; NULL = the context's own stream) without synchronising: the caller
+ * orders and waits (e.g. torch.cuda streams/events).  msgs_bytes = msg_off[n] (total message bytes), needed
+ * because the offsets live on the device.  n must not exceed the chunk size (plume_set_chunk). */
+int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n,
+                              const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
+                              const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s,
+                              const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
+                              uint8_t* ok, void* stream);
+int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n,
+                            const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
+                            const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,
+                            uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s,
+                            uint8_t* r_point, uint8_t* hashed_to_curve_r, uint8_t* status, void* stream);
+int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n,
+                                     const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
+                                     const uint8_t* pk, uint8_t* h_out, void* stream);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------------------------
+ * Per-stage device time of the most recent *_device call on this context, measured with HIP events recorded on
+ * the stream the kernels were launched on.  Fills up to `cap` entries: names[i] (static strings) and ms[i];
+ * returns the number of stages, or a negative error.  Synchronises the recorded events. */
+int plume_last_stage_times(plume_ctx* ctx, const char** names, float* ms, int cap);
+/* Integer-VALU microbenchmark: runs `iters` dependent-chain-free v_mad_u64_u32 per lane on `waves_per_cu` waves
+ * per CU and returns the measured rate in multiply-adds per second (<= 0 on error). kind: 0 v_mad_u64_u32,
+ * 1 v_add_co/v_addc chain, 2 v_mul_lo_u32, 3 f64 fma. */
+double plume_microbench(plume_ctx* ctx, int kind, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLUME_HIP_H */

@@ -1,0 +1,253 @@
+"""GPU parity tests (run on the MI355X box: `pytest -m gpu`).  Everything goes through the C ABI of
+libplume_hip.so (zk_nullifier_sig_amd.Engine is a ctypes binding of include/plume_hip.h) and is compared
+bit-exactly with the oracles; nothing here reads /root/reference."""
+import json
+import random
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests import _oracle_c as OC
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "golden_batches.json").read_text())
+N_ORDER = synth.N
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import zk_nullifier_sig_amd as plume
+    e = plume.Engine(0)
+    yield e
+    e.close()
+
+
+def _verify_args(items, ver):
+    mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+    return (ver, mb, off, OC.arr(items, "pk", 64), OC.arr(items, "nullifier", 64), OC.arr(items, "c", 32), OC.arr(items, "s", 32),
+            OC.arr(items, "r_point", 64) if ver == 1 else None, OC.arr(items, "hashed_to_curve_r", 64) if ver == 1 else None)
+
+
+def test_native_library_is_loaded(eng):
+    """the product path is the HIP library, not a fallback"""
+    import zk_nullifier_sig_amd as plume
+    maps = Path("/proc/self/maps").read_text()
+    assert str(plume.library_path()) in maps
+    assert "gfx950" in eng.version()
+
+
+# ------------------------------------------------------------------------------------------ reference KATs
+def test_reference_fixed_vector_through_facade(eng, kats):
+    """BASELINE config 1 / rust-k256/tests/signing.rs:48-64 and verification.rs:25-107, on the GPU"""
+    import zk_nullifier_sig_amd as plume
+    v = kats["plume_vector"]
+
+    class Mock:  # rust-k256/tests/signing.rs:23-44
+        def fill_bytes(self, n):
+            assert n == 32
+            return bytes.fromhex(v["r"])
+
+    sk = plume.SecretKey.from_bytes(bytes.fromhex(v["sk"]))
+    msg = v["msg_utf8"].encode()
+    s1 = plume.PlumeSignature.sign_v1(sk, msg, Mock(), eng)
+    s2 = plume.PlumeSignature.sign_v2(sk, msg, Mock(), eng)
+    assert (s1.c.to_bytes().hex(), s1.s.to_bytes().hex()) == (v["c_v1"], v["s_v1"])
+    assert (s2.c.to_bytes().hex(), s2.s.to_bytes().hex()) == (v["c_v2"], v["s_v2"])
+    assert s1.v1specific is not None and s2.v1specific is None
+    for sg in (s1, s2):
+        assert sg.pk.to_bytes64().hex() == v["pk_x"] + v["pk_y"]
+        assert sg.nullifier.to_bytes64().hex() == v["nullifier_x"] + v["nullifier_y"]
+        assert sg.verify(eng)
+    assert s1.v1specific.r_point.to_bytes64().hex() == v["g_r_x"] + v["g_r_y"]
+    assert s1.v1specific.hashed_to_curve_r.to_bytes64().hex() == v["h_r_x"] + v["h_r_y"]
+    # arkworks shape (rust-arkworks/src/tests.rs:266-299)
+    for ver, c, s in ((plume.PlumeVersion.V1, v["c_v1"], v["s_v1"]), (plume.PlumeVersion.V2, v["c_v2"], v["s_v2"])):
+        pub, prv = plume.sign_with_r((s1.pk, sk.value), msg, int(v["r"], 16), ver, eng)
+        assert prv.digest_private == int(c, 16) and pub.s == int(s, 16)
+        assert pub.nullifier == s1.nullifier and prv.r_point == s1.v1specific.r_point
+    # tampered signature is rejected
+    bad = plume.PlumeSignature(msg, s1.pk, s1.nullifier, s1.c, plume.NonZeroScalar(s1.s.value ^ 1), s1.v1specific)
+    assert not bad.verify(eng)
+
+
+def test_h2c_kats(eng, kats):
+    v = kats["plume_vector"]
+    mb, off = OC.pack_msgs([v["msg_utf8"].encode()])
+    pk = np.frombuffer(bytes.fromhex(v["pk_x"] + v["pk_y"]), dtype=np.uint8).reshape(1, 64).copy()
+    assert eng.hash_to_curve_batch(mb, off, pk)[0].tobytes().hex() == v["h_x"] + v["h_y"]
+    raw = [b"", b"abc", bytes.fromhex(kats["h2c_preimage"]["preimage_hex"])]
+    mb, off = OC.pack_msgs(raw)
+    h = eng.hash_to_curve_batch(mb, off, None)
+    assert h[0].tobytes().hex() == kats["rfc9380_empty"]["p_x"] + kats["rfc9380_empty"]["p_y"]
+    assert h[1].tobytes().hex() == kats["h2c_abc"]["x"] + kats["h2c_abc"]["y"]
+    assert h[2].tobytes().hex() == kats["h2c_preimage"]["x"] + kats["h2c_preimage"]["y"]
+
+
+def test_sec1_kG_vectors_via_sign(eng, kats):
+    """k*G for k = 1..99 (rust-arkworks/src/tests/test_vectors.rs) through the sign path's pk = sk*G"""
+    vec = [v for v in kats["sec1_kG"]["vectors"] if v[0] > 0]
+    n = len(vec)
+    mb, off = OC.pack_msgs([b"m"] * n)
+    sk = np.frombuffer(b"".join(k.to_bytes(32, "big") for k, _, _ in vec), dtype=np.uint8).reshape(n, 32).copy()
+    o = eng.sign_batch(2, mb, off, sk, sk)
+    for i, (k, comp, uncomp) in enumerate(vec):
+        assert o["pk"][i].tobytes().hex() == uncomp[2:], k
+        assert o["r_point"][i].tobytes().hex() == uncomp[2:], k
+
+
+# ------------------------------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("ver", [1, 2])
+def test_golden_verify(eng, ver):
+    items = GOLD[f"verify_v{ver}"]
+    ok = eng.verify_batch(*_verify_args(items, ver))
+    assert list(ok) == [it["ok"] for it in items]
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_golden_edge_cases(eng, ver):
+    """ragged / empty messages, identity and off-curve points, non-canonical coordinates, zero and >= n scalars,
+    sk = 0 forgery the reference accepts, sk = 1 (pk = G), r = sk, sk = n-1"""
+    items = [e for e in GOLD["edge"] if e["version"] == ver]
+    ok = eng.verify_batch(*_verify_args(items, ver))
+    bad = [(it["note"], int(o), it["ok"]) for it, o in zip(items, ok) if int(o) != it["ok"]]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_golden_sign(eng, ver):
+    items = GOLD[f"sign_v{ver}"]
+    mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+    o = eng.sign_batch(ver, mb, off, OC.arr(items, "sk", 32), OC.arr(items, "r", 32))
+    for key, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]:
+        assert np.array_equal(o[key], OC.arr(items, key, w)), key
+    assert list(o["status"]) == [it["status"] for it in items]
+    h = eng.hash_to_curve_batch(mb, off, OC.arr(items, "pk", 64))
+    assert np.array_equal(h, OC.arr(items, "h", 64))
+    o2 = eng.sign_batch(ver, mb, off, OC.arr(items, "sk", 32), OC.arr(items, "r", 32), pk_in=OC.arr(items, "pk", 64))   # BASELINE config 5 shape
+    for k in o:
+        assert np.array_equal(o[k], o2[k]), k
+
+
+# ------------------------------------------------------------------------------------------ seeded parity vs the C oracle
+def test_sign_edge_status_vs_oracle(eng):
+    rng = random.Random(9)
+    sks = [0, N_ORDER, N_ORDER + 5, 1, N_ORDER - 1, 2**256 - 1, rng.randrange(1, N_ORDER), rng.randrange(1, N_ORDER)]
+    rs = [rng.randrange(1, N_ORDER), rng.randrange(1, N_ORDER), 0, N_ORDER - 1, 1, 7, N_ORDER, rng.randrange(1, N_ORDER)]
+    msgs = [bytes(rng.randrange(256) for _ in range(l)) for l in (0, 1, 32, 55, 56, 64, 100, 257)]
+    mb, off = OC.pack_msgs(msgs)
+    sk = np.frombuffer(b"".join(x.to_bytes(32, "big") for x in sks), dtype=np.uint8).reshape(-1, 32).copy()
+    r = np.frombuffer(b"".join(x.to_bytes(32, "big") for x in rs), dtype=np.uint8).reshape(-1, 32).copy()
+    for ver in (1, 2):
+        a = eng.sign_batch(ver, mb, off, sk, r)
+        b = OC.sign_batch(ver, mb, off, sk, r)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (ver, k)
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_ragged_batch_vs_oracle(eng, ver):
+    """1000 items, message lengths 0..200, non-multiple-of-wave batch size"""
+    rng = random.Random(100 + ver)
+    n = 1000
+    b = synth.sign_inputs(n, start=5000)
+    msgs = [bytes(rng.randrange(256) for _ in range(rng.randrange(0, 201))) for _ in range(n)]
+    mb, off = OC.pack_msgs(msgs)
+    got = eng.sign_batch(ver, mb, off, b["sk"], b["r"])
+    want = OC.sign_batch(ver, mb, off, b["sk"], b["r"], nthreads=16)
+    for k in got:
+        assert np.array_equal(got[k], want[k]), k
+    bb = dict(msgs=mb, off=off)
+    v = synth.corrupt_for_verify(ver, bb, got, start=5000)
+    ok = eng.verify_batch(ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
+    want_ok = OC.verify_batch(ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"), nthreads=16)
+    assert np.array_equal(ok, want_ok)
+    assert np.array_equal(ok, synth.expected_ok(n, 5000))
+
+
+def test_config2_verify_v1_2p16_bit_exact(eng):
+    """BASELINE config 2: batch 2^16 V1 verify, ok[] byte-identical to the CPU restatement over the whole batch"""
+    n = 1 << 16
+    b = synth.sign_inputs(n)
+    signed = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    v = synth.corrupt_for_verify(1, b, signed)
+    ok = eng.verify_batch(1, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"])
+    assert np.array_equal(ok, synth.expected_ok(n))
+    import os
+    want = OC.verify_batch(1, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"], nthreads=min(64, os.cpu_count() or 8))
+    assert np.array_equal(ok, want)
+    # and the first 256 are the committed Python-oracle fixture
+    items = GOLD["verify_v1"]
+    assert np.array_equal(v["pk"][:256], OC.arr(items, "pk", 64)) and np.array_equal(v["s"][:256], OC.arr(items, "s", 32))
+    assert list(ok[:256]) == [it["ok"] for it in items]
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("ver,logn", [(1, 20), (2, 20)])
+def test_full_size_properties(eng, ver, logn):
+    """BASELINE configs 3/4 sizes (2^20 per GPU): sign -> verify round trip, corruption pattern, idempotence,
+    a checksum of checksums across chunkings, and a seeded sample against the oracle"""
+    import hashlib
+    n = 1 << logn
+    b = synth.sign_inputs(n)
+    signed = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    assert not signed["status"].any()
+    v = synth.corrupt_for_verify(ver, b, signed)
+    args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
+    ok = eng.verify_batch(*args)
+    assert np.array_equal(ok, synth.expected_ok(n))
+    # idempotence + independence from the chunking of the batch
+    digest = hashlib.sha256(b"".join(signed[k].tobytes() for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r"))).hexdigest()
+    eng.set_chunk(300_000)
+    try:
+        signed2 = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+        ok2 = eng.verify_batch(*args)
+    finally:
+        eng.set_chunk(1 << 20)
+    assert hashlib.sha256(b"".join(signed2[k].tobytes() for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r"))).hexdigest() == digest
+    assert np.array_equal(ok, ok2)
+    # seeded sample vs the oracle (sign outputs and verify bits)
+    rng = np.random.default_rng(7 + ver)
+    idx = np.sort(rng.choice(n, size=2048, replace=False))
+    sub_msgs = np.concatenate([b["msgs"][32 * i:32 * i + 32] for i in idx] + [np.zeros(16, np.uint8)])
+    sub_off = np.arange(len(idx) + 1, dtype=np.uint64) * 32
+    want = OC.sign_batch(ver, sub_msgs, sub_off, b["sk"][idx], b["r"][idx], nthreads=16)
+    for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r", "status"):
+        assert np.array_equal(signed[k][idx], want[k]), k
+    sub_vmsgs = np.concatenate([v["msgs"][32 * i:32 * i + 32] for i in idx] + [np.zeros(16, np.uint8)])
+    want_ok = OC.verify_batch(ver, sub_vmsgs, sub_off, v["pk"][idx], v["nullifier"][idx], v["c"][idx], v["s"][idx],
+                              v["r_point"][idx] if ver == 1 else None, v["hashed_to_curve_r"][idx] if ver == 1 else None, nthreads=16)
+    assert np.array_equal(ok[idx], want_ok)
+
+
+def test_device_resident_api_matches_host_api(eng):
+    """the *_device entry points (inputs already in HBM, caller's stream) give the same bytes as the host-pointer ones"""
+    import torch
+    n = 5000
+    b = synth.sign_inputs(n, start=777)
+    host = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    msgs, off, sk, r = t(b["msgs"]), t(b["off"].view(np.int64)), t(b["sk"]), t(b["r"])
+    out = {k: torch.zeros((n, w), dtype=torch.uint8, device=dev) for k, w in
+           [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
+    status = torch.zeros(n, dtype=torch.uint8, device=dev)
+    eng.sign_batch_device(1, n, msgs, off, 32 * n, sk, r, None, out["pk"], out["nullifier"], out["c"], out["s"], out["r_point"], out["hashed_to_curve_r"], status)
+    torch.cuda.synchronize()
+    for k in out:
+        assert np.array_equal(out[k].cpu().numpy(), host[k]), k
+    ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    eng.verify_batch_device(1, n, msgs, off, 32 * n, out["pk"], out["nullifier"], out["c"], out["s"], out["r_point"], out["hashed_to_curve_r"], ok)
+    torch.cuda.synchronize()
+    assert bool(ok.all())
+    st = eng.last_stage_times()
+    assert [s for s, _ in st] == ["verify_ingest_h2c", "tables", "verify_msm", "verify_finalize"] and all(ms > 0 for _, ms in st)
+
+
+def test_empty_batch(eng):
+    mb, off = OC.pack_msgs([])
+    z = lambda w: np.zeros((0, w), dtype=np.uint8)  # noqa: E731
+    assert len(eng.verify_batch(2, mb, off, z(64), z(64), z(32), z(32))) == 0
+    assert len(eng.sign_batch(1, mb, off, z(32), z(32))["status"]) == 0

@@ -1,0 +1,205 @@
+"""ctypes binding of libplume_hip.so (include/plume_hip.h) — the only way this package computes anything.
+
+There is deliberately no fallback: if the shared library is missing, or no gfx950 GPU is visible, constructing
+an Engine raises PlumeHipError.  torch is used only as plumbing (device buffers / streams) by the *_device
+methods; the host-pointer methods need numpy only.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_u8p = C.POINTER(C.c_uint8)
+_u64p = C.POINTER(C.c_uint64)
+
+
+class PlumeHipError(RuntimeError):
+    pass
+
+
+def library_path() -> Path:
+    return _HERE / "libplume_hip.so"
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = library_path()
+    if not p.exists():
+        raise PlumeHipError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            f"(or `make -C zk-nullifier-sig_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(str(p))
+    lib.plume_last_error.restype = C.c_char_p
+    lib.plume_version.restype = C.c_char_p
+    lib.plume_microbench.restype = C.c_double
+    lib.plume_microbench.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.plume_init.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.plume_destroy.argtypes = [C.c_void_p]
+    lib.plume_set_chunk.argtypes = [C.c_void_p, C.c_size_t]
+    lib.plume_last_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    lib.plume_verify_batch.argtypes = [vp, i, sz] + [vp] * 9
+    lib.plume_sign_batch.argtypes = [vp, i, sz] + [vp] * 12
+    lib.plume_hash_to_curve_batch.argtypes = [vp, sz] + [vp] * 4
+    lib.plume_verify_batch_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 8
+    lib.plume_sign_batch_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 11
+    lib.plume_hash_to_curve_batch_device.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
+    return ["plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_verify_batch", "plume_sign_batch",
+            "plume_hash_to_curve_batch", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
+            "plume_last_stage_times", "plume_microbench"]
+
+
+def pack_messages(msgs):
+    """list of bytes -> (packed uint8 array, uint64 offsets[n+1])"""
+    off = np.zeros(len(msgs) + 1, dtype=np.uint64)
+    if len(msgs):
+        off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(msgs) + b"\0" * 16, dtype=np.uint8).copy()
+    return buf, off
+
+
+def _np(a, width, n, name):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.size != width * n:
+        raise ValueError(f"{name}: expected {n} records of {width} bytes, got {a.size} bytes")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One context on one GPU (include/plume_hip.h: plume_ctx).  One Engine per process rank / device."""
+
+    def __init__(self, device_id=None):
+        lib = _load()
+        if device_id is None:
+            device_id = int(os.environ.get("LOCAL_RANK", "0"))
+        self._lib = lib
+        self._ctx = C.c_void_p()
+        rc = lib.plume_init(C.byref(self._ctx), int(device_id))
+        if rc != 0:
+            self._ctx = None
+            raise PlumeHipError(f"plume_init(device {device_id}) failed ({rc}): {lib.plume_last_error().decode()}")
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.plume_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise PlumeHipError(f"{what} failed ({rc}): {self._lib.plume_last_error().decode()}")
+
+    def version(self):
+        return self._lib.plume_version().decode()
+
+    def set_chunk(self, n):
+        self._chk(self._lib.plume_set_chunk(self._ctx, int(n)), "plume_set_chunk")
+
+    # ------------------------------------------------------------------ host-pointer API (numpy in, numpy out)
+    def verify_batch(self, version, msgs, msg_off, pk, nullifier, c, s, r_point=None, hashed_to_curve_r=None):
+        n = len(msg_off) - 1
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
+        pk, nullifier, c, s = _np(pk, 64, n, "pk"), _np(nullifier, 64, n, "nullifier"), _np(c, 32, n, "c"), _np(s, 32, n, "s")
+        if version == 1:
+            if r_point is None or hashed_to_curve_r is None:
+                raise ValueError("V1 verification needs r_point and hashed_to_curve_r")
+            r_point, hashed_to_curve_r = _np(r_point, 64, n, "r_point"), _np(hashed_to_curve_r, 64, n, "hashed_to_curve_r")
+        else:
+            r_point = hashed_to_curve_r = None
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.plume_verify_batch(self._ctx, int(version), n, _ptr(msgs), _ptr(msg_off), _ptr(pk), _ptr(nullifier), _ptr(c), _ptr(s),
+                                               _ptr(r_point), _ptr(hashed_to_curve_r), _ptr(ok)), "plume_verify_batch")
+        return ok
+
+    def sign_batch(self, version, msgs, msg_off, sk, r, pk_in=None):
+        n = len(msg_off) - 1
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
+        sk, r = _np(sk, 32, n, "sk"), _np(r, 32, n, "r")
+        pk_in = None if pk_in is None else _np(pk_in, 64, n, "pk_in")
+        o = {k: np.zeros((n, w), dtype=np.uint8) for k, w in
+             [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
+        status = np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.plume_sign_batch(self._ctx, int(version), n, _ptr(msgs), _ptr(msg_off), _ptr(sk), _ptr(r), _ptr(pk_in), _ptr(o["pk"]),
+                                             _ptr(o["nullifier"]), _ptr(o["c"]), _ptr(o["s"]), _ptr(o["r_point"]), _ptr(o["hashed_to_curve_r"]),
+                                             _ptr(status)), "plume_sign_batch")
+        o["status"] = status
+        return o
+
+    def hash_to_curve_batch(self, msgs, msg_off, pk=None):
+        n = len(msg_off) - 1
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
+        pk = None if pk is None else _np(pk, 64, n, "pk")
+        h = np.zeros((n, 64), dtype=np.uint8)
+        self._chk(self._lib.plume_hash_to_curve_batch(self._ctx, n, _ptr(msgs), _ptr(msg_off), _ptr(pk), _ptr(h)), "plume_hash_to_curve_batch")
+        return h
+
+    # ------------------------------------------------------------------ device-resident API (torch uint8 tensors on this GPU)
+    @staticmethod
+    def _dp(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def verify_batch_device(self, version, n, msgs, msg_off, msgs_bytes, pk, nullifier, c, s, r_point, hashed_to_curve_r, ok, stream=None):
+        """all tensors on cuda:<device_id>; enqueues on `stream` (torch.cuda.Stream or None = current stream); does not synchronise"""
+        import torch
+        st = (stream or torch.cuda.current_stream(self.device_id)).cuda_stream
+        d = self._dp
+        self._chk(self._lib.plume_verify_batch_device(self._ctx, int(version), int(n), d(msgs), d(msg_off), int(msgs_bytes), d(pk), d(nullifier), d(c), d(s),
+                                                      d(r_point), d(hashed_to_curve_r), d(ok), C.c_void_p(st)), "plume_verify_batch_device")
+
+    def sign_batch_device(self, version, n, msgs, msg_off, msgs_bytes, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, stream=None):
+        import torch
+        st = (stream or torch.cuda.current_stream(self.device_id)).cuda_stream
+        d = self._dp
+        self._chk(self._lib.plume_sign_batch_device(self._ctx, int(version), int(n), d(msgs), d(msg_off), int(msgs_bytes), d(sk), d(r), d(pk_in), d(pk),
+                                                    d(nullifier), d(c), d(s), d(r_point), d(hashed_to_curve_r), d(status), C.c_void_p(st)),
+                  "plume_sign_batch_device")
+
+    # ------------------------------------------------------------------ measurement
+    def last_stage_times(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        k = self._lib.plume_last_stage_times(self._ctx, names, ms, 16)
+        if k < 0:
+            raise PlumeHipError(f"plume_last_stage_times failed ({k}): {self._lib.plume_last_error().decode()}")
+        return [(names[i].decode(), float(ms[i])) for i in range(k)]
+
+    def microbench(self, kind, iters=4096):
+        v = self._lib.plume_microbench(self._ctx, int(kind), int(iters))
+        if v <= 0:
+            raise PlumeHipError(f"plume_microbench failed: {self._lib.plume_last_error().decode()}")
+        return float(v)
+
+
+_default = None
+
+
+def default_engine() -> Engine:
+    global _default
+    if _default is None:
+        _default = Engine()
+    return _default

@@ -1,0 +1,360 @@
+// C ABI of libplume_hip.so (include/plume_hip.h): context, HBM workspace, chunked pipelines, stage timing.
+// Host code only; every computation on the data path is a gfx950 kernel from plume_kernels.hip.  There is no CPU
+// fallback of any kind in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/plume_hip.h"
+#include "plume_launch.h"
+
+using namespace plume;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e__ = (expr);                                                                                  \
+        if (e__ != hipSuccess) return fail(PLUME_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(PLUME_ERR_HIP, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct StageTimer {
+    std::vector<const char*> names;
+    std::vector<hipEvent_t> ev;   // ev[0] start, ev[i+1] after stage i
+    size_t used = 0;
+    void begin(hipStream_t st) { names.clear(); used = 0; mark(st); }
+    void mark(hipStream_t st) {
+        if (used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev.push_back(e); }
+        (void)hipEventRecord(ev[used++], st);
+    }
+    void stage(const char* name, hipStream_t st) { names.push_back(name); mark(st); }
+    void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); }
+};
+
+struct plume_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t chunk = (size_t)1 << 20;
+    int jobs_per_lane = kTableJobsPerLane;
+    DevBuf gtab, bases, jobflags, itemflags, tab, res, resinf, res2, res2inf, pkaff, sink;
+    DevBuf in_msgs, in_off, in_a, in_b, in_c, in_d, in_e, in_f, out_a, out_b, out_c, out_d, out_e, out_f, out_g;  // staging for the host-pointer API
+    StageTimer timer;
+};
+
+static int bind(plume_ctx* ctx) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(ctx->device));
+    return 0;
+}
+
+extern "C" const char* plume_last_error(void) { return g_err.c_str(); }
+extern "C" const char* plume_version(void) { return "plume_hip 0.1 gfx950"; }
+
+extern "C" int plume_init(plume_ctx** out, int device_id) {
+    if (!out || device_id < 0) return fail(PLUME_ERR_ARG, "plume_init: bad argument");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(PLUME_ERR_NODEV, "no HIP device visible (this library has no CPU fallback)");
+    if (device_id >= ndev) return fail(PLUME_ERR_ARG, "device id out of range");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PLUME_ERR_NODEV, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    plume_ctx* ctx = new plume_ctx();
+    ctx->device = device_id;
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    // generator window table: run the table kernel once on the single job {G}
+    if (ctx->gtab.ensure(PLUME_TAB_WORDS * 4) || ctx->bases.ensure(24 * 4) || ctx->jobflags.ensure(4)) { delete ctx; return PLUME_ERR_HIP; }
+    uint32_t hb[24];
+    {
+        jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
+        st_jac_soa(hb, 1, 0, g);
+    }
+    uint8_t flag = 0;
+    HIPCHK(hipMemcpyAsync(ctx->bases.p, hb, sizeof hb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->jobflags.p, &flag, 1, hipMemcpyHostToDevice, ctx->stream));
+    launch_tables(ctx->gtab.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), 1, 1, ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void plume_destroy(plume_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf* b : {&ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
+                      &ctx->sink, &ctx->in_msgs, &ctx->in_off, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->out_a, &ctx->out_b,
+                      &ctx->out_c, &ctx->out_d, &ctx->out_e, &ctx->out_f, &ctx->out_g})
+        b->release();
+    ctx->timer.destroy();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
+    if (!ctx || max_items == 0 || max_items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_chunk: bad argument");
+    ctx->chunk = max_items;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ device pipelines
+static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul,
+                         const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, hipStream_t st) {
+    if (n == 0) return 0;
+    if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    if (ctx->bases.ensure(24 * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
+        ctx->res.ensure(24 * 4 * 2 * n) || ctx->resinf.ensure(2 * n))
+        return PLUME_ERR_HIP;
+    VerifyArgs a;
+    a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok;
+    a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>(); a.itemflags = ctx->itemflags.as<uint8_t>();
+    a.tab = ctx->tab.as<uint32_t>(); a.res = ctx->res.as<uint32_t>(); a.resinf = ctx->resinf.as<uint8_t>(); a.gtab = ctx->gtab.as<uint32_t>();
+    StageTimer& t = ctx->timer;
+    t.begin(st);
+    launch_verify_ingest(a, st); t.stage("verify_ingest_h2c", st);
+    launch_tables(a.tab, a.bases, a.jobflags, 3 * n, ctx->jobs_per_lane, st); t.stage("tables", st);
+    launch_verify_msm(a, st); t.stage("verify_msm", st);
+    launch_verify_finalize(a, st); t.stage("verify_finalize", st);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
+                       const uint8_t* pk_in, uint8_t* pk, uint8_t* nul, uint8_t* c, uint8_t* s, uint8_t* rpt, uint8_t* hr, uint8_t* status, uint8_t* h_out,
+                       hipStream_t st) {
+    if (n == 0) return 0;
+    if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    if (ctx->bases.ensure(24 * 4 * n) || ctx->jobflags.ensure(n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * n) ||
+        ctx->res.ensure(24 * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->res2.ensure(24 * 4 * 2 * n) || ctx->res2inf.ensure(2 * n) || ctx->pkaff.ensure(16 * 4 * n))
+        return PLUME_ERR_HIP;
+    SignArgs a;
+    a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.sk = sk; a.r = r; a.pk_in = pk_in;
+    a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
+    a.gres = ctx->res.as<uint32_t>(); a.gresinf = ctx->resinf.as<uint8_t>(); a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>();
+    a.itemflags = ctx->itemflags.as<uint8_t>(); a.pkaff = ctx->pkaff.as<uint32_t>(); a.tab = ctx->tab.as<uint32_t>();
+    a.hres = ctx->res2.as<uint32_t>(); a.hresinf = ctx->res2inf.as<uint8_t>(); a.gtab = ctx->gtab.as<uint32_t>();
+    StageTimer& t = ctx->timer;
+    t.begin(st);
+    launch_sign_gmul(a, st); t.stage("sign_gmul", st);
+    launch_sign_h2c(a, st); t.stage("sign_h2c", st);
+    launch_tables(a.tab, a.bases, a.jobflags, n, ctx->jobs_per_lane, st); t.stage("tables", st);
+    launch_sign_hmul(a, st); t.stage("sign_hmul", st);
+    launch_sign_final(a, st); t.stage("sign_final", st);
+    // the reference zeroizes secrets: wipe the device-side images derived from sk / r
+    HIPCHK(hipMemsetAsync(ctx->res.p, 0, 24 * 4 * 2 * n, st));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int args_ok(int version, size_t n, const void* msgs, const void* off) {
+    if (version != 1 && version != 2) return fail(PLUME_ERR_ARG, "version must be 1 or 2");
+    if (n > 0 && (!msgs || !off)) return fail(PLUME_ERR_ARG, "null message buffers");
+    if (n > 0xFFFFFFF0u) return fail(PLUME_ERR_ARG, "n too large");
+    return 0;
+}
+
+extern "C" int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
+                                         const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point,
+                                         const uint8_t* hashed_to_curve_r, uint8_t* ok, void* stream) {
+    (void)msgs_bytes;
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
+    if (n && (!pk || !nullifier || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
+    if (n && version == 1 && (!r_point || !hashed_to_curve_r)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
+    return verify_device(ctx, version, n, msgs, msg_off, pk, nullifier, c, s, version == 1 ? r_point : nullptr, version == 1 ? hashed_to_curve_r : nullptr, ok,
+                         stream ? (hipStream_t)stream : ctx->stream);
+}
+
+extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
+                                       const uint8_t* r, const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point,
+                                       uint8_t* hashed_to_curve_r, uint8_t* status, void* stream) {
+    (void)msgs_bytes;
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
+    if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
+    return sign_device(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, nullptr,
+                       stream ? (hipStream_t)stream : ctx->stream);
+}
+
+extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
+                                                uint8_t* h_out, void* stream) {
+    (void)msgs_bytes;
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
+    if (n && !h_out) return fail(PLUME_ERR_ARG, "null array");
+    if (n == 0) return 0;
+    H2cArgs a; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.h_out = h_out;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->timer.begin(st);
+    launch_h2c_only(a, st); ctx->timer.stage("h2c_only", st);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- host-pointer pipelines
+// Chunked: each pass stages a slice of the SoA arrays into HBM, runs the device pipeline, and copies results back.
+static int stage_msgs(plume_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t i0, size_t cnt, std::vector<uint64_t>& rel) {
+    rel.resize(cnt + 1);
+    const uint64_t base = off[i0];
+    for (size_t k = 0; k <= cnt; k++) {
+        if (off[i0 + k] < base || (k && off[i0 + k] < off[i0 + k - 1])) return fail(PLUME_ERR_ARG, "msg_off is not non-decreasing");
+        rel[k] = off[i0 + k] - base;
+    }
+    if (rel[cnt] > 0xFFFFFF00ull) return fail(PLUME_ERR_ARG, "message bytes per pass exceed 4 GiB");
+    if (ctx->in_msgs.ensure((size_t)rel[cnt] + 16) || ctx->in_off.ensure((cnt + 1) * 8)) return PLUME_ERR_HIP;
+    if (rel[cnt]) HIPCHK(hipMemcpyAsync(ctx->in_msgs.p, msgs + base, (size_t)rel[cnt], hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->in_off.p, rel.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+static int h2d(plume_ctx* ctx, DevBuf& b, const uint8_t* src, size_t bytes) {
+    if (b.ensure(bytes)) return PLUME_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+static int d2h(plume_ctx* ctx, uint8_t* dst, const DevBuf& b, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+extern "C" int plume_verify_batch(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk,
+                                  const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
+                                  uint8_t* ok) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
+    if (n && (!pk || !nullifier || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
+    if (n && version == 1 && (!r_point || !hashed_to_curve_r)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
+    std::vector<uint64_t> rel;
+    for (size_t i0 = 0; i0 < n; i0 += ctx->chunk) {
+        const size_t cnt = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
+        if (int rc = stage_msgs(ctx, msgs, msg_off, i0, cnt, rel)) return rc;
+        if (int rc = h2d(ctx, ctx->in_a, pk + 64 * i0, 64 * cnt)) return rc;
+        if (int rc = h2d(ctx, ctx->in_b, nullifier + 64 * i0, 64 * cnt)) return rc;
+        if (int rc = h2d(ctx, ctx->in_c, c + 32 * i0, 32 * cnt)) return rc;
+        if (int rc = h2d(ctx, ctx->in_d, s + 32 * i0, 32 * cnt)) return rc;
+        if (version == 1) {
+            if (int rc = h2d(ctx, ctx->in_e, r_point + 64 * i0, 64 * cnt)) return rc;
+            if (int rc = h2d(ctx, ctx->in_f, hashed_to_curve_r + 64 * i0, 64 * cnt)) return rc;
+        }
+        if (ctx->out_a.ensure(cnt)) return PLUME_ERR_HIP;
+        if (int rc = verify_device(ctx, version, cnt, ctx->in_msgs.as<uint8_t>(), ctx->in_off.as<uint64_t>(), ctx->in_a.as<uint8_t>(), ctx->in_b.as<uint8_t>(),
+                                   ctx->in_c.as<uint8_t>(), ctx->in_d.as<uint8_t>(), version == 1 ? ctx->in_e.as<uint8_t>() : nullptr,
+                                   version == 1 ? ctx->in_f.as<uint8_t>() : nullptr, ctx->out_a.as<uint8_t>(), ctx->stream))
+            return rc;
+        if (int rc = d2h(ctx, ok + i0, ctx->out_a, cnt)) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+extern "C" int plume_sign_batch(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
+                                const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point, uint8_t* hashed_to_curve_r,
+                                uint8_t* status) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
+    if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
+    std::vector<uint64_t> rel;
+    for (size_t i0 = 0; i0 < n; i0 += ctx->chunk) {
+        const size_t cnt = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
+        if (int rc = stage_msgs(ctx, msgs, msg_off, i0, cnt, rel)) return rc;
+        if (int rc = h2d(ctx, ctx->in_a, sk + 32 * i0, 32 * cnt)) return rc;
+        if (int rc = h2d(ctx, ctx->in_b, r + 32 * i0, 32 * cnt)) return rc;
+        if (pk_in) { if (int rc = h2d(ctx, ctx->in_c, pk_in + 64 * i0, 64 * cnt)) return rc; }
+        if (ctx->out_a.ensure(64 * cnt) || ctx->out_b.ensure(64 * cnt) || ctx->out_c.ensure(32 * cnt) || ctx->out_d.ensure(32 * cnt) || ctx->out_e.ensure(64 * cnt) ||
+            ctx->out_f.ensure(64 * cnt) || ctx->out_g.ensure(cnt))
+            return PLUME_ERR_HIP;
+        if (int rc = sign_device(ctx, version, cnt, ctx->in_msgs.as<uint8_t>(), ctx->in_off.as<uint64_t>(), ctx->in_a.as<uint8_t>(), ctx->in_b.as<uint8_t>(),
+                                 pk_in ? ctx->in_c.as<uint8_t>() : nullptr, ctx->out_a.as<uint8_t>(), ctx->out_b.as<uint8_t>(), ctx->out_c.as<uint8_t>(),
+                                 ctx->out_d.as<uint8_t>(), ctx->out_e.as<uint8_t>(), ctx->out_f.as<uint8_t>(), ctx->out_g.as<uint8_t>(), nullptr, ctx->stream))
+            return rc;
+        if (pk) { if (int rc = d2h(ctx, pk + 64 * i0, ctx->out_a, 64 * cnt)) return rc; }
+        if (int rc = d2h(ctx, nullifier + 64 * i0, ctx->out_b, 64 * cnt)) return rc;
+        if (int rc = d2h(ctx, c + 32 * i0, ctx->out_c, 32 * cnt)) return rc;
+        if (int rc = d2h(ctx, s + 32 * i0, ctx->out_d, 32 * cnt)) return rc;
+        if (int rc = d2h(ctx, r_point + 64 * i0, ctx->out_e, 64 * cnt)) return rc;
+        if (int rc = d2h(ctx, hashed_to_curve_r + 64 * i0, ctx->out_f, 64 * cnt)) return rc;
+        if (int rc = d2h(ctx, status + i0, ctx->out_g, cnt)) return rc;
+        // wipe the staged secrets before the buffers are reused or freed
+        HIPCHK(hipMemsetAsync(ctx->in_a.p, 0, 32 * cnt, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->in_b.p, 0, 32 * cnt, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+extern "C" int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
+    if (n && !h_out) return fail(PLUME_ERR_ARG, "null array");
+    std::vector<uint64_t> rel;
+    for (size_t i0 = 0; i0 < n; i0 += ctx->chunk) {
+        const size_t cnt = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
+        if (int rc = stage_msgs(ctx, msgs, msg_off, i0, cnt, rel)) return rc;
+        if (pk) { if (int rc = h2d(ctx, ctx->in_a, pk + 64 * i0, 64 * cnt)) return rc; }
+        if (ctx->out_a.ensure(64 * cnt)) return PLUME_ERR_HIP;
+        if (int rc = plume_hash_to_curve_batch_device(ctx, cnt, ctx->in_msgs.as<uint8_t>(), ctx->in_off.as<uint64_t>(), (size_t)rel[cnt],
+                                                      pk ? ctx->in_a.as<uint8_t>() : nullptr, ctx->out_a.as<uint8_t>(), ctx->stream))
+            return rc;
+        if (int rc = d2h(ctx, h_out + 64 * i0, ctx->out_a, 64 * cnt)) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ measurement
+extern "C" int plume_last_stage_times(plume_ctx* ctx, const char** names, float* ms, int cap) {
+    if (int rc = bind(ctx)) return rc;
+    StageTimer& t = ctx->timer;
+    const int ns = (int)t.names.size();
+    if (t.used < (size_t)ns + 1) return fail(PLUME_ERR_ARG, "no timed call recorded");
+    for (int i = 0; i < ns && i < cap; i++) {
+        HIPCHK(hipEventSynchronize(t.ev[i + 1]));
+        float v = 0;
+        HIPCHK(hipEventElapsedTime(&v, t.ev[i], t.ev[i + 1]));
+        if (names) names[i] = t.names[i];
+        if (ms) ms[i] = v;
+    }
+    return ns;
+}
+
+extern "C" double plume_microbench(plume_ctx* ctx, int kind, int iters) {
+    if (bind(ctx)) return -1.0;
+    if (iters <= 0 || kind < 0 || kind > 6) { fail(PLUME_ERR_ARG, "plume_microbench: bad argument"); return -1.0; }
+    if (ctx->sink.ensure(64 * 4)) return -1.0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return -1.0;
+    const int blocks = prop.multiProcessorCount * 8;  // 32 waves per CU
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+    launch_microbench(kind, 16, ctx->sink.as<uint32_t>(), blocks, ctx->stream);  // warm-up
+    (void)hipEventRecord(e0, ctx->stream);
+    launch_microbench(kind, iters, ctx->sink.as<uint32_t>(), blocks, ctx->stream);
+    (void)hipEventRecord(e1, ctx->stream);
+    if (hipEventSynchronize(e1) != hipSuccess) return -1.0;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const double per_lane = kind <= 4 ? 8.0 * iters : 2.0 * iters;   // ops per lane
+    return per_lane * (double)blocks * kBlock / ((double)ms * 1e-3);
+}

@@ -13,10 +13,10 @@
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define PLUME_HD __host__ __device__ __forceinline__
-#define PLUME_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#define PLUME_HD_NOINLINE __host__ __device__ inline __attribute__((noinline))
 #else
 #define PLUME_HD inline
-#define PLUME_HD_NOINLINE inline
+#define PLUME_HD_NOINLINE inline __attribute__((noinline))
 #endif
 
 #if defined(__clang__)

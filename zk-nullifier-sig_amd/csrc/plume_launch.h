@@ -1,0 +1,23 @@
+// Host-visible launchers of the gfx950 kernels (defined in the k_*.hip translation units).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "plume_stages.h"
+
+namespace plume {
+
+constexpr int kBlock = 256;      // 4 wavefronts per workgroup
+constexpr int kTableJobsPerLane = 3;
+
+void launch_verify_ingest(const VerifyArgs& a, hipStream_t st);
+void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int jobs_per_lane, hipStream_t st);
+void launch_verify_msm(const VerifyArgs& a, hipStream_t st);
+void launch_verify_finalize(const VerifyArgs& a, hipStream_t st);
+void launch_sign_gmul(const SignArgs& a, hipStream_t st);
+void launch_sign_h2c(const SignArgs& a, hipStream_t st);
+void launch_sign_hmul(const SignArgs& a, hipStream_t st);
+void launch_sign_final(const SignArgs& a, hipStream_t st);
+void launch_h2c_only(const H2cArgs& a, hipStream_t st);
+void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st);
+
+}  // namespace plume
