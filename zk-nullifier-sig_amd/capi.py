@@ -34,6 +34,13 @@ def _load():
     if not p.exists():
         raise PlumeHipError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             f"(or `make -C zk-nullifier-sig_amd/csrc`). There is no CPU fallback.")
+    # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  Whichever copy is loaded first serves the
+    # whole process; loading ours first leaves torch without a usable device ("No HIP GPUs are available").  So if
+    # torch is installed, let it load its runtime first; the library itself has no torch dependency.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(str(p))
     lib.plume_last_error.restype = C.c_char_p
     lib.plume_version.restype = C.c_char_p

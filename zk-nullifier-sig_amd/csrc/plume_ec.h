@@ -125,16 +125,16 @@ PLUME_HD void glv_split(glv_half& h1, glv_half& h2, const sc& k) {
     uint32_t c;
     mul_limbs<8, 8>(t, k.v, g1);            // c1 = round(k*g1 / 2^384)
     c = t[11] >> 31;
-    PLUME_UNROLL for (int i = 0; i < 4; i++) c1[i] = addc(t[12 + i], 0u, c);
+    PLUME_UNROLL for (int i = 0; i < 4; i++) c1[i] = addc0(t[12 + i], c);
     mul_limbs<8, 8>(t, k.v, g2);            // c2 = round(k*g2 / 2^384)
     c = t[11] >> 31;
-    PLUME_UNROLL for (int i = 0; i < 4; i++) c2[i] = addc(t[12 + i], 0u, c);
+    PLUME_UNROLL for (int i = 0; i < 4; i++) c2[i] = addc0(t[12 + i], c);
     // k2 = c1*(-b1) + c2*(-b2)  (mod n)
     uint32_t p1[8], p2[12], w[16];
     mul_limbs<4, 4>(p1, c1, mb1);
     mul_limbs<4, 8>(p2, c2, mb2);
     c = 0;
-    PLUME_UNROLL for (int i = 0; i < 12; i++) w[i] = addc(p2[i], i < 8 ? p1[i] : 0u, c);
+    PLUME_UNROLL for (int i = 0; i < 12; i++) w[i] = addc(p2[i], i < 8 ? p1[i] : opaque_zero(), c);
     w[12] = c; w[13] = 0; w[14] = 0; w[15] = 0;
     sc k2, k1, tmp;
     sc_reduce_wide(k2, w);

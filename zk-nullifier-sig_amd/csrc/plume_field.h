@@ -56,6 +56,30 @@ PLUME_HD uint32_t subb(uint32_t a, uint32_t b, uint32_t& bw) {
 }
 PLUME_HD uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 
+// A zero the optimiser cannot see through.  ROCm 7.2's AMDGPU backend rewrites
+//     uaddo_carry(add(x, y), 0, cin)  ->  uaddo_carry(x, y, cin)        (and the usubo_carry/sub twin)
+// even when the carry-OUT is used; the merged instruction then also carries when the plain 32-bit add x + y
+// wraps (observed on gfx950: SHA-256's final `state += a` folded into the first limb of the next carry chain,
+// one spurious +1 in the following limb).  Every "propagate the carry through this limb" step therefore adds
+// this opaque zero instead of the literal 0, which keeps the pattern from matching.
+PLUME_HD uint32_t opaque_zero() {
+    uint32_t z = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(z));
+#endif
+    return z;
+}
+// Values produced by WRAPPING 32-bit arithmetic (SHA-256 state words) must pass through this before they enter a
+// carry chain, for the same reason: it hides the producing `add` from the combiner.
+PLUME_HD uint32_t opaque_u32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));
+#endif
+    return x;
+}
+PLUME_HD uint32_t addc0(uint32_t a, uint32_t& c) { return addc(a, opaque_zero(), c); }
+PLUME_HD uint32_t subb0(uint32_t a, uint32_t& bw) { return subb(a, opaque_zero(), bw); }
+
 // ------------------------------------------------------------------------------------------------------- Fp
 // Invariant: every fe is an arbitrary 256-bit integer v in [0, 2^256) standing for v mod p ("weakly reduced").
 // 2^256 = PC (mod p) with PC = 2^32 + 977, so a carry out of bit 256 folds back as +PC.  Values in [p, 2^256)
@@ -77,7 +101,7 @@ PLUME_HD void fe_fold_carry(fe& r, uint32_t c) {
     uint32_t k = 0;
     r.v[0] = addc(r.v[0], (0u - c) & PLUME_PC977, k);
     r.v[1] = addc(r.v[1], c, k);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, k);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc0(r.v[i], k);
     // wrapped again: now r < PC, so adding PC stays below 2^34
     uint32_t k2 = 0;
     r.v[0] = addc(r.v[0], (0u - k) & PLUME_PC977, k2);
@@ -95,7 +119,7 @@ PLUME_HD void fe_sub(fe& r, const fe& a, const fe& b) {
     uint32_t k = 0;
     r.v[0] = subb(r.v[0], (0u - bw) & PLUME_PC977, k);
     r.v[1] = subb(r.v[1], bw, k);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = subb(r.v[i], 0u, k);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = subb0(r.v[i], k);
     uint32_t k2 = 0;
     r.v[0] = subb(r.v[0], (0u - k) & PLUME_PC977, k2);
     r.v[1] = r.v[1] - k - k2;
@@ -109,7 +133,7 @@ PLUME_HD void fe_normalize(fe& a) {
     uint32_t c = 0;
     t.v[0] = addc(a.v[0], PLUME_PC977, c);
     t.v[1] = addc(a.v[1], 1u, c);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) t.v[i] = addc(a.v[i], 0u, c);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) t.v[i] = addc0(a.v[i], c);
     // carry <=> a + PC >= 2^256 <=> a >= p
     PLUME_UNROLL for (int i = 0; i < 8; i++) a.v[i] = c ? t.v[i] : a.v[i];
 }
@@ -127,7 +151,7 @@ PLUME_HD bool fe_is_canonical(const fe& a) {
     uint32_t c = 0;
     (void)addc(a.v[0], PLUME_PC977, c);
     (void)addc(a.v[1], 1u, c);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) (void)addc(a.v[i], 0u, c);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) (void)addc0(a.v[i], c);
     return c == 0;
 }
 
@@ -188,11 +212,11 @@ PLUME_HD void fe_reduce_wide(fe& r, const uint32_t t[16]) {
     uint32_t c = 0;
     r.v[0] = addc(u[0], (uint32_t)m, c);
     r.v[1] = addc(u[1], (uint32_t)(m >> 32), c);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc(u[i], 0u, c);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc0(u[i], c);
     uint32_t c2 = 0;
     r.v[1] = addc(r.v[1], u[8], c2);
     r.v[2] = addc(r.v[2], u[9], c2);
-    PLUME_UNROLL for (int i = 3; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c2);
+    PLUME_UNROLL for (int i = 3; i < 8; i++) r.v[i] = addc0(r.v[i], c2);
     fe_fold_carry(r, c + c2);  // at most one of the two chains can carry out (total < 2^256 + 2^67)
 }
 PLUME_HD void fe_mul(fe& r, const fe& a, const fe& b) {
@@ -217,10 +241,10 @@ PLUME_HD void fe_mul_small(fe& r, const fe& a, uint32_t k) {
     uint32_t c1 = 0;
     r.v[0] = addc(r.v[0], (uint32_t)m, c1);
     r.v[1] = addc(r.v[1], (uint32_t)(m >> 32), c1);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c1);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc0(r.v[i], c1);
     uint32_t c2 = 0;
     r.v[1] = addc(r.v[1], top, c2);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc(r.v[i], 0u, c2);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc0(r.v[i], c2);
     fe_fold_carry(r, c1 + c2);
 }
 PLUME_HD void fe_sqr_n(fe& r, const fe& a, int n) {
@@ -355,13 +379,13 @@ PLUME_HD void sc_reduce_wide(sc& r, const uint32_t t[16]) {
     uint32_t a[14], m[13];
     mul_limbs<8, 5>(m, t + 8, nc);
     uint32_t c = 0;
-    PLUME_UNROLL for (int i = 0; i < 13; i++) a[i] = addc(m[i], i < 8 ? t[i] : 0u, c);
+    PLUME_UNROLL for (int i = 0; i < 13; i++) a[i] = addc(m[i], i < 8 ? t[i] : opaque_zero(), c);
     a[13] = c;
     // round 2: b = a[0..8) + a[8..14)*NC -> 6+5 = 11 limbs (value < 2^(130+129)) + lo
     uint32_t m2[11], b[12];
     mul_limbs<6, 5>(m2, a + 8, nc);
     c = 0;
-    PLUME_UNROLL for (int i = 0; i < 11; i++) b[i] = addc(m2[i], i < 8 ? a[i] : 0u, c);
+    PLUME_UNROLL for (int i = 0; i < 11; i++) b[i] = addc(m2[i], i < 8 ? a[i] : opaque_zero(), c);
     b[11] = c;
     // round 3: d = b[0..8) + b[8..12)*NC: b[8..] < 2^4 so the product < 2^133
     uint32_t m3[9], d[9];
@@ -371,7 +395,7 @@ PLUME_HD void sc_reduce_wide(sc& r, const uint32_t t[16]) {
     d[8] = m3[8] + c;  // 0 or 1
     // d < 2^256 + 2^133: if d[8] then d - 2^256 + NC (< 2^134, no further carry)
     uint32_t c4 = 0;
-    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = addc(d[i], d[8] ? sc_nc(i) : 0u, c4);
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = addc(d[i], d[8] ? sc_nc(i) : opaque_zero(), c4);
     sc_cond_sub_n(r);
     sc_cond_sub_n(r);
 }
@@ -383,7 +407,7 @@ PLUME_HD void sc_mul(sc& r, const sc& a, const sc& b) {
 // digest (32 bytes BE) -> scalar mod n; *canonical = digest in [1, n-1]  (Scalar::reduce, rust-k256/src/lib.rs:128;
 // NonZeroScalar::from_repr, randomizedsigner.rs:90)
 PLUME_HD void sc_from_digest_words(sc& r, const uint32_t h[8], bool& canonical) {
-    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = h[7 - i];
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = opaque_u32(h[7 - i]);
     canonical = sc_lt_n(r) && !sc_is_zero(r);
     sc_cond_sub_n(r);  // digest < 2^256 < 2n
 }

@@ -56,7 +56,7 @@ PLUME_HD void xmd_bi(uint32_t out[8], const uint32_t x[8], uint32_t idx) {
 // hash_to_field: two field elements from 96 uniform bytes, each OS2IP(48 B) mod p (mod.rs:32-50)
 PLUME_HD void fe_from_be48_words(fe& r, const uint32_t* w /* 12 big-endian words, most significant first */) {
     uint32_t t[16];
-    PLUME_UNROLL for (int i = 0; i < 12; i++) t[i] = w[11 - i];
+    PLUME_UNROLL for (int i = 0; i < 12; i++) t[i] = opaque_u32(w[11 - i]);   // SHA words: see opaque_zero() in plume_field.h
     PLUME_UNROLL for (int i = 12; i < 16; i++) t[i] = 0;
     fe_reduce_wide(r, t);
 }
