@@ -176,11 +176,13 @@ def main():
                 add_rate = eng.microbench(4, 4096)
                 fpmul_rate = eng.microbench(5, 512)
                 fpsqr_rate = eng.microbench(6, 512)
+                other = {name: round(eng.microbench(k, 4096), 1) for k, name in
+                         ((1, "v_addc_co_u32"), (2, "v_mul_lo_u32"), (3, "v_mad_u32_u24"), (7, "v_fma_f64"), (8, "v_lshl_add_u64"))}
                 step_s = sum(stages.values()) * 1e-3
                 whole = FPMUL_PER_ITEM[ver] * MACS_PER_FPMUL * n / step_s
                 msm = FPMUL_MSM_PER_ITEM * MACS_PER_FPMUL * n / (stages.get("verify_msm", step_s * 1e3) * 1e-3)
                 line["valu_roofline"] = {"bound": "int-valu", "unit": "32-bit MAC/s", "peak_v_mad_u64_u32": round(mad_rate, 1), "peak_v_add_u32": round(add_rate, 1),
-                                         "fp_mul_per_s": round(fpmul_rate, 1), "fp_sqr_per_s": round(fpsqr_rate, 1),
+                                         "fp_mul_per_s": round(fpmul_rate, 1), "fp_sqr_per_s": round(fpsqr_rate, 1), "other_issue_rates_per_s": other,
                                          "achieved_whole_path": round(whole, 1), "frac_whole_path": round(whole / mad_rate, 4),
                                          "achieved_msm_kernel": round(msm, 1), "frac_msm_kernel": round(msm / mad_rate, 4),
                                          "accounting": "5460 Fp-mult/verify x 72 MACs (SURVEY.md §8d, frozen in BASELINE.md §4)"}

@@ -106,10 +106,12 @@ int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n,
  * the stream the kernels were launched on.  Fills up to `cap` entries: names[i] (static strings) and ms[i];
  * returns the number of stages, or a negative error.  Synchronises the recorded events. */
 int plume_last_stage_times(plume_ctx* ctx, const char** names, float* ms, int cap);
-/* Integer-VALU microbenchmark: runs `iters` dependent-chain-free v_mad_u64_u32 per lane on `waves_per_cu` waves
- * per CU and returns the measured rate in multiply-adds per second (<= 0 on error). kind: 0 v_mad_u64_u32,
- * 1 v_add_co/v_addc chain, 2 v_mul_lo_u32, 3 f64 fma. */
+/* VALU issue-rate microbenchmark (32 waves per CU, 8 independent chains per lane, `iters` x 8 instructions per lane):
+ * returns operations per second chip-wide (<= 0 on error).  kind: 0 v_mad_u64_u32, 1 v_addc_co_u32, 2 v_mul_lo_u32,
+ * 3 v_mad_u32_u24, 4 v_add_u32, 5 one Fp multiplication, 6 one Fp squaring, 7 v_fma_f64, 8 v_lshl_add_u64. */
 double plume_microbench(plume_ctx* ctx, int kind, int iters);
+/* s_memtime ticks that workgroup 0 spent inside the last microbenchmark kernel (and its event duration in ms). */
+double plume_microbench_last_ticks(float* ms);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,8 @@ def _load():
     lib.plume_version.restype = C.c_char_p
     lib.plume_microbench.restype = C.c_double
     lib.plume_microbench.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.plume_microbench_last_ticks.restype = C.c_double
+    lib.plume_microbench_last_ticks.argtypes = [C.POINTER(C.c_float)]
     lib.plume_init.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     lib.plume_destroy.argtypes = [C.c_void_p]
     lib.plume_set_chunk.argtypes = [C.c_void_p, C.c_size_t]
@@ -65,7 +67,7 @@ def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
     return ["plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_verify_batch", "plume_sign_batch",
             "plume_hash_to_curve_batch", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
-            "plume_last_stage_times", "plume_microbench"]
+            "plume_last_stage_times", "plume_microbench", "plume_microbench_last_ticks"]
 
 
 def pack_messages(msgs):
@@ -200,6 +202,11 @@ class Engine:
         if v <= 0:
             raise PlumeHipError(f"plume_microbench failed: {self._lib.plume_last_error().decode()}")
         return float(v)
+
+    def microbench_ticks(self):
+        ms = C.c_float()
+        t = self._lib.plume_microbench_last_ticks(C.byref(ms))
+        return float(t), float(ms.value)
 
 
 _default = None

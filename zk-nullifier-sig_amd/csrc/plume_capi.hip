@@ -338,10 +338,15 @@ extern "C" int plume_last_stage_times(plume_ctx* ctx, const char** names, float*
     return ns;
 }
 
+static thread_local uint64_t g_microbench_cycles = 0;
+static thread_local float g_microbench_ms = 0;
+// s_memtime ticks spent by wave 0 in the last microbenchmark kernel, and that kernel's duration in ms
+extern "C" double plume_microbench_last_ticks(float* ms) { if (ms) *ms = g_microbench_ms; return (double)g_microbench_cycles; }
+
 extern "C" double plume_microbench(plume_ctx* ctx, int kind, int iters) {
     if (bind(ctx)) return -1.0;
-    if (iters <= 0 || kind < 0 || kind > 6) { fail(PLUME_ERR_ARG, "plume_microbench: bad argument"); return -1.0; }
-    if (ctx->sink.ensure(64 * 4)) return -1.0;
+    if (iters <= 0 || kind < 0 || kind > 8) { fail(PLUME_ERR_ARG, "plume_microbench: bad argument"); return -1.0; }
+    if (ctx->sink.ensure(128 * 4)) return -1.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return -1.0;
     const int blocks = prop.multiProcessorCount * 8;  // 32 waves per CU
@@ -355,6 +360,10 @@ extern "C" double plume_microbench(plume_ctx* ctx, int kind, int iters) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    const double per_lane = kind <= 4 ? 8.0 * iters : 2.0 * iters;   // ops per lane
+    const double per_lane = (kind == 5 || kind == 6) ? 2.0 * iters : 8.0 * iters;   // ops per lane
+    uint32_t cyc[2] = {0, 0};
+    if (hipMemcpy(cyc, ctx->sink.as<uint32_t>() + 64, 8, hipMemcpyDeviceToHost) == hipSuccess)
+        g_microbench_cycles = ((uint64_t)cyc[1] << 32) | cyc[0];
+    g_microbench_ms = ms;
     return per_lane * (double)blocks * kBlock / ((double)ms * 1e-3);
 }

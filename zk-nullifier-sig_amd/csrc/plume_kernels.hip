@@ -83,62 +83,56 @@ __global__ __launch_bounds__(kBlock) void k_h2c_only(H2cArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ microbenchmarks
-// 8 independent accumulator chains per lane so the measured figure is issue throughput, not latency.
+// Issue-rate probes for the roofline: 8 independent accumulator chains per lane, written in inline asm so that the
+// instruction under test is exactly what is counted (VALU->VALU dependencies are interlocked in hardware; the
+// hazard probe in tests/gpu_debug/hazard_probe.hip shows no software wait states are needed for these).
+// 32 instructions per loop trip (4 x 8 chains), one loop per kind so no branch sits inside a timed loop.
+#define PLUME_R4(X) X X X X
+#define PLUME_MB_LOOP32(ASM8, CTYPE, ...)                                                                          \
+    for (int it = 0; it < iters; it += 4) {                                                                       \
+        asm volatile(PLUME_R4(ASM8) : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : __VA_ARGS__ : "vcc"); \
+    }
 __global__ __launch_bounds__(kBlock) void k_microbench(int kind, int iters, uint32_t* sink) {
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t a = tid * 2654435761u + 12345u, b = tid ^ 0x9E3779B9u;
+    uint32_t a = tid * 2654435761u + 12345u, b = (tid ^ 0x9E3779B9u) | 1u;
     uint32_t out = 0;
-    if (kind == 0) {         // v_mad_u64_u32
-        uint64_t acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = tid + j;
-        for (int it = 0; it < iters; it++) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) acc[j] = (uint64_t)(uint32_t)(a + j) * (uint32_t)(acc[j] >> 7 | 1u) + acc[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) out ^= (uint32_t)acc[j] ^ (uint32_t)(acc[j] >> 32);
-    } else if (kind == 1) {  // v_add_co_u32 / v_addc_co_u32 pairs (64-bit add through the carry chain)
-        uint32_t lo[8], hi[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { lo[j] = a + j; hi[j] = b + j; }
-        for (int it = 0; it < iters; it++) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) { uint32_t c = 0; lo[j] = addc(lo[j], a, c); hi[j] = addc(hi[j], b, c); }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) out ^= lo[j] ^ hi[j];
+    const uint64_t t_begin = __builtin_readcyclecounter();
+    if (kind == 0) {         // v_mad_u64_u32 (32x32+64 -> 64): the multiply-add the field arithmetic is made of
+        uint64_t c0 = tid, c1 = tid + 1, c2 = tid + 2, c3 = tid + 3, c4 = tid + 4, c5 = tid + 5, c6 = tid + 6, c7 = tid + 7;
+        PLUME_MB_LOOP32("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\tv_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_mad_u64_u32 %3, vcc, %8, %9, %3\n\t"
+                        "v_mad_u64_u32 %4, vcc, %8, %9, %4\n\tv_mad_u64_u32 %5, vcc, %8, %9, %5\n\tv_mad_u64_u32 %6, vcc, %8, %9, %6\n\tv_mad_u64_u32 %7, vcc, %8, %9, %7\n\t", uint64_t, "v"(a), "v"(b))
+        out = (uint32_t)(c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7) ^ (uint32_t)((c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7) >> 32);
+    } else if (kind == 1) {  // v_addc_co_u32 (carry chain step)
+        uint32_t c0 = tid, c1 = tid + 1, c2 = tid + 2, c3 = tid + 3, c4 = tid + 4, c5 = tid + 5, c6 = tid + 6, c7 = tid + 7;
+        PLUME_MB_LOOP32("v_addc_co_u32 %0, vcc, %8, %0, vcc\n\tv_addc_co_u32 %1, vcc, %8, %1, vcc\n\tv_addc_co_u32 %2, vcc, %8, %2, vcc\n\tv_addc_co_u32 %3, vcc, %8, %3, vcc\n\t"
+                        "v_addc_co_u32 %4, vcc, %8, %4, vcc\n\tv_addc_co_u32 %5, vcc, %8, %5, vcc\n\tv_addc_co_u32 %6, vcc, %8, %6, vcc\n\tv_addc_co_u32 %7, vcc, %8, %7, vcc\n\t", uint32_t, "v"(a), "v"(b))
+        out = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
     } else if (kind == 2) {  // v_mul_lo_u32
-        uint32_t acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = a + j;
-        for (int it = 0; it < iters; it++) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) acc[j] = acc[j] * (b | 1u);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) out ^= acc[j];
-    } else if (kind == 3) {  // v_fma_f64
-        double acc[8];
+        uint32_t c0 = tid, c1 = tid + 1, c2 = tid + 2, c3 = tid + 3, c4 = tid + 4, c5 = tid + 5, c6 = tid + 6, c7 = tid + 7;
+        PLUME_MB_LOOP32("v_mul_lo_u32 %0, %8, %0\n\tv_mul_lo_u32 %1, %8, %1\n\tv_mul_lo_u32 %2, %8, %2\n\tv_mul_lo_u32 %3, %8, %3\n\t"
+                        "v_mul_lo_u32 %4, %8, %4\n\tv_mul_lo_u32 %5, %8, %5\n\tv_mul_lo_u32 %6, %8, %6\n\tv_mul_lo_u32 %7, %8, %7\n\t", uint32_t, "v"(b), "v"(a))
+        out = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+    } else if (kind == 3) {  // v_mad_u32_u24 (24x24+32 -> 32)
+        uint32_t c0 = tid, c1 = tid + 1, c2 = tid + 2, c3 = tid + 3, c4 = tid + 4, c5 = tid + 5, c6 = tid + 6, c7 = tid + 7;
+        PLUME_MB_LOOP32("v_mad_u32_u24 %0, %8, %9, %0\n\tv_mad_u32_u24 %1, %8, %9, %1\n\tv_mad_u32_u24 %2, %8, %9, %2\n\tv_mad_u32_u24 %3, %8, %9, %3\n\t"
+                        "v_mad_u32_u24 %4, %8, %9, %4\n\tv_mad_u32_u24 %5, %8, %9, %5\n\tv_mad_u32_u24 %6, %8, %9, %6\n\tv_mad_u32_u24 %7, %8, %9, %7\n\t", uint32_t, "v"(a), "v"(b))
+        out = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+    } else if (kind == 4) {  // v_add_u32 (plain VALU reference)
+        uint32_t c0 = tid, c1 = tid + 1, c2 = tid + 2, c3 = tid + 3, c4 = tid + 4, c5 = tid + 5, c6 = tid + 6, c7 = tid + 7;
+        PLUME_MB_LOOP32("v_add_u32 %0, %8, %0\n\tv_add_u32 %1, %8, %1\n\tv_add_u32 %2, %8, %2\n\tv_add_u32 %3, %8, %3\n\t"
+                        "v_add_u32 %4, %8, %4\n\tv_add_u32 %5, %8, %5\n\tv_add_u32 %6, %8, %6\n\tv_add_u32 %7, %8, %7\n\t", uint32_t, "v"(a), "v"(b))
+        out = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+    } else if (kind == 7) {  // v_fma_f64
+        double c0 = tid, c1 = tid + 1, c2 = tid + 2, c3 = tid + 3, c4 = tid + 4, c5 = tid + 5, c6 = tid + 6, c7 = tid + 7;
         const double m = 1.0 + (double)(a & 0xFF) * 1e-9, c = (double)(b & 0xFF) * 1e-9;
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = (double)j;
-        for (int it = 0; it < iters; it++) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) acc[j] = __builtin_fma(acc[j], m, c);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) out ^= (uint32_t)(long long)acc[j];
-    } else if (kind == 4) {  // v_add_u32 (plain full-rate VALU reference)
-        uint32_t acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = a + j;
-        for (int it = 0; it < iters; it++) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) acc[j] = (acc[j] + b) ^ a;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) out ^= acc[j];
+        PLUME_MB_LOOP32("v_fma_f64 %0, %0, %8, %9\n\tv_fma_f64 %1, %1, %8, %9\n\tv_fma_f64 %2, %2, %8, %9\n\tv_fma_f64 %3, %3, %8, %9\n\t"
+                        "v_fma_f64 %4, %4, %8, %9\n\tv_fma_f64 %5, %5, %8, %9\n\tv_fma_f64 %6, %6, %8, %9\n\tv_fma_f64 %7, %7, %8, %9\n\t", double, "v"(m), "v"(c))
+        out = (uint32_t)(long long)(c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7);
+    } else if (kind == 8) {  // v_lshl_add_u64 (64-bit add in one instruction)
+        uint64_t c0 = tid, c1 = tid + 1, c2 = tid + 2, c3 = tid + 3, c4 = tid + 4, c5 = tid + 5, c6 = tid + 6, c7 = tid + 7, e = ((uint64_t)a << 32) | b;
+        PLUME_MB_LOOP32("v_lshl_add_u64 %0, %0, 0, %8\n\tv_lshl_add_u64 %1, %1, 0, %8\n\tv_lshl_add_u64 %2, %2, 0, %8\n\tv_lshl_add_u64 %3, %3, 0, %8\n\t"
+                        "v_lshl_add_u64 %4, %4, 0, %8\n\tv_lshl_add_u64 %5, %5, 0, %8\n\tv_lshl_add_u64 %6, %6, 0, %8\n\tv_lshl_add_u64 %7, %7, 0, %8\n\t", uint64_t, "v"(e), "v"(a))
+        out = (uint32_t)(c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7);
     } else if (kind == 5) {  // one Fp multiplication (the unit of the roofline accounting), 2 independent chains
         fe x, y, z, w;
 #pragma unroll
@@ -146,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_microbench(int kind, int iters, uint
         for (int it = 0; it < iters; it++) { fe_mul(x, x, y); fe_mul(z, z, w); }
 #pragma unroll
         for (int j = 0; j < 8; j++) out ^= x.v[j] ^ z.v[j];
-    } else {                 // one Fp squaring
+    } else {                 // 6: one Fp squaring
         fe x, z;
 #pragma unroll
         for (int j = 0; j < 8; j++) { x.v[j] = a + j; z.v[j] = b + j; }
@@ -154,6 +148,8 @@ __global__ __launch_bounds__(kBlock) void k_microbench(int kind, int iters, uint
 #pragma unroll
         for (int j = 0; j < 8; j++) out ^= x.v[j] ^ z.v[j];
     }
+    const uint64_t t_end = __builtin_readcyclecounter();
+    if (tid == 0) { sink[64] = (uint32_t)(t_end - t_begin); sink[65] = (uint32_t)((t_end - t_begin) >> 32); }
     if (out == 0x12345678u) sink[tid & 63] = out;  // keep the chains live without measurable traffic
 }
 
