@@ -71,12 +71,12 @@ void ds_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
 }
 
 static void build_gtab(std::vector<uint32_t>& gtab) {
-    gtab.assign(PLUME_TAB_WORDS, 0);
+    gtab.assign(PLUME_GTAB8_WORDS, 0);
     std::vector<uint32_t> bases(24, 0);
     jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
     st_jac_soa(bases.data(), 1, 0, g);
-    uint8_t flag = 0;
-    table_build(gtab.data(), bases.data(), &flag, 1, 0, 1);
+    uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
+    table_build<PLUME_GTAB8_ENTRIES>(gtab.data(), bases.data(), &flag, 1, 0, 1);
 }
 
 // simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)

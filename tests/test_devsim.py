@@ -184,3 +184,21 @@ def test_sign_edge_status():
         b = OC.sign_batch(ver, mb, off, sk, r)
         for k in a:
             assert np.array_equal(a[k], b[k]), (ver, k)
+
+
+def test_wide_generator_digits_special_scalars():
+    """fixed-base path (w = 8 Booth digits, magnitudes up to 128, sign bytes): pk = sk*G and R = r*G for scalars that hit
+    the digit extremes, against the C oracle"""
+    rng = random.Random(21)
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    ks = [1, 2, 127, 128, 129, 255, 256, 257, 0x8080, 0x7F7F, 0x80808080, 2**64 - 1, 2**127, 2**127 - 1, 2**127 + 1, 2**128 - 1, 2**128,
+          lam, lam - 1, (128 * lam) % N, (N - 128) % N, N - 1, N - 2, (0x80 << 120), int("80" * 16, 16), int("7f" * 16, 16), int("ff" * 16, 16)]
+    ks += [rng.randrange(1, N) for _ in range(37)]
+    n = len(ks)
+    mb, off = OC.pack_msgs([b"w"] * n)
+    sk = np.frombuffer(b"".join(k.to_bytes(32, "big") for k in ks), dtype=np.uint8).reshape(n, 32).copy()
+    r = np.frombuffer(b"".join(k.to_bytes(32, "big") for k in reversed(ks)), dtype=np.uint8).reshape(n, 32).copy()
+    a = D.sign_batch(2, mb, off, sk, r)
+    b = OC.sign_batch(2, mb, off, sk, r, nthreads=8)
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -81,19 +82,20 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
         return fail(PLUME_ERR_NODEV, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     plume_ctx* ctx = new plume_ctx();
     ctx->device = device_id;
+    if (const char* e = std::getenv("PLUME_JOBS_PER_LANE")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->jobs_per_lane = v; }   // tuning knob
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    // generator window table: run the table kernel once on the single job {G}
-    if (ctx->gtab.ensure(PLUME_TAB_WORDS * 4) || ctx->bases.ensure(24 * 4) || ctx->jobflags.ensure(4)) { delete ctx; return PLUME_ERR_HIP; }
+    // generator wide window table (1..128)*G: one lane, once
+    if (ctx->gtab.ensure(PLUME_GTAB8_WORDS * 4) || ctx->bases.ensure(24 * 4) || ctx->jobflags.ensure(4)) { delete ctx; return PLUME_ERR_HIP; }
     uint32_t hb[24];
     {
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
         st_jac_soa(hb, 1, 0, g);
     }
-    uint8_t flag = 0;
+    uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
     HIPCHK(hipMemcpyAsync(ctx->bases.p, hb, sizeof hb, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->jobflags.p, &flag, 1, hipMemcpyHostToDevice, ctx->stream));
-    launch_tables(ctx->gtab.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), 1, 1, ctx->stream);
+    launch_gtab8(ctx->gtab.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = ctx;

@@ -164,6 +164,32 @@ PLUME_HD int booth_digit(const uint32_t m[4], int i) {
     }
     return (int)(u & 1) + (int)((u >> 1) & 7) - (int)((u >> 4) << 3);
 }
+// Booth recoding, w = 8 (fixed-base slots): m = sum d_k 256^k, d_k in [-128, 128], k = 0..16
+#define PLUME_NDIG8 17
+PLUME_HD int booth_digit8(const uint32_t m[4], int k) {
+    int lo = 8 * k - 1;
+    uint32_t u;
+    if (lo < 0) {
+        u = (m[0] << 1) & 0x1FF;
+    } else {
+        int wi = lo >> 5, sh = lo & 31;
+        uint32_t a = wi < 4 ? m[wi] : 0u, b = (wi + 1) < 4 ? m[wi + 1] : 0u;
+        u = ((a >> sh) | (sh > 23 ? (b << (32 - sh)) : 0u)) & 0x1FF;
+    }
+    return (int)(u & 1) + (int)((u >> 1) & 127) - (int)((u >> 8) << 7);
+}
+// wide (w = 8) digits share the 33-slot digit row of a half-scalar: magnitude (0..128) at position 2k, sign at 2k+1
+PLUME_HD void booth_store_wide(int8_t* dig, uint32_t stride, const glv_half& h, bool flip) {
+    bool neg = (h.neg != 0) != flip;
+    PLUME_UNROLL for (int k = 0; k < PLUME_NDIG8; k++) {
+        int d = booth_digit8(h.m, k);
+        bool dn = (d < 0) != neg;
+        int mag = d < 0 ? -d : d;
+        dig[(uint32_t)(2 * k) * stride] = (int8_t)(uint8_t)mag;
+        if (k < PLUME_NDIG8 - 1) dig[(uint32_t)(2 * k + 1) * stride] = (int8_t)(dn ? 1 : 0);
+        else if (mag != 0 && dn) dig[(uint32_t)(2 * k) * stride] = (int8_t)(uint8_t)(mag | 0x40);  // top digit is 0 or 1: keep its sign in bit 6
+    }
+}
 // writes the 33 signed digits of one half-scalar to dig[i*stride], sign applied
 PLUME_HD void booth_store(int8_t* dig, uint32_t stride, const glv_half& h, bool flip) {
     bool neg = (h.neg != 0) != flip;
@@ -193,13 +219,22 @@ PLUME_HD void st_jac_soa(uint32_t* base, size_t stride, size_t j, const jac& p) 
     st_fe_soa(base, stride, j, p.x); st_fe_soa(base + 8 * stride, stride, j, p.y); st_fe_soa(base + 16 * stride, stride, j, p.z);
 }
 
+#ifndef PLUME_TABLE_MADD
+#define PLUME_TABLE_MADD 0   // 1: mixed additions for Z = 1 bases in table_build (more code in the loop body)
+#endif
 #define PLUME_JOB_OK 0u
 #define PLUME_JOB_INF 1u      // base is the identity: its slots are skipped
 #define PLUME_JOB_INVALID 2u  // base failed validation: a dummy (G) table is built, the item is rejected elsewhere
+#define PLUME_JOB_AFFINE 0x80u  // OR-ed in: the base has Z = 1, its chain uses mixed additions
+PLUME_HD uint32_t job_state(uint8_t f) { return f & 3u; }
+// the generator's wide table for fixed-base slots: 128 entries (1..128)*G, same entry format
+#define PLUME_GTAB8_ENTRIES 128
+#define PLUME_GTAB8_WORDS (PLUME_GTAB8_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 
 // Build the tables of jobs [j0, j0+cnt) (cnt <= L, one lane).  Bases are Jacobian SoA (stride = njobs).
 // Pass 1 writes (X_k, Y_k, Z_k, running product before Z_k) for k = 1..8 of every job; one inversion of the
 // total product; pass 2 walks back, peels off each 1/Z_k, and overwrites the entry with affine (x, y, beta*x).
+template <int ENTRIES = PLUME_TAB_ENTRIES>
 PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt) {
     fe acc = fe_small(1);
     PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
@@ -207,12 +242,18 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
         jac b;
         ld_jac_soa(b, bases, njobs, job);
         b.inf = 0;
-        if (jobflags[job] != PLUME_JOB_OK) { b.x = fe_gx(); b.y = fe_gy(); b.z = fe_small(1); }
+        const bool zone = (jobflags[job] & PLUME_JOB_AFFINE) != 0;   // wave-uniform when job kinds repeat with period | cnt
+        (void)zone;
+        if (job_state(jobflags[job]) != PLUME_JOB_OK) { b.x = fe_gx(); b.y = fe_gy(); b.z = fe_small(1); }
         jac cur = b;
-        uint32_t* e = tab + job * PLUME_TAB_WORDS;
-        PLUME_NOUNROLL for (int k = 0; k < PLUME_TAB_ENTRIES; k++) {
+        uint32_t* e = tab + job * (size_t)(ENTRIES * PLUME_TAB_ENTRY_WORDS);
+        PLUME_NOUNROLL for (int k = 0; k < ENTRIES; k++) {
             if (k == 1) jac_dbl(cur);
+#if PLUME_TABLE_MADD
+            else if (k > 1) { if (zone) jac_madd(cur, b.x, b.y); else jac_add(cur, b); }
+#else
             else if (k > 1) jac_add(cur, b);
+#endif
             st_fe(e + 0, cur.x); st_fe(e + 8, cur.y); st_fe(e + 16, cur.z); st_fe(e + 24, acc);
             fe_mul(acc, acc, cur.z);
             e += PLUME_TAB_ENTRY_WORDS;
@@ -223,8 +264,8 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
     const fe beta = fe_beta();
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
         size_t job = j0 + (size_t)jj;
-        PLUME_NOUNROLL for (int k = PLUME_TAB_ENTRIES - 1; k >= 0; k--) {
-            uint32_t* e = tab + job * PLUME_TAB_WORDS + k * PLUME_TAB_ENTRY_WORDS;
+        PLUME_NOUNROLL for (int k = ENTRIES - 1; k >= 0; k--) {
+            uint32_t* e = tab + job * (size_t)(ENTRIES * PLUME_TAB_ENTRY_WORDS) + k * PLUME_TAB_ENTRY_WORDS;
             fe X, Y, Zk, cprev, zi, zi2;
             ld_fe(X, e + 0); ld_fe(Y, e + 8); ld_fe(Zk, e + 16); ld_fe(cprev, e + 24);
             fe_mul(zi, inv, cprev);      // 1/Z_k
@@ -243,7 +284,8 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
 // acc = sum over slots of digit * table point.  Slot s uses table tabs[s >> 1]; odd slots are the lambda
 // halves (beta*x).  dig: digits of slot s, window i at dig[(s*PLUME_NDIG + i)*stride].  A NULL table (or a
 // job flagged INF) contributes nothing.
-PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride) {
+// wide0: slots 0,1 use the generator's 128-entry table with w = 8 digits (stored by booth_store_wide).
+PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
     PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
         if (i != PLUME_NDIG - 1) {
@@ -252,6 +294,14 @@ PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int 
         PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
             const uint32_t* tab = (s & 2) ? tab1 : tab0;
             int d = dig[(uint32_t)(s * PLUME_NDIG + i) * stride];
+            if (wide0 && s < 2) {
+                if (i & 1) continue;                      // wave-uniform: wide digits sit at even windows only
+                int mag = d & 0xFF;
+                bool dn;
+                if (i == PLUME_NDIG - 1) { dn = (mag & 0x40) != 0; mag &= 0x3F; }
+                else dn = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride] != 0;
+                d = dn ? -mag : mag;
+            }
             if (d != 0 && tab != nullptr) {
                 int ad = d < 0 ? -d : d;
                 const uint32_t* e = tab + (ad - 1) * PLUME_TAB_ENTRY_WORDS;

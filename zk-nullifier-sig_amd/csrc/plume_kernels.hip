@@ -10,12 +10,24 @@
 // the ~10^6 VALU instructions per item.
 #include "plume_launch.h"
 
+#ifndef PLUME_GTAB_IN_LDS
+#define PLUME_GTAB_IN_LDS 0
+#endif
+
 namespace plume {
 
 
+// the generator's wide table (128 entries, 16 KiB) -> LDS, 16 B per lane per trip
 __device__ __forceinline__ void stage_gtab(uint32_t* s_gtab, const uint32_t* gtab) {
-    for (int w = threadIdx.x; w < PLUME_TAB_WORDS; w += kBlock) s_gtab[w] = gtab[w];
+    const uint4* src = reinterpret_cast<const uint4*>(gtab);
+    uint4* dst = reinterpret_cast<uint4*>(s_gtab);
+    for (int w = threadIdx.x; w < PLUME_GTAB8_WORDS / 4; w += kBlock) dst[w] = src[w];
     __syncthreads();
+}
+
+// one-time: (1..128)*G, affine + beta*x, by a single lane (plume_init)
+__global__ void k_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) table_build<PLUME_GTAB8_ENTRIES>(gtab8, base_g, flag, 1, 0, 1);
 }
 
 __global__ __launch_bounds__(kBlock) void k_verify_ingest(VerifyArgs a) {
@@ -35,13 +47,20 @@ __global__ __launch_bounds__(kBlock) void k_tables(uint32_t* tab, const uint32_t
 // blocks [0, nb): equation 1 (s*G - c*pk); blocks [nb, 2nb): equation 2 (s*H - c*nullifier) — the role is uniform
 // per workgroup so the generator-table-in-LDS path never diverges inside a wavefront
 __global__ __launch_bounds__(kBlock) void k_verify_msm(VerifyArgs a) {
-    __shared__ uint32_t s_gtab[PLUME_TAB_WORDS];
+#if PLUME_GTAB_IN_LDS
+    __shared__ __attribute__((aligned(16))) uint32_t s_gtab[PLUME_GTAB8_WORDS];
+#endif
     __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
-    stage_gtab(s_gtab, a.gtab);
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t eq = blockIdx.x >= nb ? 1u : 0u;
+#if PLUME_GTAB_IN_LDS
+    if (eq == 0) stage_gtab(s_gtab, a.gtab);   // block-uniform
+    const uint32_t* gt = s_gtab;
+#else
+    const uint32_t* gt = a.gtab;
+#endif
     const uint32_t i = (eq ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
-    if (i < a.n) verify_msm(a, i, eq, s_gtab, s_dig + threadIdx.x, kBlock);
+    if (i < a.n) verify_msm(a, i, eq, gt, s_dig + threadIdx.x, kBlock);
 }
 
 __global__ __launch_bounds__(kBlock) void k_verify_finalize(VerifyArgs a) {
@@ -50,13 +69,20 @@ __global__ __launch_bounds__(kBlock) void k_verify_finalize(VerifyArgs a) {
 }
 
 __global__ __launch_bounds__(kBlock) void k_sign_gmul(SignArgs a) {
-    __shared__ uint32_t s_gtab[PLUME_TAB_WORDS];
+#if PLUME_GTAB_IN_LDS
+    __shared__ __attribute__((aligned(16))) uint32_t s_gtab[PLUME_GTAB8_WORDS];
+#endif
     __shared__ int8_t s_dig[2 * PLUME_NDIG * kBlock];
+#if PLUME_GTAB_IN_LDS
     stage_gtab(s_gtab, a.gtab);
+    const uint32_t* gt = s_gtab;
+#else
+    const uint32_t* gt = a.gtab;
+#endif
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
-    if (i < a.n) sign_gmul(a, i, which, s_gtab, s_dig + threadIdx.x, kBlock);
+    if (i < a.n) sign_gmul(a, i, which, gt, s_dig + threadIdx.x, kBlock);
 }
 
 __global__ __launch_bounds__(kBlock) void k_sign_h2c(SignArgs a) {
@@ -168,6 +194,7 @@ void launch_sign_h2c(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_s
 void launch_sign_hmul(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_hmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_final(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_final, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_h2c_only(const H2cArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_only, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, hipStream_t st) { hipLaunchKernelGGL(k_gtab8, dim3(1), dim3(64), 0, st, gtab8, base_g, flag); }
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_microbench, dim3(blocks), dim3(kBlock), 0, st, kind, iters, sink);
 }

@@ -7,7 +7,7 @@
 namespace plume {
 
 constexpr int kBlock = 256;      // 4 wavefronts per workgroup
-constexpr int kTableJobsPerLane = 3;
+constexpr int kTableJobsPerLane = 6;   // multiple of 3: job kinds (pk, H, nullifier) then line up across the lanes of a wavefront
 
 void launch_verify_ingest(const VerifyArgs& a, hipStream_t st);
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int jobs_per_lane, hipStream_t st);
@@ -18,6 +18,7 @@ void launch_sign_h2c(const SignArgs& a, hipStream_t st);
 void launch_sign_hmul(const SignArgs& a, hipStream_t st);
 void launch_sign_final(const SignArgs& a, hipStream_t st);
 void launch_h2c_only(const H2cArgs& a, hipStream_t st);
+void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, hipStream_t st);
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st);
 
 }  // namespace plume

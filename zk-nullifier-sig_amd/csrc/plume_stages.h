@@ -109,7 +109,7 @@ struct VerifyArgs {
     uint32_t* tab;        // 3n tables of PLUME_TAB_WORDS
     uint32_t* res;        // 24 x (2n) words, Jacobian SoA of R' (task 2i) and Hr' (task 2i+1)
     uint8_t* resinf;      // 2n
-    const uint32_t* gtab; // table of G (PLUME_TAB_WORDS)
+    const uint32_t* gtab; // wide table of G (PLUME_GTAB8_WORDS): (1..128)*G
 };
 
 PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
@@ -130,18 +130,23 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     }
     jac p; p.inf = 0; p.z = fe_small(1);
     p.x = pkx; p.y = pky;
-    st_jac_soa(a.bases, nj, 3 * (size_t)i + 0, p); a.jobflags[3 * (size_t)i + 0] = (uint8_t)fpk;
+    st_jac_soa(a.bases, nj, 3 * (size_t)i + 0, p); a.jobflags[3 * (size_t)i + 0] = (uint8_t)(fpk | PLUME_JOB_AFFINE);
     st_jac_soa(a.bases, nj, 3 * (size_t)i + 1, h); a.jobflags[3 * (size_t)i + 1] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
     p.x = nx; p.y = ny;
-    st_jac_soa(a.bases, nj, 3 * (size_t)i + 2, p); a.jobflags[3 * (size_t)i + 2] = (uint8_t)fnul;
+    st_jac_soa(a.bases, nj, 3 * (size_t)i + 2, p); a.jobflags[3 * (size_t)i + 2] = (uint8_t)(fnul | PLUME_JOB_AFFINE);
 }
 
 // digits of one double-base task a*A + b*B into dig (4 slots x 33): slots 0,1 = a's halves, 2,3 = b's halves
-PLUME_HD void task_digits(int8_t* dig, uint32_t stride, const sc& ka, bool flip_a, const sc& kb, bool flip_b) {
+PLUME_HD void task_digits(int8_t* dig, uint32_t stride, const sc& ka, bool flip_a, const sc& kb, bool flip_b, bool wide_a) {
     glv_half h1, h2;
     glv_split(h1, h2, ka);
-    booth_store(dig + 0 * PLUME_NDIG * stride, stride, h1, flip_a);
-    booth_store(dig + 1 * PLUME_NDIG * stride, stride, h2, flip_a);
+    if (wide_a) {
+        booth_store_wide(dig + 0 * PLUME_NDIG * stride, stride, h1, flip_a);
+        booth_store_wide(dig + 1 * PLUME_NDIG * stride, stride, h2, flip_a);
+    } else {
+        booth_store(dig + 0 * PLUME_NDIG * stride, stride, h1, flip_a);
+        booth_store(dig + 1 * PLUME_NDIG * stride, stride, h2, flip_a);
+    }
     glv_split(h1, h2, kb);
     booth_store(dig + 2 * PLUME_NDIG * stride, stride, h1, flip_b);
     booth_store(dig + 3 * PLUME_NDIG * stride, stride, h2, flip_b);
@@ -157,11 +162,11 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
         sc c, s;
         sc_from_be_aligned(c, a.c + 32 * (size_t)item);
         sc_from_be_aligned(s, a.s + 32 * (size_t)item);
-        task_digits(dig, stride, s, false, c, true);
+        task_digits(dig, stride, s, false, c, true, eq == 0);
         const size_t ja = 3 * (size_t)item + 1, jb = 3 * (size_t)item + (eq ? 2 : 0);
-        const uint32_t* tab0 = eq ? (a.jobflags[ja] == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr) : gtab;
-        const uint32_t* tab1 = a.jobflags[jb] == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
-        msm_run(acc, tab0, tab1, 4, dig, stride);
+        const uint32_t* tab0 = eq ? (job_state(a.jobflags[ja]) == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr) : gtab;
+        const uint32_t* tab1 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
+        msm_run(acc, tab0, tab1, 4, dig, stride, eq == 0);
     }
     st_jac_soa(a.res, nt, t, acc);
     a.resinf[t] = (uint8_t)acc.inf;
@@ -189,7 +194,7 @@ PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
                 jac_eq_affine(rc, rx, ry, fr == PLUME_JOB_INF) && jac_eq_affine(hc, hx, hy, fh == PLUME_JOB_INF)) {   // lib.rs:117,122
                 // affine H = entry 0 of H's table (canonical); identity H has no table
                 const size_t jh = 3 * (size_t)i + 1;
-                bool hinf = a.jobflags[jh] == PLUME_JOB_INF;
+                bool hinf = job_state(a.jobflags[jh]) == PLUME_JOB_INF;
                 fe Hx, Hy;
                 ld_fe(Hx, a.tab + jh * PLUME_TAB_WORDS); ld_fe(Hy, a.tab + jh * PLUME_TAB_WORDS + 8);
                 enc_pt pts[6];
@@ -259,22 +264,22 @@ PLUME_HD uint32_t load_scalar_reduced(sc& k, const uint8_t* p) {
     return ok ? 0u : PLUME_ST_BAD_SCALAR;
 }
 // task t = 2*item + which: which 0 -> sk, 1 -> r;  result = k * (table tab0)
-PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, const uint32_t* tab0, uint32_t* res, uint8_t* resinf, int8_t* dig, uint32_t stride) {
+PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, const uint32_t* tab0, uint32_t* res, uint8_t* resinf, int8_t* dig, uint32_t stride, bool wide) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
     sc k;
     (void)load_scalar_reduced(k, (which ? a.r : a.sk) + 32 * (size_t)item);
     glv_half h1, h2;
     glv_split(h1, h2, k);
-    booth_store(dig, stride, h1, false);
-    booth_store(dig + PLUME_NDIG * stride, stride, h2, false);
+    if (wide) { booth_store_wide(dig, stride, h1, false); booth_store_wide(dig + PLUME_NDIG * stride, stride, h2, false); }
+    else { booth_store(dig, stride, h1, false); booth_store(dig + PLUME_NDIG * stride, stride, h2, false); }
     jac acc;
-    msm_run(acc, tab0, nullptr, 2, dig, stride);
+    msm_run(acc, tab0, nullptr, 2, dig, stride, wide);
     st_jac_soa(res, nt, t, acc);
     resinf[t] = (uint8_t)acc.inf;
 }
 PLUME_HD void sign_gmul(const SignArgs& a, uint32_t item, uint32_t which, const uint32_t* gtab, int8_t* dig, uint32_t stride) {
     if (which == 0 && a.pk_in) return;   // pk supplied: sk*G not needed
-    sign_mul(a, item, which, gtab, a.gres, a.gresinf, dig, stride);
+    sign_mul(a, item, which, gtab, a.gres, a.gresinf, dig, stride, true);
 }
 PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
     const size_t nt = 2 * (size_t)a.n;
@@ -309,8 +314,8 @@ PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
     a.itemflags[i] = (uint8_t)(st | (pinf ? 0x80u : 0u));
 }
 PLUME_HD void sign_hmul(const SignArgs& a, uint32_t item, uint32_t which, int8_t* dig, uint32_t stride) {
-    const uint32_t* tab0 = a.jobflags[item] == PLUME_JOB_OK ? a.tab + (size_t)item * PLUME_TAB_WORDS : nullptr;
-    sign_mul(a, item, which, tab0, a.hres, a.hresinf, dig, stride);
+    const uint32_t* tab0 = job_state(a.jobflags[item]) == PLUME_JOB_OK ? a.tab + (size_t)item * PLUME_TAB_WORDS : nullptr;
+    sign_mul(a, item, which, tab0, a.hres, a.hresinf, dig, stride, false);
 }
 PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
     const size_t nt = 2 * (size_t)a.n;
@@ -332,7 +337,7 @@ PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
     fe_sqr(t, i2); fe_mul(hr.x, hr.x, t); fe_mul(t, t, i2); fe_mul(hr.y, hr.y, t);
     fe px, py, Hx, Hy;
     ld_fe_soa(px, a.pkaff, a.n, i); ld_fe_soa(py, a.pkaff + 8 * (size_t)a.n, a.n, i);
-    bool hinf = a.jobflags[i] == PLUME_JOB_INF;
+    bool hinf = job_state(a.jobflags[i]) == PLUME_JOB_INF;
     ld_fe(Hx, a.tab + (size_t)i * PLUME_TAB_WORDS); ld_fe(Hy, a.tab + (size_t)i * PLUME_TAB_WORDS + 8);
     uint32_t dg[8];
     enc_pt e_nul = enc_of(nul.x, nul.y, nul.inf != 0), e_r = enc_of(R.x, R.y, R.inf != 0), e_hr = enc_of(hr.x, hr.y, hr.inf != 0);
