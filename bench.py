@@ -172,11 +172,13 @@ def main():
                                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                                 "note": "path is integer-VALU bound (SURVEY.md §8d); see valu_roofline"}
             try:
-                mad_rate = eng.microbench(0, 4096)
-                add_rate = eng.microbench(4, 4096)
-                fpmul_rate = eng.microbench(5, 512)
-                fpsqr_rate = eng.microbench(6, 512)
-                other = {name: round(eng.microbench(k, 4096), 1) for k, name in
+                # long enough (tens of ms each) for the clocks to settle where the real kernels run
+                eng.microbench(0, 1 << 17)
+                mad_rate = eng.microbench(0, 1 << 18)
+                add_rate = eng.microbench(4, 1 << 18)
+                fpmul_rate = eng.microbench(5, 1 << 13)
+                fpsqr_rate = eng.microbench(6, 1 << 13)
+                other = {name: round(eng.microbench(k, 1 << 17), 1) for k, name in
                          ((1, "v_addc_co_u32"), (2, "v_mul_lo_u32"), (3, "v_mad_u32_u24"), (7, "v_fma_f64"), (8, "v_lshl_add_u64"))}
                 step_s = sum(stages.values()) * 1e-3
                 whole = FPMUL_PER_ITEM[ver] * MACS_PER_FPMUL * n / step_s

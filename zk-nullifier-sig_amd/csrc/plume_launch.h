@@ -6,7 +6,10 @@
 
 namespace plume {
 
-constexpr int kBlock = 256;      // 4 wavefronts per workgroup
+#ifndef PLUME_BLOCK
+#define PLUME_BLOCK 256
+#endif
+constexpr int kBlock = PLUME_BLOCK;      // wavefronts per workgroup = kBlock / 64
 constexpr int kTableJobsPerLane = 6;   // multiple of 3: job kinds (pk, H, nullifier) then line up across the lanes of a wavefront
 
 void launch_verify_ingest(const VerifyArgs& a, hipStream_t st);
