@@ -62,6 +62,18 @@ int plume_verify_batch(plume_ctx* ctx, int version, size_t n,
                        const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
                        uint8_t* ok);
 
+/* ---- verify with SEC1-compressed points (33-byte records) --------------------------------------------------
+ * The wire format of the reference's serde / wasm layer (javascript/src/lib.rs:95-118,147-184; sec1_affine,
+ * rust-arkworks/src/lib.rs:76-88): 02|03 || x big-endian, or a record whose first byte is 00 for the identity (the
+ * remaining 32 bytes are ignored).  Decompression (y = sqrt(x^3 + 7), parity from the tag) and on-curve validation run
+ * on the GPU; a record that would fail to deserialize in the reference (other tag, x >= p, x not on the curve) gives
+ * ok = 0.  Everything else as plume_verify_batch. */
+int plume_verify_batch_sec1(plume_ctx* ctx, int version, size_t n,
+                            const uint8_t* msgs, const uint64_t* msg_off,
+                            const uint8_t* pk33, const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s,
+                            const uint8_t* r_point33, const uint8_t* hashed_to_curve_r33,
+                            uint8_t* ok);
+
 /* ---- PlumeSigner::try_sign_with_rng / PlumeSignature::sign_v1|sign_v2, batched, nonce supplied -----------
  * (rust-k256/src/randomizedsigner.rs:43-112, rust-k256/src/lib.rs:149-156; the RNG stays on the host: r[i] is
  * the 32 bytes the reference would draw, cf. the mock RNG in rust-k256/tests/signing.rs:23-44).
@@ -92,6 +104,11 @@ int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n,
                               const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s,
                               const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
                               uint8_t* ok, void* stream);
+int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_t n,
+                                   const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
+                                   const uint8_t* pk33, const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s,
+                                   const uint8_t* r_point33, const uint8_t* hashed_to_curve_r33,
+                                   uint8_t* ok, void* stream);
 int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n,
                             const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                             const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,

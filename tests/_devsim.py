@@ -92,6 +92,16 @@ def verify_batch(version, msgs_buf, msg_off, pk, nul, c, s, r_point=None, hr=Non
     return ok
 
 
+def verify_batch_sec1(version, msgs_buf, msg_off, pk33, nul33, c, s, r33=None, hr33=None):
+    n = len(msg_off) - 1
+    ok = np.full(n, 0xEE, dtype=np.uint8)
+    c, s = map(_aligned, (c, s))
+    f = lambda a: None if a is None else np.ascontiguousarray(a)  # noqa: E731  (33-byte records: no alignment requirement)
+    rc = lib().ds_verify_batch_sec1(C.c_int(version), C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), _p(f(pk33)), _p(f(nul33)), _p(c), _p(s), _p(f(r33)), _p(f(hr33)), _p(ok))
+    assert rc == 0
+    return ok
+
+
 def sign_batch(version, msgs_buf, msg_off, sk, r, pk_in=None, L=3):
     n = len(msg_off) - 1
     o = {k: np.zeros((n, w), dtype=np.uint8) for k, w in

@@ -82,14 +82,32 @@ static void build_gtab(std::vector<uint32_t>& gtab) {
 // simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)
 static const uint32_t B = 8;
 
+static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
+                       const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags);
 int ds_verify_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
                     const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L) {
+    return verify_impl(version, n, msgs, msg_off, pk, nul, c, s, rpt, hr, ok, L, nullptr);
+}
+// SEC1-compressed ingest: decompress_item per lane, then the same pipeline
+int ds_verify_batch_sec1(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk33, const uint8_t* nul33, const uint8_t* c,
+                         const uint8_t* s, const uint8_t* r33, const uint8_t* hr33, uint8_t* ok) {
+    if (version != 1 && version != 2) return -1;
+    std::vector<uint8_t> dec[4], pre(n);
+    DecompressArgs d; d.n = n; d.npts = version == 1 ? 4 : 2;
+    d.in[0] = pk33; d.in[1] = nul33; d.in[2] = r33; d.in[3] = hr33;
+    for (int k = 0; k < 4; k++) { dec[k].resize(64 * (size_t)n + 16); d.out[k] = dec[k].data(); }
+    d.preflags = pre.data();
+    for (uint32_t i = 0; i < n; i++) decompress_item(d, i);
+    return verify_impl(version, n, msgs, msg_off, d.out[0], d.out[1], c, s, version == 1 ? d.out[2] : nullptr, version == 1 ? d.out[3] : nullptr, ok, 3, pre.data());
+}
+static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
+                       const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags) {
     if (version != 1 && version != 2) return -1;
     std::vector<uint32_t> gtab; build_gtab(gtab);
     std::vector<uint32_t> bases(24 * 3 * (size_t)n), tab((size_t)3 * n * PLUME_TAB_WORDS), res(24 * 2 * (size_t)n);
     std::vector<uint8_t> jobflags(3 * (size_t)n), itemflags(n), resinf(2 * (size_t)n);
     VerifyArgs a;
-    a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok;
+    a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags;
     a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data(); a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data();
     a.gtab = gtab.data();
     for (uint32_t i = 0; i < n; i++) verify_ingest_h2c(a, i);

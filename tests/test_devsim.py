@@ -202,3 +202,23 @@ def test_wide_generator_digits_special_scalars():
     b = OC.sign_batch(2, mb, off, sk, r, nthreads=8)
     for key in a:
         assert np.array_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_sec1_compressed_ingest(ver):
+    """'next' row f-1: 33-byte SEC1 records, decompressed + validated by the device code"""
+    from tests import _sec1
+    items = GOLD[f"verify_v{ver}"][:64] + [e for e in GOLD["edge"] if e["version"] == ver and "off curve" not in e["note"] and "non-canonical" not in e["note"] and "= p" not in e["note"]]
+    mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+    c33 = lambda k: _sec1.compress(OC.arr(items, k, 64))  # noqa: E731
+    ok = D.verify_batch_sec1(ver, mb, off, c33("pk"), c33("nullifier"), OC.arr(items, "c", 32), OC.arr(items, "s", 32),
+                             c33("r_point") if ver == 1 else None, c33("hashed_to_curve_r") if ver == 1 else None)
+    assert list(ok) == [it["ok"] for it in items]
+    cases = _sec1.malformed_cases(ver, GOLD[f"verify_v{ver}"])
+    mb, off = OC.pack_msgs([c[0] for c in cases])
+    col = lambda j, w: np.frombuffer(b"".join(c[j] for c in cases), dtype=np.uint8).reshape(-1, w).copy()  # noqa: E731
+    ok = D.verify_batch_sec1(ver, mb, off, col(1, 33), col(2, 33), col(3, 32), col(4, 32), col(5, 33) if ver == 1 else None, col(6, 33) if ver == 1 else None)
+    want = [int(_sec1.oracle_verify_sec1(ver, *c[:7])) for c in cases]
+    bad = [(c[7], int(o), w) for c, o, w in zip(cases, ok, want) if int(o) != w]
+    assert not bad, bad
+    assert sum(want) >= 2   # the honest mutations still verify

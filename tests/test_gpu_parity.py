@@ -251,3 +251,31 @@ def test_empty_batch(eng):
     z = lambda w: np.zeros((0, w), dtype=np.uint8)  # noqa: E731
     assert len(eng.verify_batch(2, mb, off, z(64), z(64), z(32), z(32))) == 0
     assert len(eng.sign_batch(1, mb, off, z(32), z(32))["status"]) == 0
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_sec1_compressed_ingest(eng, ver):
+    """33-byte SEC1 records decompressed + validated on the GPU (plume_verify_batch_sec1)"""
+    from tests import _sec1
+    items = GOLD[f"verify_v{ver}"] + [e for e in GOLD["edge"] if e["version"] == ver and "off curve" not in e["note"] and "non-canonical" not in e["note"] and "= p" not in e["note"]]
+    mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+    c33 = lambda k: _sec1.compress(OC.arr(items, k, 64))  # noqa: E731
+    ok = eng.verify_batch_sec1(ver, mb, off, c33("pk"), c33("nullifier"), OC.arr(items, "c", 32), OC.arr(items, "s", 32),
+                               c33("r_point") if ver == 1 else None, c33("hashed_to_curve_r") if ver == 1 else None)
+    assert list(ok) == [it["ok"] for it in items]
+    cases = _sec1.malformed_cases(ver, GOLD[f"verify_v{ver}"])
+    mb, off = OC.pack_msgs([c[0] for c in cases])
+    col = lambda j, w: np.frombuffer(b"".join(c[j] for c in cases), dtype=np.uint8).reshape(-1, w).copy()  # noqa: E731
+    ok = eng.verify_batch_sec1(ver, mb, off, col(1, 33), col(2, 33), col(3, 32), col(4, 32), col(5, 33) if ver == 1 else None, col(6, 33) if ver == 1 else None)
+    want = [int(_sec1.oracle_verify_sec1(ver, *c[:7])) for c in cases]
+    bad = [(c[7], int(o), w) for c, o, w in zip(cases, ok, want) if int(o) != w]
+    assert not bad, bad
+    # a larger seeded batch: compressed ingest == 64-byte ingest
+    n = 20000
+    b = synth.sign_inputs(n, start=123456)
+    signed = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    v = synth.corrupt_for_verify(ver, b, signed, start=123456)
+    a = eng.verify_batch(ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
+    bb = eng.verify_batch_sec1(ver, v["msgs"], v["off"], _sec1.compress(v["pk"]), _sec1.compress(v["nullifier"]), v["c"], v["s"],
+                               _sec1.compress(v["r_point"]) if ver == 1 else None, _sec1.compress(v["hashed_to_curve_r"]) if ver == 1 else None)
+    assert np.array_equal(a, bb) and np.array_equal(a, synth.expected_ok(n, 123456))

@@ -54,6 +54,8 @@ def _load():
     lib.plume_last_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
     lib.plume_verify_batch.argtypes = [vp, i, sz] + [vp] * 9
+    lib.plume_verify_batch_sec1.argtypes = [vp, i, sz] + [vp] * 9
+    lib.plume_verify_batch_sec1_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 8
     lib.plume_sign_batch.argtypes = [vp, i, sz] + [vp] * 12
     lib.plume_hash_to_curve_batch.argtypes = [vp, sz] + [vp] * 4
     lib.plume_verify_batch_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 8
@@ -65,7 +67,7 @@ def _load():
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_verify_batch", "plume_sign_batch",
+    return ["plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch",
             "plume_hash_to_curve_batch", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
             "plume_last_stage_times", "plume_microbench", "plume_microbench_last_ticks"]
 
@@ -141,6 +143,23 @@ class Engine:
         ok = np.zeros(n, dtype=np.uint8)
         self._chk(self._lib.plume_verify_batch(self._ctx, int(version), n, _ptr(msgs), _ptr(msg_off), _ptr(pk), _ptr(nullifier), _ptr(c), _ptr(s),
                                                _ptr(r_point), _ptr(hashed_to_curve_r), _ptr(ok)), "plume_verify_batch")
+        return ok
+
+    def verify_batch_sec1(self, version, msgs, msg_off, pk33, nullifier33, c, s, r_point33=None, hashed_to_curve_r33=None):
+        """verify with 33-byte SEC1-compressed points (decompressed and validated on the GPU)"""
+        n = len(msg_off) - 1
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
+        pk33, nullifier33, c, s = _np(pk33, 33, n, "pk33"), _np(nullifier33, 33, n, "nullifier33"), _np(c, 32, n, "c"), _np(s, 32, n, "s")
+        if version == 1:
+            if r_point33 is None or hashed_to_curve_r33 is None:
+                raise ValueError("V1 verification needs r_point and hashed_to_curve_r")
+            r_point33, hashed_to_curve_r33 = _np(r_point33, 33, n, "r_point33"), _np(hashed_to_curve_r33, 33, n, "hashed_to_curve_r33")
+        else:
+            r_point33 = hashed_to_curve_r33 = None
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.plume_verify_batch_sec1(self._ctx, int(version), n, _ptr(msgs), _ptr(msg_off), _ptr(pk33), _ptr(nullifier33), _ptr(c), _ptr(s),
+                                                    _ptr(r_point33), _ptr(hashed_to_curve_r33), _ptr(ok)), "plume_verify_batch_sec1")
         return ok
 
     def sign_batch(self, version, msgs, msg_off, sk, r, pk_in=None):

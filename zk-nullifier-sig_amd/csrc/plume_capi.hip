@@ -57,6 +57,7 @@ struct plume_ctx {
     size_t chunk = (size_t)1 << 20;
     int jobs_per_lane = kTableJobsPerLane;
     DevBuf gtab, bases, jobflags, itemflags, tab, res, resinf, res2, res2inf, pkaff, sink;
+    DevBuf dec[4], preflags;   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
     DevBuf in_msgs, in_off, in_a, in_b, in_c, in_d, in_e, in_f, out_a, out_b, out_c, out_d, out_e, out_f, out_g;  // staging for the host-pointer API
     StageTimer timer;
 };
@@ -107,7 +108,7 @@ extern "C" void plume_destroy(plume_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
-                      &ctx->sink, &ctx->in_msgs, &ctx->in_off, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->out_a, &ctx->out_b,
+                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->in_msgs, &ctx->in_off, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->out_a, &ctx->out_b,
                       &ctx->out_c, &ctx->out_d, &ctx->out_e, &ctx->out_f, &ctx->out_g})
         b->release();
     ctx->timer.destroy();
@@ -123,18 +124,19 @@ extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
 
 // ------------------------------------------------------------------------------------------ device pipelines
 static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul,
-                         const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, hipStream_t st) {
+                         const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, hipStream_t st,
+                         const uint8_t* preflags = nullptr, bool continue_timer = false) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
     if (ctx->bases.ensure(24 * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
         ctx->res.ensure(24 * 4 * 2 * n) || ctx->resinf.ensure(2 * n))
         return PLUME_ERR_HIP;
     VerifyArgs a;
-    a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok;
+    a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags;
     a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>(); a.itemflags = ctx->itemflags.as<uint8_t>();
     a.tab = ctx->tab.as<uint32_t>(); a.res = ctx->res.as<uint32_t>(); a.resinf = ctx->resinf.as<uint8_t>(); a.gtab = ctx->gtab.as<uint32_t>();
     StageTimer& t = ctx->timer;
-    t.begin(st);
+    if (!continue_timer) t.begin(st);
     launch_verify_ingest(a, st); t.stage("verify_ingest_h2c", st);
     launch_tables(a.tab, a.bases, a.jobflags, 3 * n, ctx->jobs_per_lane, st); t.stage("tables", st);
     launch_verify_msm(a, st); t.stage("verify_msm", st);
@@ -187,6 +189,36 @@ extern "C" int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n, 
     if (n && version == 1 && (!r_point || !hashed_to_curve_r)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
     return verify_device(ctx, version, n, msgs, msg_off, pk, nullifier, c, s, version == 1 ? r_point : nullptr, version == 1 ? hashed_to_curve_r : nullptr, ok,
                          stream ? (hipStream_t)stream : ctx->stream);
+}
+
+// SEC1-compressed ingest: decompress on the GPU into the context's 64-byte staging arrays, then the normal pipeline
+static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk33, const uint8_t* nul33,
+                              const uint8_t* c, const uint8_t* s, const uint8_t* r33, const uint8_t* hr33, uint8_t* ok, hipStream_t st) {
+    if (n == 0) return 0;
+    if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    const int npts = version == 1 ? 4 : 2;
+    for (int k = 0; k < npts; k++) if (ctx->dec[k].ensure(64 * n)) return PLUME_ERR_HIP;
+    if (ctx->preflags.ensure(n)) return PLUME_ERR_HIP;
+    DecompressArgs d;
+    d.n = (uint32_t)n; d.npts = npts;
+    d.in[0] = pk33; d.in[1] = nul33; d.in[2] = r33; d.in[3] = hr33;
+    for (int k = 0; k < 4; k++) d.out[k] = ctx->dec[k].as<uint8_t>();
+    d.preflags = ctx->preflags.as<uint8_t>();
+    ctx->timer.begin(st);
+    launch_decompress(d, st); ctx->timer.stage("sec1_decompress", st);
+    return verify_device(ctx, version, n, msgs, msg_off, d.out[0], d.out[1], c, s, version == 1 ? d.out[2] : nullptr, version == 1 ? d.out[3] : nullptr, ok, st,
+                         d.preflags, true);
+}
+
+extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
+                                              const uint8_t* pk33, const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s, const uint8_t* r_point33,
+                                              const uint8_t* hashed_to_curve_r33, uint8_t* ok, void* stream) {
+    (void)msgs_bytes;
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
+    if (n && (!pk33 || !nullifier33 || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
+    if (n && version == 1 && (!r_point33 || !hashed_to_curve_r33)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
+    return verify_sec1_device(ctx, version, n, msgs, msg_off, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, ok, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
@@ -263,6 +295,36 @@ extern "C" int plume_verify_batch(plume_ctx* ctx, int version, size_t n, const u
         if (int rc = verify_device(ctx, version, cnt, ctx->in_msgs.as<uint8_t>(), ctx->in_off.as<uint64_t>(), ctx->in_a.as<uint8_t>(), ctx->in_b.as<uint8_t>(),
                                    ctx->in_c.as<uint8_t>(), ctx->in_d.as<uint8_t>(), version == 1 ? ctx->in_e.as<uint8_t>() : nullptr,
                                    version == 1 ? ctx->in_f.as<uint8_t>() : nullptr, ctx->out_a.as<uint8_t>(), ctx->stream))
+            return rc;
+        if (int rc = d2h(ctx, ok + i0, ctx->out_a, cnt)) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+extern "C" int plume_verify_batch_sec1(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk33,
+                                       const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s, const uint8_t* r_point33,
+                                       const uint8_t* hashed_to_curve_r33, uint8_t* ok) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
+    if (n && (!pk33 || !nullifier33 || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
+    if (n && version == 1 && (!r_point33 || !hashed_to_curve_r33)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
+    std::vector<uint64_t> rel;
+    for (size_t i0 = 0; i0 < n; i0 += ctx->chunk) {
+        const size_t cnt = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
+        if (int rc = stage_msgs(ctx, msgs, msg_off, i0, cnt, rel)) return rc;
+        if (int rc = h2d(ctx, ctx->in_a, pk33 + 33 * i0, 33 * cnt)) return rc;
+        if (int rc = h2d(ctx, ctx->in_b, nullifier33 + 33 * i0, 33 * cnt)) return rc;
+        if (int rc = h2d(ctx, ctx->in_c, c + 32 * i0, 32 * cnt)) return rc;
+        if (int rc = h2d(ctx, ctx->in_d, s + 32 * i0, 32 * cnt)) return rc;
+        if (version == 1) {
+            if (int rc = h2d(ctx, ctx->in_e, r_point33 + 33 * i0, 33 * cnt)) return rc;
+            if (int rc = h2d(ctx, ctx->in_f, hashed_to_curve_r33 + 33 * i0, 33 * cnt)) return rc;
+        }
+        if (ctx->out_a.ensure(cnt)) return PLUME_ERR_HIP;
+        if (int rc = verify_sec1_device(ctx, version, cnt, ctx->in_msgs.as<uint8_t>(), ctx->in_off.as<uint64_t>(), ctx->in_a.as<uint8_t>(), ctx->in_b.as<uint8_t>(),
+                                        ctx->in_c.as<uint8_t>(), ctx->in_d.as<uint8_t>(), version == 1 ? ctx->in_e.as<uint8_t>() : nullptr,
+                                        version == 1 ? ctx->in_f.as<uint8_t>() : nullptr, ctx->out_a.as<uint8_t>(), ctx->stream))
             return rc;
         if (int rc = d2h(ctx, ok + i0, ctx->out_a, cnt)) return rc;
         HIPCHK(hipStreamSynchronize(ctx->stream));

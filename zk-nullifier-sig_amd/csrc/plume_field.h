@@ -283,6 +283,14 @@ PLUME_HD void fe_pow_c1(fe& r, const fe& a) {
     fe_sqr_n(t, t, 3); fe_mul(r, t, x2);
 }
 
+// a^((p+1)/4): the square root of a when a is a quadratic residue (p = 3 mod 4); 253 squarings + 13 multiplications
+PLUME_HD void fe_sqrt_candidate(fe& r, const fe& a) {
+    fe t, x2;
+    fe_pow_prefix(t, x2, a);
+    fe_sqr_n(t, t, 6); fe_mul(t, t, x2);
+    fe_sqr_n(r, t, 2);
+}
+
 // big-endian 32 bytes <-> fe.  The pointers may be unaligned (caller arrays are byte arrays).
 PLUME_HD void fe_from_be(fe& r, const uint8_t* b) {
     PLUME_UNROLL for (int i = 0; i < 8; i++) {

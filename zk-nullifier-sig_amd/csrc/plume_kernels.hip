@@ -103,6 +103,11 @@ __global__ __launch_bounds__(kBlock) void k_sign_final(SignArgs a) {
     if (i < a.n) sign_final(a, i);
 }
 
+__global__ __launch_bounds__(kBlock) void k_decompress(DecompressArgs a) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < a.n) decompress_item(a, i);
+}
+
 __global__ __launch_bounds__(kBlock) void k_h2c_only(H2cArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) h2c_only(a, i);
@@ -193,6 +198,7 @@ void launch_sign_gmul(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_
 void launch_sign_h2c(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_h2c, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_hmul(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_hmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_final(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_final, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_decompress(const DecompressArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_decompress, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_h2c_only(const H2cArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_only, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, hipStream_t st) { hipLaunchKernelGGL(k_gtab8, dim3(1), dim3(64), 0, st, gtab8, base_g, flag); }
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st) {

@@ -102,6 +102,7 @@ struct VerifyArgs {
     const uint8_t* msgs; const uint64_t* msg_off;
     const uint8_t *pk, *nul, *c, *s, *rpt, *hr;
     uint8_t* ok;
+    const uint8_t* preflags;  // optional, n bytes: non-zero = reject (set by the SEC1 decompression stage)
     // scratch (device memory)
     uint32_t* bases;      // 24 x (3n) words, Jacobian SoA, job j = word-row w at bases[w*3n + j]
     uint8_t* jobflags;    // 3n
@@ -119,7 +120,7 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     uint32_t fnul = load_affine_be(nx, ny, a.nul + 64 * (size_t)i);
     sc c, s;
     bool okc = load_scalar_be(c, a.c + 32 * (size_t)i), oks = load_scalar_be(s, a.s + 32 * (size_t)i);
-    bool bad = !okc || !oks || fpk == PLUME_JOB_INVALID || fnul == PLUME_JOB_INVALID;
+    bool bad = !okc || !oks || fpk == PLUME_JOB_INVALID || fnul == PLUME_JOB_INVALID || (a.preflags && a.preflags[i]);
     a.itemflags[i] = bad ? 1 : 0;
     jac h;
     if (!bad) {
@@ -364,6 +365,41 @@ PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
     store_affine_be(a.hr + 64 * (size_t)i, hr.x, hr.y, hr.inf != 0);
     if (a.h_out) store_affine_be(a.h_out + 64 * (size_t)i, Hx, Hy, hinf);
     a.status[i] = (uint8_t)st;
+}
+
+// ================================================================================= SEC1-compressed ingest ("next" row f-1)
+// 33-byte records: 02|03 || x (big-endian), or 00 (+ 32 ignored bytes) for the identity — the wire format of the
+// reference's serde / wasm layer (javascript/src/lib.rs:95-118,147-184; rust-arkworks/src/lib.rs:76-88).  Any other tag,
+// x >= p, or an x with no point on the curve is a decoding error there; here it rejects the item.
+struct DecompressArgs {
+    uint32_t n;
+    int npts;                      // 2 (pk, nullifier) or 4 (+ r_point, hashed_to_curve_r)
+    const uint8_t* in[4];          // 33 B / item each
+    uint8_t* out[4];               // 64 B / item each (the engine's affine format)
+    uint8_t* preflags;             // n
+};
+// returns true when the record decodes; out64 always gets a well-formed 64-byte record
+PLUME_HD bool decompress_point(uint8_t* out64, const uint8_t* in33) {
+    const uint32_t tag = in33[0];
+    fe x, y, rhs, t;
+    fe_from_be(x, in33 + 1);
+    bool ok = (tag == 2u || tag == 3u) && fe_is_canonical(x);
+    fe_sqr(rhs, x); fe_mul(rhs, rhs, x);
+    fe seven = fe_small(7);
+    fe_add(rhs, rhs, seven);
+    fe_sqrt_candidate(y, rhs);
+    fe_sqr(t, y);
+    ok = ok && fe_eq(t, rhs);
+    if (fe_is_odd(y) != ((tag & 1u) != 0)) fe_neg(y, y);
+    const bool inf = tag == 0u;
+    if (!ok) { x = fe_gx(); y = fe_gy(); }      // placeholder; the item is rejected through preflags
+    store_affine_be(out64, x, y, inf);
+    return ok || inf;
+}
+PLUME_HD void decompress_item(const DecompressArgs& a, uint32_t i) {
+    bool ok = true;
+    PLUME_NOUNROLL for (int k = 0; k < a.npts; k++) ok = decompress_point(a.out[k] + 64 * (size_t)i, a.in[k] + 33 * (size_t)i) && ok;
+    a.preflags[i] = ok ? 0 : 1;
 }
 
 // ============================================================================================ h2c only (KAT pinning)
