@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--log2-batch", type=int, default=20, help="items per GPU per step = 2^this (BASELINE: 20)")
     ap.add_argument("--version", type=int, default=1, choices=(1, 2))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (V2 verify, V1 sign, SEC1 ingest) reported at N=1")
     return ap.parse_args()
 
 
@@ -79,6 +80,45 @@ def cpu_baseline(version: int):
             "sample": f"first {n} items of the same synthetic V{version} batch, plain-C oracle (4-bit window, no endomorphism), {threads} threads; "
                       f"single thread: {n1 / t_1:.1f} verifies/s. rust-k256 itself cannot be built here (no rustc/cargo).",
             "single_thread_value": round(n1 / t_1, 1)}
+
+
+def extras(eng, dev, n, b, signed_v1):
+    """secondary workloads of BASELINE.json's configs at N=1, device-resident, 2 timed passes each (not the headline metric)"""
+    import numpy as np
+    import torch
+
+    from tests import _sec1, synth
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    out = {}
+
+    def timed(fn, reps=2):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    msgs, off, sk, r = t(b["msgs"]), t(b["off"].view(np.int64)), t(b["sk"]), t(b["r"])
+    mbytes = int(b["off"][-1])
+    o = {k: torch.zeros((n, w), dtype=torch.uint8, device=dev) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
+    st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    for ver in (1, 2):
+        dt = timed(lambda: eng.sign_batch_device(ver, n, msgs, off, mbytes, sk, r, None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], st))
+        out[f"sign_v{ver}"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
+    # V2 verify on the V2 signatures just produced (honest batch)
+    ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    dt = timed(lambda: eng.verify_batch_device(2, n, msgs, off, mbytes, o["pk"], o["nullifier"], o["c"], o["s"], None, None, ok))
+    assert bool(ok.all())
+    out["verify_v2"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
+    # V1 verify with SEC1-compressed points (decompression on the GPU)
+    if signed_v1 is not None:
+        c33 = {k: t(_sec1.compress(signed_v1[k])) for k in ("pk", "nullifier", "r_point", "hashed_to_curve_r")}
+        cc, ss = t(signed_v1["c"]), t(signed_v1["s"])
+        dt = timed(lambda: eng.verify_batch_sec1_device(1, n, msgs, off, mbytes, c33["pk"], c33["nullifier"], cc, ss, c33["r_point"], c33["hashed_to_curve_r"], ok))
+        assert bool(ok.all())
+        out["verify_v1_sec1_compressed"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
+    return out
 
 
 def main():
@@ -190,6 +230,11 @@ def main():
                                          "accounting": "5460 Fp-mult/verify x 72 MACs (SURVEY.md §8d, frozen in BASELINE.md §4)"}
             except Exception as e:  # measurement extras must not kill the bench line
                 line["valu_roofline"] = {"error": str(e)}
+        if world == 1 and not a.no_extras:
+            try:
+                line["other_workloads"] = extras(eng, dev, n, b, signed if ver == 1 else None)
+            except Exception as e:
+                line["other_workloads"] = {"error": str(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(ver)

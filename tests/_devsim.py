@@ -127,3 +127,9 @@ def point_mul(k: bytes, p: bytes):
     out = (C.c_uint8 * 64)()
     ok = lib().ds_point_mul((C.c_uint8 * 32).from_buffer_copy(k), (C.c_uint8 * 64).from_buffer_copy(p), out)
     return bytes(out) if ok else None
+
+
+def eq1(s: bytes, c: bytes, pk: bytes):
+    out = (C.c_uint8 * 64)()
+    ok = lib().ds_eq1((C.c_uint8 * 32).from_buffer_copy(s), (C.c_uint8 * 32).from_buffer_copy(c), (C.c_uint8 * 64).from_buffer_copy(pk), out)
+    return bytes(out) if ok else None

@@ -79,6 +79,19 @@ static void build_gtab(std::vector<uint32_t>& gtab) {
     table_build<PLUME_GTAB8_ENTRIES>(gtab.data(), bases.data(), &flag, 1, 0, 1);
 }
 
+static void build_gcomb(std::vector<uint32_t>& comb) {
+    comb.assign(PLUME_COMB_WORDS, 0);
+    std::vector<uint32_t> bases(24 * PLUME_COMB_WINDOWS, 0);
+    std::vector<uint8_t> flags(PLUME_COMB_WINDOWS, 0);
+    for (uint32_t i = 0; i < PLUME_COMB_WINDOWS; i++) {      // mirrors k_gcomb
+        jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
+        for (uint32_t d = 0; d < 8 * i; d++) jac_dbl(g);
+        st_jac_soa(bases.data(), PLUME_COMB_WINDOWS, i, g);
+        flags[i] = PLUME_JOB_OK;
+        table_build<PLUME_GTAB8_ENTRIES>(comb.data(), bases.data(), flags.data(), PLUME_COMB_WINDOWS, i, 1);
+    }
+}
+
 // simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)
 static const uint32_t B = 8;
 
@@ -124,22 +137,49 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
                   uint8_t* pk, uint8_t* nul, uint8_t* c, uint8_t* s, uint8_t* rpt, uint8_t* hr, uint8_t* h_out, uint8_t* status, int L) {
     if (version != 1 && version != 2) return -1;
     std::vector<uint32_t> gtab; build_gtab(gtab);
+    static std::vector<uint32_t> gcomb; if (gcomb.empty()) build_gcomb(gcomb);
     std::vector<uint32_t> gres(24 * 2 * (size_t)n), hres(24 * 2 * (size_t)n), bases(24 * (size_t)n), pkaff(16 * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
     std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(n), itemflags(n);
     SignArgs a;
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.sk = sk; a.r = r; a.pk_in = pk_in;
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
     a.gres = gres.data(); a.gresinf = gresinf.data(); a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
-    a.pkaff = pkaff.data(); a.tab = tab.data(); a.hres = hres.data(); a.hresinf = hresinf.data(); a.gtab = gtab.data();
+    a.pkaff = pkaff.data(); a.tab = tab.data(); a.hres = hres.data(); a.hresinf = hresinf.data(); a.gtab = gtab.data(); a.gcomb = gcomb.data();
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);
     for (uint32_t w = 0; w < 2; w++)
-        for (uint32_t i = 0; i < n; i++) sign_gmul(a, i, w, a.gtab, dig.data() + (i % B), B);
+        for (uint32_t i = 0; i < n; i++) sign_gmul(a, i, w);
     for (uint32_t i = 0; i < n; i++) sign_h2c(a, i);
     for (size_t j0 = 0; j0 < n; j0 += L) table_build(a.tab, a.bases, a.jobflags, n, j0, (int)((n - j0) < (size_t)L ? (n - j0) : L));
     for (uint32_t w = 0; w < 2; w++)
         for (uint32_t i = 0; i < n; i++) sign_hmul(a, i, w, dig.data() + (i % B), B);
     for (uint32_t i = 0; i < n; i++) sign_final(a, i);
     return 0;
+}
+
+// R' = s*G - c*pk through the verify multi-scalar body (equation 1: wide generator digits + the pk window table)
+int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[64], uint8_t out[64]) {
+    std::vector<uint32_t> gtab; build_gtab(gtab);
+    alignas(16) uint8_t sb[32], cb[32], pb[64], ob[64];
+    memcpy(sb, s_be, 32); memcpy(cb, c_be, 32); memcpy(pb, pk_be, 64);
+    fe x, y;
+    uint32_t f = load_affine_be(x, y, pb);
+    if (f == PLUME_JOB_INVALID) return 0;
+    std::vector<uint32_t> bases(24 * 3), tab(3 * PLUME_TAB_WORDS), res(24 * 2);
+    std::vector<uint8_t> jobflags(3), itemflags(1, 0), resinf(2);
+    VerifyArgs a; memset(&a, 0, sizeof a);
+    a.version = 2; a.n = 1; a.c = cb; a.s = sb; a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
+    a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data(); a.gtab = gtab.data();
+    jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
+    for (int j = 0; j < 3; j++) { st_jac_soa(a.bases, 3, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
+    table_build(a.tab, a.bases, a.jobflags, 3, 0, 3);
+    std::vector<int8_t> dig(4 * PLUME_NDIG);
+    verify_msm(a, 0, 0, a.gtab, dig.data(), 1);
+    jac r; ld_jac_soa(r, a.res, 2, 0); r.inf = a.resinf[0];
+    fe ox = fe_zero(), oy = fe_zero();
+    if (!r.inf) { fe zi, zi2; fe_inv(zi, r.z); fe_sqr(zi2, zi); fe_mul(ox, r.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(oy, r.y, zi2); }
+    store_affine_be(ob, ox, oy, r.inf != 0);
+    memcpy(out, ob, 64);
+    return 1;
 }
 
 int ds_h2c_batch(uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out) {

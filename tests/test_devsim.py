@@ -222,3 +222,19 @@ def test_sec1_compressed_ingest(ver):
     bad = [(c[7], int(o), w) for c, o, w in zip(cases, ok, want) if int(o) != w]
     assert not bad, bad
     assert sum(want) >= 2   # the honest mutations still verify
+
+
+def test_verify_equation1_wide_digits_special_scalars():
+    """s*G - c*pk through the verify multi-scalar body for scalars that hit the w = 8 digit extremes (+-128, sign bytes,
+    top digit), and for pk = +-G where the two bases coincide"""
+    rng = random.Random(33)
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    specials = [1, 2, 127, 128, 129, 255, 256, 0x8080, 0x80808080, 2**127, 2**127 - 1, 2**128 - 1, 2**128, lam, (128 * lam) % N, N - 128, N - 1,
+                int("80" * 16, 16), int("7f" * 16, 16), int("ff" * 16, 16), (int("80" * 16, 16) * lam + int("80" * 16, 16)) % N]
+    pks = [O.G, O.pt_neg(O.G), O.pt_mul(rng.randrange(1, N), O.G)]
+    for pk in pks:
+        for s_ in specials + [rng.randrange(1, N) for _ in range(4)]:
+            for c_ in (1, s_, rng.randrange(1, N)):
+                want = O.pt_add(O.pt_mul(s_, O.G), O.pt_neg(O.pt_mul(c_, pk)))
+                got = D.eq1(s_.to_bytes(32, "big"), c_.to_bytes(32, "big"), O.pt_bytes(pk))
+                assert got == O.pt_bytes(want), (hex(s_), hex(c_))

@@ -199,6 +199,13 @@ class Engine:
         self._chk(self._lib.plume_verify_batch_device(self._ctx, int(version), int(n), d(msgs), d(msg_off), int(msgs_bytes), d(pk), d(nullifier), d(c), d(s),
                                                       d(r_point), d(hashed_to_curve_r), d(ok), C.c_void_p(st)), "plume_verify_batch_device")
 
+    def verify_batch_sec1_device(self, version, n, msgs, msg_off, msgs_bytes, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, ok, stream=None):
+        import torch
+        st = (stream or torch.cuda.current_stream(self.device_id)).cuda_stream
+        d = self._dp
+        self._chk(self._lib.plume_verify_batch_sec1_device(self._ctx, int(version), int(n), d(msgs), d(msg_off), int(msgs_bytes), d(pk33), d(nullifier33), d(c), d(s),
+                                                           d(r_point33), d(hashed_to_curve_r33), d(ok), C.c_void_p(st)), "plume_verify_batch_sec1_device")
+
     def sign_batch_device(self, version, n, msgs, msg_off, msgs_bytes, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, stream=None):
         import torch
         st = (stream or torch.cuda.current_stream(self.device_id)).cuda_stream

@@ -56,7 +56,7 @@ struct plume_ctx {
     hipStream_t stream = nullptr;
     size_t chunk = (size_t)1 << 20;
     int jobs_per_lane = kTableJobsPerLane;
-    DevBuf gtab, bases, jobflags, itemflags, tab, res, resinf, res2, res2inf, pkaff, sink;
+    DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, res, resinf, res2, res2inf, pkaff, sink;
     DevBuf dec[4], preflags;   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
     DevBuf in_msgs, in_off, in_a, in_b, in_c, in_d, in_e, in_f, out_a, out_b, out_c, out_d, out_e, out_f, out_g;  // staging for the host-pointer API
     StageTimer timer;
@@ -87,7 +87,7 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     // generator wide window table (1..128)*G: one lane, once
-    if (ctx->gtab.ensure(PLUME_GTAB8_WORDS * 4) || ctx->bases.ensure(24 * 4) || ctx->jobflags.ensure(4)) { delete ctx; return PLUME_ERR_HIP; }
+    if (ctx->gtab.ensure(PLUME_GTAB8_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(24 * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64)) { delete ctx; return PLUME_ERR_HIP; }
     uint32_t hb[24];
     {
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
@@ -99,6 +99,9 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
     launch_gtab8(ctx->gtab.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    launch_gcomb(ctx->gcomb.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->stream);   // fixed-base comb for the signer
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = ctx;
     return 0;
 }
@@ -107,7 +110,7 @@ extern "C" void plume_destroy(plume_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf* b : {&ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
+    for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
                       &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->in_msgs, &ctx->in_off, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->out_a, &ctx->out_b,
                       &ctx->out_c, &ctx->out_d, &ctx->out_e, &ctx->out_f, &ctx->out_g})
         b->release();
@@ -158,7 +161,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
     a.gres = ctx->res.as<uint32_t>(); a.gresinf = ctx->resinf.as<uint8_t>(); a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>();
     a.itemflags = ctx->itemflags.as<uint8_t>(); a.pkaff = ctx->pkaff.as<uint32_t>(); a.tab = ctx->tab.as<uint32_t>();
-    a.hres = ctx->res2.as<uint32_t>(); a.hresinf = ctx->res2inf.as<uint8_t>(); a.gtab = ctx->gtab.as<uint32_t>();
+    a.hres = ctx->res2.as<uint32_t>(); a.hresinf = ctx->res2inf.as<uint8_t>(); a.gtab = ctx->gtab.as<uint32_t>(); a.gcomb = ctx->gcomb.as<uint32_t>();
     StageTimer& t = ctx->timer;
     t.begin(st);
     launch_sign_gmul(a, st); t.stage("sign_gmul", st);

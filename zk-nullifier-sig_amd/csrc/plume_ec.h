@@ -280,6 +280,42 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
     }
 }
 
+// ------------------------------------------------------------------------------- fixed-base comb (generator only)
+// k*G with NO doublings: k = sum d_i 256^i (Booth w = 8, d_i in [-128, 128], i = 0..32) and a precomputed table
+// comb[i][e] = (e+1) * 256^i * G  (33 windows x 128 entries, 528 KiB, L2-resident).  33 mixed additions per
+// multiplication instead of 128 doublings + 34 additions; used by the signer's pk = sk*G and R = r*G
+// (rust-k256/src/randomizedsigner.rs:51,53).
+#define PLUME_COMB_WINDOWS 33
+#define PLUME_COMB_WORDS (PLUME_COMB_WINDOWS * PLUME_GTAB8_WORDS)
+PLUME_HD int booth_digit8_256(const uint32_t m[8], int k) {   // k is a runtime loop index here (no unrolling)
+    const int lo = 8 * k - 1;
+    uint32_t u;
+    if (lo < 0) {
+        u = (m[0] << 1) & 0x1FF;
+    } else {
+        const uint32_t wi = (uint32_t)lo >> 5, sh = (uint32_t)lo & 31;
+        uint32_t a = 0, b = 0;
+        PLUME_UNROLL for (int i = 0; i < 8; i++) { a = (wi == (uint32_t)i) ? m[i] : a; b = (wi + 1 == (uint32_t)i) ? m[i] : b; }
+        u = ((a >> sh) | (sh > 23 ? (b << (32 - sh)) : 0u)) & 0x1FF;
+    }
+    return (int)(u & 1) + (int)((u >> 1) & 127) - (int)((u >> 8) << 7);
+}
+PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
+    acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
+    PLUME_NOUNROLL for (int i = 0; i < PLUME_COMB_WINDOWS; i++) {
+        const int d = booth_digit8_256(k.v, i);
+        if (d != 0) {
+            const int ad = d < 0 ? -d : d;
+            const uint32_t* e = comb + ((size_t)i * PLUME_GTAB8_ENTRIES + (size_t)(ad - 1)) * PLUME_TAB_ENTRY_WORDS;
+            fe qx, qy;
+            ld_fe(qx, e);
+            ld_fe(qy, e + 8);
+            if (d < 0) fe_neg(qy, qy);
+            jac_madd(acc, qx, qy);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------- multi-scalar loop
 // acc = sum over slots of digit * table point.  Slot s uses table tabs[s >> 1]; odd slots are the lambda
 // halves (beta*x).  dig: digits of slot s, window i at dig[(s*PLUME_NDIG + i)*stride].  A NULL table (or a

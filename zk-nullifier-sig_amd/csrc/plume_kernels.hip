@@ -69,20 +69,22 @@ __global__ __launch_bounds__(kBlock) void k_verify_finalize(VerifyArgs a) {
 }
 
 __global__ __launch_bounds__(kBlock) void k_sign_gmul(SignArgs a) {
-#if PLUME_GTAB_IN_LDS
-    __shared__ __attribute__((aligned(16))) uint32_t s_gtab[PLUME_GTAB8_WORDS];
-#endif
-    __shared__ int8_t s_dig[2 * PLUME_NDIG * kBlock];
-#if PLUME_GTAB_IN_LDS
-    stage_gtab(s_gtab, a.gtab);
-    const uint32_t* gt = s_gtab;
-#else
-    const uint32_t* gt = a.gtab;
-#endif
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
-    if (i < a.n) sign_gmul(a, i, which, gt, s_dig + threadIdx.x, kBlock);
+    if (i < a.n) sign_gmul(a, i, which);
+}
+
+// one-time: comb[i] = table of 256^i * G, i = 0..32.  Lane i first walks 8*i doublings from G (a few hundred
+// microseconds once per context), then builds its 128-entry window.
+__global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* 24 x 33 words scratch */, uint8_t* flags /* 33 */) {
+    const uint32_t i = threadIdx.x;
+    if (blockIdx.x != 0 || i >= PLUME_COMB_WINDOWS) return;
+    jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
+    for (uint32_t d = 0; d < 8 * i; d++) jac_dbl(g);
+    st_jac_soa(bases, PLUME_COMB_WINDOWS, i, g);
+    flags[i] = PLUME_JOB_OK;
+    table_build<PLUME_GTAB8_ENTRIES>(comb, bases, flags, PLUME_COMB_WINDOWS, i, 1);
 }
 
 __global__ __launch_bounds__(kBlock) void k_sign_h2c(SignArgs a) {
@@ -201,6 +203,7 @@ void launch_sign_final(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k
 void launch_decompress(const DecompressArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_decompress, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_h2c_only(const H2cArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_only, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, hipStream_t st) { hipLaunchKernelGGL(k_gtab8, dim3(1), dim3(64), 0, st, gtab8, base_g, flag); }
+void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, hipStream_t st) { hipLaunchKernelGGL(k_gcomb, dim3(1), dim3(64), 0, st, comb, bases, flags); }
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_microbench, dim3(blocks), dim3(kBlock), 0, st, kind, iters, sink);
 }

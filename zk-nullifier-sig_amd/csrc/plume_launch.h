@@ -23,6 +23,7 @@ void launch_sign_final(const SignArgs& a, hipStream_t st);
 void launch_decompress(const DecompressArgs& a, hipStream_t st);
 void launch_h2c_only(const H2cArgs& a, hipStream_t st);
 void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, hipStream_t st);
+void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, hipStream_t st);
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st);
 
 }  // namespace plume

@@ -255,6 +255,7 @@ struct SignArgs {
     uint32_t* tab;                       // n tables
     uint32_t* hres;  uint8_t* hresinf;   // 2n tasks: sk*H, r*H
     const uint32_t* gtab;
+    const uint32_t* gcomb;               // fixed-base comb of G (PLUME_COMB_WORDS)
 };
 
 // scalars reduced mod n for the arithmetic, status bit if out of range (the Rust types cannot hold such values)
@@ -278,9 +279,16 @@ PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, const u
     st_jac_soa(res, nt, t, acc);
     resinf[t] = (uint8_t)acc.inf;
 }
-PLUME_HD void sign_gmul(const SignArgs& a, uint32_t item, uint32_t which, const uint32_t* gtab, int8_t* dig, uint32_t stride) {
+// task t = 2*item + which: sk*G (which 0) or r*G (which 1) by the doubling-free comb
+PLUME_HD void sign_gmul(const SignArgs& a, uint32_t item, uint32_t which) {
     if (which == 0 && a.pk_in) return;   // pk supplied: sk*G not needed
-    sign_mul(a, item, which, gtab, a.gres, a.gresinf, dig, stride, true);
+    const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
+    sc k;
+    (void)load_scalar_reduced(k, (which ? a.r : a.sk) + 32 * (size_t)item);
+    jac acc;
+    comb_mul_g(acc, k, a.gcomb);
+    st_jac_soa(a.gres, nt, t, acc);
+    a.gresinf[t] = (uint8_t)acc.inf;
 }
 PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
     const size_t nt = 2 * (size_t)a.n;
