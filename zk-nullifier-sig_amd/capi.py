@@ -20,7 +20,9 @@ class PlumeHipError(RuntimeError):
 
 
 def library_path() -> Path:
-    return _HERE / "libplume_hip.so"
+    """the in-tree build; PLUME_HIP_LIB selects another build of the same library (A/B tuning runs only)"""
+    alt = os.environ.get("PLUME_HIP_LIB")
+    return Path(alt).resolve() if alt else _HERE / "libplume_hip.so"
 
 
 _lib = None

@@ -10,6 +10,14 @@
 // the ~10^6 VALU instructions per item.
 #include "plume_launch.h"
 
+#ifndef PLUME_MSM_WAVES
+#define PLUME_MSM_WAVES 0   // 0: compiler default; N: __launch_bounds__(kBlock, N) for the multi-scalar kernels
+#endif
+#if PLUME_MSM_WAVES
+#define PLUME_MSM_BOUNDS __launch_bounds__(kBlock, PLUME_MSM_WAVES)
+#else
+#define PLUME_MSM_BOUNDS __launch_bounds__(kBlock)
+#endif
 #ifndef PLUME_GTAB_IN_LDS
 #define PLUME_GTAB_IN_LDS 0
 #endif
@@ -46,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void k_tables(uint32_t* tab, const uint32_t
 
 // blocks [0, nb): equation 1 (s*G - c*pk); blocks [nb, 2nb): equation 2 (s*H - c*nullifier) — the role is uniform
 // per workgroup so the generator-table-in-LDS path never diverges inside a wavefront
-__global__ __launch_bounds__(kBlock) void k_verify_msm(VerifyArgs a) {
+__global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
 #if PLUME_GTAB_IN_LDS
     __shared__ __attribute__((aligned(16))) uint32_t s_gtab[PLUME_GTAB8_WORDS];
 #endif
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void k_sign_h2c(SignArgs a) {
     if (i < a.n) sign_h2c(a, i);
 }
 
-__global__ __launch_bounds__(kBlock) void k_sign_hmul(SignArgs a) {
+__global__ PLUME_MSM_BOUNDS void k_sign_hmul(SignArgs a) {
     __shared__ int8_t s_dig[2 * PLUME_NDIG * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
