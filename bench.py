@@ -53,6 +53,17 @@ def shard_bounds(total: int, rank: int, world: int):
     return (total * rank) // world, (total * (rank + 1)) // world
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json: FETCH_SIZE + WRITE_SIZE,
+    separate --pmc runs of this same bench; raw counter values, see the file's _notes for the gfx950 calibration caveat), or None"""
+    try:
+        f = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))[-1]
+        d = json.loads(f.read_text())[kernel]
+        return int((d["FETCH_SIZE_KB_raw"] + d["WRITE_SIZE_KB_raw"]) * 1024), f"profiles/{f.name} (2^20-item launch)"
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(version: int):
     """plain-C oracle on the host cores, bounded sample of the same workload"""
     import numpy as np  # noqa: F401

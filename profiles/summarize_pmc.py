@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 --pmc passes under gpurun_out/pmc_{sq,sq2,fetch,write}/ into profiles/<round>_pmc_summary.json.
+usage: python profiles/summarize_pmc.py r01"""
+import collections
+import csv
+import json
+import sys
+
+
+def load(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0]
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[name]["_dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for k, c in (("_vgpr", "VGPR_Count"), ("_sgpr", "SGPR_Count"), ("_lds", "LDS_Block_Size"), ("_scratch", "Scratch_Size")):
+            agg[name][k] = [int(r[c])]
+    return agg
+
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = {}
+for tag in ("sq", "sq2"):
+    for k, v in load(f"gpurun_out/pmc_{tag}/{tag}_counter_collection.csv").items():
+        if not (k.startswith("plume::k_verify") or k == "plume::k_tables"):
+            continue
+        d = out.setdefault(k, {})
+        for c, x in v.items():
+            if c == "_dur_ns":
+                d.setdefault("_dur_ns_max", max(x))
+            else:
+                d[c] = max(x) if k == "plume::k_tables" else sum(x) / len(x)
+fe, wr = load("gpurun_out/pmc_fetch/fetch_counter_collection.csv"), load("gpurun_out/pmc_write/write_counter_collection.csv")
+for k in out:
+    if k in fe:
+        out[k]["FETCH_SIZE_KB_raw"] = max(fe[k]["FETCH_SIZE"])
+    if k in wr:
+        out[k]["WRITE_SIZE_KB_raw"] = max(wr[k]["WRITE_SIZE"])
+out["_notes"] = {
+    "collection": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv, separate passes (sq, sq2, FETCH_SIZE, WRITE_SIZE); "
+                  "command: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras",
+    "units": "FETCH_SIZE / WRITE_SIZE in KB as reported. MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced streaming reads by 2x on gfx950; "
+             "the access pattern here (16-byte per-lane gathers of 64-byte table records) is uncalibrated, as is WRITE_SIZE",
+    "k_tables": "max over launches (the first launch of each process is the one-off generator table)"}
+json.dump(out, open(f"profiles/{rnd}_pmc_summary.json", "w"), indent=1)
+for k, d in out.items():
+    if not k.startswith("_"):
+        print(k, {c: "%.3g" % x for c, x in sorted(d.items()) if c in ("FETCH_SIZE_KB_raw", "WRITE_SIZE_KB_raw", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE", "_vgpr", "_scratch", "_dur_ns_max")})
