@@ -238,3 +238,21 @@ def test_verify_equation1_wide_digits_special_scalars():
                 want = O.pt_add(O.pt_mul(s_, O.G), O.pt_neg(O.pt_mul(c_, pk)))
                 got = D.eq1(s_.to_bytes(32, "big"), c_.to_bytes(32, "big"), O.pt_bytes(pk))
                 assert got == O.pt_bytes(want), (hex(s_), hex(c_))
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_fuzzed_verify_batch_vs_oracle(ver):
+    """device code on the host: 384 honest-then-mutated items, ok[] == C oracle"""
+    from tests import _fuzz, synth
+    n = 384
+    b = synth.sign_inputs(n, start=700000)
+    rng = random.Random(77 + ver)
+    msgs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 31, 32, 33, 55, 56, 64, 100]))) for _ in range(n)]
+    mb, off = OC.pack_msgs(msgs)
+    signed = OC.sign_batch(ver, mb, off, b["sk"], b["r"], nthreads=8)
+    v = _fuzz.fuzz_verify_batch(ver, signed, dict(msgs=mb, off=off), seed=5 + ver)
+    args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"] if ver == 1 else None, v["hashed_to_curve_r"] if ver == 1 else None)
+    got = D.verify_batch(*args)
+    want = OC.verify_batch(*args, nthreads=8)
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
+    assert 0.2 * n < int(got.sum()) < 0.8 * n

@@ -279,3 +279,24 @@ def test_sec1_compressed_ingest(eng, ver):
     bb = eng.verify_batch_sec1(ver, v["msgs"], v["off"], _sec1.compress(v["pk"]), _sec1.compress(v["nullifier"]), v["c"], v["s"],
                                _sec1.compress(v["r_point"]) if ver == 1 else None, _sec1.compress(v["hashed_to_curve_r"]) if ver == 1 else None)
     assert np.array_equal(a, bb) and np.array_equal(a, synth.expected_ok(n, 123456))
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_fuzzed_verify_batch_vs_oracle(eng, ver):
+    """8192 items: honest signatures with random mutations (bit flips, garbage records, identities, boundary scalars,
+    negated / non-canonical points, cross-item fields, swapped fields) — ok[] must equal the C oracle's byte for byte"""
+    from tests import _fuzz
+    import os
+    n = 8192
+    b = synth.sign_inputs(n, start=900000)
+    rng = random.Random(4242 + ver)
+    msgs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 31, 32, 33, 55, 56, 64, 100]))) for _ in range(n)]
+    mb, off = OC.pack_msgs(msgs)
+    signed = eng.sign_batch(ver, mb, off, b["sk"], b["r"])
+    v = _fuzz.fuzz_verify_batch(ver, signed, dict(msgs=mb, off=off), seed=99 + ver)
+    args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"] if ver == 1 else None, v["hashed_to_curve_r"] if ver == 1 else None)
+    got = eng.verify_batch(*args)
+    want = OC.verify_batch(*args, nthreads=min(64, os.cpu_count() or 8))
+    diff = np.nonzero(got != want)[0]
+    assert len(diff) == 0, diff[:10]
+    assert 0.25 * n < int(got.sum()) < 0.75 * n     # the batch really mixes accepted and rejected items
