@@ -129,6 +129,10 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);
     for (uint32_t eq = 0; eq < 2; eq++)
         for (uint32_t i = 0; i < n; i++) verify_msm(a, i, eq, a.gtab, dig.data() + (i % B), B);
+    if (version == 2) {                                   // mirrors launch_normalize
+        const size_t npts = 2 * (size_t)n, nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;
+        for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.res, a.resinf, npts, lane, nlanes);
+    }
     for (uint32_t i = 0; i < n; i++) verify_finalize(a, i);
     return 0;
 }
@@ -148,10 +152,18 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);
     for (uint32_t w = 0; w < 2; w++)
         for (uint32_t i = 0; i < n; i++) sign_gmul(a, i, w);
+    {
+        const size_t npts = 2 * (size_t)n, nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;
+        for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.gres, a.gresinf, npts, lane, nlanes);
+    }
     for (uint32_t i = 0; i < n; i++) sign_h2c(a, i);
     for (size_t j0 = 0; j0 < n; j0 += L) table_build(a.tab, a.bases, a.jobflags, n, j0, (int)((n - j0) < (size_t)L ? (n - j0) : L));
     for (uint32_t w = 0; w < 2; w++)
         for (uint32_t i = 0; i < n; i++) sign_hmul(a, i, w, dig.data() + (i % B), B);
+    {
+        const size_t npts = 2 * (size_t)n, nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;
+        for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.hres, a.hresinf, npts, lane, nlanes);
+    }
     for (uint32_t i = 0; i < n; i++) sign_final(a, i);
     return 0;
 }

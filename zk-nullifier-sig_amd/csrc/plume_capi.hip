@@ -143,6 +143,7 @@ static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* m
     launch_verify_ingest(a, st); t.stage("verify_ingest_h2c", st);
     launch_tables(a.tab, a.bases, a.jobflags, 3 * n, ctx->jobs_per_lane, st); t.stage("tables", st);
     launch_verify_msm(a, st); t.stage("verify_msm", st);
+    if (version == 2) { launch_normalize(a.res, a.resinf, 2 * n, st); t.stage("to_affine", st); }   // V2 hashes the computed R', Hr'
     launch_verify_finalize(a, st); t.stage("verify_finalize", st);
     HIPCHK(hipGetLastError());
     return 0;
@@ -165,9 +166,11 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     StageTimer& t = ctx->timer;
     t.begin(st);
     launch_sign_gmul(a, st); t.stage("sign_gmul", st);
+    launch_normalize(a.gres, a.gresinf, 2 * n, st); t.stage("to_affine_g", st);
     launch_sign_h2c(a, st); t.stage("sign_h2c", st);
     launch_tables(a.tab, a.bases, a.jobflags, n, ctx->jobs_per_lane, st); t.stage("tables", st);
     launch_sign_hmul(a, st); t.stage("sign_hmul", st);
+    launch_normalize(a.hres, a.hresinf, 2 * n, st); t.stage("to_affine_h", st);
     launch_sign_final(a, st); t.stage("sign_final", st);
     // the reference zeroizes secrets: wipe the device-side images derived from sk / r
     HIPCHK(hipMemsetAsync(ctx->res.p, 0, 24 * 4 * 2 * n, st));

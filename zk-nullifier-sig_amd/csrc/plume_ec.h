@@ -284,6 +284,40 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
     }
 }
 
+// ------------------------------------------------------------------------------------ batched affine conversion
+// Jacobian -> affine for the points of a SoA array, PLUME_NORM_K points per lane sharing ONE field inversion
+// (Montgomery's trick, prefix products kept in registers).  Lane `lane` of `nlanes` handles points lane + j*nlanes, so
+// every load/store is coalesced across the wavefront.  X and Y are overwritten with the affine coordinates (Z is left
+// as it was and must no longer be used); points flagged infinite are skipped.
+#define PLUME_NORM_K 8
+PLUME_HD void normalize_points(uint32_t* pts, const uint8_t* inf, size_t npts, size_t lane, size_t nlanes) {
+    fe z[PLUME_NORM_K], pre[PLUME_NORM_K];
+    fe acc = fe_small(1);
+    PLUME_UNROLL for (int j = 0; j < PLUME_NORM_K; j++) {
+        const size_t idx = lane + (size_t)j * nlanes;
+        const bool live = idx < npts && !inf[idx < npts ? idx : 0];
+        if (live) ld_fe_soa(z[j], pts + 16 * npts, npts, idx); else z[j] = fe_small(1);
+        pre[j] = acc;
+        fe_mul(acc, acc, z[j]);
+    }
+    fe inv;
+    fe_inv(inv, acc);
+    PLUME_UNROLL for (int j = PLUME_NORM_K - 1; j >= 0; j--) {
+        const size_t idx = lane + (size_t)j * nlanes;
+        const bool live = idx < npts && !inf[idx < npts ? idx : 0];
+        fe zi, zi2, x, y;
+        fe_mul(zi, inv, pre[j]);
+        fe_mul(inv, inv, z[j]);
+        if (live) {
+            ld_fe_soa(x, pts, npts, idx); ld_fe_soa(y, pts + 8 * npts, npts, idx);
+            fe_sqr(zi2, zi);
+            fe_mul(x, x, zi2);
+            fe_mul(zi2, zi2, zi); fe_mul(y, y, zi2);
+            st_fe_soa(pts, npts, idx, x); st_fe_soa(pts + 8 * npts, npts, idx, y);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- fixed-base comb (generator only)
 // k*G with NO doublings: k = sum d_i 256^i (Booth w = 8, d_i in [-128, 128], i = 0..32) and a precomputed table
 // comb[i][e] = (e+1) * 256^i * G  (33 windows x 128 entries, 528 KiB, L2-resident).  33 mixed additions per

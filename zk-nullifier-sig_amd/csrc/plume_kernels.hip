@@ -113,6 +113,12 @@ __global__ __launch_bounds__(kBlock) void k_sign_final(SignArgs a) {
     if (i < a.n) sign_final(a, i);
 }
 
+// batched Jacobian -> affine (8 points per lane, one inversion): V2 verify results, signer outputs
+__global__ __launch_bounds__(kBlock) void k_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, size_t nlanes) {
+    size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (lane < nlanes) normalize_points(pts, inf, npts, lane, nlanes);
+}
+
 __global__ __launch_bounds__(kBlock) void k_decompress(DecompressArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) decompress_item(a, i);
@@ -208,6 +214,10 @@ void launch_sign_gmul(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_
 void launch_sign_h2c(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_h2c, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_hmul(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_hmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_final(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_final, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, hipStream_t st) {
+    size_t nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;
+    hipLaunchKernelGGL(k_normalize, dim3(nblocks(nlanes)), dim3(kBlock), 0, st, pts, inf, npts, nlanes);
+}
 void launch_decompress(const DecompressArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_decompress, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_h2c_only(const H2cArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_only, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, hipStream_t st) { hipLaunchKernelGGL(k_gtab8, dim3(1), dim3(64), 0, st, gtab8, base_g, flag); }

@@ -20,6 +20,7 @@ void launch_sign_gmul(const SignArgs& a, hipStream_t st);
 void launch_sign_h2c(const SignArgs& a, hipStream_t st);
 void launch_sign_hmul(const SignArgs& a, hipStream_t st);
 void launch_sign_final(const SignArgs& a, hipStream_t st);
+void launch_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, hipStream_t st);
 void launch_decompress(const DecompressArgs& a, hipStream_t st);
 void launch_h2c_only(const H2cArgs& a, hipStream_t st);
 void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, hipStream_t st);

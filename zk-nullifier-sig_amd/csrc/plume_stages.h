@@ -209,13 +209,7 @@ PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
                 hashed = true;
             }
         } else {
-            // affine R', Hr' with one shared inversion
-            fe zr = rc.inf ? fe_small(1) : rc.z, zh = hc.inf ? fe_small(1) : hc.z, zz, inv, zri, zhi, t;
-            fe_mul(zz, zr, zh);
-            fe_inv(inv, zz);
-            fe_mul(zri, inv, zh); fe_mul(zhi, inv, zr);
-            fe_sqr(t, zri); fe_mul(rc.x, rc.x, t); fe_mul(t, t, zri); fe_mul(rc.y, rc.y, t);
-            fe_sqr(t, zhi); fe_mul(hc.x, hc.x, t); fe_mul(t, t, zhi); fe_mul(hc.y, hc.y, t);
+            // R', Hr' were made affine by the batched conversion stage (normalize_points): X, Y are the coordinates
             enc_pt pts[3];
             pts[0] = enc_of(nx, ny, fnul == PLUME_JOB_INF);
             pts[1] = enc_of(rc.x, rc.y, rc.inf != 0);
@@ -281,8 +275,8 @@ PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, const u
 }
 // task t = 2*item + which: sk*G (which 0) or r*G (which 1) by the doubling-free comb
 PLUME_HD void sign_gmul(const SignArgs& a, uint32_t item, uint32_t which) {
-    if (which == 0 && a.pk_in) return;   // pk supplied: sk*G not needed
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
+    if (which == 0 && a.pk_in) { a.gresinf[t] = 1; return; }   // pk supplied: sk*G not needed (flagged so the affine conversion skips it)
     sc k;
     (void)load_scalar_reduced(k, (which ? a.r : a.sk) + 32 * (size_t)item);
     jac acc;
@@ -306,10 +300,7 @@ PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
         jac p;
         ld_jac_soa(p, a.gres, nt, 2 * (size_t)i); p.inf = a.gresinf[2 * (size_t)i];
         pinf = p.inf != 0;
-        fe zi, zi2;
-        fe z = pinf ? fe_small(1) : p.z;
-        fe_inv(zi, z); fe_sqr(zi2, zi);
-        fe_mul(px, p.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(py, p.y, zi2);
+        px = p.x; py = p.y;   // affine already (normalize_points ran on gres)
         fe_normalize(px); fe_normalize(py);
     }
     if (pinf) { px = fe_zero(); py = fe_zero(); }
@@ -334,16 +325,7 @@ PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
     ld_jac_soa(R, a.gres, nt, 2 * (size_t)i + 1); R.inf = a.gresinf[2 * (size_t)i + 1];
     ld_jac_soa(nul, a.hres, nt, 2 * (size_t)i); nul.inf = a.hresinf[2 * (size_t)i];
     ld_jac_soa(hr, a.hres, nt, 2 * (size_t)i + 1); hr.inf = a.hresinf[2 * (size_t)i + 1];
-    // three affine conversions, one inversion
-    fe z0 = R.inf ? fe_small(1) : R.z, z1 = nul.inf ? fe_small(1) : nul.z, z2 = hr.inf ? fe_small(1) : hr.z;
-    fe p01, p012, inv, i0, i1, i2, t;
-    fe_mul(p01, z0, z1); fe_mul(p012, p01, z2);
-    fe_inv(inv, p012);
-    fe_mul(i2, inv, p01); fe_mul(inv, inv, z2);   // inv = 1/(z0 z1)
-    fe_mul(i1, inv, z0); fe_mul(i0, inv, z1);
-    fe_sqr(t, i0); fe_mul(R.x, R.x, t); fe_mul(t, t, i0); fe_mul(R.y, R.y, t);
-    fe_sqr(t, i1); fe_mul(nul.x, nul.x, t); fe_mul(t, t, i1); fe_mul(nul.y, nul.y, t);
-    fe_sqr(t, i2); fe_mul(hr.x, hr.x, t); fe_mul(t, t, i2); fe_mul(hr.y, hr.y, t);
+    // R, nullifier, Hr are affine already (normalize_points ran on gres and hres)
     fe px, py, Hx, Hy;
     ld_fe_soa(px, a.pkaff, a.n, i); ld_fe_soa(py, a.pkaff + 8 * (size_t)a.n, a.n, i);
     bool hinf = job_state(a.jobflags[i]) == PLUME_JOB_INF;
