@@ -208,10 +208,11 @@ def main():
         value = n * world * a.steps / elapsed
         stages = {k: round(vv / a.steps, 4) for k, vv in stage_acc.items()}
         line = {
-            "metric": f"PLUME V{ver} verifies/sec (secp256k1 + SHA-256), batch 2^{a.log2_batch} per GPU", "value": round(value, 1), "unit": "verifies/s",
+            "metric": f"PLUME verifies/sec (secp256k1 V{ver}) at batch=2^{a.log2_batch} per GPU", "value": round(value, 1), "unit": "verifies/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32x8 limbs (v_mad_u64_u32 integer)", "data": "synthetic",
-            "config": {"workload": f"batch 2^{a.log2_batch} PLUME V{ver} verify per GPU, 32-byte messages, 1/16 corrupted, inputs resident in HBM",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]/metric: batch 2^{a.log2_batch} PLUME V{ver} verify (secp256k1 + SHA-256) per GPU, 32-byte messages, 1/16 corrupted, "
+                                   f"inputs resident in HBM; arithmetic in 8x32-bit limbs through v_mad_u64_u32",
                        "items_per_gpu": n, "global_items_per_step": n * world, "parallelism": f"shard x{world}, no collective"},
             "stage_ms": stages,
         }
