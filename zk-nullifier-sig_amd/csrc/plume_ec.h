@@ -252,7 +252,16 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
         jac cur = b;
         uint32_t* e = tab + job * (size_t)(ENTRIES * PLUME_TAB_ENTRY_WORDS);
         PLUME_NOUNROLL for (int k = 0; k < ENTRIES; k++) {
-            if (k == 1) jac_dbl(cur);
+            // entry k holds (k+1)P.  Even multiples are doublings of an earlier entry (3M+4S instead of a 12M+4S addition):
+            // 2P = 2*P, 3P = 2P+P, 4P = 2*(2P), 5P = 4P+P, 6P = 2*(3P), ...  The half entry is re-read from the table this lane
+            // has just written (X, Y, Z are still the Jacobian coordinates in pass 1).
+            if (k >= 1 && (k & 1)) {
+                if (k > 1) {
+                    const uint32_t* hsrc = tab + job * (size_t)(ENTRIES * PLUME_TAB_ENTRY_WORDS) + (size_t)((k + 1) / 2 - 1) * PLUME_TAB_ENTRY_WORDS;
+                    ld_fe(cur.x, hsrc + 0); ld_fe(cur.y, hsrc + 8); ld_fe(cur.z, hsrc + 16);
+                }
+                jac_dbl(cur);
+            }
 #if PLUME_TABLE_MADD
             else if (k > 1) { if (zone) jac_madd(cur, b.x, b.y); else jac_add(cur, b); }
 #else
