@@ -300,3 +300,27 @@ def test_fuzzed_verify_batch_vs_oracle(eng, ver):
     diff = np.nonzero(got != want)[0]
     assert len(diff) == 0, diff[:10]
     assert 0.25 * n < int(got.sum()) < 0.75 * n     # the batch really mixes accepted and rejected items
+
+
+def test_odd_batch_sizes_and_long_messages(eng):
+    """batch sizes around wavefront / workgroup boundaries, and messages far longer than one SHA block"""
+    rng = random.Random(2718)
+    for n in (1, 2, 63, 64, 65, 127, 255, 256, 257, 511, 513):
+        b = synth.sign_inputs(n, start=31337)
+        got = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+        want = OC.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"], nthreads=8)
+        for k in got:
+            assert np.array_equal(got[k], want[k]), (n, k)
+        ok = eng.verify_batch(1, b["msgs"], b["off"], got["pk"], got["nullifier"], got["c"], got["s"], got["r_point"], got["hashed_to_curve_r"])
+        assert ok.all() and len(ok) == n
+    lens = [0, 1, 1000, 4096, 65536, 100001, 55, 56]
+    msgs = [bytes(rng.randrange(256) for _ in range(l)) for l in lens]
+    mb, off = OC.pack_msgs(msgs)
+    b = synth.sign_inputs(len(lens), start=99)
+    for ver in (1, 2):
+        got = eng.sign_batch(ver, mb, off, b["sk"], b["r"])
+        want = OC.sign_batch(ver, mb, off, b["sk"], b["r"], nthreads=8)
+        for k in got:
+            assert np.array_equal(got[k], want[k]), (ver, k)
+        ok = eng.verify_batch(ver, mb, off, got["pk"], got["nullifier"], got["c"], got["s"], got["r_point"] if ver == 1 else None, got["hashed_to_curve_r"] if ver == 1 else None)
+        assert ok.all()
