@@ -56,6 +56,7 @@ struct plume_ctx {
     hipStream_t stream = nullptr;
     size_t chunk = (size_t)1 << 20;
     int jobs_per_lane = kTableJobsPerLane;
+    bool jobs_per_lane_forced = false;
     DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, res, resinf, res2, res2inf, pkaff, sink;
     DevBuf dec[4], preflags;   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
     DevBuf in_msgs, in_off, in_a, in_b, in_c, in_d, in_e, in_f, out_a, out_b, out_c, out_d, out_e, out_f, out_g;  // staging for the host-pointer API
@@ -83,7 +84,7 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
         return fail(PLUME_ERR_NODEV, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     plume_ctx* ctx = new plume_ctx();
     ctx->device = device_id;
-    if (const char* e = std::getenv("PLUME_JOBS_PER_LANE")) { int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->jobs_per_lane = v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_JOBS_PER_LANE")) { int v = std::atoi(e); if (v >= 1 && v <= 64) { ctx->jobs_per_lane = v; ctx->jobs_per_lane_forced = true; } }   // tuning knob
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     // generator wide window table (1..128)*G: one lane, once
@@ -125,6 +126,16 @@ extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
     return 0;
 }
 
+// table jobs per lane: more jobs share one inversion, but small batches need the lanes (>= ~4 workgroups per CU first)
+static int pick_jobs_per_lane(const plume_ctx* ctx, size_t njobs, bool kinds_of_three) {
+    if (ctx->jobs_per_lane_forced) return ctx->jobs_per_lane;
+    size_t l = njobs / ((size_t)256 * 4 * kBlock);
+    if (l > (size_t)ctx->jobs_per_lane) l = (size_t)ctx->jobs_per_lane;
+    if (kinds_of_three) { l = (l / 3) * 3; if (l < 3) l = 3; }   // keep pk / H / nullifier kinds aligned across a wavefront
+    if (l < 1) l = 1;
+    return (int)l;
+}
+
 // ------------------------------------------------------------------------------------------ device pipelines
 static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul,
                          const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, hipStream_t st,
@@ -141,7 +152,7 @@ static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* m
     StageTimer& t = ctx->timer;
     if (!continue_timer) t.begin(st);
     launch_verify_ingest(a, st); t.stage("verify_ingest_h2c", st);
-    launch_tables(a.tab, a.bases, a.jobflags, 3 * n, ctx->jobs_per_lane, st); t.stage("tables", st);
+    launch_tables(a.tab, a.bases, a.jobflags, 3 * n, pick_jobs_per_lane(ctx, 3 * n, true), st); t.stage("tables", st);
     launch_verify_msm(a, st); t.stage("verify_msm", st);
     if (version == 2) { launch_normalize(a.res, a.resinf, 2 * n, st); t.stage("to_affine", st); }   // V2 hashes the computed R', Hr'
     launch_verify_finalize(a, st); t.stage("verify_finalize", st);
@@ -168,7 +179,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     launch_sign_gmul(a, st); t.stage("sign_gmul", st);
     launch_normalize(a.gres, a.gresinf, 2 * n, st); t.stage("to_affine_g", st);
     launch_sign_h2c(a, st); t.stage("sign_h2c", st);
-    launch_tables(a.tab, a.bases, a.jobflags, n, ctx->jobs_per_lane, st); t.stage("tables", st);
+    launch_tables(a.tab, a.bases, a.jobflags, n, pick_jobs_per_lane(ctx, n, false), st); t.stage("tables", st);
     launch_sign_hmul(a, st); t.stage("sign_hmul", st);
     launch_normalize(a.hres, a.hresinf, 2 * n, st); t.stage("to_affine_h", st);
     launch_sign_final(a, st); t.stage("sign_final", st);
