@@ -50,6 +50,10 @@ const char* plume_last_error(void);
 const char* plume_version(void);
 /* Upper bound on items processed per internal pass (workspace is ~3.7 KB per in-flight item). Default 1<<20. */
 int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
+/* Host-pointer calls only: items per pipelined piece (default 1<<18, capped by the chunk size).  A call is cut into
+ * pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (three streams, two staging slots), so
+ * for batches of several pieces only the first upload and the last download are exposed.  Results do not depend on it. */
+int plume_set_host_piece(plume_ctx* ctx, size_t items_per_piece);
 
 /* ---- PlumeSignature::verify, batched  (rust-k256/src/lib.rs:93-145) -------------------------------------
  * version 1: V1 (v1specific = Some{r_point, hashed_to_curve_r}); version 2: V2 (r_point, hashed_to_curve_r NULL).

@@ -9,7 +9,7 @@ using namespace plume;
 struct Dump { uint32_t b0[8]; uint32_t uni[24]; fe u0, u1; fe xn, xd, y; jac q0, q1, h; uint32_t sha_abc[8]; fe c1; fe sq; fe ms; };
 
 __host__ __device__ void run(Dump& d, const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag) {
-    xmd_b0(d.b0, msg, mlen, pkx, tag, false);
+    xmd_b0(d.b0, msg, mlen, pkx, tag, PLUME_ENC_POINT);
     uint32_t x[8];
     xmd_bi(d.uni, d.b0, 1);
     for (int i = 0; i < 8; i++) x[i] = d.b0[i] ^ d.uni[i];

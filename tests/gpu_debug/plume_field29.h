@@ -166,4 +166,85 @@ PLUME_HD void fe29_sqr(fe29& r, const fe29& a) {
     fe29_reduce_cols(r, c);
 }
 
+// ---- v2: the carry of column k-1 is the 64-bit ADDEND of column k's first multiply-add, and the fold of the high half
+// (2^261 = 2^37 + 31264 mod p) is two more multiply-adds per low column: no 64-bit shifts or adds remain, only
+// alignbit / shift / mask on 32-bit halves.
+PLUME_HD uint64_t shr29(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    return ((uint64_t)(opaque_u32(hi) >> 29) << 32) | __builtin_amdgcn_alignbit(hi, lo, 29);
+#else
+    return x >> 29;
+#endif
+}
+// a * b + c as ONE v_mad_u64_u32 (the compiler otherwise strength-reduces small constants into 64-bit shift/add pairs)
+#ifndef PLUME_F29_ASM_MAD
+#define PLUME_F29_ASM_MAD 1
+#endif
+PLUME_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__) && PLUME_F29_ASM_MAD
+    uint64_t d, cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return (uint64_t)a * b + c;
+#endif
+}
+PLUME_HD uint64_t mad64k(uint32_t a, uint32_t k, uint64_t c) {   // k: wave-uniform constant (SGPR)
+#if defined(__HIP_DEVICE_COMPILE__) && PLUME_F29_ASM_MAD
+    uint64_t d, cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "s"(k), "v"(c));
+    return d;
+#elif defined(__HIP_DEVICE_COMPILE__)
+    return (uint64_t)a * opaque_u32(k) + c;
+#else
+    return (uint64_t)a * k + c;
+#endif
+}
+template <bool SQR>
+PLUME_HD void fe29_mul2_impl(fe29& r, const fe29& a, const fe29& b) {
+    uint32_t d[9];
+    if (SQR) { PLUME_UNROLL for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1; }
+    auto column = [&](uint64_t acc, int k) -> uint64_t {
+        PLUME_UNROLL for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= 9) continue;
+            if (!SQR) acc = mad64(a.v[i], b.v[j], acc);
+            else if (i < j) acc = mad64(a.v[i], d[j], acc);
+            else if (i == j) acc = mad64(a.v[i], a.v[i], acc);
+        }
+        return acc;
+    };
+    // high half: columns 9..16 -> h[0..7] (29 bits each) and h[8] (what is left)
+    uint32_t h[9];
+    uint64_t acc = 0;
+    PLUME_UNROLL for (int k = 9; k < 17; k++) {
+        acc = column(acc, k);
+        h[k - 9] = (uint32_t)acc & PLUME_FE29_MASK;
+        acc = shr29(acc);
+    }
+    h[8] = (uint32_t)acc;
+    // low half with the fold: column k += h[k] * 31264 + h[k-1] * 2^8
+    acc = 0;
+    PLUME_UNROLL for (int k = 0; k < 9; k++) {
+        acc = column(acc, k);
+        acc = mad64k(h[k], 31264u, acc);
+        if (k > 0) acc = mad64k(h[k - 1], 256u, acc);
+        if (k == 8) acc = ((uint64_t)((uint32_t)(acc >> 32) + (h[8] << 5)) << 32) | (uint32_t)acc;          // h[8] * 2^8 belongs to column 9 = 2^29 * column 8 (h[8] < 2^21)
+        if (k < 8) { r.v[k] = (uint32_t)acc & PLUME_FE29_MASK; acc = shr29(acc); }
+    }
+    // acc = column 8 (weight 2^232): bits >= 24 are multiples of 2^256 -> t = t0 + t1 * 2^29, times (2^32 + 977)
+    const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+    r.v[8] = lo & 0x00FFFFFFu;
+    const uint32_t t0 = ((lo >> 24) | (hi << 8)) & PLUME_FE29_MASK;      // bits 24..52
+    const uint32_t t1 = hi >> 21;                                       // bits 53..
+    uint64_t x0 = mad64k(t0, 977u, r.v[0]);
+    r.v[0] = (uint32_t)x0 & PLUME_FE29_MASK;
+    uint64_t x1 = mad64k(t0, 8u, r.v[1] + (uint32_t)shr29(x0) + t1 * 977u);
+    r.v[1] = (uint32_t)x1 & PLUME_FE29_MASK;
+    r.v[2] += (uint32_t)shr29(x1) + (t1 << 3);
+}
+PLUME_HD void fe29_mul2(fe29& r, const fe29& a, const fe29& b) { fe29_mul2_impl<false>(r, a, b); }
+PLUME_HD void fe29_sqr2(fe29& r, const fe29& a) { fe29_mul2_impl<true>(r, a, a); }
+
 }  // namespace plume

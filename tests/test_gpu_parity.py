@@ -324,3 +324,44 @@ def test_odd_batch_sizes_and_long_messages(eng):
             assert np.array_equal(got[k], want[k]), (ver, k)
         ok = eng.verify_batch(ver, mb, off, got["pk"], got["nullifier"], got["c"], got["s"], got["r_point"] if ver == 1 else None, got["hashed_to_curve_r"] if ver == 1 else None)
         assert ok.all()
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_host_pieces_do_not_change_results(eng, ver):
+    """host-pointer calls are pipelined in pieces (plume_set_host_piece): 3001 ragged items through 1 / 5 / 47 pieces, and 40 items
+    through pieces of ONE item, give the C oracle's bytes every time, for sign, verify, SEC1 verify and hash_to_curve"""
+    from tests import _sec1
+    rng = random.Random(4242 + ver)
+    n = 3001
+    b = synth.sign_inputs(n, start=77000)
+    msgs = [bytes(rng.randrange(256) for _ in range(rng.randrange(1, 90))) for _ in range(n)]
+    mb, off = OC.pack_msgs(msgs)
+    want = OC.sign_batch(ver, mb, off, b["sk"], b["r"], nthreads=16)
+    v = synth.corrupt_for_verify(ver, dict(msgs=mb, off=off), want, start=77000)
+    want_ok = synth.expected_ok(n, 77000)
+    want_h = OC.hash_to_curve_batch(mb, off, want["pk"], nthreads=16)
+    pts = ("pk", "nullifier", "r_point", "hashed_to_curve_r") if ver == 1 else ("pk", "nullifier")
+    comp = {k: _sec1.compress(v[k]) for k in pts}
+
+    def rows(a, w, cnt):
+        return np.ascontiguousarray(np.asarray(a).reshape(-1, w)[:cnt])
+
+    try:
+        for piece, cnt in ((1 << 20, n), (700, n), (64, n), (1, 40)):
+            m2, o2 = OC.pack_msgs(msgs[:cnt])
+            eng.set_host_piece(piece)
+            got = eng.sign_batch(ver, m2, o2, rows(b["sk"], 32, cnt), rows(b["r"], 32, cnt))
+            for k in got:
+                w = np.asarray(want[k])
+                assert np.array_equal(np.asarray(got[k]).reshape(cnt, -1), w.reshape(n, -1)[:cnt]), (piece, k)
+            vm, vo = OC.pack_msgs([bytes(v["msgs"][int(v["off"][i]):int(v["off"][i + 1])]) for i in range(cnt)])
+            ok = eng.verify_batch(ver, vm, vo, rows(v["pk"], 64, cnt), rows(v["nullifier"], 64, cnt), rows(v["c"], 32, cnt), rows(v["s"], 32, cnt),
+                                  rows(v["r_point"], 64, cnt) if ver == 1 else None, rows(v["hashed_to_curve_r"], 64, cnt) if ver == 1 else None)
+            assert np.array_equal(ok, want_ok[:cnt]), piece
+            ok = eng.verify_batch_sec1(ver, vm, vo, rows(comp["pk"], 33, cnt), rows(comp["nullifier"], 33, cnt), rows(v["c"], 32, cnt), rows(v["s"], 32, cnt),
+                                       rows(comp["r_point"], 33, cnt) if ver == 1 else None, rows(comp["hashed_to_curve_r"], 33, cnt) if ver == 1 else None)
+            assert np.array_equal(ok, want_ok[:cnt]), piece
+            h = eng.hash_to_curve_batch(m2, o2, rows(want["pk"], 64, cnt))
+            assert np.array_equal(np.asarray(h).reshape(cnt, 64), want_h[:cnt]), piece
+    finally:
+        eng.set_host_piece(1 << 18)

@@ -53,6 +53,7 @@ def _load():
     lib.plume_init.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     lib.plume_destroy.argtypes = [C.c_void_p]
     lib.plume_set_chunk.argtypes = [C.c_void_p, C.c_size_t]
+    lib.plume_set_host_piece.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_last_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
     lib.plume_verify_batch.argtypes = [vp, i, sz] + [vp] * 9
@@ -69,7 +70,7 @@ def _load():
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch",
+    return ["plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch",
             "plume_hash_to_curve_batch", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
             "plume_last_stage_times", "plume_microbench", "plume_microbench_last_ticks"]
 
@@ -129,6 +130,10 @@ class Engine:
 
     def set_chunk(self, n):
         self._chk(self._lib.plume_set_chunk(self._ctx, int(n)), "plume_set_chunk")
+
+    def set_host_piece(self, n):
+        """host-pointer calls: items per pipelined piece (upload / compute / download overlap across pieces)"""
+        self._chk(self._lib.plume_set_host_piece(self._ctx, int(n)), "plume_set_host_piece")
 
     # ------------------------------------------------------------------ host-pointer API (numpy in, numpy out)
     def verify_batch(self, version, msgs, msg_off, pk, nullifier, c, s, r_point=None, hashed_to_curve_r=None):

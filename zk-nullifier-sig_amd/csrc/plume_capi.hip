@@ -51,15 +51,24 @@ struct StageTimer {
     void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); }
 };
 
+// staging for one piece of a host-pointer call
+struct HostSlot {
+    DevBuf msgs, off, in[6], out[7];
+    std::vector<uint64_t> rel;                                        // piece-relative message offsets (source of an upload: lives until the slot is reused)
+    hipEvent_t ready = nullptr, computed = nullptr, drained = nullptr;   // uploads landed / kernels finished / downloads landed
+    bool in_flight = false;
+};
+
 struct plume_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, up = nullptr, down = nullptr;   // kernels / host->HBM / HBM->host
     size_t chunk = (size_t)1 << 20;
+    size_t host_piece = (size_t)1 << 18;                            // host-pointer calls: items per pipelined piece
+    HostSlot slot[2];
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
     DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, res, resinf, res2, res2inf, pkaff, sink;
     DevBuf dec[4], preflags;   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
-    DevBuf in_msgs, in_off, in_a, in_b, in_c, in_d, in_e, in_f, out_a, out_b, out_c, out_d, out_e, out_f, out_g;  // staging for the host-pointer API
     StageTimer timer;
 };
 
@@ -86,7 +95,15 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
     ctx->device = device_id;
     if (const char* e = std::getenv("PLUME_JOBS_PER_LANE")) { int v = std::atoi(e); if (v >= 1 && v <= 64) { ctx->jobs_per_lane = v; ctx->jobs_per_lane_forced = true; } }   // tuning knob
     HIPCHK(hipSetDevice(device_id));
+    if (const char* e = std::getenv("PLUME_HOST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_piece = (size_t)v; }   // tuning knob
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->down, hipStreamNonBlocking));
+    for (HostSlot& sl : ctx->slot) {
+        HIPCHK(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
+    }
     // generator wide window table (1..128)*G: one lane, once
     if (ctx->gtab.ensure(PLUME_GTAB8_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(24 * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64)) { delete ctx; return PLUME_ERR_HIP; }
     uint32_t hb[24];
@@ -111,18 +128,33 @@ extern "C" void plume_destroy(plume_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->up) (void)hipStreamSynchronize(ctx->up);
+    if (ctx->down) (void)hipStreamSynchronize(ctx->down);
     for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
-                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->in_msgs, &ctx->in_off, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->in_d, &ctx->in_e, &ctx->in_f, &ctx->out_a, &ctx->out_b,
-                      &ctx->out_c, &ctx->out_d, &ctx->out_e, &ctx->out_f, &ctx->out_g})
+                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags})
         b->release();
+    for (HostSlot& sl : ctx->slot) {
+        sl.msgs.release(); sl.off.release();
+        for (DevBuf& b : sl.in) b.release();
+        for (DevBuf& b : sl.out) b.release();
+        for (hipEvent_t e : {sl.ready, sl.computed, sl.drained}) if (e) (void)hipEventDestroy(e);
+    }
     ctx->timer.destroy();
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->up) (void)hipStreamDestroy(ctx->up);
+    if (ctx->down) (void)hipStreamDestroy(ctx->down);
     delete ctx;
 }
 
 extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
     if (!ctx || max_items == 0 || max_items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_chunk: bad argument");
     ctx->chunk = max_items;
+    return 0;
+}
+
+extern "C" int plume_set_host_piece(plume_ctx* ctx, size_t items) {
+    if (!ctx || items == 0 || items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_host_piece: bad argument");
+    ctx->host_piece = items;
     return 0;
 }
 
@@ -265,8 +297,12 @@ extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const 
 }
 
 // ------------------------------------------------------------------------------------- host-pointer pipelines
-// Chunked: each pass stages a slice of the SoA arrays into HBM, runs the device pipeline, and copies results back.
-static int stage_msgs(plume_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t i0, size_t cnt, std::vector<uint64_t>& rel) {
+// The batch is cut into pieces (ctx->host_piece items, at most ctx->chunk).  Piece k+1 is staged into HBM on the upload
+// stream while piece k computes on the context stream and piece k-1 drains on the download stream; two staging slots
+// alternate.  With pageable caller memory the copies block the calling thread, which is why piece k-1 is drained only
+// AFTER piece k has been submitted: the thread then waits on work that is already behind it in the queue.
+static int stage_msgs(plume_ctx* ctx, HostSlot& sl, const uint8_t* msgs, const uint64_t* off, size_t i0, size_t cnt) {
+    std::vector<uint64_t>& rel = sl.rel;
     rel.resize(cnt + 1);
     const uint64_t base = off[i0];
     for (size_t k = 0; k <= cnt; k++) {
@@ -274,19 +310,62 @@ static int stage_msgs(plume_ctx* ctx, const uint8_t* msgs, const uint64_t* off, 
         rel[k] = off[i0 + k] - base;
     }
     if (rel[cnt] > 0xFFFFFF00ull) return fail(PLUME_ERR_ARG, "message bytes per pass exceed 4 GiB");
-    if (ctx->in_msgs.ensure((size_t)rel[cnt] + 16) || ctx->in_off.ensure((cnt + 1) * 8)) return PLUME_ERR_HIP;
-    if (rel[cnt]) HIPCHK(hipMemcpyAsync(ctx->in_msgs.p, msgs + base, (size_t)rel[cnt], hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->in_off.p, rel.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (sl.msgs.ensure((size_t)rel[cnt] + 16) || sl.off.ensure((cnt + 1) * 8)) return PLUME_ERR_HIP;
+    if (rel[cnt]) HIPCHK(hipMemcpyAsync(sl.msgs.p, msgs + base, (size_t)rel[cnt], hipMemcpyHostToDevice, ctx->up));
+    HIPCHK(hipMemcpyAsync(sl.off.p, rel.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->up));
     return 0;
 }
 static int h2d(plume_ctx* ctx, DevBuf& b, const uint8_t* src, size_t bytes) {
     if (b.ensure(bytes)) return PLUME_ERR_HIP;
-    HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->up));
     return 0;
 }
 static int d2h(plume_ctx* ctx, uint8_t* dst, const DevBuf& b, size_t bytes) {
-    HIPCHK(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, ctx->down));
     return 0;
+}
+static void quiesce(plume_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->up);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->down);
+    ctx->slot[0].in_flight = ctx->slot[1].in_flight = false;
+}
+
+// up(slot, i0, cnt): enqueue the uploads of one piece on ctx->up;  run(slot, cnt): enqueue its kernels on ctx->stream;
+// down(slot, i0, cnt): enqueue the downloads on ctx->down.  Any error drains all three streams before it is returned, so no
+// copy is left in flight on the caller's memory.
+template <class Up, class Run, class Down>
+static int host_pipeline(plume_ctx* ctx, size_t n, Up up, Run run, Down down) {
+    const size_t piece = ctx->host_piece < ctx->chunk ? ctx->host_piece : ctx->chunk;
+    struct { HostSlot* sl = nullptr; size_t i0 = 0, cnt = 0; } prev;
+    auto drain = [&]() -> int {
+        HIPCHK(hipStreamWaitEvent(ctx->down, prev.sl->computed, 0));
+        if (int rc = down(*prev.sl, prev.i0, prev.cnt)) return rc;
+        HIPCHK(hipEventRecord(prev.sl->drained, ctx->down));
+        return 0;
+    };
+    auto body = [&]() -> int {
+        size_t k = 0;
+        for (size_t i0 = 0; i0 < n; i0 += piece, k++) {
+            const size_t cnt = n - i0 < piece ? n - i0 : piece;
+            HostSlot& sl = ctx->slot[k & 1];
+            if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.drained)); sl.in_flight = false; }   // piece k-2 has left this slot
+            if (int rc = up(sl, i0, cnt)) return rc;
+            HIPCHK(hipEventRecord(sl.ready, ctx->up));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, sl.ready, 0));
+            if (int rc = run(sl, cnt)) return rc;
+            HIPCHK(hipEventRecord(sl.computed, ctx->stream));
+            sl.in_flight = true;
+            if (prev.sl) { if (int rc = drain()) return rc; }
+            prev.sl = &sl; prev.i0 = i0; prev.cnt = cnt;
+        }
+        if (prev.sl) { if (int rc = drain()) return rc; }
+        return 0;
+    };
+    const int rc = body();
+    quiesce(ctx);
+    if (rc == 0) HIPCHK(hipGetLastError());
+    return rc;
 }
 
 extern "C" int plume_verify_batch(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk,
@@ -296,27 +375,27 @@ extern "C" int plume_verify_batch(plume_ctx* ctx, int version, size_t n, const u
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk || !nullifier || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
     if (n && version == 1 && (!r_point || !hashed_to_curve_r)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
-    std::vector<uint64_t> rel;
-    for (size_t i0 = 0; i0 < n; i0 += ctx->chunk) {
-        const size_t cnt = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
-        if (int rc = stage_msgs(ctx, msgs, msg_off, i0, cnt, rel)) return rc;
-        if (int rc = h2d(ctx, ctx->in_a, pk + 64 * i0, 64 * cnt)) return rc;
-        if (int rc = h2d(ctx, ctx->in_b, nullifier + 64 * i0, 64 * cnt)) return rc;
-        if (int rc = h2d(ctx, ctx->in_c, c + 32 * i0, 32 * cnt)) return rc;
-        if (int rc = h2d(ctx, ctx->in_d, s + 32 * i0, 32 * cnt)) return rc;
-        if (version == 1) {
-            if (int rc = h2d(ctx, ctx->in_e, r_point + 64 * i0, 64 * cnt)) return rc;
-            if (int rc = h2d(ctx, ctx->in_f, hashed_to_curve_r + 64 * i0, 64 * cnt)) return rc;
-        }
-        if (ctx->out_a.ensure(cnt)) return PLUME_ERR_HIP;
-        if (int rc = verify_device(ctx, version, cnt, ctx->in_msgs.as<uint8_t>(), ctx->in_off.as<uint64_t>(), ctx->in_a.as<uint8_t>(), ctx->in_b.as<uint8_t>(),
-                                   ctx->in_c.as<uint8_t>(), ctx->in_d.as<uint8_t>(), version == 1 ? ctx->in_e.as<uint8_t>() : nullptr,
-                                   version == 1 ? ctx->in_f.as<uint8_t>() : nullptr, ctx->out_a.as<uint8_t>(), ctx->stream))
-            return rc;
-        if (int rc = d2h(ctx, ok + i0, ctx->out_a, cnt)) return rc;
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    return 0;
+    const bool v1 = version == 1;
+    return host_pipeline(
+        ctx, n,
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
+            if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[0], pk + 64 * i0, 64 * cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[1], nullifier + 64 * i0, 64 * cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[2], c + 32 * i0, 32 * cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[3], s + 32 * i0, 32 * cnt)) return rc;
+            if (v1) {
+                if (int rc = h2d(ctx, sl.in[4], r_point + 64 * i0, 64 * cnt)) return rc;
+                if (int rc = h2d(ctx, sl.in[5], hashed_to_curve_r + 64 * i0, 64 * cnt)) return rc;
+            }
+            return sl.out[0].ensure(cnt);
+        },
+        [&](HostSlot& sl, size_t cnt) -> int {
+            return verify_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(), sl.in[2].as<uint8_t>(),
+                                 sl.in[3].as<uint8_t>(), v1 ? sl.in[4].as<uint8_t>() : nullptr, v1 ? sl.in[5].as<uint8_t>() : nullptr, sl.out[0].as<uint8_t>(),
+                                 ctx->stream);
+        },
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); });
 }
 
 extern "C" int plume_verify_batch_sec1(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk33,
@@ -326,27 +405,27 @@ extern "C" int plume_verify_batch_sec1(plume_ctx* ctx, int version, size_t n, co
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk33 || !nullifier33 || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
     if (n && version == 1 && (!r_point33 || !hashed_to_curve_r33)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
-    std::vector<uint64_t> rel;
-    for (size_t i0 = 0; i0 < n; i0 += ctx->chunk) {
-        const size_t cnt = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
-        if (int rc = stage_msgs(ctx, msgs, msg_off, i0, cnt, rel)) return rc;
-        if (int rc = h2d(ctx, ctx->in_a, pk33 + 33 * i0, 33 * cnt)) return rc;
-        if (int rc = h2d(ctx, ctx->in_b, nullifier33 + 33 * i0, 33 * cnt)) return rc;
-        if (int rc = h2d(ctx, ctx->in_c, c + 32 * i0, 32 * cnt)) return rc;
-        if (int rc = h2d(ctx, ctx->in_d, s + 32 * i0, 32 * cnt)) return rc;
-        if (version == 1) {
-            if (int rc = h2d(ctx, ctx->in_e, r_point33 + 33 * i0, 33 * cnt)) return rc;
-            if (int rc = h2d(ctx, ctx->in_f, hashed_to_curve_r33 + 33 * i0, 33 * cnt)) return rc;
-        }
-        if (ctx->out_a.ensure(cnt)) return PLUME_ERR_HIP;
-        if (int rc = verify_sec1_device(ctx, version, cnt, ctx->in_msgs.as<uint8_t>(), ctx->in_off.as<uint64_t>(), ctx->in_a.as<uint8_t>(), ctx->in_b.as<uint8_t>(),
-                                        ctx->in_c.as<uint8_t>(), ctx->in_d.as<uint8_t>(), version == 1 ? ctx->in_e.as<uint8_t>() : nullptr,
-                                        version == 1 ? ctx->in_f.as<uint8_t>() : nullptr, ctx->out_a.as<uint8_t>(), ctx->stream))
-            return rc;
-        if (int rc = d2h(ctx, ok + i0, ctx->out_a, cnt)) return rc;
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    return 0;
+    const bool v1 = version == 1;
+    return host_pipeline(
+        ctx, n,
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
+            if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[0], pk33 + 33 * i0, 33 * cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[1], nullifier33 + 33 * i0, 33 * cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[2], c + 32 * i0, 32 * cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[3], s + 32 * i0, 32 * cnt)) return rc;
+            if (v1) {
+                if (int rc = h2d(ctx, sl.in[4], r_point33 + 33 * i0, 33 * cnt)) return rc;
+                if (int rc = h2d(ctx, sl.in[5], hashed_to_curve_r33 + 33 * i0, 33 * cnt)) return rc;
+            }
+            return sl.out[0].ensure(cnt);
+        },
+        [&](HostSlot& sl, size_t cnt) -> int {
+            return verify_sec1_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
+                                      sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), v1 ? sl.in[4].as<uint8_t>() : nullptr, v1 ? sl.in[5].as<uint8_t>() : nullptr,
+                                      sl.out[0].as<uint8_t>(), ctx->stream);
+        },
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); });
 }
 
 extern "C" int plume_sign_batch(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
@@ -355,52 +434,55 @@ extern "C" int plume_sign_batch(plume_ctx* ctx, int version, size_t n, const uin
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
-    std::vector<uint64_t> rel;
-    for (size_t i0 = 0; i0 < n; i0 += ctx->chunk) {
-        const size_t cnt = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
-        if (int rc = stage_msgs(ctx, msgs, msg_off, i0, cnt, rel)) return rc;
-        if (int rc = h2d(ctx, ctx->in_a, sk + 32 * i0, 32 * cnt)) return rc;
-        if (int rc = h2d(ctx, ctx->in_b, r + 32 * i0, 32 * cnt)) return rc;
-        if (pk_in) { if (int rc = h2d(ctx, ctx->in_c, pk_in + 64 * i0, 64 * cnt)) return rc; }
-        if (ctx->out_a.ensure(64 * cnt) || ctx->out_b.ensure(64 * cnt) || ctx->out_c.ensure(32 * cnt) || ctx->out_d.ensure(32 * cnt) || ctx->out_e.ensure(64 * cnt) ||
-            ctx->out_f.ensure(64 * cnt) || ctx->out_g.ensure(cnt))
-            return PLUME_ERR_HIP;
-        if (int rc = sign_device(ctx, version, cnt, ctx->in_msgs.as<uint8_t>(), ctx->in_off.as<uint64_t>(), ctx->in_a.as<uint8_t>(), ctx->in_b.as<uint8_t>(),
-                                 pk_in ? ctx->in_c.as<uint8_t>() : nullptr, ctx->out_a.as<uint8_t>(), ctx->out_b.as<uint8_t>(), ctx->out_c.as<uint8_t>(),
-                                 ctx->out_d.as<uint8_t>(), ctx->out_e.as<uint8_t>(), ctx->out_f.as<uint8_t>(), ctx->out_g.as<uint8_t>(), nullptr, ctx->stream))
-            return rc;
-        if (pk) { if (int rc = d2h(ctx, pk + 64 * i0, ctx->out_a, 64 * cnt)) return rc; }
-        if (int rc = d2h(ctx, nullifier + 64 * i0, ctx->out_b, 64 * cnt)) return rc;
-        if (int rc = d2h(ctx, c + 32 * i0, ctx->out_c, 32 * cnt)) return rc;
-        if (int rc = d2h(ctx, s + 32 * i0, ctx->out_d, 32 * cnt)) return rc;
-        if (int rc = d2h(ctx, r_point + 64 * i0, ctx->out_e, 64 * cnt)) return rc;
-        if (int rc = d2h(ctx, hashed_to_curve_r + 64 * i0, ctx->out_f, 64 * cnt)) return rc;
-        if (int rc = d2h(ctx, status + i0, ctx->out_g, cnt)) return rc;
-        // wipe the staged secrets before the buffers are reused or freed
-        HIPCHK(hipMemsetAsync(ctx->in_a.p, 0, 32 * cnt, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->in_b.p, 0, 32 * cnt, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    return 0;
+    return host_pipeline(
+        ctx, n,
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
+            if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[0], sk + 32 * i0, 32 * cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[1], r + 32 * i0, 32 * cnt)) return rc;
+            if (pk_in) { if (int rc = h2d(ctx, sl.in[2], pk_in + 64 * i0, 64 * cnt)) return rc; }
+            return sl.out[0].ensure(64 * cnt) || sl.out[1].ensure(64 * cnt) || sl.out[2].ensure(32 * cnt) || sl.out[3].ensure(32 * cnt) || sl.out[4].ensure(64 * cnt) ||
+                           sl.out[5].ensure(64 * cnt) || sl.out[6].ensure(cnt)
+                       ? PLUME_ERR_HIP
+                       : 0;
+        },
+        [&](HostSlot& sl, size_t cnt) -> int {
+            if (int rc = sign_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
+                                     pk_in ? sl.in[2].as<uint8_t>() : nullptr, sl.out[0].as<uint8_t>(), sl.out[1].as<uint8_t>(), sl.out[2].as<uint8_t>(),
+                                     sl.out[3].as<uint8_t>(), sl.out[4].as<uint8_t>(), sl.out[5].as<uint8_t>(), sl.out[6].as<uint8_t>(), nullptr, ctx->stream))
+                return rc;
+            // wipe the staged secrets before the slot is reused or freed
+            HIPCHK(hipMemsetAsync(sl.in[0].p, 0, 32 * cnt, ctx->stream));
+            HIPCHK(hipMemsetAsync(sl.in[1].p, 0, 32 * cnt, ctx->stream));
+            return 0;
+        },
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
+            if (pk) { if (int rc = d2h(ctx, pk + 64 * i0, sl.out[0], 64 * cnt)) return rc; }
+            if (int rc = d2h(ctx, nullifier + 64 * i0, sl.out[1], 64 * cnt)) return rc;
+            if (int rc = d2h(ctx, c + 32 * i0, sl.out[2], 32 * cnt)) return rc;
+            if (int rc = d2h(ctx, s + 32 * i0, sl.out[3], 32 * cnt)) return rc;
+            if (int rc = d2h(ctx, r_point + 64 * i0, sl.out[4], 64 * cnt)) return rc;
+            if (int rc = d2h(ctx, hashed_to_curve_r + 64 * i0, sl.out[5], 64 * cnt)) return rc;
+            return d2h(ctx, status + i0, sl.out[6], cnt);
+        });
 }
 
 extern "C" int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
     if (n && !h_out) return fail(PLUME_ERR_ARG, "null array");
-    std::vector<uint64_t> rel;
-    for (size_t i0 = 0; i0 < n; i0 += ctx->chunk) {
-        const size_t cnt = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
-        if (int rc = stage_msgs(ctx, msgs, msg_off, i0, cnt, rel)) return rc;
-        if (pk) { if (int rc = h2d(ctx, ctx->in_a, pk + 64 * i0, 64 * cnt)) return rc; }
-        if (ctx->out_a.ensure(64 * cnt)) return PLUME_ERR_HIP;
-        if (int rc = plume_hash_to_curve_batch_device(ctx, cnt, ctx->in_msgs.as<uint8_t>(), ctx->in_off.as<uint64_t>(), (size_t)rel[cnt],
-                                                      pk ? ctx->in_a.as<uint8_t>() : nullptr, ctx->out_a.as<uint8_t>(), ctx->stream))
-            return rc;
-        if (int rc = d2h(ctx, h_out + 64 * i0, ctx->out_a, 64 * cnt)) return rc;
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    return 0;
+    return host_pipeline(
+        ctx, n,
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
+            if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
+            if (pk) { if (int rc = h2d(ctx, sl.in[0], pk + 64 * i0, 64 * cnt)) return rc; }
+            return sl.out[0].ensure(64 * cnt);
+        },
+        [&](HostSlot& sl, size_t cnt) -> int {
+            return plume_hash_to_curve_batch_device(ctx, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], pk ? sl.in[0].as<uint8_t>() : nullptr,
+                                                    sl.out[0].as<uint8_t>(), ctx->stream);
+        },
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, h_out + 64 * i0, sl.out[0], 64 * cnt); });
 }
 
 // ------------------------------------------------------------------------------------------------ measurement

@@ -25,15 +25,18 @@ PLUME_HD uint32_t dst_prime_byte(uint32_t k) {
     return (word >> (8 * (3 - (k & 3)))) & 0xFF;
 }
 
-// b0 = SHA256( 0^64 || msg || enc(pk) || 00 60 00 || DST' ); enc(pk) = tag || x (33 B) or the single byte 00 for the identity
-PLUME_HD void xmd_b0(uint32_t b0[8], const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag, bool pk_inf) {
-    const uint32_t elen = pk_inf ? 1u : 33u;
+// how the public key is appended to the message before hashing
+#define PLUME_ENC_NONE 0u      // nothing appended (raw hash_from_bytes(&[msg]) — KAT pinning)
+#define PLUME_ENC_IDENTITY 1u  // the single byte 00
+#define PLUME_ENC_POINT 33u    // tag || x
+// b0 = SHA256( 0^64 || msg || enc(pk) || 00 60 00 || DST' ); elen = length of enc(pk): 0, 1 or 33
+PLUME_HD void xmd_b0(uint32_t b0[8], const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag, uint32_t elen) {
     const uint32_t len = mlen + elen + 53u;
     sha256_init_after_zero_block(b0);
     sha256_absorb_pad(b0, 64u, len, [&](uint32_t pos) -> uint32_t {
         if (pos < mlen) return msg[pos];
         uint32_t k = pos - mlen;
-        if (k < elen) return k == 0 ? (pk_inf ? 0u : tag) : be_byte_of_limbs(pkx.v, k - 1);
+        if (k < elen) return k == 0 ? (elen == PLUME_ENC_IDENTITY ? 0u : tag) : be_byte_of_limbs(pkx.v, k - 1);
         k -= elen;
         if (k < 3) return k == 1 ? 0x60u : 0u;   // I2OSP(96, 2) || I2OSP(0, 1)
         return dst_prime_byte(k - 3);
@@ -60,9 +63,9 @@ PLUME_HD void fe_from_be48_words(fe& r, const uint32_t* w /* 12 big-endian words
     PLUME_UNROLL for (int i = 12; i < 16; i++) t[i] = 0;
     fe_reduce_wide(r, t);
 }
-PLUME_HD void hash_to_field2(fe& u0, fe& u1, const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag, bool pk_inf) {
+PLUME_HD void hash_to_field2(fe& u0, fe& u1, const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag, uint32_t elen) {
     uint32_t b0[8], uni[24], x[8];
-    xmd_b0(b0, msg, mlen, pkx, tag, pk_inf);
+    xmd_b0(b0, msg, mlen, pkx, tag, elen);
     xmd_bi(uni, b0, 1);
     PLUME_UNROLL for (int i = 0; i < 8; i++) x[i] = b0[i] ^ uni[i];
     xmd_bi(uni + 8, x, 2);
@@ -154,10 +157,10 @@ PLUME_HD void iso3_frac_to_jac(jac& q, const fe& xn, const fe& xd, const fe& y) 
     q.inf = fe_is_zero(q.z) ? 1u : 0u;
 }
 
-// H = h2c(msg || enc(pk)) as a Jacobian point
-PLUME_HD void hash_to_curve_jac(jac& h, const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag, bool pk_inf) {
+// H = h2c(msg || enc(pk)) as a Jacobian point; enc: PLUME_ENC_POINT / PLUME_ENC_IDENTITY / PLUME_ENC_NONE
+PLUME_HD void hash_to_curve_jac(jac& h, const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag, uint32_t enc) {
     fe u[2];
-    hash_to_field2(u[0], u[1], msg, mlen, pkx, tag, pk_inf);
+    hash_to_field2(u[0], u[1], msg, mlen, pkx, tag, enc);
     jac q[2];
     PLUME_NOUNROLL for (int i = 0; i < 2; i++) {
         fe xn, xd, y;

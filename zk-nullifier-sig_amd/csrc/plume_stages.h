@@ -125,7 +125,7 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     jac h;
     if (!bad) {
         const uint64_t o0 = a.msg_off[i], o1 = a.msg_off[i + 1];
-        hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), pkx, 2u + (fe_is_odd(pky) ? 1u : 0u), fpk == PLUME_JOB_INF);
+        hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), pkx, 2u + (fe_is_odd(pky) ? 1u : 0u), fpk == PLUME_JOB_INF ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
     } else {
         h.x = fe_gx(); h.y = fe_gy(); h.z = fe_small(1); h.inf = 0;
     }
@@ -307,7 +307,7 @@ PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
     st_fe_soa(a.pkaff, a.n, i, px); st_fe_soa(a.pkaff + 8 * (size_t)a.n, a.n, i, py);
     jac h;
     const uint64_t o0 = a.msg_off[i], o1 = a.msg_off[i + 1];
-    hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), px, 2u + (fe_is_odd(py) ? 1u : 0u), pinf);
+    hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), px, 2u + (fe_is_odd(py) ? 1u : 0u), pinf ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
     if (h.inf) st |= PLUME_ST_IDENTITY;
     st_jac_soa(a.bases, a.n, i, h);
     a.jobflags[i] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
@@ -408,31 +408,9 @@ PLUME_HD void h2c_only(const H2cArgs& a, uint32_t i) {
         fe px, py;
         uint32_t f = load_affine_be(px, py, a.pk + 64 * (size_t)i);
         bad = f == PLUME_JOB_INVALID;
-        if (!bad) hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), px, 2u + (fe_is_odd(py) ? 1u : 0u), f == PLUME_JOB_INF);
+        if (!bad) hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), px, 2u + (fe_is_odd(py) ? 1u : 0u), f == PLUME_JOB_INF ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
     } else {
-        // raw: m || <nothing>: reuse the same stream with a zero-length "encoding" by folding it into the message
-        fe u0, u1;
-        {
-            uint32_t b0[8], uni[24], xx[8];
-            const uint8_t* msg = a.msgs + o0; const uint32_t mlen = (uint32_t)(o1 - o0);
-            sha256_init_after_zero_block(b0);
-            sha256_absorb_pad(b0, 64u, mlen + 53u, [&](uint32_t pos) -> uint32_t {
-                if (pos < mlen) return msg[pos];
-                uint32_t k = pos - mlen;
-                if (k < 3) return k == 1 ? 0x60u : 0u;
-                return dst_prime_byte(k - 3);
-            });
-            xmd_bi(uni, b0, 1);
-            PLUME_UNROLL for (int k = 0; k < 8; k++) xx[k] = b0[k] ^ uni[k];
-            xmd_bi(uni + 8, xx, 2);
-            PLUME_UNROLL for (int k = 0; k < 8; k++) xx[k] = b0[k] ^ uni[8 + k];
-            xmd_bi(uni + 16, xx, 3);
-            fe_from_be48_words(u0, uni); fe_from_be48_words(u1, uni + 12);
-        }
-        jac q0, q1; fe xn, xd, yy;
-        sswu_frac(xn, xd, yy, u0); iso3_frac_to_jac(q0, xn, xd, yy);
-        sswu_frac(xn, xd, yy, u1); iso3_frac_to_jac(q1, xn, xd, yy);
-        h = q0; jac_add(h, q1);
+        hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), x, 0u, PLUME_ENC_NONE);   // raw message bytes only
     }
     if (!bad && !h.inf) {
         fe zi, zi2;
