@@ -247,4 +247,62 @@ PLUME_HD void fe29_mul2_impl(fe29& r, const fe29& a, const fe29& b) {
 PLUME_HD void fe29_mul2(fe29& r, const fe29& a, const fe29& b) { fe29_mul2_impl<false>(r, a, b); }
 PLUME_HD void fe29_sqr2(fe29& r, const fe29& a) { fe29_mul2_impl<true>(r, a, a); }
 
+
+// ---- v3: plain C++ chains only (hipcc turns `acc = (u64)a*b + acc` into one v_mad_u64_u32 and `acc >>= 29` into one
+// v_lshrrev_b64, with no hazard nops); the fold constants are made opaque so they stay multiply-adds.
+// Column bookkeeping: h[k] (k = 0..8) has weight 2^(261 + 29k) = (2^37 + 31264) * 2^(29k):
+//   column k   += h[k] * 31264,  column k+1 += h[k] * 2^8            for k = 0..7
+//   h[8]: column 8 += h[8] * 31264; its 2^8 part lands on column 9 = 2^261 again: column 0 += h[8] * (31264 << 8), column 1 += h[8] << 16
+PLUME_HD void pin64(uint64_t& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));        // no instruction: only stops the compiler from re-associating the accumulation chain across this point
+#endif
+}
+template <bool SQR>
+PLUME_HD void fe29_mul3_impl(fe29& r, const fe29& a, const fe29& b) {
+    uint32_t d[9];
+    if (SQR) { PLUME_UNROLL for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1; }
+    auto column = [&](uint64_t acc, int k) -> uint64_t {
+        PLUME_UNROLL for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= 9) continue;
+            if (!SQR) { acc += (uint64_t)a.v[i] * b.v[j]; pin64(acc); }
+            else if (i < j) { acc += (uint64_t)a.v[i] * d[j]; pin64(acc); }
+            else if (i == j) { acc += (uint64_t)a.v[i] * a.v[i]; pin64(acc); }
+        }
+        return acc;
+    };
+    const uint32_t K0 = opaque_u32(31264u), K1 = opaque_u32(256u), K2 = opaque_u32(31264u << 8), K3 = opaque_u32(65536u), K4 = opaque_u32(977u), K5 = opaque_u32(8u);
+    uint32_t h[9];
+    uint64_t acc = 0;
+    PLUME_UNROLL for (int k = 9; k < 17; k++) {
+        acc = column(acc, k);
+        h[k - 9] = (uint32_t)acc & PLUME_FE29_MASK;
+        acc >>= 29;
+    }
+    h[8] = (uint32_t)acc;                                   // < 2^27 for top limbs < 2^27
+    acc = 0;
+    PLUME_UNROLL for (int k = 0; k < 9; k++) {
+        acc = column(acc, k);
+        acc += (uint64_t)h[k] * K0;
+        pin64(acc);
+        if (k > 0) { acc += (uint64_t)h[k - 1] * K1; pin64(acc); }
+        if (k == 0) { acc += (uint64_t)h[8] * K2; pin64(acc); }
+        if (k == 1) { acc += (uint64_t)h[8] * K3; pin64(acc); }
+        if (k < 8) { r.v[k] = (uint32_t)acc & PLUME_FE29_MASK; acc >>= 29; }
+    }
+    // acc = column 8 (weight 2^232): bits >= 24 are multiples of 2^256 -> t = t0 + t1 * 2^29, times (2^32 + 977)
+    r.v[8] = (uint32_t)acc & 0x00FFFFFFu;
+    acc >>= 24;
+    const uint32_t t0 = (uint32_t)acc & PLUME_FE29_MASK;
+    const uint32_t t1 = (uint32_t)(acc >> 29);
+    uint64_t x = (uint64_t)t0 * K4 + r.v[0];
+    r.v[0] = (uint32_t)x & PLUME_FE29_MASK;
+    x = (uint64_t)t0 * K5 + (r.v[1] + t1 * 977u) + (x >> 29);
+    r.v[1] = (uint32_t)x & PLUME_FE29_MASK;
+    r.v[2] += (uint32_t)(x >> 29) + (t1 << 3);
+}
+PLUME_HD void fe29_mul3(fe29& r, const fe29& a, const fe29& b) { fe29_mul3_impl<false>(r, a, b); }
+PLUME_HD void fe29_sqr3(fe29& r, const fe29& a) { fe29_mul3_impl<true>(r, a, a); }
+
 }  // namespace plume
