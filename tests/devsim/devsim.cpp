@@ -11,15 +11,17 @@
 
 using namespace plume;
 
-static void fe_from_le_words(fe& r, const uint32_t* w) { for (int i = 0; i < 8; i++) r.v[i] = w[i]; }
+static void fe_from_le_words(fe& r, const uint32_t* w) { fe_from_words(r, w); }   // any 256-bit integer, also >= p
 
 extern "C" {
 
-// op: 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 inv, 6 pow_c1, 7 normalize, 8 mul_small(b[0]), 9 is_zero->out[0], 10 eq->out[0], 11 is_odd->out[0]
-// operands/outputs: 8 little-endian 32-bit limbs; count elements
+// op: 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 inv, 6 pow_c1, 7 normalize, 8 mul_small(b[0]), 9 is_zero->out[0], 10 eq->out[0], 11 is_odd->out[0],
+//     12 (a+b)*(a+2p-b) on unreduced operands, 13 (a+4p-2b)^2 through fe_carry, 14 words round trip
+// operands/outputs: 256-bit integers as 8 little-endian 32-bit words (outputs canonical); count elements
 void ds_fe_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     for (size_t i = 0; i < count; i++) {
         fe x, y, r = fe_zero();
+        bool flag = false;
         fe_from_le_words(x, a + 8 * i);
         fe_from_le_words(y, b + 8 * i);
         switch (op) {
@@ -31,12 +33,17 @@ void ds_fe_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32
             case 5: fe_inv(r, x); break;
             case 6: fe_pow_c1(r, x); break;
             case 7: r = x; fe_normalize(r); break;
-            case 8: fe_mul_small(r, x, y.v[0]); break;
-            case 9: r.v[0] = fe_is_zero(x); break;
-            case 10: r.v[0] = fe_eq(x, y); break;
-            case 11: r.v[0] = fe_is_odd(x); break;
+            case 8: fe_mul_small(r, x, b[8 * i]); break;
+            case 9: flag = fe_is_zero(x); break;
+            case 10: flag = fe_eq(x, y); break;
+            case 11: flag = fe_is_odd(x); break;
+            case 12: { fe s, d; fe_add_lazy(s, x, y); fe_sub_lazy<2>(d, x, y); fe_mul(r, d, s); break; }          // (a+b)(a-b), both operands unreduced
+            case 13: { fe t; fe_add_lazy(t, y, y); fe_sub_lazy<4>(t, x, t); fe_carry(t); fe_sqr(r, t); break; }  // (a-2b)^2
+            case 14: r = x; break;
         }
-        for (int k = 0; k < 8; k++) out[8 * i + k] = r.v[k];
+        if (op >= 9 && op <= 11) { for (int k = 0; k < 8; k++) out[8 * i + k] = k == 0 ? (uint32_t)flag : 0u; continue; }
+        fe_normalize(r);
+        fe_to_words(out + 8 * i, r);
     }
 }
 // op: 0 mul, 1 add, 2 neg, 3 reduce of 512-bit a|b (a low)
@@ -72,7 +79,7 @@ void ds_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
 
 static void build_gtab(std::vector<uint32_t>& gtab) {
     gtab.assign(PLUME_GTAB8_WORDS, 0);
-    std::vector<uint32_t> bases(24, 0);
+    std::vector<uint32_t> bases(PLUME_JAC_WORDS, 0);
     jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
     st_jac_soa(bases.data(), 1, 0, g);
     uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
@@ -81,7 +88,7 @@ static void build_gtab(std::vector<uint32_t>& gtab) {
 
 static void build_gcomb(std::vector<uint32_t>& comb) {
     comb.assign(PLUME_COMB_WORDS, 0);
-    std::vector<uint32_t> bases(24 * PLUME_COMB_WINDOWS, 0);
+    std::vector<uint32_t> bases(PLUME_JAC_WORDS * PLUME_COMB_WINDOWS, 0);
     std::vector<uint8_t> flags(PLUME_COMB_WINDOWS, 0);
     for (uint32_t i = 0; i < PLUME_COMB_WINDOWS; i++) {      // mirrors k_gcomb
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
@@ -117,7 +124,7 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
                        const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags) {
     if (version != 1 && version != 2) return -1;
     std::vector<uint32_t> gtab; build_gtab(gtab);
-    std::vector<uint32_t> bases(24 * 3 * (size_t)n), tab((size_t)3 * n * PLUME_TAB_WORDS), res(24 * 2 * (size_t)n);
+    std::vector<uint32_t> bases(PLUME_JAC_WORDS * 3 * (size_t)n), tab((size_t)3 * n * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2 * (size_t)n);
     std::vector<uint8_t> jobflags(3 * (size_t)n), itemflags(n), resinf(2 * (size_t)n);
     VerifyArgs a;
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags;
@@ -142,7 +149,7 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     if (version != 1 && version != 2) return -1;
     std::vector<uint32_t> gtab; build_gtab(gtab);
     static std::vector<uint32_t> gcomb; if (gcomb.empty()) build_gcomb(gcomb);
-    std::vector<uint32_t> gres(24 * 2 * (size_t)n), hres(24 * 2 * (size_t)n), bases(24 * (size_t)n), pkaff(16 * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
+    std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_JAC_WORDS * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
     std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(n), itemflags(n);
     SignArgs a;
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.sk = sk; a.r = r; a.pk_in = pk_in;
@@ -176,7 +183,7 @@ int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[6
     fe x, y;
     uint32_t f = load_affine_be(x, y, pb);
     if (f == PLUME_JOB_INVALID) return 0;
-    std::vector<uint32_t> bases(24 * 3), tab(3 * PLUME_TAB_WORDS), res(24 * 2);
+    std::vector<uint32_t> bases(PLUME_JAC_WORDS * 3), tab(3 * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2);
     std::vector<uint8_t> jobflags(3), itemflags(1, 0), resinf(2);
     VerifyArgs a; memset(&a, 0, sizeof a);
     a.version = 2; a.n = 1; a.c = cb; a.s = sb; a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
@@ -209,7 +216,7 @@ int ds_point_mul(const uint8_t k_be[32], const uint8_t p_be[64], uint8_t out[64]
     if (f == PLUME_JOB_INVALID) return 0;
     alignas(16) uint8_t ob[64];
     if (f == PLUME_JOB_INF) { memset(out, 0, 64); return 1; }
-    std::vector<uint32_t> bases(24), tab(PLUME_TAB_WORDS);
+    std::vector<uint32_t> bases(PLUME_JAC_WORDS), tab(PLUME_TAB_WORDS);
     jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
     st_jac_soa(bases.data(), 1, 0, p);
     uint8_t flag = 0;

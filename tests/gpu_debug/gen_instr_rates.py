@@ -23,6 +23,13 @@ KINDS = [
     ("v_addc_co_u32 (vcc in+out)", "u32", "v_addc_co_u32 {c}, vcc, %8, {c}, vcc"),
     ("v_addc_co_u32 e64 (sgpr pair carry)", "u32", "v_addc_co_u32 {c}, s[20:21], %8, {c}, s[20:21]"),
     ("v_cndmask_b32 (vcc)", "u32", "v_cndmask_b32 {c}, {c}, %8, vcc"),
+    ("v_cndmask_b32 e64 (sgpr pair mask)", "u32", "v_cndmask_b32 {c}, {c}, %8, s[20:21]"),
+    ("v_cndmask_b32 (vcc), dst != src", "u32", None),
+    ("v_cmp_lt_u32 + v_cndmask (vcc)", "u32", None),
+    ("v_bfi_b32", "u32", "v_bfi_b32 {c}, %8, {c}, %9"),
+    ("v_sub_u32", "u32", "v_sub_u32 {c}, %8, {c}"),
+    ("v_lshlrev_b32", "u32", "v_lshlrev_b32 {c}, 1, {c}"),
+    ("v_or_b32", "u32", "v_or_b32 {c}, %8, {c}"),
     ("v_mad_u64_u32 (8 chains)", "u64", "v_mad_u64_u32 {c}, s[20:21], %8, %9, {c}"),
     ("v_mad_u64_u32 (1 chain)", "u64", "v_mad_u64_u32 %0, s[20:21], %8, %9, %0"),
     ("v_mad_u64_u32 (2 chains)", "u64", None),
@@ -55,6 +62,14 @@ def block(kind):
     if name == "v_mad_u64_u32 (2 chains)":
         for r in range(16):
             lines += ["v_mad_u64_u32 %0, s[20:21], %8, %9, %0", "v_mad_u64_u32 %1, s[20:21], %8, %9, %1"]
+    elif name == "v_cndmask_b32 (vcc), dst != src":
+        for r in range(4):
+            for i in range(8):
+                lines.append(f"v_cndmask_b32 %{i}, %8, %9, vcc")
+    elif name == "v_cmp_lt_u32 + v_cndmask (vcc)":
+        for r in range(2):
+            for i in range(8):
+                lines += [f"v_cmp_lt_u32 vcc, %8, %{i}", f"v_cndmask_b32 %{i}, %{i}, %9, vcc"]
     elif name == "v_cvt_f64_u32 + back":
         # 16 x (u32 -> f64 -> u32) on 8 chains, temp pair v[100:101] .. per chain
         for r in range(2):

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Generate plume_fe_mul.inc: the secp256k1 field multiplication and squaring on 9 x 29-bit limbs for gfx950.
+
+    python gen_fe_mul.py > plume_fe_mul.inc          (the generated file is committed; rerun only when this script changes)
+
+Why this shape (measured on MI355X, tests/gpu_debug/instr_rates_r01.txt): a carry-chain step (v_add_co / v_addc_co) costs as
+much issue time as a 32x32+64 multiply-add (v_mad_u64_u32), so the fast multiplication is the one with no carry steps at all.
+With 29-bit limbs a whole product column (<= 9 products < 2^60.4 each) accumulates inside the 64-bit addend of a CHAIN of
+v_mad_u64_u32, and the carry into the next column is simply that chain's initial addend:
+
+    high half   columns 9..16 -> h[0..8]   (h[k] has weight 2^(261+29k); 2^261 = 2^37 + 31264 (mod p))
+    low half    column k = sum a_i b_(k-i) + h[k]*31264 + h[k-1]*2^8          (k = 0..8; the fold is two more multiply-adds)
+                h[8]: its 2^8 part lands on column 9 = 2^261 again -> column 0 += h[8]*(31264 << 8), column 1 += h[8] << 16
+    tail        bits >= 2^256 of column 8 fold as t*(2^32 + 977) into limbs 0..2
+
+103 multiply-adds + 16 v_lshrrev_b64 + 20 v_and_b32 per multiplication (squaring: 67 multiply-adds).  Each chain is ONE asm
+statement with compiler-allocated registers: hipcc keeps scheduling and register allocation but can neither re-associate the
+chain (that costs a 64-bit add per column) nor strength-reduce the fold constants into shift/add pairs, and it inserts no
+hazard nops inside a statement.  Host builds (tests/devsim) compile the same column algorithm as plain C++.
+"""
+
+
+def col_terms(k, sqr):
+    t = []
+    for i in range(9):
+        j = k - i
+        if j < 0 or j > 8:
+            continue
+        if not sqr:
+            t.append((f"a.v[{i}]", f"b.v[{j}]"))
+        elif i < j:
+            t.append((f"a.v[{i}]", f"d[{j}]"))
+        elif i == j:
+            t.append((f"a.v[{i}]", f"a.v[{i}]"))
+    return t
+
+
+A_CONS = "v"   # constraint of the a.v[i] operands: "s" in fe_mul_k (a is a wave-uniform constant held in SGPRs)
+
+
+def emit_chain(terms, indent="    "):
+    regs = []
+
+    def idx(name, cons):
+        key = (name, cons)
+        if key not in regs:
+            regs.append(key)
+        return regs.index(key) + 2
+
+    lines = []
+    for (x, y, ys) in terms:
+        xc = A_CONS if x.startswith("a.v[") else "v"
+        lines.append(f"v_mad_u64_u32 %0, %1, %{idx(x, xc)}, %{idx(y, 's' if ys else 'v')}, %0")
+    body = "\\n\\t".join(lines)
+    ins = ", ".join(f'"{c}"({n})' for (n, c) in regs)
+    host = " ".join(f"acc += (uint64_t){x} * {y};" for (x, y, ys) in terms)
+    return (f"{indent}PLUME_FE_CHAIN(\"{body}\", {ins});\n", f"{indent}{host}\n")
+
+
+def gen(name, sqr):
+    dev, host = [], []
+
+    def both(s):
+        dev.append(s)
+        host.append(s)
+
+    both("    uint32_t h[9], l[9];     // l: result limbs (r may alias a or b)\n    uint64_t acc = 0;\n")
+    if sqr:
+        both("    uint32_t d[9];\n    PLUME_UNROLL for (int i = 0; i < 9; i++) d[i] = a.v[i] + a.v[i];\n")
+    for k in range(9, 17):
+        d, h = emit_chain([(x, y, False) for (x, y) in col_terms(k, sqr)])
+        dev.append(d)
+        host.append(h)
+        if k < 16:
+            both(f"    h[{k - 9}] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;\n")
+        else:
+            both("    h[7] = (uint32_t)acc & PLUME_FE_MASK; h[8] = (uint32_t)(acc >> 29);\n    PLUME_FE_ASSERT((acc >> 29) < (1ull << 27));\n    acc = 0;\n")
+    for k in range(9):
+        t = [(x, y, False) for (x, y) in col_terms(k, sqr)]
+        t.append((f"h[{k}]", "K0", True))
+        if k > 0:
+            t.append((f"h[{k - 1}]", "K1", True))
+        if k == 0:
+            t.append(("h[8]", "K2", True))
+        if k == 1:
+            t.append(("h[8]", "K3", True))
+        d, h = emit_chain(t)
+        dev.append(d)
+        host.append(h)
+        if k < 8:
+            both(f"    l[{k}] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;\n")
+    both("""    // acc = column 8 (weight 2^232): bits >= 24 are multiples of 2^256 -> t = t0 + t1 * 2^29, times (2^32 + 977)
+    l[8] = (uint32_t)acc & 0x00FFFFFFu;
+    acc >>= 24;
+    const uint32_t t0 = (uint32_t)acc & PLUME_FE_MASK, t1 = (uint32_t)(acc >> 29);
+    acc = l[0];
+""")
+    dev.append('    PLUME_FE_CHAIN("v_mad_u64_u32 %0, %1, %2, %3, %0", "v"(t0), "s"(K4));\n')
+    host.append("    acc += (uint64_t)t0 * K4;\n")
+    both("    l[0] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;\n    acc += l[1] + t1 * 977u;\n")
+    dev.append('    PLUME_FE_CHAIN("v_mad_u64_u32 %0, %1, %2, %3, %0", "v"(t0), "s"(K5));\n')
+    host.append("    acc += (uint64_t)t0 * K5;\n")
+    both("    l[1] = (uint32_t)acc & PLUME_FE_MASK;\n    l[2] += (uint32_t)(acc >> 29) + (t1 << 3);\n    PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = l[i];\n")
+    sig = f"PLUME_HD void {name}(fe& r, const fe& a)" if sqr else f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b)"
+    check = "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, a));\n" if sqr else "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, b));\n"
+    consts = "    const uint32_t K0 = 31264u, K1 = 256u, K2 = 31264u << 8, K3 = 65536u, K4 = 977u, K5 = 8u;\n"
+    return f"{sig} {{\n{check}{consts}#if defined(__HIP_DEVICE_COMPILE__)\n{''.join(dev)}#else\n{''.join(host)}#endif\n}}\n"
+
+
+def main():
+    print("""// GENERATED by gen_fe_mul.py -- do not edit (see that script for the design and the measurements behind it).
+// Included by plume_field.h inside namespace plume.
+// one chain of multiply-adds on `acc`; the carry-out pair of v_mad_u64_u32 is a dead SGPR pair the compiler picks
+#define PLUME_FE_CHAIN(TEXT, ...) do { uint64_t cy_; asm(TEXT : "+v"(acc), "=&s"(cy_) : __VA_ARGS__); } while (0)
+""")
+    print(gen("fe_mul", False))
+    print(gen("fe_sqr", True))
+    global A_CONS
+    A_CONS = "s"
+    print("// a is a compile-time constant (curve / isogeny coefficients): its limbs stay in SGPRs instead of occupying 9 VGPRs each")
+    print(gen("fe_mul_k", False))
+    print("#undef PLUME_FE_CHAIN")
+
+
+if __name__ == "__main__":
+    main()

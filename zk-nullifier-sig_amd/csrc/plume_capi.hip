@@ -105,8 +105,8 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
         HIPCHK(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
     }
     // generator wide window table (1..128)*G: one lane, once
-    if (ctx->gtab.ensure(PLUME_GTAB8_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(24 * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64)) { delete ctx; return PLUME_ERR_HIP; }
-    uint32_t hb[24];
+    if (ctx->gtab.ensure(PLUME_GTAB8_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(PLUME_JAC_WORDS * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64)) { delete ctx; return PLUME_ERR_HIP; }
+    uint32_t hb[PLUME_JAC_WORDS];
     {
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
         st_jac_soa(hb, 1, 0, g);
@@ -174,8 +174,8 @@ static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* m
                          const uint8_t* preflags = nullptr, bool continue_timer = false) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
-    if (ctx->bases.ensure(24 * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
-        ctx->res.ensure(24 * 4 * 2 * n) || ctx->resinf.ensure(2 * n))
+    if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
+        ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n))
         return PLUME_ERR_HIP;
     VerifyArgs a;
     a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags;
@@ -197,8 +197,8 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
                        hipStream_t st) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
-    if (ctx->bases.ensure(24 * 4 * n) || ctx->jobflags.ensure(n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * n) ||
-        ctx->res.ensure(24 * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->res2.ensure(24 * 4 * 2 * n) || ctx->res2inf.ensure(2 * n) || ctx->pkaff.ensure(16 * 4 * n))
+    if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * n) || ctx->jobflags.ensure(n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * n) ||
+        ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->res2.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->res2inf.ensure(2 * n) || ctx->pkaff.ensure((size_t)2 * PLUME_FE_WORDS * 4 * n))
         return PLUME_ERR_HIP;
     SignArgs a;
     a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.sk = sk; a.r = r; a.pk_in = pk_in;
@@ -216,7 +216,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     launch_normalize(a.hres, a.hresinf, 2 * n, st); t.stage("to_affine_h", st);
     launch_sign_final(a, st); t.stage("sign_final", st);
     // the reference zeroizes secrets: wipe the device-side images derived from sk / r
-    HIPCHK(hipMemsetAsync(ctx->res.p, 0, 24 * 4 * 2 * n, st));
+    HIPCHK(hipMemsetAsync(ctx->res.p, 0, (size_t)PLUME_JAC_WORDS * 4 * 2 * n, st));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -204,23 +204,25 @@ PLUME_HD void booth_store(int8_t* dig, uint32_t stride, const glv_half& h, bool 
 }
 
 // ------------------------------------------------------------------------------------------ window tables
-// One table = 8 entries x 32 words (128 B): [x(8) | y(8) | beta*x(8) | scratch(8)], entry e holds (e+1)*P.
-// Words are little-endian limbs of weakly reduced field elements.
+// One table = 8 entries x 36 words (144 B): [x(9) | y(9) | beta*x(9) | scratch(9)], entry e holds (e+1)*P.
+// Words are the 29-bit limbs of tight field elements (plume_field.h).
 #define PLUME_TAB_ENTRIES 8
-#define PLUME_TAB_ENTRY_WORDS 32
+#define PLUME_FE_W PLUME_FE_WORDS
+#define PLUME_JAC_WORDS (3 * PLUME_FE_WORDS)      // Jacobian point in HBM scratch: x | y | z
+#define PLUME_TAB_ENTRY_WORDS (4 * PLUME_FE_WORDS)
 #define PLUME_TAB_WORDS (PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 
-PLUME_HD void ld_fe(fe& r, const uint32_t* p) { PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = p[i]; }
-PLUME_HD void st_fe(uint32_t* p, const fe& a) { PLUME_UNROLL for (int i = 0; i < 8; i++) p[i] = a.v[i]; }
+PLUME_HD void ld_fe(fe& r, const uint32_t* p) { PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = p[i]; }
+PLUME_HD void st_fe(uint32_t* p, const fe& a) { PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) p[i] = a.v[i]; }
 // strided (SoA) field element: word w of element j lives at base[w*stride + j]
-PLUME_HD void ld_fe_soa(fe& r, const uint32_t* base, size_t stride, size_t j) { PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = base[(size_t)i * stride + j]; }
-PLUME_HD void st_fe_soa(uint32_t* base, size_t stride, size_t j, const fe& a) { PLUME_UNROLL for (int i = 0; i < 8; i++) base[(size_t)i * stride + j] = a.v[i]; }
-// Jacobian point SoA: x words 0..7, y 8..15, z 16..23
+PLUME_HD void ld_fe_soa(fe& r, const uint32_t* base, size_t stride, size_t j) { PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = base[(size_t)i * stride + j]; }
+PLUME_HD void st_fe_soa(uint32_t* base, size_t stride, size_t j, const fe& a) { PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) base[(size_t)i * stride + j] = a.v[i]; }
+// Jacobian point SoA: x words 0..8, y 9..17, z 18..26
 PLUME_HD void ld_jac_soa(jac& p, const uint32_t* base, size_t stride, size_t j) {
-    ld_fe_soa(p.x, base, stride, j); ld_fe_soa(p.y, base + 8 * stride, stride, j); ld_fe_soa(p.z, base + 16 * stride, stride, j);
+    ld_fe_soa(p.x, base, stride, j); ld_fe_soa(p.y, base + PLUME_FE_W * stride, stride, j); ld_fe_soa(p.z, base + 2 * PLUME_FE_W * stride, stride, j);
 }
 PLUME_HD void st_jac_soa(uint32_t* base, size_t stride, size_t j, const jac& p) {
-    st_fe_soa(base, stride, j, p.x); st_fe_soa(base + 8 * stride, stride, j, p.y); st_fe_soa(base + 16 * stride, stride, j, p.z);
+    st_fe_soa(base, stride, j, p.x); st_fe_soa(base + PLUME_FE_W * stride, stride, j, p.y); st_fe_soa(base + 2 * PLUME_FE_W * stride, stride, j, p.z);
 }
 
 #ifndef PLUME_TABLE_MADD
@@ -258,7 +260,7 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
             if (k >= 1 && (k & 1)) {
                 if (k > 1) {
                     const uint32_t* hsrc = tab + job * (size_t)(ENTRIES * PLUME_TAB_ENTRY_WORDS) + (size_t)((k + 1) / 2 - 1) * PLUME_TAB_ENTRY_WORDS;
-                    ld_fe(cur.x, hsrc + 0); ld_fe(cur.y, hsrc + 8); ld_fe(cur.z, hsrc + 16);
+                    ld_fe(cur.x, hsrc + 0); ld_fe(cur.y, hsrc + PLUME_FE_W); ld_fe(cur.z, hsrc + 2 * PLUME_FE_W);
                 }
                 jac_dbl(cur);
             }
@@ -267,7 +269,7 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
 #else
             else if (k > 1) jac_add(cur, b);
 #endif
-            st_fe(e + 0, cur.x); st_fe(e + 8, cur.y); st_fe(e + 16, cur.z); st_fe(e + 24, acc);
+            st_fe(e + 0, cur.x); st_fe(e + PLUME_FE_W, cur.y); st_fe(e + 2 * PLUME_FE_W, cur.z); st_fe(e + 3 * PLUME_FE_W, acc);
             fe_mul(acc, acc, cur.z);
             e += PLUME_TAB_ENTRY_WORDS;
         }
@@ -280,15 +282,14 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
         PLUME_NOUNROLL for (int k = ENTRIES - 1; k >= 0; k--) {
             uint32_t* e = tab + job * (size_t)(ENTRIES * PLUME_TAB_ENTRY_WORDS) + k * PLUME_TAB_ENTRY_WORDS;
             fe X, Y, Zk, cprev, zi, zi2;
-            ld_fe(X, e + 0); ld_fe(Y, e + 8); ld_fe(Zk, e + 16); ld_fe(cprev, e + 24);
+            ld_fe(X, e + 0); ld_fe(Y, e + PLUME_FE_W); ld_fe(Zk, e + 2 * PLUME_FE_W); ld_fe(cprev, e + 3 * PLUME_FE_W);
             fe_mul(zi, inv, cprev);      // 1/Z_k
             fe_mul(inv, inv, Zk);        // inverse of the product before Z_k
             fe_sqr(zi2, zi);
             fe_mul(X, X, zi2);
             fe_mul(zi2, zi2, zi); fe_mul(Y, Y, zi2);
-            fe_normalize(X); fe_normalize(Y);
-            fe bx; fe_mul(bx, X, beta);
-            st_fe(e + 0, X); st_fe(e + 8, Y); st_fe(e + 16, bx);
+            fe bx; fe_mul_k(bx, beta, X);
+            st_fe(e + 0, X); st_fe(e + PLUME_FE_W, Y); st_fe(e + 2 * PLUME_FE_W, bx);     // tight, not canonical: only ever multiplied / negated
         }
     }
 }
@@ -305,7 +306,7 @@ PLUME_HD void normalize_points(uint32_t* pts, const uint8_t* inf, size_t npts, s
     PLUME_UNROLL for (int j = 0; j < PLUME_NORM_K; j++) {
         const size_t idx = lane + (size_t)j * nlanes;
         const bool live = idx < npts && !inf[idx < npts ? idx : 0];
-        if (live) ld_fe_soa(z[j], pts + 16 * npts, npts, idx); else z[j] = fe_small(1);
+        if (live) ld_fe_soa(z[j], pts + 2 * PLUME_FE_W * npts, npts, idx); else z[j] = fe_small(1);
         pre[j] = acc;
         fe_mul(acc, acc, z[j]);
     }
@@ -318,18 +319,18 @@ PLUME_HD void normalize_points(uint32_t* pts, const uint8_t* inf, size_t npts, s
         fe_mul(zi, inv, pre[j]);
         fe_mul(inv, inv, z[j]);
         if (live) {
-            ld_fe_soa(x, pts, npts, idx); ld_fe_soa(y, pts + 8 * npts, npts, idx);
+            ld_fe_soa(x, pts, npts, idx); ld_fe_soa(y, pts + PLUME_FE_W * npts, npts, idx);
             fe_sqr(zi2, zi);
             fe_mul(x, x, zi2);
             fe_mul(zi2, zi2, zi); fe_mul(y, y, zi2);
-            st_fe_soa(pts, npts, idx, x); st_fe_soa(pts + 8 * npts, npts, idx, y);
+            st_fe_soa(pts, npts, idx, x); st_fe_soa(pts + PLUME_FE_W * npts, npts, idx, y);
         }
     }
 }
 
 // ------------------------------------------------------------------------------- fixed-base comb (generator only)
 // k*G with NO doublings: k = sum d_i 256^i (Booth w = 8, d_i in [-128, 128], i = 0..32) and a precomputed table
-// comb[i][e] = (e+1) * 256^i * G  (33 windows x 128 entries, 528 KiB, L2-resident).  33 mixed additions per
+// comb[i][e] = (e+1) * 256^i * G  (33 windows x 128 entries, 594 KiB, L2-resident).  33 mixed additions per
 // multiplication instead of 128 doublings + 34 additions; used by the signer's pk = sk*G and R = r*G
 // (rust-k256/src/randomizedsigner.rs:51,53).
 #define PLUME_COMB_WINDOWS 33
@@ -356,7 +357,7 @@ PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
             const uint32_t* e = comb + ((size_t)i * PLUME_GTAB8_ENTRIES + (size_t)(ad - 1)) * PLUME_TAB_ENTRY_WORDS;
             fe qx, qy;
             ld_fe(qx, e);
-            ld_fe(qy, e + 8);
+            ld_fe(qy, e + PLUME_FE_W);
             if (d < 0) fe_neg(qy, qy);
             jac_madd(acc, qx, qy);
         }
@@ -389,8 +390,8 @@ PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int 
                 int ad = d < 0 ? -d : d;
                 const uint32_t* e = tab + (ad - 1) * PLUME_TAB_ENTRY_WORDS;
                 fe qx, qy;
-                ld_fe(qx, (s & 1) ? e + 16 : e);
-                ld_fe(qy, e + 8);
+                ld_fe(qx, (s & 1) ? e + 2 * PLUME_FE_W : e);
+                ld_fe(qy, e + PLUME_FE_W);
                 if (d < 0) fe_neg(qy, qy);
                 jac_madd(acc, qx, qy);
             }

@@ -1,6 +1,7 @@
 // secp256k1 base field Fp (p = 2^256 - 2^32 - 977) and scalar field Fn arithmetic for the PLUME hot path.
-// Written for gfx950 (CDNA4): 8 x 32-bit limbs per element held in VGPRs, products through v_mad_u64_u32
-// (32x32+64 -> 64), carries through v_add_co/v_addc_co chains (__builtin_addc).  No MFMA: this is integer VALU.
+// Written for gfx950 (CDNA4): Fp elements are 9 x 29-bit limbs in VGPRs with products and their column sums through chains
+// of v_mad_u64_u32 (32x32+64 -> 64) and NO carry chains; Fn elements (a few operations per item) are 8 x 32-bit limbs with
+// v_add_co/v_addc_co chains (__builtin_addc).  No MFMA: this is integer VALU.
 //
 // The same header compiles as plain C++ for the host (tests/devsim) so that the exact device arithmetic is
 // unit-tested on the CPU against the oracle; that build is test infrastructure and is never linked into the
@@ -10,6 +11,9 @@
 // arithmetic from the un-vendored k256 ~0.13.3 crate, rust-k256/Cargo.toml:18).
 #pragma once
 #include <stdint.h>
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(PLUME_FE_CHECK)
+#include <assert.h>
+#endif
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define PLUME_HD __host__ __device__ __forceinline__
@@ -81,171 +85,173 @@ PLUME_HD uint32_t addc0(uint32_t a, uint32_t& c) { return addc(a, opaque_zero(),
 PLUME_HD uint32_t subb0(uint32_t a, uint32_t& bw) { return subb(a, opaque_zero(), bw); }
 
 // ------------------------------------------------------------------------------------------------------- Fp
-// Invariant: every fe is an arbitrary 256-bit integer v in [0, 2^256) standing for v mod p ("weakly reduced").
-// 2^256 = PC (mod p) with PC = 2^32 + 977, so a carry out of bit 256 folds back as +PC.  Values in [p, 2^256)
-// are legal (non-canonical zero..PC-1); fe_normalize gives the canonical representative where one is needed
-// (comparisons, parity, serialisation).
+// Representation: 9 limbs of 29 bits in 32-bit VGPRs, value = sum v[i] * 2^(29 i) (mod p), NOT necessarily reduced.
+// Why not 8 x 32: on gfx950 a carry-chain step (v_add_co / v_addc_co) costs as much issue time as a 32x32+64
+// multiply-add, and the saturated product is 73 multiply-adds + ~105 carry steps.  With 29-bit limbs a product column
+// accumulates inside the 64-bit addend of chained v_mad_u64_u32, and additions are 9 independent plain adds
+// (tests/gpu_debug/instr_rates_r01.txt, gen_fe_mul.py).
+//
+// Limb bounds ("magnitudes") are the caller's contract, checked by assertions in host builds with PLUME_FE_CHECK:
+//   tight      limbs 0..7 <= 2^29 + 2^19, limb 8 <= 2^24 + 2^10        what fe_mul / fe_sqr / fe_carry / fe_add / fe_sub return
+//   fe_mul, fe_sqr inputs: 9 * max(a[0..7]) * max(b[0..7]) < 2^64 - 2^50 and limb 8 <= 2^27 on both sides, i.e. both
+//              operands up to ~1.3 * 2^30 (sums of two tight values), or one up to 2^31 and the other tight
+//   fe_add_lazy / fe_sub_lazy<M> return unreduced sums: limb bounds add (a + M*p - b), no carry pass
+//   fe_normalize gives the canonical representative (limbs < 2^29, value < p) where one is needed (comparisons, parity,
+//              serialisation).
 struct fe {
-    uint32_t v[8];
+    uint32_t v[9];
 };
+#define PLUME_FE_MASK 0x1FFFFFFFu
+#define PLUME_FE_WORDS 9          // 32-bit words per field element in HBM scratch (limb form)
 #define PLUME_PC977 977u
 
-PLUME_HD fe fe_zero() { fe r; PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
-PLUME_HD fe fe_small(uint32_t x) { fe r = fe_zero(); r.v[0] = x; return r; }
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(PLUME_FE_CHECK)
+#define PLUME_FE_ASSERT(x) assert(x)
+#else
+#define PLUME_FE_ASSERT(x) ((void)0)
+#endif
+
+// p = 2^256 - 2^32 - 977 as limbs: (2^29 - 977), (2^29 - 1 - 8), 2^29 - 1 (x6), 2^24 - 1
+PLUME_HD constexpr uint32_t fe_p(int i) { return i == 0 ? 0x1FFFFC2Fu : i == 1 ? 0x1FFFFFF7u : i == 8 ? 0x00FFFFFFu : 0x1FFFFFFFu; }
+
+PLUME_HD fe fe_zero() { fe r; PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = 0; return r; }
+PLUME_HD fe fe_small(uint32_t x) { fe r = fe_zero(); r.v[0] = x & PLUME_FE_MASK; r.v[1] = x >> 29; return r; }
+PLUME_HD bool fe_is_tight(const fe& a) {
+    bool ok = a.v[8] <= (1u << 24) + (1u << 10);
+    PLUME_UNROLL for (int i = 0; i < 8; i++) ok = ok && a.v[i] <= (1u << 29) + (1u << 19);
+    return ok;
+}
+PLUME_HD bool fe_mul_inputs_ok(const fe& a, const fe& b) {
+    uint64_t ma = 0, mb = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) { if (a.v[i] > ma) ma = a.v[i]; if (b.v[i] > mb) mb = b.v[i]; }
+    if (a.v[8] > (1u << 27) || b.v[8] > (1u << 27) || ma >= (1ull << 31) || mb >= (1ull << 31)) return false;
+    const uint64_t prod = ma * mb;                                     // < 2^62
+    return prod < ((0xFFFFFFFFFFFFFFFFull - (1ull << 50)) / 9);
+}
+
+// 8 x 32-bit little-endian words (any 256-bit integer) <-> limbs
+PLUME_HD void fe_from_words(fe& r, const uint32_t w[8]) {
+    PLUME_UNROLL for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+        uint32_t x = w[wi] >> sh;
+        if (sh > 3 && wi + 1 < 8) x |= w[wi + 1] << (32 - sh);
+        r.v[i] = x & PLUME_FE_MASK;
+    }
+}
+// exact inverse for a CANONICAL value (limbs < 2^29, top < 2^24)
+PLUME_HD void fe_to_words(uint32_t w[8], const fe& a) {
+    PLUME_UNROLL for (int k = 0; k < 8; k++) {
+        const int bit = 32 * k, li = bit / 29, sh = bit - 29 * li;   // word k = bits [32k, 32k+32)
+        uint32_t x = a.v[li] >> sh;
+        const int have = 29 - sh;
+        if (li + 1 < 9) x |= a.v[li + 1] << have;
+        if (have + 29 < 32 && li + 2 < 9) x |= a.v[li + 2] << (have + 29);
+        w[k] = x;
+    }
+}
 PLUME_HD fe fe_set(uint32_t w7, uint32_t w6, uint32_t w5, uint32_t w4, uint32_t w3, uint32_t w2, uint32_t w1, uint32_t w0) {
-    fe r; r.v[0] = w0; r.v[1] = w1; r.v[2] = w2; r.v[3] = w3; r.v[4] = w4; r.v[5] = w5; r.v[6] = w6; r.v[7] = w7; return r;  // big-endian word order, as hex reads
+    const uint32_t w[8] = {w0, w1, w2, w3, w4, w5, w6, w7};   // arguments in big-endian word order, as hex reads
+    fe r; fe_from_words(r, w); return r;
 }
 
-// r += c*PC for a carry bit c in {0,1} out of bit 256, twice (the second can only touch limbs 0..1)
-PLUME_HD void fe_fold_carry(fe& r, uint32_t c) {
-    uint32_t k = 0;
-    r.v[0] = addc(r.v[0], (0u - c) & PLUME_PC977, k);
-    r.v[1] = addc(r.v[1], c, k);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc0(r.v[i], k);
-    // wrapped again: now r < PC, so adding PC stays below 2^34
-    uint32_t k2 = 0;
-    r.v[0] = addc(r.v[0], (0u - k) & PLUME_PC977, k2);
-    r.v[1] = r.v[1] + k + k2;
+// One parallel carry pass: any limbs < 2^32 -> tight.  The part above bit 256 folds as *(2^32 + 977) into limbs 0 and 1.
+PLUME_HD void fe_carry(fe& a) {
+    const uint32_t t = a.v[8] >> 24;
+    uint32_t c[8];
+    PLUME_UNROLL for (int i = 0; i < 8; i++) c[i] = a.v[i] >> 29;
+    a.v[0] = (a.v[0] & PLUME_FE_MASK) + t * 977u;
+    a.v[1] = (a.v[1] & PLUME_FE_MASK) + c[0] + (t << 3);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) a.v[i] = (a.v[i] & PLUME_FE_MASK) + c[i - 1];
+    a.v[8] = (a.v[8] & 0x00FFFFFFu) + c[7];
 }
-PLUME_HD void fe_add(fe& r, const fe& a, const fe& b) {
+PLUME_HD void fe_add_lazy(fe& r, const fe& a, const fe& b) {
+    PLUME_UNROLL for (int i = 0; i < 9; i++) { PLUME_FE_ASSERT((uint64_t)a.v[i] + b.v[i] < (1ull << 32)); r.v[i] = a.v[i] + b.v[i]; }
+}
+// r = a + M*p - b limbwise: needs b[i] <= M*p[i] and a[i] + M*p[i] < 2^32.  M = 2 covers a tight b, M = 4 a sum of two.
+template <int M>
+PLUME_HD void fe_sub_lazy(fe& r, const fe& a, const fe& b) {
+    PLUME_UNROLL for (int i = 0; i < 9; i++) {
+        PLUME_FE_ASSERT(b.v[i] <= (uint32_t)M * fe_p(i) && (uint64_t)a.v[i] + (uint32_t)M * fe_p(i) < (1ull << 32));
+        r.v[i] = a.v[i] + ((uint32_t)M * fe_p(i) - b.v[i]);
+    }
+}
+// safe defaults: any operands with limbs <= 2^31 - 2^13 (sums of up to three tight values), tight result
+PLUME_HD void fe_add(fe& r, const fe& a, const fe& b) { fe_add_lazy(r, a, b); fe_carry(r); }
+PLUME_HD void fe_sub(fe& r, const fe& a, const fe& b) { fe_sub_lazy<4>(r, a, b); fe_carry(r); }
+PLUME_HD void fe_neg(fe& r, const fe& a) { fe z = fe_zero(); fe_sub_lazy<4>(r, z, a); fe_carry(r); }
+PLUME_HD void fe_dbl(fe& r, const fe& a) { fe_add_lazy(r, a, a); fe_carry(r); }
+
+// canonical representative in [0, p): limbs < 2^29, top limb < 2^24
+PLUME_HD void fe_ripple(fe& a) {   // sequential carry: limbs 0..7 < 2^29 afterwards, the excess collects in limb 8
     uint32_t c = 0;
-    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = addc(a.v[i], b.v[i], c);
-    fe_fold_carry(r, c);
+    PLUME_UNROLL for (int i = 0; i < 8; i++) { a.v[i] += c; c = a.v[i] >> 29; a.v[i] &= PLUME_FE_MASK; }
+    a.v[8] += c;
 }
-PLUME_HD void fe_sub(fe& r, const fe& a, const fe& b) {
-    uint32_t bw = 0;
-    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = subb(a.v[i], b.v[i], bw);
-    // a - b + 2^256 = a - b + PC (mod p): take PC back out; a second borrow can only touch limbs 0..1
-    uint32_t k = 0;
-    r.v[0] = subb(r.v[0], (0u - bw) & PLUME_PC977, k);
-    r.v[1] = subb(r.v[1], bw, k);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = subb0(r.v[i], k);
-    uint32_t k2 = 0;
-    r.v[0] = subb(r.v[0], (0u - k) & PLUME_PC977, k2);
-    r.v[1] = r.v[1] - k - k2;
-}
-PLUME_HD void fe_neg(fe& r, const fe& a) { fe z = fe_zero(); fe_sub(r, z, a); }
-PLUME_HD void fe_dbl(fe& r, const fe& a) { fe_add(r, a, a); }
-
-// canonical representative in [0, p)
 PLUME_HD void fe_normalize(fe& a) {
-    fe t;
-    uint32_t c = 0;
-    t.v[0] = addc(a.v[0], PLUME_PC977, c);
-    t.v[1] = addc(a.v[1], 1u, c);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) t.v[i] = addc0(a.v[i], c);
-    // carry <=> a + PC >= 2^256 <=> a >= p
-    PLUME_UNROLL for (int i = 0; i < 8; i++) a.v[i] = c ? t.v[i] : a.v[i];
+    fe_carry(a);
+    fe_ripple(a);
+    const uint32_t t = a.v[8] >> 24;               // 0 or 1
+    a.v[8] &= 0x00FFFFFFu;
+    a.v[0] += t * 977u; a.v[1] += t << 3;
+    fe_ripple(a);                                   // value < 2^256 now (if t was 1 the low part was tiny)
+    // a >= p  <=>  a + (2^32 + 977) reaches bit 256; the sum with that bit cleared is a - p
+    fe u = a;
+    u.v[0] += 977u; u.v[1] += 8u;
+    fe_ripple(u);
+    const bool ge = (u.v[8] >> 24) != 0;
+    u.v[8] &= 0x00FFFFFFu;
+    PLUME_UNROLL for (int i = 0; i < 9; i++) a.v[i] = ge ? u.v[i] : a.v[i];
 }
-PLUME_HD bool fe_is_zero(const fe& a) {  // a == 0 (mod p): a is 0 or p
-    uint32_t z = 0, pp = (a.v[0] ^ 0xFFFFFC2Fu) | (a.v[1] ^ 0xFFFFFFFEu);
-    PLUME_UNROLL for (int i = 0; i < 8; i++) z |= a.v[i];
-    PLUME_UNROLL for (int i = 2; i < 8; i++) pp |= ~a.v[i];
+PLUME_HD bool fe_is_zero(const fe& a) {  // a == 0 (mod p), any limbs < 2^32
+    fe t = a;
+    fe_carry(t);
+    fe_ripple(t);                                   // unique limbs 0..7; value < 2^256 + 2^236 < 2p: zero is 0 or p
+    uint32_t z = 0, pp = t.v[8] ^ fe_p(8);
+    PLUME_UNROLL for (int i = 0; i < 9; i++) z |= t.v[i];
+    PLUME_UNROLL for (int i = 0; i < 8; i++) pp |= t.v[i] ^ fe_p(i);
     return z == 0 || pp == 0;
 }
 PLUME_HD bool fe_eq(const fe& a, const fe& b) { fe d; fe_sub(d, a, b); return fe_is_zero(d); }
 PLUME_HD bool fe_is_odd(const fe& a) { fe t = a; fe_normalize(t); return t.v[0] & 1; }
-PLUME_HD void fe_cmov(fe& r, const fe& a, bool flag) { PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = flag ? a.v[i] : r.v[i]; }
-// true iff the 256-bit integer is < p (canonical encoding check for caller-supplied coordinates)
-PLUME_HD bool fe_is_canonical(const fe& a) {
+PLUME_HD void fe_cmov(fe& r, const fe& a, bool flag) { PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = flag ? a.v[i] : r.v[i]; }
+// true iff the 256-bit integer in 8 little-endian words is < p (canonical encoding check for caller-supplied coordinates)
+PLUME_HD bool words_lt_p(const uint32_t w[8]) {
     uint32_t c = 0;
-    (void)addc(a.v[0], PLUME_PC977, c);
-    (void)addc(a.v[1], 1u, c);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) (void)addc0(a.v[i], c);
+    (void)addc(w[0], PLUME_PC977, c);
+    (void)addc(w[1], 1u, c);
+    PLUME_UNROLL for (int i = 2; i < 8; i++) (void)addc0(w[i], c);
     return c == 0;
 }
 
-// 256x256 -> 512: row-wise; the 8 products of a row are independent v_mad_u64_u32 (addend = the running limb),
-// their high words ripple through one v_addc chain.  a_i*b_j + t <= 2^64 - 2^32, so nothing overflows.
-PLUME_HD void mul_wide(uint32_t t[16], const uint32_t a[8], const uint32_t b[8]) {
-    PLUME_UNROLL for (int i = 0; i < 16; i++) t[i] = 0;
-    PLUME_UNROLL for (int i = 0; i < 8; i++) {
-        uint64_t p[8];
-        PLUME_UNROLL for (int j = 0; j < 8; j++) p[j] = (uint64_t)a[i] * b[j] + t[i + j];
-        uint32_t c = 0;
-        t[i] = (uint32_t)p[0];
-        PLUME_UNROLL for (int j = 1; j < 8; j++) t[i + j] = addc((uint32_t)p[j], (uint32_t)(p[j - 1] >> 32), c);
-        t[i + 8] = (uint32_t)(p[7] >> 32) + c;
-    }
-}
-// a^2 as 512 bits: off-diagonal products once, doubled, plus the diagonal
-PLUME_HD void sqr_wide(uint32_t t[16], const uint32_t a[8]) {
-    PLUME_UNROLL for (int i = 0; i < 16; i++) t[i] = 0;
-    PLUME_UNROLL for (int i = 0; i < 7; i++) {  // row i: a_i * a_j, j > i, lands at limbs i+j ..
-        uint64_t p[8];
-        PLUME_UNROLL for (int j = i + 1; j < 8; j++) p[j] = (uint64_t)a[i] * a[j] + t[i + j];
-        uint32_t c = 0;
-        t[2 * i + 1] = (uint32_t)p[i + 1];
-        PLUME_UNROLL for (int j = i + 2; j < 8; j++) t[i + j] = addc((uint32_t)p[j], (uint32_t)(p[j - 1] >> 32), c);
-        t[i + 8] = (uint32_t)(p[7] >> 32) + c;
-    }
-    // t = 2*t + sum a_i^2 * 2^(64 i)
-    uint32_t top = 0, c = 0;
-    PLUME_UNROLL for (int i = 0; i < 16; i++) { uint32_t nt = t[i] >> 31; t[i] = (t[i] << 1) | top; top = nt; }
-    PLUME_UNROLL for (int i = 0; i < 8; i++) {
-        uint64_t s = (uint64_t)a[i] * a[i];
-        t[2 * i] = addc(t[2 * i], (uint32_t)s, c);
-        t[2 * i + 1] = addc(t[2 * i + 1], (uint32_t)(s >> 32), c);
-    }
-}
-// 512 -> weakly reduced 256: lo + hi*PC, PC = 2^32 + 977
-PLUME_HD void fe_reduce_wide(fe& r, const uint32_t t[16]) {
-    // u = lo + hi*977  (9 limbs)
-    uint32_t u[10];
-    {
-        uint64_t q[8];
-        PLUME_UNROLL for (int i = 0; i < 8; i++) q[i] = (uint64_t)t[8 + i] * PLUME_PC977 + t[i];
-        uint32_t c = 0;
-        u[0] = (uint32_t)q[0];
-        PLUME_UNROLL for (int i = 1; i < 8; i++) u[i] = addc((uint32_t)q[i], (uint32_t)(q[i - 1] >> 32), c);
-        u[8] = (uint32_t)(q[7] >> 32) + c;  // < 2^11
-    }
-    // u += hi << 32  (10 limbs; top < 2)
-    {
-        uint32_t c = 0;
-        PLUME_UNROLL for (int i = 1; i < 8; i++) u[i] = addc(u[i], t[8 + i - 1], c);
-        u[8] = addc(u[8], t[15], c);
-        u[9] = c;
-    }
-    // fold the part above bit 256: top = u[8] + u[9]*2^32 (< 2^34);  top*PC = top*977 + (top << 32)
-    uint64_t m = (uint64_t)u[8] * PLUME_PC977 + (uint64_t)u[9] * ((uint64_t)PLUME_PC977 << 32);  // < 2^44
-    uint32_t c = 0;
-    r.v[0] = addc(u[0], (uint32_t)m, c);
-    r.v[1] = addc(u[1], (uint32_t)(m >> 32), c);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc0(u[i], c);
-    uint32_t c2 = 0;
-    r.v[1] = addc(r.v[1], u[8], c2);
-    r.v[2] = addc(r.v[2], u[9], c2);
-    PLUME_UNROLL for (int i = 3; i < 8; i++) r.v[i] = addc0(r.v[i], c2);
-    fe_fold_carry(r, c + c2);  // at most one of the two chains can carry out (total < 2^256 + 2^67)
-}
-PLUME_HD void fe_mul(fe& r, const fe& a, const fe& b) {
-    uint32_t t[16];
-    mul_wide(t, a.v, b.v);
-    fe_reduce_wide(r, t);
-}
-PLUME_HD void fe_sqr(fe& r, const fe& a) {
-    uint32_t t[16];
-    sqr_wide(t, a.v);
-    fe_reduce_wide(r, t);
-}
-// r = a * k for a small k (k*2^256 folds as k*PC; k < 2^20)
+#include "plume_fe_mul.inc"
+
+// r = a * k for a small k (< 2^20), any a with limbs < 2^32; tight result
 PLUME_HD void fe_mul_small(fe& r, const fe& a, uint32_t k) {
-    uint64_t q[8];
-    PLUME_UNROLL for (int i = 0; i < 8; i++) q[i] = (uint64_t)a.v[i] * k;
-    uint32_t c = 0;
-    r.v[0] = (uint32_t)q[0];
-    PLUME_UNROLL for (int i = 1; i < 8; i++) r.v[i] = addc((uint32_t)q[i], (uint32_t)(q[i - 1] >> 32), c);
-    uint32_t top = (uint32_t)(q[7] >> 32) + c;  // < k
-    uint64_t m = (uint64_t)top * PLUME_PC977;   // top*PC = m + (top << 32)
-    uint32_t c1 = 0;
-    r.v[0] = addc(r.v[0], (uint32_t)m, c1);
-    r.v[1] = addc(r.v[1], (uint32_t)(m >> 32), c1);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc0(r.v[i], c1);
-    uint32_t c2 = 0;
-    r.v[1] = addc(r.v[1], top, c2);
-    PLUME_UNROLL for (int i = 2; i < 8; i++) r.v[i] = addc0(r.v[i], c2);
-    fe_fold_carry(r, c1 + c2);
+    // k is hidden from the optimiser: with a literal 11 hipcc (ROCm 7.2) strength-reduces the 64-bit products into shift/add
+    // chains and then merges their carries wrongly (the uaddo_carry combine described at opaque_zero(); caught by
+    // tests/gpu_debug/fe_diff.hip) -- an opaque k keeps each product one v_mad_u64_u32
+    k = opaque_u32(k);
+    uint32_t l[9];
+    uint64_t acc = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) { acc += (uint64_t)a.v[i] * k; l[i] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29; }
+    acc += (uint64_t)a.v[8] * k;
+    l[8] = (uint32_t)acc & 0x00FFFFFFu;
+    const uint64_t t = acc >> 24;                  // < 2^29: multiples of 2^256 -> t * (2^32 + 977)
+    acc = l[0] + t * 977u;
+    l[0] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;
+    acc += l[1] + (t << 3);
+    l[1] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;
+    l[2] += (uint32_t)acc;
+    PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = l[i];
+}
+// lo + hi * 2^256 for two 256-bit integers given as words (hash_to_field's 48-byte OS2IP): hi * (2^32 + 977) + lo
+PLUME_HD void fe_from_words16(fe& r, const uint32_t t[16]) {
+    fe lo, hi, pc = fe_zero();
+    fe_from_words(lo, t);
+    fe_from_words(hi, t + 8);
+    pc.v[0] = 977u; pc.v[1] = 8u;                  // 2^32 + 977
+    fe_mul_k(hi, pc, hi);
+    fe_add(r, lo, hi);
 }
 PLUME_HD void fe_sqr_n(fe& r, const fe& a, int n) {
     r = a;
@@ -291,28 +297,32 @@ PLUME_HD void fe_sqrt_candidate(fe& r, const fe& a) {
     fe_sqr_n(r, t, 2);
 }
 
-// big-endian 32 bytes <-> fe.  The pointers may be unaligned (caller arrays are byte arrays).
-PLUME_HD void fe_from_be(fe& r, const uint8_t* b) {
+// big-endian 32 bytes <-> little-endian words.  The pointers may be unaligned (caller arrays are byte arrays).
+PLUME_HD void words_from_be(uint32_t w[8], const uint8_t* b) {
     PLUME_UNROLL for (int i = 0; i < 8; i++) {
         const uint8_t* q = b + 4 * (7 - i);
-        r.v[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+        w[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
     }
 }
-PLUME_HD void fe_to_be(uint8_t* b, const fe& a) {  // a must be canonical
+PLUME_HD void words_to_be(uint8_t* b, const uint32_t w[8]) {
     PLUME_UNROLL for (int i = 0; i < 8; i++) {
         uint8_t* q = b + 4 * (7 - i);
-        q[0] = (uint8_t)(a.v[i] >> 24); q[1] = (uint8_t)(a.v[i] >> 16); q[2] = (uint8_t)(a.v[i] >> 8); q[3] = (uint8_t)a.v[i];
+        q[0] = (uint8_t)(w[i] >> 24); q[1] = (uint8_t)(w[i] >> 16); q[2] = (uint8_t)(w[i] >> 8); q[3] = (uint8_t)w[i];
     }
 }
 // 16-byte-aligned variants (caller arrays of 32/64-byte records in HBM are at least 16-byte aligned)
-PLUME_HD void fe_from_be_aligned(fe& r, const uint8_t* b) {
-    const uint32_t* w = (const uint32_t*)b;
-    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = bswap32(w[7 - i]);
+PLUME_HD void words_from_be_aligned(uint32_t w[8], const uint8_t* b) {
+    const uint32_t* q = (const uint32_t*)b;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) w[i] = bswap32(q[7 - i]);
 }
-PLUME_HD void fe_to_be_aligned(uint8_t* b, const fe& a) {
-    uint32_t* w = (uint32_t*)b;
-    PLUME_UNROLL for (int i = 0; i < 8; i++) w[7 - i] = bswap32(a.v[i]);
+PLUME_HD void words_to_be_aligned(uint8_t* b, const uint32_t w[8]) {
+    uint32_t* q = (uint32_t*)b;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) q[7 - i] = bswap32(w[i]);
 }
+PLUME_HD void fe_from_be(fe& r, const uint8_t* b) { uint32_t w[8]; words_from_be(w, b); fe_from_words(r, w); }
+PLUME_HD void fe_from_be_aligned(fe& r, const uint8_t* b) { uint32_t w[8]; words_from_be_aligned(w, b); fe_from_words(r, w); }
+PLUME_HD void fe_to_be(uint8_t* b, const fe& a) { uint32_t w[8]; fe_to_words(w, a); words_to_be(b, w); }                   // a must be canonical
+PLUME_HD void fe_to_be_aligned(uint8_t* b, const fe& a) { uint32_t w[8]; fe_to_words(w, a); words_to_be_aligned(b, w); }   // a must be canonical
 
 // ------------------------------------------------------------------------------------------------------- Fn
 // Scalars mod n, 8 x 32-bit limbs, canonical (< n).  Used once or twice per item (range checks, GLV split,

@@ -29,14 +29,16 @@ PLUME_HD uint32_t dst_prime_byte(uint32_t k) {
 #define PLUME_ENC_NONE 0u      // nothing appended (raw hash_from_bytes(&[msg]) — KAT pinning)
 #define PLUME_ENC_IDENTITY 1u  // the single byte 00
 #define PLUME_ENC_POINT 33u    // tag || x
-// b0 = SHA256( 0^64 || msg || enc(pk) || 00 60 00 || DST' ); elen = length of enc(pk): 0, 1 or 33
+// b0 = SHA256( 0^64 || msg || enc(pk) || 00 60 00 || DST' ); elen = length of enc(pk): 0, 1 or 33; pkx must be CANONICAL
 PLUME_HD void xmd_b0(uint32_t b0[8], const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag, uint32_t elen) {
     const uint32_t len = mlen + elen + 53u;
+    uint32_t xw[8];
+    fe_to_words(xw, pkx);
     sha256_init_after_zero_block(b0);
     sha256_absorb_pad(b0, 64u, len, [&](uint32_t pos) -> uint32_t {
         if (pos < mlen) return msg[pos];
         uint32_t k = pos - mlen;
-        if (k < elen) return k == 0 ? (elen == PLUME_ENC_IDENTITY ? 0u : tag) : be_byte_of_limbs(pkx.v, k - 1);
+        if (k < elen) return k == 0 ? (elen == PLUME_ENC_IDENTITY ? 0u : tag) : be_byte_of_limbs(xw, k - 1);
         k -= elen;
         if (k < 3) return k == 1 ? 0x60u : 0u;   // I2OSP(96, 2) || I2OSP(0, 1)
         return dst_prime_byte(k - 3);
@@ -59,9 +61,9 @@ PLUME_HD void xmd_bi(uint32_t out[8], const uint32_t x[8], uint32_t idx) {
 // hash_to_field: two field elements from 96 uniform bytes, each OS2IP(48 B) mod p (mod.rs:32-50)
 PLUME_HD void fe_from_be48_words(fe& r, const uint32_t* w /* 12 big-endian words, most significant first */) {
     uint32_t t[16];
-    PLUME_UNROLL for (int i = 0; i < 12; i++) t[i] = opaque_u32(w[11 - i]);   // SHA words: see opaque_zero() in plume_field.h
+    PLUME_UNROLL for (int i = 0; i < 12; i++) t[i] = w[11 - i];
     PLUME_UNROLL for (int i = 12; i < 16; i++) t[i] = 0;
-    fe_reduce_wide(r, t);
+    fe_from_words16(r, t);
 }
 PLUME_HD void hash_to_field2(fe& u0, fe& u1, const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag, uint32_t elen) {
     uint32_t b0[8], uni[24], x[8];
@@ -87,10 +89,10 @@ PLUME_HD void sswu_frac(fe& xn, fe& xd, fe& y, const fe& u) {
     fe_add(tv3, tv2, one);
     fe_mul_small(tv3, tv3, 1771);                          // B'
     if (fe_is_zero(tv2)) { tv4 = fe_small(11); fe_neg(tv4, tv4); } else { fe_neg(tv4, tv2); }
-    fe_mul(tv4, A, tv4);
+    fe_mul_k(tv4, A, tv4);
     fe_sqr(tv2, tv3);
     fe_sqr(tv6, tv4);
-    fe_mul(tv5, A, tv6);
+    fe_mul_k(tv5, A, tv6);
     fe_add(tv2, tv2, tv5);
     fe_mul(tv2, tv2, tv3);
     fe_mul(tv6, tv6, tv4);
@@ -106,7 +108,7 @@ PLUME_HD void sswu_frac(fe& xn, fe& xd, fe& y, const fe& u) {
     fe_mul(y1, y1, s2);
     fe_sqr(s3, y1); fe_mul(s3, s3, tv6);
     bool is_sq = fe_eq(s3, tv2);
-    fe y2; fe_mul(y2, y1, fe_sqrt_neg_z());
+    fe y2; fe_mul_k(y2, fe_sqrt_neg_z(), y1);
     fe_cmov(y1, y2, !is_sq);
     fe_mul(y, tv1, u);
     fe_mul(y, y, y1);
@@ -138,13 +140,13 @@ PLUME_HD void iso3_frac_to_jac(jac& q, const fe& xn, const fe& xd, const fe& y) 
     fe_sqr(xn2, xn); fe_mul(xn3, xn2, xn);
     fe_mul(n2d, xn2, xd); fe_mul(nd2, xn, xd2);
     // Nx = k13 xn^3 + k12 xn^2 xd + k11 xn xd^2 + k10 xd^3
-    fe_mul(nx, k13, xn3); fe_mul(t, k12, n2d); fe_add(nx, nx, t); fe_mul(t, k11, nd2); fe_add(nx, nx, t); fe_mul(t, k10, xd3); fe_add(nx, nx, t);
+    fe_mul_k(nx, k13, xn3); fe_mul_k(t, k12, n2d); fe_add(nx, nx, t); fe_mul_k(t, k11, nd2); fe_add(nx, nx, t); fe_mul_k(t, k10, xd3); fe_add(nx, nx, t);
     // Dx = xd * (xn^2 + k21 xn xd + k20 xd^2)
-    fe_mul(dx, k21, xn); fe_mul(dx, dx, xd); fe_add(dx, dx, xn2); fe_mul(t, k20, xd2); fe_add(dx, dx, t); fe_mul(dx, dx, xd);
+    fe_mul_k(dx, k21, xn); fe_mul(dx, dx, xd); fe_add(dx, dx, xn2); fe_mul_k(t, k20, xd2); fe_add(dx, dx, t); fe_mul(dx, dx, xd);
     // Ny = k33 xn^3 + k32 xn^2 xd + k31 xn xd^2 + k30 xd^3
-    fe_mul(ny, k33, xn3); fe_mul(t, k32, n2d); fe_add(ny, ny, t); fe_mul(t, k31, nd2); fe_add(ny, ny, t); fe_mul(t, k30, xd3); fe_add(ny, ny, t);
+    fe_mul_k(ny, k33, xn3); fe_mul_k(t, k32, n2d); fe_add(ny, ny, t); fe_mul_k(t, k31, nd2); fe_add(ny, ny, t); fe_mul_k(t, k30, xd3); fe_add(ny, ny, t);
     // Dy = xn^3 + k42 xn^2 xd + k41 xn xd^2 + k40 xd^3
-    fe_mul(dy, k42, n2d); fe_add(dy, dy, xn3); fe_mul(t, k41, nd2); fe_add(dy, dy, t); fe_mul(t, k40, xd3); fe_add(dy, dy, t);
+    fe_mul_k(dy, k42, n2d); fe_add(dy, dy, xn3); fe_mul_k(t, k41, nd2); fe_add(dy, dy, t); fe_mul_k(t, k40, xd3); fe_add(dy, dy, t);
     // x' = Nx/Dx, y' = y Ny/Dy;  Z = Dx Dy, X = Nx Dx Dy^2, Y = y Ny Dx^3 Dy^2
     fe dy2, w;
     fe_mul(q.z, dx, dy);

@@ -1,5 +1,5 @@
 // gfx950 (CDNA4 / MI355X) kernels of the batch PLUME engine.  Each kernel is a thin index-mapping wrapper over a
-// per-lane body in plume_stages.h; the heavy integer work (8x32-bit-limb Fp arithmetic through v_mad_u64_u32) is
+// per-lane body in plume_stages.h; the heavy integer work (9x29-bit-limb Fp arithmetic through chains of v_mad_u64_u32) is
 // all in those headers.  Geometry: 256-thread workgroups (4 wavefronts), one item / job-group / task per lane,
 // grids of n/256 workgroups (>> 256 CUs at the batch sizes this engine is built for).
 //
@@ -10,14 +10,17 @@
 // the ~10^6 VALU instructions per item.
 #include "plume_launch.h"
 
+// Minimum waves per SIMD the register allocator must leave room for (HIP's second __launch_bounds__ argument).  The
+// instruction-rate probe (tests/gpu_debug/instr_rates_r01.txt) shows the VALU saturates at 4 waves per SIMD and loses
+// 2-3x at one; without a floor hipcc takes up to 300 VGPRs for the hash-to-curve kernels (one wave per SIMD).
+#ifndef PLUME_MIN_WAVES
+#define PLUME_MIN_WAVES 4
+#endif
 #ifndef PLUME_MSM_WAVES
-#define PLUME_MSM_WAVES 0   // 0: compiler default; N: __launch_bounds__(kBlock, N) for the multi-scalar kernels
+#define PLUME_MSM_WAVES PLUME_MIN_WAVES
 #endif
-#if PLUME_MSM_WAVES
+#define PLUME_BOUNDS __launch_bounds__(kBlock, PLUME_MIN_WAVES)
 #define PLUME_MSM_BOUNDS __launch_bounds__(kBlock, PLUME_MSM_WAVES)
-#else
-#define PLUME_MSM_BOUNDS __launch_bounds__(kBlock)
-#endif
 #ifndef PLUME_GTAB_IN_LDS
 #define PLUME_GTAB_IN_LDS 0
 #endif
@@ -38,12 +41,12 @@ __global__ void k_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* 
     if (blockIdx.x == 0 && threadIdx.x == 0) table_build<PLUME_GTAB8_ENTRIES>(gtab8, base_g, flag, 1, 0, 1);
 }
 
-__global__ __launch_bounds__(kBlock) void k_verify_ingest(VerifyArgs a) {
+__global__ PLUME_BOUNDS void k_verify_ingest(VerifyArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) verify_ingest_h2c(a, i);
 }
 
-__global__ __launch_bounds__(kBlock) void k_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
+__global__ PLUME_BOUNDS void k_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
     size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x;
     size_t j0 = lane * (size_t)L;
     if (j0 < njobs) {
@@ -71,12 +74,12 @@ __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
     if (i < a.n) verify_msm(a, i, eq, gt, s_dig + threadIdx.x, kBlock);
 }
 
-__global__ __launch_bounds__(kBlock) void k_verify_finalize(VerifyArgs a) {
+__global__ PLUME_BOUNDS void k_verify_finalize(VerifyArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) verify_finalize(a, i);
 }
 
-__global__ __launch_bounds__(kBlock) void k_sign_gmul(SignArgs a) {
+__global__ PLUME_BOUNDS void k_sign_gmul(SignArgs a) {
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_sign_gmul(SignArgs a) {
 
 // one-time: comb[i] = table of 256^i * G, i = 0..32.  Lane i first walks 8*i doublings from G (a few hundred
 // microseconds once per context), then builds its 128-entry window.
-__global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* 24 x 33 words scratch */, uint8_t* flags /* 33 */) {
+__global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* PLUME_JAC_WORDS x 33 words scratch */, uint8_t* flags /* 33 */) {
     const uint32_t i = threadIdx.x;
     if (blockIdx.x != 0 || i >= PLUME_COMB_WINDOWS) return;
     jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
@@ -95,7 +98,7 @@ __global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* 24 x 33 words scratch
     table_build<PLUME_GTAB8_ENTRIES>(comb, bases, flags, PLUME_COMB_WINDOWS, i, 1);
 }
 
-__global__ __launch_bounds__(kBlock) void k_sign_h2c(SignArgs a) {
+__global__ PLUME_BOUNDS void k_sign_h2c(SignArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) sign_h2c(a, i);
 }
@@ -108,23 +111,23 @@ __global__ PLUME_MSM_BOUNDS void k_sign_hmul(SignArgs a) {
     if (i < a.n) sign_hmul(a, i, which, s_dig + threadIdx.x, kBlock);
 }
 
-__global__ __launch_bounds__(kBlock) void k_sign_final(SignArgs a) {
+__global__ PLUME_BOUNDS void k_sign_final(SignArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) sign_final(a, i);
 }
 
 // batched Jacobian -> affine (8 points per lane, one inversion): V2 verify results, signer outputs
-__global__ __launch_bounds__(kBlock) void k_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, size_t nlanes) {
+__global__ PLUME_BOUNDS void k_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, size_t nlanes) {
     size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (lane < nlanes) normalize_points(pts, inf, npts, lane, nlanes);
 }
 
-__global__ __launch_bounds__(kBlock) void k_decompress(DecompressArgs a) {
+__global__ PLUME_BOUNDS void k_decompress(DecompressArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) decompress_item(a, i);
 }
 
-__global__ __launch_bounds__(kBlock) void k_h2c_only(H2cArgs a) {
+__global__ PLUME_BOUNDS void k_h2c_only(H2cArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) h2c_only(a, i);
 }
@@ -183,17 +186,17 @@ __global__ __launch_bounds__(kBlock) void k_microbench(int kind, int iters, uint
     } else if (kind == 5) {  // one Fp multiplication (the unit of the roofline accounting), 2 independent chains
         fe x, y, z, w;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { x.v[j] = a + j; y.v[j] = b * (j + 1); z.v[j] = b + j; w.v[j] = a * (j + 3); }
+        for (int j = 0; j < 9; j++) { x.v[j] = (a + j) & 0xFFFFFFu; y.v[j] = (b * (j + 1)) & 0xFFFFFFu; z.v[j] = (b + j) & 0xFFFFFFu; w.v[j] = (a * (j + 3)) & 0xFFFFFFu; }
         for (int it = 0; it < iters; it++) { fe_mul(x, x, y); fe_mul(z, z, w); }
 #pragma unroll
-        for (int j = 0; j < 8; j++) out ^= x.v[j] ^ z.v[j];
+        for (int j = 0; j < 9; j++) out ^= x.v[j] ^ z.v[j];
     } else {                 // 6: one Fp squaring
         fe x, z;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { x.v[j] = a + j; z.v[j] = b + j; }
+        for (int j = 0; j < 9; j++) { x.v[j] = (a + j) & 0xFFFFFFu; z.v[j] = (b + j) & 0xFFFFFFu; }
         for (int it = 0; it < iters; it++) { fe_sqr(x, x); fe_sqr(z, z); }
 #pragma unroll
-        for (int j = 0; j < 8; j++) out ^= x.v[j] ^ z.v[j];
+        for (int j = 0; j < 9; j++) out ^= x.v[j] ^ z.v[j];
     }
     const uint64_t t_end = __builtin_readcyclecounter();
     if (tid == 0) { sink[64] = (uint32_t)(t_end - t_begin); sink[65] = (uint32_t)((t_end - t_begin) >> 32); }

@@ -22,13 +22,17 @@ namespace plume {
 
 // ------------------------------------------------------------------------------------------- point ingest
 // 64-byte affine x||y big-endian, all-zero = identity (include/plume_hip.h).  flag: 0 ok, 1 identity, 2 invalid
+// x, y come out CANONICAL (their limbs are exactly the 256-bit integers read, which are checked to be < p)
 PLUME_HD uint32_t load_affine_be(fe& x, fe& y, const uint8_t* p) {
-    fe_from_be_aligned(x, p);
-    fe_from_be_aligned(y, p + 32);
+    uint32_t wx[8], wy[8];
+    words_from_be_aligned(wx, p);
+    words_from_be_aligned(wy, p + 32);
+    fe_from_words(x, wx);
+    fe_from_words(y, wy);
     uint32_t nz = 0;
-    PLUME_UNROLL for (int i = 0; i < 8; i++) nz |= x.v[i] | y.v[i];
+    PLUME_UNROLL for (int i = 0; i < 8; i++) nz |= wx[i] | wy[i];
     if (nz == 0) return PLUME_JOB_INF;
-    if (!fe_is_canonical(x) || !fe_is_canonical(y)) return PLUME_JOB_INVALID;
+    if (!words_lt_p(wx) || !words_lt_p(wy)) return PLUME_JOB_INVALID;
     return affine_on_curve(x, y) ? PLUME_JOB_OK : PLUME_JOB_INVALID;
 }
 PLUME_HD void store_affine_be(uint8_t* p, fe x, fe y, bool inf) {
@@ -47,13 +51,13 @@ PLUME_HD bool load_scalar_be(sc& k, const uint8_t* p) {
 // One SEC1-compressed operand of the c-hash: canonical x, parity of y, or the identity (encoded as the single byte 00;
 // rust-k256/src/utils.rs:23-25, rust-arkworks/src/lib.rs:112-118)
 struct enc_pt {
-    fe x;
-    uint32_t tag;  // 2 | 3, or 0 for the identity
+    uint32_t xw[8];  // canonical x as little-endian 32-bit words
+    uint32_t tag;    // 2 | 3, or 0 for the identity
 };
 PLUME_HD enc_pt enc_of(fe x, const fe& y, bool inf) {
     enc_pt e;
     fe_normalize(x);
-    e.x = x;
+    fe_to_words(e.xw, x);
     e.tag = inf ? 0u : (2u + (fe_is_odd(y) ? 1u : 0u));
     return e;
 }
@@ -72,7 +76,7 @@ PLUME_HD void c_hash(uint32_t out[8], const enc_pt* pts) {
             // record i occupies bytes [33i, 33i+33): tag then x big-endian; static shifts after unrolling
             PLUME_UNROLL for (int k = 0; k < 33; k++) {
                 const int pos = 33 * i + k;
-                uint32_t byte = k == 0 ? pts[i].tag : ((pts[i].x.v[7 - ((k - 1) >> 2)] >> (8 * (3 - ((k - 1) & 3)))) & 0xFF);
+                uint32_t byte = k == 0 ? pts[i].tag : ((pts[i].xw[7 - ((k - 1) >> 2)] >> (8 * (3 - ((k - 1) & 3)))) & 0xFF);
                 w[pos >> 2] |= byte << (8 * (3 - (pos & 3)));
             }
         }
@@ -86,7 +90,7 @@ PLUME_HD void c_hash(uint32_t out[8], const enc_pt* pts) {
             uint32_t v = 0, base = 0;
             PLUME_UNROLL for (int i = 0; i < NPTS; i++) {
                 uint32_t l = pts[i].tag ? 33u : 1u;
-                if (pos >= base && pos < base + l) v = (pos == base) ? pts[i].tag : be_byte_of_limbs(pts[i].x.v, pos - base - 1);
+                if (pos >= base && pos < base + l) v = (pos == base) ? pts[i].tag : be_byte_of_limbs(pts[i].xw, pos - base - 1);
                 base += l;
             }
             return v;
@@ -104,11 +108,11 @@ struct VerifyArgs {
     uint8_t* ok;
     const uint8_t* preflags;  // optional, n bytes: non-zero = reject (set by the SEC1 decompression stage)
     // scratch (device memory)
-    uint32_t* bases;      // 24 x (3n) words, Jacobian SoA, job j = word-row w at bases[w*3n + j]
+    uint32_t* bases;      // PLUME_JAC_WORDS x (3n) words, Jacobian SoA, job j = word-row w at bases[w*3n + j]
     uint8_t* jobflags;    // 3n
     uint8_t* itemflags;   // n : 1 = rejected at ingest (bad scalar / invalid point)
     uint32_t* tab;        // 3n tables of PLUME_TAB_WORDS
-    uint32_t* res;        // 24 x (2n) words, Jacobian SoA of R' (task 2i) and Hr' (task 2i+1)
+    uint32_t* res;        // PLUME_JAC_WORDS x (2n) words, Jacobian SoA of R' (task 2i) and Hr' (task 2i+1)
     uint8_t* resinf;      // 2n
     const uint32_t* gtab; // wide table of G (PLUME_GTAB8_WORDS): (1..128)*G
 };
@@ -193,11 +197,11 @@ PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
             uint32_t fh = load_affine_be(hx, hy, a.hr + 64 * (size_t)i);
             if (fr != PLUME_JOB_INVALID && fh != PLUME_JOB_INVALID &&
                 jac_eq_affine(rc, rx, ry, fr == PLUME_JOB_INF) && jac_eq_affine(hc, hx, hy, fh == PLUME_JOB_INF)) {   // lib.rs:117,122
-                // affine H = entry 0 of H's table (canonical); identity H has no table
+                // affine H = entry 0 of H's table; identity H has no table
                 const size_t jh = 3 * (size_t)i + 1;
                 bool hinf = job_state(a.jobflags[jh]) == PLUME_JOB_INF;
                 fe Hx, Hy;
-                ld_fe(Hx, a.tab + jh * PLUME_TAB_WORDS); ld_fe(Hy, a.tab + jh * PLUME_TAB_WORDS + 8);
+                ld_fe(Hx, a.tab + jh * PLUME_TAB_WORDS); ld_fe(Hy, a.tab + jh * PLUME_TAB_WORDS + PLUME_FE_W);
                 enc_pt pts[6];
                 pts[0] = enc_of(fe_gx(), fe_gy(), false);
                 pts[1] = enc_of(pkx, pky, fpk == PLUME_JOB_INF);
@@ -245,7 +249,7 @@ struct SignArgs {
     uint32_t* gres;  uint8_t* gresinf;   // 2n tasks: sk*G, r*G (Jacobian SoA)
     uint32_t* bases; uint8_t* jobflags;  // n jobs: H
     uint8_t* itemflags;                  // n: status bits accumulated across stages
-    uint32_t* pkaff;                     // 16 x n words SoA: affine pk (x, y) for the final stage
+    uint32_t* pkaff;                     // 2 * PLUME_FE_WORDS x n words SoA: affine pk (x, y), canonical, for the final stage
     uint32_t* tab;                       // n tables
     uint32_t* hres;  uint8_t* hresinf;   // 2n tasks: sk*H, r*H
     const uint32_t* gtab;
@@ -304,7 +308,7 @@ PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
         fe_normalize(px); fe_normalize(py);
     }
     if (pinf) { px = fe_zero(); py = fe_zero(); }
-    st_fe_soa(a.pkaff, a.n, i, px); st_fe_soa(a.pkaff + 8 * (size_t)a.n, a.n, i, py);
+    st_fe_soa(a.pkaff, a.n, i, px); st_fe_soa(a.pkaff + PLUME_FE_W * (size_t)a.n, a.n, i, py);
     jac h;
     const uint64_t o0 = a.msg_off[i], o1 = a.msg_off[i + 1];
     hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), px, 2u + (fe_is_odd(py) ? 1u : 0u), pinf ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
@@ -327,9 +331,9 @@ PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
     ld_jac_soa(hr, a.hres, nt, 2 * (size_t)i + 1); hr.inf = a.hresinf[2 * (size_t)i + 1];
     // R, nullifier, Hr are affine already (normalize_points ran on gres and hres)
     fe px, py, Hx, Hy;
-    ld_fe_soa(px, a.pkaff, a.n, i); ld_fe_soa(py, a.pkaff + 8 * (size_t)a.n, a.n, i);
+    ld_fe_soa(px, a.pkaff, a.n, i); ld_fe_soa(py, a.pkaff + PLUME_FE_W * (size_t)a.n, a.n, i);
     bool hinf = job_state(a.jobflags[i]) == PLUME_JOB_INF;
-    ld_fe(Hx, a.tab + (size_t)i * PLUME_TAB_WORDS); ld_fe(Hy, a.tab + (size_t)i * PLUME_TAB_WORDS + 8);
+    ld_fe(Hx, a.tab + (size_t)i * PLUME_TAB_WORDS); ld_fe(Hy, a.tab + (size_t)i * PLUME_TAB_WORDS + PLUME_FE_W);
     uint32_t dg[8];
     enc_pt e_nul = enc_of(nul.x, nul.y, nul.inf != 0), e_r = enc_of(R.x, R.y, R.inf != 0), e_hr = enc_of(hr.x, hr.y, hr.inf != 0);
     if (a.version == 1) {
@@ -372,8 +376,10 @@ struct DecompressArgs {
 PLUME_HD bool decompress_point(uint8_t* out64, const uint8_t* in33) {
     const uint32_t tag = in33[0];
     fe x, y, rhs, t;
-    fe_from_be(x, in33 + 1);
-    bool ok = (tag == 2u || tag == 3u) && fe_is_canonical(x);
+    uint32_t wx[8];
+    words_from_be(wx, in33 + 1);
+    fe_from_words(x, wx);
+    bool ok = (tag == 2u || tag == 3u) && words_lt_p(wx);
     fe_sqr(rhs, x); fe_mul(rhs, rhs, x);
     fe seven = fe_small(7);
     fe_add(rhs, rhs, seven);
