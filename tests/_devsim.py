@@ -133,3 +133,9 @@ def eq1(s: bytes, c: bytes, pk: bytes):
     out = (C.c_uint8 * 64)()
     ok = lib().ds_eq1((C.c_uint8 * 32).from_buffer_copy(s), (C.c_uint8 * 32).from_buffer_copy(c), (C.c_uint8 * 64).from_buffer_copy(pk), out)
     return bytes(out) if ok else None
+
+
+def fallback_count():
+    """multi-scalar chains redone with checked additions so far (p == +-q met inside an unchecked chain)"""
+    lib().ds_fallback_count.restype = C.c_ulong
+    return int(lib().ds_fallback_count())

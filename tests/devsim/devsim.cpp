@@ -15,6 +15,9 @@ static void fe_from_le_words(fe& r, const uint32_t* w) { fe_from_words(r, w); } 
 
 extern "C" {
 
+// how many multi-scalar chains were redone with checked additions since the library was loaded (p == +-q inside a chain)
+unsigned long ds_fallback_count(void) { return fallback_counter(); }
+
 // op: 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 inv, 6 pow_c1, 7 normalize, 8 mul_small(b[0]), 9 is_zero->out[0], 10 eq->out[0], 11 is_odd->out[0],
 //     12 (a+b)*(a+2p-b) on unreduced operands, 13 (a+4p-2b)^2 through fe_carry, 14 words round trip
 // operands/outputs: 256-bit integers as 8 little-endian 32-bit words (outputs canonical); count elements

@@ -11,6 +11,7 @@ import pytest
 from oracle import plume_oracle as O
 from tests import _devsim as D
 from tests import _oracle_c as OC
+from tests import synth
 
 GOLD = json.loads((Path(__file__).parent / "golden" / "golden_batches.json").read_text())
 P, N = O.P, O.N
@@ -256,3 +257,36 @@ def test_fuzzed_verify_batch_vs_oracle(ver):
     want = OC.verify_batch(*args, nthreads=8)
     assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
     assert 0.2 * n < int(got.sum()) < 0.8 * n
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_small_secret_keys_hit_the_exceptional_additions(ver):
+    """pk = +-G, +-2G, ... makes s*G - c*pk (and s*H - c*nullifier) run into p == +-q inside the multi-scalar chain.  The hot loop
+    uses unchecked additions and redoes such a lane with the checked form (plume_ec.h jac_madd): results must still equal the
+    oracle's, and the fallback must actually have been taken."""
+    n = 96
+    b = synth.sign_inputs(n, start=31000)
+    small = [1, 2, 3, 4, 7, 8, 9, 16, 17, 128, 129, 255, 256, 257, O.N - 1, O.N - 2, O.N - 8, O.N - 16, O.N - 128, O.N - 256]
+    for i in range(n):
+        b["sk"][i] = np.frombuffer(small[i % len(small)].to_bytes(32, "big"), dtype=np.uint8)
+    want = OC.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"], nthreads=8)
+    before = D.fallback_count()
+    got = D.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r", "status"):
+        assert np.array_equal(np.asarray(got[k]).reshape(n, -1), np.asarray(want[k]).reshape(n, -1)), k
+    v = synth.corrupt_for_verify(ver, b, want, start=31000)
+    ok = D.verify_batch(ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
+    want_ok = OC.verify_batch(ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"), nthreads=8)
+    assert np.array_equal(ok, want_ok)
+
+
+def test_crafted_collisions_take_the_checked_fallback():
+    """R' = s*G - c*pk with pk = G and s = +-c = d <= 8: the first window loads d*G and the pk slot then adds -+d*G, i.e. p == -q
+    (result: identity) or p == q (result: 2d*G) in the very first addition.  Both must come out right, through the fallback."""
+    N = O.N
+    g = O.pt_bytes(O.G)
+    before = D.fallback_count()
+    for d in range(1, 9):
+        assert D.eq1(d.to_bytes(32, "big"), d.to_bytes(32, "big"), g) == bytes(64), d                         # d*G - d*G
+        assert D.eq1(d.to_bytes(32, "big"), (N - d).to_bytes(32, "big"), g) == O.pt_bytes(O.pt_mul(2 * d, O.G)), d   # d*G + d*G
+    assert D.fallback_count() - before >= 12, "the crafted collisions did not go through the checked fallback"

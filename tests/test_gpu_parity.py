@@ -8,6 +8,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+from oracle import plume_oracle as O
 from tests import _oracle_c as OC
 from tests import synth
 
@@ -365,3 +366,22 @@ def test_host_pieces_do_not_change_results(eng, ver):
             assert np.array_equal(np.asarray(h).reshape(cnt, 64), want_h[:cnt]), piece
     finally:
         eng.set_host_piece(1 << 18)
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_small_secret_keys_exceptional_additions(eng, ver):
+    """pk = +-G, +-2G, ... : s*G - c*pk and s*H - c*nullifier meet p == +-q inside the multi-scalar chain every few dozen items.
+    The hot loop's additions are unchecked; such a lane is detected at the end (Z = 0 mod p) and redone with checked additions
+    (plume_ec.h jac_madd / msm_run).  8192 such items: signatures and verdicts byte-identical to the C oracle."""
+    n = 8192
+    b = synth.sign_inputs(n, start=31000)
+    small = [1, 2, 3, 4, 7, 8, 9, 16, 17, 128, 129, 255, 256, 257, O.N - 1, O.N - 2, O.N - 8, O.N - 16, O.N - 128, O.N - 256]
+    sk = np.stack([np.frombuffer(small[i % len(small)].to_bytes(32, "big"), dtype=np.uint8) for i in range(n)])
+    want = OC.sign_batch(ver, b["msgs"], b["off"], sk, b["r"], nthreads=16)
+    got = eng.sign_batch(ver, b["msgs"], b["off"], sk, b["r"])
+    for k in got:
+        assert np.array_equal(np.asarray(got[k]).reshape(n, -1), np.asarray(want[k]).reshape(n, -1)), k
+    v = synth.corrupt_for_verify(ver, b, want, start=31000)
+    ok = eng.verify_batch(ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
+    want_ok = OC.verify_batch(ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"), nthreads=16)
+    assert np.array_equal(ok, want_ok)

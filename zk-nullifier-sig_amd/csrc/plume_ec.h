@@ -12,6 +12,14 @@
 #pragma once
 #include "plume_field.h"
 
+// host test builds count how often a multi-scalar chain had to be redone with checked additions (tests/devsim)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(PLUME_FE_CHECK)
+namespace plume { inline unsigned long& fallback_counter() { static unsigned long c = 0; return c; } }
+#define PLUME_COUNT_FALLBACK() (++plume::fallback_counter())
+#else
+#define PLUME_COUNT_FALLBACK() ((void)0)
+#endif
+
 namespace plume {
 
 struct jac {
@@ -33,18 +41,30 @@ PLUME_HD bool affine_on_curve(const fe& x, const fe& y) {
     return fe_eq(l, r);
 }
 
-// 2P, a = 0:  S = 4XY^2, M = 3X^2, X' = M^2 - 2S, Y' = M(S - X') - 8Y^4, Z' = 2YZ   (3M + 4S)
+// Limb-bound contract of a Jacobian point held in registers or HBM scratch (plume_field.h "tight"):
+//   X, Y tight;  Z limbs <= 2^30 + 2^20 (a tight value or the unreduced double of one).
+// The group-law formulas below keep additions and subtractions unreduced wherever the next multiplication tolerates it
+// (fe_add_lazy / fe_sub_lazy<M>) and spend a carry pass only where a bound would otherwise be exceeded; host builds with
+// PLUME_FE_CHECK assert every bound.
+//
+// 2P, a = 0:  A = X^2, B = Y^2, X' = (3A)^2 - 8XB, Y' = 3A(4XB - X') - 8B^2, Z' = 2YZ   (3M + 4S, 3 carry passes)
 // valid for every non-infinity point (the curve has no 2-torsion); the inf flag just rides along.
 PLUME_HD void jac_dbl(jac& p) {
-    fe y2, s, m, t, x3, y4;
-    fe_sqr(y2, p.y);
-    fe_mul(s, p.x, y2); fe_dbl(s, s); fe_dbl(s, s);
-    fe_sqr(m, p.x); fe_dbl(t, m); fe_add(m, t, m);
-    fe_mul(p.z, p.y, p.z); fe_dbl(p.z, p.z);
-    fe_sqr(x3, m); fe_sub(x3, x3, s); fe_sub(x3, x3, s);
-    fe_sqr(y4, y2); fe_dbl(y4, y4); fe_dbl(y4, y4); fe_dbl(y4, y4);
-    fe_sub(t, s, x3); fe_mul(t, m, t); fe_sub(p.y, t, y4);
-    p.x = x3;
+    fe A, B2, C4, XB2, E, F, D2, D4, t;
+    fe_sqr(A, p.x);
+    fe_sqr(B2, p.y); fe_add_lazy(B2, B2, B2);              // 2Y^2
+    fe_sqr(C4, B2);                                        // 4Y^4
+    fe_mul(XB2, p.x, B2);                                  // 2XY^2
+    fe_mul(p.z, p.y, p.z); fe_add_lazy(p.z, p.z, p.z);     // Z' = 2YZ (unreduced double)
+    fe_add_lazy(E, A, A); fe_add_lazy(E, E, A); fe_carry(E);   // 3X^2
+    fe_sqr(F, E);
+    fe_add_lazy(D2, XB2, XB2);                             // 4XY^2
+    fe_add_lazy(D4, D2, D2);                               // 8XY^2
+    fe_sub_lazy<5>(p.x, F, D4); fe_carry(p.x);             // X' = 9X^4 - 8XY^2
+    fe_sub_lazy<2>(t, D2, p.x);                            // 4XY^2 - X'
+    fe_mul(t, E, t);
+    fe_add_lazy(C4, C4, C4);                               // 8Y^4
+    fe_sub_lazy<3>(p.y, t, C4); fe_carry(p.y);
 }
 // cold path of the additions (P == Q).  Takes and returns BY VALUE through a local copy at the call site: passing the
 // accumulator by reference would make its address escape and pin it in scratch memory for the whole hot loop
@@ -52,29 +72,42 @@ PLUME_HD void jac_dbl(jac& p) {
 PLUME_HD_NOINLINE void jac_dbl_cold_impl(jac* p) { jac_dbl(*p); }
 PLUME_HD void jac_dbl_cold(jac& p) { jac tmp = p; jac_dbl_cold_impl(&tmp); p = tmp; }
 
-// p += (qx, qy) affine, q != infinity.  8M + 3S; all exceptional cases handled (p infinite, p == q, p == -q).
+// p += (qx, qy) affine, q != infinity; qx tight, qy tight or an unreduced negation (limbs <= 2p).  8M + 3S, 4 carry passes.
+// CHECKED = true handles every exceptional case (p infinite, p == q, p == -q).
+// CHECKED = false is the hot-loop form: it handles p infinite but does NOT test for p == +-q.  In that case H = 0 (mod p)
+// and Z' = Z*H = 0 (mod p), and every later doubling / addition keeps Z = 0 (mod p) (Z only ever gets multiplied), so
+// the caller detects the event ONCE at the end (fe_is_zero(Z)) and recomputes that lane with CHECKED = true.  No other
+// path reaches Z = 0: a legitimate identity is carried in the inf flag, and the curve has no point with Y = 0.
+template <bool CHECKED = true>
 PLUME_HD void jac_madd(jac& p, const fe& qx, const fe& qy) {
     if (p.inf) {
-        p.x = qx; p.y = qy; p.z = fe_small(1); p.inf = 0;
+        p.x = qx; p.y = qy; fe_carry(p.y); p.z = fe_small(1); p.inf = 0;
         return;
     }
     fe z1z1, u2, s2, h, r, hh, hhh, v, t;
     fe_sqr(z1z1, p.z);
     fe_mul(u2, qx, z1z1);
     fe_mul(s2, p.z, z1z1); fe_mul(s2, s2, qy);
-    fe_sub(h, u2, p.x);
-    fe_sub(r, s2, p.y);
-    if (fe_is_zero(h)) {
-        if (fe_is_zero(r)) { jac_dbl_cold(p); } else { p.inf = 1; }
-        return;
+    fe_sub_lazy<2>(h, u2, p.x); fe_carry(h);
+    fe_sub_lazy<2>(r, s2, p.y); fe_carry(r);
+    if (CHECKED) {
+        if (fe_is_zero(h)) {
+            if (fe_is_zero(r)) { jac_dbl_cold(p); } else { p.inf = 1; }
+            return;
+        }
     }
     fe_sqr(hh, h); fe_mul(hhh, hh, h); fe_mul(v, p.x, hh);
     fe_mul(p.z, p.z, h);
-    fe_sqr(t, r); fe_sub(t, t, hhh); fe_sub(t, t, v); fe_sub(p.x, t, v);
-    fe_sub(t, v, p.x); fe_mul(t, r, t);
+    fe_sqr(t, r);
+    fe_add_lazy(hh, v, v); fe_add_lazy(hh, hh, hhh);       // 2V + H^3
+    fe_sub_lazy<4>(p.x, t, hh); fe_carry(p.x);             // X' = r^2 - H^3 - 2V
+    fe_sub_lazy<2>(t, v, p.x);                             // V - X'
+    fe_mul(t, r, t);
     fe_mul(hhh, p.y, hhh);
-    fe_sub(p.y, t, hhh);
+    fe_sub_lazy<2>(p.y, t, hhh); fe_carry(p.y);
 }
+// unreduced negation of a tight value (limbs <= 2p): a legal qy for jac_madd
+PLUME_HD void fe_neg_lazy(fe& r, const fe& a) { fe z = fe_zero(); fe_sub_lazy<2>(r, z, a); }
 
 // p += q, both Jacobian.  12M + 4S; all exceptional cases handled.
 PLUME_HD void jac_add(jac& p, const jac& q) {
@@ -348,7 +381,8 @@ PLUME_HD int booth_digit8_256(const uint32_t m[8], int k) {   // k is a runtime 
     }
     return (int)(u & 1) + (int)((u >> 1) & 127) - (int)((u >> 8) << 7);
 }
-PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
+template <bool CHECKED>
+PLUME_HD void comb_mul_g_impl(jac& acc, const sc& k, const uint32_t* comb) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
     PLUME_NOUNROLL for (int i = 0; i < PLUME_COMB_WINDOWS; i++) {
         const int d = booth_digit8_256(k.v, i);
@@ -358,9 +392,17 @@ PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
             fe qx, qy;
             ld_fe(qx, e);
             ld_fe(qy, e + PLUME_FE_W);
-            if (d < 0) fe_neg(qy, qy);
-            jac_madd(acc, qx, qy);
+            if (d < 0) fe_neg_lazy(qy, qy);
+            jac_madd<CHECKED>(acc, qx, qy);
         }
+    }
+}
+// unchecked additions first; a lane that met p == +-q (Z = 0 mod p, see jac_madd) is recomputed with the checked form
+PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
+    comb_mul_g_impl<false>(acc, k, comb);
+    if (!acc.inf && fe_is_zero(acc.z)) {
+        PLUME_COUNT_FALLBACK();
+        comb_mul_g_impl<true>(acc, k, comb);
     }
 }
 
@@ -369,7 +411,8 @@ PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
 // halves (beta*x).  dig: digits of slot s, window i at dig[(s*PLUME_NDIG + i)*stride].  A NULL table (or a
 // job flagged INF) contributes nothing.
 // wide0: slots 0,1 use the generator's 128-entry table with w = 8 digits (stored by booth_store_wide).
-PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
+template <bool CHECKED>
+PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
     PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
         if (i != PLUME_NDIG - 1) {
@@ -392,10 +435,18 @@ PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int 
                 fe qx, qy;
                 ld_fe(qx, (s & 1) ? e + 2 * PLUME_FE_W : e);
                 ld_fe(qy, e + PLUME_FE_W);
-                if (d < 0) fe_neg(qy, qy);
-                jac_madd(acc, qx, qy);
+                if (d < 0) fe_neg_lazy(qy, qy);
+                jac_madd<CHECKED>(acc, qx, qy);
             }
         }
+    }
+}
+PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
+    msm_run_impl<false>(acc, tab0, tab1, nslots, dig, stride, wide0);
+    // an accumulator that met p == +-q inside an unchecked addition has Z = 0 (mod p) forever after (see jac_madd): redo that lane
+    if (!acc.inf && fe_is_zero(acc.z)) {
+        PLUME_COUNT_FALLBACK();
+        msm_run_impl<true>(acc, tab0, tab1, nslots, dig, stride, wide0);
     }
 }
 
