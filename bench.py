@@ -212,7 +212,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]/metric: batch 2^{a.log2_batch} PLUME V{ver} verify (secp256k1 + SHA-256) per GPU, 32-byte messages, 1/16 corrupted, "
-                                   f"inputs resident in HBM; arithmetic in 8x32-bit limbs through v_mad_u64_u32",
+                                   f"inputs resident in HBM; Fp arithmetic on 9x29-bit limbs through chains of v_mad_u64_u32 (32x32+64)",
                        "items_per_gpu": n, "global_items_per_step": n * world, "parallelism": f"shard x{world}, no collective"},
             "stage_ms": stages,
         }
@@ -239,7 +239,7 @@ def main():
                                          "fp_mul_per_s": round(fpmul_rate, 1), "fp_sqr_per_s": round(fpsqr_rate, 1), "other_issue_rates_per_s": other,
                                          "achieved_whole_path": round(whole, 1), "frac_whole_path": round(whole / mad_rate, 4),
                                          "achieved_msm_kernel": round(msm, 1), "frac_msm_kernel": round(msm / mad_rate, 4),
-                                         "accounting": "5460 Fp-mult/verify x 72 MACs (SURVEY.md §8d, frozen in BASELINE.md §4)"}
+                                         "accounting": "5460 Fp-mult/verify x 72 MACs (SURVEY.md §8d, frozen in BASELINE.md §4); the 9x29-limb code issues 103 multiply-adds per Fp-mult, the accounting stays on the frozen 72"}
             except Exception as e:  # measurement extras must not kill the bench line
                 line["valu_roofline"] = {"error": str(e)}
         if world == 1 and not a.no_extras:

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collect the round's measurements on the GPU box (run through gpurun from the repo root):
+#     gpurun -- 'bash profiles/collect.sh r01'
+# then, back in the container:  cp gpurun_out/prof_r01/r01_kernel_{stats,trace}.csv profiles/ ; tail -1 gpurun_out/bench_r01.log > profiles/r01_bench_line.json ;
+#                               python profiles/summarize_pmc.py r01
+# Counters go in their own passes, each with --kernel-trace only (never with sys/hip/hsa traces).
+R=${1:-r01}
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python3 bench.py > gpurun_out/bench_$R.log 2> gpurun_out/bench_$R.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/bench_${R}_prof.log 2>&1
+for spec in "sq:SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+            "sq2:SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY" \
+            "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+  tg=${spec%%:*}; cn=${spec#*:}
+  rocprofv3 --pmc $cn --kernel-trace --output-format csv -d gpurun_out/pmc_$tg -o $tg -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/pmc_$tg.log 2>&1
+done
+tail -1 gpurun_out/bench_$R.log | cut -c1-400
+head -8 gpurun_out/prof_$R/${R}_kernel_stats.csv | cut -c1-130

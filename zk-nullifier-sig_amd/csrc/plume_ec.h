@@ -259,7 +259,7 @@ PLUME_HD void st_jac_soa(uint32_t* base, size_t stride, size_t j, const jac& p) 
 }
 
 #ifndef PLUME_TABLE_MADD
-#define PLUME_TABLE_MADD 0   // 1: mixed additions for Z = 1 bases in table_build (more code in the loop body)
+#define PLUME_TABLE_MADD 1   // mixed additions for Z = 1 bases (pk, nullifier) in table_build: 8M+3S instead of 12M+4S per odd multiple
 #endif
 #define PLUME_JOB_OK 0u
 #define PLUME_JOB_INF 1u      // base is the identity: its slots are skipped

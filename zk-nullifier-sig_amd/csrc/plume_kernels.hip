@@ -19,8 +19,16 @@
 #ifndef PLUME_MSM_WAVES
 #define PLUME_MSM_WAVES PLUME_MIN_WAVES
 #endif
+#ifndef PLUME_TABLES_WAVES
+#define PLUME_TABLES_WAVES 3   // the table kernel streams ~3.6 KB per job through HBM; 3 waves with fewer spills measured 9 % faster than 4
+#endif
+#ifndef PLUME_H2C_WAVES
+#define PLUME_H2C_WAVES PLUME_MIN_WAVES
+#endif
 #define PLUME_BOUNDS __launch_bounds__(kBlock, PLUME_MIN_WAVES)
 #define PLUME_MSM_BOUNDS __launch_bounds__(kBlock, PLUME_MSM_WAVES)
+#define PLUME_TABLES_BOUNDS __launch_bounds__(kBlock, PLUME_TABLES_WAVES)
+#define PLUME_H2C_BOUNDS __launch_bounds__(kBlock, PLUME_H2C_WAVES)
 #ifndef PLUME_GTAB_IN_LDS
 #define PLUME_GTAB_IN_LDS 0
 #endif
@@ -41,12 +49,12 @@ __global__ void k_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* 
     if (blockIdx.x == 0 && threadIdx.x == 0) table_build<PLUME_GTAB8_ENTRIES>(gtab8, base_g, flag, 1, 0, 1);
 }
 
-__global__ PLUME_BOUNDS void k_verify_ingest(VerifyArgs a) {
+__global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) verify_ingest_h2c(a, i);
 }
 
-__global__ PLUME_BOUNDS void k_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
+__global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
     size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x;
     size_t j0 = lane * (size_t)L;
     if (j0 < njobs) {
@@ -98,7 +106,7 @@ __global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* PLUME_JAC_WORDS x 33 
     table_build<PLUME_GTAB8_ENTRIES>(comb, bases, flags, PLUME_COMB_WINDOWS, i, 1);
 }
 
-__global__ PLUME_BOUNDS void k_sign_h2c(SignArgs a) {
+__global__ PLUME_H2C_BOUNDS void k_sign_h2c(SignArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) sign_h2c(a, i);
 }
@@ -127,7 +135,7 @@ __global__ PLUME_BOUNDS void k_decompress(DecompressArgs a) {
     if (i < a.n) decompress_item(a, i);
 }
 
-__global__ PLUME_BOUNDS void k_h2c_only(H2cArgs a) {
+__global__ PLUME_H2C_BOUNDS void k_h2c_only(H2cArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) h2c_only(a, i);
 }
