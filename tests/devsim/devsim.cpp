@@ -86,19 +86,31 @@ static void build_gtab(std::vector<uint32_t>& gtab) {
     jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
     st_jac_soa(bases.data(), 1, 0, g);
     uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
-    table_build<PLUME_GTAB8_ENTRIES>(gtab.data(), bases.data(), &flag, 1, 0, 1);
+    std::vector<uint32_t> scr((size_t)PLUME_GTAB8_ENTRIES * PLUME_TAB_SCR_WORDS);
+    table_build<PLUME_GTAB8_ENTRIES>(gtab.data(), bases.data(), &flag, 1, 0, 1, scr.data(), 1, 0);
 }
 
 static void build_gcomb(std::vector<uint32_t>& comb) {
     comb.assign(PLUME_COMB_WORDS, 0);
     std::vector<uint32_t> bases(PLUME_JAC_WORDS * PLUME_COMB_WINDOWS, 0);
     std::vector<uint8_t> flags(PLUME_COMB_WINDOWS, 0);
+    std::vector<uint32_t> scr((size_t)PLUME_COMB_WINDOWS * PLUME_GTAB8_ENTRIES * PLUME_TAB_SCR_WORDS);
     for (uint32_t i = 0; i < PLUME_COMB_WINDOWS; i++) {      // mirrors k_gcomb
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
         for (uint32_t d = 0; d < 8 * i; d++) jac_dbl(g);
         st_jac_soa(bases.data(), PLUME_COMB_WINDOWS, i, g);
         flags[i] = PLUME_JOB_OK;
-        table_build<PLUME_GTAB8_ENTRIES>(comb.data(), bases.data(), flags.data(), PLUME_COMB_WINDOWS, i, 1);
+        table_build<PLUME_GTAB8_ENTRIES>(comb.data(), bases.data(), flags.data(), PLUME_COMB_WINDOWS, i, 1, scr.data(), PLUME_COMB_WINDOWS, i);
+    }
+}
+
+// host stand-in for launch_tables: the same lane -> jobs mapping and the same lane-interleaved scratch indexing as k_tables
+static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
+    const size_t lanes = (njobs + L - 1) / L, stride = ((lanes + 7) / 8) * 8;     // "grid" rounded up like the kernel's
+    std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_ENTRIES * PLUME_TAB_SCR_WORDS);
+    for (size_t lane = 0; lane < lanes; lane++) {
+        const size_t j0 = lane * (size_t)L, rem = njobs - j0;
+        table_build(tab, bases, jobflags, njobs, j0, (int)(rem < (size_t)L ? rem : (size_t)L), scr.data(), stride, lane);
     }
 }
 
@@ -135,7 +147,7 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     a.gtab = gtab.data();
     for (uint32_t i = 0; i < n; i++) verify_ingest_h2c(a, i);
     const size_t nj = 3 * (size_t)n;
-    for (size_t j0 = 0; j0 < nj; j0 += L) table_build(a.tab, a.bases, a.jobflags, nj, j0, (int)((nj - j0) < (size_t)L ? (nj - j0) : L));
+    run_tables(a.tab, a.bases, a.jobflags, nj, L);
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);
     for (uint32_t eq = 0; eq < 2; eq++)
         for (uint32_t i = 0; i < n; i++) verify_msm(a, i, eq, a.gtab, dig.data() + (i % B), B);
@@ -167,7 +179,7 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
         for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.gres, a.gresinf, npts, lane, nlanes);
     }
     for (uint32_t i = 0; i < n; i++) sign_h2c(a, i);
-    for (size_t j0 = 0; j0 < n; j0 += L) table_build(a.tab, a.bases, a.jobflags, n, j0, (int)((n - j0) < (size_t)L ? (n - j0) : L));
+    run_tables(a.tab, a.bases, a.jobflags, n, L);
     for (uint32_t w = 0; w < 2; w++)
         for (uint32_t i = 0; i < n; i++) sign_hmul(a, i, w, dig.data() + (i % B), B);
     {
@@ -193,7 +205,7 @@ int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[6
     a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data(); a.gtab = gtab.data();
     jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
     for (int j = 0; j < 3; j++) { st_jac_soa(a.bases, 3, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
-    table_build(a.tab, a.bases, a.jobflags, 3, 0, 3);
+    run_tables(a.tab, a.bases, a.jobflags, 3, 3);
     std::vector<int8_t> dig(4 * PLUME_NDIG);
     verify_msm(a, 0, 0, a.gtab, dig.data(), 1);
     jac r; ld_jac_soa(r, a.res, 2, 0); r.inf = a.resinf[0];
@@ -223,7 +235,7 @@ int ds_point_mul(const uint8_t k_be[32], const uint8_t p_be[64], uint8_t out[64]
     jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
     st_jac_soa(bases.data(), 1, 0, p);
     uint8_t flag = 0;
-    table_build(tab.data(), bases.data(), &flag, 1, 0, 1);
+    run_tables(tab.data(), bases.data(), &flag, 1, 1);
     sc k; sc_from_be_aligned(k, kb);
     while (!sc_lt_n(k)) sc_cond_sub_n(k);
     glv_half h1, h2; glv_split(h1, h2, k);

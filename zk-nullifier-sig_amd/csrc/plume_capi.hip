@@ -67,7 +67,7 @@ struct plume_ctx {
     HostSlot slot[2];
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
-    DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, res, resinf, res2, res2inf, pkaff, sink;
+    DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink;
     DevBuf dec[4], preflags;   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
     StageTimer timer;
 };
@@ -105,7 +105,8 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
         HIPCHK(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
     }
     // generator wide window table (1..128)*G: one lane, once
-    if (ctx->gtab.ensure(PLUME_GTAB8_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(PLUME_JAC_WORDS * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64)) { delete ctx; return PLUME_ERR_HIP; }
+    if (ctx->gtab.ensure(PLUME_GTAB8_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(PLUME_JAC_WORDS * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64) ||
+        ctx->tabscr.ensure((size_t)PLUME_COMB_WINDOWS * PLUME_GTAB8_ENTRIES * PLUME_TAB_SCR_WORDS * 4)) { delete ctx; return PLUME_ERR_HIP; }
     uint32_t hb[PLUME_JAC_WORDS];
     {
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
@@ -114,10 +115,10 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
     uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
     HIPCHK(hipMemcpyAsync(ctx->bases.p, hb, sizeof hb, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->jobflags.p, &flag, 1, hipMemcpyHostToDevice, ctx->stream));
-    launch_gtab8(ctx->gtab.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->stream);
+    launch_gtab8(ctx->gtab.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->tabscr.as<uint32_t>(), ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    launch_gcomb(ctx->gcomb.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->stream);   // fixed-base comb for the signer
+    launch_gcomb(ctx->gcomb.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->tabscr.as<uint32_t>(), ctx->stream);   // fixed-base comb for the signer
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = ctx;
@@ -130,7 +131,7 @@ extern "C" void plume_destroy(plume_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->up) (void)hipStreamSynchronize(ctx->up);
     if (ctx->down) (void)hipStreamSynchronize(ctx->down);
-    for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
+    for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
                       &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags})
         b->release();
     for (HostSlot& sl : ctx->slot) {
@@ -174,7 +175,9 @@ static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* m
                          const uint8_t* preflags = nullptr, bool continue_timer = false) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    const int jpl = pick_jobs_per_lane(ctx, 3 * n, true);
     if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
+        ctx->tabscr.ensure(tables_scratch_bytes(3 * n, jpl)) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n))
         return PLUME_ERR_HIP;
     VerifyArgs a;
@@ -184,7 +187,7 @@ static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* m
     StageTimer& t = ctx->timer;
     if (!continue_timer) t.begin(st);
     launch_verify_ingest(a, st); t.stage("verify_ingest_h2c", st);
-    launch_tables(a.tab, a.bases, a.jobflags, 3 * n, pick_jobs_per_lane(ctx, 3 * n, true), st); t.stage("tables", st);
+    launch_tables(a.tab, a.bases, a.jobflags, 3 * n, jpl, ctx->tabscr.as<uint32_t>(), st); t.stage("tables", st);
     launch_verify_msm(a, st); t.stage("verify_msm", st);
     if (version == 2) { launch_normalize(a.res, a.resinf, 2 * n, st); t.stage("to_affine", st); }   // V2 hashes the computed R', Hr'
     launch_verify_finalize(a, st); t.stage("verify_finalize", st);
@@ -197,7 +200,9 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
                        hipStream_t st) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    const int jpl = pick_jobs_per_lane(ctx, n, false);
     if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * n) || ctx->jobflags.ensure(n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * n) ||
+        ctx->tabscr.ensure(tables_scratch_bytes(n, jpl)) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->res2.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->res2inf.ensure(2 * n) || ctx->pkaff.ensure((size_t)2 * PLUME_FE_WORDS * 4 * n))
         return PLUME_ERR_HIP;
     SignArgs a;
@@ -211,7 +216,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     launch_sign_gmul(a, st); t.stage("sign_gmul", st);
     launch_normalize(a.gres, a.gresinf, 2 * n, st); t.stage("to_affine_g", st);
     launch_sign_h2c(a, st); t.stage("sign_h2c", st);
-    launch_tables(a.tab, a.bases, a.jobflags, n, pick_jobs_per_lane(ctx, n, false), st); t.stage("tables", st);
+    launch_tables(a.tab, a.bases, a.jobflags, n, jpl, ctx->tabscr.as<uint32_t>(), st); t.stage("tables", st);
     launch_sign_hmul(a, st); t.stage("sign_hmul", st);
     launch_normalize(a.hres, a.hresinf, 2 * n, st); t.stage("to_affine_h", st);
     launch_sign_final(a, st); t.stage("sign_final", st);

@@ -237,14 +237,27 @@ PLUME_HD void booth_store(int8_t* dig, uint32_t stride, const glv_half& h, bool 
 }
 
 // ------------------------------------------------------------------------------------------ window tables
-// One table = 8 entries x 36 words (144 B): [x(9) | y(9) | beta*x(9) | scratch(9)], entry e holds (e+1)*P.
-// Words are the 29-bit limbs of tight field elements (plume_field.h).
+// One table = 8 entries x 28 words (112 B), entry e holds (e+1)*P affine as 29-bit limbs of tight field elements:
+//     [ x0..x7 | y0..y7 | b0..b7 | x8 y8 b8 0 ]        b = beta * x (the x of lambda*P)
+// i.e. seven 16-byte quads; one table addition gathers five of them (x or b, y, the top limbs) with aligned 16-byte loads.
 #define PLUME_TAB_ENTRIES 8
 #define PLUME_FE_W PLUME_FE_WORDS
 #define PLUME_JAC_WORDS (3 * PLUME_FE_WORDS)      // Jacobian point in HBM scratch: x | y | z
-#define PLUME_TAB_ENTRY_WORDS (4 * PLUME_FE_WORDS)
+#define PLUME_TAB_ENTRY_WORDS 28
+#define PLUME_TAB_SCR_WORDS (4 * PLUME_FE_WORDS)  // pass-1 scratch per entry: X | Y | Z | running product
 #define PLUME_TAB_WORDS (PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 
+// table entry access (layout above)
+PLUME_HD void ld_tab_xy(fe& x, fe& y, const uint32_t* e, bool lambda_half) {
+    const uint32_t* xs = lambda_half ? e + 16 : e;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) { x.v[i] = xs[i]; y.v[i] = e[8 + i]; }
+    x.v[8] = lambda_half ? e[26] : e[24];
+    y.v[8] = e[25];
+}
+PLUME_HD void st_tab_entry(uint32_t* e, const fe& x, const fe& y, const fe& bx) {
+    PLUME_UNROLL for (int i = 0; i < 8; i++) { e[i] = x.v[i]; e[8 + i] = y.v[i]; e[16 + i] = bx.v[i]; }
+    e[24] = x.v[8]; e[25] = y.v[8]; e[26] = bx.v[8]; e[27] = 0;
+}
 PLUME_HD void ld_fe(fe& r, const uint32_t* p) { PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = p[i]; }
 PLUME_HD void st_fe(uint32_t* p, const fe& a) { PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) p[i] = a.v[i]; }
 // strided (SoA) field element: word w of element j lives at base[w*stride + j]
@@ -271,10 +284,20 @@ PLUME_HD uint32_t job_state(uint8_t f) { return f & 3u; }
 #define PLUME_GTAB8_WORDS (PLUME_GTAB8_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 
 // Build the tables of jobs [j0, j0+cnt) (cnt <= L, one lane).  Bases are Jacobian SoA (stride = njobs).
-// Pass 1 writes (X_k, Y_k, Z_k, running product before Z_k) for k = 1..8 of every job; one inversion of the
-// total product; pass 2 walks back, peels off each 1/Z_k, and overwrites the entry with affine (x, y, beta*x).
+// Pass 1 writes (X_k, Y_k, Z_k, running product before Z_k) for k = 1..8 of every job to the lane's slice of `scr`; one
+// inversion of the total product; pass 2 walks back, peels off each 1/Z_k, and writes the affine entry (x, y, beta*x) to `tab`.
+// scr is lane-interleaved: word w of the lane's q-th scratch entry lives at scr[(q * PLUME_TAB_SCR_WORDS + w) * sstride + slane],
+// so the 64 lanes of a wavefront (which walk their entries in lock step) touch 64 consecutive words per instruction -- the
+// pass-1 traffic (288 B per entry, written once and read once or twice) is fully coalesced; only the final 112-byte rows,
+// which the multi-scalar kernel gathers per lane, are scattered.  A single-lane build passes sstride = 1, slane = 0.
+PLUME_HD void scr_st(uint32_t* scr, size_t sstride, size_t slane, size_t q, int f, const fe& a) {
+    PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) scr[((q * PLUME_TAB_SCR_WORDS + (size_t)(f * PLUME_FE_W + i)) * sstride) + slane] = a.v[i];
+}
+PLUME_HD void scr_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, size_t q, int f) {
+    PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = scr[((q * PLUME_TAB_SCR_WORDS + (size_t)(f * PLUME_FE_W + i)) * sstride) + slane];
+}
 template <int ENTRIES = PLUME_TAB_ENTRIES>
-PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt) {
+PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane) {
     fe acc = fe_small(1);
     PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
         size_t job = j0 + (size_t)jj;
@@ -285,15 +308,15 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
         (void)zone;
         if (job_state(jobflags[job]) != PLUME_JOB_OK) { b.x = fe_gx(); b.y = fe_gy(); b.z = fe_small(1); }
         jac cur = b;
-        uint32_t* e = tab + job * (size_t)(ENTRIES * PLUME_TAB_ENTRY_WORDS);
         PLUME_NOUNROLL for (int k = 0; k < ENTRIES; k++) {
             // entry k holds (k+1)P.  Even multiples are doublings of an earlier entry (3M+4S instead of a 12M+4S addition):
-            // 2P = 2*P, 3P = 2P+P, 4P = 2*(2P), 5P = 4P+P, 6P = 2*(3P), ...  The half entry is re-read from the table this lane
-            // has just written (X, Y, Z are still the Jacobian coordinates in pass 1).
+            // 2P = 2*P, 3P = 2P+P, 4P = 2*(2P), 5P = 4P+P, 6P = 2*(3P), ...  The half entry is re-read from the scratch this lane
+            // has just written (Jacobian coordinates).
+            const size_t q = (size_t)jj * ENTRIES + (size_t)k;
             if (k >= 1 && (k & 1)) {
                 if (k > 1) {
-                    const uint32_t* hsrc = tab + job * (size_t)(ENTRIES * PLUME_TAB_ENTRY_WORDS) + (size_t)((k + 1) / 2 - 1) * PLUME_TAB_ENTRY_WORDS;
-                    ld_fe(cur.x, hsrc + 0); ld_fe(cur.y, hsrc + PLUME_FE_W); ld_fe(cur.z, hsrc + 2 * PLUME_FE_W);
+                    const size_t qh = (size_t)jj * ENTRIES + (size_t)((k + 1) / 2 - 1);
+                    scr_ld(cur.x, scr, sstride, slane, qh, 0); scr_ld(cur.y, scr, sstride, slane, qh, 1); scr_ld(cur.z, scr, sstride, slane, qh, 2);
                 }
                 jac_dbl(cur);
             }
@@ -302,27 +325,28 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
 #else
             else if (k > 1) jac_add(cur, b);
 #endif
-            st_fe(e + 0, cur.x); st_fe(e + PLUME_FE_W, cur.y); st_fe(e + 2 * PLUME_FE_W, cur.z); st_fe(e + 3 * PLUME_FE_W, acc);
+            scr_st(scr, sstride, slane, q, 0, cur.x); scr_st(scr, sstride, slane, q, 1, cur.y); scr_st(scr, sstride, slane, q, 2, cur.z); scr_st(scr, sstride, slane, q, 3, acc);
             fe_mul(acc, acc, cur.z);
-            e += PLUME_TAB_ENTRY_WORDS;
         }
     }
     fe inv;
     fe_inv(inv, acc);
     const fe beta = fe_beta();
+    // (a software-pipelined pass 2 -- fetch entry q-1 while converting entry q -- measured 25 % SLOWER: 36 more live registers)
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
         size_t job = j0 + (size_t)jj;
         PLUME_NOUNROLL for (int k = ENTRIES - 1; k >= 0; k--) {
+            const size_t q = (size_t)jj * ENTRIES + (size_t)k;
             uint32_t* e = tab + job * (size_t)(ENTRIES * PLUME_TAB_ENTRY_WORDS) + k * PLUME_TAB_ENTRY_WORDS;
             fe X, Y, Zk, cprev, zi, zi2;
-            ld_fe(X, e + 0); ld_fe(Y, e + PLUME_FE_W); ld_fe(Zk, e + 2 * PLUME_FE_W); ld_fe(cprev, e + 3 * PLUME_FE_W);
+            scr_ld(X, scr, sstride, slane, q, 0); scr_ld(Y, scr, sstride, slane, q, 1); scr_ld(Zk, scr, sstride, slane, q, 2); scr_ld(cprev, scr, sstride, slane, q, 3);
             fe_mul(zi, inv, cprev);      // 1/Z_k
             fe_mul(inv, inv, Zk);        // inverse of the product before Z_k
             fe_sqr(zi2, zi);
             fe_mul(X, X, zi2);
             fe_mul(zi2, zi2, zi); fe_mul(Y, Y, zi2);
             fe bx; fe_mul_k(bx, beta, X);
-            st_fe(e + 0, X); st_fe(e + PLUME_FE_W, Y); st_fe(e + 2 * PLUME_FE_W, bx);     // tight, not canonical: only ever multiplied / negated
+            st_tab_entry(e, X, Y, bx);   // tight, not canonical: only ever multiplied / negated
         }
     }
 }
@@ -363,7 +387,7 @@ PLUME_HD void normalize_points(uint32_t* pts, const uint8_t* inf, size_t npts, s
 
 // ------------------------------------------------------------------------------- fixed-base comb (generator only)
 // k*G with NO doublings: k = sum d_i 256^i (Booth w = 8, d_i in [-128, 128], i = 0..32) and a precomputed table
-// comb[i][e] = (e+1) * 256^i * G  (33 windows x 128 entries, 594 KiB, L2-resident).  33 mixed additions per
+// comb[i][e] = (e+1) * 256^i * G  (33 windows x 128 entries, 462 KiB, L2-resident).  33 mixed additions per
 // multiplication instead of 128 doublings + 34 additions; used by the signer's pk = sk*G and R = r*G
 // (rust-k256/src/randomizedsigner.rs:51,53).
 #define PLUME_COMB_WINDOWS 33
@@ -390,8 +414,7 @@ PLUME_HD void comb_mul_g_impl(jac& acc, const sc& k, const uint32_t* comb) {
             const int ad = d < 0 ? -d : d;
             const uint32_t* e = comb + ((size_t)i * PLUME_GTAB8_ENTRIES + (size_t)(ad - 1)) * PLUME_TAB_ENTRY_WORDS;
             fe qx, qy;
-            ld_fe(qx, e);
-            ld_fe(qy, e + PLUME_FE_W);
+            ld_tab_xy(qx, qy, e, false);
             if (d < 0) fe_neg_lazy(qy, qy);
             jac_madd<CHECKED>(acc, qx, qy);
         }
@@ -433,8 +456,7 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
                 int ad = d < 0 ? -d : d;
                 const uint32_t* e = tab + (ad - 1) * PLUME_TAB_ENTRY_WORDS;
                 fe qx, qy;
-                ld_fe(qx, (s & 1) ? e + 2 * PLUME_FE_W : e);
-                ld_fe(qy, e + PLUME_FE_W);
+                ld_tab_xy(qx, qy, e, (s & 1) != 0);
                 if (d < 0) fe_neg_lazy(qy, qy);
                 jac_madd<CHECKED>(acc, qx, qy);
             }

@@ -45,8 +45,8 @@ __device__ __forceinline__ void stage_gtab(uint32_t* s_gtab, const uint32_t* gta
 }
 
 // one-time: (1..128)*G, affine + beta*x, by a single lane (plume_init)
-__global__ void k_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) table_build<PLUME_GTAB8_ENTRIES>(gtab8, base_g, flag, 1, 0, 1);
+__global__ void k_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) table_build<PLUME_GTAB8_ENTRIES>(gtab8, base_g, flag, 1, 0, 1, scr, 1, 0);
 }
 
 __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
@@ -54,12 +54,12 @@ __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
     if (i < a.n) verify_ingest_h2c(a, i);
 }
 
-__global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
+__global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr) {
     size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x;
     size_t j0 = lane * (size_t)L;
     if (j0 < njobs) {
         size_t rem = njobs - j0;
-        table_build(tab, bases, jobflags, njobs, j0, (int)(rem < (size_t)L ? rem : (size_t)L));
+        table_build(tab, bases, jobflags, njobs, j0, (int)(rem < (size_t)L ? rem : (size_t)L), scr, (size_t)gridDim.x * kBlock, lane);
     }
 }
 
@@ -96,14 +96,14 @@ __global__ PLUME_BOUNDS void k_sign_gmul(SignArgs a) {
 
 // one-time: comb[i] = table of 256^i * G, i = 0..32.  Lane i first walks 8*i doublings from G (a few hundred
 // microseconds once per context), then builds its 128-entry window.
-__global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* PLUME_JAC_WORDS x 33 words scratch */, uint8_t* flags /* 33 */) {
+__global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* PLUME_JAC_WORDS x 33 words scratch */, uint8_t* flags /* 33 */, uint32_t* scr /* 33 x 128 scratch entries */) {
     const uint32_t i = threadIdx.x;
     if (blockIdx.x != 0 || i >= PLUME_COMB_WINDOWS) return;
     jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
     for (uint32_t d = 0; d < 8 * i; d++) jac_dbl(g);
     st_jac_soa(bases, PLUME_COMB_WINDOWS, i, g);
     flags[i] = PLUME_JOB_OK;
-    table_build<PLUME_GTAB8_ENTRIES>(comb, bases, flags, PLUME_COMB_WINDOWS, i, 1);
+    table_build<PLUME_GTAB8_ENTRIES>(comb, bases, flags, PLUME_COMB_WINDOWS, i, 1, scr, PLUME_COMB_WINDOWS, i);
 }
 
 __global__ PLUME_H2C_BOUNDS void k_sign_h2c(SignArgs a) {
@@ -215,9 +215,13 @@ __global__ __launch_bounds__(kBlock) void k_microbench(int kind, int iters, uint
 static inline unsigned nblocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 void launch_verify_ingest(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_ingest, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
-void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, hipStream_t st) {
+size_t tables_scratch_bytes(size_t njobs, int L) {
+    const size_t lanes = (njobs + L - 1) / L;
+    return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_ENTRIES * PLUME_TAB_SCR_WORDS * 4;
+}
+void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st) {
     size_t lanes = (njobs + L - 1) / L;
-    hipLaunchKernelGGL(k_tables, dim3(nblocks(lanes)), dim3(kBlock), 0, st, tab, bases, jobflags, njobs, L);
+    hipLaunchKernelGGL(k_tables, dim3(nblocks(lanes)), dim3(kBlock), 0, st, tab, bases, jobflags, njobs, L, scr);
 }
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_msm, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_finalize, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
@@ -231,8 +235,8 @@ void launch_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, hipStream_
 }
 void launch_decompress(const DecompressArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_decompress, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_h2c_only(const H2cArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_only, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
-void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, hipStream_t st) { hipLaunchKernelGGL(k_gtab8, dim3(1), dim3(64), 0, st, gtab8, base_g, flag); }
-void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, hipStream_t st) { hipLaunchKernelGGL(k_gcomb, dim3(1), dim3(64), 0, st, comb, bases, flags); }
+void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gtab8, dim3(1), dim3(64), 0, st, gtab8, base_g, flag, scr); }
+void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gcomb, dim3(1), dim3(64), 0, st, comb, bases, flags, scr); }
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_microbench, dim3(blocks), dim3(kBlock), 0, st, kind, iters, sink);
 }

@@ -13,7 +13,9 @@ constexpr int kBlock = PLUME_BLOCK;      // wavefronts per workgroup = kBlock / 
 constexpr int kTableJobsPerLane = 6;   // multiple of 3: job kinds (pk, H, nullifier) then line up across the lanes of a wavefront
 
 void launch_verify_ingest(const VerifyArgs& a, hipStream_t st);
-void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int jobs_per_lane, hipStream_t st);
+// scr: lane-interleaved pass-1 scratch of tables_scratch_bytes(njobs, jobs_per_lane) bytes (plume_ec.h table_build)
+size_t tables_scratch_bytes(size_t njobs, int jobs_per_lane);
+void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int jobs_per_lane, uint32_t* scr, hipStream_t st);
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st);
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st);
 void launch_sign_gmul(const SignArgs& a, hipStream_t st);
@@ -23,8 +25,8 @@ void launch_sign_final(const SignArgs& a, hipStream_t st);
 void launch_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, hipStream_t st);
 void launch_decompress(const DecompressArgs& a, hipStream_t st);
 void launch_h2c_only(const H2cArgs& a, hipStream_t st);
-void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, hipStream_t st);
-void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, hipStream_t st);
+void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr /* 128 scratch entries */, hipStream_t st);
+void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, uint32_t* scr /* 33 x 128 scratch entries */, hipStream_t st);
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st);
 
 }  // namespace plume

@@ -201,7 +201,7 @@ PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
                 const size_t jh = 3 * (size_t)i + 1;
                 bool hinf = job_state(a.jobflags[jh]) == PLUME_JOB_INF;
                 fe Hx, Hy;
-                ld_fe(Hx, a.tab + jh * PLUME_TAB_WORDS); ld_fe(Hy, a.tab + jh * PLUME_TAB_WORDS + PLUME_FE_W);
+                ld_tab_xy(Hx, Hy, a.tab + jh * PLUME_TAB_WORDS, false);
                 enc_pt pts[6];
                 pts[0] = enc_of(fe_gx(), fe_gy(), false);
                 pts[1] = enc_of(pkx, pky, fpk == PLUME_JOB_INF);
@@ -333,7 +333,7 @@ PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
     fe px, py, Hx, Hy;
     ld_fe_soa(px, a.pkaff, a.n, i); ld_fe_soa(py, a.pkaff + PLUME_FE_W * (size_t)a.n, a.n, i);
     bool hinf = job_state(a.jobflags[i]) == PLUME_JOB_INF;
-    ld_fe(Hx, a.tab + (size_t)i * PLUME_TAB_WORDS); ld_fe(Hy, a.tab + (size_t)i * PLUME_TAB_WORDS + PLUME_FE_W);
+    ld_tab_xy(Hx, Hy, a.tab + (size_t)i * PLUME_TAB_WORDS, false);
     uint32_t dg[8];
     enc_pt e_nul = enc_of(nul.x, nul.y, nul.inf != 0), e_r = enc_of(R.x, R.y, R.inf != 0), e_hr = enc_of(hr.x, hr.y, hr.inf != 0);
     if (a.version == 1) {
