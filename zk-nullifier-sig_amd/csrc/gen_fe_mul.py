@@ -20,14 +20,15 @@ hazard nops inside a statement.  Host builds (tests/devsim) compile the same col
 """
 
 
-def col_terms(k, sqr):
+def col_terms(k, sqr, pair=("a", "b")):
     t = []
+    x, y = pair
     for i in range(9):
         j = k - i
         if j < 0 or j > 8:
             continue
         if not sqr:
-            t.append((f"a.v[{i}]", f"b.v[{j}]"))
+            t.append((f"{x}.v[{i}]", f"{y}.v[{j}]"))
         elif i < j:
             t.append((f"a.v[{i}]", f"d[{j}]"))
         elif i == j:
@@ -57,7 +58,8 @@ def emit_chain(terms, indent="    "):
     return (f"{indent}PLUME_FE_CHAIN(\"{body}\", {ins});\n", f"{indent}{host}\n")
 
 
-def gen(name, sqr):
+def gen(name, sqr, two=False):
+    """two: r = a*b + c*d with ONE fold -- the two products share their column sums (each column: two chain statements)"""
     dev, host = [], []
 
     def both(s):
@@ -71,11 +73,19 @@ def gen(name, sqr):
         d, h = emit_chain([(x, y, False) for (x, y) in col_terms(k, sqr)])
         dev.append(d)
         host.append(h)
+        if two:
+            d, h = emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))])
+            dev.append(d)
+            host.append(h)
         if k < 16:
             both(f"    h[{k - 9}] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;\n")
         else:
             both("    h[7] = (uint32_t)acc & PLUME_FE_MASK; h[8] = (uint32_t)(acc >> 29);\n    PLUME_FE_ASSERT((acc >> 29) < (1ull << 27));\n    acc = 0;\n")
     for k in range(9):
+        if two:
+            d, h = emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))])
+            dev.append(d)
+            host.append(h)
         t = [(x, y, False) for (x, y) in col_terms(k, sqr)]
         t.append((f"h[{k}]", "K0", True))
         if k > 0:
@@ -103,6 +113,9 @@ def gen(name, sqr):
     both("    l[1] = (uint32_t)acc & PLUME_FE_MASK;\n    l[2] += (uint32_t)(acc >> 29) + (t1 << 3);\n    PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = l[i];\n")
     sig = f"PLUME_HD void {name}(fe& r, const fe& a)" if sqr else f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b)"
     check = "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, a));\n" if sqr else "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, b));\n"
+    if two:
+        sig = f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b, const fe& c, const fe& e)"
+        check = "    PLUME_FE_ASSERT(fe_muladd_inputs_ok(a, b, c, e));\n"
     consts = "    const uint32_t K0 = 31264u, K1 = 256u, K2 = 31264u << 8, K3 = 65536u, K4 = 977u, K5 = 8u;\n"
     return f"{sig} {{\n{check}{consts}#if defined(__HIP_DEVICE_COMPILE__)\n{''.join(dev)}#else\n{''.join(host)}#endif\n}}\n"
 
@@ -116,6 +129,10 @@ def main():
     print(gen("fe_mul", False))
     print(gen("fe_sqr", True))
     global A_CONS
+    A_CONS_SAVE = A_CONS
+    A_CONS = "v"
+    print("// r = a*b + c*e with one fold: the 17 column sums of both products accumulate in the same chains (bound: fe_muladd_inputs_ok)")
+    print(gen("fe_muladd", False, True))
     A_CONS = "s"
     print("// a is a compile-time constant (curve / isogeny coefficients): its limbs stay in SGPRs instead of occupying 9 VGPRs each")
     print(gen("fe_mul_k", False))

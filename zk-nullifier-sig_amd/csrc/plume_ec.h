@@ -74,10 +74,12 @@ PLUME_HD void jac_dbl_cold(jac& p) { jac tmp = p; jac_dbl_cold_impl(&tmp); p = t
 
 // p += (qx, qy) affine, q != infinity; qx tight, qy tight or an unreduced negation (limbs <= 2p).  8M + 3S, 4 carry passes.
 // CHECKED = true handles every exceptional case (p infinite, p == q, p == -q).
+// (fe_neg_lazy: unreduced negation of a tight value, limbs <= 2p -- also a legal qy)
 // CHECKED = false is the hot-loop form: it handles p infinite but does NOT test for p == +-q.  In that case H = 0 (mod p)
 // and Z' = Z*H = 0 (mod p), and every later doubling / addition keeps Z = 0 (mod p) (Z only ever gets multiplied), so
 // the caller detects the event ONCE at the end (fe_is_zero(Z)) and recomputes that lane with CHECKED = true.  No other
 // path reaches Z = 0: a legitimate identity is carried in the inf flag, and the curve has no point with Y = 0.
+PLUME_HD void fe_neg_lazy(fe& r, const fe& a) { fe z = fe_zero(); fe_sub_lazy<2>(r, z, a); }
 template <bool CHECKED = true>
 PLUME_HD void jac_madd(jac& p, const fe& qx, const fe& qy) {
     if (p.inf) {
@@ -102,12 +104,9 @@ PLUME_HD void jac_madd(jac& p, const fe& qx, const fe& qy) {
     fe_add_lazy(hh, v, v); fe_add_lazy(hh, hh, hhh);       // 2V + H^3
     fe_sub_lazy<4>(p.x, t, hh); fe_carry(p.x);             // X' = r^2 - H^3 - 2V
     fe_sub_lazy<2>(t, v, p.x);                             // V - X'
-    fe_mul(t, r, t);
-    fe_mul(hhh, p.y, hhh);
-    fe_sub_lazy<2>(p.y, t, hhh); fe_carry(p.y);
+    fe_neg_lazy(v, p.y);                                   // -Y1, unreduced
+    fe_muladd(p.y, r, t, v, hhh);                          // Y' = r(V - X') - Y1*H^3: both products share one fold
 }
-// unreduced negation of a tight value (limbs <= 2p): a legal qy for jac_madd
-PLUME_HD void fe_neg_lazy(fe& r, const fe& a) { fe z = fe_zero(); fe_sub_lazy<2>(r, z, a); }
 
 // p += q, both Jacobian.  12M + 4S; all exceptional cases handled.
 PLUME_HD void jac_add(jac& p, const jac& q) {
@@ -127,9 +126,9 @@ PLUME_HD void jac_add(jac& p, const jac& q) {
     fe_sqr(hh, h); fe_mul(hhh, hh, h); fe_mul(v, u1, hh);
     fe_mul(p.z, p.z, q.z); fe_mul(p.z, p.z, h);
     fe_sqr(t, r); fe_sub(t, t, hhh); fe_sub(t, t, v); fe_sub(p.x, t, v);
-    fe_sub(t, v, p.x); fe_mul(t, r, t);
-    fe_mul(hhh, s1, hhh);
-    fe_sub(p.y, t, hhh);
+    fe_sub_lazy<2>(t, v, p.x);
+    fe_neg_lazy(v, s1);
+    fe_muladd(p.y, r, t, v, hhh);                          // r(V - X') - S1*H^3 with one fold
 }
 
 // Jacobian p == affine (ax, ay)?  (ProjectivePoint == AffinePoint, rust-k256/src/lib.rs:117,122); a_inf = the affine side is the identity

@@ -129,6 +129,19 @@ PLUME_HD bool fe_mul_inputs_ok(const fe& a, const fe& b) {
     return prod < ((0xFFFFFFFFFFFFFFFFull - (1ull << 50)) / 9);
 }
 
+PLUME_HD bool fe_muladd_inputs_ok(const fe& a, const fe& b, const fe& c, const fe& e) {   // a*b + c*e through shared column sums
+    uint64_t ma = 0, mb = 0, mc = 0, me = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) {
+        if (a.v[i] > ma) ma = a.v[i];
+        if (b.v[i] > mb) mb = b.v[i];
+        if (c.v[i] > mc) mc = c.v[i];
+        if (e.v[i] > me) me = e.v[i];
+    }
+    if (a.v[8] > (1u << 26) || b.v[8] > (1u << 26) || c.v[8] > (1u << 26) || e.v[8] > (1u << 26)) return false;
+    const unsigned __int128 sum = (unsigned __int128)ma * mb + (unsigned __int128)mc * me;
+    return sum < (unsigned __int128)((0xFFFFFFFFFFFFFFFFull - (1ull << 50)) / 9);
+}
+
 // 8 x 32-bit little-endian words (any 256-bit integer) <-> limbs
 PLUME_HD void fe_from_words(fe& r, const uint32_t w[8]) {
     PLUME_UNROLL for (int i = 0; i < 9; i++) {
