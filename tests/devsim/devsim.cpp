@@ -81,13 +81,16 @@ void ds_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
 }
 
 static void build_gtab(std::vector<uint32_t>& gtab) {
-    gtab.assign(PLUME_GTAB8_WORDS, 0);
+    static std::vector<uint32_t> cached;           // the table only depends on G: build it once per process (2048 entries for W = 12)
+    if (!cached.empty()) { gtab = cached; return; }
+    gtab.assign(PLUME_GTAB_WORDS, 0);
     std::vector<uint32_t> bases(PLUME_JAC_WORDS, 0);
     jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
     st_jac_soa(bases.data(), 1, 0, g);
     uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
-    std::vector<uint32_t> scr((size_t)PLUME_GTAB8_ENTRIES * PLUME_TAB_SCR_WORDS);
-    table_build<PLUME_GTAB8_ENTRIES>(gtab.data(), bases.data(), &flag, 1, 0, 1, scr.data(), 1, 0);
+    std::vector<uint32_t> scr((size_t)PLUME_GTAB_ENTRIES * PLUME_TAB_SCR_WORDS);
+    table_build<PLUME_GTAB_ENTRIES>(gtab.data(), bases.data(), &flag, 1, 0, 1, scr.data(), 1, 0);
+    cached = gtab;
 }
 
 static void build_gcomb(std::vector<uint32_t>& comb) {

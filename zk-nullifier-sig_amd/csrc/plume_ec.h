@@ -200,30 +200,45 @@ PLUME_HD int booth_digit(const uint32_t m[4], int i) {
     }
     return (int)(u & 1) + (int)((u >> 1) & 7) - (int)((u >> 4) << 3);
 }
-// Booth recoding, w = 8 (fixed-base slots): m = sum d_k 256^k, d_k in [-128, 128], k = 0..16
-#define PLUME_NDIG8 17
-PLUME_HD int booth_digit8(const uint32_t m[4], int k) {
-    int lo = 8 * k - 1;
+// Booth recoding with a WIDE window for the generator's slots of the verifier: m = sum d_k 2^(W k), d_k in [-2^(W-1), 2^(W-1)].
+// W = PLUME_GW must be a multiple of 4 so that digit k lines up with the 4-bit window i = k * W/4 of the shared doubling chain.
+// W = 12: 11 digits per 128-bit half (22 generator additions per verify instead of 34 with W = 8) from a 2048-entry table
+// (224 KiB, L2-resident).
+#ifndef PLUME_GW
+#define PLUME_GW 12
+#endif
+#define PLUME_GWS (PLUME_GW / 4)                          // 4-bit windows per wide digit
+#define PLUME_NDIGW ((128 + PLUME_GW) / PLUME_GW)         // digits covering 129 bits: 11 for W = 12, 17 for W = 8
+#define PLUME_GTAB_ENTRIES (1 << (PLUME_GW - 1))
+PLUME_HD int booth_digit_w(const uint32_t m[4], int k) {
+    const int W = PLUME_GW, lo = W * k - 1;
+    const uint32_t mask = (1u << (W + 1)) - 1u;
     uint32_t u;
     if (lo < 0) {
-        u = (m[0] << 1) & 0x1FF;
+        u = (m[0] << 1) & mask;
     } else {
         int wi = lo >> 5, sh = lo & 31;
         uint32_t a = wi < 4 ? m[wi] : 0u, b = (wi + 1) < 4 ? m[wi + 1] : 0u;
-        u = ((a >> sh) | (sh > 23 ? (b << (32 - sh)) : 0u)) & 0x1FF;
+        u = ((a >> sh) | ((sh > 31 - W) ? (b << (32 - sh)) : 0u)) & mask;
     }
-    return (int)(u & 1) + (int)((u >> 1) & 127) - (int)((u >> 8) << 7);
+    return (int)(u & 1) + (int)((u >> 1) & ((1u << (W - 1)) - 1u)) - (int)((u >> W) << (W - 1));
 }
-// wide (w = 8) digits share the 33-slot digit row of a half-scalar: magnitude (0..128) at position 2k, sign at 2k+1
+// wide digits share the 33-slot digit row of a half-scalar: digit k occupies positions S*k .. S*k+S-1 (S = W/4):
+// byte 0 = magnitude bits 0..7, byte 1 = magnitude bits 8..11 | sign << 7.  If byte 1 would fall off the row (W = 8, top digit,
+// which is 0 or 1) the sign goes to bit 6 of byte 0.
 PLUME_HD void booth_store_wide(int8_t* dig, uint32_t stride, const glv_half& h, bool flip) {
     bool neg = (h.neg != 0) != flip;
-    PLUME_UNROLL for (int k = 0; k < PLUME_NDIG8; k++) {
-        int d = booth_digit8(h.m, k);
+    PLUME_UNROLL for (int k = 0; k < PLUME_NDIGW; k++) {
+        int d = booth_digit_w(h.m, k);
         bool dn = (d < 0) != neg;
         int mag = d < 0 ? -d : d;
-        dig[(uint32_t)(2 * k) * stride] = (int8_t)(uint8_t)mag;
-        if (k < PLUME_NDIG8 - 1) dig[(uint32_t)(2 * k + 1) * stride] = (int8_t)(dn ? 1 : 0);
-        else if (mag != 0 && dn) dig[(uint32_t)(2 * k) * stride] = (int8_t)(uint8_t)(mag | 0x40);  // top digit is 0 or 1: keep its sign in bit 6
+        const int pos = PLUME_GWS * k;
+        if (pos + 1 < PLUME_NDIG) {
+            dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)(mag & 0xFF);
+            dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)(((mag >> 8) & 0xF) | ((mag != 0 && dn) ? 0x80 : 0));
+        } else {
+            dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)((mag & 0x3F) | ((mag != 0 && dn) ? 0x40 : 0));
+        }
     }
 }
 // writes the 33 signed digits of one half-scalar to dig[i*stride], sign applied
@@ -278,7 +293,9 @@ PLUME_HD void st_jac_soa(uint32_t* base, size_t stride, size_t j, const jac& p) 
 #define PLUME_JOB_INVALID 2u  // base failed validation: a dummy (G) table is built, the item is rejected elsewhere
 #define PLUME_JOB_AFFINE 0x80u  // OR-ed in: the base has Z = 1, its chain uses mixed additions
 PLUME_HD uint32_t job_state(uint8_t f) { return f & 3u; }
-// the generator's wide table for fixed-base slots: 128 entries (1..128)*G, same entry format
+// the generator's wide table for the verifier's fixed-base slots: (1..2^(W-1))*G, same row format
+#define PLUME_GTAB_WORDS (PLUME_GTAB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
+// window size of the signer's doubling-free comb (below): 128 entries per 8-bit window
 #define PLUME_GTAB8_ENTRIES 128
 #define PLUME_GTAB8_WORDS (PLUME_GTAB8_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 
@@ -432,7 +449,7 @@ PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
 // acc = sum over slots of digit * table point.  Slot s uses table tabs[s >> 1]; odd slots are the lambda
 // halves (beta*x).  dig: digits of slot s, window i at dig[(s*PLUME_NDIG + i)*stride].  A NULL table (or a
 // job flagged INF) contributes nothing.
-// wide0: slots 0,1 use the generator's 128-entry table with w = 8 digits (stored by booth_store_wide).
+// wide0: slots 0,1 use the generator's wide table with W-bit digits (stored by booth_store_wide).
 template <bool CHECKED>
 PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
@@ -444,11 +461,13 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
             const uint32_t* tab = (s & 2) ? tab1 : tab0;
             int d = dig[(uint32_t)(s * PLUME_NDIG + i) * stride];
             if (wide0 && s < 2) {
-                if (i & 1) continue;                      // wave-uniform: wide digits sit at even windows only
+                if (i % PLUME_GWS) continue;              // wave-uniform: a wide digit sits at every (W/4)-th window only
                 int mag = d & 0xFF;
                 bool dn;
-                if (i == PLUME_NDIG - 1) { dn = (mag & 0x40) != 0; mag &= 0x3F; }
-                else dn = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride] != 0;
+                if (i + 1 < PLUME_NDIG) {
+                    const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
+                    mag |= (hi & 0xF) << 8; dn = (hi & 0x80) != 0;
+                } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
                 d = dn ? -mag : mag;
             }
             if (d != 0 && tab != nullptr) {

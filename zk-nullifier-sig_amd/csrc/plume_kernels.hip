@@ -36,17 +36,20 @@
 namespace plume {
 
 
-// the generator's wide table (128 entries, 16 KiB) -> LDS, 16 B per lane per trip
+#if PLUME_GTAB_IN_LDS
+static_assert(PLUME_GTAB_WORDS * 4 <= 32768, "the generator's wide table only fits LDS for PLUME_GW = 8");
+// the generator's wide table -> LDS, 16 B per lane per trip (measured 10 % slower than reading it through L1/L2: bank conflicts)
 __device__ __forceinline__ void stage_gtab(uint32_t* s_gtab, const uint32_t* gtab) {
     const uint4* src = reinterpret_cast<const uint4*>(gtab);
     uint4* dst = reinterpret_cast<uint4*>(s_gtab);
-    for (int w = threadIdx.x; w < PLUME_GTAB8_WORDS / 4; w += kBlock) dst[w] = src[w];
+    for (int w = threadIdx.x; w < PLUME_GTAB_WORDS / 4; w += kBlock) dst[w] = src[w];
     __syncthreads();
 }
+#endif
 
-// one-time: (1..128)*G, affine + beta*x, by a single lane (plume_init)
+// one-time: (1..2^(W-1))*G, affine + beta*x, by a single lane (plume_init; ~15 ms for W = 12)
 __global__ void k_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) table_build<PLUME_GTAB8_ENTRIES>(gtab8, base_g, flag, 1, 0, 1, scr, 1, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) table_build<PLUME_GTAB_ENTRIES>(gtab8, base_g, flag, 1, 0, 1, scr, 1, 0);
 }
 
 __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
@@ -67,7 +70,7 @@ __global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* base
 // per workgroup so the generator-table-in-LDS path never diverges inside a wavefront
 __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
 #if PLUME_GTAB_IN_LDS
-    __shared__ __attribute__((aligned(16))) uint32_t s_gtab[PLUME_GTAB8_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_gtab[PLUME_GTAB_WORDS];
 #endif
     __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;

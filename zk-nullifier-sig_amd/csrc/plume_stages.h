@@ -114,7 +114,7 @@ struct VerifyArgs {
     uint32_t* tab;        // 3n tables of PLUME_TAB_WORDS
     uint32_t* res;        // PLUME_JAC_WORDS x (2n) words, Jacobian SoA of R' (task 2i) and Hr' (task 2i+1)
     uint8_t* resinf;      // 2n
-    const uint32_t* gtab; // wide table of G (PLUME_GTAB8_WORDS): (1..128)*G
+    const uint32_t* gtab; // wide table of G (PLUME_GTAB_WORDS): (1..2^(W-1))*G
 };
 
 PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
