@@ -220,8 +220,13 @@ def main():
             dom = max(stages, key=stages.get)
             dom_s = stages[dom] * 1e-3
             achieved = BYTES_PER_ITEM[ver] * n / dom_s / 1e9
+            # HBM bytes per launch from the committed PMC passes (2^20-item launch, scaled to this batch), as GB/s over this run's kernel time
+            tb, tsrc = pmc_traffic("plume::k_" + dom)
+            traffic = round(tb * (n / float(1 << 20)) / dom_s / 1e9, 1) if tb else None
             line["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                                "traffic_note": (f"{tb} raw FETCH_SIZE+WRITE_SIZE bytes per 2^20-item launch, {tsrc}; uncorrected (the guide's 2x FETCH_SIZE correction is calibrated "
+                                                 f"for wide coalesced streams, these are 16-byte per-lane gathers)") if tb else None,
                                 "note": "path is integer-VALU bound (SURVEY.md §8d); see valu_roofline"}
             try:
                 # long enough (tens of ms each) for the clocks to settle where the real kernels run

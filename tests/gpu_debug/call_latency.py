@@ -28,3 +28,5 @@ t0 = time.perf_counter()
 for _ in range(8): call()
 torch.cuda.synchronize()
 print(f"8 calls back to back: {1e3*(time.perf_counter()-t0)/8:6.2f} ms per call")
+t0 = time.perf_counter(); e2 = plume.Engine(0); t1 = time.perf_counter()
+print(f"plume_init (second context, includes the 2048-entry generator table and the comb): {1e3*(t1-t0):.1f} ms")
