@@ -226,12 +226,15 @@ def test_sec1_compressed_ingest(ver):
 
 
 def test_verify_equation1_wide_digits_special_scalars():
-    """s*G - c*pk through the verify multi-scalar body for scalars that hit the w = 8 digit extremes (+-128, sign bytes,
-    top digit), and for pk = +-G where the two bases coincide"""
+    """s*G - c*pk through the verify multi-scalar body for scalars that hit the wide-digit extremes of the generator's slots
+    (12-bit Booth digits: +-2048, the carry into the top digit, the sign / high-nibble byte; and the 8-bit patterns of the previous
+    window size), and for pk = +-G where the two bases coincide"""
     rng = random.Random(33)
     lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    w12 = [int("800" * 10 + "80", 16), int("7ff" * 10 + "7f", 16), int("fff" * 10 + "ff", 16), int("801" * 10 + "80", 16), int("001" * 10 + "00", 16)]
     specials = [1, 2, 127, 128, 129, 255, 256, 0x8080, 0x80808080, 2**127, 2**127 - 1, 2**128 - 1, 2**128, lam, (128 * lam) % N, N - 128, N - 1,
-                int("80" * 16, 16), int("7f" * 16, 16), int("ff" * 16, 16), (int("80" * 16, 16) * lam + int("80" * 16, 16)) % N]
+                int("80" * 16, 16), int("7f" * 16, 16), int("ff" * 16, 16), (int("80" * 16, 16) * lam + int("80" * 16, 16)) % N,
+                2047, 2048, 2049, 4095, 4096, 4097, 0x800800, 0x7FF800, N - 2048, (2048 * lam) % N, (2048 * lam + 2048) % N] + w12 + [(w12[0] * lam + w12[1]) % N]
     pks = [O.G, O.pt_neg(O.G), O.pt_mul(rng.randrange(1, N), O.G)]
     for pk in pks:
         for s_ in specials + [rng.randrange(1, N) for _ in range(4)]:
