@@ -25,7 +25,15 @@
 #ifndef PLUME_H2C_WAVES
 #define PLUME_H2C_WAVES PLUME_MIN_WAVES
 #endif
+#ifndef PLUME_FINAL_WAVES
+#define PLUME_FINAL_WAVES 2    // the finalize kernels hold six encodings + SHA state: at 4 waves they spill ~200 VGPRs (measured 0.48 -> 0.33 ms at 2)
+#endif
+#ifndef PLUME_NORM_WAVES
+#define PLUME_NORM_WAVES 2     // 8 points per lane with their prefix products live in registers
+#endif
 #define PLUME_BOUNDS __launch_bounds__(kBlock, PLUME_MIN_WAVES)
+#define PLUME_FINAL_BOUNDS __launch_bounds__(kBlock, PLUME_FINAL_WAVES)
+#define PLUME_NORM_BOUNDS __launch_bounds__(kBlock, PLUME_NORM_WAVES)
 #define PLUME_MSM_BOUNDS __launch_bounds__(kBlock, PLUME_MSM_WAVES)
 #define PLUME_TABLES_BOUNDS __launch_bounds__(kBlock, PLUME_TABLES_WAVES)
 #define PLUME_H2C_BOUNDS __launch_bounds__(kBlock, PLUME_H2C_WAVES)
@@ -97,7 +105,7 @@ __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
     if (i < a.n) verify_msm(a, i, eq, gt, s_dig + threadIdx.x, kBlock);
 }
 
-__global__ PLUME_BOUNDS void k_verify_finalize(VerifyArgs a) {
+__global__ PLUME_FINAL_BOUNDS void k_verify_finalize(VerifyArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) verify_finalize(a, i);
 }
@@ -134,13 +142,13 @@ __global__ PLUME_MSM_BOUNDS void k_sign_hmul(SignArgs a) {
     if (i < a.n) sign_hmul(a, i, which, s_dig + threadIdx.x, kBlock);
 }
 
-__global__ PLUME_BOUNDS void k_sign_final(SignArgs a) {
+__global__ PLUME_FINAL_BOUNDS void k_sign_final(SignArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) sign_final(a, i);
 }
 
 // batched Jacobian -> affine (8 points per lane, one inversion): V2 verify results, signer outputs
-__global__ PLUME_BOUNDS void k_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, size_t nlanes) {
+__global__ PLUME_NORM_BOUNDS void k_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, size_t nlanes) {
     size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (lane < nlanes) normalize_points(pts, inf, npts, lane, nlanes);
 }
