@@ -97,13 +97,13 @@ static void build_gcomb(std::vector<uint32_t>& comb) {
     comb.assign(PLUME_COMB_WORDS, 0);
     std::vector<uint32_t> bases(PLUME_JAC_WORDS * PLUME_COMB_WINDOWS, 0);
     std::vector<uint8_t> flags(PLUME_COMB_WINDOWS, 0);
-    std::vector<uint32_t> scr((size_t)PLUME_COMB_WINDOWS * PLUME_GTAB8_ENTRIES * PLUME_TAB_SCR_WORDS);
+    std::vector<uint32_t> scr((size_t)PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES * PLUME_TAB_SCR_WORDS);
     for (uint32_t i = 0; i < PLUME_COMB_WINDOWS; i++) {      // mirrors k_gcomb
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
-        for (uint32_t d = 0; d < 8 * i; d++) jac_dbl(g);
+        for (uint32_t d = 0; d < PLUME_COMB_W * i; d++) jac_dbl(g);
         st_jac_soa(bases.data(), PLUME_COMB_WINDOWS, i, g);
         flags[i] = PLUME_JOB_OK;
-        table_build<PLUME_GTAB8_ENTRIES>(comb.data(), bases.data(), flags.data(), PLUME_COMB_WINDOWS, i, 1, scr.data(), PLUME_COMB_WINDOWS, i);
+        table_build<PLUME_COMB_ENTRIES>(comb.data(), bases.data(), flags.data(), PLUME_COMB_WINDOWS, i, 1, scr.data(), PLUME_COMB_WINDOWS, i);
     }
 }
 

@@ -106,7 +106,7 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
     }
     // generator wide window table (1..128)*G: one lane, once
     if (ctx->gtab.ensure((size_t)PLUME_GTAB_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(PLUME_JAC_WORDS * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64) ||
-        ctx->tabscr.ensure((size_t)(PLUME_COMB_WINDOWS * PLUME_GTAB8_ENTRIES > PLUME_GTAB_ENTRIES ? PLUME_COMB_WINDOWS * PLUME_GTAB8_ENTRIES : PLUME_GTAB_ENTRIES) * PLUME_TAB_SCR_WORDS * 4)) { delete ctx; return PLUME_ERR_HIP; }
+        ctx->tabscr.ensure((size_t)(PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES > PLUME_GTAB_ENTRIES ? PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES : PLUME_GTAB_ENTRIES) * PLUME_TAB_SCR_WORDS * 4)) { delete ctx; return PLUME_ERR_HIP; }
     uint32_t hb[PLUME_JAC_WORDS];
     {
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;

@@ -295,9 +295,12 @@ PLUME_HD void st_jac_soa(uint32_t* base, size_t stride, size_t j, const jac& p) 
 PLUME_HD uint32_t job_state(uint8_t f) { return f & 3u; }
 // the generator's wide table for the verifier's fixed-base slots: (1..2^(W-1))*G, same row format
 #define PLUME_GTAB_WORDS (PLUME_GTAB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
-// window size of the signer's doubling-free comb (below): 128 entries per 8-bit window
-#define PLUME_GTAB8_ENTRIES 128
-#define PLUME_GTAB8_WORDS (PLUME_GTAB8_ENTRIES * PLUME_TAB_ENTRY_WORDS)
+// the signer's doubling-free comb (below): 2^(W-1) entries per W-bit window
+#ifndef PLUME_COMB_W
+#define PLUME_COMB_W 11
+#endif
+#define PLUME_COMB_ENTRIES (1 << (PLUME_COMB_W - 1))
+#define PLUME_COMB_WINDOW_WORDS (PLUME_COMB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 
 // Build the tables of jobs [j0, j0+cnt) (cnt <= L, one lane).  Bases are Jacobian SoA (stride = njobs).
 // Pass 1 writes (X_k, Y_k, Z_k, running product before Z_k) for k = 1..8 of every job to the lane's slice of `scr`; one
@@ -402,33 +405,34 @@ PLUME_HD void normalize_points(uint32_t* pts, const uint8_t* inf, size_t npts, s
 }
 
 // ------------------------------------------------------------------------------- fixed-base comb (generator only)
-// k*G with NO doublings: k = sum d_i 256^i (Booth w = 8, d_i in [-128, 128], i = 0..32) and a precomputed table
-// comb[i][e] = (e+1) * 256^i * G  (33 windows x 128 entries, 462 KiB, L2-resident).  33 mixed additions per
-// multiplication instead of 128 doublings + 34 additions; used by the signer's pk = sk*G and R = r*G
+// k*G with NO doublings: k = sum d_i 2^(W i) (Booth, d_i in [-2^(W-1), 2^(W-1)], i = 0..NW-1) and a precomputed table
+// comb[i][e] = (e+1) * 2^(W i) * G.  W = 11: 24 windows x 1024 entries (2.6 MiB, L2-resident), 24 mixed additions per
+// multiplication (W = 8: 33 windows x 128 entries, 33 additions); used by the signer's pk = sk*G and R = r*G
 // (rust-k256/src/randomizedsigner.rs:51,53).
-#define PLUME_COMB_WINDOWS 33
-#define PLUME_COMB_WORDS (PLUME_COMB_WINDOWS * PLUME_GTAB8_WORDS)
-PLUME_HD int booth_digit8_256(const uint32_t m[8], int k) {   // k is a runtime loop index here (no unrolling)
-    const int lo = 8 * k - 1;
+#define PLUME_COMB_WINDOWS ((256 + PLUME_COMB_W) / PLUME_COMB_W)     // windows covering 257 bits
+#define PLUME_COMB_WORDS (PLUME_COMB_WINDOWS * PLUME_COMB_WINDOW_WORDS)
+PLUME_HD int booth_digit_comb(const uint32_t m[8], int k) {   // k is a runtime loop index here (no unrolling)
+    const int W = PLUME_COMB_W, lo = W * k - 1;
+    const uint32_t mask = (1u << (W + 1)) - 1u;
     uint32_t u;
     if (lo < 0) {
-        u = (m[0] << 1) & 0x1FF;
+        u = (m[0] << 1) & mask;
     } else {
         const uint32_t wi = (uint32_t)lo >> 5, sh = (uint32_t)lo & 31;
         uint32_t a = 0, b = 0;
         PLUME_UNROLL for (int i = 0; i < 8; i++) { a = (wi == (uint32_t)i) ? m[i] : a; b = (wi + 1 == (uint32_t)i) ? m[i] : b; }
-        u = ((a >> sh) | (sh > 23 ? (b << (32 - sh)) : 0u)) & 0x1FF;
+        u = ((a >> sh) | (sh > (uint32_t)(31 - W) ? (b << (32 - sh)) : 0u)) & mask;
     }
-    return (int)(u & 1) + (int)((u >> 1) & 127) - (int)((u >> 8) << 7);
+    return (int)(u & 1) + (int)((u >> 1) & ((1u << (W - 1)) - 1u)) - (int)((u >> W) << (W - 1));
 }
 template <bool CHECKED>
 PLUME_HD void comb_mul_g_impl(jac& acc, const sc& k, const uint32_t* comb) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
     PLUME_NOUNROLL for (int i = 0; i < PLUME_COMB_WINDOWS; i++) {
-        const int d = booth_digit8_256(k.v, i);
+        const int d = booth_digit_comb(k.v, i);
         if (d != 0) {
             const int ad = d < 0 ? -d : d;
-            const uint32_t* e = comb + ((size_t)i * PLUME_GTAB8_ENTRIES + (size_t)(ad - 1)) * PLUME_TAB_ENTRY_WORDS;
+            const uint32_t* e = comb + ((size_t)i * PLUME_COMB_ENTRIES + (size_t)(ad - 1)) * PLUME_TAB_ENTRY_WORDS;
             fe qx, qy;
             ld_tab_xy(qx, qy, e, false);
             if (d < 0) fe_neg_lazy(qy, qy);

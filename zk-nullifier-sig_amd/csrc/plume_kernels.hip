@@ -117,16 +117,16 @@ __global__ PLUME_BOUNDS void k_sign_gmul(SignArgs a) {
     if (i < a.n) sign_gmul(a, i, which);
 }
 
-// one-time: comb[i] = table of 256^i * G, i = 0..32.  Lane i first walks 8*i doublings from G (a few hundred
-// microseconds once per context), then builds its 128-entry window.
-__global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* PLUME_JAC_WORDS x 33 words scratch */, uint8_t* flags /* 33 */, uint32_t* scr /* 33 x 128 scratch entries */) {
+// one-time: comb[i] = table of 2^(W i) * G, i = 0..NW-1.  Lane i first walks W*i doublings from G, then builds its window
+// (2^(W-1) entries; ~10 ms once per context for W = 11).
+__global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* PLUME_JAC_WORDS x 33 words scratch */, uint8_t* flags /* 33 */, uint32_t* scr /* windows x entries scratch entries */) {
     const uint32_t i = threadIdx.x;
     if (blockIdx.x != 0 || i >= PLUME_COMB_WINDOWS) return;
     jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
-    for (uint32_t d = 0; d < 8 * i; d++) jac_dbl(g);
+    for (uint32_t d = 0; d < PLUME_COMB_W * i; d++) jac_dbl(g);
     st_jac_soa(bases, PLUME_COMB_WINDOWS, i, g);
     flags[i] = PLUME_JOB_OK;
-    table_build<PLUME_GTAB8_ENTRIES>(comb, bases, flags, PLUME_COMB_WINDOWS, i, 1, scr, PLUME_COMB_WINDOWS, i);
+    table_build<PLUME_COMB_ENTRIES>(comb, bases, flags, PLUME_COMB_WINDOWS, i, 1, scr, PLUME_COMB_WINDOWS, i);
 }
 
 __global__ PLUME_H2C_BOUNDS void k_sign_h2c(SignArgs a) {
