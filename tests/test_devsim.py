@@ -188,12 +188,14 @@ def test_sign_edge_status():
 
 
 def test_wide_generator_digits_special_scalars():
-    """fixed-base path (w = 8 Booth digits, magnitudes up to 128, sign bytes): pk = sk*G and R = r*G for scalars that hit
-    the digit extremes, against the C oracle"""
+    """fixed-base comb (11-bit Booth digits over the whole 256-bit scalar, magnitudes up to 1024; the 8-bit patterns of the previous
+    window size are kept): pk = sk*G and R = r*G for scalars that hit the digit extremes, against the C oracle"""
     rng = random.Random(21)
     lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
     ks = [1, 2, 127, 128, 129, 255, 256, 257, 0x8080, 0x7F7F, 0x80808080, 2**64 - 1, 2**127, 2**127 - 1, 2**127 + 1, 2**128 - 1, 2**128,
           lam, lam - 1, (128 * lam) % N, (N - 128) % N, N - 1, N - 2, (0x80 << 120), int("80" * 16, 16), int("7f" * 16, 16), int("ff" * 16, 16)]
+    w11 = [int("10000000000" * 23, 2), int("01111111111" * 23, 2), int("11111111111" * 23, 2), int("10000000001" * 23, 2), (1 << 253) + 1024, (1 << 255) + (1 << 252)]
+    ks += [1023, 1024, 1025, 2047, 2048, 2049, N - 1024, N - 1025] + [k % N for k in w11]
     ks += [rng.randrange(1, N) for _ in range(37)]
     n = len(ks)
     mb, off = OC.pack_msgs([b"w"] * n)
