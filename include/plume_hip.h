@@ -48,7 +48,7 @@ void plume_destroy(plume_ctx* ctx);
 const char* plume_last_error(void);
 /* Library / build information, e.g. "plume_hip 0.1 gfx950". */
 const char* plume_version(void);
-/* Upper bound on items processed per internal pass (workspace is ~6.7 KB per in-flight item). Default 1<<20. */
+/* Upper bound on items processed per internal pass (workspace is ~7.1 KB per in-flight item). Default 1<<20. */
 int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
 /* Host-pointer calls only: items per pipelined piece (default 1<<18, capped by the chunk size).  A call is cut into
  * pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (three streams, two staging slots), so

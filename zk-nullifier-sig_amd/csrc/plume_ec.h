@@ -203,7 +203,7 @@ PLUME_HD int booth_digit(const uint32_t m[4], int i) {
 // Booth recoding with a WIDE window for the generator's slots of the verifier: m = sum d_k 2^(W k), d_k in [-2^(W-1), 2^(W-1)].
 // W = PLUME_GW must be a multiple of 4 so that digit k lines up with the 4-bit window i = k * W/4 of the shared doubling chain.
 // W = 12: 11 digits per 128-bit half (22 generator additions per verify instead of 34 with W = 8) from a 2048-entry table
-// (224 KiB, L2-resident).
+// (256 KiB, L2-resident).
 #ifndef PLUME_GW
 #define PLUME_GW 12
 #endif
@@ -251,13 +251,16 @@ PLUME_HD void booth_store(int8_t* dig, uint32_t stride, const glv_half& h, bool 
 }
 
 // ------------------------------------------------------------------------------------------ window tables
-// One table = 8 entries x 28 words (112 B), entry e holds (e+1)*P affine as 29-bit limbs of tight field elements:
-//     [ x0..x7 | y0..y7 | b0..b7 | x8 y8 b8 0 ]        b = beta * x (the x of lambda*P)
-// i.e. seven 16-byte quads; one table addition gathers five of them (x or b, y, the top limbs) with aligned 16-byte loads.
+// One table = 8 rows x 32 words (128 B = one cache line), row e holds (e+1)*P affine as 29-bit limbs of tight field elements:
+//     [ x0..x7 | y0..y7 | b0..b7 | x8 y8 b8 0 | 0 0 0 0 ]        b = beta * x (the x of lambda*P)
+// i.e. eight 16-byte quads; one table addition gathers five of them (x or b, y, the top limbs) with aligned 16-byte loads from
+// ONE line, and the table kernel writes whole lines (112-byte rows, without the padding quad, measured 6 % slower there).
 #define PLUME_TAB_ENTRIES 8
 #define PLUME_FE_W PLUME_FE_WORDS
 #define PLUME_JAC_WORDS (3 * PLUME_FE_WORDS)      // Jacobian point in HBM scratch: x | y | z
-#define PLUME_TAB_ENTRY_WORDS 28
+#ifndef PLUME_TAB_ENTRY_WORDS
+#define PLUME_TAB_ENTRY_WORDS 32
+#endif
 #define PLUME_TAB_SCR_WORDS (4 * PLUME_FE_WORDS)  // pass-1 scratch per entry: X | Y | Z | running product
 #define PLUME_TAB_WORDS (PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 
@@ -271,6 +274,9 @@ PLUME_HD void ld_tab_xy(fe& x, fe& y, const uint32_t* e, bool lambda_half) {
 PLUME_HD void st_tab_entry(uint32_t* e, const fe& x, const fe& y, const fe& bx) {
     PLUME_UNROLL for (int i = 0; i < 8; i++) { e[i] = x.v[i]; e[8 + i] = y.v[i]; e[16 + i] = bx.v[i]; }
     e[24] = x.v[8]; e[25] = y.v[8]; e[26] = bx.v[8]; e[27] = 0;
+#if PLUME_TAB_ENTRY_WORDS == 32
+    e[28] = 0; e[29] = 0; e[30] = 0; e[31] = 0;     // padding quad: the row is written as a whole cache line
+#endif
 }
 PLUME_HD void ld_fe(fe& r, const uint32_t* p) { PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = p[i]; }
 PLUME_HD void st_fe(uint32_t* p, const fe& a) { PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) p[i] = a.v[i]; }
@@ -307,7 +313,7 @@ PLUME_HD uint32_t job_state(uint8_t f) { return f & 3u; }
 // inversion of the total product; pass 2 walks back, peels off each 1/Z_k, and writes the affine entry (x, y, beta*x) to `tab`.
 // scr is lane-interleaved: word w of the lane's q-th scratch entry lives at scr[(q * PLUME_TAB_SCR_WORDS + w) * sstride + slane],
 // so the 64 lanes of a wavefront (which walk their entries in lock step) touch 64 consecutive words per instruction -- the
-// pass-1 traffic (288 B per entry, written once and read once or twice) is fully coalesced; only the final 112-byte rows,
+// pass-1 traffic (288 B per entry, written once and read once or twice) is fully coalesced; only the final 128-byte rows,
 // which the multi-scalar kernel gathers per lane, are scattered.  A single-lane build passes sstride = 1, slane = 0.
 PLUME_HD void scr_st(uint32_t* scr, size_t sstride, size_t slane, size_t q, int f, const fe& a) {
     PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) scr[((q * PLUME_TAB_SCR_WORDS + (size_t)(f * PLUME_FE_W + i)) * sstride) + slane] = a.v[i];
@@ -406,7 +412,7 @@ PLUME_HD void normalize_points(uint32_t* pts, const uint8_t* inf, size_t npts, s
 
 // ------------------------------------------------------------------------------- fixed-base comb (generator only)
 // k*G with NO doublings: k = sum d_i 2^(W i) (Booth, d_i in [-2^(W-1), 2^(W-1)], i = 0..NW-1) and a precomputed table
-// comb[i][e] = (e+1) * 2^(W i) * G.  W = 11: 24 windows x 1024 entries (2.6 MiB, L2-resident), 24 mixed additions per
+// comb[i][e] = (e+1) * 2^(W i) * G.  W = 11: 24 windows x 1024 entries (3 MiB, L2-resident), 24 mixed additions per
 // multiplication (W = 8: 33 windows x 128 entries, 33 additions); used by the signer's pk = sk*G and R = r*G
 // (rust-k256/src/randomizedsigner.rs:51,53).
 #define PLUME_COMB_WINDOWS ((256 + PLUME_COMB_W) / PLUME_COMB_W)     // windows covering 257 bits
