@@ -129,6 +129,16 @@ def extras(eng, dev, n, b, signed_v1):
         dt = timed(lambda: eng.verify_batch_sec1_device(1, n, msgs, off, mbytes, c33["pk"], c33["nullifier"], cc, ss, c33["r_point"], c33["hashed_to_curve_r"], ok))
         assert bool(ok.all())
         out["verify_v1_sec1_compressed"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
+    # nullifier-set post-processing on the nullifiers just produced: first occurrences among 2^20 records, 1/16 of them
+    # made repeats of an earlier item; HBM view = 66 algorithmic bytes per item (64-byte record + live flag in, first flag out)
+    nul = o["nullifier"].clone()
+    nul[16::16] = nul[8::16][: nul[16::16].shape[0]]
+    first = torch.zeros(n, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    dt = timed(lambda: eng.nullifier_first_occurrence_device(n, nul, ok, None, first, cnt), reps=5)
+    assert int(cnt.item()) == n - (n - 1) // 16 and int(first.sum().item()) == int(cnt.item())
+    out["nullifier_first_occurrence"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "algorithmic_GBps": round(66 * n / dt / 1e9, 1),
+                                         "hbm_frac": round(66 * n / dt / 1e9 / HBM_PEAK_GBS, 4), "stage_ms": {k: round(v, 4) for k, v in eng.last_stage_times()}}
     return out
 
 

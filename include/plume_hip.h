@@ -98,6 +98,19 @@ int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n,
                               const uint8_t* msgs, const uint64_t* msg_off,
                               const uint8_t* pk, uint8_t* h_out);
 
+/* ---- nullifier-set post-processing: first occurrences   --------------------------------
+ * PLUME exists so that an application can accept ONE nullifier per (pk, message) (reference README.md:5; the field
+ * rust-k256/src/lib.rs:72-73); after verifying a batch the application has to find repeated nullifiers.
+ *   nullifier : n x 64 B (x||y big-endian, all-zero = identity), as passed to / produced by the calls above
+ *   live      : optional n bytes; 0 = the item takes no part (e.g. ok[i] == 0).  NULL = all items
+ *   ids       : optional n distinct 64-bit ids deciding which of several equal nullifiers is "first" (smallest id); NULL = the
+ *               position i.  Used when the arrays are one shard of a larger set (multi-GPU exchange)
+ *   first     : out, n bytes: 1 iff the item is live and no live item with the same 64-byte nullifier has a smaller id
+ *   n_unique  : out, optional: number of 1s in `first`
+ * Deterministic whatever the execution order.  n <= 2^30. */
+int plume_nullifier_first_occurrence(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live,
+                                     const uint64_t* ids, uint8_t* first, uint64_t* n_unique);
+
 /* ---- device-resident forms -------------------------------------------------------------------------------
  * Same semantics, but every data pointer is a DEVICE pointer on the context's GPU and the work is enqueued on
  * `stream` (a hipStream_t passed as void*; NULL = the context's own stream) without synchronising: the caller
@@ -121,6 +134,9 @@ int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n,
 int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n,
                                      const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                      const uint8_t* pk, uint8_t* h_out, void* stream);
+/* n_unique, when not NULL, is a DEVICE pointer to one uint64_t */
+int plume_nullifier_first_occurrence_device(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live,
+                                            const uint64_t* ids, uint8_t* first, uint64_t* n_unique, void* stream);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------------------
  * Per-stage device time of the most recent *_device call on this context, measured with HIP events recorded on

@@ -330,3 +330,24 @@ def pt_from_bytes(b: bytes) -> Point:
     if b == bytes(64):
         return None
     return (int.from_bytes(b[:32], "big"), int.from_bytes(b[32:], "big"))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Nullifier-set post-processing.  The reference has no such function: PLUME's stated purpose is one
+# nullifier per (pk, message) (README.md:5), and this is the check its consumers run on a verified batch.  Plain definition:
+def nullifier_first_occurrence(nullifiers, live=None, ids=None):
+    """nullifiers: sequence of 64-byte records; live: optional sequence of truthy/falsy; ids: optional distinct integers (default
+    position).  Returns (first flags list, count): first[i] = live[i] and no live j with the same record and a smaller id."""
+    n = len(nullifiers)
+    best = {}
+    for i in range(n):
+        if live is not None and not live[i]:
+            continue
+        key = bytes(nullifiers[i])
+        ident = i if ids is None else int(ids[i])
+        if key not in best or ident < best[key][0]:
+            best[key] = (ident, i)
+    first = [0] * n
+    for ident, i in best.values():
+        first[i] = 1
+    return first, len(best)

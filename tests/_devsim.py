@@ -139,3 +139,16 @@ def fallback_count():
     """multi-scalar chains redone with checked additions so far (p == +-q met inside an unchecked chain)"""
     lib().ds_fallback_count.restype = C.c_ulong
     return int(lib().ds_fallback_count())
+
+
+def nullifier_first_occurrence(nul, live=None, ids=None, order=None):
+    nul = np.ascontiguousarray(nul, dtype=np.uint8).reshape(-1, 64)
+    n = len(nul)
+    buf = _aligned(nul)
+    first = np.zeros(n, dtype=np.uint8)
+    cnt = C.c_uint64(0)
+    live = None if live is None else np.ascontiguousarray(live, dtype=np.uint8)
+    ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+    order = None if order is None else np.ascontiguousarray(order, dtype=np.uint32)
+    lib().ds_nullifier_first_occurrence(C.c_uint32(n), _p(buf), _p(live), _p(ids, u64p), _p(order, u32p), _p(first), C.byref(cnt))
+    return first, int(cnt.value)

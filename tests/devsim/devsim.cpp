@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "plume_stages.h"
+#include "plume_dedup.h"
 
 using namespace plume;
 
@@ -250,5 +251,22 @@ int ds_point_mul(const uint8_t k_be[32], const uint8_t p_be[64], uint8_t out[64]
     store_affine_be(ob, ox, oy, acc.inf != 0);
     memcpy(out, ob, 64);
     return 1;
+}
+
+// nullifier-set post-processing through the per-lane bodies (lanes run one after another; order = `order`, to show the result does not depend on it)
+int ds_nullifier_first_occurrence(uint32_t n, const uint8_t* nul, const uint8_t* live, const uint64_t* ids, const uint32_t* order, uint8_t* first, uint64_t* n_unique) {
+    DedupArgs a;
+    a.n = n; a.nul = nul; a.live = live; a.ids = ids; a.first = first;
+    const uint32_t m = dedup_table_size(n);
+    a.mask = m - 1;
+    std::vector<uint32_t> slots(m), myslot(n ? n : 1);
+    std::vector<unsigned long long> minid(m);
+    unsigned long long cnt = 0;
+    a.slots = slots.data(); a.minid = minid.data(); a.myslot = myslot.data(); a.n_unique = &cnt;
+    for (uint32_t s2 = 0; s2 < m; s2++) dedup_clear(a, s2);
+    for (uint32_t k = 0; k < n; k++) dedup_insert(a, order ? order[k] : k);
+    for (uint32_t i = 0; i < n; i++) cnt += dedup_mark(a, i) ? 1 : 0;
+    if (n_unique) *n_unique = cnt;
+    return 0;
 }
 }

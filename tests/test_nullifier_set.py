@@ -1,0 +1,169 @@
+"""Nullifier-set post-processing: first-occurrence marking.
+CPU part: the definition (oracle), the device code on the host (tests/devsim), and the sharded exchange over gloo with a stand-in
+engine that answers with the oracle.  GPU part: the C ABI against the oracle."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import plume_oracle as O
+from tests import _devsim as D
+
+
+def make_set(n, seed, dup_every=7, dead_every=11):
+    """n 64-byte records with planted repeats (also of dead items, of the identity, and triple repeats) + live flags"""
+    rng = random.Random(seed)
+    recs = [bytes(rng.randrange(256) for _ in range(64)) for _ in range(n)]
+    for i in range(1, n):
+        if i % dup_every == 0:
+            recs[i] = recs[rng.randrange(0, i)]                 # repeat of an earlier record
+        if i % 97 == 5:
+            recs[i] = bytes(64)                                 # the identity, several times
+        if i % 131 == 3 and i > 2:
+            recs[i] = recs[i - 1][:63] + bytes([recs[i - 1][63] ^ 1])   # differs in the last byte only
+    live = np.array([0 if (i % dead_every == 4) else 1 for i in range(n)], dtype=np.uint8)
+    return np.frombuffer(b"".join(recs), dtype=np.uint8).reshape(n, 64).copy(), live
+
+
+def test_oracle_definition():
+    a, b, c = bytes([1]) * 64, bytes([2]) * 64, bytes(64)
+    recs = [a, b, a, c, c, b, a]
+    assert O.nullifier_first_occurrence(recs) == ([1, 1, 0, 1, 0, 0, 0], 3)
+    assert O.nullifier_first_occurrence(recs, live=[0, 1, 1, 0, 1, 1, 1]) == ([0, 1, 1, 0, 1, 0, 0], 3)
+    assert O.nullifier_first_occurrence(recs, ids=[9, 8, 7, 6, 5, 4, 3]) == ([0, 0, 0, 0, 1, 1, 1], 3)
+    assert O.nullifier_first_occurrence([]) == ([], 0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 5000])
+def test_device_code_on_host_matches_definition(n):
+    nul, live = make_set(n, seed=n)
+    want = O.nullifier_first_occurrence([bytes(r) for r in nul], live)
+    got = D.nullifier_first_occurrence(nul, live)
+    assert (list(got[0]), got[1]) == want
+    # no live mask, and an execution order that is not the index order: same answer (smallest id wins, not first to arrive)
+    want = O.nullifier_first_occurrence([bytes(r) for r in nul])
+    order = np.random.default_rng(n).permutation(n).astype(np.uint32)
+    got = D.nullifier_first_occurrence(nul, None, None, order)
+    assert (list(got[0]), got[1]) == want
+    # caller-supplied ids reverse the preference
+    ids = (np.arange(n, dtype=np.uint64)[::-1] + 1000).copy()
+    want = O.nullifier_first_occurrence([bytes(r) for r in nul], live, ids)
+    got = D.nullifier_first_occurrence(nul, live, ids, order)
+    assert (list(got[0]), got[1]) == want
+
+
+def test_colliding_hashes_stay_correct():
+    """all records fall into a handful of table slots when the table is tiny; the probe sequence must still separate them"""
+    n = 40
+    nul = np.zeros((n, 64), dtype=np.uint8)
+    for i in range(n):
+        nul[i, 0] = i // 2          # pairs of equal records
+    got = D.nullifier_first_occurrence(nul)
+    assert list(got[0]) == [1, 0] * (n // 2) and got[1] == n // 2
+
+
+# ------------------------------------------------------------------------------------------ sharded form over gloo (CPU)
+class OracleEngine:
+    """stand-in for zk_nullifier_sig_amd.Engine in the CPU test of the exchange logic (test infrastructure: answers with the oracle)"""
+    def nullifier_first_occurrence_device(self, n, nullifier, live, ids, first, n_unique=None, stream=None):
+        recs = [bytes(r) for r in nullifier.numpy().reshape(n, 64)]
+        f, c = O.nullifier_first_occurrence(recs, None if live is None else live.numpy().tolist(), None if ids is None else ids.numpy().tolist())
+        import torch
+        first.copy_(torch.tensor(f, dtype=torch.uint8))
+        if n_unique is not None:
+            n_unique.fill_(c)
+
+
+def _worker(rank, world, port, total, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import zk_nullifier_sig_amd.nullifier_set as NS
+        nul, live = make_set(total, seed=4242)
+        lo, hi = (total * rank) // world, (total * (rank + 1)) // world          # the same contiguous split bench.py uses
+        first, cnt = NS.distributed_first_occurrence(torch.from_numpy(nul[lo:hi].copy()), torch.from_numpy(live[lo:hi].copy()), OracleEngine())
+        out[rank] = (first.numpy().tolist(), cnt)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_exchange_matches_global_definition(world):
+    import torch.multiprocessing as mp
+    total = 3000
+    nul, live = make_set(total, seed=4242)
+    want, want_cnt = O.nullifier_first_occurrence([bytes(r) for r in nul], live)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, 29650 + world, total, out), nprocs=world, join=True)
+        got = []
+        for r in range(world):
+            f, c = out[r]
+            assert c == want_cnt
+            got += f
+    assert got == want
+
+
+# ------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 65, 4096, 1 << 17])
+def test_gpu_first_occurrence_matches_definition(n):
+    import zk_nullifier_sig_amd as plume
+    eng = plume.default_engine()
+    nul, live = make_set(n, seed=7 * n + 1)
+    recs = [bytes(r) for r in nul]
+    for lv in (live, None):
+        want = O.nullifier_first_occurrence(recs, lv)
+        first, cnt = eng.nullifier_first_occurrence(nul, lv)
+        assert (first.tolist(), cnt) == want
+    ids = (np.arange(n, dtype=np.uint64)[::-1] + (1 << 40)).copy()
+    want = O.nullifier_first_occurrence(recs, live, ids)
+    first, cnt = eng.nullifier_first_occurrence(nul, live, ids)
+    assert (first.tolist(), cnt) == want
+    assert eng.nullifier_first_occurrence(np.zeros((0, 64), dtype=np.uint8)) [1] == 0
+
+
+@pytest.mark.gpu
+def test_gpu_first_occurrence_on_real_nullifiers():
+    """signed batch with repeated (sk, message) pairs: repeats share a nullifier, everything else is distinct"""
+    import zk_nullifier_sig_amd as plume
+    from tests import synth
+    eng = plume.default_engine()
+    n = 4096
+    b = synth.sign_inputs(n)
+    for i in range(0, n, 8):                 # item i+1 repeats item i's key and message (fresh nonce r)
+        b["sk"][i + 1] = b["sk"][i]
+        b["msgs"][32 * (i + 1):32 * (i + 2)] = b["msgs"][32 * i:32 * (i + 1)]
+    signed = eng.sign_batch(2, b["msgs"], b["off"], b["sk"], b["r"])
+    first, cnt = eng.nullifier_first_occurrence(signed["nullifier"])
+    want = np.ones(n, dtype=np.uint8)
+    want[1::8] = 0
+    assert np.array_equal(first, want) and cnt == n - n // 8
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_form_single_rank_rccl():
+    """the sharded code path with the real engine and RCCL (world size 1 on the one GPU of the test box): same answer as the direct call"""
+    import torch
+    import torch.distributed as dist
+    import zk_nullifier_sig_amd as plume
+    import zk_nullifier_sig_amd.nullifier_set as NS
+    eng = plume.default_engine()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29671")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        n = 20000
+        nul, live = make_set(n, seed=99)
+        want = O.nullifier_first_occurrence([bytes(r) for r in nul], live)
+        first, cnt = NS.distributed_first_occurrence(torch.from_numpy(nul).cuda(), torch.from_numpy(live).cuda(), eng)
+        assert (first.cpu().numpy().tolist(), cnt) == want
+    finally:
+        if created:
+            dist.destroy_process_group()

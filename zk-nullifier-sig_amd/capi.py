@@ -60,6 +60,8 @@ def _load():
     lib.plume_verify_batch_sec1.argtypes = [vp, i, sz] + [vp] * 9
     lib.plume_verify_batch_sec1_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 8
     lib.plume_sign_batch.argtypes = [vp, i, sz] + [vp] * 12
+    lib.plume_nullifier_first_occurrence.argtypes = [vp, sz, vp, vp, vp, vp, C.POINTER(C.c_uint64)]
+    lib.plume_nullifier_first_occurrence_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
     lib.plume_hash_to_curve_batch.argtypes = [vp, sz] + [vp] * 4
     lib.plume_verify_batch_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 8
     lib.plume_sign_batch_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 11
@@ -71,7 +73,7 @@ def _load():
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
     return ["plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch",
-            "plume_hash_to_curve_batch", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
+            "plume_hash_to_curve_batch", "plume_nullifier_first_occurrence", "plume_nullifier_first_occurrence_device", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
             "plume_last_stage_times", "plume_microbench", "plume_microbench_last_ticks"]
 
 
@@ -193,6 +195,19 @@ class Engine:
         self._chk(self._lib.plume_hash_to_curve_batch(self._ctx, n, _ptr(msgs), _ptr(msg_off), _ptr(pk), _ptr(h)), "plume_hash_to_curve_batch")
         return h
 
+    def nullifier_first_occurrence(self, nullifier, live=None, ids=None):
+        """first[i] = 1 iff item i is live and holds the smallest id (default: position) among the live items with the same 64-byte
+        nullifier; returns (first uint8[n], number of ones)"""
+        nullifier = np.ascontiguousarray(nullifier, dtype=np.uint8).reshape(-1, 64)
+        n = len(nullifier)
+        live = None if live is None else np.ascontiguousarray(live, dtype=np.uint8).reshape(n)
+        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64).reshape(n)
+        first = np.zeros(n, dtype=np.uint8)
+        cnt = C.c_uint64(0)
+        self._chk(self._lib.plume_nullifier_first_occurrence(self._ctx, n, _ptr(nullifier), _ptr(live), _ptr(ids), _ptr(first), C.byref(cnt)),
+                  "plume_nullifier_first_occurrence")
+        return first, int(cnt.value)
+
     # ------------------------------------------------------------------ device-resident API (torch uint8 tensors on this GPU)
     @staticmethod
     def _dp(t):
@@ -220,6 +235,14 @@ class Engine:
         self._chk(self._lib.plume_sign_batch_device(self._ctx, int(version), int(n), d(msgs), d(msg_off), int(msgs_bytes), d(sk), d(r), d(pk_in), d(pk),
                                                     d(nullifier), d(c), d(s), d(r_point), d(hashed_to_curve_r), d(status), C.c_void_p(st)),
                   "plume_sign_batch_device")
+
+    def nullifier_first_occurrence_device(self, n, nullifier, live, ids, first, n_unique=None, stream=None):
+        """tensors on cuda:<device_id> (nullifier n x 64 uint8, live / first uint8[n] or None, ids int64/uint64[n] or None, n_unique one 64-bit word or None)"""
+        import torch
+        st = (stream or torch.cuda.current_stream(self.device_id)).cuda_stream
+        d = self._dp
+        self._chk(self._lib.plume_nullifier_first_occurrence_device(self._ctx, int(n), d(nullifier), d(live), d(ids), d(first), d(n_unique), C.c_void_p(st)),
+                  "plume_nullifier_first_occurrence_device")
 
     # ------------------------------------------------------------------ measurement
     def last_stage_times(self):

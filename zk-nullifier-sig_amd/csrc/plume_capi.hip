@@ -68,7 +68,8 @@ struct plume_ctx {
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
     DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink;
-    DevBuf dec[4], preflags;   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
+    DevBuf dec[4], preflags;
+    DevBuf dslots, dminid, dmyslot, dcount;   // nullifier-set post-processing (plume_dedup.h)   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
     StageTimer timer;
 };
 
@@ -132,7 +133,7 @@ extern "C" void plume_destroy(plume_ctx* ctx) {
     if (ctx->up) (void)hipStreamSynchronize(ctx->up);
     if (ctx->down) (void)hipStreamSynchronize(ctx->down);
     for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
-                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags})
+                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount})
         b->release();
     for (HostSlot& sl : ctx->slot) {
         sl.msgs.release(); sl.off.release();
@@ -298,6 +299,52 @@ extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const 
     ctx->timer.begin(st);
     launch_h2c_only(a, st); ctx->timer.stage("h2c_only", st);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ nullifier-set post-processing
+static int dedup_device(plume_ctx* ctx, size_t n, const uint8_t* nul, const uint8_t* live, const uint64_t* ids, uint8_t* first, uint64_t* n_unique_dev, hipStream_t st) {
+    if (n == 0) { if (n_unique_dev) HIPCHK(hipMemsetAsync(n_unique_dev, 0, 8, st)); return 0; }
+    if (n > ((size_t)1 << 30)) return fail(PLUME_ERR_ARG, "n too large");
+    DedupArgs a;
+    a.n = (uint32_t)n; a.nul = nul; a.live = live; a.ids = ids; a.first = first;
+    const uint32_t m = dedup_table_size(a.n);
+    a.mask = m - 1;
+    if (ctx->dslots.ensure((size_t)m * 4) || ctx->dminid.ensure((size_t)m * 8) || ctx->dmyslot.ensure(n * 4) || ctx->dcount.ensure(8)) return PLUME_ERR_HIP;
+    a.slots = ctx->dslots.as<uint32_t>(); a.minid = ctx->dminid.as<unsigned long long>(); a.myslot = ctx->dmyslot.as<uint32_t>();
+    a.n_unique = ctx->dcount.as<unsigned long long>();
+    ctx->timer.begin(st);
+    launch_dedup(a, st); ctx->timer.stage("nullifier_first_occurrence", st);
+    HIPCHK(hipGetLastError());
+    if (n_unique_dev) HIPCHK(hipMemcpyAsync(n_unique_dev, ctx->dcount.p, 8, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+extern "C" int plume_nullifier_first_occurrence_device(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live, const uint64_t* ids, uint8_t* first,
+                                                       uint64_t* n_unique, void* stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!nullifier || !first)) return fail(PLUME_ERR_ARG, "null array");
+    return dedup_device(ctx, n, nullifier, live, ids, first, n_unique, stream ? (hipStream_t)stream : ctx->stream);
+}
+// host-pointer form: one pass (every record has to be resident to be compared), staged through slot 0
+extern "C" int plume_nullifier_first_occurrence(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live, const uint64_t* ids, uint8_t* first,
+                                                uint64_t* n_unique) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!nullifier || !first)) return fail(PLUME_ERR_ARG, "null array");
+    if (n == 0) { if (n_unique) *n_unique = 0; return 0; }
+    HostSlot& sl = ctx->slot[0];
+    hipStream_t st = ctx->stream;
+    if (sl.in[0].ensure(64 * n) || sl.in[1].ensure(n) || sl.in[2].ensure(8 * n) || sl.out[0].ensure(n) || sl.out[1].ensure(8)) return PLUME_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(sl.in[0].p, nullifier, 64 * n, hipMemcpyHostToDevice, st));
+    if (live) HIPCHK(hipMemcpyAsync(sl.in[1].p, live, n, hipMemcpyHostToDevice, st));
+    if (ids) HIPCHK(hipMemcpyAsync(sl.in[2].p, ids, 8 * n, hipMemcpyHostToDevice, st));
+    if (int rc = dedup_device(ctx, n, sl.in[0].as<uint8_t>(), live ? sl.in[1].as<uint8_t>() : nullptr, ids ? sl.in[2].as<uint64_t>() : nullptr, sl.out[0].as<uint8_t>(),
+                              sl.out[1].as<uint64_t>(), st))
+        return rc;
+    HIPCHK(hipMemcpyAsync(first, sl.out[0].p, n, hipMemcpyDeviceToHost, st));
+    uint64_t cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, sl.out[1].p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_unique) *n_unique = cnt;
     return 0;
 }
 

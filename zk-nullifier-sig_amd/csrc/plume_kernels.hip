@@ -9,6 +9,7 @@
 // more than LDS can hold at any useful occupancy, and their traffic (~17 KiB per verify) is negligible next to
 // the ~10^6 VALU instructions per item.
 #include "plume_launch.h"
+#include "plume_dedup.h"
 
 // Minimum waves per SIMD the register allocator must leave room for (HIP's second __launch_bounds__ argument).  The
 // instruction-rate probe (tests/gpu_debug/instr_rates_r01.txt) shows the VALU saturates at 4 waves per SIMD and loses
@@ -163,6 +164,22 @@ __global__ PLUME_H2C_BOUNDS void k_h2c_only(H2cArgs a) {
     if (i < a.n) h2c_only(a, i);
 }
 
+// ------------------------------------------------------------------------------ nullifier-set post-processing
+__global__ __launch_bounds__(kBlock) void k_dedup_clear(DedupArgs a) {
+    uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    if (s <= a.mask) dedup_clear(a, s);
+}
+__global__ __launch_bounds__(kBlock) void k_dedup_insert(DedupArgs a) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < a.n) dedup_insert(a, i);
+}
+__global__ __launch_bounds__(kBlock) void k_dedup_mark(DedupArgs a) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool f = i < a.n ? dedup_mark(a, i) : false;
+    const unsigned long long b = __ballot(f);
+    if ((threadIdx.x & 63u) == 0 && b) atomicAdd(a.n_unique, (unsigned long long)__popcll(b));
+}
+
 // ------------------------------------------------------------------------------------------ microbenchmarks
 // Issue-rate probes for the roofline: 8 independent accumulator chains per lane, written in inline asm so that the
 // instruction under test is exactly what is counted (VALU->VALU dependencies are interlocked in hardware; the
@@ -260,6 +277,11 @@ void launch_decompress(const DecompressArgs& a, hipStream_t st) { hipLaunchKerne
 void launch_h2c_only(const H2cArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_only, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gtab8, dim3(1), dim3(64), 0, st, gtab8, base_g, flag, scr); }
 void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gcomb, dim3(1), dim3(64), 0, st, comb, bases, flags, scr); }
+void launch_dedup(const DedupArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_dedup_clear, dim3(nblocks((size_t)a.mask + 1)), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(k_dedup_insert, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(k_dedup_mark, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a);
+}
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_microbench, dim3(blocks), dim3(kBlock), 0, st, kind, iters, sink);
 }

@@ -21,3 +21,4 @@ from .plume import (  # noqa: E402,F401
     sign,
     sign_with_r,
 )
+from . import nullifier_set  # noqa: E402,F401
