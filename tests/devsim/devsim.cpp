@@ -262,7 +262,7 @@ int ds_nullifier_first_occurrence(uint32_t n, const uint8_t* nul, const uint8_t*
     std::vector<uint32_t> slots(m), myslot(n ? n : 1);
     std::vector<unsigned long long> minid(m);
     unsigned long long cnt = 0;
-    a.slots = slots.data(); a.minid = minid.data(); a.myslot = myslot.data(); a.n_unique = &cnt;
+    a.slots = slots.data(); a.minid = minid.data(); a.myslot = myslot.data(); a.n_unique = &cnt; a.blockcnt = nullptr;
     for (uint32_t s2 = 0; s2 < m; s2++) dedup_clear(a, s2);
     for (uint32_t k = 0; k < n; k++) dedup_insert(a, order ? order[k] : k);
     for (uint32_t i = 0; i < n; i++) cnt += dedup_mark(a, i) ? 1 : 0;

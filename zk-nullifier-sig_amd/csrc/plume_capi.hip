@@ -69,7 +69,7 @@ struct plume_ctx {
     bool jobs_per_lane_forced = false;
     DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink;
     DevBuf dec[4], preflags;
-    DevBuf dslots, dminid, dmyslot, dcount;   // nullifier-set post-processing (plume_dedup.h)   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
+    DevBuf dslots, dminid, dmyslot, dcount, dblockcnt;   // nullifier-set post-processing (plume_dedup.h)   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
     StageTimer timer;
 };
 
@@ -133,7 +133,7 @@ extern "C" void plume_destroy(plume_ctx* ctx) {
     if (ctx->up) (void)hipStreamSynchronize(ctx->up);
     if (ctx->down) (void)hipStreamSynchronize(ctx->down);
     for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
-                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount})
+                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
     for (HostSlot& sl : ctx->slot) {
         sl.msgs.release(); sl.off.release();
@@ -310,9 +310,9 @@ static int dedup_device(plume_ctx* ctx, size_t n, const uint8_t* nul, const uint
     a.n = (uint32_t)n; a.nul = nul; a.live = live; a.ids = ids; a.first = first;
     const uint32_t m = dedup_table_size(a.n);
     a.mask = m - 1;
-    if (ctx->dslots.ensure((size_t)m * 4) || ctx->dminid.ensure((size_t)m * 8) || ctx->dmyslot.ensure(n * 4) || ctx->dcount.ensure(8)) return PLUME_ERR_HIP;
+    if (ctx->dslots.ensure((size_t)m * 4) || ctx->dminid.ensure((size_t)m * 8) || ctx->dmyslot.ensure(n * 4) || ctx->dcount.ensure(8) || ctx->dblockcnt.ensure(dedup_blockcnt_bytes(n))) return PLUME_ERR_HIP;
     a.slots = ctx->dslots.as<uint32_t>(); a.minid = ctx->dminid.as<unsigned long long>(); a.myslot = ctx->dmyslot.as<uint32_t>();
-    a.n_unique = ctx->dcount.as<unsigned long long>();
+    a.n_unique = ctx->dcount.as<unsigned long long>(); a.blockcnt = ctx->dblockcnt.as<uint32_t>();
     ctx->timer.begin(st);
     launch_dedup(a, st); ctx->timer.stage("nullifier_first_occurrence", st);
     HIPCHK(hipGetLastError());

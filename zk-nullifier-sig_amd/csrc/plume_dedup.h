@@ -25,7 +25,9 @@ struct DedupArgs {
     const uint8_t* live;             // optional, n bytes: 0 = the item does not take part (e.g. it failed verification)
     const uint64_t* ids;             // optional, n global ids (distinct); NULL: id = position
     uint8_t* first;                  // out, n bytes
-    unsigned long long* n_unique;    // out (device counter, zeroed by dedup_clear): number of first occurrences
+    unsigned long long* n_unique;    // out (device word): number of first occurrences
+    uint32_t* blockcnt;              // scratch: first occurrences per workgroup of the mark kernel (summed by one small kernel:
+                                     // 16384 wavefronts adding to ONE counter serialise in L2 -- measured 0.2 ms of a 0.33 ms stage)
     // scratch
     uint32_t* slots;                 // mask+1 entries: index of the item that claimed the slot, or PLUME_DEDUP_EMPTY
     unsigned long long* minid;       // mask+1 entries: smallest id among the items sharing the slot
@@ -68,7 +70,6 @@ PLUME_HD void plume_host_min_u64(unsigned long long* p, unsigned long long v) { 
 PLUME_HD void dedup_clear(const DedupArgs& a, uint32_t slot) {
     a.slots[slot] = PLUME_DEDUP_EMPTY;
     a.minid[slot] = ~0ull;
-    if (slot == 0) *a.n_unique = 0;
 }
 PLUME_HD void dedup_insert(const DedupArgs& a, uint32_t i) {
     if (a.live && !a.live[i]) return;
@@ -92,7 +93,7 @@ PLUME_HD void dedup_insert(const DedupArgs& a, uint32_t i) {
     PLUME_ATOMIC_MIN_U64(&a.minid[h], a.ids ? (unsigned long long)a.ids[i] : (unsigned long long)i);
     a.myslot[i] = h;
 }
-// returns the flag; the caller (kernel: wave ballot, host: plain sum) accumulates n_unique
+// returns the flag; the caller (kernel: workgroup reduction into blockcnt, host: plain sum) accumulates n_unique
 PLUME_HD bool dedup_mark(const DedupArgs& a, uint32_t i) {
     bool f = false;
     if (!a.live || a.live[i]) f = a.minid[a.myslot[i]] == (a.ids ? (unsigned long long)a.ids[i] : (unsigned long long)i);

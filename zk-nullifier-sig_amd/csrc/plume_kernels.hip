@@ -174,10 +174,30 @@ __global__ __launch_bounds__(kBlock) void k_dedup_insert(DedupArgs a) {
     if (i < a.n) dedup_insert(a, i);
 }
 __global__ __launch_bounds__(kBlock) void k_dedup_mark(DedupArgs a) {
+    __shared__ uint32_t s_cnt[kBlock / 64];
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const bool f = i < a.n ? dedup_mark(a, i) : false;
     const unsigned long long b = __ballot(f);
-    if ((threadIdx.x & 63u) == 0 && b) atomicAdd(a.n_unique, (unsigned long long)__popcll(b));
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0;
+        for (int w = 0; w < kBlock / 64; w++) c += s_cnt[w];
+        a.blockcnt[blockIdx.x] = c;
+    }
+}
+// one workgroup: n_unique = sum of the per-workgroup counts
+__global__ __launch_bounds__(kBlock) void k_dedup_sum(DedupArgs a, uint32_t nb) {
+    __shared__ unsigned long long s_sum[kBlock];
+    unsigned long long c = 0;
+    for (uint32_t k = threadIdx.x; k < nb; k += kBlock) c += a.blockcnt[k];
+    s_sum[threadIdx.x] = c;
+    __syncthreads();
+    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) s_sum[threadIdx.x] += s_sum[threadIdx.x + stride];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *a.n_unique = s_sum[0];
 }
 
 // ------------------------------------------------------------------------------------------ microbenchmarks
@@ -281,7 +301,9 @@ void launch_dedup(const DedupArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_dedup_clear, dim3(nblocks((size_t)a.mask + 1)), dim3(kBlock), 0, st, a);
     hipLaunchKernelGGL(k_dedup_insert, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a);
     hipLaunchKernelGGL(k_dedup_mark, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL(k_dedup_sum, dim3(1), dim3(kBlock), 0, st, a, (uint32_t)nblocks(a.n));
 }
+size_t dedup_blockcnt_bytes(size_t n) { return (size_t)nblocks(n) * 4; }
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_microbench, dim3(blocks), dim3(kBlock), 0, st, kind, iters, sink);
 }
