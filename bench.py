@@ -34,6 +34,7 @@ FPMUL_PER_ITEM = {1: 5460, 2: 5460}               # accounting algorithm, whole 
 FPMUL_MSM_PER_ITEM = 1900 + 2260                  # the two double-base multiplications (dominant kernel)
 MACS_PER_FPMUL = 72
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s spec
+MAD_PEAK_REF = 3.5e13                             # v_mad_u64_u32 lane-ops/s: 1024 SIMDs x 64 lanes / 1.83 ns (tests/gpu_debug/instr_rates_r01.txt)
 
 
 def parse():
@@ -250,7 +251,12 @@ def main():
                 step_s = sum(stages.values()) * 1e-3
                 whole = FPMUL_PER_ITEM[ver] * MACS_PER_FPMUL * n / step_s
                 msm = FPMUL_MSM_PER_ITEM * MACS_PER_FPMUL * n / (stages.get("verify_msm", step_s * 1e3) * 1e-3)
-                line["valu_roofline"] = {"bound": "int-valu", "unit": "32-bit MAC/s", "peak_v_mad_u64_u32": round(mad_rate, 1), "peak_v_add_u32": round(add_rate, 1),
+                # some boxes of the pool throttle a pure multiply-add stream (a power virus) far below what the real kernels sustain: the
+                # roof is the larger of this run's measurement and the reference rate, so a throttled probe cannot inflate the fraction
+                mad_measured = mad_rate
+                mad_rate = max(mad_rate, MAD_PEAK_REF)
+                line["valu_roofline"] = {"bound": "int-valu", "unit": "32-bit MAC/s", "peak_v_mad_u64_u32": round(mad_rate, 1), "peak_v_mad_u64_u32_measured_this_run": round(mad_measured, 1),
+                                         "peak_v_add_u32": round(add_rate, 1),
                                          "fp_mul_per_s": round(fpmul_rate, 1), "fp_sqr_per_s": round(fpsqr_rate, 1), "other_issue_rates_per_s": other,
                                          "achieved_whole_path": round(whole, 1), "frac_whole_path": round(whole / mad_rate, 4),
                                          "achieved_msm_kernel": round(msm, 1), "frac_msm_kernel": round(msm / mad_rate, 4),

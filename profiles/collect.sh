@@ -8,7 +8,7 @@ R=${1:-r01}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python3 bench.py > gpurun_out/bench_$R.log 2> gpurun_out/bench_$R.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/bench_${R}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_${R}_prof.log 2>&1
 for spec in "sq:SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
             "sq2:SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY" \
             "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
