@@ -39,7 +39,7 @@ def col_terms(k, sqr, pair=("a", "b")):
 A_CONS = "v"   # constraint of the a.v[i] operands: "s" in fe_mul_k (a is a wave-uniform constant held in SGPRs)
 
 
-def emit_chain(terms, indent="    "):
+def emit_chain(terms, indent="    ", acc="acc"):
     regs = []
 
     def idx(name, cons):
@@ -54,62 +54,78 @@ def emit_chain(terms, indent="    "):
         lines.append(f"v_mad_u64_u32 %0, %1, %{idx(x, xc)}, %{idx(y, 's' if ys else 'v')}, %0")
     body = "\\n\\t".join(lines)
     ins = ", ".join(f'"{c}"({n})' for (n, c) in regs)
-    host = " ".join(f"acc += (uint64_t){x} * {y};" for (x, y, ys) in terms)
-    return (f"{indent}PLUME_FE_CHAIN(\"{body}\", {ins});\n", f"{indent}{host}\n")
+    host = " ".join(f"{acc} += (uint64_t){x} * {y};" for (x, y, ys) in terms)
+    return (f"{indent}PLUME_FE_CHAIN({acc}, \"{body}\", {ins});\n", f"{indent}{host}\n")
 
 
 def gen(name, sqr, two=False):
-    """two: r = a*b + c*d with ONE fold -- the two products share their column sums (each column: two chain statements)"""
+    """two: r = a*b + c*d with ONE fold -- the two products share their column sums (each column: two chain statements).
+
+    Statement order: the high-half chain (columns 9..16, accumulator acch) and the low-half chain (columns 0..8, accumulator acc)
+    are INTERLEAVED, the low half lagging by two columns (column k needs h[k] and h[k-1]): every asm statement is followed by an
+    independent one, so the mask / shift that reads its result is no longer the very next instruction and hipcc does not have to
+    pad with s_nop (it places one after every inline-asm statement whose result the next instruction reads)."""
     dev, host = [], []
 
     def both(s):
         dev.append(s)
         host.append(s)
 
-    both("    uint32_t h[9], l[9];     // l: result limbs (r may alias a or b)\n    uint64_t acc = 0;\n")
-    if sqr:
-        both("    uint32_t d[9];\n    PLUME_UNROLL for (int i = 0; i < 9; i++) d[i] = a.v[i] + a.v[i];\n")
-    for k in range(9, 17):
-        d, h = emit_chain([(x, y, False) for (x, y) in col_terms(k, sqr)])
-        dev.append(d)
-        host.append(h)
+    def stmts_high(k):
+        out = [emit_chain([(x, y, False) for (x, y) in col_terms(k, sqr)], acc="acch")]
         if two:
-            d, h = emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))])
-            dev.append(d)
-            host.append(h)
+            out.append(emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))], acc="acch"))
+        return out
+
+    def mask_high(k):
         if k < 16:
-            both(f"    h[{k - 9}] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;\n")
-        else:
-            both("    h[7] = (uint32_t)acc & PLUME_FE_MASK; h[8] = (uint32_t)(acc >> 29);\n    PLUME_FE_ASSERT((acc >> 29) < (1ull << 27));\n    acc = 0;\n")
-    for k in range(9):
+            return f"    h[{k - 9}] = (uint32_t)acch & PLUME_FE_MASK; acch >>= 29;\n"
+        return "    h[7] = (uint32_t)acch & PLUME_FE_MASK; h[8] = (uint32_t)(acch >> 29);\n    PLUME_FE_ASSERT((acch >> 29) < (1ull << 27));\n"
+
+    def stmts_low(k):
+        out = []
         if two:
-            d, h = emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))])
-            dev.append(d)
-            host.append(h)
+            out.append(emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))]))
         t = [(x, y, False) for (x, y) in col_terms(k, sqr)]
         t.append((f"h[{k}]", "K0", True))
         if k > 0:
             t.append((f"h[{k - 1}]", "K1", True))
-        if k == 0:
-            t.append(("h[8]", "K2", True))
-        if k == 1:
-            t.append(("h[8]", "K3", True))
-        d, h = emit_chain(t)
-        dev.append(d)
-        host.append(h)
-        if k < 8:
-            both(f"    l[{k}] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;\n")
-    both("""    // acc = column 8 (weight 2^232): bits >= 24 are multiples of 2^256 -> t = t0 + t1 * 2^29, times (2^32 + 977)
+        out.append(emit_chain(t))
+        return out
+
+    def mask_low(k):
+        return f"    l[{k}] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;\n"
+
+    def put(pairs):
+        for d, h in pairs:
+            dev.append(d)
+            host.append(h)
+
+    both("    uint32_t h[9], l[9];     // l: result limbs (r may alias a or b)\n    uint64_t acc = 0, acch = 0;\n")
+    if sqr:
+        both("    uint32_t d[9];\n    PLUME_UNROLL for (int i = 0; i < 9; i++) d[i] = a.v[i] + a.v[i];\n")
+    # H9, mH9, H10, then per step j: L(j), mH(j+10), H(j+11), mL(j)
+    put(stmts_high(9)); both(mask_high(9)); put(stmts_high(10))
+    for j in range(0, 9):
+        put(stmts_low(j))
+        if j + 10 <= 16:
+            both(mask_high(j + 10))
+        if j + 11 <= 16:
+            put(stmts_high(j + 11))
+        if j < 8:
+            both(mask_low(j))
+    both("""    // acc = column 8 (weight 2^232): bits >= 24 are multiples of 2^256 -> t = t0 + t1 * 2^29, times (2^32 + 977).  h[8] (weight 2^(261+232))
+    // joins here: its 31264 part went to column 8 above, its 2^8 part is 2^261 again: limb 0 += h[8] * (31264 << 8), limb 1 += h[8] << 16
     l[8] = (uint32_t)acc & 0x00FFFFFFu;
     acc >>= 24;
     const uint32_t t0 = (uint32_t)acc & PLUME_FE_MASK, t1 = (uint32_t)(acc >> 29);
     acc = l[0];
 """)
-    dev.append('    PLUME_FE_CHAIN("v_mad_u64_u32 %0, %1, %2, %3, %0", "v"(t0), "s"(K4));\n')
-    host.append("    acc += (uint64_t)t0 * K4;\n")
+    dev.append('    PLUME_FE_CHAIN(acc, "v_mad_u64_u32 %0, %1, %2, %3, %0\\n\\tv_mad_u64_u32 %0, %1, %4, %5, %0", "v"(t0), "s"(K4), "v"(h[8]), "s"(K2));\n')
+    host.append("    acc += (uint64_t)t0 * K4; acc += (uint64_t)h[8] * K2;\n")
     both("    l[0] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;\n    acc += l[1] + t1 * 977u;\n")
-    dev.append('    PLUME_FE_CHAIN("v_mad_u64_u32 %0, %1, %2, %3, %0", "v"(t0), "s"(K5));\n')
-    host.append("    acc += (uint64_t)t0 * K5;\n")
+    dev.append('    PLUME_FE_CHAIN(acc, "v_mad_u64_u32 %0, %1, %2, %3, %0\\n\\tv_mad_u64_u32 %0, %1, %4, %5, %0", "v"(t0), "s"(K5), "v"(h[8]), "s"(K3));\n')
+    host.append("    acc += (uint64_t)t0 * K5; acc += (uint64_t)h[8] * K3;\n")
     both("    l[1] = (uint32_t)acc & PLUME_FE_MASK;\n    l[2] += (uint32_t)(acc >> 29) + (t1 << 3);\n    PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = l[i];\n")
     sig = f"PLUME_HD void {name}(fe& r, const fe& a)" if sqr else f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b)"
     check = "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, a));\n" if sqr else "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, b));\n"
@@ -124,7 +140,7 @@ def main():
     print("""// GENERATED by gen_fe_mul.py -- do not edit (see that script for the design and the measurements behind it).
 // Included by plume_field.h inside namespace plume.
 // one chain of multiply-adds on `acc`; the carry-out pair of v_mad_u64_u32 is a dead SGPR pair the compiler picks
-#define PLUME_FE_CHAIN(TEXT, ...) do { uint64_t cy_; asm(TEXT : "+v"(acc), "=&s"(cy_) : __VA_ARGS__); } while (0)
+#define PLUME_FE_CHAIN(ACC, TEXT, ...) do { uint64_t cy_; asm(TEXT : "+v"(ACC), "=&s"(cy_) : __VA_ARGS__); } while (0)
 """)
     print(gen("fe_mul", False))
     print(gen("fe_sqr", True))
