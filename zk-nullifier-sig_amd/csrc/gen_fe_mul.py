@@ -10,8 +10,8 @@ v_mad_u64_u32, and the carry into the next column is simply that chain's initial
 
     high half   columns 9..16 -> h[0..8]   (h[k] has weight 2^(261+29k); 2^261 = 2^37 + 31264 (mod p))
     low half    column k = sum a_i b_(k-i) + h[k]*31264 + h[k-1]*2^8          (k = 0..8; the fold is two more multiply-adds)
-                h[8]: its 2^8 part lands on column 9 = 2^261 again -> column 0 += h[8]*(31264 << 8), column 1 += h[8] << 16
-    tail        bits >= 2^256 of column 8 fold as t*(2^32 + 977) into limbs 0..2
+    tail        bits >= 2^256 of column 8 fold as t*(2^32 + 977) into limbs 0..2; h[8]'s 2^8 part lands on column 9 = 2^261 again and
+                joins the tail: limb 0 += h[8]*(31264 << 8), limb 1 += h[8] << 16 (so the low half never waits for the last high column)
 
 103 multiply-adds + 16 v_lshrrev_b64 + 20 v_and_b32 per multiplication (squaring: 67 multiply-adds).  Each chain is ONE asm
 statement with compiler-allocated registers: hipcc keeps scheduling and register allocation but can neither re-associate the
