@@ -321,8 +321,14 @@ PLUME_HD void scr_st(uint32_t* scr, size_t sstride, size_t slane, size_t q, int 
 PLUME_HD void scr_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, size_t q, int f) {
     PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = scr[((q * PLUME_TAB_SCR_WORDS + (size_t)(f * PLUME_FE_W + i)) * sstride) + slane];
 }
-template <int ENTRIES = PLUME_TAB_ENTRIES>
-PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane) {
+// how pass 2 writes a finished row: directly (each lane its own 128 bytes), or through a kernel-supplied sink (plume_kernels.hip
+// transposes the rows of a wavefront through LDS so that every store instruction writes whole cache lines)
+struct DirectRowSink {
+    PLUME_HD void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const { st_tab_entry(e, x, y, bx); }
+};
+template <int ENTRIES = PLUME_TAB_ENTRIES, class RowSink = DirectRowSink>
+PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
+                          const RowSink& sink = RowSink()) {
     fe acc = fe_small(1);
     PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
         size_t job = j0 + (size_t)jj;
@@ -371,7 +377,7 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
             fe_mul(X, X, zi2);
             fe_mul(zi2, zi2, zi); fe_mul(Y, Y, zi2);
             fe bx; fe_mul_k(bx, beta, X);
-            st_tab_entry(e, X, Y, bx);   // tight, not canonical: only ever multiplied / negated
+            sink(e, X, Y, bx);           // tight, not canonical: only ever multiplied / negated
         }
     }
 }

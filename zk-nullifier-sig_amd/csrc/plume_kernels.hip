@@ -66,13 +66,62 @@ __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
     if (i < a.n) verify_ingest_h2c(a, i);
 }
 
+// Row sink of the table kernel.  A lane finishes one 128-byte row at a time, and the 64 rows a wavefront finishes together lie
+// kilobytes apart, so storing them directly makes every store instruction touch 64 different cache lines with 16 bytes each.  When
+// all 64 lanes of the wavefront are in lock step (every wave except the batch's last one) the rows are transposed through LDS
+// instead: lane i then stores quad (i mod 8) of row (i div 8 + 8q), q = 0..7, i.e. every store instruction writes 8 complete lines.
+#ifndef PLUME_TABLES_COOP_STORE
+#define PLUME_TABLES_COOP_STORE 1
+#endif
+struct CoopRowSink {
+    uint4* rows;             // this wavefront's 64 x 8 quads (quad index xor-swizzled by row against bank conflicts)
+    uint32_t** ptrs;         // this wavefront's 64 row addresses
+    bool full;               // wave-uniform: all 64 lanes build the same number of rows
+    __device__ void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const {
+        if (!full) { st_tab_entry(e, x, y, bx); return; }
+        const uint32_t lane = threadIdx.x & 63u, sw = lane & 7u;
+        uint4* mine = rows + lane * 8;
+        mine[0 ^ sw] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        mine[1 ^ sw] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+        mine[2 ^ sw] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+        mine[3 ^ sw] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+        mine[4 ^ sw] = make_uint4(bx.v[0], bx.v[1], bx.v[2], bx.v[3]);
+        mine[5 ^ sw] = make_uint4(bx.v[4], bx.v[5], bx.v[6], bx.v[7]);
+        mine[6 ^ sw] = make_uint4(x.v[8], y.v[8], bx.v[8], 0u);
+        mine[7 ^ sw] = make_uint4(0u, 0u, 0u, 0u);
+        ptrs[lane] = e;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t quad = lane & 7u;
+        PLUME_UNROLL for (uint32_t q = 0; q < 8; q++) {
+            const uint32_t r = (lane >> 3) + 8u * q;
+            const uint4 v = rows[r * 8 + (quad ^ (r & 7u))];
+            reinterpret_cast<uint4*>(ptrs[r])[quad] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
 __global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr) {
+#if PLUME_TABLES_COOP_STORE
+    static_assert(PLUME_TAB_ENTRY_WORDS == 32, "the cooperative row store assumes 128-byte rows");
+    __shared__ uint4 s_rows[kBlock * 8];
+    __shared__ uint32_t* s_ptrs[kBlock];
+#endif
     size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x;
     size_t j0 = lane * (size_t)L;
-    if (j0 < njobs) {
-        size_t rem = njobs - j0;
-        table_build(tab, bases, jobflags, njobs, j0, (int)(rem < (size_t)L ? rem : (size_t)L), scr, (size_t)gridDim.x * kBlock, lane);
-    }
+    const int cnt = j0 < njobs ? (int)((njobs - j0) < (size_t)L ? (njobs - j0) : (size_t)L) : 0;
+#if PLUME_TABLES_COOP_STORE
+    CoopRowSink sink;
+    sink.rows = s_rows + (threadIdx.x & ~63u) * 8;
+    sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
+    sink.full = __ballot(cnt == L) == ~0ull;
+    if (cnt > 0) table_build<PLUME_TAB_ENTRIES, CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane, sink);
+#else
+    if (cnt > 0) table_build(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane);
+#endif
 }
 
 // blocks [0, nb): equation 1 (s*G - c*pk); blocks [nb, 2nb): equation 2 (s*H - c*nullifier) — the role is uniform
