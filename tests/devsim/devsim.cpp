@@ -20,7 +20,7 @@ extern "C" {
 unsigned long ds_fallback_count(void) { return fallback_counter(); }
 
 // op: 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 inv, 6 pow_c1, 7 normalize, 8 mul_small(b[0]), 9 is_zero->out[0], 10 eq->out[0], 11 is_odd->out[0],
-//     12 (a+b)*(a+2p-b) on unreduced operands, 13 (a+4p-2b)^2 through fe_carry, 14 words round trip
+//     12 (a+b)*(a+2p-b) on unreduced operands, 13 (a+4p-2b)^2 through fe_carry, 14 words round trip, 15 inversion by divsteps
 // operands/outputs: 256-bit integers as 8 little-endian 32-bit words (outputs canonical); count elements
 void ds_fe_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     for (size_t i = 0; i < count; i++) {
@@ -34,7 +34,7 @@ void ds_fe_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32
             case 2: fe_add(r, x, y); break;
             case 3: fe_sub(r, x, y); break;
             case 4: fe_neg(r, x); break;
-            case 5: fe_inv(r, x); break;
+            case 5: fe_inv_fermat(r, x); break;
             case 6: fe_pow_c1(r, x); break;
             case 7: r = x; fe_normalize(r); break;
             case 8: fe_mul_small(r, x, b[8 * i]); break;
@@ -44,6 +44,7 @@ void ds_fe_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32
             case 12: { fe s, d; fe_add_lazy(s, x, y); fe_sub_lazy<2>(d, x, y); fe_mul(r, d, s); break; }          // (a+b)(a-b), both operands unreduced
             case 13: { fe t; fe_add_lazy(t, y, y); fe_sub_lazy<4>(t, x, t); fe_carry(t); fe_sqr(r, t); break; }  // (a-2b)^2
             case 14: r = x; break;
+            case 15: fe_inv_gcd(r, x); break;
         }
         if (op >= 9 && op <= 11) { for (int k = 0; k < 8; k++) out[8 * i + k] = k == 0 ? (uint32_t)flag : 0u; continue; }
         fe_normalize(r);

@@ -6,7 +6,7 @@
 #include <vector>
 #include "plume_ec.h"
 using namespace plume;
-#define NOPS 20
+#define NOPS 22
 // in: 2 x 8 words per item; out: NOPS x 8 words per item
 __host__ __device__ inline void run_item(const uint32_t* in, uint32_t* out) {
     fe a, b, r;
@@ -22,7 +22,9 @@ __host__ __device__ inline void run_item(const uint32_t* in, uint32_t* out) {
     { fe s, d; fe_add_lazy(s, a, b); fe_sub_lazy<2>(d, a, b); fe_mul(r, d, s); put(r); }
     fe_mul_small(r, a, 1771); put(r);
     r = a; put(r);
-    fe_inv(r, a); put(r);
+    fe_inv_fermat(r, a); put(r);
+    fe_inv_gcd(r, a); put(r);
+    { fe t1, t2; fe_inv_gcd(t1, a); fe_mul(t2, t1, a); put(t2); }
     { uint32_t t[16]; for (int i = 0; i < 8; i++) { t[i] = in[i]; t[8 + i] = i < 4 ? in[8 + i] : 0; } fe_from_words16(r, t); put(r); }
     {   // the opening of sswu_frac, step by step
         const fe A = fe_set(0x3F8731ABu, 0xDD661ADCu, 0xA08A5558u, 0xF0F5D272u, 0xE953D363u, 0xCB6F0E5Du, 0x405447C0u, 0x1A444533u);
@@ -56,7 +58,7 @@ int main() {
     hipMemcpy(din, in.data(), in.size() * 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k, dim3((n + 63) / 64), dim3(64), 0, 0, din, dd, n);
     hipMemcpy(dout.data(), dd, dout.size() * 4, hipMemcpyDeviceToHost);
-    const char* names[NOPS] = {"mul", "sqr", "mul_k(beta)", "add", "sub", "neg", "lazy (a+b)(a-b)", "mul_small", "normalize", "inv", "from_words16", "s1 sqr", "s2 *11", "s3 neg", "s4 tv2", "s5 tv3", "s6 tv4 sel", "s7 A*tv4", "muladd", "dbl+madd x"};
+    const char* names[NOPS] = {"mul", "sqr", "mul_k(beta)", "add", "sub", "neg", "lazy (a+b)(a-b)", "mul_small", "normalize", "inv fermat", "inv divsteps", "a * inv(a)", "from_words16", "s1 sqr", "s2 *11", "s3 neg", "s4 tv2", "s5 tv3", "s6 tv4 sel", "s7 A*tv4", "muladd", "dbl+madd x"};
     int bad[NOPS] = {0};
     for (int i = 0; i < n; i++) for (int o = 0; o < NOPS; o++) if (memcmp(&hout[8 * (NOPS * i + o)], &dout[8 * (NOPS * i + o)], 32)) { if (!bad[o]) printf("first mismatch op %s item %d\n", names[o], i); bad[o]++; }
     int tot = 0; for (int o = 0; o < NOPS; o++) { printf("%-18s mismatches %d / %d\n", names[o], bad[o], n); tot += bad[o]; }

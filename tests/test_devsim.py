@@ -295,3 +295,15 @@ def test_crafted_collisions_take_the_checked_fallback():
         assert D.eq1(d.to_bytes(32, "big"), d.to_bytes(32, "big"), g) == bytes(64), d                         # d*G - d*G
         assert D.eq1(d.to_bytes(32, "big"), (N - d).to_bytes(32, "big"), g) == O.pt_bytes(O.pt_mul(2 * d, O.G)), d   # d*G + d*G
     assert D.fallback_count() - before >= 12, "the crafted collisions did not go through the checked fallback"
+
+
+def test_inversion_by_divsteps_matches_fermat_and_python():
+    """fe_inv (Bernstein-Yang divsteps, 20 x 30 steps) against pow(x, -1, p), and against the Fermat chain it replaced; 0 and p give 0"""
+    rng = random.Random(2024)
+    vals = [1, 2, 3, P - 1, P - 2, P + 1, 2**255, 2**256 - 1, 977, 2**32 + 977, 2**128, 2**30, 2**30 - 1, 2**60, (P + 1) // 2]
+    vals += [rng.getrandbits(256) for _ in range(3000)] + [rng.getrandbits(k) | 1 for k in (1, 8, 29, 30, 31, 58, 60, 61, 200, 255) for _ in range(20)]
+    vals = [v for v in vals if v % P]
+    got = D.fe_op(15, vals)
+    assert got == [pow(v % P, -1, P) for v in vals]
+    assert [g % P for g in D.fe_op(5, vals)] == got
+    assert D.fe_op(15, [0, P]) == [0, 0]
