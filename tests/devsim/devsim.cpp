@@ -123,7 +123,8 @@ static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobf
 static const uint32_t B = 8;
 
 static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
-                       const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags);
+                       const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags, const uint8_t* rpt33 = nullptr,
+                       const uint8_t* hr33 = nullptr);
 int ds_verify_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
                     const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L) {
     return verify_impl(version, n, msgs, msg_off, pk, nul, c, s, rpt, hr, ok, L, nullptr);
@@ -133,21 +134,21 @@ int ds_verify_batch_sec1(int version, uint32_t n, const uint8_t* msgs, const uin
                          const uint8_t* s, const uint8_t* r33, const uint8_t* hr33, uint8_t* ok) {
     if (version != 1 && version != 2) return -1;
     std::vector<uint8_t> dec[4], pre(n);
-    DecompressArgs d; d.n = n; d.npts = version == 1 ? 4 : 2;
+    DecompressArgs d; d.n = n; d.npts = 2;       // mirrors verify_sec1_device: r_point / hashed_to_curve_r stay compressed
     d.in[0] = pk33; d.in[1] = nul33; d.in[2] = r33; d.in[3] = hr33;
     for (int k = 0; k < 4; k++) { dec[k].resize(64 * (size_t)n + 16); d.out[k] = dec[k].data(); }
     d.preflags = pre.data();
     for (uint32_t i = 0; i < n; i++) decompress_item(d, i);
-    return verify_impl(version, n, msgs, msg_off, d.out[0], d.out[1], c, s, version == 1 ? d.out[2] : nullptr, version == 1 ? d.out[3] : nullptr, ok, 3, pre.data());
+    return verify_impl(version, n, msgs, msg_off, d.out[0], d.out[1], c, s, nullptr, nullptr, ok, 3, pre.data(), version == 1 ? r33 : nullptr, version == 1 ? hr33 : nullptr);
 }
 static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
-                       const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags) {
+                       const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags, const uint8_t* rpt33, const uint8_t* hr33) {
     if (version != 1 && version != 2) return -1;
     std::vector<uint32_t> gtab; build_gtab(gtab);
     std::vector<uint32_t> bases(PLUME_JAC_WORDS * 3 * (size_t)n), tab((size_t)3 * n * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2 * (size_t)n);
     std::vector<uint8_t> jobflags(3 * (size_t)n), itemflags(n), resinf(2 * (size_t)n);
     VerifyArgs a;
-    a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags;
+    a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags; a.rpt33 = rpt33; a.hr33 = hr33;
     a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data(); a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data();
     a.gtab = gtab.data();
     for (uint32_t i = 0; i < n; i++) verify_ingest_h2c(a, i);

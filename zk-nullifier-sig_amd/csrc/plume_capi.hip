@@ -173,7 +173,7 @@ static int pick_jobs_per_lane(const plume_ctx* ctx, size_t njobs, bool kinds_of_
 // ------------------------------------------------------------------------------------------ device pipelines
 static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul,
                          const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, hipStream_t st,
-                         const uint8_t* preflags = nullptr, bool continue_timer = false) {
+                         const uint8_t* preflags = nullptr, bool continue_timer = false, const uint8_t* rpt33 = nullptr, const uint8_t* hr33 = nullptr) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
     const int jpl = pick_jobs_per_lane(ctx, 3 * n, true);
@@ -182,7 +182,7 @@ static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* m
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n))
         return PLUME_ERR_HIP;
     VerifyArgs a;
-    a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags;
+    a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags; a.rpt33 = rpt33; a.hr33 = hr33;
     a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>(); a.itemflags = ctx->itemflags.as<uint8_t>();
     a.tab = ctx->tab.as<uint32_t>(); a.res = ctx->res.as<uint32_t>(); a.resinf = ctx->resinf.as<uint8_t>(); a.gtab = ctx->gtab.as<uint32_t>();
     StageTimer& t = ctx->timer;
@@ -251,7 +251,9 @@ static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8
                               const uint8_t* c, const uint8_t* s, const uint8_t* r33, const uint8_t* hr33, uint8_t* ok, hipStream_t st) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
-    const int npts = version == 1 ? 4 : 2;
+    // only pk and the nullifier are decompressed (they become bases of scalar multiplications); V1's r_point and hashed_to_curve_r stay
+    // in their 33-byte form and are compared / hashed as x + parity by the finalize stage
+    const int npts = 2;
     for (int k = 0; k < npts; k++) if (ctx->dec[k].ensure(64 * n)) return PLUME_ERR_HIP;
     if (ctx->preflags.ensure(n)) return PLUME_ERR_HIP;
     DecompressArgs d;
@@ -261,8 +263,8 @@ static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8
     d.preflags = ctx->preflags.as<uint8_t>();
     ctx->timer.begin(st);
     launch_decompress(d, st); ctx->timer.stage("sec1_decompress", st);
-    return verify_device(ctx, version, n, msgs, msg_off, d.out[0], d.out[1], c, s, version == 1 ? d.out[2] : nullptr, version == 1 ? d.out[3] : nullptr, ok, st,
-                         d.preflags, true);
+    return verify_device(ctx, version, n, msgs, msg_off, d.out[0], d.out[1], c, s, nullptr, nullptr, ok, st, d.preflags, true, version == 1 ? r33 : nullptr,
+                         version == 1 ? hr33 : nullptr);
 }
 
 extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,

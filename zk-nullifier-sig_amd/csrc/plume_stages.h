@@ -107,6 +107,8 @@ struct VerifyArgs {
     const uint8_t *pk, *nul, *c, *s, *rpt, *hr;
     uint8_t* ok;
     const uint8_t* preflags;  // optional, n bytes: non-zero = reject (set by the SEC1 decompression stage)
+    const uint8_t *rpt33, *hr33;   // optional (V1, SEC1 ingest): r_point / hashed_to_curve_r as 33-byte records, used INSTEAD of rpt / hr:
+                                   // they are only compared with computed points and hashed, which needs x and the parity -- no square root
     // scratch (device memory)
     uint32_t* bases;      // PLUME_JAC_WORDS x (3n) words, Jacobian SoA, job j = word-row w at bases[w*3n + j]
     uint8_t* jobflags;    // 3n
@@ -191,7 +193,48 @@ PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
         sc_from_be_aligned(c, a.c + 32 * (size_t)i);
         uint32_t dg[8];
         bool hashed = false;
-        if (a.version == 1) {
+        if (a.version == 1 && a.rpt33) {
+            // SEC1 records for R and Hr.  The reference decodes them (failing on a bad tag, x >= p, or an x with no curve point) and then
+            // compares with the computed points: a computed point IS on the curve, so "x matches and the parity matches" already implies that
+            // the record decodes, and the comparison needs the computed points in affine form: one shared inversion instead of two square roots.
+            const uint8_t* r33 = a.rpt33 + 33 * (size_t)i;
+            const uint8_t* h33 = a.hr33 + 33 * (size_t)i;
+            uint32_t rw[8], hw[8];
+            words_from_be(rw, r33 + 1); words_from_be(hw, h33 + 1);
+            const uint32_t rtag = r33[0], htag = h33[0];
+            const bool rfmt = rtag == 0u || ((rtag == 2u || rtag == 3u) && words_lt_p(rw));
+            const bool hfmt = htag == 0u || ((htag == 2u || htag == 3u) && words_lt_p(hw));
+            bool match = rfmt && hfmt && (rc.inf != 0) == (rtag == 0u) && (hc.inf != 0) == (htag == 0u);
+            fe rxa = fe_zero(), rya = fe_zero(), hxa = fe_zero(), hya = fe_zero();
+            if (match) {
+                // 1 / (Zr * Zh) -> both inverses (an identity contributes Z = 1)
+                fe zr = rc.inf ? fe_small(1) : rc.z, zh = hc.inf ? fe_small(1) : hc.z, zz, zi, t, t2;
+                fe_mul(zz, zr, zh); fe_inv(zz, zz);
+                fe_mul(zi, zz, zh);                               // 1 / Zr
+                fe_sqr(t, zi); fe_mul(rxa, rc.x, t); fe_mul(t2, t, zi); fe_mul(rya, rc.y, t2);
+                fe_mul(zi, zz, zr);                               // 1 / Zh
+                fe_sqr(t, zi); fe_mul(hxa, hc.x, t); fe_mul(t2, t, zi); fe_mul(hya, hc.y, t2);
+                fe gx, gh;
+                fe_from_words(gx, rw); fe_from_words(gh, hw);
+                if (!rc.inf) match = match && fe_eq(rxa, gx) && (uint32_t)fe_is_odd(rya) == (rtag & 1u);
+                if (!hc.inf) match = match && fe_eq(hxa, gh) && (uint32_t)fe_is_odd(hya) == (htag & 1u);
+            }
+            if (match) {                                                                                           // lib.rs:117,122
+                const size_t jh = 3 * (size_t)i + 1;
+                bool hinf = job_state(a.jobflags[jh]) == PLUME_JOB_INF;
+                fe Hx, Hy;
+                ld_tab_xy(Hx, Hy, a.tab + jh * PLUME_TAB_WORDS, false);
+                enc_pt pts[6];
+                pts[0] = enc_of(fe_gx(), fe_gy(), false);
+                pts[1] = enc_of(pkx, pky, fpk == PLUME_JOB_INF);
+                pts[2] = enc_of(Hx, Hy, hinf);
+                pts[3] = enc_of(nx, ny, fnul == PLUME_JOB_INF);
+                pts[4] = enc_of(rxa, rya, rc.inf != 0);
+                pts[5] = enc_of(hxa, hya, hc.inf != 0);
+                c_hash<6>(dg, pts);                                                                                  // lib.rs:128-135
+                hashed = true;
+            }
+        } else if (a.version == 1) {
             fe rx, ry, hx, hy;
             uint32_t fr = load_affine_be(rx, ry, a.rpt + 64 * (size_t)i);
             uint32_t fh = load_affine_be(hx, hy, a.hr + 64 * (size_t)i);
