@@ -98,6 +98,14 @@ int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n,
                               const uint8_t* msgs, const uint64_t* msg_off,
                               const uint8_t* pk, uint8_t* h_out);
 
+/* plume_sign_batch with the point outputs as 33-byte SEC1-compressed records (02|03 || x; identity = 00 followed by 32 zero
+ * bytes) -- the wire format of the reference's serde / wasm layer (javascript/src/lib.rs:95-118).  pk_in stays 64-byte affine. */
+int plume_sign_batch_sec1(plume_ctx* ctx, int version, size_t n,
+                          const uint8_t* msgs, const uint64_t* msg_off,
+                          const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,
+                          uint8_t* pk33, uint8_t* nullifier33, uint8_t* c, uint8_t* s,
+                          uint8_t* r_point33, uint8_t* hashed_to_curve_r33, uint8_t* status);
+
 /* ---- nullifier-set post-processing: first occurrences   --------------------------------
  * PLUME exists so that an application can accept ONE nullifier per (pk, message) (reference README.md:5; the field
  * rust-k256/src/lib.rs:72-73); after verifying a batch the application has to find repeated nullifiers.
@@ -134,6 +142,11 @@ int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n,
 int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n,
                                      const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                      const uint8_t* pk, uint8_t* h_out, void* stream);
+int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n,
+                                 const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
+                                 const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,
+                                 uint8_t* pk33, uint8_t* nullifier33, uint8_t* c, uint8_t* s,
+                                 uint8_t* r_point33, uint8_t* hashed_to_curve_r33, uint8_t* status, void* stream);
 /* n_unique, when not NULL, is a DEVICE pointer to one uint64_t */
 int plume_nullifier_first_occurrence_device(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live,
                                             const uint64_t* ids, uint8_t* first, uint64_t* n_unique, void* stream);

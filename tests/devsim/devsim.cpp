@@ -172,7 +172,7 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     static std::vector<uint32_t> gcomb; if (gcomb.empty()) build_gcomb(gcomb);
     std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_JAC_WORDS * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
     std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(n), itemflags(n);
-    SignArgs a;
+    SignArgs a; memset(&a, 0, sizeof a);
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.sk = sk; a.r = r; a.pk_in = pk_in;
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
     a.gres = gres.data(); a.gresinf = gresinf.data(); a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();

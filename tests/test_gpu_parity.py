@@ -385,3 +385,25 @@ def test_small_secret_keys_exceptional_additions(eng, ver):
     ok = eng.verify_batch(ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
     want_ok = OC.verify_batch(ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"), nthreads=16)
     assert np.array_equal(ok, want_ok)
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_sign_with_sec1_outputs(eng, ver):
+    """plume_sign_batch_sec1: the same signatures with the points as 33-byte SEC1 records (incl. the identity public key of an out-of-range
+    secret key), and they verify through the SEC1 ingest"""
+    from tests import _sec1
+    n = 777
+    b = synth.sign_inputs(n, start=123456)
+    b["sk"][5] = 0                                   # sk = 0: pk and the nullifier are the identity -> records 00 || zeros
+    want = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    got = eng.sign_batch_sec1(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    for k in ("pk", "nullifier", "r_point", "hashed_to_curve_r"):
+        assert np.array_equal(got[k], _sec1.compress(want[k])), k
+    for k in ("c", "s", "status"):
+        assert np.array_equal(got[k], want[k]), k
+    assert bytes(got["pk"][5]) == bytes(33)
+    ok = eng.verify_batch_sec1(ver, b["msgs"], b["off"], got["pk"], got["nullifier"], got["c"], got["s"],
+                               got["r_point"] if ver == 1 else None, got["hashed_to_curve_r"] if ver == 1 else None)
+    oracle_ok = OC.verify_batch(ver, b["msgs"], b["off"], want["pk"], want["nullifier"], want["c"], want["s"],
+                                want["r_point"] if ver == 1 else None, want["hashed_to_curve_r"] if ver == 1 else None, nthreads=8)
+    assert np.array_equal(ok, oracle_ok)

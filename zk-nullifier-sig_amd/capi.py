@@ -60,6 +60,8 @@ def _load():
     lib.plume_verify_batch_sec1.argtypes = [vp, i, sz] + [vp] * 9
     lib.plume_verify_batch_sec1_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 8
     lib.plume_sign_batch.argtypes = [vp, i, sz] + [vp] * 12
+    lib.plume_sign_batch_sec1.argtypes = [vp, i, sz] + [vp] * 12
+    lib.plume_sign_batch_sec1_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 11
     lib.plume_nullifier_first_occurrence.argtypes = [vp, sz, vp, vp, vp, vp, C.POINTER(C.c_uint64)]
     lib.plume_nullifier_first_occurrence_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
     lib.plume_hash_to_curve_batch.argtypes = [vp, sz] + [vp] * 4
@@ -72,7 +74,7 @@ def _load():
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch",
+    return ["plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
             "plume_hash_to_curve_batch", "plume_nullifier_first_occurrence", "plume_nullifier_first_occurrence_device", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
             "plume_last_stage_times", "plume_microbench", "plume_microbench_last_ticks"]
 
@@ -183,6 +185,22 @@ class Engine:
         self._chk(self._lib.plume_sign_batch(self._ctx, int(version), n, _ptr(msgs), _ptr(msg_off), _ptr(sk), _ptr(r), _ptr(pk_in), _ptr(o["pk"]),
                                              _ptr(o["nullifier"]), _ptr(o["c"]), _ptr(o["s"]), _ptr(o["r_point"]), _ptr(o["hashed_to_curve_r"]),
                                              _ptr(status)), "plume_sign_batch")
+        o["status"] = status
+        return o
+
+    def sign_batch_sec1(self, version, msgs, msg_off, sk, r, pk_in=None):
+        """sign_batch with pk, nullifier, r_point, hashed_to_curve_r as 33-byte SEC1-compressed records"""
+        n = len(msg_off) - 1
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
+        sk, r = _np(sk, 32, n, "sk"), _np(r, 32, n, "r")
+        pk_in = None if pk_in is None else _np(pk_in, 64, n, "pk_in")
+        o = {k: np.zeros((n, w), dtype=np.uint8) for k, w in
+             [("pk", 33), ("nullifier", 33), ("c", 32), ("s", 32), ("r_point", 33), ("hashed_to_curve_r", 33)]}
+        status = np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.plume_sign_batch_sec1(self._ctx, int(version), n, _ptr(msgs), _ptr(msg_off), _ptr(sk), _ptr(r), _ptr(pk_in), _ptr(o["pk"]),
+                                                  _ptr(o["nullifier"]), _ptr(o["c"]), _ptr(o["s"]), _ptr(o["r_point"]), _ptr(o["hashed_to_curve_r"]),
+                                                  _ptr(status)), "plume_sign_batch_sec1")
         o["status"] = status
         return o
 

@@ -198,7 +198,7 @@ static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* m
 
 static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
                        const uint8_t* pk_in, uint8_t* pk, uint8_t* nul, uint8_t* c, uint8_t* s, uint8_t* rpt, uint8_t* hr, uint8_t* status, uint8_t* h_out,
-                       hipStream_t st) {
+                       hipStream_t st, bool out33 = false) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
     const int jpl = pick_jobs_per_lane(ctx, n, false);
@@ -208,7 +208,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
         return PLUME_ERR_HIP;
     SignArgs a;
     a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.sk = sk; a.r = r; a.pk_in = pk_in;
-    a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
+    a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out; a.out33 = out33 ? 1 : 0;
     a.gres = ctx->res.as<uint32_t>(); a.gresinf = ctx->resinf.as<uint8_t>(); a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>();
     a.itemflags = ctx->itemflags.as<uint8_t>(); a.pkaff = ctx->pkaff.as<uint32_t>(); a.tab = ctx->tab.as<uint32_t>();
     a.hres = ctx->res2.as<uint32_t>(); a.hresinf = ctx->res2inf.as<uint8_t>(); a.gtab = ctx->gtab.as<uint32_t>(); a.gcomb = ctx->gcomb.as<uint32_t>();
@@ -287,6 +287,17 @@ extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, co
     if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
     return sign_device(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, nullptr,
                        stream ? (hipStream_t)stream : ctx->stream);
+}
+
+extern "C" int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
+                                            const uint8_t* r, const uint8_t* pk_in, uint8_t* pk33, uint8_t* nullifier33, uint8_t* c, uint8_t* s, uint8_t* r_point33,
+                                            uint8_t* hashed_to_curve_r33, uint8_t* status, void* stream) {
+    (void)msgs_bytes;
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
+    if (n && (!sk || !r || !nullifier33 || !c || !s || !r_point33 || !hashed_to_curve_r33 || !status)) return fail(PLUME_ERR_ARG, "null array");
+    return sign_device(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, status, nullptr,
+                       stream ? (hipStream_t)stream : ctx->stream, true);
 }
 
 extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
@@ -482,9 +493,9 @@ extern "C" int plume_verify_batch_sec1(plume_ctx* ctx, int version, size_t n, co
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); });
 }
 
-extern "C" int plume_sign_batch(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
-                                const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point, uint8_t* hashed_to_curve_r,
-                                uint8_t* status) {
+static int sign_host(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
+                     const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point, uint8_t* hashed_to_curve_r,
+                     uint8_t* status, const size_t P /* bytes per output point record: 64, or 33 for SEC1 */) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
@@ -495,15 +506,15 @@ extern "C" int plume_sign_batch(plume_ctx* ctx, int version, size_t n, const uin
             if (int rc = h2d(ctx, sl.in[0], sk + 32 * i0, 32 * cnt)) return rc;
             if (int rc = h2d(ctx, sl.in[1], r + 32 * i0, 32 * cnt)) return rc;
             if (pk_in) { if (int rc = h2d(ctx, sl.in[2], pk_in + 64 * i0, 64 * cnt)) return rc; }
-            return sl.out[0].ensure(64 * cnt) || sl.out[1].ensure(64 * cnt) || sl.out[2].ensure(32 * cnt) || sl.out[3].ensure(32 * cnt) || sl.out[4].ensure(64 * cnt) ||
-                           sl.out[5].ensure(64 * cnt) || sl.out[6].ensure(cnt)
+            return sl.out[0].ensure(P * cnt) || sl.out[1].ensure(P * cnt) || sl.out[2].ensure(32 * cnt) || sl.out[3].ensure(32 * cnt) || sl.out[4].ensure(P * cnt) ||
+                           sl.out[5].ensure(P * cnt) || sl.out[6].ensure(cnt)
                        ? PLUME_ERR_HIP
                        : 0;
         },
         [&](HostSlot& sl, size_t cnt) -> int {
             if (int rc = sign_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
                                      pk_in ? sl.in[2].as<uint8_t>() : nullptr, sl.out[0].as<uint8_t>(), sl.out[1].as<uint8_t>(), sl.out[2].as<uint8_t>(),
-                                     sl.out[3].as<uint8_t>(), sl.out[4].as<uint8_t>(), sl.out[5].as<uint8_t>(), sl.out[6].as<uint8_t>(), nullptr, ctx->stream))
+                                     sl.out[3].as<uint8_t>(), sl.out[4].as<uint8_t>(), sl.out[5].as<uint8_t>(), sl.out[6].as<uint8_t>(), nullptr, ctx->stream, P == 33))
                 return rc;
             // wipe the staged secrets before the slot is reused or freed
             HIPCHK(hipMemsetAsync(sl.in[0].p, 0, 32 * cnt, ctx->stream));
@@ -511,14 +522,25 @@ extern "C" int plume_sign_batch(plume_ctx* ctx, int version, size_t n, const uin
             return 0;
         },
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
-            if (pk) { if (int rc = d2h(ctx, pk + 64 * i0, sl.out[0], 64 * cnt)) return rc; }
-            if (int rc = d2h(ctx, nullifier + 64 * i0, sl.out[1], 64 * cnt)) return rc;
+            if (pk) { if (int rc = d2h(ctx, pk + P * i0, sl.out[0], P * cnt)) return rc; }
+            if (int rc = d2h(ctx, nullifier + P * i0, sl.out[1], P * cnt)) return rc;
             if (int rc = d2h(ctx, c + 32 * i0, sl.out[2], 32 * cnt)) return rc;
             if (int rc = d2h(ctx, s + 32 * i0, sl.out[3], 32 * cnt)) return rc;
-            if (int rc = d2h(ctx, r_point + 64 * i0, sl.out[4], 64 * cnt)) return rc;
-            if (int rc = d2h(ctx, hashed_to_curve_r + 64 * i0, sl.out[5], 64 * cnt)) return rc;
+            if (int rc = d2h(ctx, r_point + P * i0, sl.out[4], P * cnt)) return rc;
+            if (int rc = d2h(ctx, hashed_to_curve_r + P * i0, sl.out[5], P * cnt)) return rc;
             return d2h(ctx, status + i0, sl.out[6], cnt);
         });
+}
+
+extern "C" int plume_sign_batch(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
+                                const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point, uint8_t* hashed_to_curve_r,
+                                uint8_t* status) {
+    return sign_host(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, 64);
+}
+extern "C" int plume_sign_batch_sec1(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
+                                     const uint8_t* pk_in, uint8_t* pk33, uint8_t* nullifier33, uint8_t* c, uint8_t* s, uint8_t* r_point33,
+                                     uint8_t* hashed_to_curve_r33, uint8_t* status) {
+    return sign_host(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, status, 33);
 }
 
 extern "C" int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out) {

@@ -41,6 +41,20 @@ PLUME_HD void store_affine_be(uint8_t* p, fe x, fe y, bool inf) {
     fe_to_be_aligned(p, x);
     fe_to_be_aligned(p + 32, y);
 }
+// SEC1-compressed record: 02|03 || x, or 00 followed by 32 zero bytes for the identity (33-byte stride: byte stores)
+PLUME_HD void store_sec1_be(uint8_t* p, fe x, fe y, bool inf) {
+    fe_normalize(x);
+    uint32_t w[8];
+    fe_to_words(w, x);
+    p[0] = (uint8_t)(inf ? 0u : 2u + (fe_is_odd(y) ? 1u : 0u));
+    PLUME_UNROLL for (int i = 0; i < 8; i++) {
+        const uint32_t v = inf ? 0u : w[7 - i];
+        p[1 + 4 * i] = (uint8_t)(v >> 24); p[2 + 4 * i] = (uint8_t)(v >> 16); p[3 + 4 * i] = (uint8_t)(v >> 8); p[4 + 4 * i] = (uint8_t)v;
+    }
+}
+PLUME_HD void store_point_be(uint8_t* base, size_t i, int out33, const fe& x, const fe& y, bool inf) {
+    if (out33) store_sec1_be(base + 33 * i, x, y, inf); else store_affine_be(base + 64 * i, x, y, inf);
+}
 // scalar in [1, n-1]?
 PLUME_HD bool load_scalar_be(sc& k, const uint8_t* p) {
     sc_from_be_aligned(k, p);
@@ -288,6 +302,7 @@ struct SignArgs {
     const uint8_t* pk_in;   // optional (arkworks-shaped sign_with_r: pk supplied, not derived)
     uint8_t *pk, *nul, *c, *s, *rpt, *hr, *status;
     uint8_t* h_out;         // optional 64 B/item
+    int out33;              // 0: pk, nul, rpt, hr are 64-byte affine records; 1: 33-byte SEC1-compressed records (stride 33)
     // scratch
     uint32_t* gres;  uint8_t* gresinf;   // 2n tasks: sk*G, r*G (Jacobian SoA)
     uint32_t* bases; uint8_t* jobflags;  // n jobs: H
@@ -394,12 +409,12 @@ PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
     (void)load_scalar_reduced(r, a.r + 32 * (size_t)i);
     sc_mul(tt, c, sk); sc_add(s, r, tt);                                             // :94
     if (sc_is_zero(s)) st |= PLUME_ST_IDENTITY;                                      // :95
-    if (a.pk) store_affine_be(a.pk + 64 * (size_t)i, px, py, pinf);
-    store_affine_be(a.nul + 64 * (size_t)i, nul.x, nul.y, nul.inf != 0);
+    if (a.pk) store_point_be(a.pk, i, a.out33, px, py, pinf);
+    store_point_be(a.nul, i, a.out33, nul.x, nul.y, nul.inf != 0);
     sc_to_be_aligned(a.c + 32 * (size_t)i, c);
     sc_to_be_aligned(a.s + 32 * (size_t)i, s);
-    store_affine_be(a.rpt + 64 * (size_t)i, R.x, R.y, R.inf != 0);
-    store_affine_be(a.hr + 64 * (size_t)i, hr.x, hr.y, hr.inf != 0);
+    store_point_be(a.rpt, i, a.out33, R.x, R.y, R.inf != 0);
+    store_point_be(a.hr, i, a.out33, hr.x, hr.y, hr.inf != 0);
     if (a.h_out) store_affine_be(a.h_out + 64 * (size_t)i, Hx, Hy, hinf);
     a.status[i] = (uint8_t)st;
 }
