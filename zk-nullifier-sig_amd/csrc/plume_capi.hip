@@ -116,7 +116,7 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
     uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
     HIPCHK(hipMemcpyAsync(ctx->bases.p, hb, sizeof hb, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->jobflags.p, &flag, 1, hipMemcpyHostToDevice, ctx->stream));
-    launch_gtab8(ctx->gtab.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->tabscr.as<uint32_t>(), ctx->stream);
+    launch_gtab(ctx->gtab.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->tabscr.as<uint32_t>(), ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     launch_gcomb(ctx->gcomb.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->tabscr.as<uint32_t>(), ctx->stream);   // fixed-base comb for the signer

@@ -3,11 +3,11 @@
 // all in those headers.  Geometry: 256-thread workgroups (4 wavefronts), one item / job-group / task per lane,
 // grids of n/256 workgroups (>> 256 CUs at the batch sizes this engine is built for).
 //
-// LDS use: the multi-scalar kernels stage the generator's window table (1 KiB, shared by every lane of the
-// workgroup) and each lane's signed window digits (4 x 33 bytes, lane-strided so a wave's accesses to one digit
-// row fall in consecutive bytes).  The per-lane tables of the variable bases live in HBM: 1 KiB per base is far
-// more than LDS can hold at any useful occupancy, and their traffic (~17 KiB per verify) is negligible next to
-// the ~10^6 VALU instructions per item.
+// LDS use: the multi-scalar kernels keep each lane's signed window digits (4 x 33 bytes, lane-strided so a wave's accesses
+// to one digit row fall in consecutive bytes); the table kernel transposes finished rows through LDS so that its stores
+// are whole cache lines.  The generator's tables (256 KiB / 3 MiB) are read through L1/L2, the per-lane tables of the variable
+// bases live in HBM: 1 KiB per base is far more than LDS can hold at any useful occupancy, and their traffic (~10 KiB per
+// verify) is negligible next to the ~7 * 10^5 VALU instructions per item.
 #include "plume_launch.h"
 #include "plume_dedup.h"
 
@@ -38,27 +38,14 @@
 #define PLUME_MSM_BOUNDS __launch_bounds__(kBlock, PLUME_MSM_WAVES)
 #define PLUME_TABLES_BOUNDS __launch_bounds__(kBlock, PLUME_TABLES_WAVES)
 #define PLUME_H2C_BOUNDS __launch_bounds__(kBlock, PLUME_H2C_WAVES)
-#ifndef PLUME_GTAB_IN_LDS
-#define PLUME_GTAB_IN_LDS 0
-#endif
 
 namespace plume {
 
 
-#if PLUME_GTAB_IN_LDS
-static_assert(PLUME_GTAB_WORDS * 4 <= 32768, "the generator's wide table only fits LDS for PLUME_GW = 8");
-// the generator's wide table -> LDS, 16 B per lane per trip (measured 10 % slower than reading it through L1/L2: bank conflicts)
-__device__ __forceinline__ void stage_gtab(uint32_t* s_gtab, const uint32_t* gtab) {
-    const uint4* src = reinterpret_cast<const uint4*>(gtab);
-    uint4* dst = reinterpret_cast<uint4*>(s_gtab);
-    for (int w = threadIdx.x; w < PLUME_GTAB_WORDS / 4; w += kBlock) dst[w] = src[w];
-    __syncthreads();
-}
-#endif
 
 // one-time: (1..2^(W-1))*G, affine + beta*x, by a single lane (plume_init; ~15 ms for W = 12)
-__global__ void k_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) table_build<PLUME_GTAB_ENTRIES>(gtab8, base_g, flag, 1, 0, 1, scr, 1, 0);
+__global__ void k_gtab(uint32_t* gtab, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) table_build<PLUME_GTAB_ENTRIES>(gtab, base_g, flag, 1, 0, 1, scr, 1, 0);
 }
 
 __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
@@ -127,9 +114,6 @@ __global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* base
 // blocks [0, nb): equation 1 (s*G - c*pk); blocks [nb, 2nb): equation 2 (s*H - c*nullifier) — the role is uniform
 // per workgroup so the generator-table-in-LDS path never diverges inside a wavefront
 __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
-#if PLUME_GTAB_IN_LDS
-    __shared__ __attribute__((aligned(16))) uint32_t s_gtab[PLUME_GTAB_WORDS];
-#endif
     __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
 #ifndef PLUME_MSM_ORDER
@@ -145,12 +129,7 @@ __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
     const uint32_t eq = blockIdx.x & 1u;
     const uint32_t blk = blockIdx.x >> 1;
 #endif
-#if PLUME_GTAB_IN_LDS
-    if (eq == 0) stage_gtab(s_gtab, a.gtab);   // block-uniform
-    const uint32_t* gt = s_gtab;
-#else
-    const uint32_t* gt = a.gtab;
-#endif
+    const uint32_t* gt = a.gtab;   // read through L1/L2 (a 128-entry table staged in LDS was 10 % slower: bank conflicts on per-lane random rows)
     const uint32_t i = blk * kBlock + threadIdx.x;
     if (i < a.n) verify_msm(a, i, eq, gt, s_dig + threadIdx.x, kBlock);
 }
@@ -344,7 +323,7 @@ void launch_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, hipStream_
 }
 void launch_decompress(const DecompressArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_decompress, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_h2c_only(const H2cArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_only, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
-void launch_gtab8(uint32_t* gtab8, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gtab8, dim3(1), dim3(64), 0, st, gtab8, base_g, flag, scr); }
+void launch_gtab(uint32_t* gtab, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gtab, dim3(1), dim3(64), 0, st, gtab, base_g, flag, scr); }
 void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gcomb, dim3(1), dim3(64), 0, st, comb, bases, flags, scr); }
 void launch_dedup(const DedupArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_dedup_clear, dim3(nblocks((size_t)a.mask + 1)), dim3(kBlock), 0, st, a);

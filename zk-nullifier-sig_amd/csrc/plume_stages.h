@@ -322,16 +322,15 @@ PLUME_HD uint32_t load_scalar_reduced(sc& k, const uint8_t* p) {
     return ok ? 0u : PLUME_ST_BAD_SCALAR;
 }
 // task t = 2*item + which: which 0 -> sk, 1 -> r;  result = k * (table tab0)
-PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, const uint32_t* tab0, uint32_t* res, uint8_t* resinf, int8_t* dig, uint32_t stride, bool wide) {
+PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, const uint32_t* tab0, uint32_t* res, uint8_t* resinf, int8_t* dig, uint32_t stride) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
     sc k;
     (void)load_scalar_reduced(k, (which ? a.r : a.sk) + 32 * (size_t)item);
     glv_half h1, h2;
     glv_split(h1, h2, k);
-    if (wide) { booth_store_wide(dig, stride, h1, false); booth_store_wide(dig + PLUME_NDIG * stride, stride, h2, false); }
-    else { booth_store(dig, stride, h1, false); booth_store(dig + PLUME_NDIG * stride, stride, h2, false); }
+    booth_store(dig, stride, h1, false); booth_store(dig + PLUME_NDIG * stride, stride, h2, false);
     jac acc;
-    msm_run(acc, tab0, nullptr, 2, dig, stride, wide);
+    msm_run(acc, tab0, nullptr, 2, dig, stride, false);
     st_jac_soa(res, nt, t, acc);
     resinf[t] = (uint8_t)acc.inf;
 }
@@ -377,7 +376,7 @@ PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
 }
 PLUME_HD void sign_hmul(const SignArgs& a, uint32_t item, uint32_t which, int8_t* dig, uint32_t stride) {
     const uint32_t* tab0 = job_state(a.jobflags[item]) == PLUME_JOB_OK ? a.tab + (size_t)item * PLUME_TAB_WORDS : nullptr;
-    sign_mul(a, item, which, tab0, a.hres, a.hresinf, dig, stride, false);
+    sign_mul(a, item, which, tab0, a.hres, a.hresinf, dig, stride);
 }
 PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
     const size_t nt = 2 * (size_t)a.n;
