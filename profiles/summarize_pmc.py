@@ -36,6 +36,10 @@ for k in out:
         out[k]["FETCH_SIZE_KB_raw"] = max(fe[k]["FETCH_SIZE"])
     if k in wr:
         out[k]["WRITE_SIZE_KB_raw"] = max(wr[k]["WRITE_SIZE"])
+for k, d in out.items():
+    if "SQ_ACTIVE_INST_VALU" in d and d.get("GRBM_GUI_ACTIVE"):
+        # rocprof's derived VALUBusy: 4 cycles per wave64 VALU instruction, 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        d["VALUBusy"] = round(d["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (d["GRBM_GUI_ACTIVE"] / 8), 3)
 out["_notes"] = {
     "collection": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv, separate passes (sq, sq2, FETCH_SIZE, WRITE_SIZE); "
                   "command: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras",
