@@ -15,9 +15,12 @@
  * Nothing throws or unwinds across this boundary.  There is NO CPU fallback: without a gfx950 device
  * plume_init fails with -3.
  *
- * Threading: one plume_ctx is used by one host thread at a time; distinct contexts (one per GPU / per process
- * rank) are independent.  Multi-GPU = one context per device over a contiguous shard of the batch; the path has
- * no cross-device exchange, so no collective is involved.
+ * Threading: one plume_ctx is used by one host thread at a time; distinct contexts are independent and may be used
+ * concurrently from different threads, also on the same GPU.  Multi-GPU, two ways: (a) one process holding all the
+ * devices creates ONE context with plume_init_multi and passes whole batches to the host-pointer entry points, the
+ * library shards them; (b) one process per GPU (torch.distributed / MPI ranks) each creates a plume_init context for
+ * its device and passes its own contiguous shard.  The path has no cross-device exchange, so neither way involves a
+ * collective.
  */
 #ifndef PLUME_HIP_H
 #define PLUME_HIP_H
@@ -38,11 +41,22 @@ typedef struct plume_ctx plume_ctx;
 /* sign status bits (per item) */
 #define PLUME_STATUS_C_NOT_CANONICAL 1 /* SHA-256 digest was 0 or >= n: k256's sign panics here (rust-k256/src/randomizedsigner.rs:90-91), \
                                           arkworks' reduces (rust-arkworks/src/lib.rs:257); c is emitted reduced mod n */
-#define PLUME_STATUS_BAD_SCALAR 2      /* sk or r outside [1, n-1] (NonZeroScalar / SecretKey invariant), or a supplied pk not on the curve */
+#define PLUME_STATUS_BAD_SCALAR 2      /* sk or r outside [1, n-1] (NonZeroScalar / SecretKey invariant), a supplied pk not on the curve, or \
+                                          (device-resident calls) message offsets that decrease or reach past msgs_bytes */
 #define PLUME_STATUS_IDENTITY 4        /* H == identity (randomizedsigner.rs:61) or s == 0 (randomizedsigner.rs:95) */
 
 /* Create a context bound to HIP device `device_id` (>= 0).  Builds the generator's window table on the device. */
 int plume_init(plume_ctx** out, int device_id);
+/* Create a multi-device context: one shard (a complete single-device context with its own streams and workspace, driven by its own
+ * worker thread) per entry of device_ids (SURVEY.md §8b sketch, §8e).  Every HOST-POINTER entry point below then splits its batch
+ * evenly and contiguously -- shard d of g gets items [floor(d*n/g), floor((d+1)*n/g)) of every array -- runs the shards concurrently
+ * and writes each shard's results into its slice of the caller's output arrays; there is no cross-device exchange and no collective.
+ * A device id may repeat (two shards on one GPU overlap one's copies with the other's kernels).  The *_device entry points need
+ * a single-device context (device pointers belong to one GPU) and return PLUME_ERR_ARG on a multi-device one;
+ * plume_nullifier_first_occurrence runs on the first shard (every record has to meet every other). */
+int plume_init_multi(plume_ctx** out, const int* device_ids, int n_devices);
+/* 1 for plume_init contexts, n_devices for plume_init_multi contexts */
+int plume_num_shards(const plume_ctx* ctx);
 void plume_destroy(plume_ctx* ctx);
 /* Last error text of this thread (valid until the next failing call on the thread). */
 const char* plume_last_error(void);
@@ -54,6 +68,22 @@ int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
  * pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (three streams, two staging slots), so
  * for batches of several pieces only the first upload and the last download are exposed.  Results do not depend on it. */
 int plume_set_host_piece(plume_ctx* ctx, size_t items_per_piece);
+/* ... and of the FIRST piece of a call (default 1<<17, capped by the piece size): its upload is the only one no kernel hides. */
+int plume_set_host_first_piece(plume_ctx* ctx, size_t items);
+/* Host-pointer calls: caller arrays of at least `bytes` bytes that are not page-locked yet are registered (hipHostRegister) for the
+ * duration of the call; 0 (default) = never.  Registration costs more than one batch's copies save: callers that reuse their buffers
+ * should page-lock them ONCE with the helpers below instead. */
+int plume_set_host_register_min(plume_ctx* ctx, size_t bytes);
+
+/* ---- page-locked host memory ----------------------------------------------------------------------------------
+ * The host-pointer entry points accept any memory.  When the caller's arrays are page-locked the GPU's copy engines read and
+ * write them directly and every transfer overlaps the kernels of the neighbouring pieces; pageable arrays go through the
+ * runtime's staging copies and block the calling thread.  plume_host_alloc returns page-locked memory (NULL on failure);
+ * plume_host_register page-locks memory the caller already owns (e.g. a Rust Vec's buffer) until plume_host_unregister. */
+void* plume_host_alloc(size_t bytes);
+void plume_host_free(void* p);
+int plume_host_register(void* p, size_t bytes);
+int plume_host_unregister(void* p);
 
 /* ---- PlumeSignature::verify, batched  (rust-k256/src/lib.rs:93-145) -------------------------------------
  * version 1: V1 (v1specific = Some{r_point, hashed_to_curve_r}); version 2: V2 (r_point, hashed_to_curve_r NULL).
@@ -65,6 +95,20 @@ int plume_verify_batch(plume_ctx* ctx, int version, size_t n,
                        const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s,
                        const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
                        uint8_t* ok);
+
+/* ---- plume_arkworks' verify_non_zk, batched  (rust-arkworks/src/tests.rs:28-78; the verification the arkworks crate's tests and the
+ * circuit's witness checks use) -------------------------------------------------------------------------------------------------
+ * Inputs as the reference takes them: pk, message, PlumeSignaturePublic{s, nullifier}, PlumeSignaturePrivate{hashed_to_curve_r,
+ * r_point, digest_private}.  Differences from plume_verify_batch: the challenge c' = SHA256(..) mod n is hashed from the GIVEN
+ * r_point / hashed_to_curve_r (6 encodings for V1, 3 for V2: compute_c_v1 / compute_c_v2, rust-arkworks/src/lib.rs:120-163); BOTH
+ * equations s*G - digest_private*pk == r_point and s*H - digest_private*nullifier == hashed_to_curve_r are checked for V1 AND V2;
+ * s and digest_private are Fr elements, so zero is a value (>= n cannot be represented: ok = 0).
+ * ok[i] = 1 Ok(true), 0 Ok(false), 2 Err(HashToCurveError) (pk is the identity, rust-arkworks/src/lib.rs:99-101). */
+int plume_verify_non_zk_batch(plume_ctx* ctx, int version, size_t n,
+                              const uint8_t* msgs, const uint64_t* msg_off,
+                              const uint8_t* pk, const uint8_t* nullifier, const uint8_t* s,
+                              const uint8_t* r_point, const uint8_t* hashed_to_curve_r, const uint8_t* digest_private,
+                              uint8_t* ok);
 
 /* ---- verify with SEC1-compressed points (33-byte records) --------------------------------------------------
  * The wire format of the reference's serde / wasm layer (javascript/src/lib.rs:95-118,147-184; sec1_affine,
@@ -122,13 +166,23 @@ int plume_nullifier_first_occurrence(plume_ctx* ctx, size_t n, const uint8_t* nu
 /* ---- device-resident forms -------------------------------------------------------------------------------
  * Same semantics, but every data pointer is a DEVICE pointer on the context's GPU and the work is enqueued on
  * `stream` (a hipStream_t passed as void*; NULL = the context's own stream) without synchronising: the caller
- * orders and waits (e.g. torch.cuda streams/events).  msgs_bytes = msg_off[n] (total message bytes), needed
- * because the offsets live on the device.  n must not exceed the chunk size (plume_set_chunk). */
+ * orders and waits (e.g. torch.cuda streams/events).  n must not exceed the chunk size (plume_set_chunk).
+ * msgs_bytes = the size of the msgs buffer: the offsets live on the device, so the kernels check them -- an item whose offsets
+ * decrease or reach past msgs_bytes is rejected (verify: ok = 0; sign: PLUME_STATUS_BAD_SCALAR; hash_to_curve: identity) and its
+ * lane never reads msgs.
+ * Streams: the calls of one context share its workspace.  Each call first makes its stream wait (hipStreamWaitEvent) for the
+ * previous call's last kernel, so calls issued on DIFFERENT streams of one context are safe (they serialise on the workspace);
+ * outputs are ready when the stream the call was issued on reaches the end of the call.  One host thread per context at a time. */
 int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n,
                               const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                               const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s,
                               const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
                               uint8_t* ok, void* stream);
+int plume_verify_non_zk_batch_device(plume_ctx* ctx, int version, size_t n,
+                                     const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
+                                     const uint8_t* pk, const uint8_t* nullifier, const uint8_t* s,
+                                     const uint8_t* r_point, const uint8_t* hashed_to_curve_r, const uint8_t* digest_private,
+                                     uint8_t* ok, void* stream);
 int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_t n,
                                    const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                    const uint8_t* pk33, const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s,

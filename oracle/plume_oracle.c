@@ -463,6 +463,31 @@ static int verify_one(int version, const uint8_t *msg, size_t mlen, const uint8_
     return memcmp(cc.l, c.l, 32) == 0;                                                              /* lib.rs:127-143 */
 }
 
+/* plume_arkworks' verify_non_zk (rust-arkworks/src/tests.rs:28-78): 1 = Ok(true), 0 = Ok(false), 2 = Err(HashToCurveError) (pk is the identity:
+ * rust-arkworks/src/lib.rs:99-101).  s and digest_private are Fr elements (zero allowed); values the types cannot hold (>= n, coordinates >= p,
+ * points off the curve) give 0. */
+static int verify_non_zk_one(int version, const uint8_t *msg, size_t mlen, const uint8_t *pk_b, const uint8_t *nul_b, const uint8_t *s_b,
+                             const uint8_t *r_b, const uint8_t *hr_b, const uint8_t *dp_b) {
+    aff pk, nul, rp, hrp, h;
+    sc c, s, cc;
+    from_be32(s.l, s_b); from_be32(c.l, dp_b);
+    if (ge256(s.l, N_) || ge256(c.l, N_)) return 0;
+    if (!aff_from_bytes(&pk, pk_b) || !aff_from_bytes(&nul, nul_b) || !aff_from_bytes(&rp, r_b) || !aff_from_bytes(&hrp, hr_b)) return 0;
+    if (pk.inf) return 2;                                                                           /* tests.rs:36 -> lib.rs:99-101 */
+    plume_h2c(&h, msg, mlen, &pk);                                                                  /* tests.rs:36 */
+    uint8_t d[32]; int canon;
+    c_hash(d, version, &pk, &h, &nul, &rp, &hrp);                                                   /* tests.rs:40-51: the GIVEN r_point, hashed_to_curve_r */
+    sc_from_digest(&cc, d, &canon);                                                                 /* tests.rs:52 from_be_bytes_mod_order */
+    jac g, pkj, nulj, hj, t1, t2, rcalc, hrcalc;
+    aff ga; ga.x = FE_GX; ga.y = FE_GY; ga.inf = 0;
+    jac_from_aff(&g, &ga); jac_from_aff(&pkj, &pk); jac_from_aff(&nulj, &nul); jac_from_aff(&hj, &h);
+    jac_mul(&t1, &s, &g); jac_mul(&t2, &c, &pkj); jac_neg(&t2, &t2); jac_add(&rcalc, &t1, &t2);      /* tests.rs:55-57 */
+    if (!jac_eq_aff(&rcalc, &rp)) return 0;                                                         /* tests.rs:59-61 */
+    jac_mul(&t1, &s, &hj); jac_mul(&t2, &c, &nulj); jac_neg(&t2, &t2); jac_add(&hrcalc, &t1, &t2);   /* tests.rs:64-66 */
+    if (!jac_eq_aff(&hrcalc, &hrp)) return 0;                                                       /* tests.rs:68-70 */
+    return memcmp(cc.l, c.l, 32) == 0;                                                              /* tests.rs:73-75 */
+}
+
 static void sign_one(int version, const uint8_t *msg, size_t mlen, const uint8_t *sk_b, const uint8_t *r_b, const uint8_t *pk_in,
                      uint8_t *pk_o, uint8_t *nul_o, uint8_t *c_o, uint8_t *s_o, uint8_t *r_o, uint8_t *hr_o, uint8_t *h_o, uint8_t *status) {
     sc sk, r, c, s, t;
@@ -513,6 +538,8 @@ static void *worker(void *arg) {
         else if (j->kind == 1)
             sign_one(j->version, m, ml, j->a0 + 32 * i, j->a1 + 32 * i, j->a2 ? j->a2 + 64 * i : 0, j->o0 ? j->o0 + 64 * i : 0, j->o1 + 64 * i,
                      j->o2 + 32 * i, j->o3 + 32 * i, j->o4 + 64 * i, j->o5 + 64 * i, j->o6 ? j->o6 + 64 * i : 0, j->o7 + i);
+        else if (j->kind == 3)
+            j->o0[i] = (uint8_t)verify_non_zk_one(j->version, m, ml, j->a0 + 64 * i, j->a1 + 64 * i, j->a3 + 32 * i, j->a4 + 64 * i, j->a5 + 64 * i, j->a2 + 32 * i);
         else {
             aff pk, h;
             if (!aff_from_bytes(&pk, j->a0 + 64 * i)) { memset(j->o0 + 64 * i, 0, 64); continue; }
@@ -544,6 +571,16 @@ int oracle_verify_batch(int version, size_t n, const uint8_t *msgs, const uint64
     job j; memset(&j, 0, sizeof j);
     j.kind = 0; j.version = version; j.msgs = msgs; j.off = msg_off; j.a0 = pk; j.a1 = nullifier; j.a2 = c; j.a3 = s;
     j.a4 = version == 1 ? r_point : 0; j.a5 = version == 1 ? hashed_to_curve_r : 0; j.o0 = ok;
+    run(&j, n, nthreads);
+    return 0;
+}
+/* same argument meaning as plume_verify_non_zk_batch; ok: 1 Ok(true), 0 Ok(false), 2 Err */
+int oracle_verify_non_zk_batch(int version, size_t n, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *pk, const uint8_t *nullifier,
+                               const uint8_t *s, const uint8_t *r_point, const uint8_t *hashed_to_curve_r, const uint8_t *digest_private, uint8_t *ok, int nthreads) {
+    if ((version != 1 && version != 2) || !r_point || !hashed_to_curve_r) return -1;
+    job j; memset(&j, 0, sizeof j);
+    j.kind = 3; j.version = version; j.msgs = msgs; j.off = msg_off; j.a0 = pk; j.a1 = nullifier; j.a2 = digest_private; j.a3 = s;
+    j.a4 = r_point; j.a5 = hashed_to_curve_r; j.o0 = ok;
     run(&j, n, nthreads);
     return 0;
 }

@@ -290,8 +290,15 @@ def verify(version: int, msg: bytes, pk: Point, nul: Point, c: int, s: int,
     return c == int.from_bytes(digest, "big") % N                 # Scalar::reduce, :128,:139
 
 
+class HashToCurveError(Exception):
+    """rust-arkworks/src/lib.rs:99-101: `pk` shouldn't be the identity element"""
+
+
 def verify_non_zk(version: int, msg: bytes, pk: Point, nul: Point, s: int, r_point: Point, hr: Point, digest_private: int) -> bool:
-    """rust-arkworks/src/tests.rs:28-78: c' hashed from the GIVEN R, Hr; both EC equations checked for V1 and V2."""
+    """rust-arkworks/src/tests.rs:28-78: c' hashed from the GIVEN R, Hr; both EC equations checked for V1 and V2.
+    Raises HashToCurveError where the reference returns Err (pk = identity, tests.rs:36 -> lib.rs:99-101)."""
+    if pk is None:
+        raise HashToCurveError("`pk` shouldn't be the identity element")
     h = hash_to_curve(msg, pk)
     c2 = int.from_bytes(c_hash(version, pk, h, nul, r_point, hr), "big") % N
     if r_point != pt_add(pt_mul(s, G), pt_neg(pt_mul(digest_private, pk))):

@@ -92,6 +92,27 @@ def verify_batch(version, msgs_buf, msg_off, pk, nul, c, s, r_point=None, hr=Non
     return ok
 
 
+def verify_non_zk_batch(version, msgs_buf, msg_off, pk, nul, s, r_point, hr, digest_private, L=3):
+    n = len(msg_off) - 1
+    ok = np.full(n, 0xEE, dtype=np.uint8)
+    pk, nul, s, r_point, hr, digest_private = map(_aligned, (pk, nul, s, r_point, hr, digest_private))
+    rc = lib().ds_verify_non_zk_batch(C.c_int(version), C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), _p(pk), _p(nul), _p(s), _p(r_point), _p(hr),
+                                      _p(digest_private), _p(ok), C.c_int(L))
+    assert rc == 0
+    return ok
+
+
+def verify_batch_bounded(version, msgs_buf, msg_off, msgs_bytes, pk, nul, c, s, r_point=None, hr=None):
+    """explicit msgs buffer size: items whose offsets are malformed must be rejected without touching msgs"""
+    n = len(msg_off) - 1
+    ok = np.full(n, 0xEE, dtype=np.uint8)
+    pk, nul, c, s, r_point, hr = map(_aligned, (pk, nul, c, s, r_point, hr))
+    rc = lib().ds_verify_batch_bounded(C.c_int(version), C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), C.c_uint64(msgs_bytes), _p(pk), _p(nul),
+                                       _p(c), _p(s), _p(r_point), _p(hr), _p(ok))
+    assert rc == 0
+    return ok
+
+
 def verify_batch_sec1(version, msgs_buf, msg_off, pk33, nul33, c, s, r33=None, hr33=None):
     n = len(msg_off) - 1
     ok = np.full(n, 0xEE, dtype=np.uint8)

@@ -59,3 +59,22 @@ def fuzz_verify_batch(ver, signed, b, seed):
             t = v[a][i].copy(); v[a][i] = v[bb][i]; v[bb][i] = t
         # 13..15: honest
     return v
+
+
+def fuzz_non_zk_batch(ver, signed, b, seed):
+    """verify_non_zk inputs from a signed batch: honest items and field-level mutations incl. what only the non-zk semantics allow
+    (zero scalars, identity pk -> Err).  Expected results come from the C oracle."""
+    rng = random.Random(seed)
+    v = fuzz_verify_batch(ver, signed, b, seed)           # same mutation kinds on pk / nullifier / c / s / R / Hr / msg
+    n = len(b["off"]) - 1
+    for i in range(n):
+        k = rng.randrange(24)
+        if k == 0:                                         # s = 0, c = 0 with identity R, Hr: both equations hold, the hash decides
+            v["s"][i] = 0; v["c"][i] = 0; v["r_point"][i] = 0; v["hashed_to_curve_r"][i] = 0
+        elif k == 1:
+            v["s"][i] = 0
+        elif k == 2:
+            v["c"][i] = 0
+        elif k == 3:
+            v["pk"][i] = 0                                 # Err(HashToCurveError)
+    return v

@@ -49,6 +49,17 @@ def verify_batch(version, msgs_buf, msg_off, pk, nul, c, s, r_point=None, hr=Non
     return ok
 
 
+def verify_non_zk_batch(version, msgs_buf, msg_off, pk, nul, s, r_point, hr, digest_private, nthreads=1):
+    """rust-arkworks/src/tests.rs:28-78; 1 Ok(true), 0 Ok(false), 2 Err(HashToCurveError)"""
+    n = len(msg_off) - 1
+    ok = np.zeros(n, dtype=np.uint8)
+    lib().oracle_verify_non_zk_batch.restype = C.c_int
+    rc = lib().oracle_verify_non_zk_batch(C.c_int(version), C.c_size_t(n), _p(msgs_buf), msg_off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          _p(pk), _p(nul), _p(s), _p(r_point), _p(hr), _p(digest_private), _p(ok), C.c_int(nthreads))
+    assert rc == 0, rc
+    return ok
+
+
 def sign_batch(version, msgs_buf, msg_off, sk, r, pk_in=None, nthreads=1):
     n = len(msg_off) - 1
     o = {k: np.zeros((n, w), dtype=np.uint8) for k, w in

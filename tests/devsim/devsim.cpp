@@ -124,7 +124,17 @@ static const uint32_t B = 8;
 
 static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
                        const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags, const uint8_t* rpt33 = nullptr,
-                       const uint8_t* hr33 = nullptr);
+                       const uint8_t* hr33 = nullptr, int mode = PLUME_MODE_VERIFY, uint64_t msgs_bytes = ~0ull);
+// plume_arkworks' verify_non_zk through the same per-lane bodies (PLUME_MODE_NON_ZK); c = digest_private
+int ds_verify_non_zk_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* s,
+                           const uint8_t* rpt, const uint8_t* hr, const uint8_t* digest_private, uint8_t* ok, int L) {
+    return verify_impl(version, n, msgs, msg_off, pk, nul, digest_private, s, rpt, hr, ok, L, nullptr, nullptr, nullptr, PLUME_MODE_NON_ZK);
+}
+// verify with an explicit msgs buffer size (malformed offsets must reject the item without reading out of bounds)
+int ds_verify_batch_bounded(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, uint64_t msgs_bytes, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
+                            const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok) {
+    return verify_impl(version, n, msgs, msg_off, pk, nul, c, s, rpt, hr, ok, 3, nullptr, nullptr, nullptr, PLUME_MODE_VERIFY, msgs_bytes);
+}
 int ds_verify_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
                     const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L) {
     return verify_impl(version, n, msgs, msg_off, pk, nul, c, s, rpt, hr, ok, L, nullptr);
@@ -142,12 +152,14 @@ int ds_verify_batch_sec1(int version, uint32_t n, const uint8_t* msgs, const uin
     return verify_impl(version, n, msgs, msg_off, d.out[0], d.out[1], c, s, nullptr, nullptr, ok, 3, pre.data(), version == 1 ? r33 : nullptr, version == 1 ? hr33 : nullptr);
 }
 static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
-                       const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags, const uint8_t* rpt33, const uint8_t* hr33) {
+                       const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags, const uint8_t* rpt33, const uint8_t* hr33, int mode,
+                       uint64_t msgs_bytes) {
     if (version != 1 && version != 2) return -1;
     std::vector<uint32_t> gtab; build_gtab(gtab);
     std::vector<uint32_t> bases(PLUME_JAC_WORDS * 3 * (size_t)n), tab((size_t)3 * n * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2 * (size_t)n);
     std::vector<uint8_t> jobflags(3 * (size_t)n), itemflags(n), resinf(2 * (size_t)n);
     VerifyArgs a;
+    a.mode = mode; a.msgs_bytes = msgs_bytes == ~0ull ? msg_off[n] : msgs_bytes;
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags; a.rpt33 = rpt33; a.hr33 = hr33;
     a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data(); a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data();
     a.gtab = gtab.data();
@@ -157,7 +169,7 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);
     for (uint32_t eq = 0; eq < 2; eq++)
         for (uint32_t i = 0; i < n; i++) verify_msm(a, i, eq, a.gtab, dig.data() + (i % B), B);
-    if (version == 2) {                                   // mirrors launch_normalize
+    if (version == 2 && mode == PLUME_MODE_VERIFY) {      // mirrors launch_normalize
         const size_t npts = 2 * (size_t)n, nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;
         for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.res, a.resinf, npts, lane, nlanes);
     }
@@ -173,7 +185,7 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_JAC_WORDS * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
     std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(n), itemflags(n);
     SignArgs a; memset(&a, 0, sizeof a);
-    a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.sk = sk; a.r = r; a.pk_in = pk_in;
+    a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msg_off[n]; a.sk = sk; a.r = r; a.pk_in = pk_in;
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
     a.gres = gres.data(); a.gresinf = gresinf.data(); a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
     a.pkaff = pkaff.data(); a.tab = tab.data(); a.hres = hres.data(); a.hresinf = hresinf.data(); a.gtab = gtab.data(); a.gcomb = gcomb.data();
@@ -207,7 +219,7 @@ int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[6
     std::vector<uint32_t> bases(PLUME_JAC_WORDS * 3), tab(3 * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2);
     std::vector<uint8_t> jobflags(3), itemflags(1, 0), resinf(2);
     VerifyArgs a; memset(&a, 0, sizeof a);
-    a.version = 2; a.n = 1; a.c = cb; a.s = sb; a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
+    a.version = 2; a.mode = PLUME_MODE_VERIFY; a.n = 1; a.c = cb; a.s = sb; a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
     a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data(); a.gtab = gtab.data();
     jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
     for (int j = 0; j < 3; j++) { st_jac_soa(a.bases, 3, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
@@ -223,7 +235,7 @@ int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[6
 }
 
 int ds_h2c_batch(uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out) {
-    H2cArgs a; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.h_out = h_out;
+    H2cArgs a; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msg_off[n]; a.pk = pk; a.h_out = h_out;
     for (uint32_t i = 0; i < n; i++) h2c_only(a, i);
     return 0;
 }
@@ -261,6 +273,7 @@ int ds_nullifier_first_occurrence(uint32_t n, const uint8_t* nul, const uint8_t*
     a.n = n; a.nul = nul; a.live = live; a.ids = ids; a.first = first;
     const uint32_t m = dedup_table_size(n);
     a.mask = m - 1;
+    a.key[0] = 0x1234567u ^ n; a.key[1] = 0x9E3779B9u;
     std::vector<uint32_t> slots(m), myslot(n ? n : 1);
     std::vector<unsigned long long> minid(m);
     unsigned long long cnt = 0;

@@ -66,6 +66,12 @@ class FakeEngine:
         return OC.verify_batch(version, np.ascontiguousarray(msgs), np.ascontiguousarray(off), f(pk, 64), f(nul, 64), f(c, 32), f(s, 32), f(r_point, 64), f(hr, 64))
 
 
+    def verify_non_zk_batch(self, version, msgs, off, pk, nul, s, r_point, hr, digest_private):
+        from tests import _oracle_c as OC
+        f = lambda a, w: np.ascontiguousarray(a).reshape(-1, w)  # noqa: E731
+        return OC.verify_non_zk_batch(version, np.ascontiguousarray(msgs), np.ascontiguousarray(off), f(pk, 64), f(nul, 64), f(s, 32), f(r_point, 64), f(hr, 64), f(digest_private, 32))
+
+
 def test_facade_marshalling_and_reference_shapes(kats):
     import zk_nullifier_sig_amd as plume
     v = kats["plume_vector"]
@@ -89,6 +95,11 @@ def test_facade_marshalling_and_reference_shapes(kats):
     assert s2.v1specific is None and s2.c.to_bytes().hex() == v["c_v2"] and s2.verify(eng)
     pub, prv = plume.sign_with_r((s1.pk, sk.value), msg, int(v["r"], 16), plume.PlumeVersion.V2, eng)
     assert prv.digest_private == int(v["c_v2"], 16) and pub.s == int(v["s_v2"], 16) and pub.variant is plume.PlumeVersion.V2
+    # verify_non_zk (rust-arkworks/src/tests.rs:28-78): Ok(true) / Ok(false) / Err
+    assert plume.verify_non_zk((pub, prv), s1.pk, msg, plume.PlumeVersion.V2, eng) is True
+    assert plume.verify_non_zk((pub, prv), s1.pk, msg, plume.PlumeVersion.V1, eng) is False
+    with pytest.raises(plume.SignatureError):
+        plume.verify_non_zk((pub, prv), plume.AffinePoint(), msg, plume.PlumeVersion.V2, eng)
     prv.zeroize()
     assert prv.digest_private == 0 and prv.r_point.is_identity
     # type invariants of the Rust types

@@ -264,6 +264,46 @@ def test_fuzzed_verify_batch_vs_oracle(ver):
     assert 0.2 * n < int(got.sum()) < 0.8 * n
 
 
+NONZK = json.loads((Path(__file__).parent / "golden" / "golden_non_zk.json").read_text())["items"]
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_verify_non_zk_golden_and_fuzz(ver):
+    """device code on the host, PLUME_MODE_NON_ZK (rust-arkworks/src/tests.rs:28-78): the Python oracle's vectors (incl. Err = 2, zero scalars),
+    then 256 fuzzed items against the C oracle"""
+    from tests import _fuzz
+    from tests.test_oracle_c import non_zk_args
+    items = [it for it in NONZK if it["version"] == ver]
+    ok = D.verify_non_zk_batch(ver, *non_zk_args(items))
+    bad = [(it["note"], int(o), it["ok"]) for it, o in zip(items, ok) if int(o) != it["ok"]]
+    assert not bad, bad
+    n = 256
+    b = synth.sign_inputs(n, start=810000)
+    signed = OC.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"], nthreads=8)
+    v = _fuzz.fuzz_non_zk_batch(ver, signed, b, seed=11 + ver)
+    args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["s"], v["r_point"], v["hashed_to_curve_r"], v["c"])
+    got = D.verify_non_zk_batch(*args)
+    want = OC.verify_non_zk_batch(*args, nthreads=8)
+    assert np.array_equal(got, want), [(int(i), int(got[i]), int(want[i])) for i in np.nonzero(got != want)[0][:10]]
+    assert {int(x) for x in got} == {0, 1, 2} and 0.15 * n < int((got == 1).sum()) < 0.8 * n
+
+
+def test_malformed_message_offsets_reject_without_reading():
+    """device-resident calls hand the kernels device-side offsets: decreasing offsets, offsets past msgs_bytes and spans over 4 GiB must reject
+    the ITEM (ok = 0) and never dereference msgs (here: msgs is a 64-byte buffer, any such read would be far out of bounds)"""
+    n = 8
+    b = synth.sign_inputs(n, start=820000)
+    signed = OC.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"], nthreads=4)
+    args = lambda off, nbytes: D.verify_batch_bounded(1, b["msgs"], off, nbytes, signed["pk"], signed["nullifier"], signed["c"], signed["s"],  # noqa: E731
+                                                      signed["r_point"], signed["hashed_to_curve_r"])
+    assert list(args(b["off"], 32 * n)) == [1] * n
+    off = b["off"].copy(); off[3] = 2**40                  # item 2 reaches far past the buffer, item 3 starts there and "ends" before it starts
+    assert list(args(off, 32 * n)) == [1, 1, 0, 0, 1, 1, 1, 1]
+    assert list(args(b["off"], 32 * 5 + 1)) == [1] * 5 + [0] * 3      # msgs_bytes cuts items 5.. off
+    off = b["off"].copy(); off[8] = off[7] + 2**32 + 5     # a span the 32-bit SHA front end cannot take
+    assert list(args(off, 2**33)) == [1] * 7 + [0]
+
+
 @pytest.mark.parametrize("ver", [1, 2])
 def test_small_secret_keys_hit_the_exceptional_additions(ver):
     """pk = +-G, +-2G, ... makes s*G - c*pk (and s*H - c*nullifier) run into p == +-q inside the multi-scalar chain.  The hot loop

@@ -87,3 +87,22 @@ def test_golden_edge(ver):
                          OC.arr(items, "r_point", 64) if ver == 1 else None, OC.arr(items, "hashed_to_curve_r", 64) if ver == 1 else None, nthreads=8)
     bad = [(it["note"], int(o), it["ok"]) for it, o in zip(items, ok) if int(o) != it["ok"]]
     assert not bad, bad
+
+
+NONZK = json.loads((Path(__file__).parent / "golden" / "golden_non_zk.json").read_text())["items"]
+
+
+def non_zk_args(items):
+    mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+    return (mb, off, OC.arr(items, "pk", 64), OC.arr(items, "nullifier", 64), OC.arr(items, "s", 32), OC.arr(items, "r_point", 64),
+            OC.arr(items, "hashed_to_curve_r", 64), OC.arr(items, "digest_private", 32))
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_golden_verify_non_zk(ver):
+    """plume_arkworks' verify_non_zk (rust-arkworks/src/tests.rs:28-78): C oracle == Python oracle's vectors, incl. Err (2)"""
+    items = [it for it in NONZK if it["version"] == ver]
+    ok = OC.verify_non_zk_batch(ver, *non_zk_args(items), nthreads=8)
+    bad = [(it["note"], int(o), it["ok"]) for it, o in zip(items, ok) if int(o) != it["ok"]]
+    assert not bad, bad
+    assert {int(o) for o in ok} == {0, 1, 2}

@@ -51,6 +51,15 @@ def _load():
     lib.plume_microbench_last_ticks.restype = C.c_double
     lib.plume_microbench_last_ticks.argtypes = [C.POINTER(C.c_float)]
     lib.plume_init.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.plume_init_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
+    lib.plume_num_shards.argtypes = [C.c_void_p]
+    lib.plume_set_host_first_piece.argtypes = [C.c_void_p, C.c_size_t]
+    lib.plume_set_host_register_min.argtypes = [C.c_void_p, C.c_size_t]
+    lib.plume_host_alloc.restype = C.c_void_p
+    lib.plume_host_alloc.argtypes = [C.c_size_t]
+    lib.plume_host_free.argtypes = [C.c_void_p]
+    lib.plume_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.plume_host_unregister.argtypes = [C.c_void_p]
     lib.plume_destroy.argtypes = [C.c_void_p]
     lib.plume_set_chunk.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_set_host_piece.argtypes = [C.c_void_p, C.c_size_t]
@@ -58,6 +67,8 @@ def _load():
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
     lib.plume_verify_batch.argtypes = [vp, i, sz] + [vp] * 9
     lib.plume_verify_batch_sec1.argtypes = [vp, i, sz] + [vp] * 9
+    lib.plume_verify_non_zk_batch.argtypes = [vp, i, sz] + [vp] * 9
+    lib.plume_verify_non_zk_batch_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 8
     lib.plume_verify_batch_sec1_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 8
     lib.plume_sign_batch.argtypes = [vp, i, sz] + [vp] * 12
     lib.plume_sign_batch_sec1.argtypes = [vp, i, sz] + [vp] * 12
@@ -74,7 +85,9 @@ def _load():
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
+    return ["plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_host_alloc", "plume_host_free", "plume_host_register",
+            "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device",
+            "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
             "plume_hash_to_curve_batch", "plume_nullifier_first_occurrence", "plume_nullifier_first_occurrence_device", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
             "plume_last_stage_times", "plume_microbench", "plume_microbench_last_ticks"]
 
@@ -99,8 +112,40 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def pinned_empty(shape, dtype=np.uint8):
+    """numpy array in page-locked host memory (plume_host_alloc): the copy engines read / write it directly, so the host-pointer calls
+    overlap every transfer with the neighbouring pieces' kernels.  Freed when the array (and every view of it) is gone."""
+    lib = _load()
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(x) for x in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    p = lib.plume_host_alloc(max(nbytes, 1))
+    if not p:
+        raise PlumeHipError(f"plume_host_alloc({nbytes}) failed: {lib.plume_last_error().decode()}")
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def __del__(self):
+            try:
+                lib.plume_host_free(self.ptr)
+            except Exception:
+                pass
+
+    buf = (C.c_uint8 * max(nbytes, 1)).from_address(p)
+    buf._plume_owner = _Owner(p)   # the ctypes buffer is the base object of the numpy array: it keeps the owner alive
+    return np.frombuffer(buf, dtype=np.uint8, count=nbytes).view(dtype).reshape(shape)
+
+
+def pinned_copy(a):
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
 class Engine:
-    """One context on one GPU (include/plume_hip.h: plume_ctx).  One Engine per process rank / device."""
+    """One context (include/plume_hip.h: plume_ctx).  Engine(k) = one GPU (plume_init; one Engine per process rank / device);
+    Engine([k0, k1, ..]) = a multi-device context (plume_init_multi): the host-pointer calls shard every batch over the devices."""
 
     def __init__(self, device_id=None):
         lib = _load()
@@ -108,11 +153,23 @@ class Engine:
             device_id = int(os.environ.get("LOCAL_RANK", "0"))
         self._lib = lib
         self._ctx = C.c_void_p()
-        rc = lib.plume_init(C.byref(self._ctx), int(device_id))
+        if isinstance(device_id, (list, tuple)):
+            ids = (C.c_int * len(device_id))(*[int(d) for d in device_id])
+            rc = lib.plume_init_multi(C.byref(self._ctx), ids, len(device_id))
+            what = f"plume_init_multi(devices {list(device_id)})"
+            self.device_ids = [int(d) for d in device_id]
+            self.device_id = self.device_ids[0] if self.device_ids else 0
+        else:
+            rc = lib.plume_init(C.byref(self._ctx), int(device_id))
+            what = f"plume_init(device {device_id})"
+            self.device_id = int(device_id)
+            self.device_ids = [self.device_id]
         if rc != 0:
             self._ctx = None
-            raise PlumeHipError(f"plume_init(device {device_id}) failed ({rc}): {lib.plume_last_error().decode()}")
-        self.device_id = int(device_id)
+            raise PlumeHipError(f"{what} failed ({rc}): {lib.plume_last_error().decode()}")
+
+    def num_shards(self):
+        return int(self._lib.plume_num_shards(self._ctx))
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -139,8 +196,28 @@ class Engine:
         """host-pointer calls: items per pipelined piece (upload / compute / download overlap across pieces)"""
         self._chk(self._lib.plume_set_host_piece(self._ctx, int(n)), "plume_set_host_piece")
 
+    def set_host_first_piece(self, n):
+        self._chk(self._lib.plume_set_host_first_piece(self._ctx, int(n)), "plume_set_host_first_piece")
+
+    def set_host_register_min(self, nbytes):
+        """host-pointer calls: page-lock pageable caller arrays of at least nbytes for the duration of the call (0 = never)"""
+        self._chk(self._lib.plume_set_host_register_min(self._ctx, int(nbytes)), "plume_set_host_register_min")
+
     # ------------------------------------------------------------------ host-pointer API (numpy in, numpy out)
-    def verify_batch(self, version, msgs, msg_off, pk, nullifier, c, s, r_point=None, hashed_to_curve_r=None):
+    def verify_non_zk_batch(self, version, msgs, msg_off, pk, nullifier, s, r_point, hashed_to_curve_r, digest_private, out=None):
+        """plume_arkworks' verify_non_zk (rust-arkworks/src/tests.rs:28-78), batched: 1 Ok(true), 0 Ok(false), 2 Err(HashToCurveError)"""
+        n = len(msg_off) - 1
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
+        pk, nullifier, s = _np(pk, 64, n, "pk"), _np(nullifier, 64, n, "nullifier"), _np(s, 32, n, "s")
+        r_point, hashed_to_curve_r = _np(r_point, 64, n, "r_point"), _np(hashed_to_curve_r, 64, n, "hashed_to_curve_r")
+        digest_private = _np(digest_private, 32, n, "digest_private")
+        ok = np.zeros(n, dtype=np.uint8) if out is None else out
+        self._chk(self._lib.plume_verify_non_zk_batch(self._ctx, int(version), n, _ptr(msgs), _ptr(msg_off), _ptr(pk), _ptr(nullifier), _ptr(s), _ptr(r_point),
+                                                      _ptr(hashed_to_curve_r), _ptr(digest_private), _ptr(ok)), "plume_verify_non_zk_batch")
+        return ok
+
+    def verify_batch(self, version, msgs, msg_off, pk, nullifier, c, s, r_point=None, hashed_to_curve_r=None, out=None):
         n = len(msg_off) - 1
         msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
         msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
@@ -151,7 +228,7 @@ class Engine:
             r_point, hashed_to_curve_r = _np(r_point, 64, n, "r_point"), _np(hashed_to_curve_r, 64, n, "hashed_to_curve_r")
         else:
             r_point = hashed_to_curve_r = None
-        ok = np.zeros(n, dtype=np.uint8)
+        ok = np.zeros(n, dtype=np.uint8) if out is None else out
         self._chk(self._lib.plume_verify_batch(self._ctx, int(version), n, _ptr(msgs), _ptr(msg_off), _ptr(pk), _ptr(nullifier), _ptr(c), _ptr(s),
                                                _ptr(r_point), _ptr(hashed_to_curve_r), _ptr(ok)), "plume_verify_batch")
         return ok
@@ -173,15 +250,16 @@ class Engine:
                                                     _ptr(r_point33), _ptr(hashed_to_curve_r33), _ptr(ok)), "plume_verify_batch_sec1")
         return ok
 
-    def sign_batch(self, version, msgs, msg_off, sk, r, pk_in=None):
+    def sign_batch(self, version, msgs, msg_off, sk, r, pk_in=None, out=None):
+        """out: optional dict of preallocated arrays (pk, nullifier, c, s, r_point, hashed_to_curve_r, status), e.g. page-locked ones"""
         n = len(msg_off) - 1
         msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
         msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
         sk, r = _np(sk, 32, n, "sk"), _np(r, 32, n, "r")
         pk_in = None if pk_in is None else _np(pk_in, 64, n, "pk_in")
-        o = {k: np.zeros((n, w), dtype=np.uint8) for k, w in
-             [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
-        status = np.zeros(n, dtype=np.uint8)
+        o = out if out is not None else {k: np.zeros((n, w), dtype=np.uint8) for k, w in
+                                         [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
+        status = o["status"] if out is not None else np.zeros(n, dtype=np.uint8)
         self._chk(self._lib.plume_sign_batch(self._ctx, int(version), n, _ptr(msgs), _ptr(msg_off), _ptr(sk), _ptr(r), _ptr(pk_in), _ptr(o["pk"]),
                                              _ptr(o["nullifier"]), _ptr(o["c"]), _ptr(o["s"]), _ptr(o["r_point"]), _ptr(o["hashed_to_curve_r"]),
                                              _ptr(status)), "plume_sign_batch")
@@ -238,6 +316,13 @@ class Engine:
         d = self._dp
         self._chk(self._lib.plume_verify_batch_device(self._ctx, int(version), int(n), d(msgs), d(msg_off), int(msgs_bytes), d(pk), d(nullifier), d(c), d(s),
                                                       d(r_point), d(hashed_to_curve_r), d(ok), C.c_void_p(st)), "plume_verify_batch_device")
+
+    def verify_non_zk_batch_device(self, version, n, msgs, msg_off, msgs_bytes, pk, nullifier, s, r_point, hashed_to_curve_r, digest_private, ok, stream=None):
+        import torch
+        st = (stream or torch.cuda.current_stream(self.device_id)).cuda_stream
+        d = self._dp
+        self._chk(self._lib.plume_verify_non_zk_batch_device(self._ctx, int(version), int(n), d(msgs), d(msg_off), int(msgs_bytes), d(pk), d(nullifier), d(s), d(r_point),
+                                                             d(hashed_to_curve_r), d(digest_private), d(ok), C.c_void_p(st)), "plume_verify_non_zk_batch_device")
 
     def verify_batch_sec1_device(self, version, n, msgs, msg_off, msgs_bytes, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, ok, stream=None):
         import torch

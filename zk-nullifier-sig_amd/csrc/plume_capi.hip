@@ -3,10 +3,15 @@
 // fallback of any kind in this library.
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/plume_hip.h"
@@ -59,11 +64,29 @@ struct HostSlot {
     bool in_flight = false;
 };
 
+// one worker thread per shard of a multi-device context: it binds the shard's device once and then runs the jobs handed to it
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = false, quit = false;
+    int rc = 0;
+    std::string err;
+};
+
 struct plume_ctx {
     int device = 0;
     hipStream_t stream = nullptr, up = nullptr, down = nullptr;   // kernels / host->HBM / HBM->host
+    hipEvent_t ws_free = nullptr;     // recorded behind the last kernel of every device-resident call: the next call's stream waits on it before it
+    bool ws_used = false;             // touches the per-context workspace, so calls on DIFFERENT streams of one context cannot race on that scratch
     size_t chunk = (size_t)1 << 20;
     size_t host_piece = (size_t)1 << 18;                            // host-pointer calls: items per pipelined piece
+    size_t host_first_piece = (size_t)1 << 17;                      // ... of the first piece: its upload is the only one no kernel hides
+    size_t host_register_min = 0;                                   // host-pointer calls: page-lock caller arrays of at least this many bytes for the call (0 = never)
+    // multi-device parent (plume_init_multi): the shards are complete single-device contexts, one worker thread each; a parent owns no GPU state
+    std::vector<plume_ctx*> shards;
+    std::vector<Worker*> workers;
     HostSlot slot[2];
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
@@ -75,39 +98,67 @@ struct plume_ctx {
 
 static int bind(plume_ctx* ctx) {
     if (!ctx) return fail(PLUME_ERR_ARG, "null context");
+    if (!ctx->shards.empty()) return fail(PLUME_ERR_ARG, "device-resident entry points need a single-device context (plume_init): device pointers belong to one GPU");
     HIPCHK(hipSetDevice(ctx->device));
+    return 0;
+}
+// Workspace ordering for the device-resident entry points: every call leaves ws_free behind its last kernel, and the next call's stream
+// waits on it first.  Calls on one stream are ordered anyway; this makes calls on DIFFERENT streams of one context safe too.
+static int ws_acquire(plume_ctx* ctx, hipStream_t st) {
+    if (ctx->ws_used) HIPCHK(hipStreamWaitEvent(st, ctx->ws_free, 0));
+    return 0;
+}
+static int ws_release(plume_ctx* ctx, hipStream_t st) {
+    HIPCHK(hipEventRecord(ctx->ws_free, st));
+    ctx->ws_used = true;
     return 0;
 }
 
 extern "C" const char* plume_last_error(void) { return g_err.c_str(); }
 extern "C" const char* plume_version(void) { return "plume_hip 0.1 gfx950"; }
 
-extern "C" int plume_init(plume_ctx** out, int device_id) {
-    if (!out || device_id < 0) return fail(PLUME_ERR_ARG, "plume_init: bad argument");
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0) return fail(PLUME_ERR_NODEV, "no HIP device visible (this library has no CPU fallback)");
-    if (device_id >= ndev) return fail(PLUME_ERR_ARG, "device id out of range");
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device_id));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(PLUME_ERR_NODEV, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
-    plume_ctx* ctx = new plume_ctx();
-    ctx->device = device_id;
+static void destroy_single(plume_ctx* ctx) {
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->up) (void)hipStreamSynchronize(ctx->up);
+    if (ctx->down) (void)hipStreamSynchronize(ctx->down);
+    for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
+                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
+        b->release();
+    for (HostSlot& sl : ctx->slot) {
+        sl.msgs.release(); sl.off.release();
+        for (DevBuf& b : sl.in) b.release();
+        for (DevBuf& b : sl.out) b.release();
+        for (hipEvent_t e : {sl.ready, sl.computed, sl.drained}) if (e) (void)hipEventDestroy(e);
+    }
+    ctx->timer.destroy();
+    if (ctx->ws_free) (void)hipEventDestroy(ctx->ws_free);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->up) (void)hipStreamDestroy(ctx->up);
+    if (ctx->down) (void)hipStreamDestroy(ctx->down);
+    delete ctx;
+}
+
+// everything plume_init does after the context object exists; any failure leaves a context that destroy_single() can release
+static int init_single(plume_ctx* ctx) {
+    HIPCHK(hipSetDevice(ctx->device));
     if (const char* e = std::getenv("PLUME_JOBS_PER_LANE")) { int v = std::atoi(e); if (v >= 1 && v <= 64) { ctx->jobs_per_lane = v; ctx->jobs_per_lane_forced = true; } }   // tuning knob
-    HIPCHK(hipSetDevice(device_id));
     if (const char* e = std::getenv("PLUME_HOST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_piece = (size_t)v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_HOST_FIRST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_first_piece = (size_t)v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->down, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ws_free, hipEventDisableTiming));
     for (HostSlot& sl : ctx->slot) {
         HIPCHK(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
     }
-    // generator wide window table (1..128)*G: one lane, once
+    // the generator's tables: the verifier's wide window table (1..2^(W-1))*G and the signer's doubling-free comb, built once on the device
     if (ctx->gtab.ensure((size_t)PLUME_GTAB_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(PLUME_JAC_WORDS * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64) ||
-        ctx->tabscr.ensure((size_t)(PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES > PLUME_GTAB_ENTRIES ? PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES : PLUME_GTAB_ENTRIES) * PLUME_TAB_SCR_WORDS * 4)) { delete ctx; return PLUME_ERR_HIP; }
+        ctx->tabscr.ensure((size_t)(PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES > PLUME_GTAB_ENTRIES ? PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES : PLUME_GTAB_ENTRIES) * PLUME_TAB_SCR_WORDS * 4))
+        return PLUME_ERR_HIP;
     uint32_t hb[PLUME_JAC_WORDS];
     {
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
@@ -122,41 +173,162 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
     launch_gcomb(ctx->gcomb.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->tabscr.as<uint32_t>(), ctx->stream);   // fixed-base comb for the signer
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static int check_device(int device_id) {
+    if (device_id < 0) return fail(PLUME_ERR_ARG, "negative device id");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(PLUME_ERR_NODEV, "no HIP device visible (this library has no CPU fallback)");
+    if (device_id >= ndev) return fail(PLUME_ERR_ARG, "device id out of range");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PLUME_ERR_NODEV, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    return 0;
+}
+
+extern "C" int plume_init(plume_ctx** out, int device_id) {
+    if (!out) return fail(PLUME_ERR_ARG, "plume_init: bad argument");
+    *out = nullptr;
+    if (int rc = check_device(device_id)) return rc;
+    plume_ctx* ctx = new plume_ctx();
+    ctx->device = device_id;
+    if (int rc = init_single(ctx)) { const std::string keep = g_err; destroy_single(ctx); g_err = keep; return rc; }
     *out = ctx;
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------- multi-device contexts
+static void worker_main(Worker* w, int device) {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+        if (w->quit) return;
+        std::function<int()> job = std::move(w->job);
+        w->has_job = false;
+        lk.unlock();
+        g_err.clear();
+        const int rc = job();
+        lk.lock();
+        w->rc = rc; w->err = g_err; w->done = true;
+        w->cv.notify_all();
+    }
+}
+static void worker_post(Worker* w, std::function<int()> job) {
+    std::lock_guard<std::mutex> lk(w->m);
+    w->job = std::move(job); w->has_job = true; w->done = false;
+    w->cv.notify_all();
+}
+static int worker_wait(Worker* w, std::string& err) {
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv.wait(lk, [&] { return w->done; });
+    err = w->err;
+    return w->rc;
+}
+static void destroy_multi(plume_ctx* ctx) {
+    for (Worker* w : ctx->workers) {
+        { std::lock_guard<std::mutex> lk(w->m); w->quit = true; w->cv.notify_all(); }
+        if (w->th.joinable()) w->th.join();
+        delete w;
+    }
+    for (plume_ctx* sh : ctx->shards) destroy_single(sh);
+    delete ctx;
+}
+
+// Run f(shard context, lo, hi) for the contiguous even split [floor(d*n/g), floor((d+1)*n/g)) of [0, n) on every shard's worker thread
+//  and wait for all of them; the first failure (in shard order) is the call's result.
+template <class F>
+static int for_shards(plume_ctx* ctx, size_t n, F f) {
+    const size_t g = ctx->shards.size();
+    for (size_t d = 0; d < g; d++) {
+        const size_t lo = n * d / g, hi = n * (d + 1) / g;
+        plume_ctx* sh = ctx->shards[d];
+        worker_post(ctx->workers[d], [=]() -> int { return lo < hi ? f(sh, lo, hi) : 0; });
+    }
+    int rc = 0;
+    std::string err, first;
+    for (size_t d = 0; d < g; d++) {
+        const int r = worker_wait(ctx->workers[d], err);
+        if (r != 0 && rc == 0) { rc = r; first = "shard " + std::to_string(d) + " (device " + std::to_string(ctx->shards[d]->device) + "): " + err; }
+    }
+    return rc ? fail(rc, first) : 0;
+}
+
+extern "C" int plume_init_multi(plume_ctx** out, const int* device_ids, int n_devices) {
+    if (!out || !device_ids || n_devices <= 0 || n_devices > 64) return fail(PLUME_ERR_ARG, "plume_init_multi: bad argument");
+    *out = nullptr;
+    for (int d = 0; d < n_devices; d++) if (int rc = check_device(device_ids[d])) return rc;
+    plume_ctx* ctx = new plume_ctx();
+    ctx->device = device_ids[0];
+    for (int d = 0; d < n_devices; d++) {
+        plume_ctx* sh = new plume_ctx();
+        sh->device = device_ids[d];
+        ctx->shards.push_back(sh);
+        if (int rc = init_single(sh)) { const std::string keep = g_err; destroy_multi(ctx); g_err = keep; return rc; }
+    }
+    for (int d = 0; d < n_devices; d++) {
+        Worker* w = new Worker();
+        ctx->workers.push_back(w);
+        w->th = std::thread(worker_main, w, device_ids[d]);
+    }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" int plume_num_shards(const plume_ctx* ctx) { return ctx ? (ctx->shards.empty() ? 1 : (int)ctx->shards.size()) : 0; }
+
 extern "C" void plume_destroy(plume_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->up) (void)hipStreamSynchronize(ctx->up);
-    if (ctx->down) (void)hipStreamSynchronize(ctx->down);
-    for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
-                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
-        b->release();
-    for (HostSlot& sl : ctx->slot) {
-        sl.msgs.release(); sl.off.release();
-        for (DevBuf& b : sl.in) b.release();
-        for (DevBuf& b : sl.out) b.release();
-        for (hipEvent_t e : {sl.ready, sl.computed, sl.drained}) if (e) (void)hipEventDestroy(e);
-    }
-    ctx->timer.destroy();
-    (void)hipStreamDestroy(ctx->stream);
-    if (ctx->up) (void)hipStreamDestroy(ctx->up);
-    if (ctx->down) (void)hipStreamDestroy(ctx->down);
-    delete ctx;
+    if (!ctx->shards.empty()) destroy_multi(ctx); else destroy_single(ctx);
+}
+
+// ------------------------------------------------------------------------------------------------ pinned host memory
+extern "C" void* plume_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 1;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { fail(PLUME_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+extern "C" void plume_host_free(void* p) { if (p) (void)hipHostFree(p); }
+extern "C" int plume_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return fail(PLUME_ERR_ARG, "plume_host_register: bad argument");
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return 0;
+}
+extern "C" int plume_host_unregister(void* p) {
+    if (!p) return fail(PLUME_ERR_ARG, "plume_host_unregister: bad argument");
+    HIPCHK(hipHostUnregister(p));
+    return 0;
 }
 
 extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
     if (!ctx || max_items == 0 || max_items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_chunk: bad argument");
     ctx->chunk = max_items;
+    for (plume_ctx* sh : ctx->shards) sh->chunk = max_items;
     return 0;
 }
 
 extern "C" int plume_set_host_piece(plume_ctx* ctx, size_t items) {
     if (!ctx || items == 0 || items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_host_piece: bad argument");
     ctx->host_piece = items;
+    if (ctx->host_first_piece > items) ctx->host_first_piece = items;
+    for (plume_ctx* sh : ctx->shards) { sh->host_piece = items; if (sh->host_first_piece > items) sh->host_first_piece = items; }
+    return 0;
+}
+extern "C" int plume_set_host_first_piece(plume_ctx* ctx, size_t items) {
+    if (!ctx || items == 0 || items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_host_first_piece: bad argument");
+    ctx->host_first_piece = items;
+    for (plume_ctx* sh : ctx->shards) sh->host_first_piece = items;
+    return 0;
+}
+extern "C" int plume_set_host_register_min(plume_ctx* ctx, size_t bytes) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "plume_set_host_register_min: bad argument");
+    ctx->host_register_min = bytes;
+    for (plume_ctx* sh : ctx->shards) sh->host_register_min = bytes;
     return 0;
 }
 
@@ -171,18 +343,20 @@ static int pick_jobs_per_lane(const plume_ctx* ctx, size_t njobs, bool kinds_of_
 }
 
 // ------------------------------------------------------------------------------------------ device pipelines
-static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul,
+static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk, const uint8_t* nul,
                          const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, hipStream_t st,
                          const uint8_t* preflags = nullptr, bool continue_timer = false, const uint8_t* rpt33 = nullptr, const uint8_t* hr33 = nullptr) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    if (!continue_timer) { if (int rc = ws_acquire(ctx, st)) return rc; }
     const int jpl = pick_jobs_per_lane(ctx, 3 * n, true);
     if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
         ctx->tabscr.ensure(tables_scratch_bytes(3 * n, jpl)) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n))
         return PLUME_ERR_HIP;
     VerifyArgs a;
-    a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags; a.rpt33 = rpt33; a.hr33 = hr33;
+    a.version = version; a.mode = mode; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msgs_bytes; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok;
+    a.preflags = preflags; a.rpt33 = rpt33; a.hr33 = hr33;
     a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>(); a.itemflags = ctx->itemflags.as<uint8_t>();
     a.tab = ctx->tab.as<uint32_t>(); a.res = ctx->res.as<uint32_t>(); a.resinf = ctx->resinf.as<uint8_t>(); a.gtab = ctx->gtab.as<uint32_t>();
     StageTimer& t = ctx->timer;
@@ -190,24 +364,25 @@ static int verify_device(plume_ctx* ctx, int version, size_t n, const uint8_t* m
     launch_verify_ingest(a, st); t.stage("verify_ingest_h2c", st);
     launch_tables(a.tab, a.bases, a.jobflags, 3 * n, jpl, ctx->tabscr.as<uint32_t>(), st); t.stage("tables", st);
     launch_verify_msm(a, st); t.stage("verify_msm", st);
-    if (version == 2) { launch_normalize(a.res, a.resinf, 2 * n, st); t.stage("to_affine", st); }   // V2 hashes the computed R', Hr'
+    if (version == 2 && mode == PLUME_MODE_VERIFY) { launch_normalize(a.res, a.resinf, 2 * n, st); t.stage("to_affine", st); }   // V2 hashes the computed R', Hr'
     launch_verify_finalize(a, st); t.stage("verify_finalize", st);
     HIPCHK(hipGetLastError());
-    return 0;
+    return ws_release(ctx, st);
 }
 
-static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
+static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk, const uint8_t* r,
                        const uint8_t* pk_in, uint8_t* pk, uint8_t* nul, uint8_t* c, uint8_t* s, uint8_t* rpt, uint8_t* hr, uint8_t* status, uint8_t* h_out,
                        hipStream_t st, bool out33 = false) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    if (int rc = ws_acquire(ctx, st)) return rc;
     const int jpl = pick_jobs_per_lane(ctx, n, false);
     if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * n) || ctx->jobflags.ensure(n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * n) ||
         ctx->tabscr.ensure(tables_scratch_bytes(n, jpl)) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->res2.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->res2inf.ensure(2 * n) || ctx->pkaff.ensure((size_t)2 * PLUME_FE_WORDS * 4 * n))
         return PLUME_ERR_HIP;
     SignArgs a;
-    a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.sk = sk; a.r = r; a.pk_in = pk_in;
+    a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msgs_bytes; a.sk = sk; a.r = r; a.pk_in = pk_in;
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out; a.out33 = out33 ? 1 : 0;
     a.gres = ctx->res.as<uint32_t>(); a.gresinf = ctx->resinf.as<uint8_t>(); a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>();
     a.itemflags = ctx->itemflags.as<uint8_t>(); a.pkaff = ctx->pkaff.as<uint32_t>(); a.tab = ctx->tab.as<uint32_t>();
@@ -224,7 +399,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     // the reference zeroizes secrets: wipe the device-side images derived from sk / r
     HIPCHK(hipMemsetAsync(ctx->res.p, 0, (size_t)PLUME_JAC_WORDS * 4 * 2 * n, st));
     HIPCHK(hipGetLastError());
-    return 0;
+    return ws_release(ctx, st);
 }
 
 static int args_ok(int version, size_t n, const void* msgs, const void* off) {
@@ -237,20 +412,31 @@ static int args_ok(int version, size_t n, const void* msgs, const void* off) {
 extern "C" int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                          const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point,
                                          const uint8_t* hashed_to_curve_r, uint8_t* ok, void* stream) {
-    (void)msgs_bytes;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk || !nullifier || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
     if (n && version == 1 && (!r_point || !hashed_to_curve_r)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
-    return verify_device(ctx, version, n, msgs, msg_off, pk, nullifier, c, s, version == 1 ? r_point : nullptr, version == 1 ? hashed_to_curve_r : nullptr, ok,
+    return verify_device(ctx, version, PLUME_MODE_VERIFY, n, msgs, msg_off, msgs_bytes, pk, nullifier, c, s, version == 1 ? r_point : nullptr,
+                         version == 1 ? hashed_to_curve_r : nullptr, ok, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+// plume_arkworks' verify_non_zk (rust-arkworks/src/tests.rs:28-78): same pipeline, PLUME_MODE_NON_ZK
+extern "C" int plume_verify_non_zk_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
+                                                const uint8_t* pk, const uint8_t* nullifier, const uint8_t* s, const uint8_t* r_point,
+                                                const uint8_t* hashed_to_curve_r, const uint8_t* digest_private, uint8_t* ok, void* stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
+    if (n && (!pk || !nullifier || !s || !r_point || !hashed_to_curve_r || !digest_private || !ok)) return fail(PLUME_ERR_ARG, "null array");
+    return verify_device(ctx, version, PLUME_MODE_NON_ZK, n, msgs, msg_off, msgs_bytes, pk, nullifier, digest_private, s, r_point, hashed_to_curve_r, ok,
                          stream ? (hipStream_t)stream : ctx->stream);
 }
 
 // SEC1-compressed ingest: decompress on the GPU into the context's 64-byte staging arrays, then the normal pipeline
-static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk33, const uint8_t* nul33,
+static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk33, const uint8_t* nul33,
                               const uint8_t* c, const uint8_t* s, const uint8_t* r33, const uint8_t* hr33, uint8_t* ok, hipStream_t st) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    if (int rc = ws_acquire(ctx, st)) return rc;
     // only pk and the nullifier are decompressed (they become bases of scalar multiplications); V1's r_point and hashed_to_curve_r stay
     // in their 33-byte form and are compared / hashed as x + parity by the finalize stage
     const int npts = 2;
@@ -263,51 +449,47 @@ static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8
     d.preflags = ctx->preflags.as<uint8_t>();
     ctx->timer.begin(st);
     launch_decompress(d, st); ctx->timer.stage("sec1_decompress", st);
-    return verify_device(ctx, version, n, msgs, msg_off, d.out[0], d.out[1], c, s, nullptr, nullptr, ok, st, d.preflags, true, version == 1 ? r33 : nullptr,
-                         version == 1 ? hr33 : nullptr);
+    return verify_device(ctx, version, PLUME_MODE_VERIFY, n, msgs, msg_off, msgs_bytes, d.out[0], d.out[1], c, s, nullptr, nullptr, ok, st, d.preflags, true,
+                         version == 1 ? r33 : nullptr, version == 1 ? hr33 : nullptr);
 }
 
 extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                               const uint8_t* pk33, const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s, const uint8_t* r_point33,
                                               const uint8_t* hashed_to_curve_r33, uint8_t* ok, void* stream) {
-    (void)msgs_bytes;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk33 || !nullifier33 || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
     if (n && version == 1 && (!r_point33 || !hashed_to_curve_r33)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
-    return verify_sec1_device(ctx, version, n, msgs, msg_off, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, ok, stream ? (hipStream_t)stream : ctx->stream);
+    return verify_sec1_device(ctx, version, n, msgs, msg_off, msgs_bytes, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, ok, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
                                        const uint8_t* r, const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point,
                                        uint8_t* hashed_to_curve_r, uint8_t* status, void* stream) {
-    (void)msgs_bytes;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
-    return sign_device(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, nullptr,
+    return sign_device(ctx, version, n, msgs, msg_off, msgs_bytes, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, nullptr,
                        stream ? (hipStream_t)stream : ctx->stream);
 }
 
 extern "C" int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
                                             const uint8_t* r, const uint8_t* pk_in, uint8_t* pk33, uint8_t* nullifier33, uint8_t* c, uint8_t* s, uint8_t* r_point33,
                                             uint8_t* hashed_to_curve_r33, uint8_t* status, void* stream) {
-    (void)msgs_bytes;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier33 || !c || !s || !r_point33 || !hashed_to_curve_r33 || !status)) return fail(PLUME_ERR_ARG, "null array");
-    return sign_device(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, status, nullptr,
+    return sign_device(ctx, version, n, msgs, msg_off, msgs_bytes, sk, r, pk_in, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, status, nullptr,
                        stream ? (hipStream_t)stream : ctx->stream, true);
 }
 
 extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
                                                 uint8_t* h_out, void* stream) {
-    (void)msgs_bytes;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
     if (n && !h_out) return fail(PLUME_ERR_ARG, "null array");
     if (n == 0) return 0;
-    H2cArgs a; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.h_out = h_out;
+    H2cArgs a; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msgs_bytes; a.pk = pk; a.h_out = h_out;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->timer.begin(st);
     launch_h2c_only(a, st); ctx->timer.stage("h2c_only", st);
@@ -323,14 +505,16 @@ static int dedup_device(plume_ctx* ctx, size_t n, const uint8_t* nul, const uint
     a.n = (uint32_t)n; a.nul = nul; a.live = live; a.ids = ids; a.first = first;
     const uint32_t m = dedup_table_size(a.n);
     a.mask = m - 1;
+    { static thread_local std::random_device rd; a.key[0] = rd(); a.key[1] = rd() | 1u; }   // fresh hash key per call (plume_dedup.h)
     if (ctx->dslots.ensure((size_t)m * 4) || ctx->dminid.ensure((size_t)m * 8) || ctx->dmyslot.ensure(n * 4) || ctx->dcount.ensure(8) || ctx->dblockcnt.ensure(dedup_blockcnt_bytes(n))) return PLUME_ERR_HIP;
     a.slots = ctx->dslots.as<uint32_t>(); a.minid = ctx->dminid.as<unsigned long long>(); a.myslot = ctx->dmyslot.as<uint32_t>();
     a.n_unique = ctx->dcount.as<unsigned long long>(); a.blockcnt = ctx->dblockcnt.as<uint32_t>();
+    if (int rc = ws_acquire(ctx, st)) return rc;
     ctx->timer.begin(st);
     launch_dedup(a, st); ctx->timer.stage("nullifier_first_occurrence", st);
     HIPCHK(hipGetLastError());
     if (n_unique_dev) HIPCHK(hipMemcpyAsync(n_unique_dev, ctx->dcount.p, 8, hipMemcpyDeviceToDevice, st));
-    return 0;
+    return ws_release(ctx, st);
 }
 extern "C" int plume_nullifier_first_occurrence_device(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live, const uint64_t* ids, uint8_t* first,
                                                        uint64_t* n_unique, void* stream) {
@@ -341,6 +525,7 @@ extern "C" int plume_nullifier_first_occurrence_device(plume_ctx* ctx, size_t n,
 // host-pointer form: one pass (every record has to be resident to be compared), staged through slot 0
 extern "C" int plume_nullifier_first_occurrence(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live, const uint64_t* ids, uint8_t* first,
                                                 uint64_t* n_unique) {
+    if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];   // every record has to meet every other: one device holds the whole set
     if (int rc = bind(ctx)) return rc;
     if (n && (!nullifier || !first)) return fail(PLUME_ERR_ARG, "null array");
     if (n == 0) { if (n_unique) *n_unique = 0; return 0; }
@@ -362,10 +547,12 @@ extern "C" int plume_nullifier_first_occurrence(plume_ctx* ctx, size_t n, const 
 }
 
 // ------------------------------------------------------------------------------------- host-pointer pipelines
-// The batch is cut into pieces (ctx->host_piece items, at most ctx->chunk).  Piece k+1 is staged into HBM on the upload
-// stream while piece k computes on the context stream and piece k-1 drains on the download stream; two staging slots
-// alternate.  With pageable caller memory the copies block the calling thread, which is why piece k-1 is drained only
-// AFTER piece k has been submitted: the thread then waits on work that is already behind it in the queue.
+// The batch is cut into pieces (ctx->host_piece items, the first one ctx->host_first_piece, at most ctx->chunk).  Piece k+1 is staged
+// into HBM on the upload stream while piece k computes on the context stream and piece k-1 drains on the download stream; two staging
+// slots alternate.  Caller memory that is page-locked (plume_host_alloc / plume_host_register, or any hipHostMalloc'ed / registered
+// range) is read and written by the copy engines directly and every copy is asynchronous; with pageable caller memory the copies block
+// the calling thread, which is why piece k-1 is drained only AFTER piece k has been submitted: the thread then waits on work that is
+// already behind it in the queue.
 static int stage_msgs(plume_ctx* ctx, HostSlot& sl, const uint8_t* msgs, const uint64_t* off, size_t i0, size_t cnt) {
     std::vector<uint64_t>& rel = sl.rel;
     rel.resize(cnt + 1);
@@ -396,12 +583,28 @@ static void quiesce(plume_ctx* ctx) {
     ctx->slot[0].in_flight = ctx->slot[1].in_flight = false;
 }
 
+// Page-locks caller arrays for the duration of one host-pointer call when ctx->host_register_min asks for it (arrays that are already
+// pinned, or too small, are left alone; a failed registration just leaves that array pageable).
+struct ScopedPins {
+    std::vector<void*> pinned;
+    void add(const plume_ctx* ctx, const void* p, size_t bytes) {
+        if (!p || !ctx->host_register_min || bytes < ctx->host_register_min) return;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) return;   // already known to the runtime
+        (void)hipGetLastError();
+        if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) pinned.push_back(const_cast<void*>(p));
+        else (void)hipGetLastError();
+    }
+    ~ScopedPins() { for (void* p : pinned) (void)hipHostUnregister(p); }
+};
+
 // up(slot, i0, cnt): enqueue the uploads of one piece on ctx->up;  run(slot, cnt): enqueue its kernels on ctx->stream;
 // down(slot, i0, cnt): enqueue the downloads on ctx->down.  Any error drains all three streams before it is returned, so no
 // copy is left in flight on the caller's memory.
 template <class Up, class Run, class Down>
 static int host_pipeline(plume_ctx* ctx, size_t n, Up up, Run run, Down down) {
     const size_t piece = ctx->host_piece < ctx->chunk ? ctx->host_piece : ctx->chunk;
+    const size_t first = ctx->host_first_piece < piece ? ctx->host_first_piece : piece;
     struct { HostSlot* sl = nullptr; size_t i0 = 0, cnt = 0; } prev;
     auto drain = [&]() -> int {
         HIPCHK(hipStreamWaitEvent(ctx->down, prev.sl->computed, 0));
@@ -411,8 +614,9 @@ static int host_pipeline(plume_ctx* ctx, size_t n, Up up, Run run, Down down) {
     };
     auto body = [&]() -> int {
         size_t k = 0;
-        for (size_t i0 = 0; i0 < n; i0 += piece, k++) {
-            const size_t cnt = n - i0 < piece ? n - i0 : piece;
+        for (size_t i0 = 0; i0 < n; k++) {
+            const size_t want = (k == 0 && n > piece) ? first : piece;
+            const size_t cnt = n - i0 < want ? n - i0 : want;
             HostSlot& sl = ctx->slot[k & 1];
             if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.drained)); sl.in_flight = false; }   // piece k-2 has left this slot
             if (int rc = up(sl, i0, cnt)) return rc;
@@ -423,6 +627,7 @@ static int host_pipeline(plume_ctx* ctx, size_t n, Up up, Run run, Down down) {
             sl.in_flight = true;
             if (prev.sl) { if (int rc = drain()) return rc; }
             prev.sl = &sl; prev.i0 = i0; prev.cnt = cnt;
+            i0 += cnt;
         }
         if (prev.sl) { if (int rc = drain()) return rc; }
         return 0;
@@ -433,72 +638,86 @@ static int host_pipeline(plume_ctx* ctx, size_t n, Up up, Run run, Down down) {
     return rc;
 }
 
-extern "C" int plume_verify_batch(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk,
-                                  const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
-                                  uint8_t* ok) {
-    if (int rc = bind(ctx)) return rc;
-    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
-    if (n && (!pk || !nullifier || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
-    if (n && version == 1 && (!r_point || !hashed_to_curve_r)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
-    const bool v1 = version == 1;
+// one single-device context, items [0, n) of the arrays given (a shard of a multi-device call passes offset pointers; msg_off keeps the
+// caller's absolute offsets into the same msgs buffer)
+static int verify_host(plume_ctx* ctx, int version, int mode, bool sec1, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nullifier,
+                       const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r, uint8_t* ok) {
+    HIPCHK(hipSetDevice(ctx->device));
+    const bool pts = version == 1 || mode == PLUME_MODE_NON_ZK;
+    const size_t P = sec1 ? 33 : 64;
+    ScopedPins pins;
+    if (n) {
+        pins.add(ctx, msgs + msg_off[0], (size_t)(msg_off[n] - msg_off[0]));
+        pins.add(ctx, pk, P * n); pins.add(ctx, nullifier, P * n); pins.add(ctx, c, 32 * n); pins.add(ctx, s, 32 * n);
+        if (pts) { pins.add(ctx, r_point, P * n); pins.add(ctx, hashed_to_curve_r, P * n); }
+    }
     return host_pipeline(
         ctx, n,
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
             if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
-            if (int rc = h2d(ctx, sl.in[0], pk + 64 * i0, 64 * cnt)) return rc;
-            if (int rc = h2d(ctx, sl.in[1], nullifier + 64 * i0, 64 * cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[0], pk + P * i0, P * cnt)) return rc;
+            if (int rc = h2d(ctx, sl.in[1], nullifier + P * i0, P * cnt)) return rc;
             if (int rc = h2d(ctx, sl.in[2], c + 32 * i0, 32 * cnt)) return rc;
             if (int rc = h2d(ctx, sl.in[3], s + 32 * i0, 32 * cnt)) return rc;
-            if (v1) {
-                if (int rc = h2d(ctx, sl.in[4], r_point + 64 * i0, 64 * cnt)) return rc;
-                if (int rc = h2d(ctx, sl.in[5], hashed_to_curve_r + 64 * i0, 64 * cnt)) return rc;
+            if (pts) {
+                if (int rc = h2d(ctx, sl.in[4], r_point + P * i0, P * cnt)) return rc;
+                if (int rc = h2d(ctx, sl.in[5], hashed_to_curve_r + P * i0, P * cnt)) return rc;
             }
             return sl.out[0].ensure(cnt);
         },
         [&](HostSlot& sl, size_t cnt) -> int {
-            return verify_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(), sl.in[2].as<uint8_t>(),
-                                 sl.in[3].as<uint8_t>(), v1 ? sl.in[4].as<uint8_t>() : nullptr, v1 ? sl.in[5].as<uint8_t>() : nullptr, sl.out[0].as<uint8_t>(),
-                                 ctx->stream);
+            const uint8_t *rp = pts ? sl.in[4].as<uint8_t>() : nullptr, *hp = pts ? sl.in[5].as<uint8_t>() : nullptr;
+            if (sec1)
+                return verify_sec1_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
+                                          sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), rp, hp, sl.out[0].as<uint8_t>(), ctx->stream);
+            return verify_device(ctx, version, mode, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
+                                 sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), rp, hp, sl.out[0].as<uint8_t>(), ctx->stream);
         },
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); });
 }
 
+static int verify_host_any(plume_ctx* ctx, int version, int mode, bool sec1, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nullifier,
+                           const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r, uint8_t* ok) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "null context");
+    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
+    if (n && (!pk || !nullifier || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
+    const bool pts = version == 1 || mode == PLUME_MODE_NON_ZK;
+    if (n && pts && (!r_point || !hashed_to_curve_r)) return fail(PLUME_ERR_ARG, "r_point and hashed_to_curve_r are required");
+    if (n == 0) return 0;
+    const size_t P = sec1 ? 33 : 64;
+    if (ctx->shards.empty()) return verify_host(ctx, version, mode, sec1, n, msgs, msg_off, pk, nullifier, c, s, pts ? r_point : nullptr, pts ? hashed_to_curve_r : nullptr, ok);
+    return for_shards(ctx, n, [=](plume_ctx* sh, size_t lo, size_t hi) -> int {
+        return verify_host(sh, version, mode, sec1, hi - lo, msgs, msg_off + lo, pk + P * lo, nullifier + P * lo, c + 32 * lo, s + 32 * lo, pts ? r_point + P * lo : nullptr,
+                           pts ? hashed_to_curve_r + P * lo : nullptr, ok + lo);
+    });
+}
+
+extern "C" int plume_verify_batch(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk,
+                                  const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
+                                  uint8_t* ok) {
+    return verify_host_any(ctx, version, PLUME_MODE_VERIFY, false, n, msgs, msg_off, pk, nullifier, c, s, r_point, hashed_to_curve_r, ok);
+}
 extern "C" int plume_verify_batch_sec1(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk33,
                                        const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s, const uint8_t* r_point33,
                                        const uint8_t* hashed_to_curve_r33, uint8_t* ok) {
-    if (int rc = bind(ctx)) return rc;
-    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
-    if (n && (!pk33 || !nullifier33 || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
-    if (n && version == 1 && (!r_point33 || !hashed_to_curve_r33)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
-    const bool v1 = version == 1;
-    return host_pipeline(
-        ctx, n,
-        [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
-            if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
-            if (int rc = h2d(ctx, sl.in[0], pk33 + 33 * i0, 33 * cnt)) return rc;
-            if (int rc = h2d(ctx, sl.in[1], nullifier33 + 33 * i0, 33 * cnt)) return rc;
-            if (int rc = h2d(ctx, sl.in[2], c + 32 * i0, 32 * cnt)) return rc;
-            if (int rc = h2d(ctx, sl.in[3], s + 32 * i0, 32 * cnt)) return rc;
-            if (v1) {
-                if (int rc = h2d(ctx, sl.in[4], r_point33 + 33 * i0, 33 * cnt)) return rc;
-                if (int rc = h2d(ctx, sl.in[5], hashed_to_curve_r33 + 33 * i0, 33 * cnt)) return rc;
-            }
-            return sl.out[0].ensure(cnt);
-        },
-        [&](HostSlot& sl, size_t cnt) -> int {
-            return verify_sec1_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
-                                      sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), v1 ? sl.in[4].as<uint8_t>() : nullptr, v1 ? sl.in[5].as<uint8_t>() : nullptr,
-                                      sl.out[0].as<uint8_t>(), ctx->stream);
-        },
-        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); });
+    return verify_host_any(ctx, version, PLUME_MODE_VERIFY, true, n, msgs, msg_off, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, ok);
+}
+extern "C" int plume_verify_non_zk_batch(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk,
+                                         const uint8_t* nullifier, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
+                                         const uint8_t* digest_private, uint8_t* ok) {
+    return verify_host_any(ctx, version, PLUME_MODE_NON_ZK, false, n, msgs, msg_off, pk, nullifier, digest_private, s, r_point, hashed_to_curve_r, ok);
 }
 
 static int sign_host(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
                      const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point, uint8_t* hashed_to_curve_r,
                      uint8_t* status, const size_t P /* bytes per output point record: 64, or 33 for SEC1 */) {
-    if (int rc = bind(ctx)) return rc;
-    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
-    if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
+    HIPCHK(hipSetDevice(ctx->device));
+    ScopedPins pins;
+    if (n) {
+        pins.add(ctx, msgs + msg_off[0], (size_t)(msg_off[n] - msg_off[0]));
+        pins.add(ctx, sk, 32 * n); pins.add(ctx, r, 32 * n); pins.add(ctx, pk_in, 64 * n);
+        pins.add(ctx, pk, P * n); pins.add(ctx, nullifier, P * n); pins.add(ctx, c, 32 * n); pins.add(ctx, s, 32 * n); pins.add(ctx, r_point, P * n); pins.add(ctx, hashed_to_curve_r, P * n);
+    }
     return host_pipeline(
         ctx, n,
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
@@ -512,7 +731,7 @@ static int sign_host(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs,
                        : 0;
         },
         [&](HostSlot& sl, size_t cnt) -> int {
-            if (int rc = sign_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
+            if (int rc = sign_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
                                      pk_in ? sl.in[2].as<uint8_t>() : nullptr, sl.out[0].as<uint8_t>(), sl.out[1].as<uint8_t>(), sl.out[2].as<uint8_t>(),
                                      sl.out[3].as<uint8_t>(), sl.out[4].as<uint8_t>(), sl.out[5].as<uint8_t>(), sl.out[6].as<uint8_t>(), nullptr, ctx->stream, P == 33))
                 return rc;
@@ -531,22 +750,33 @@ static int sign_host(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs,
             return d2h(ctx, status + i0, sl.out[6], cnt);
         });
 }
+static int sign_host_any(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
+                         const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point, uint8_t* hashed_to_curve_r,
+                         uint8_t* status, const size_t P) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "null context");
+    if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
+    if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
+    if (n == 0) return 0;
+    if (ctx->shards.empty()) return sign_host(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, P);
+    return for_shards(ctx, n, [=](plume_ctx* sh, size_t lo, size_t hi) -> int {
+        return sign_host(sh, version, hi - lo, msgs, msg_off + lo, sk + 32 * lo, r + 32 * lo, pk_in ? pk_in + 64 * lo : nullptr, pk ? pk + P * lo : nullptr, nullifier + P * lo,
+                         c + 32 * lo, s + 32 * lo, r_point + P * lo, hashed_to_curve_r + P * lo, status + lo, P);
+    });
+}
 
 extern "C" int plume_sign_batch(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
                                 const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point, uint8_t* hashed_to_curve_r,
                                 uint8_t* status) {
-    return sign_host(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, 64);
+    return sign_host_any(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, 64);
 }
 extern "C" int plume_sign_batch_sec1(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
                                      const uint8_t* pk_in, uint8_t* pk33, uint8_t* nullifier33, uint8_t* c, uint8_t* s, uint8_t* r_point33,
                                      uint8_t* hashed_to_curve_r33, uint8_t* status) {
-    return sign_host(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, status, 33);
+    return sign_host_any(ctx, version, n, msgs, msg_off, sk, r, pk_in, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, status, 33);
 }
 
-extern "C" int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out) {
-    if (int rc = bind(ctx)) return rc;
-    if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
-    if (n && !h_out) return fail(PLUME_ERR_ARG, "null array");
+static int h2c_host(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out) {
+    HIPCHK(hipSetDevice(ctx->device));
     return host_pipeline(
         ctx, n,
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
@@ -560,9 +790,18 @@ extern "C" int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n, const uint8_t
         },
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, h_out + 64 * i0, sl.out[0], 64 * cnt); });
 }
+extern "C" int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "null context");
+    if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
+    if (n && !h_out) return fail(PLUME_ERR_ARG, "null array");
+    if (n == 0) return 0;
+    if (ctx->shards.empty()) return h2c_host(ctx, n, msgs, msg_off, pk, h_out);
+    return for_shards(ctx, n, [=](plume_ctx* sh, size_t lo, size_t hi) -> int { return h2c_host(sh, hi - lo, msgs, msg_off + lo, pk ? pk + 64 * lo : nullptr, h_out + 64 * lo); });
+}
 
 // ------------------------------------------------------------------------------------------------ measurement
 extern "C" int plume_last_stage_times(plume_ctx* ctx, const char** names, float* ms, int cap) {
+    if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];   // a multi-device context reports its first shard
     if (int rc = bind(ctx)) return rc;
     StageTimer& t = ctx->timer;
     const int ns = (int)t.names.size();
@@ -583,6 +822,7 @@ static thread_local float g_microbench_ms = 0;
 extern "C" double plume_microbench_last_ticks(float* ms) { if (ms) *ms = g_microbench_ms; return (double)g_microbench_cycles; }
 
 extern "C" double plume_microbench(plume_ctx* ctx, int kind, int iters) {
+    if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
     if (bind(ctx)) return -1.0;
     if (iters <= 0 || kind < 0 || kind > 8) { fail(PLUME_ERR_ARG, "plume_microbench: bad argument"); return -1.0; }
     if (ctx->sink.ensure(128 * 4)) return -1.0;

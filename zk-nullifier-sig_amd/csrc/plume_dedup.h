@@ -33,6 +33,8 @@ struct DedupArgs {
     unsigned long long* minid;       // mask+1 entries: smallest id among the items sharing the slot
     uint32_t* myslot;                // n entries
     uint32_t mask;                   // table size - 1 (power of two >= 2n)
+    uint32_t key[2];                 // per-call hash key (plume_capi.hip draws it from std::random_device): records ground to collide under one key
+                                     // do not collide under the next, so a crafted batch cannot pin the probe length at O(n).  Results do not depend on it.
 };
 
 PLUME_HD uint32_t dedup_table_size(uint32_t n) {
@@ -40,12 +42,14 @@ PLUME_HD uint32_t dedup_table_size(uint32_t n) {
     while (m < 2u * n && m < 0x80000000u) m <<= 1;
     return m;
 }
-// 32-bit mix of the 64-byte record (murmur3-style; nullifiers are group elements, honest ones are uniformly distributed, but
-// the table stays correct -- only slower -- for records chosen to collide)
-PLUME_HD uint32_t dedup_hash(const uint32_t* rec /* 16 words */) {
-    uint32_t h = 0x9747B28Cu;
+// 32-bit keyed mix of the 64-byte record (murmur3-style rounds; the key enters before each word's multiplication, so the word
+// differences that cancel in the unkeyed function cannot be chosen without it).  Honest nullifiers are uniformly distributed group
+// elements; the table stays correct -- only slower -- whatever the records are.
+PLUME_HD uint32_t dedup_hash(const uint32_t* rec /* 16 words */, const uint32_t key[2]) {
+    uint32_t h = 0x9747B28Cu ^ key[0];
     PLUME_UNROLL for (int i = 0; i < 16; i++) {
-        uint32_t k = rec[i] * 0xCC9E2D51u;
+        const uint32_t kr = (key[1] << (i & 15)) | (key[1] >> ((32 - (i & 15)) & 31));
+        uint32_t k = (rec[i] ^ kr) * 0xCC9E2D51u;
         k = (k << 15) | (k >> 17);
         k *= 0x1B873593u;
         h ^= k;
@@ -76,7 +80,7 @@ PLUME_HD void dedup_insert(const DedupArgs& a, uint32_t i) {
     uint32_t rec[16];
     const uint32_t* mine = (const uint32_t*)(a.nul + 64 * (size_t)i);
     PLUME_UNROLL for (int k = 0; k < 16; k++) rec[k] = mine[k];
-    uint32_t h = dedup_hash(rec) & a.mask;
+    uint32_t h = dedup_hash(rec, a.key) & a.mask;
     for (;;) {
         uint32_t owner = a.slots[h];
         if (owner == PLUME_DEDUP_EMPTY) {

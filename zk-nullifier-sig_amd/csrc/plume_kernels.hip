@@ -111,6 +111,15 @@ __global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* base
 #endif
 }
 
+// LDS is not cleared between workgroups: a lane overwrites its digit rows before it leaves (the reference zeroizes what it derives from
+// secrets, rust-arkworks/src/lib.rs:202-214)
+template <int ROWS>
+__device__ __forceinline__ void wipe_digits(int8_t* s_dig) {
+    volatile int8_t* rows = s_dig;   // volatile: stores nothing reads again must still be issued
+    PLUME_NOUNROLL for (int k = 0; k < ROWS; k++) rows[k * kBlock + threadIdx.x] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
 // blocks [0, nb): equation 1 (s*G - c*pk); blocks [nb, 2nb): equation 2 (s*H - c*nullifier) — the role is uniform
 // per workgroup so the generator-table-in-LDS path never diverges inside a wavefront
 __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
@@ -132,6 +141,7 @@ __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
     const uint32_t* gt = a.gtab;   // read through L1/L2 (a 128-entry table staged in LDS was 10 % slower: bank conflicts on per-lane random rows)
     const uint32_t i = blk * kBlock + threadIdx.x;
     if (i < a.n) verify_msm(a, i, eq, gt, s_dig + threadIdx.x, kBlock);
+    wipe_digits<4 * PLUME_NDIG>(s_dig);
 }
 
 __global__ PLUME_FINAL_BOUNDS void k_verify_finalize(VerifyArgs a) {
@@ -169,6 +179,7 @@ __global__ PLUME_MSM_BOUNDS void k_sign_hmul(SignArgs a) {
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
     if (i < a.n) sign_hmul(a, i, which, s_dig + threadIdx.x, kBlock);
+    wipe_digits<2 * PLUME_NDIG>(s_dig);   // the rows are digits of sk and r: nothing derived from a secret stays in LDS when the workgroup retires
 }
 
 __global__ PLUME_FINAL_BOUNDS void k_sign_final(SignArgs a) {

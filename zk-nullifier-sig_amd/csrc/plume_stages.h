@@ -112,12 +112,30 @@ PLUME_HD void c_hash(uint32_t out[8], const enc_pt* pts) {
     }
 }
 
+// message i = msgs[msg_off[i] .. msg_off[i+1]): false (and an empty span) when the offsets decrease, reach past the buffer or span more than the
+// 32-bit length the SHA-256 front end takes -- the lane then never touches msgs
+PLUME_HD bool msg_span(uint64_t& o0, uint32_t& len, const uint64_t* msg_off, size_t i, uint64_t msgs_bytes) {
+    o0 = msg_off[i];
+    const uint64_t o1 = msg_off[i + 1];
+    const bool ok = o1 >= o0 && o1 <= msgs_bytes && o1 - o0 <= 0xFFFFFF00ull;
+    len = ok ? (uint32_t)(o1 - o0) : 0u;
+    if (!ok) o0 = 0;
+    return ok;
+}
+
 // ===================================================================================================== verify
+#define PLUME_MODE_VERIFY 0   // PlumeSignature::verify (rust-k256/src/lib.rs:93-145)
+#define PLUME_MODE_NON_ZK 1   // plume_arkworks' verify_non_zk (rust-arkworks/src/tests.rs:28-78): c' hashed from the GIVEN r_point / hashed_to_curve_r,
+                              // both EC equations checked for V1 AND V2, scalars are Fr elements (zero allowed), pk = identity is Err(HashToCurveError)
+#define PLUME_ITEM_REJECT 1u  // itemflags: the item's inputs cannot be represented by the reference's types -> ok = 0
+#define PLUME_ITEM_ERR 2u     // itemflags (non-zk mode): the reference returns Err (pk is the identity, rust-arkworks/src/lib.rs:99-101) -> ok = 2
 struct VerifyArgs {
     int version;       // 1 | 2
+    int mode;          // PLUME_MODE_*
     uint32_t n;
     // caller arrays (device memory): SoA of big-endian records
     const uint8_t* msgs; const uint64_t* msg_off;
+    uint64_t msgs_bytes;   // size of msgs: an item whose offsets are decreasing or reach past it is rejected, never read
     const uint8_t *pk, *nul, *c, *s, *rpt, *hr;
     uint8_t* ok;
     const uint8_t* preflags;  // optional, n bytes: non-zero = reject (set by the SEC1 decompression stage)
@@ -140,12 +158,16 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     uint32_t fnul = load_affine_be(nx, ny, a.nul + 64 * (size_t)i);
     sc c, s;
     bool okc = load_scalar_be(c, a.c + 32 * (size_t)i), oks = load_scalar_be(s, a.s + 32 * (size_t)i);
-    bool bad = !okc || !oks || fpk == PLUME_JOB_INVALID || fnul == PLUME_JOB_INVALID || (a.preflags && a.preflags[i]);
-    a.itemflags[i] = bad ? 1 : 0;
+    if (a.mode == PLUME_MODE_NON_ZK) { okc = sc_lt_n(c); oks = sc_lt_n(s); }          // Fr elements: zero is a value
+    uint64_t o0; uint32_t mlen;
+    const bool okm = msg_span(o0, mlen, a.msg_off, i, a.msgs_bytes);
+    bool bad = !okc || !oks || !okm || fpk == PLUME_JOB_INVALID || fnul == PLUME_JOB_INVALID || (a.preflags && a.preflags[i]);
+    const bool err = a.mode == PLUME_MODE_NON_ZK && !bad && fpk == PLUME_JOB_INF;      // hash_to_curve(message, pk)? -> Err
+    a.itemflags[i] = (uint8_t)(bad ? PLUME_ITEM_REJECT : err ? PLUME_ITEM_ERR : 0u);
+    bad = bad || err;
     jac h;
     if (!bad) {
-        const uint64_t o0 = a.msg_off[i], o1 = a.msg_off[i + 1];
-        hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), pkx, 2u + (fe_is_odd(pky) ? 1u : 0u), fpk == PLUME_JOB_INF ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
+        hash_to_curve_jac(h, a.msgs + o0, mlen, pkx, 2u + (fe_is_odd(pky) ? 1u : 0u), fpk == PLUME_JOB_INF ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
     } else {
         h.x = fe_gx(); h.y = fe_gy(); h.z = fe_small(1); h.inf = 0;
     }
@@ -195,7 +217,7 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
 
 PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
     const size_t nt = 2 * (size_t)a.n;
-    uint8_t ok = 0;
+    uint8_t ok = a.itemflags[i] == PLUME_ITEM_ERR ? 2 : 0;
     if (!a.itemflags[i]) {
         jac rc, hc;
         ld_jac_soa(rc, a.res, nt, 2 * (size_t)i); rc.inf = a.resinf[2 * (size_t)i];
@@ -248,7 +270,9 @@ PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
                 c_hash<6>(dg, pts);                                                                                  // lib.rs:128-135
                 hashed = true;
             }
-        } else if (a.version == 1) {
+        } else if (a.version == 1 || a.mode == PLUME_MODE_NON_ZK) {
+            // the given R, Hr are compared with the computed points (lib.rs:117,122; verify_non_zk tests.rs:55-70) and the challenge is hashed
+            // from the GIVEN encodings (non-zk: tests.rs:40-51, for V2 too)
             fe rx, ry, hx, hy;
             uint32_t fr = load_affine_be(rx, ry, a.rpt + 64 * (size_t)i);
             uint32_t fh = load_affine_be(hx, hy, a.hr + 64 * (size_t)i);
@@ -266,7 +290,8 @@ PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
                 pts[3] = enc_of(nx, ny, fnul == PLUME_JOB_INF);
                 pts[4] = enc_of(rx, ry, fr == PLUME_JOB_INF);
                 pts[5] = enc_of(hx, hy, fh == PLUME_JOB_INF);
-                c_hash<6>(dg, pts);                                                                                  // lib.rs:128-135
+                if (a.version == 1) c_hash<6>(dg, pts);                                                              // lib.rs:128-135
+                else c_hash<3>(dg, pts + 3);                                                                         // compute_c_v2(nul, r_point, hashed_to_curve_r)
                 hashed = true;
             }
         } else {
@@ -298,6 +323,7 @@ struct SignArgs {
     int version;
     uint32_t n;
     const uint8_t* msgs; const uint64_t* msg_off;
+    uint64_t msgs_bytes;    // size of msgs (see VerifyArgs)
     const uint8_t *sk, *r;
     const uint8_t* pk_in;   // optional (arkworks-shaped sign_with_r: pk supplied, not derived)
     uint8_t *pk, *nul, *c, *s, *rpt, *hr, *status;
@@ -367,8 +393,9 @@ PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
     if (pinf) { px = fe_zero(); py = fe_zero(); }
     st_fe_soa(a.pkaff, a.n, i, px); st_fe_soa(a.pkaff + PLUME_FE_W * (size_t)a.n, a.n, i, py);
     jac h;
-    const uint64_t o0 = a.msg_off[i], o1 = a.msg_off[i + 1];
-    hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), px, 2u + (fe_is_odd(py) ? 1u : 0u), pinf ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
+    uint64_t o0; uint32_t mlen;
+    if (!msg_span(o0, mlen, a.msg_off, i, a.msgs_bytes)) st |= PLUME_ST_BAD_SCALAR;   // malformed offsets: flagged, the (empty) span is hashed
+    hash_to_curve_jac(h, a.msgs + o0, mlen, px, 2u + (fe_is_odd(py) ? 1u : 0u), pinf ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
     if (h.inf) st |= PLUME_ST_IDENTITY;
     st_jac_soa(a.bases, a.n, i, h);
     a.jobflags[i] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
@@ -459,21 +486,24 @@ PLUME_HD void decompress_item(const DecompressArgs& a, uint32_t i) {
 struct H2cArgs {
     uint32_t n;
     const uint8_t* msgs; const uint64_t* msg_off;
+    uint64_t msgs_bytes; // size of msgs (see VerifyArgs)
     const uint8_t* pk;   // may be NULL: hash the raw message bytes (no encoding appended)
     uint8_t* h_out;      // 64 B/item, all-zero for identity or invalid pk
 };
 PLUME_HD void h2c_only(const H2cArgs& a, uint32_t i) {
-    const uint64_t o0 = a.msg_off[i], o1 = a.msg_off[i + 1];
+    uint64_t o0; uint32_t mlen;
     jac h;
     fe x = fe_zero(), y = fe_zero();
-    bool bad = false;
-    if (a.pk) {
+    bool bad = !msg_span(o0, mlen, a.msg_off, i, a.msgs_bytes);
+    if (bad) {
+        h.inf = 1;
+    } else if (a.pk) {
         fe px, py;
         uint32_t f = load_affine_be(px, py, a.pk + 64 * (size_t)i);
         bad = f == PLUME_JOB_INVALID;
-        if (!bad) hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), px, 2u + (fe_is_odd(py) ? 1u : 0u), f == PLUME_JOB_INF ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
+        if (!bad) hash_to_curve_jac(h, a.msgs + o0, mlen, px, 2u + (fe_is_odd(py) ? 1u : 0u), f == PLUME_JOB_INF ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
     } else {
-        hash_to_curve_jac(h, a.msgs + o0, (uint32_t)(o1 - o0), x, 0u, PLUME_ENC_NONE);   // raw message bytes only
+        hash_to_curve_jac(h, a.msgs + o0, mlen, x, 0u, PLUME_ENC_NONE);   // raw message bytes only
     }
     if (!bad && !h.inf) {
         fe zi, zi2;

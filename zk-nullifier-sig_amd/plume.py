@@ -217,6 +217,22 @@ def sign_with_r(keypair: Tuple[AffinePoint, int], message: bytes, r_scalar: int,
             PlumeSignaturePrivate(pt("hashed_to_curve_r"), pt("r_point"), int.from_bytes(o["c"][0].tobytes(), "big"), version))
 
 
+def verify_non_zk(sig: Tuple[PlumeSignaturePublic, PlumeSignaturePrivate], pk: AffinePoint, message: bytes, version: PlumeVersion,
+                  engine: Optional[Engine] = None) -> bool:
+    """plume_arkworks' verify_non_zk (rust-arkworks/src/tests.rs:28-78) on the GPU: c' from the GIVEN r_point / hashed_to_curve_r, both
+    equations g^s pk^-c == g^r and h^s nul^-c == z for V1 and V2, then c' == digest_private.  Raises SignatureError where the reference
+    returns Err(HashToCurveError) (pk = identity, rust-arkworks/src/lib.rs:99-101)."""
+    eng = engine or default_engine()
+    pub, prv = sig
+    msgs, off = pack_messages([bytes(message)])
+    a = lambda b: np.frombuffer(b, dtype=np.uint8)  # noqa: E731
+    ok = eng.verify_non_zk_batch(version.value, msgs, off, a(pk.to_bytes64()), a(pub.nullifier.to_bytes64()), a((pub.s % _N).to_bytes(32, "big")),
+                                 a(prv.r_point.to_bytes64()), a(prv.hashed_to_curve_r.to_bytes64()), a((prv.digest_private % _N).to_bytes(32, "big")))
+    if int(ok[0]) == 2:
+        raise SignatureError("`pk` shouldn't be the identity element")
+    return bool(ok[0])
+
+
 def sign(rng, keypair: Tuple[AffinePoint, int], message: bytes, version: PlumeVersion, engine: Optional[Engine] = None):
     """plume_arkworks::sign (rust-arkworks/src/lib.rs:281-291): r = Fr::rand(rng)"""
     r = int.from_bytes(rng.fill_bytes(48), "big") % _N

@@ -20,5 +20,6 @@ from .plume import (  # noqa: E402,F401
     SignatureError,
     sign,
     sign_with_r,
+    verify_non_zk,
 )
 from . import nullifier_set  # noqa: E402,F401
