@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
 """bench.py — PLUME V1 verifies/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2-batch 20] [--version 1] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--config 4] [--log2-batch 20] [--version 1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the verify pipeline (ingest+h2c -> window tables -> multi-scalar loop -> finalize) over one
-batch of 2^20 synthetic V1 signatures per GPU, inputs already resident in HBM, through the C ABI's device-resident
-entry point (plume_verify_batch_device) on torch's current stream.  Weak scaling: every rank verifies its own
-2^20-item shard (items [rank*2^20, (rank+1)*2^20) of the BASELINE.md §3 generator); the path has no cross-device
-exchange, so the only collectives are the timing barrier and the MAX over ranks.
+A "step" is one pass of the verify pipeline (ingest+h2c -> window tables -> multi-scalar loop -> finalize) over one batch of synthetic
+signatures, inputs already resident in HBM, through the C ABI's device-resident entry point (plume_verify_batch_device) on torch's
+current stream.  One process per GPU; the path has no cross-device exchange, so the only collectives are the timing barrier, the MAX
+over ranks and the gather of the per-rank times (backend nccl = RCCL).
+  --scaling weak   (default) every rank verifies its own 2^log2-batch items per step: items [rank*2^k, (rank+1)*2^k) of the BASELINE.md §3 generator
+  --scaling strong 2^log2-batch items per step IN TOTAL, contiguous even split [floor(rT/W), floor((r+1)T/W)) over the ranks
+  --config 4       BASELINE.json configs[3]: 2^22 V2 verifies in total, even split over the ranks (= --scaling strong --log2-batch 22 --version 2)
 
-Extra objects on the line:
-  roofline      dominant kernel (k_verify_msm): algorithmic bytes (353 B/item) / its HIP-event duration
-                vs 8 TB/s — the schema's HBM view, honest and tiny because this path is integer-VALU bound;
-  valu_roofline the meaningful one: accounting MACs (SURVEY.md §8d, 72 per Fp-mult) per second vs the v_mad_u64_u32
-                issue rate measured by a microbenchmark in this same run;
-  cpu_baseline  the plain-C oracle (kind "port": rust-k256 cannot be built here) timed on the host cores, rank 0, N=1.
+Objects on the line besides the contract's keys:
+  roofline         the BINDING roof of the dominant kernel (k_verify_msm): integer VALU.  achieved = accounting 32-bit MACs of the two double-base
+                   multiplications (4 160 Fp-mult x 72, SURVEY.md §8d, frozen in BASELINE.md §4) / that kernel's HIP-event duration; peak = the
+                   v_mad_u64_u32 issue rate measured by a microbenchmark in this run (the spec-derived half-rate figure beside it)
+  hbm_view         the same kernel against HBM: algorithmic bytes (353 B/item) / kernel time vs 8 TB/s, and the PMC traffic (table gathers)
+  valu_roofline    the whole path against the same roof, plus the measured issue rates
+  e2e_host_pinned  N=1: whole-call rates of the HOST-POINTER entry points with page-locked caller arrays (H2D + kernels + D2H), verify and sign
+  cpu_baseline     the plain-C oracle (kind "port": rust-k256 cannot be built here) on ALL host cores, first 2^16 items of the same batch, and
+                   beside it an optimised CPU leg (GLV + wNAF + dedicated squaring + one inversion per point set) so the oracle can stay simple
 """
 import argparse
 import json
@@ -34,7 +39,8 @@ FPMUL_PER_ITEM = {1: 5460, 2: 5460}               # accounting algorithm, whole 
 FPMUL_MSM_PER_ITEM = 1900 + 2260                  # the two double-base multiplications (dominant kernel)
 MACS_PER_FPMUL = 72
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s spec
-MAD_PEAK_REF = 3.5e13                             # v_mad_u64_u32 lane-ops/s: 1024 SIMDs x 64 lanes / 1.83 ns (tests/gpu_debug/instr_rates_r01.txt)
+MAD_PEAK_REF = 3.5e13                             # v_mad_u64_u32 lane-ops/s measured on this pool: 1024 SIMDs x 64 lanes / 1.83 ns (tests/gpu_debug/instr_rates_r01.txt)
+MAD_PEAK_SPEC = 256 * 4 * 16 * 2.4e9              # half rate of the 32-lane-per-clock VALU: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 3.93e13
 
 
 def parse():
@@ -42,11 +48,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log2-batch", type=int, default=20, help="items per GPU per step = 2^this (BASELINE: 20)")
+    ap.add_argument("--log2-batch", type=int, default=20, help="weak: items per GPU per step = 2^this; strong: items per step in total (BASELINE: 20)")
     ap.add_argument("--version", type=int, default=1, choices=(1, 2))
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4), help="BASELINE.json preset: 2 = 2^16 V1 verify; 4 = 2^22 V2 verify split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (V2 verify, V1 sign, SEC1 ingest) reported at N=1")
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (V2 verify, V1 sign, SEC1 ingest, e2e) reported at N=1")
+    a = ap.parse_args()
+    if a.config == 4:
+        a.scaling, a.log2_batch, a.version = "strong", 22, 2
+    elif a.config == 2:
+        a.log2_batch, a.version = 16, 1
+    return a
 
 
 def shard_bounds(total: int, rank: int, world: int):
@@ -66,32 +79,82 @@ def pmc_traffic(kernel: str):
 
 
 def cpu_baseline(version: int):
-    """plain-C oracle on the host cores, bounded sample of the same workload"""
+    """plain-C oracle on ALL host cores over the first 2^16 items of the same synthetic batch, one core beside it, and the
+    optimised CPU leg (oracle/plume_cpu_fast.c) when it is built"""
     import numpy as np  # noqa: F401
 
     from tests import _oracle_c as OC
     from tests import synth
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    n = max(1024, min(16384, 256 * threads))
+    n = 1 << 16
     b = synth.sign_inputs(n)
-    signed = OC.sign_batch(version, b["msgs"], b["off"], b["sk"], b["r"], nthreads=threads)
+    signed = OC.sign_batch(version, b["msgs"], b["off"], b["sk"], b["r"], nthreads=cores)
     v = synth.corrupt_for_verify(version, b, signed)
     args = (version, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
     t0 = time.perf_counter()
-    ok_mt = OC.verify_batch(*args, nthreads=threads)
+    ok_mt = OC.verify_batch(*args, nthreads=cores)
     t_mt = time.perf_counter() - t0
-    n1 = min(n, 1024)
+    n1 = 2048
     a1 = (version, v["msgs"], v["off"][: n1 + 1], v["pk"][:n1], v["nullifier"][:n1], v["c"][:n1], v["s"][:n1],
           v["r_point"][:n1] if version == 1 else None, v["hashed_to_curve_r"][:n1] if version == 1 else None)
     t0 = time.perf_counter()
     OC.verify_batch(*a1, nthreads=1)
     t_1 = time.perf_counter() - t0
     assert list(ok_mt) == list(synth.expected_ok(n))
-    return {"value": round(n / t_mt, 1), "unit": "verifies/s", "cores": threads, "kind": "port",
-            "sample": f"first {n} items of the same synthetic V{version} batch, plain-C oracle (4-bit window, no endomorphism), {threads} threads; "
-                      f"single thread: {n1 / t_1:.1f} verifies/s. rust-k256 itself cannot be built here (no rustc/cargo).",
-            "single_thread_value": round(n1 / t_1, 1)}
+    out = {"value": round(n / t_mt, 1), "unit": "verifies/s", "cores": cores, "kind": "port",
+           "sample": f"first {n} items of the same synthetic V{version} batch (1/16 corrupted), plain-C oracle (4x64-bit limbs, 4-bit window, no endomorphism, "
+                     f"one inversion per encoded point), {cores} threads = os.cpu_count(); single thread ({n1} items): {n1 / t_1:.1f} verifies/s. "
+                     f"rust-k256 itself cannot be built here (no rustc/cargo).",
+           "single_thread_value": round(n1 / t_1, 1)}
+    try:
+        from tests import _cpu_fast as CF
+        t0 = time.perf_counter()
+        ok_f = CF.verify_batch(*args, nthreads=cores)
+        t_f = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        CF.verify_batch(*a1, nthreads=1)
+        t_f1 = time.perf_counter() - t0
+        assert list(ok_f) == list(ok_mt)
+        out["optimized"] = {"value": round(n / t_f, 1), "unit": "verifies/s", "cores": cores, "kind": "port (optimised)", "single_thread_value": round(n1 / t_f1, 1),
+                            "sample": "same items; oracle/plume_cpu_fast.c: GLV + width-5 wNAF, 4x64-bit limbs with a dedicated squaring, Jacobian mixed additions, "
+                                      "inversion by addition chain, checked item by item against the plain oracle in tests/"}
+    except Exception as e:  # the optimised leg is optional
+        out["optimized"] = {"error": str(e)[:200]}
+    return out
+
+
+def e2e_host_pinned(eng, n, b, signed_v1):
+    """whole-call rate of the host-pointer entry points with page-locked caller arrays: H2D + kernels + D2H, pipelined in pieces (SURVEY §8d 'secondary')"""
+    import numpy as np
+
+    from tests import synth
+    from zk_nullifier_sig_amd import capi
+    out = {}
+    pin = {k: capi.pinned_copy(b[k]) for k in ("msgs", "off", "sk", "r")}
+    so = {k: capi.pinned_empty((n, w)) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
+    so["status"] = capi.pinned_empty(n)
+
+    def best(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return min(ts), sorted(ts)[len(ts) // 2]
+
+    tb, tm = best(lambda: eng.sign_batch(1, pin["msgs"], pin["off"], pin["sk"], pin["r"], out=so))
+    assert np.array_equal(so["s"], signed_v1["s"]) and not so["status"].any()
+    out["sign_v1"] = {"items_per_s": round(n / tm, 1), "ms_per_call": round(tm * 1e3, 3), "best_ms": round(tb * 1e3, 3), "bytes_in": 96 * n, "bytes_out": 321 * n}
+    v = synth.corrupt_for_verify(1, b, signed_v1)
+    vp = {k: capi.pinned_copy(v[k]) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+    ok = capi.pinned_empty(n)
+    tb, tm = best(lambda: eng.verify_batch(1, vp["msgs"], pin["off"], vp["pk"], vp["nullifier"], vp["c"], vp["s"], vp["r_point"], vp["hashed_to_curve_r"], out=ok))
+    assert np.array_equal(ok, synth.expected_ok(n))
+    out["verify_v1"] = {"items_per_s": round(n / tm, 1), "ms_per_call": round(tm * 1e3, 3), "best_ms": round(tb * 1e3, 3), "bytes_in": 352 * n, "bytes_out": n}
+    # the same call with pageable caller arrays (the runtime stages them), for comparison
+    tb, tm = best(lambda: eng.verify_batch(1, v["msgs"], b["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"]), reps=2)
+    out["verify_v1_pageable"] = {"items_per_s": round(n / tm, 1), "ms_per_call": round(tm * 1e3, 3)}
+    out["note"] = "median of 3 calls after one warm-up; page-locked arrays from plume_host_alloc; pieces of 2^18 items (first 2^17), three streams"
+    return out
 
 
 def extras(eng, dev, n, b, signed_v1):
@@ -118,11 +181,14 @@ def extras(eng, dev, n, b, signed_v1):
     for ver in (1, 2):
         dt = timed(lambda: eng.sign_batch_device(ver, n, msgs, off, mbytes, sk, r, None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], st))
         out[f"sign_v{ver}"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
-    # V2 verify on the V2 signatures just produced (honest batch)
+    # V2 verify on the V2 signatures just produced (honest batch); the arkworks verification (verify_non_zk) of the same batch beside it
     ok = torch.zeros(n, dtype=torch.uint8, device=dev)
     dt = timed(lambda: eng.verify_batch_device(2, n, msgs, off, mbytes, o["pk"], o["nullifier"], o["c"], o["s"], None, None, ok))
     assert bool(ok.all())
     out["verify_v2"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
+    dt = timed(lambda: eng.verify_non_zk_batch_device(2, n, msgs, off, mbytes, o["pk"], o["nullifier"], o["s"], o["r_point"], o["hashed_to_curve_r"], o["c"], ok))
+    assert bool((ok == 1).all())
+    out["verify_non_zk_v2"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
     # V1 verify with SEC1-compressed points (decompression on the GPU)
     if signed_v1 is not None:
         c33 = {k: t(_sec1.compress(signed_v1[k])) for k in ("pk", "nullifier", "r_point", "hashed_to_curve_r")}
@@ -167,12 +233,13 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     eng = plume.Engine(local_rank)
-    n = 1 << a.log2_batch
     ver = a.version
+    total = (1 << a.log2_batch) * (world if a.scaling == "weak" else 1)      # items per step over all ranks
+    start, stop = shard_bounds(total, rank, world)
+    n = stop - start                                                           # this rank's items per step
     eng.set_chunk(max(n, 1 << 20))
 
     # ---- synthetic shard of this rank, signed on the GPU (setup, untimed), corrupted 1/16 as BASELINE.md §3
-    start, _ = shard_bounds(n * world, rank, world)
     b = synth.sign_inputs(n, start=start)
     signed = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
     v = synth.corrupt_for_verify(ver, b, signed, start=start)
@@ -206,68 +273,92 @@ def main():
             for name, ms in eng.last_stage_times():
                 stage_acc[name] = stage_acc.get(name, 0.0) + ms
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed_rank = time.perf_counter() - t0
     assert bool((ok == expected).all()), "verify results differ from the expected corruption pattern"
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed_rank], dtype=torch.float64, device=dev)
+    per_rank = [elapsed_rank]
     if world > 1:
+        gathered = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(gathered, tmax.clone())
+        per_rank = [float(g.item()) for g in gathered]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / a.steps
-        value = n * world * a.steps / elapsed
+        value = total * a.steps / elapsed
         stages = {k: round(vv / a.steps, 4) for k, vv in stage_acc.items()}
+        what = f"2^{a.log2_batch} per GPU" if a.scaling == "weak" else f"2^{a.log2_batch} in total, even split over {world} GPU(s)"
         line = {
-            "metric": f"PLUME verifies/sec (secp256k1 V{ver}) at batch=2^{a.log2_batch} per GPU", "value": round(value, 1), "unit": "verifies/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "metric": f"PLUME verifies/sec (secp256k1 V{ver}) at batch=2^{a.log2_batch}" + (" per GPU" if a.scaling == "weak" else " total"), "value": round(value, 1), "unit": "verifies/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]/metric: batch 2^{a.log2_batch} PLUME V{ver} verify (secp256k1 + SHA-256) per GPU, 32-byte messages, 1/16 corrupted, "
+            "config": {"workload": f"BASELINE.json configs[{3 if a.config == 4 else 1}]/metric: batch {what}, PLUME V{ver} verify (secp256k1 + SHA-256), 32-byte messages, 1/16 corrupted, "
                                    f"inputs resident in HBM; Fp arithmetic on 9x29-bit limbs through chains of v_mad_u64_u32 (32x32+64)",
-                       "items_per_gpu": n, "global_items_per_step": n * world, "parallelism": f"shard x{world}, no collective"},
+                       "items_per_gpu": n, "global_items_per_step": total, "parallelism": f"shard x{world}, no collective on the data path",
+                       "world_size": world, "collective_backend": "nccl (RCCL): barrier + MAX + gather of the timings only" if world > 1 else None},
+            "per_rank": {"items_per_step": [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)],
+                         "verifies_per_s": [round((shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]) * a.steps / per_rank[r], 1) for r in range(world)]},
             "stage_ms": stages,
         }
         if stages:
             dom = max(stages, key=stages.get)
             dom_s = stages[dom] * 1e-3
-            achieved = BYTES_PER_ITEM[ver] * n / dom_s / 1e9
-            # HBM bytes per launch from the committed PMC passes (2^20-item launch, scaled to this batch), as GB/s over this run's kernel time
+            hbm_achieved = BYTES_PER_ITEM[ver] * n / dom_s / 1e9
+            # HBM bytes per launch from the committed PMC passes (2^20-item launch, scaled to this batch)
             tb, tsrc = pmc_traffic("plume::k_" + dom)
-            traffic = round(tb * (n / float(1 << 20)) / dom_s / 1e9, 1) if tb else None
-            line["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                                "traffic_note": (f"{tb} raw FETCH_SIZE+WRITE_SIZE bytes per 2^20-item launch, {tsrc}; uncorrected (the guide's 2x FETCH_SIZE correction is calibrated "
-                                                 f"for wide coalesced streams, these are 16-byte per-lane gathers)") if tb else None,
-                                "note": "path is integer-VALU bound (SURVEY.md §8d); see valu_roofline"}
+            traffic_bytes = int(tb * (n / float(1 << 20))) if tb else None
             try:
                 # long enough (tens of ms each) for the clocks to settle where the real kernels run
                 eng.microbench(0, 1 << 17)
-                mad_rate = eng.microbench(0, 1 << 18)
+                mad_measured = eng.microbench(0, 1 << 18)
                 add_rate = eng.microbench(4, 1 << 18)
                 fpmul_rate = eng.microbench(5, 1 << 13)
                 fpsqr_rate = eng.microbench(6, 1 << 13)
                 other = {name: round(eng.microbench(k, 1 << 17), 1) for k, name in
                          ((1, "v_addc_co_u32"), (2, "v_mul_lo_u32"), (3, "v_mad_u32_u24"), (7, "v_fma_f64"), (8, "v_lshl_add_u64"))}
+            except Exception as e:  # measurement extras must not kill the bench line
+                mad_measured, add_rate, fpmul_rate, fpsqr_rate, other = None, None, None, None, {"error": str(e)}
+            # some boxes of the pool throttle a pure multiply-add stream (a power virus) far below what the real kernels sustain: the
+            # roof is the larger of this run's measurement and the pool's reference rate, so a throttled probe cannot inflate the fraction
+            mad_rate = max(mad_measured or 0.0, MAD_PEAK_REF)
+            msm_ms = stages.get("verify_msm")
+            if dom == "verify_msm":
+                msm = FPMUL_MSM_PER_ITEM * MACS_PER_FPMUL * n / dom_s
+                line["roofline"] = {"bound": "int-valu", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(msm, 1), "peak": round(mad_rate, 1),
+                                    "unit": "32-bit MAC/s", "frac": round(msm / mad_rate, 4),
+                                    "peak_measured_this_run": round(mad_measured, 1) if mad_measured else None, "peak_spec_half_rate": MAD_PEAK_SPEC,
+                                    "frac_of_spec_half_rate": round(msm / MAD_PEAK_SPEC, 4),
+                                    "traffic": traffic_bytes, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, raw)",
+                                    "accounting": f"{FPMUL_MSM_PER_ITEM} Fp-mult per verify in this kernel (s*G - c*pk: 1900, s*H - c*nul: 2260) x {MACS_PER_FPMUL} MACs x {n} items per launch "
+                                                  f"(SURVEY.md §8d, frozen in BASELINE.md §4); the 9x29-limb code issues 103 multiply-adds per Fp-mult, the accounting stays on the frozen 72"}
+            line["hbm_view"] = {"bound": "hbm", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(hbm_achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": BYTES_PER_ITEM[ver] * n,
+                                "traffic": round(traffic_bytes / dom_s / 1e9, 1) if traffic_bytes else None, "traffic_bytes_per_launch": traffic_bytes,
+                                "traffic_over_algorithmic": round(traffic_bytes / (BYTES_PER_ITEM[ver] * n), 1) if traffic_bytes else None,
+                                "traffic_note": (f"raw FETCH_SIZE+WRITE_SIZE of {tsrc}: the per-lane gathers of the HBM-resident window tables; uncorrected (the guide's 2x FETCH_SIZE "
+                                                 f"correction is calibrated for wide coalesced streams, these are 16-byte per-lane gathers)") if tb else None,
+                                "note": "the path is integer-VALU bound (SURVEY.md §8d): see roofline"}
+            if mad_measured:
                 step_s = sum(stages.values()) * 1e-3
                 whole = FPMUL_PER_ITEM[ver] * MACS_PER_FPMUL * n / step_s
-                msm = FPMUL_MSM_PER_ITEM * MACS_PER_FPMUL * n / (stages.get("verify_msm", step_s * 1e3) * 1e-3)
-                # some boxes of the pool throttle a pure multiply-add stream (a power virus) far below what the real kernels sustain: the
-                # roof is the larger of this run's measurement and the reference rate, so a throttled probe cannot inflate the fraction
-                mad_measured = mad_rate
-                mad_rate = max(mad_rate, MAD_PEAK_REF)
                 line["valu_roofline"] = {"bound": "int-valu", "unit": "32-bit MAC/s", "peak_v_mad_u64_u32": round(mad_rate, 1), "peak_v_mad_u64_u32_measured_this_run": round(mad_measured, 1),
-                                         "peak_v_add_u32": round(add_rate, 1),
+                                         "peak_spec_half_rate": MAD_PEAK_SPEC, "peak_v_add_u32": round(add_rate, 1),
                                          "fp_mul_per_s": round(fpmul_rate, 1), "fp_sqr_per_s": round(fpsqr_rate, 1), "other_issue_rates_per_s": other,
                                          "achieved_whole_path": round(whole, 1), "frac_whole_path": round(whole / mad_rate, 4),
-                                         "achieved_msm_kernel": round(msm, 1), "frac_msm_kernel": round(msm / mad_rate, 4),
-                                         "accounting": "5460 Fp-mult/verify x 72 MACs (SURVEY.md §8d, frozen in BASELINE.md §4); the 9x29-limb code issues 103 multiply-adds per Fp-mult, the accounting stays on the frozen 72"}
-            except Exception as e:  # measurement extras must not kill the bench line
-                line["valu_roofline"] = {"error": str(e)}
-        if world == 1 and not a.no_extras:
+                                         "msm_kernel_ms": msm_ms,
+                                         "accounting": "5460 Fp-mult/verify x 72 MACs (SURVEY.md §8d, frozen in BASELINE.md §4)"}
+        if world == 1 and not a.no_extras and a.scaling == "weak" and a.log2_batch == 20:
             try:
                 line["other_workloads"] = extras(eng, dev, n, b, signed if ver == 1 else None)
             except Exception as e:
                 line["other_workloads"] = {"error": str(e)}
+            if ver == 1:
+                try:
+                    line["e2e_host_pinned"] = e2e_host_pinned(eng, n, b, signed)
+                except Exception as e:
+                    line["e2e_host_pinned"] = {"error": str(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(ver)

@@ -142,6 +142,25 @@ int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n,
                               const uint8_t* msgs, const uint64_t* msg_off,
                               const uint8_t* pk, uint8_t* h_out);
 
+/* ---- circuit witness hints from the GPU hash_to_curve   -----------------------------------------------
+ * The circom verifier (circuits/circom/verify_nullifier.circom:14-31,152-162) takes the hash_to_curve intermediates as
+ * precomputed inputs; the GPU computes them anyway.  Per item, for h2c(msg_i || SEC1c(pk_i)) (pk == NULL: the raw message bytes):
+ *   u       n x 64  : u0 | u1                                     hash_to_field (RFC 9380 §5.2)
+ *   mapped  n x 128 : q0_x_mapped | q0_y_mapped | q1_x_mapped | q1_y_mapped     simplified-SWU outputs, affine, on the isogenous curve E'
+ *   q       n x 128 : Q0.x | Q0.y | Q1.x | Q1.y                   after the 3-isogeny, on secp256k1 (identity = zeros)
+ *   h       n x 64  : H = Q0 + Q1
+ * Any output may be NULL.  registers = 0: every value is 32 big-endian bytes; registers = 1: every value is the circuit's 4 x 64-bit
+ * little-endian registers (circuits/circom/utils.ts:11-17 scalarToCircuitValue), i.e. out + 32*k is a uint64_t[4].
+ * NOT produced: q*_gx1_sqrt, q*_gx2_sqrt, q*_y_pos -- their definitions live in the un-vendored npm package
+ * secp256k1_hash_to_curve_circom (ts/generate_inputs; circuits/circom/test/v1.test.ts:5,38-40) and cannot be pinned here.
+ * An invalid pk (or malformed message offsets) zeroes the item's outputs. */
+int plume_h2c_intermediates_batch(plume_ctx* ctx, size_t n,
+                                  const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk,
+                                  int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h);
+/* 32-byte big-endian values (c, s, pk.x, pk.y, nullifier.x, ... of a signature) -> 4 x 64-bit little-endian registers each
+ * (circuits/circom/utils.ts:11-17, verify_nullifier.circom:380-385).  Host memory; no context needed. */
+int plume_registers_from_be(size_t nvalues, const uint8_t* be32, uint64_t* registers);
+
 /* plume_sign_batch with the point outputs as 33-byte SEC1-compressed records (02|03 || x; identity = 00 followed by 32 zero
  * bytes) -- the wire format of the reference's serde / wasm layer (javascript/src/lib.rs:95-118).  pk_in stays 64-byte affine. */
 int plume_sign_batch_sec1(plume_ctx* ctx, int version, size_t n,
@@ -196,6 +215,10 @@ int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n,
 int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n,
                                      const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                      const uint8_t* pk, uint8_t* h_out, void* stream);
+int plume_h2c_intermediates_batch_device(plume_ctx* ctx, size_t n,
+                                         const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
+                                         int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h, void* stream);
+int plume_registers_from_be_device(plume_ctx* ctx, size_t nvalues, const uint8_t* be32, uint64_t* registers, void* stream);
 int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n,
                                  const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                  const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,

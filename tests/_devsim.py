@@ -144,6 +144,21 @@ def h2c_batch(msgs_buf, msg_off, pk):
     return h
 
 
+def h2c_intermediates(msgs_buf, msg_off, pk=None, registers=False):
+    n = len(msg_off) - 1
+    o = {k: np.zeros((n, w, 32), dtype=np.uint8) for k, w in [("u", 2), ("mapped", 4), ("q", 4), ("h", 2)]}
+    rc = lib().ds_h2c_intermediates(C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), _p(_aligned(pk)), C.c_int(1 if registers else 0), _p(o["u"]), _p(o["mapped"]), _p(o["q"]), _p(o["h"]))
+    assert rc == 0
+    return {k: v.view(np.uint64) for k, v in o.items()} if registers else o
+
+
+def registers_from_be(values):
+    v = np.ascontiguousarray(values, dtype=np.uint8)
+    out = np.zeros(v.shape, dtype=np.uint8)
+    lib().ds_registers_from_be(C.c_size_t(v.size // 32), _p(v), _p(out))
+    return out.view(np.uint64)
+
+
 def point_mul(k: bytes, p: bytes):
     out = (C.c_uint8 * 64)()
     ok = lib().ds_point_mul((C.c_uint8 * 32).from_buffer_copy(k), (C.c_uint8 * 64).from_buffer_copy(p), out)

@@ -1,0 +1,109 @@
+/* abi_smoke.c — a NON-Python caller of the drop-in boundary: plain C, includes only include/plume_hip.h, links -lplume_hip.
+ * This is what a Rust / Go / Java FFI sees: no numpy, no torch, no ctypes conveniences.
+ *
+ * Reproduces the reference's fixed vector (rust-k256/tests/signing.rs:9-21,48-64; rust-k256/tests/verification.rs:25-107;
+ * rust-arkworks/src/tests.rs:266-299) through plume_sign_batch / plume_verify_batch / plume_verify_non_zk_batch, on a single-device
+ * and on a two-shard context, with pageable and with page-locked buffers.  Exit code 0 and "abi_smoke ok" on success.
+ *
+ *   gcc -O1 -Wall -I include tests/abi_c/abi_smoke.c -L zk-nullifier-sig_amd -lplume_hip -Wl,-rpath,$PWD/zk-nullifier-sig_amd -o /tmp/abi_smoke
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "plume_hip.h"
+
+static int fails = 0;
+#define CHECK(cond, what)                                                       \
+    do {                                                                        \
+        if (!(cond)) { fprintf(stderr, "FAIL %s:%d: %s (%s)\n", __FILE__, __LINE__, what, plume_last_error()); fails++; } \
+    } while (0)
+
+static void unhex(uint8_t* out, const char* hex) {
+    for (size_t i = 0; hex[2 * i]; i++) { unsigned v; sscanf(hex + 2 * i, "%2x", &v); out[i] = (uint8_t)v; }
+}
+static int eq_hex(const uint8_t* b, const char* hex) {
+    uint8_t t[64];
+    size_t n = strlen(hex) / 2;
+    unhex(t, hex);
+    return memcmp(b, t, n) == 0;
+}
+
+/* rust-k256/tests/signing.rs:9-21 */
+static const char* SK = "519b423d715f8b581f4fa8ee59f4771a5b44c8130b4e3eacca54a56dda72b464";
+static const char* R = "93b9323b629f251b8f3fc2dd11f4672c5544e8230d493eceea98a90bda789808";
+static const char* MSG = "An example app message string";
+static const char* C_V1 = "c6a7fc2c926ddbaf20731a479fb6566f2daa5514baae5223fe3b32edbce83254";
+static const char* S_V1 = "e69f027d84cb6fe5f761e333d12e975fb190d163e8ea132d7de0bd6079ba28ca";
+static const char* C_V2 = "3dbfb717705010d4f44a70720c95e74b475bd3a783ab0b9e8a6b3b363434eb96";
+static const char* S_V2 = "528e8fbb6452f82200797b1a73b2947a92524bd611085a920f1177cb8098136b";
+/* rust-arkworks/src/tests.rs:189-262 */
+static const char* PK = "0cec028ee08d09e02672a68310814354f9eabfff0de6dacc1cd3a774496076aeeff471fba0409897b6a48e8801ad12f95d0009b753cf8f51c128bf6b0bd27fbd";
+static const char* NUL = "57bc3ed28172ef8adde4b9e0c2cce745fcc5a66473a45c1e626f1d0c67e558306a2f41488d58f33ae46edd2188e111609f9f3ae67ea38fa891d6087fe59ecb73";
+static const char* GR = "9d8ca4350e7e2ad27abc6d2a281365818076662962a28429590e2dc736fe9804ff08c30b8afd4e854623c835d9c3aac6bcebe45112472d9b9054816a7670c5a1";
+static const char* HR = "6d017c6f63c59fa7a5b1e9a654e27d2869579f4d152131db270558fccd27b97c586c43fb5c99818c564a8f80a88a65f83e3f44d3c6caf5a1a4e290b777ac56ed";
+
+enum { N = 3 };   /* the vector three times over, so that a two-shard context has something to split */
+
+static void run(plume_ctx* ctx, int pinned, const char* label) {
+    const size_t mlen = strlen(MSG);
+    uint8_t* base = pinned ? (uint8_t*)plume_host_alloc(4096) : (uint8_t*)malloc(4096);
+    CHECK(base != NULL, "buffer allocation");
+    if (!base) return;
+    memset(base, 0, 4096);
+    uint8_t *msgs = base, *sk = base + 256, *r = sk + 32 * N, *pk = r + 32 * N, *nul = pk + 64 * N, *c = nul + 64 * N, *s = c + 32 * N, *rp = s + 32 * N, *hr = rp + 64 * N,
+            *status = hr + 64 * N, *ok = status + 16;
+    uint64_t off[N + 1];
+    for (int i = 0; i < N; i++) { memcpy(msgs + mlen * i, MSG, mlen); off[i] = mlen * i; unhex(sk + 32 * i, SK); unhex(r + 32 * i, R); }
+    off[N] = mlen * N;
+    for (int ver = 1; ver <= 2; ver++) {
+        int rc = plume_sign_batch(ctx, ver, N, msgs, off, sk, r, NULL, pk, nul, c, s, rp, hr, status);
+        CHECK(rc == PLUME_OK, "plume_sign_batch");
+        for (int i = 0; i < N; i++) {
+            CHECK(status[i] == 0, "sign status");
+            CHECK(eq_hex(c + 32 * i, ver == 1 ? C_V1 : C_V2), "c matches rust-k256/tests/signing.rs");
+            CHECK(eq_hex(s + 32 * i, ver == 1 ? S_V1 : S_V2), "s matches rust-k256/tests/signing.rs");
+            CHECK(eq_hex(pk + 64 * i, PK) && eq_hex(nul + 64 * i, NUL) && eq_hex(rp + 64 * i, GR) && eq_hex(hr + 64 * i, HR), "points match rust-arkworks/src/tests.rs");
+        }
+        rc = plume_verify_batch(ctx, ver, N, msgs, off, pk, nul, c, s, ver == 1 ? rp : NULL, ver == 1 ? hr : NULL, ok);
+        CHECK(rc == PLUME_OK && ok[0] == 1 && ok[1] == 1 && ok[2] == 1, "verify accepts the reference signature");
+        rc = plume_verify_non_zk_batch(ctx, ver, N, msgs, off, pk, nul, s, rp, hr, c, ok);
+        CHECK(rc == PLUME_OK && ok[0] == 1 && ok[1] == 1 && ok[2] == 1, "verify_non_zk accepts the reference signature");
+        s[32 + 31] ^= 1;   /* tamper with item 1 only */
+        rc = plume_verify_batch(ctx, ver, N, msgs, off, pk, nul, c, s, ver == 1 ? rp : NULL, ver == 1 ? hr : NULL, ok);
+        CHECK(rc == PLUME_OK && ok[0] == 1 && ok[1] == 0 && ok[2] == 1, "verify rejects exactly the tampered item");
+        s[32 + 31] ^= 1;
+        /* arkworks shape: pk supplied, identical bytes */
+        uint8_t c2[32 * N], s2[32 * N], nul2[64 * N], rp2[64 * N], hr2[64 * N];
+        rc = plume_sign_batch(ctx, ver, N, msgs, off, sk, r, pk, NULL, nul2, c2, s2, rp2, hr2, status);
+        CHECK(rc == PLUME_OK && !memcmp(c2, c, sizeof c2) && !memcmp(s2, s, sizeof s2) && !memcmp(nul2, nul, sizeof nul2), "sign_with_r shape gives identical bytes");
+    }
+    /* error behaviour: argument errors come back as codes with a message, nothing unwinds */
+    CHECK(plume_verify_batch(ctx, 3, N, msgs, off, pk, nul, c, s, rp, hr, ok) == PLUME_ERR_ARG && strlen(plume_last_error()) > 0, "bad version is PLUME_ERR_ARG");
+    CHECK(plume_verify_batch(ctx, 1, N, msgs, off, pk, nul, c, s, NULL, NULL, ok) == PLUME_ERR_ARG, "V1 without r_point is PLUME_ERR_ARG");
+    CHECK(plume_sign_batch(ctx, 1, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL) == PLUME_OK, "empty batch");
+    /* circuit registers (circuits/circom/utils.ts:11-17): c_v1 as four little-endian 64-bit registers */
+    uint8_t be[32]; uint64_t regs[4];
+    unhex(be, C_V1);
+    CHECK(plume_registers_from_be(1, be, regs) == PLUME_OK && regs[0] == 0xfe3b32edbce83254ull && regs[3] == 0xc6a7fc2c926ddbafull, "register packing");
+    if (pinned) plume_host_free(base); else free(base);
+    printf("  %s: done\n", label);
+}
+
+int main(void) {
+    plume_ctx* ctx = NULL;
+    int rc = plume_init(&ctx, 0);
+    if (rc != PLUME_OK) { fprintf(stderr, "plume_init failed (%d): %s\n", rc, plume_last_error()); return 2; }
+    printf("%s, %d shard(s)\n", plume_version(), plume_num_shards(ctx));
+    run(ctx, 0, "single device, pageable buffers");
+    run(ctx, 1, "single device, page-locked buffers");
+    plume_destroy(ctx);
+    const int ids[2] = {0, 0};
+    rc = plume_init_multi(&ctx, ids, 2);
+    CHECK(rc == PLUME_OK && plume_num_shards(ctx) == 2, "plume_init_multi");
+    if (rc == PLUME_OK) { run(ctx, 0, "two shards, pageable buffers"); plume_destroy(ctx); }
+    CHECK(plume_init(&ctx, 9999) != PLUME_OK, "bad device id is an error");
+    if (fails) { fprintf(stderr, "%d check(s) failed\n", fails); return 1; }
+    printf("abi_smoke ok\n");
+    return 0;
+}

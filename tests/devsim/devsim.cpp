@@ -240,6 +240,13 @@ int ds_h2c_batch(uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const
     return 0;
 }
 
+int ds_h2c_intermediates(uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h) {
+    H2cInterArgs a; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msg_off[n]; a.pk = pk; a.registers = registers; a.u = u; a.mapped = mapped; a.q = q; a.h = h;
+    for (uint32_t i = 0; i < n; i++) h2c_intermediates(a, i);
+    return 0;
+}
+void ds_registers_from_be(size_t nvalues, const uint8_t* in, uint8_t* out) { for (size_t k = 0; k < nvalues; k++) registers_from_be(out, in, k); }
+
 // k*P through the device table + msm path (single base, affine 64-byte BE in/out); returns 0 for invalid input
 int ds_point_mul(const uint8_t k_be[32], const uint8_t p_be[64], uint8_t out[64]) {
     fe x, y;

@@ -120,3 +120,26 @@ def test_generated_field_multiplication_is_current():
     csrc = ROOT / "zk-nullifier-sig_amd" / "csrc"
     out = subprocess.run([sys.executable, str(csrc / "gen_fe_mul.py")], capture_output=True, text=True, check=True).stdout
     assert out == (csrc / "plume_fe_mul.inc").read_text(), "run `python gen_fe_mul.py > plume_fe_mul.inc` in zk-nullifier-sig_amd/csrc"
+
+
+def build_abi_smoke(tmp_path):
+    """compile tests/abi_c/abi_smoke.c with plain gcc against include/plume_hip.h and the in-tree library"""
+    import subprocess
+    import zk_nullifier_sig_amd as plume
+    exe = tmp_path / "abi_smoke"
+    libdir = plume.library_path().parent
+    subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-I", str(ROOT / "include"), str(ROOT / "tests" / "abi_c" / "abi_smoke.c"), "-L", str(libdir), "-lplume_hip",
+                    f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True, capture_output=True, text=True)
+    return exe
+
+
+@needs_lib
+def test_c_caller_builds_against_the_header_and_fails_loudly_without_a_gpu(tmp_path):
+    """a non-Python FFI caller: the header is valid C, every symbol it uses links, and without a GPU plume_init reports PLUME_ERR_NODEV"""
+    import subprocess
+    import torch
+    exe = build_abi_smoke(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (the GPU suite runs the program)")
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 2 and "no CPU fallback" in r.stderr

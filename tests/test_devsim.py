@@ -270,17 +270,17 @@ NONZK = json.loads((Path(__file__).parent / "golden" / "golden_non_zk.json").rea
 @pytest.mark.parametrize("ver", [1, 2])
 def test_verify_non_zk_golden_and_fuzz(ver):
     """device code on the host, PLUME_MODE_NON_ZK (rust-arkworks/src/tests.rs:28-78): the Python oracle's vectors (incl. Err = 2, zero scalars),
-    then 256 fuzzed items against the C oracle"""
+    then 768 fuzzed items against the C oracle"""
     from tests import _fuzz
     from tests.test_oracle_c import non_zk_args
     items = [it for it in NONZK if it["version"] == ver]
     ok = D.verify_non_zk_batch(ver, *non_zk_args(items))
     bad = [(it["note"], int(o), it["ok"]) for it, o in zip(items, ok) if int(o) != it["ok"]]
     assert not bad, bad
-    n = 256
-    b = synth.sign_inputs(n, start=810000)
+    n = 768
+    b = synth.sign_inputs(n, start=830000)
     signed = OC.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"], nthreads=8)
-    v = _fuzz.fuzz_non_zk_batch(ver, signed, b, seed=11 + ver)
+    v = _fuzz.fuzz_non_zk_batch(ver, signed, b, seed=21 + ver)
     args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["s"], v["r_point"], v["hashed_to_curve_r"], v["c"])
     got = D.verify_non_zk_batch(*args)
     want = OC.verify_non_zk_batch(*args, nthreads=8)
@@ -347,3 +347,48 @@ def test_inversion_by_divsteps_matches_fermat_and_python():
     assert got == [pow(v % P, -1, P) for v in vals]
     assert [g % P for g in D.fe_op(5, vals)] == got
     assert D.fe_op(15, [0, P]) == [0, 0]
+
+
+def _check_h2c_intermediates(get, regs_from_be, kats):
+    """shared by the host simulation and the GPU test: u0, u1, Q0, Q1, H against the RFC 9380 J.8.1 vector the reference holds
+    (rust-arkworks/src/secp256k1/tests.rs:89-108) and the goldens' u0, u1, q0, q1; the E' points against the Python oracle's simplified SWU;
+    the register form against circuits/circom/utils.ts:11-17 (value = sum r_i 2^(64 i))"""
+    k = kats["rfc9380_empty"]
+    mb, off = OC.pack_msgs([b"", b"abc"])
+    o = get(mb, off, None, False)
+    hx = lambda a: a.tobytes().hex()  # noqa: E731
+    assert (hx(o["u"][0, 0]), hx(o["u"][0, 1])) == (k["u0"], k["u1"])
+    assert (hx(o["q"][0, 0]), hx(o["q"][0, 1]), hx(o["q"][0, 2]), hx(o["q"][0, 3])) == (k["q0_x"], k["q0_y"], k["q1_x"], k["q1_y"])
+    assert (hx(o["h"][0, 0]), hx(o["h"][0, 1])) == (k["p_x"], k["p_y"])
+    assert hx(o["h"][1, 0]) + hx(o["h"][1, 1]) == kats["h2c_abc"]["x"] + kats["h2c_abc"]["y"]
+    items = GOLD["sign_v1"][:32]
+    msgs = [bytes.fromhex(it["msg"]) for it in items]
+    mb, off = OC.pack_msgs(msgs)
+    pk = OC.arr(items, "pk", 64)
+    o = get(mb, off, pk, False)
+    r = get(mb, off, pk, True)
+    for i, it in enumerate(items):
+        assert (hx(o["u"][i, 0]), hx(o["u"][i, 1])) == (it["u0"], it["u1"])
+        assert hx(o["q"][i, :2]) == it["q0"] and hx(o["q"][i, 2:]) == it["q1"] and hx(o["h"][i]) == it["h"]
+        for j, uu in enumerate((int(it["u0"], 16), int(it["u1"], 16))):
+            x, y = O.map_to_curve_sswu(uu)                                # on E'
+            assert (int(hx(o["mapped"][i, 2 * j]), 16), int(hx(o["mapped"][i, 2 * j + 1]), 16)) == (x, y)
+            assert (y * y - x**3 - O.ISO_A * x - O.ISO_B) % P == 0
+            assert O.pt_bytes(O.iso_map((x, y))).hex() == it["q0" if j == 0 else "q1"]
+        for key in ("u", "mapped", "q", "h"):                             # registers: little-endian 64-bit limbs of the same values
+            for j in range(o[key].shape[1]):
+                val = int(hx(o[key][i, j]), 16)
+                assert [int(x) for x in r[key][i, j]] == [(val >> (64 * t)) & (2**64 - 1) for t in range(4)]
+    # c, s, pk, nullifier -> registers (scalarToCircuitValue / pointToCircuitValue)
+    vals = np.concatenate([OC.arr(items, "c", 32), OC.arr(items, "s", 32), OC.arr(items, "nullifier", 64).reshape(-1, 32)])
+    regs = regs_from_be(vals)
+    for v, rg in zip(vals, regs.reshape(-1, 4)):
+        assert sum(int(x) << (64 * t) for t, x in enumerate(rg)) == int(v.tobytes().hex(), 16)
+    # invalid pk -> zeros
+    bad = pk.copy(); bad[0, 63] ^= 1
+    z = get(mb, off, bad, False)
+    assert not z["u"][0].any() and not z["h"][0].any() and z["h"][1].any()
+
+
+def test_h2c_intermediates_and_registers(kats):
+    _check_h2c_intermediates(lambda mb, off, pk, regs: D.h2c_intermediates(mb, off, pk, regs), D.registers_from_be, kats)

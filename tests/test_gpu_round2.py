@@ -311,3 +311,47 @@ def test_error_paths(eng):
     stn = st.cpu().numpy()
     assert stn[99] == 2 and stn[100] == 2 and int(stn.sum()) == 4
     assert np.array_equal(o["s"].cpu().numpy()[:99], sg["s"][:99])
+
+
+# ------------------------------------------------------------------------------- f3: circuit witness hints
+def test_h2c_intermediates_and_registers(eng, kats):
+    """plume_h2c_intermediates_batch + plume_registers_from_be on the GPU / through the C ABI: same checks as the host simulation"""
+    import zk_nullifier_sig_amd as plume
+    from zk_nullifier_sig_amd import capi
+    from tests.test_devsim import _check_h2c_intermediates
+    _check_h2c_intermediates(lambda mb, off, pk, regs: eng.h2c_intermediates_batch(mb, off, pk, registers=regs), capi.registers_from_be, kats)
+    # device form of the register packing
+    import torch
+    v = np.frombuffer(np.random.default_rng(1).bytes(32 * 1000), dtype=np.uint8).reshape(1000, 32)
+    dv = torch.from_numpy(v.copy()).to("cuda:0")
+    out = torch.zeros((1000, 4), dtype=torch.int64, device="cuda:0")
+    eng._chk(eng._lib.plume_registers_from_be_device(eng._ctx, 1000, eng._dp(dv), eng._dp(out), None), "plume_registers_from_be_device")
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), capi.registers_from_be(v))
+    # the façade's circuit-input dictionary for the reference's fixed vector (circuits/circom/test/v1.test.ts:64-80 uses the same sk / r / message)
+    vv = kats["plume_vector"]
+
+    class Mock:
+        def fill_bytes(self, n):
+            return bytes.fromhex(vv["r"])
+
+    sig = plume.PlumeSignature.sign_v1(plume.SecretKey.from_bytes(bytes.fromhex(vv["sk"])), vv["msg_utf8"].encode(), Mock(), eng)
+    ci = plume.circuit_inputs(sig, eng)
+    val = lambda regs: sum(int(x) << (64 * t) for t, x in enumerate(regs))  # noqa: E731
+    assert val(ci["c"]) == int(vv["c_v1"], 16) and val(ci["s"]) == int(vv["s_v1"], 16)
+    assert (val(ci["pk"][0]), val(ci["pk"][1])) == (int(vv["pk_x"], 16), int(vv["pk_y"], 16))
+    assert (val(ci["nullifier"][0]), val(ci["nullifier"][1])) == (int(vv["nullifier_x"], 16), int(vv["nullifier_y"], 16))
+    u0, u1 = O.hash_to_field2(vv["msg_utf8"].encode() + O.sec1_compress((int(vv["pk_x"], 16), int(vv["pk_y"], 16))))
+    assert (val(ci["q0_x_mapped"]), val(ci["q0_y_mapped"])) == O.map_to_curve_sswu(u0)
+    assert (val(ci["q1_x_mapped"]), val(ci["q1_y_mapped"])) == O.map_to_curve_sswu(u1)
+
+
+# ------------------------------------------------------------------------------- f2: a non-Python caller of the C ABI
+def test_c_program_reproduces_the_reference_vector(tmp_path):
+    """tests/abi_c/abi_smoke.c (gcc, only include/plume_hip.h, -lplume_hip): rust-k256/tests/signing.rs:9-21 through the exact FFI surface a Rust
+    binding would use -- single device, page-locked buffers, two-shard context, error codes"""
+    import subprocess
+    from tests.test_abi_cpu import build_abi_smoke
+    exe = build_abi_smoke(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "abi_smoke ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -79,6 +79,10 @@ def _load():
     lib.plume_verify_batch_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 8
     lib.plume_sign_batch_device.argtypes = [vp, i, sz, vp, vp, sz] + [vp] * 11
     lib.plume_hash_to_curve_batch_device.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp]
+    lib.plume_h2c_intermediates_batch.argtypes = [vp, sz, vp, vp, vp, i, vp, vp, vp, vp]
+    lib.plume_h2c_intermediates_batch_device.argtypes = [vp, sz, vp, vp, sz, vp, i, vp, vp, vp, vp, vp]
+    lib.plume_registers_from_be.argtypes = [sz, vp, vp]
+    lib.plume_registers_from_be_device.argtypes = [vp, sz, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -86,7 +90,8 @@ def _load():
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
     return ["plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_host_alloc", "plume_host_free", "plume_host_register",
-            "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device",
+            "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
+            "plume_registers_from_be", "plume_registers_from_be_device",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
             "plume_hash_to_curve_batch", "plume_nullifier_first_occurrence", "plume_nullifier_first_occurrence_device", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
             "plume_last_stage_times", "plume_microbench", "plume_microbench_last_ticks"]
@@ -110,6 +115,19 @@ def _np(a, width, n, name):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def registers_from_be(values):
+    """(.., 32) uint8 big-endian values -> (.., 4) uint64 little-endian 64-bit registers (circuits/circom/utils.ts:11-17)"""
+    lib = _load()
+    v = np.ascontiguousarray(values, dtype=np.uint8)
+    if v.shape[-1] != 32:
+        raise ValueError("values must be 32-byte records")
+    out = np.zeros(v.shape[:-1] + (4,), dtype=np.uint64)
+    rc = lib.plume_registers_from_be(v.size // 32, _ptr(v), _ptr(out))
+    if rc != 0:
+        raise PlumeHipError(f"plume_registers_from_be failed ({rc}): {lib.plume_last_error().decode()}")
+    return out
 
 
 def pinned_empty(shape, dtype=np.uint8):
@@ -290,6 +308,20 @@ class Engine:
         h = np.zeros((n, 64), dtype=np.uint8)
         self._chk(self._lib.plume_hash_to_curve_batch(self._ctx, n, _ptr(msgs), _ptr(msg_off), _ptr(pk), _ptr(h)), "plume_hash_to_curve_batch")
         return h
+
+    def h2c_intermediates_batch(self, msgs, msg_off, pk=None, registers=False):
+        """circuit witness hints from the GPU hash_to_curve: dict u (n,2,·), mapped (n,4,·), q (n,4,·), h (n,2,·); values are 32
+        big-endian bytes (uint8, last axis 32) or, with registers=True, 4 little-endian 64-bit registers (uint64, last axis 4)"""
+        n = len(msg_off) - 1
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
+        pk = None if pk is None else _np(pk, 64, n, "pk")
+        o = {k: np.zeros((n, w, 32), dtype=np.uint8) for k, w in [("u", 2), ("mapped", 4), ("q", 4), ("h", 2)]}
+        self._chk(self._lib.plume_h2c_intermediates_batch(self._ctx, n, _ptr(msgs), _ptr(msg_off), _ptr(pk), 1 if registers else 0, _ptr(o["u"]), _ptr(o["mapped"]),
+                                                          _ptr(o["q"]), _ptr(o["h"])), "plume_h2c_intermediates_batch")
+        if registers:
+            o = {k: v.view(np.uint64) for k, v in o.items()}
+        return o
 
     def nullifier_first_occurrence(self, nullifier, live=None, ids=None):
         """first[i] = 1 iff item i is live and holds the smallest id (default: position) among the live items with the same 64-byte

@@ -497,6 +497,30 @@ extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const 
     return 0;
 }
 
+// ------------------------------------------------------------------------------ circuit witness hints
+extern "C" int plume_h2c_intermediates_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
+                                                    int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h, void* stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
+    if (registers != 0 && registers != 1) return fail(PLUME_ERR_ARG, "registers must be 0 or 1");
+    if (n == 0) return 0;
+    H2cInterArgs a;
+    a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msgs_bytes; a.pk = pk; a.registers = registers; a.u = u; a.mapped = mapped; a.q = q; a.h = h;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->timer.begin(st);
+    launch_h2c_intermediates(a, st); ctx->timer.stage("h2c_intermediates", st);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int plume_registers_from_be_device(plume_ctx* ctx, size_t nvalues, const uint8_t* be32, uint64_t* registers, void* stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (nvalues && (!be32 || !registers)) return fail(PLUME_ERR_ARG, "null array");
+    if (nvalues == 0) return 0;
+    launch_registers_from_be((uint8_t*)registers, be32, nvalues, stream ? (hipStream_t)stream : ctx->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ nullifier-set post-processing
 static int dedup_device(plume_ctx* ctx, size_t n, const uint8_t* nul, const uint8_t* live, const uint64_t* ids, uint8_t* first, uint64_t* n_unique_dev, hipStream_t st) {
     if (n == 0) { if (n_unique_dev) HIPCHK(hipMemsetAsync(n_unique_dev, 0, 8, st)); return 0; }
@@ -797,6 +821,53 @@ extern "C" int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n, const uint8_t
     if (n == 0) return 0;
     if (ctx->shards.empty()) return h2c_host(ctx, n, msgs, msg_off, pk, h_out);
     return for_shards(ctx, n, [=](plume_ctx* sh, size_t lo, size_t hi) -> int { return h2c_host(sh, hi - lo, msgs, msg_off + lo, pk ? pk + 64 * lo : nullptr, h_out + 64 * lo); });
+}
+
+static int h2c_inter_host(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* u, uint8_t* mapped, uint8_t* q,
+                          uint8_t* h) {
+    HIPCHK(hipSetDevice(ctx->device));
+    return host_pipeline(
+        ctx, n,
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
+            if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
+            if (pk) { if (int rc = h2d(ctx, sl.in[0], pk + 64 * i0, 64 * cnt)) return rc; }
+            return sl.out[0].ensure(64 * cnt) || sl.out[1].ensure(128 * cnt) || sl.out[2].ensure(128 * cnt) || sl.out[3].ensure(64 * cnt) ? PLUME_ERR_HIP : 0;
+        },
+        [&](HostSlot& sl, size_t cnt) -> int {
+            return plume_h2c_intermediates_batch_device(ctx, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], pk ? sl.in[0].as<uint8_t>() : nullptr, registers,
+                                                        u ? sl.out[0].as<uint8_t>() : nullptr, mapped ? sl.out[1].as<uint8_t>() : nullptr, q ? sl.out[2].as<uint8_t>() : nullptr,
+                                                        h ? sl.out[3].as<uint8_t>() : nullptr, ctx->stream);
+        },
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
+            if (u) { if (int rc = d2h(ctx, u + 64 * i0, sl.out[0], 64 * cnt)) return rc; }
+            if (mapped) { if (int rc = d2h(ctx, mapped + 128 * i0, sl.out[1], 128 * cnt)) return rc; }
+            if (q) { if (int rc = d2h(ctx, q + 128 * i0, sl.out[2], 128 * cnt)) return rc; }
+            if (h) { if (int rc = d2h(ctx, h + 64 * i0, sl.out[3], 64 * cnt)) return rc; }
+            return 0;
+        });
+}
+extern "C" int plume_h2c_intermediates_batch(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* u,
+                                             uint8_t* mapped, uint8_t* q, uint8_t* h) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "null context");
+    if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
+    if (registers != 0 && registers != 1) return fail(PLUME_ERR_ARG, "registers must be 0 or 1");
+    if (n == 0) return 0;
+    if (ctx->shards.empty()) return h2c_inter_host(ctx, n, msgs, msg_off, pk, registers, u, mapped, q, h);
+    return for_shards(ctx, n, [=](plume_ctx* sh, size_t lo, size_t hi) -> int {
+        return h2c_inter_host(sh, hi - lo, msgs, msg_off + lo, pk ? pk + 64 * lo : nullptr, registers, u ? u + 64 * lo : nullptr, mapped ? mapped + 128 * lo : nullptr,
+                              q ? q + 128 * lo : nullptr, h ? h + 64 * lo : nullptr);
+    });
+}
+// host form of the register packing: a byte reversal, done on the host (no reason to cross PCIe for it)
+extern "C" int plume_registers_from_be(size_t nvalues, const uint8_t* be32, uint64_t* registers) {
+    if (nvalues && (!be32 || !registers)) return fail(PLUME_ERR_ARG, "null array");
+    for (size_t k = 0; k < nvalues; k++)
+        for (int j = 0; j < 4; j++) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; b++) v = (v << 8) | be32[32 * k + 8 * (3 - j) + b];
+            registers[4 * k + j] = v;
+        }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ measurement

@@ -203,6 +203,15 @@ __global__ PLUME_H2C_BOUNDS void k_h2c_only(H2cArgs a) {
     if (i < a.n) h2c_only(a, i);
 }
 
+__global__ PLUME_H2C_BOUNDS void k_h2c_intermediates(H2cInterArgs a) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < a.n) h2c_intermediates(a, i);
+}
+__global__ __launch_bounds__(kBlock) void k_registers_from_be(uint8_t* out, const uint8_t* in, size_t nvalues) {
+    size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k < nvalues) registers_from_be(out, in, k);
+}
+
 // ------------------------------------------------------------------------------ nullifier-set post-processing
 __global__ __launch_bounds__(kBlock) void k_dedup_clear(DedupArgs a) {
     uint32_t s = blockIdx.x * kBlock + threadIdx.x;
@@ -334,6 +343,10 @@ void launch_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, hipStream_
 }
 void launch_decompress(const DecompressArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_decompress, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_h2c_only(const H2cArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_only, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_h2c_intermediates(const H2cInterArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_intermediates, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_registers_from_be(uint8_t* out, const uint8_t* in, size_t nvalues, hipStream_t st) {
+    hipLaunchKernelGGL(k_registers_from_be, dim3(nblocks(nvalues)), dim3(kBlock), 0, st, out, in, nvalues);
+}
 void launch_gtab(uint32_t* gtab, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gtab, dim3(1), dim3(64), 0, st, gtab, base_g, flag, scr); }
 void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gcomb, dim3(1), dim3(64), 0, st, comb, bases, flags, scr); }
 void launch_dedup(const DedupArgs& a, hipStream_t st) {

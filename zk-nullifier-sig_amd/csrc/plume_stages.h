@@ -217,7 +217,12 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
 
 PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
     const size_t nt = 2 * (size_t)a.n;
-    uint8_t ok = a.itemflags[i] == PLUME_ITEM_ERR ? 2 : 0;
+    uint8_t ok = 0;
+    if (a.itemflags[i] == PLUME_ITEM_ERR) {
+        // Err(HashToCurveError) needs every argument to be a value of its type first: an r_point / hashed_to_curve_r that is no curve point rejects
+        fe x, y;
+        ok = (load_affine_be(x, y, a.rpt + 64 * (size_t)i) != PLUME_JOB_INVALID && load_affine_be(x, y, a.hr + 64 * (size_t)i) != PLUME_JOB_INVALID) ? 2 : 0;
+    }
     if (!a.itemflags[i]) {
         jac rc, hc;
         ld_jac_soa(rc, a.res, nt, 2 * (size_t)i); rc.inf = a.resinf[2 * (size_t)i];
@@ -511,6 +516,94 @@ PLUME_HD void h2c_only(const H2cArgs& a, uint32_t i) {
         fe_mul(x, h.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y, h.y, zi2);
     }
     store_affine_be(a.h_out + 64 * (size_t)i, x, y, bad || h.inf);
+}
+
+// ================================================================== circuit witness hints ("next" row f-3, the pinnable part)
+// What a prover farm needs to fill the circom verifier's inputs (circuits/circom/verify_nullifier.circom:14-31,152-162) from the same h2c the
+// verifier runs: u0, u1 (hash_to_field), the simplified-SWU outputs on the isogenous curve E' (q{0,1}_x_mapped, q{0,1}_y_mapped), Q0, Q1 (after
+// the 3-isogeny) and H = Q0 + Q1; each value either as 32 big-endian bytes or as the circuit's 4 x 64-bit little-endian registers
+// (circuits/circom/utils.ts:11-17 scalarToCircuitValue; verify_nullifier.circom:380-385).  q*_gx1_sqrt, q*_gx2_sqrt and q*_y_pos are NOT produced:
+// their definitions live in the un-vendored secp256k1_hash_to_curve_circom/ts/generate_inputs (circuits/circom/test/v1.test.ts:5,38-40), unpinnable here.
+struct H2cInterArgs {
+    uint32_t n;
+    const uint8_t* msgs; const uint64_t* msg_off;
+    uint64_t msgs_bytes;
+    const uint8_t* pk;     // may be NULL: hash the raw message bytes (RFC 9380 J.8.1 vectors)
+    int registers;         // 0: 32 big-endian bytes per value; 1: 4 little-endian 64-bit registers per value
+    uint8_t* u;            // optional, n x 64 : u0 | u1
+    uint8_t* mapped;       // optional, n x 128: q0_x_mapped | q0_y_mapped | q1_x_mapped | q1_y_mapped   (affine, on E')
+    uint8_t* q;            // optional, n x 128: Q0.x | Q0.y | Q1.x | Q1.y   (affine, on secp256k1; identity = zeros)
+    uint8_t* h;            // optional, n x 64 : H.x | H.y
+};
+// one 256-bit value: canonical, big-endian bytes or little-endian registers (= little-endian bytes); dst is 4-byte aligned
+PLUME_HD void store_value(uint8_t* dst, fe v, int registers) {
+    fe_normalize(v);
+    uint32_t w[8];
+    fe_to_words(w, v);
+    if (registers) { uint32_t* q = (uint32_t*)dst; PLUME_UNROLL for (int k = 0; k < 8; k++) q[k] = w[k]; }
+    else words_to_be_aligned(dst, w);
+}
+PLUME_HD void h2c_intermediates(const H2cInterArgs& a, uint32_t i) {
+    uint64_t o0; uint32_t mlen;
+    bool bad = !msg_span(o0, mlen, a.msg_off, i, a.msgs_bytes);
+    fe px = fe_zero(), py = fe_zero();
+    uint32_t enc = PLUME_ENC_NONE;
+    if (a.pk) {
+        const uint32_t f = load_affine_be(px, py, a.pk + 64 * (size_t)i);
+        bad = bad || f == PLUME_JOB_INVALID;
+        enc = f == PLUME_JOB_INF ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT;
+    }
+    fe u[2], xn[2], xd[2], y[2];
+    jac q[2], h;
+    if (bad) {   // all outputs zero
+        const fe z = fe_zero();
+        PLUME_NOUNROLL for (int k = 0; k < 4; k++) {
+            if (a.u && k < 2) store_value(a.u + 64 * (size_t)i + 32 * k, z, a.registers);
+            if (a.mapped) store_value(a.mapped + 128 * (size_t)i + 32 * k, z, a.registers);
+            if (a.q) store_value(a.q + 128 * (size_t)i + 32 * k, z, a.registers);
+            if (a.h && k < 2) store_value(a.h + 64 * (size_t)i + 32 * k, z, a.registers);
+        }
+        return;
+    }
+    hash_to_field2(u[0], u[1], a.msgs + o0, mlen, px, 2u + (fe_is_odd(py) ? 1u : 0u), enc);
+    PLUME_NOUNROLL for (int k = 0; k < 2; k++) {
+        sswu_frac(xn[k], xd[k], y[k], u[k]);
+        iso3_frac_to_jac(q[k], xn[k], xd[k], y[k]);
+    }
+    h = q[0];
+    jac_add(h, q[1]);
+    // one inversion for the five denominators xd0, xd1, Z(Q0), Z(Q1), Z(H) (an identity contributes 1; xd is never zero)
+    fe d[5], pre[5], acc = fe_small(1), inv;
+    d[0] = xd[0]; d[1] = xd[1];
+    d[2] = q[0].inf ? fe_small(1) : q[0].z; d[3] = q[1].inf ? fe_small(1) : q[1].z; d[4] = h.inf ? fe_small(1) : h.z;
+    PLUME_UNROLL for (int k = 0; k < 5; k++) { pre[k] = acc; fe_mul(acc, acc, d[k]); }
+    fe_inv(inv, acc);
+    fe di[5];
+    PLUME_UNROLL for (int k = 4; k >= 0; k--) { fe_mul(di[k], inv, pre[k]); fe_mul(inv, inv, d[k]); }
+    if (a.u) { store_value(a.u + 64 * (size_t)i, u[0], a.registers); store_value(a.u + 64 * (size_t)i + 32, u[1], a.registers); }
+    if (a.mapped) {
+        PLUME_NOUNROLL for (int k = 0; k < 2; k++) {
+            fe x; fe_mul(x, xn[k], di[k]);
+            store_value(a.mapped + 128 * (size_t)i + 64 * k, x, a.registers);
+            store_value(a.mapped + 128 * (size_t)i + 64 * k + 32, y[k], a.registers);
+        }
+    }
+    PLUME_NOUNROLL for (int k = 0; k < 3; k++) {
+        const jac& p = k == 2 ? h : q[k];
+        uint8_t* dst = k == 2 ? (a.h ? a.h + 64 * (size_t)i : nullptr) : (a.q ? a.q + 128 * (size_t)i + 64 * k : nullptr);
+        if (!dst) continue;
+        fe x = fe_zero(), yy = fe_zero(), zi2;
+        if (!p.inf) { fe_sqr(zi2, di[2 + k]); fe_mul(x, p.x, zi2); fe_mul(zi2, zi2, di[2 + k]); fe_mul(yy, p.y, zi2); }
+        store_value(dst, x, a.registers); store_value(dst + 32, yy, a.registers);
+    }
+}
+// 32-byte big-endian values -> the circuit's 4 x 64-bit little-endian registers (c, s, pk, nullifier ... of a signature): a byte reversal
+PLUME_HD void registers_from_be(uint8_t* out, const uint8_t* in, size_t k) {
+    const uint32_t* src = (const uint32_t*)(in + 32 * k);
+    uint32_t* dst = (uint32_t*)(out + 32 * k);
+    uint32_t w[8];
+    PLUME_UNROLL for (int j = 0; j < 8; j++) w[j] = bswap32(src[7 - j]);
+    PLUME_UNROLL for (int j = 0; j < 8; j++) dst[j] = w[j];
 }
 
 }  // namespace plume

@@ -18,6 +18,7 @@ from .plume import (  # noqa: E402,F401
     PlumeVersion,
     SecretKey,
     SignatureError,
+    circuit_inputs,
     sign,
     sign_with_r,
     verify_non_zk,
