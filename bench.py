@@ -85,7 +85,25 @@ def cpu_baseline(version: int):
 
     from tests import _oracle_c as OC
     from tests import synth
-    cores = os.cpu_count() or 1
+    visible = os.cpu_count() or 1
+    cores, quota = visible, None
+    try:                                       # the GPU box is a container: a cgroup CPU quota may grant far fewer cores than it shows
+        q, per = (Path("/sys/fs/cgroup/cpu.max").read_text().split() + ["100000"])[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            if q > 0:
+                quota = q / float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        except Exception:
+            pass
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    if quota:
+        cores = max(1, min(cores, int(quota + 0.999)))
     n = 1 << 16
     b = synth.sign_inputs(n)
     signed = OC.sign_batch(version, b["msgs"], b["off"], b["sk"], b["r"], nthreads=cores)
@@ -101,9 +119,10 @@ def cpu_baseline(version: int):
     OC.verify_batch(*a1, nthreads=1)
     t_1 = time.perf_counter() - t0
     assert list(ok_mt) == list(synth.expected_ok(n))
-    out = {"value": round(n / t_mt, 1), "unit": "verifies/s", "cores": cores, "kind": "port",
+    out = {"value": round(n / t_mt, 1), "unit": "verifies/s", "cores": cores, "cores_visible": visible, "kind": "port",
            "sample": f"first {n} items of the same synthetic V{version} batch (1/16 corrupted), plain-C oracle (4x64-bit limbs, 4-bit window, no endomorphism, "
-                     f"one inversion per encoded point), {cores} threads = os.cpu_count(); single thread ({n1} items): {n1 / t_1:.1f} verifies/s. "
+                     f"one inversion per encoded point), {cores} threads (os.cpu_count() = {visible}, cgroup CPU quota = {quota if quota else 'none'}, effective parallelism "
+                     f"measured = {n / t_mt / (n1 / t_1):.1f} cores); single thread ({n1} items): {n1 / t_1:.1f} verifies/s. "
                      f"rust-k256 itself cannot be built here (no rustc/cargo).",
            "single_thread_value": round(n1 / t_1, 1)}
     try:

@@ -64,12 +64,13 @@ const char* plume_last_error(void);
 const char* plume_version(void);
 /* Upper bound on items processed per internal pass (workspace is ~7.1 KB per in-flight item). Default 1<<20. */
 int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
-/* Host-pointer calls only: items per pipelined piece (default 1<<18, capped by the chunk size).  A call is cut into
- * pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (three streams, two staging slots), so
- * for batches of several pieces only the first upload and the last download are exposed.  Results do not depend on it. */
-int plume_set_host_piece(plume_ctx* ctx, size_t items_per_piece);
-/* ... and of the FIRST piece of a call (default 1<<17, capped by the piece size): its upload is the only one no kernel hides. */
+/* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (three streams,
+ * two staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each
+ * following piece up to three times the one before, up to the largest piece (default 1<<19, capped by the chunk size); calls with large
+ * outputs (the signer) end on a small piece (default 1<<17).  Results do not depend on any of this. */
+int plume_set_host_piece(plume_ctx* ctx, size_t largest_piece_items);
 int plume_set_host_first_piece(plume_ctx* ctx, size_t items);
+int plume_set_host_tail_piece(plume_ctx* ctx, size_t items);
 /* Host-pointer calls: caller arrays of at least `bytes` bytes that are not page-locked yet are registered (hipHostRegister) for the
  * duration of the call; 0 (default) = never.  Registration costs more than one batch's copies save: callers that reuse their buffers
  * should page-lock them ONCE with the helpers below instead. */
@@ -161,6 +162,16 @@ int plume_h2c_intermediates_batch(plume_ctx* ctx, size_t n,
  * (circuits/circom/utils.ts:11-17, verify_nullifier.circom:380-385).  Host memory; no context needed. */
 int plume_registers_from_be(size_t nvalues, const uint8_t* be32, uint64_t* registers);
 
+/* ---- SEC1-DER scalar marshalling  (the wasm layer's wire format for `s` and `digest_private`) --------------
+ * der109[i] = SecretKey::from(scalar_i).to_sec1_der() (javascript/src/lib.rs:98-110): the 109-byte RFC 5915 ECPrivateKey
+ *   30 6b 02 01 01 04 20 <scalar> a1 44 03 42 00 04 <x> <y>      with (x, y) = scalar * G
+ * The generator multiplications run on the GPU (doubling-free comb).  status[i] = 0, or PLUME_STATUS_BAD_SCALAR with an all-zero
+ * record when the scalar is outside [1, n-1] (no SecretKey holds it). */
+int plume_scalars_to_sec1_der_batch(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status);
+/* SecretKey::from_sec1_der for that fixed form: ok[i] = 1 iff record i has exactly this structure and a scalar in [1, n-1] (then
+ * scalars[i] holds it, else zeros).  The embedded public key is not recomputed.  Host memory; no context needed. */
+int plume_sec1_der_to_scalars(size_t n, const uint8_t* der109, uint8_t* scalars, uint8_t* ok);
+
 /* plume_sign_batch with the point outputs as 33-byte SEC1-compressed records (02|03 || x; identity = 00 followed by 32 zero
  * bytes) -- the wire format of the reference's serde / wasm layer (javascript/src/lib.rs:95-118).  pk_in stays 64-byte affine. */
 int plume_sign_batch_sec1(plume_ctx* ctx, int version, size_t n,
@@ -218,6 +229,7 @@ int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n,
 int plume_h2c_intermediates_batch_device(plume_ctx* ctx, size_t n,
                                          const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
                                          int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h, void* stream);
+int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status, void* stream);
 int plume_registers_from_be_device(plume_ctx* ctx, size_t nvalues, const uint8_t* be32, uint64_t* registers, void* stream);
 int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n,
                                  const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,

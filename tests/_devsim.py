@@ -152,6 +152,13 @@ def h2c_intermediates(msgs_buf, msg_off, pk=None, registers=False):
     return {k: v.view(np.uint64) for k, v in o.items()} if registers else o
 
 
+def scalars_to_der(scalars):
+    sc = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+    der, st = np.zeros((len(sc), 109), dtype=np.uint8), np.zeros(len(sc), dtype=np.uint8)
+    lib().ds_scalars_to_der(C.c_uint32(len(sc)), _p(_aligned(sc)), _p(der), _p(st))
+    return der, st
+
+
 def registers_from_be(values):
     v = np.ascontiguousarray(values, dtype=np.uint8)
     out = np.zeros(v.shape, dtype=np.uint8)

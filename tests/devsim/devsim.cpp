@@ -245,6 +245,12 @@ int ds_h2c_intermediates(uint32_t n, const uint8_t* msgs, const uint64_t* msg_of
     for (uint32_t i = 0; i < n; i++) h2c_intermediates(a, i);
     return 0;
 }
+int ds_scalars_to_der(uint32_t n, const uint8_t* scalars, uint8_t* der, uint8_t* status) {
+    static std::vector<uint32_t> gcomb; if (gcomb.empty()) build_gcomb(gcomb);
+    DerArgs a; a.n = n; a.scalars = scalars; a.der = der; a.status = status; a.gcomb = gcomb.data();
+    for (uint32_t i = 0; i < n; i++) scalar_to_sec1_der(a, i);
+    return 0;
+}
 void ds_registers_from_be(size_t nvalues, const uint8_t* in, uint8_t* out) { for (size_t k = 0; k < nvalues; k++) registers_from_be(out, in, k); }
 
 // k*P through the device table + msm path (single base, affine 64-byte BE in/out); returns 0 for invalid input

@@ -130,7 +130,13 @@ def main():
     der = next(b for b in byte_arrs if len(b) > 100 and b[0] == 48)
     nul = next(b for b in byte_arrs if len(b) == 33 and b[0] == 3 and b[1] == 87)
     pk = next(b for b in byte_arrs if len(b) == 33 and b[0] == 3 and b[1] == 12)
-    k["wasm_readme"] = {"sk_sec1_der": der.hex(), "nullifier_sec1": nul.hex(), "pk_sec1": pk.hex(), "src": f + ":26-32,48-54,73-79"}
+    # `s` of the README's sample output, as SEC1-DER (SecretKey::from(value.s).to_sec1_der(), javascript/src/lib.rs:101-104): the listing is cut after
+    # 100 of its 109 bytes ("... 9 more items") -- scalar, the whole x and 23 bytes of y of s*G are there
+    m = re.search(r"\bs: \[([\d,\s]+)\.\.\. 9 more items", txt)
+    s_pre = bytes(int(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip())
+    assert len(s_pre) == 100 and s_pre[:7] == der[:7]
+    k["wasm_readme"] = {"sk_sec1_der": der.hex(), "nullifier_sec1": nul.hex(), "pk_sec1": pk.hex(), "s_sec1_der_first_100_bytes": s_pre.hex(),
+                        "src": f + ":26-32,48-54,58-72,73-79"}
 
     # ---- 8. constants ---------------------------------------------------------------------------------------
     c = {}

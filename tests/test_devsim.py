@@ -392,3 +392,29 @@ def _check_h2c_intermediates(get, regs_from_be, kats):
 
 def test_h2c_intermediates_and_registers(kats):
     _check_h2c_intermediates(lambda mb, off, pk, regs: D.h2c_intermediates(mb, off, pk, regs), D.registers_from_be, kats)
+
+
+def _check_sec1_der(to_der, from_der, kats):
+    """SecretKey::to_sec1_der / from_sec1_der as the wasm layer uses them (javascript/src/lib.rs:98-110,124-140), against the README's records: the whole
+    109-byte secret-key record (javascript/README.md:26-32) and the first 100 bytes of the sample output's `s` (README :58-72, cut there by the listing)"""
+    w = kats["wasm_readme"]
+    sk_der, s_pre = bytes.fromhex(w["sk_sec1_der"]), bytes.fromhex(w["s_sec1_der_first_100_bytes"])
+    rng = random.Random(4)
+    ks = [int.from_bytes(sk_der[7:39], "big"), int.from_bytes(s_pre[7:39], "big"), 1, 2, N - 1] + [rng.randrange(1, N) for _ in range(27)] + [0, N, 2**256 - 1]
+    arr = np.frombuffer(b"".join(k.to_bytes(32, "big") for k in ks), dtype=np.uint8).reshape(-1, 32)
+    der, st = to_der(arr)
+    assert der[0].tobytes() == sk_der and der[1].tobytes()[:100] == s_pre
+    assert list(st) == [0] * 32 + [2, 2, 2] and not der[32:].any()
+    for k, d in zip(ks[:32], der):
+        x, y = O.pt_mul(k, O.G)
+        assert d.tobytes() == bytes.fromhex("306b0201010420") + k.to_bytes(32, "big") + bytes.fromhex("a14403420004") + x.to_bytes(32, "big") + y.to_bytes(32, "big")
+    if from_der is not None:
+        bad = der.copy()
+        bad[3, 0] ^= 1; bad[4, 40] ^= 1; bad[5, 7:39] = 0; bad[6, 7:39] = np.frombuffer(N.to_bytes(32, "big"), dtype=np.uint8)
+        sc, ok = from_der(bad)
+        assert list(ok) == [1, 1, 1, 0, 0, 0, 0] + [1] * 25 + [0, 0, 0]
+        assert np.array_equal(sc[:3], arr[:3]) and not sc[3:7].any() and np.array_equal(sc[7:32], arr[7:32])
+
+
+def test_sec1_der_scalar_marshalling(kats):
+    _check_sec1_der(D.scalars_to_der, None, kats)

@@ -355,3 +355,16 @@ def test_c_program_reproduces_the_reference_vector(tmp_path):
     exe = build_abi_smoke(tmp_path)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "abi_smoke ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_sec1_der_scalar_marshalling(eng, kats):
+    """plume_scalars_to_sec1_der_batch (public keys by the GPU comb) + plume_sec1_der_to_scalars against the wasm README's records"""
+    from zk_nullifier_sig_amd import capi
+    from tests.test_devsim import _check_sec1_der
+    _check_sec1_der(eng.scalars_to_sec1_der_batch, capi.sec1_der_to_scalars, kats)
+    # a larger batch against the signer's own generator multiplications: der(sk).public_key == pk
+    n = 5000
+    b = synth.sign_inputs(n, start=123456)
+    sg = eng.sign_batch(2, b["msgs"], b["off"], b["sk"], b["r"])
+    der, st = eng.scalars_to_sec1_der_batch(b["sk"])
+    assert not st.any() and np.array_equal(der[:, 45:109], sg["pk"]) and np.array_equal(der[:, 7:39], b["sk"])

@@ -55,6 +55,7 @@ def _load():
     lib.plume_num_shards.argtypes = [C.c_void_p]
     lib.plume_set_host_first_piece.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_set_host_register_min.argtypes = [C.c_void_p, C.c_size_t]
+    lib.plume_set_host_tail_piece.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_host_alloc.restype = C.c_void_p
     lib.plume_host_alloc.argtypes = [C.c_size_t]
     lib.plume_host_free.argtypes = [C.c_void_p]
@@ -82,6 +83,9 @@ def _load():
     lib.plume_h2c_intermediates_batch.argtypes = [vp, sz, vp, vp, vp, i, vp, vp, vp, vp]
     lib.plume_h2c_intermediates_batch_device.argtypes = [vp, sz, vp, vp, sz, vp, i, vp, vp, vp, vp, vp]
     lib.plume_registers_from_be.argtypes = [sz, vp, vp]
+    lib.plume_scalars_to_sec1_der_batch.argtypes = [vp, sz, vp, vp, vp]
+    lib.plume_scalars_to_sec1_der_batch_device.argtypes = [vp, sz, vp, vp, vp, vp]
+    lib.plume_sec1_der_to_scalars.argtypes = [sz, vp, vp, vp]
     lib.plume_registers_from_be_device.argtypes = [vp, sz, vp, vp, vp]
     _lib = lib
     return lib
@@ -89,9 +93,9 @@ def _load():
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_host_alloc", "plume_host_free", "plume_host_register",
+    return ["plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
-            "plume_registers_from_be", "plume_registers_from_be_device",
+            "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
             "plume_hash_to_curve_batch", "plume_nullifier_first_occurrence", "plume_nullifier_first_occurrence_device", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
             "plume_last_stage_times", "plume_microbench", "plume_microbench_last_ticks"]
@@ -128,6 +132,17 @@ def registers_from_be(values):
     if rc != 0:
         raise PlumeHipError(f"plume_registers_from_be failed ({rc}): {lib.plume_last_error().decode()}")
     return out
+
+
+def sec1_der_to_scalars(der109):
+    """(n, 109) SEC1-DER secret-key records (the wasm layer's `s` / `digest_private`) -> (scalars (n, 32), ok (n,)); SecretKey::from_sec1_der's structure check"""
+    lib = _load()
+    d = np.ascontiguousarray(der109, dtype=np.uint8).reshape(-1, 109)
+    sc, ok = np.zeros((len(d), 32), dtype=np.uint8), np.zeros(len(d), dtype=np.uint8)
+    rc = lib.plume_sec1_der_to_scalars(len(d), _ptr(d), _ptr(sc), _ptr(ok))
+    if rc != 0:
+        raise PlumeHipError(f"plume_sec1_der_to_scalars failed ({rc}): {lib.plume_last_error().decode()}")
+    return sc, ok
 
 
 def pinned_empty(shape, dtype=np.uint8):
@@ -216,6 +231,9 @@ class Engine:
 
     def set_host_first_piece(self, n):
         self._chk(self._lib.plume_set_host_first_piece(self._ctx, int(n)), "plume_set_host_first_piece")
+
+    def set_host_tail_piece(self, n):
+        self._chk(self._lib.plume_set_host_tail_piece(self._ctx, int(n)), "plume_set_host_tail_piece")
 
     def set_host_register_min(self, nbytes):
         """host-pointer calls: page-lock pageable caller arrays of at least nbytes for the duration of the call (0 = never)"""
@@ -322,6 +340,15 @@ class Engine:
         if registers:
             o = {k: v.view(np.uint64) for k, v in o.items()}
         return o
+
+    def scalars_to_sec1_der_batch(self, scalars):
+        """SecretKey::from(scalar).to_sec1_der() for a batch (javascript/src/lib.rs:98-110): (n, 109) records incl. the public key scalar*G computed on the GPU,
+        and a status array (2 = scalar outside [1, n-1], record zeroed)"""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        n = len(scalars)
+        der, status = np.zeros((n, 109), dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.plume_scalars_to_sec1_der_batch(self._ctx, n, _ptr(scalars), _ptr(der), _ptr(status)), "plume_scalars_to_sec1_der_batch")
+        return der, status
 
     def nullifier_first_occurrence(self, nullifier, live=None, ids=None):
         """first[i] = 1 iff item i is live and holds the smallest id (default: position) among the live items with the same 64-byte

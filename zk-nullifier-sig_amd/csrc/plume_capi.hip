@@ -81,8 +81,9 @@ struct plume_ctx {
     hipEvent_t ws_free = nullptr;     // recorded behind the last kernel of every device-resident call: the next call's stream waits on it before it
     bool ws_used = false;             // touches the per-context workspace, so calls on DIFFERENT streams of one context cannot race on that scratch
     size_t chunk = (size_t)1 << 20;
-    size_t host_piece = (size_t)1 << 18;                            // host-pointer calls: items per pipelined piece
-    size_t host_first_piece = (size_t)1 << 17;                      // ... of the first piece: its upload is the only one no kernel hides
+    size_t host_piece = (size_t)1 << 19;                            // host-pointer calls: largest pipelined piece
+    size_t host_first_piece = (size_t)1 << 16;                      // ... the first piece (its upload is the only one no kernel hides); pieces then grow 3x per step
+    size_t host_tail_piece = (size_t)1 << 17;                       // ... the last piece of calls with large outputs (its download is the only one no kernel hides)
     size_t host_register_min = 0;                                   // host-pointer calls: page-lock caller arrays of at least this many bytes for the call (0 = never)
     // multi-device parent (plume_init_multi): the shards are complete single-device contexts, one worker thread each; a parent owns no GPU state
     std::vector<plume_ctx*> shards;
@@ -145,6 +146,7 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_JOBS_PER_LANE")) { int v = std::atoi(e); if (v >= 1 && v <= 64) { ctx->jobs_per_lane = v; ctx->jobs_per_lane_forced = true; } }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_FIRST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_first_piece = (size_t)v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_HOST_TAIL_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_tail_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
@@ -315,14 +317,19 @@ extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
 extern "C" int plume_set_host_piece(plume_ctx* ctx, size_t items) {
     if (!ctx || items == 0 || items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_host_piece: bad argument");
     ctx->host_piece = items;
-    if (ctx->host_first_piece > items) ctx->host_first_piece = items;
-    for (plume_ctx* sh : ctx->shards) { sh->host_piece = items; if (sh->host_first_piece > items) sh->host_first_piece = items; }
+    for (plume_ctx* sh : ctx->shards) sh->host_piece = items;
     return 0;
 }
 extern "C" int plume_set_host_first_piece(plume_ctx* ctx, size_t items) {
     if (!ctx || items == 0 || items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_host_first_piece: bad argument");
     ctx->host_first_piece = items;
     for (plume_ctx* sh : ctx->shards) sh->host_first_piece = items;
+    return 0;
+}
+extern "C" int plume_set_host_tail_piece(plume_ctx* ctx, size_t items) {
+    if (!ctx || items == 0 || items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_host_tail_piece: bad argument");
+    ctx->host_tail_piece = items;
+    for (plume_ctx* sh : ctx->shards) sh->host_tail_piece = items;
     return 0;
 }
 extern "C" int plume_set_host_register_min(plume_ctx* ctx, size_t bytes) {
@@ -512,6 +519,18 @@ extern "C" int plume_h2c_intermediates_batch_device(plume_ctx* ctx, size_t n, co
     HIPCHK(hipGetLastError());
     return 0;
 }
+extern "C" int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status, void* stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!scalars || !der109 || !status)) return fail(PLUME_ERR_ARG, "null array");
+    if (n > 0xFFFFFFF0u) return fail(PLUME_ERR_ARG, "n too large");
+    if (n == 0) return 0;
+    DerArgs a; a.n = (uint32_t)n; a.scalars = scalars; a.der = der109; a.status = status; a.gcomb = ctx->gcomb.as<uint32_t>();
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->timer.begin(st);
+    launch_scalars_der(a, st); ctx->timer.stage("scalars_to_sec1_der", st);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 extern "C" int plume_registers_from_be_device(plume_ctx* ctx, size_t nvalues, const uint8_t* be32, uint64_t* registers, void* stream) {
     if (int rc = bind(ctx)) return rc;
     if (nvalues && (!be32 || !registers)) return fail(PLUME_ERR_ARG, "null array");
@@ -625,10 +644,28 @@ struct ScopedPins {
 // up(slot, i0, cnt): enqueue the uploads of one piece on ctx->up;  run(slot, cnt): enqueue its kernels on ctx->stream;
 // down(slot, i0, cnt): enqueue the downloads on ctx->down.  Any error drains all three streams before it is returned, so no
 // copy is left in flight on the caller's memory.
-template <class Up, class Run, class Down>
-static int host_pipeline(plume_ctx* ctx, size_t n, Up up, Run run, Down down) {
+// Piece schedule: the first piece is small (nothing hides its upload), every following piece may be up to three times the one before it (an
+// upload runs at ~7 ns per item, the kernels at ~23 ns per item, so piece k+1's upload still hides behind piece k's kernels) up to the
+// largest piece; calls with large outputs (the signer: 320 bytes out per item) also end on a small piece, whose download nothing hides.
+static std::vector<size_t> piece_schedule(const plume_ctx* ctx, size_t n, bool out_heavy) {
     const size_t piece = ctx->host_piece < ctx->chunk ? ctx->host_piece : ctx->chunk;
-    const size_t first = ctx->host_first_piece < piece ? ctx->host_first_piece : piece;
+    std::vector<size_t> sched;
+    size_t rem = n, cur = ctx->host_first_piece < piece ? ctx->host_first_piece : piece;
+    if (n <= piece && n <= 2 * cur) { sched.push_back(n); return sched; }   // small calls: one piece
+    while (rem) {
+        const size_t c = cur < rem ? cur : rem;
+        sched.push_back(c);
+        rem -= c;
+        cur = cur * 3 < piece ? cur * 3 : piece;
+    }
+    const size_t tail = ctx->host_tail_piece;
+    if (out_heavy && sched.size() > 1 && sched.back() > 2 * tail) { const size_t last = sched.back(); sched.back() = last - tail; sched.push_back(tail); }
+    return sched;
+}
+
+template <class Up, class Run, class Down>
+static int host_pipeline(plume_ctx* ctx, size_t n, bool out_heavy, Up up, Run run, Down down) {
+    const std::vector<size_t> sched = piece_schedule(ctx, n, out_heavy);
     struct { HostSlot* sl = nullptr; size_t i0 = 0, cnt = 0; } prev;
     auto drain = [&]() -> int {
         HIPCHK(hipStreamWaitEvent(ctx->down, prev.sl->computed, 0));
@@ -637,10 +674,9 @@ static int host_pipeline(plume_ctx* ctx, size_t n, Up up, Run run, Down down) {
         return 0;
     };
     auto body = [&]() -> int {
-        size_t k = 0;
-        for (size_t i0 = 0; i0 < n; k++) {
-            const size_t want = (k == 0 && n > piece) ? first : piece;
-            const size_t cnt = n - i0 < want ? n - i0 : want;
+        size_t i0 = 0;
+        for (size_t k = 0; k < sched.size(); k++) {
+            const size_t cnt = sched[k];
             HostSlot& sl = ctx->slot[k & 1];
             if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.drained)); sl.in_flight = false; }   // piece k-2 has left this slot
             if (int rc = up(sl, i0, cnt)) return rc;
@@ -676,7 +712,7 @@ static int verify_host(plume_ctx* ctx, int version, int mode, bool sec1, size_t 
         if (pts) { pins.add(ctx, r_point, P * n); pins.add(ctx, hashed_to_curve_r, P * n); }
     }
     return host_pipeline(
-        ctx, n,
+        ctx, n, false,
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
             if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
             if (int rc = h2d(ctx, sl.in[0], pk + P * i0, P * cnt)) return rc;
@@ -743,7 +779,7 @@ static int sign_host(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs,
         pins.add(ctx, pk, P * n); pins.add(ctx, nullifier, P * n); pins.add(ctx, c, 32 * n); pins.add(ctx, s, 32 * n); pins.add(ctx, r_point, P * n); pins.add(ctx, hashed_to_curve_r, P * n);
     }
     return host_pipeline(
-        ctx, n,
+        ctx, n, true,
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
             if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
             if (int rc = h2d(ctx, sl.in[0], sk + 32 * i0, 32 * cnt)) return rc;
@@ -802,7 +838,7 @@ extern "C" int plume_sign_batch_sec1(plume_ctx* ctx, int version, size_t n, cons
 static int h2c_host(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out) {
     HIPCHK(hipSetDevice(ctx->device));
     return host_pipeline(
-        ctx, n,
+        ctx, n, false,
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
             if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
             if (pk) { if (int rc = h2d(ctx, sl.in[0], pk + 64 * i0, 64 * cnt)) return rc; }
@@ -827,7 +863,7 @@ static int h2c_inter_host(plume_ctx* ctx, size_t n, const uint8_t* msgs, const u
                           uint8_t* h) {
     HIPCHK(hipSetDevice(ctx->device));
     return host_pipeline(
-        ctx, n,
+        ctx, n, true,
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
             if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
             if (pk) { if (int rc = h2d(ctx, sl.in[0], pk + 64 * i0, 64 * cnt)) return rc; }
@@ -857,6 +893,50 @@ extern "C" int plume_h2c_intermediates_batch(plume_ctx* ctx, size_t n, const uin
         return h2c_inter_host(sh, hi - lo, msgs, msg_off + lo, pk ? pk + 64 * lo : nullptr, registers, u ? u + 64 * lo : nullptr, mapped ? mapped + 128 * lo : nullptr,
                               q ? q + 128 * lo : nullptr, h ? h + 64 * lo : nullptr);
     });
+}
+static int der_host(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HostSlot& sl = ctx->slot[0];
+    hipStream_t st = ctx->stream;
+    for (size_t i0 = 0; i0 < n; i0 += ctx->chunk) {
+        const size_t cnt = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
+        if (sl.in[0].ensure(32 * cnt) || sl.out[0].ensure(PLUME_DER_LEN * cnt) || sl.out[1].ensure(cnt)) return PLUME_ERR_HIP;
+        HIPCHK(hipMemcpyAsync(sl.in[0].p, scalars + 32 * i0, 32 * cnt, hipMemcpyHostToDevice, st));
+        if (int rc = plume_scalars_to_sec1_der_batch_device(ctx, cnt, sl.in[0].as<uint8_t>(), sl.out[0].as<uint8_t>(), sl.out[1].as<uint8_t>(), st)) return rc;
+        HIPCHK(hipMemsetAsync(sl.in[0].p, 0, 32 * cnt, st));                       // the scalars may be secret keys: wipe the staged copy
+        HIPCHK(hipMemcpyAsync(der109 + PLUME_DER_LEN * i0, sl.out[0].p, PLUME_DER_LEN * cnt, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(status + i0, sl.out[1].p, cnt, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemsetAsync(sl.out[0].p, 0, PLUME_DER_LEN * cnt, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+extern "C" int plume_scalars_to_sec1_der_batch(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "null context");
+    if (n && (!scalars || !der109 || !status)) return fail(PLUME_ERR_ARG, "null array");
+    if (n == 0) return 0;
+    if (ctx->shards.empty()) return der_host(ctx, n, scalars, der109, status);
+    return for_shards(ctx, n, [=](plume_ctx* sh, size_t lo, size_t hi) -> int { return der_host(sh, hi - lo, scalars + 32 * lo, der109 + PLUME_DER_LEN * lo, status + lo); });
+}
+// SecretKey::from_sec1_der for the fixed 109-byte form above (what the wasm layer emits): structure check + the scalar; ok[i] = 1 iff the record has
+// that exact shape and its scalar is in [1, n-1].  The embedded public key is NOT recomputed here (run plume_scalars_to_sec1_der_batch on the
+// result and compare the records where that matters).  Host memory; no context needed.
+extern "C" int plume_sec1_der_to_scalars(size_t n, const uint8_t* der109, uint8_t* scalars, uint8_t* ok) {
+    if (n && (!der109 || !scalars || !ok)) return fail(PLUME_ERR_ARG, "null array");
+    static const uint8_t head[7] = {0x30, 0x6b, 0x02, 0x01, 0x01, 0x04, 0x20}, mid[6] = {0xa1, 0x44, 0x03, 0x42, 0x00, 0x04};
+    static const uint8_t order[32] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFE,
+                                      0xBA, 0xAE, 0xDC, 0xE6, 0xAF, 0x48, 0xA0, 0x3B, 0xBF, 0xD2, 0x5E, 0x8C, 0xD0, 0x36, 0x41, 0x41};
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* d = der109 + PLUME_DER_LEN * i;
+        bool good = std::memcmp(d, head, 7) == 0 && std::memcmp(d + 39, mid, 6) == 0;
+        bool nz = false;
+        for (int j = 0; j < 32; j++) nz = nz || d[7 + j] != 0;
+        good = good && nz && std::memcmp(d + 7, order, 32) < 0;
+        std::memcpy(scalars + 32 * i, d + 7, 32);
+        if (!good) std::memset(scalars + 32 * i, 0, 32);
+        ok[i] = good ? 1 : 0;
+    }
+    return 0;
 }
 // host form of the register packing: a byte reversal, done on the host (no reason to cross PCIe for it)
 extern "C" int plume_registers_from_be(size_t nvalues, const uint8_t* be32, uint64_t* registers) {

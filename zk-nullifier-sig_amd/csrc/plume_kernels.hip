@@ -207,6 +207,10 @@ __global__ PLUME_H2C_BOUNDS void k_h2c_intermediates(H2cInterArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) h2c_intermediates(a, i);
 }
+__global__ PLUME_BOUNDS void k_scalars_der(DerArgs a) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < a.n) scalar_to_sec1_der(a, i);
+}
 __global__ __launch_bounds__(kBlock) void k_registers_from_be(uint8_t* out, const uint8_t* in, size_t nvalues) {
     size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (k < nvalues) registers_from_be(out, in, k);
@@ -344,6 +348,7 @@ void launch_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, hipStream_
 void launch_decompress(const DecompressArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_decompress, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_h2c_only(const H2cArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_only, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_h2c_intermediates(const H2cInterArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_h2c_intermediates, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_scalars_der(const DerArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_scalars_der, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_registers_from_be(uint8_t* out, const uint8_t* in, size_t nvalues, hipStream_t st) {
     hipLaunchKernelGGL(k_registers_from_be, dim3(nblocks(nvalues)), dim3(kBlock), 0, st, out, in, nvalues);
 }

@@ -27,6 +27,7 @@ void launch_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, hipStream_
 void launch_decompress(const DecompressArgs& a, hipStream_t st);
 void launch_h2c_only(const H2cArgs& a, hipStream_t st);
 void launch_h2c_intermediates(const H2cInterArgs& a, hipStream_t st);
+void launch_scalars_der(const DerArgs& a, hipStream_t st);
 void launch_registers_from_be(uint8_t* out, const uint8_t* in, size_t nvalues, hipStream_t st);
 void launch_gtab(uint32_t* gtab, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr /* PLUME_GTAB_ENTRIES scratch entries */, hipStream_t st);
 void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, uint32_t* scr /* 33 x 128 scratch entries */, hipStream_t st);

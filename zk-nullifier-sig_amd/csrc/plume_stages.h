@@ -597,6 +597,42 @@ PLUME_HD void h2c_intermediates(const H2cInterArgs& a, uint32_t i) {
         store_value(dst, x, a.registers); store_value(dst + 32, yy, a.registers);
     }
 }
+// ================================================================== SEC1-DER scalar marshalling ("next" row f-2, the wasm wire format)
+// SecretKey::from(scalar).to_sec1_der() (javascript/src/lib.rs:98-110 uses it for `s` and `digest_private`): RFC 5915 ECPrivateKey with the public key
+//   30 6b | 02 01 01 | 04 20 <scalar, 32 B> | a1 44 03 42 00 | 04 <x, 32 B> <y, 32 B>        = 109 bytes, public key = scalar * G
+// The generator multiplication is what costs: one doubling-free comb per scalar here.  A scalar outside [1, n-1] (no SecretKey exists for it) gets
+// status PLUME_ST_BAD_SCALAR and an all-zero record.
+#define PLUME_DER_LEN 109
+struct DerArgs {
+    uint32_t n;
+    const uint8_t* scalars;   // n x 32 big-endian
+    uint8_t* der;             // n x 109
+    uint8_t* status;          // n
+    const uint32_t* gcomb;
+};
+PLUME_HD void scalar_to_sec1_der(const DerArgs& a, uint32_t i) {
+    sc k;
+    uint8_t* out = a.der + (size_t)PLUME_DER_LEN * i;
+    if (!load_scalar_be(k, a.scalars + 32 * (size_t)i)) {
+        PLUME_NOUNROLL for (int j = 0; j < PLUME_DER_LEN; j++) out[j] = 0;
+        a.status[i] = (uint8_t)PLUME_ST_BAD_SCALAR;
+        return;
+    }
+    jac p;
+    comb_mul_g(p, k, a.gcomb);                 // never the identity for k in [1, n-1]
+    fe zi, zi2, x, y;
+    fe_inv(zi, p.z); fe_sqr(zi2, zi); fe_mul(x, p.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y, p.y, zi2);
+    fe_normalize(x); fe_normalize(y);
+    uint32_t xw[8], yw[8];
+    fe_to_words(xw, x); fe_to_words(yw, y);
+    const uint8_t head[7] = {0x30, 0x6b, 0x02, 0x01, 0x01, 0x04, 0x20}, mid[6] = {0xa1, 0x44, 0x03, 0x42, 0x00, 0x04};
+    PLUME_UNROLL for (int j = 0; j < 7; j++) out[j] = head[j];
+    PLUME_UNROLL for (int j = 0; j < 32; j++) out[7 + j] = (uint8_t)(k.v[7 - (j >> 2)] >> (8 * (3 - (j & 3))));
+    PLUME_UNROLL for (int j = 0; j < 6; j++) out[39 + j] = mid[j];
+    PLUME_UNROLL for (int j = 0; j < 32; j++) { out[45 + j] = (uint8_t)(xw[7 - (j >> 2)] >> (8 * (3 - (j & 3)))); out[77 + j] = (uint8_t)(yw[7 - (j >> 2)] >> (8 * (3 - (j & 3)))); }
+    a.status[i] = 0;
+}
+
 // 32-byte big-endian values -> the circuit's 4 x 64-bit little-endian registers (c, s, pk, nullifier ... of a signature): a byte reversal
 PLUME_HD void registers_from_be(uint8_t* out, const uint8_t* in, size_t k) {
     const uint32_t* src = (const uint32_t*)(in + 32 * k);
