@@ -36,10 +36,13 @@ def col_terms(k, sqr, pair=("a", "b")):
     return t
 
 
+HICARRY = True   # high-half hand-off by one multiply-add (carry = high word * 8) instead of mask + 64-bit shift; --no-hicarry for the A/B build
 A_CONS = "v"   # constraint of the a.v[i] operands: "s" in fe_mul_k (a is a wave-uniform constant held in SGPRs)
 
 
-def emit_chain(terms, indent="    ", acc="acc"):
+def emit_chain(terms, indent="    ", acc="acc", carry=None):
+    """carry: name of a 32-bit variable holding the previous column's high word: the chain then STARTS a fresh accumulator with carry * 8 (the
+    hand-off multiply-add) instead of continuing in place."""
     regs = []
 
     def idx(name, cons):
@@ -49,12 +52,16 @@ def emit_chain(terms, indent="    ", acc="acc"):
         return regs.index(key) + 2
 
     lines = []
+    if carry:
+        lines.append(f"v_mad_u64_u32 %0, %1, %{idx(carry, 'v')}, 8, 0")
     for (x, y, ys) in terms:
         xc = A_CONS if x.startswith("a.v[") else "v"
         lines.append(f"v_mad_u64_u32 %0, %1, %{idx(x, xc)}, %{idx(y, 's' if ys else 'v')}, %0")
     body = "\\n\\t".join(lines)
     ins = ", ".join(f'"{c}"({n})' for (n, c) in regs)
     host = " ".join(f"{acc} += (uint64_t){x} * {y};" for (x, y, ys) in terms)
+    if carry:
+        return (f"{indent}PLUME_FE_CHAIN_NEW({acc}, \"{body}\", {ins});\n", f"{indent}{acc} = (uint64_t){carry} * 8u; {host}\n")
     return (f"{indent}PLUME_FE_CHAIN({acc}, \"{body}\", {ins});\n", f"{indent}{host}\n")
 
 
@@ -72,12 +79,21 @@ def gen(name, sqr, two=False):
         host.append(s)
 
     def stmts_high(k):
-        out = [emit_chain([(x, y, False) for (x, y) in col_terms(k, sqr)], acc="acch")]
+        out = [emit_chain([(x, y, False) for (x, y) in col_terms(k, sqr)], acc="acch", carry=(f"hw{k - 1}" if (HICARRY and k > 9) else None))]
         if two:
             out.append(emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))], acc="acch"))
         return out
 
     def mask_high(k):
+        if HICARRY:
+            # h[k-9] = the column's low 32 bits as they are (a free sub-register, no mask); the rest, acch >> 32, has weight 2^32 = 8 * 2^29 relative to
+            # this column and enters the next one as hi * 8: ONE multiply-add instead of v_and + v_lshrrev_b64.  The fold multiplies h[] by 31264 and
+            # 256 only, so 32-bit h[] leave the column bounds where they were (h * 31264 < 2^47).
+            # The hand-off instruction opens the next column's asm statement (emit_chain(carry=...)), which writes a FRESH accumulator pair: the old
+            # pair's halves stay where they are as h[] and the carry, no copies.
+            if k < 16:
+                return f"    h[{k - 9}] = (uint32_t)acch; const uint32_t hw{k} = (uint32_t)(acch >> 32);\n"
+            return "    h[7] = (uint32_t)acch; h[8] = (uint32_t)(acch >> 32);   // h[8] counts units of 8 * 2^(261+232): constants K0H, K2H, K3H\n    PLUME_FE_ASSERT((acch >> 32) < (1ull << 24));\n"
         if k < 16:
             return f"    h[{k - 9}] = (uint32_t)acch & PLUME_FE_MASK; acch >>= 29;\n"
         return "    h[7] = (uint32_t)acch & PLUME_FE_MASK; h[8] = (uint32_t)(acch >> 29);\n    PLUME_FE_ASSERT((acch >> 29) < (1ull << 27));\n"
@@ -87,7 +103,7 @@ def gen(name, sqr, two=False):
         if two:
             out.append(emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))]))
         t = [(x, y, False) for (x, y) in col_terms(k, sqr)]
-        t.append((f"h[{k}]", "K0", True))
+        t.append((f"h[{k}]", "K0H" if (HICARRY and k == 8) else "K0", True))
         if k > 0:
             t.append((f"h[{k - 1}]", "K1", True))
         out.append(emit_chain(t))
@@ -103,7 +119,7 @@ def gen(name, sqr, two=False):
 
     both("    uint32_t h[9], l[9];     // l: result limbs (r may alias a or b)\n    uint64_t acc = 0, acch = 0;\n")
     if sqr:
-        both("    uint32_t d[9];\n    PLUME_UNROLL for (int i = 0; i < 9; i++) d[i] = a.v[i] + a.v[i];\n")
+        both("    uint32_t d[9];\n    PLUME_UNROLL for (int i = 0; i < 9; i++) d[i] = u32_dbl(a.v[i]);\n")
     # H9, mH9, H10, then per step j: L(j), mH(j+10), H(j+11), mL(j)
     put(stmts_high(9)); both(mask_high(9)); put(stmts_high(10))
     for j in range(0, 9):
@@ -121,11 +137,12 @@ def gen(name, sqr, two=False):
     const uint32_t t0 = (uint32_t)acc & PLUME_FE_MASK, t1 = (uint32_t)(acc >> 29);
     acc = l[0];
 """)
-    dev.append('    PLUME_FE_CHAIN(acc, "v_mad_u64_u32 %0, %1, %2, %3, %0\\n\\tv_mad_u64_u32 %0, %1, %4, %5, %0", "v"(t0), "s"(K4), "v"(h[8]), "s"(K2));\n')
-    host.append("    acc += (uint64_t)t0 * K4; acc += (uint64_t)h[8] * K2;\n")
+    k2, k3 = ("K2H", "K3H") if HICARRY else ("K2", "K3")
+    dev.append(f'    PLUME_FE_CHAIN(acc, "v_mad_u64_u32 %0, %1, %2, %3, %0\\n\\tv_mad_u64_u32 %0, %1, %4, %5, %0", "v"(t0), "s"(K4), "v"(h[8]), "s"({k2}));\n')
+    host.append(f"    acc += (uint64_t)t0 * K4; acc += (uint64_t)h[8] * {k2};\n")
     both("    l[0] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;\n    acc += l[1] + t1 * 977u;\n")
-    dev.append('    PLUME_FE_CHAIN(acc, "v_mad_u64_u32 %0, %1, %2, %3, %0\\n\\tv_mad_u64_u32 %0, %1, %4, %5, %0", "v"(t0), "s"(K5), "v"(h[8]), "s"(K3));\n')
-    host.append("    acc += (uint64_t)t0 * K5; acc += (uint64_t)h[8] * K3;\n")
+    dev.append(f'    PLUME_FE_CHAIN(acc, "v_mad_u64_u32 %0, %1, %2, %3, %0\\n\\tv_mad_u64_u32 %0, %1, %4, %5, %0", "v"(t0), "s"(K5), "v"(h[8]), "s"({k3}));\n')
+    host.append(f"    acc += (uint64_t)t0 * K5; acc += (uint64_t)h[8] * {k3};\n")
     both("    l[1] = (uint32_t)acc & PLUME_FE_MASK;\n    l[2] += (uint32_t)(acc >> 29) + (t1 << 3);\n    PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = l[i];\n")
     sig = f"PLUME_HD void {name}(fe& r, const fe& a)" if sqr else f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b)"
     check = "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, a));\n" if sqr else "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, b));\n"
@@ -133,14 +150,22 @@ def gen(name, sqr, two=False):
         sig = f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b, const fe& c, const fe& e)"
         check = "    PLUME_FE_ASSERT(fe_muladd_inputs_ok(a, b, c, e));\n"
     consts = "    const uint32_t K0 = 31264u, K1 = 256u, K2 = 31264u << 8, K3 = 65536u, K4 = 977u, K5 = 8u;\n"
+    if HICARRY:
+        consts = "    const uint32_t K0 = 31264u, K1 = 256u, K0H = 31264u << 3, K2H = 31264u << 11, K3H = 65536u << 3, K4 = 977u, K5 = 8u;\n"
     return f"{sig} {{\n{check}{consts}#if defined(__HIP_DEVICE_COMPILE__)\n{''.join(dev)}#else\n{''.join(host)}#endif\n}}\n"
 
 
 def main():
+    import sys
+    global HICARRY
+    if "--no-hicarry" in sys.argv:
+        HICARRY = False
     print("""// GENERATED by gen_fe_mul.py -- do not edit (see that script for the design and the measurements behind it).
 // Included by plume_field.h inside namespace plume.
 // one chain of multiply-adds on `acc`; the carry-out pair of v_mad_u64_u32 is a dead SGPR pair the compiler picks
 #define PLUME_FE_CHAIN(ACC, TEXT, ...) do { uint64_t cy_; asm(TEXT : "+v"(ACC), "=&s"(cy_) : __VA_ARGS__); } while (0)
+// the same, but the chain's first instruction starts a fresh accumulator (previous column's high word * 8: a 29-bit limb step is 2^29 = 2^32 / 8)
+#define PLUME_FE_CHAIN_NEW(ACC, TEXT, ...) do { uint64_t cy_; asm(TEXT : "=&v"(ACC), "=&s"(cy_) : __VA_ARGS__); } while (0)
 """)
     print(gen("fe_mul", False))
     print(gen("fe_sqr", True))
@@ -153,6 +178,7 @@ def main():
     print("// a is a compile-time constant (curve / isogeny coefficients): its limbs stay in SGPRs instead of occupying 9 VGPRs each")
     print(gen("fe_mul_k", False))
     print("#undef PLUME_FE_CHAIN")
+    print("#undef PLUME_FE_CHAIN_NEW")
 
 
 if __name__ == "__main__":

@@ -52,18 +52,18 @@ PLUME_HD bool affine_on_curve(const fe& x, const fe& y) {
 PLUME_HD void jac_dbl(jac& p) {
     fe A, B2, C4, XB2, E, F, D2, D4, t;
     fe_sqr(A, p.x);
-    fe_sqr(B2, p.y); fe_add_lazy(B2, B2, B2);              // 2Y^2
+    fe_sqr(B2, p.y); fe_dbl_lazy(B2, B2);              // 2Y^2
     fe_sqr(C4, B2);                                        // 4Y^4
     fe_mul(XB2, p.x, B2);                                  // 2XY^2
-    fe_mul(p.z, p.y, p.z); fe_add_lazy(p.z, p.z, p.z);     // Z' = 2YZ (unreduced double)
+    fe_mul(p.z, p.y, p.z); fe_dbl_lazy(p.z, p.z);     // Z' = 2YZ (unreduced double)
     fe_add_lazy(E, A, A); fe_add_lazy(E, E, A); fe_carry(E);   // 3X^2
     fe_sqr(F, E);
-    fe_add_lazy(D2, XB2, XB2);                             // 4XY^2
-    fe_add_lazy(D4, D2, D2);                               // 8XY^2
+    fe_dbl_lazy(D2, XB2);                             // 4XY^2
+    fe_dbl_lazy(D4, D2);                               // 8XY^2
     fe_sub_lazy<5>(p.x, F, D4); fe_carry(p.x);             // X' = 9X^4 - 8XY^2
     fe_sub_lazy<2>(t, D2, p.x);                            // 4XY^2 - X'
     fe_mul(t, E, t);
-    fe_add_lazy(C4, C4, C4);                               // 8Y^4
+    fe_dbl_lazy(C4, C4);                               // 8Y^4
     fe_sub_lazy<3>(p.y, t, C4); fe_carry(p.y);
 }
 // cold path of the additions (P == Q).  Takes and returns BY VALUE through a local copy at the call site: passing the
@@ -101,7 +101,7 @@ PLUME_HD void jac_madd(jac& p, const fe& qx, const fe& qy) {
     fe_sqr(hh, h); fe_mul(hhh, hh, h); fe_mul(v, p.x, hh);
     fe_mul(p.z, p.z, h);
     fe_sqr(t, r);
-    fe_add_lazy(hh, v, v); fe_add_lazy(hh, hh, hhh);       // 2V + H^3
+    fe_dbl_lazy(hh, v); fe_add_lazy(hh, hh, hhh);       // 2V + H^3
     fe_sub_lazy<4>(p.x, t, hh); fe_carry(p.x);             // X' = r^2 - H^3 - 2V
     fe_sub_lazy<2>(t, v, p.x);                             // V - X'
     fe_neg_lazy(v, p.y);                                   // -Y1, unreduced

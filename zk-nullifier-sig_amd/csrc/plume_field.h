@@ -236,7 +236,29 @@ PLUME_HD bool words_lt_p(const uint32_t w[8]) {
     return c == 0;
 }
 
-#include "plume_fe_mul.inc"
+// r = 2a limbwise, no carry pass.  hipcc turns a + a into v_lshlrev_b32, which the issue-rate probe puts at the multiply-add's cost on gfx950.
+// Forcing a plain-rate v_add_u32 through inline asm (-DPLUME_DBL_BY_ADD=1) was measured 0.9 % SLOWER on the multi-scalar kernel (r02 A/B, same box:
+// 20.0 vs 19.9 ms): the asm statement costs the compiler its folding of the doubling into neighbouring v_lshl_add / v_add3 forms.  Kept as the experiment's record.
+#ifndef PLUME_DBL_BY_ADD
+#define PLUME_DBL_BY_ADD 0
+#endif
+PLUME_HD uint32_t u32_dbl(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__) && PLUME_DBL_BY_ADD
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x + x;
+#endif
+}
+PLUME_HD void fe_dbl_lazy(fe& r, const fe& a) {
+    PLUME_UNROLL for (int i = 0; i < 9; i++) { PLUME_FE_ASSERT((uint64_t)a.v[i] * 2 < (1ull << 32)); r.v[i] = u32_dbl(a.v[i]); }
+}
+
+#ifndef PLUME_FE_MUL_INC
+#define PLUME_FE_MUL_INC "plume_fe_mul.inc"
+#endif
+#include PLUME_FE_MUL_INC
 
 // r = a * k for a small k (< 2^20), any a with limbs < 2^32; tight result
 PLUME_HD void fe_mul_small(fe& r, const fe& a, uint32_t k) {
