@@ -1,0 +1,461 @@
+/* PLUME verify on the CPU, OPTIMISED — the second CPU leg of bench.py's cpu_baseline.  TEST / MEASUREMENT INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * The plain oracle (plume_oracle.c) is written to be read: no endomorphism, squaring = multiplication, exponentiation-ladder inversions, one
+ * inversion per encoded point.  That understates what a tuned CPU library does (rust-k256 itself cannot be built here: no rustc / cargo), so this
+ * file restates the SAME verification (rust-k256/src/lib.rs:93-145, same edge semantics) with the usual CPU techniques:
+ *   - Fp on 4 x 64-bit limbs, lazy ("weak") reduction, dedicated squaring (10 instead of 16 limb products), inversion / square root by addition chains;
+ *   - GLV endomorphism split of every scalar into two 128-bit halves, width-5 wNAF for the per-signature bases, width-8 wNAF with a static table for G,
+ *     one interleaved (Strauss) doubling chain of 128 steps per equation with mixed Jacobian-affine additions;
+ *   - ONE field inversion per signature for all window-table entries and the affine H (Montgomery's trick);
+ *   - hash_to_curve with the inversion-free simplified SWU / isogeny (x kept as a fraction) and one square-root exponentiation per map.
+ * Inputs with an identity point take the plain oracle's path (unreachable for honest signatures).  Every result is checked item by item against the
+ * plain oracle in tests/test_cpu_fast.py; only tests/ and bench.py's cpu_baseline load this library.
+ */
+#include "plume_oracle.c" /* SHA-256, expand_message_xmd, Fn arithmetic, byte helpers, the reference-shaped slow path */
+
+typedef struct { uint64_t l[4]; } ff;                 /* mod p, value < 2^256, not necessarily < p */
+typedef struct { ff x, y, z; int inf; } pj;           /* Jacobian */
+typedef struct { ff x, y; } pa;                       /* affine, never the identity */
+
+static const ff FF_ONE = {{1, 0, 0, 0}};
+static const ff FF_BETA = {{0xC1396C28719501EEULL, 0x9CF0497512F58995ULL, 0x6E64479EAC3434E9ULL, 0x7AE96A2B657C0710ULL}};
+
+/* ---------------------------------------------------------------------------------------------------------------- field */
+static inline void ff_fold(ff *r, uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3, uint64_t c) { /* value = r + c * 2^256, c < 2^35 */
+    u128 a = (u128)c * PC + r0; r0 = (uint64_t)a; a >>= 64;
+    a += r1; r1 = (uint64_t)a; a >>= 64;
+    a += r2; r2 = (uint64_t)a; a >>= 64;
+    a += r3; r3 = (uint64_t)a; a >>= 64;
+    if ((uint64_t)a) { /* once more: the remainder is tiny now */
+        u128 b = (u128)r0 + PC; r0 = (uint64_t)b; b >>= 64;
+        b += r1; r1 = (uint64_t)b; b >>= 64;
+        b += r2; r2 = (uint64_t)b; b >>= 64;
+        r3 += (uint64_t)b;
+    }
+    r->l[0] = r0; r->l[1] = r1; r->l[2] = r2; r->l[3] = r3;
+}
+static inline void ff_reduce512(ff *r, const uint64_t t[8]) {
+    u128 a = (u128)t[4] * PC + t[0]; uint64_t r0 = (uint64_t)a; a >>= 64;
+    a += (u128)t[5] * PC + t[1]; uint64_t r1 = (uint64_t)a; a >>= 64;
+    a += (u128)t[6] * PC + t[2]; uint64_t r2 = (uint64_t)a; a >>= 64;
+    a += (u128)t[7] * PC + t[3]; uint64_t r3 = (uint64_t)a; a >>= 64;
+    ff_fold(r, r0, r1, r2, r3, (uint64_t)a);
+}
+static inline void ff_mul(ff *r, const ff *x, const ff *y) {
+    const uint64_t *a = x->l, *b = y->l;
+    uint64_t t[8];
+    u128 c;
+    c = (u128)a[0] * b[0]; t[0] = (uint64_t)c; c >>= 64;
+    c += (u128)a[0] * b[1]; t[1] = (uint64_t)c; c >>= 64;
+    c += (u128)a[0] * b[2]; t[2] = (uint64_t)c; c >>= 64;
+    c += (u128)a[0] * b[3]; t[3] = (uint64_t)c; t[4] = (uint64_t)(c >> 64);
+    for (int i = 1; i < 4; i++) {
+        c = (u128)a[i] * b[0] + t[i]; t[i] = (uint64_t)c; c >>= 64;
+        c += (u128)a[i] * b[1] + t[i + 1]; t[i + 1] = (uint64_t)c; c >>= 64;
+        c += (u128)a[i] * b[2] + t[i + 2]; t[i + 2] = (uint64_t)c; c >>= 64;
+        c += (u128)a[i] * b[3] + t[i + 3]; t[i + 3] = (uint64_t)c; t[i + 4] = (uint64_t)(c >> 64);
+    }
+    ff_reduce512(r, t);
+}
+static inline void ff_sqr(ff *r, const ff *x) { /* 6 cross products (doubled) + 4 squares */
+    const uint64_t *a = x->l;
+    uint64_t t[8];
+    u128 c;
+    c = (u128)a[0] * a[1]; t[1] = (uint64_t)c; c >>= 64;
+    c += (u128)a[0] * a[2]; t[2] = (uint64_t)c; c >>= 64;
+    c += (u128)a[0] * a[3]; t[3] = (uint64_t)c; t[4] = (uint64_t)(c >> 64);
+    c = (u128)a[1] * a[2] + t[3]; t[3] = (uint64_t)c; c >>= 64;
+    c += (u128)a[1] * a[3] + t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+    c = (u128)a[2] * a[3] + t[5]; t[5] = (uint64_t)c; t[6] = (uint64_t)(c >> 64);
+    t[7] = t[6] >> 63; t[6] = (t[6] << 1) | (t[5] >> 63); t[5] = (t[5] << 1) | (t[4] >> 63); t[4] = (t[4] << 1) | (t[3] >> 63);
+    t[3] = (t[3] << 1) | (t[2] >> 63); t[2] = (t[2] << 1) | (t[1] >> 63); t[1] <<= 1;
+    c = (u128)a[0] * a[0]; t[0] = (uint64_t)c; c >>= 64;
+    c += t[1]; t[1] = (uint64_t)c; c >>= 64;
+    c += (u128)a[1] * a[1] + t[2]; t[2] = (uint64_t)c; c >>= 64;
+    c += t[3]; t[3] = (uint64_t)c; c >>= 64;
+    c += (u128)a[2] * a[2] + t[4]; t[4] = (uint64_t)c; c >>= 64;
+    c += t[5]; t[5] = (uint64_t)c; c >>= 64;
+    c += (u128)a[3] * a[3] + t[6]; t[6] = (uint64_t)c; c >>= 64;
+    t[7] += (uint64_t)c;
+    ff_reduce512(r, t);
+}
+static inline void ff_add(ff *r, const ff *a, const ff *b) {
+    u128 c = (u128)a->l[0] + b->l[0]; uint64_t r0 = (uint64_t)c; c >>= 64;
+    c += (u128)a->l[1] + b->l[1]; uint64_t r1 = (uint64_t)c; c >>= 64;
+    c += (u128)a->l[2] + b->l[2]; uint64_t r2 = (uint64_t)c; c >>= 64;
+    c += (u128)a->l[3] + b->l[3]; uint64_t r3 = (uint64_t)c; c >>= 64;
+    ff_fold(r, r0, r1, r2, r3, (uint64_t)c);
+}
+static inline void ff_normalize(ff *a) { while (ge256(a->l, P_)) sub256(a->l, a->l, P_); }   /* at most twice */
+static inline void ff_neg(ff *r, const ff *a) { /* p - a for a <= p after normalisation; 2p - a otherwise stays < 2^256? keep it simple: normalise */
+    ff t = *a; ff_normalize(&t);
+    if (is_zero256(t.l)) { *r = t; return; }
+    sub256(r->l, P_, t.l);
+}
+static inline void ff_sub(ff *r, const ff *a, const ff *b) { ff nb; ff_neg(&nb, b); ff_add(r, a, &nb); }
+static inline void ff_mul_small(ff *r, const ff *a, uint64_t k) { /* k < 2^32 */
+    u128 c = (u128)a->l[0] * k; uint64_t r0 = (uint64_t)c; c >>= 64;
+    c += (u128)a->l[1] * k; uint64_t r1 = (uint64_t)c; c >>= 64;
+    c += (u128)a->l[2] * k; uint64_t r2 = (uint64_t)c; c >>= 64;
+    c += (u128)a->l[3] * k; uint64_t r3 = (uint64_t)c; c >>= 64;
+    ff_fold(r, r0, r1, r2, r3, (uint64_t)c);
+}
+static inline int ff_is_zero(const ff *a) { ff t = *a; ff_normalize(&t); return is_zero256(t.l); }
+static inline int ff_eq(const ff *a, const ff *b) { ff x = *a, y = *b; ff_normalize(&x); ff_normalize(&y); return memcmp(&x, &y, sizeof x) == 0; }
+static inline int ff_is_odd(const ff *a) { ff t = *a; ff_normalize(&t); return (int)(t.l[0] & 1); }
+static inline void ff_sqr_n(ff *r, const ff *a, int n) { *r = *a; for (int i = 0; i < n; i++) ff_sqr(r, r); }
+/* t = a^((2^223 - 1) * 2^23 + 2^22 - 1), x2 = a^3: the shared prefix of a^(p-2), a^((p-3)/4), a^((p+1)/4) */
+static void ff_pow_prefix(ff *t, ff *x2, const ff *a) {
+    ff x3, x6, x9, x11, x22, x44, x88, x176, x220, x223;
+    ff_sqr(x2, a); ff_mul(x2, x2, a);
+    ff_sqr(&x3, x2); ff_mul(&x3, &x3, a);
+    ff_sqr_n(&x6, &x3, 3); ff_mul(&x6, &x6, &x3);
+    ff_sqr_n(&x9, &x6, 3); ff_mul(&x9, &x9, &x3);
+    ff_sqr_n(&x11, &x9, 2); ff_mul(&x11, &x11, x2);
+    ff_sqr_n(&x22, &x11, 11); ff_mul(&x22, &x22, &x11);
+    ff_sqr_n(&x44, &x22, 22); ff_mul(&x44, &x44, &x22);
+    ff_sqr_n(&x88, &x44, 44); ff_mul(&x88, &x88, &x44);
+    ff_sqr_n(&x176, &x88, 88); ff_mul(&x176, &x176, &x88);
+    ff_sqr_n(&x220, &x176, 44); ff_mul(&x220, &x220, &x44);
+    ff_sqr_n(&x223, &x220, 3); ff_mul(&x223, &x223, &x3);
+    ff_sqr_n(t, &x223, 23); ff_mul(t, t, &x22);
+}
+static void ff_inv(ff *r, const ff *a) { /* a^(p-2) */
+    ff t, x2;
+    ff_pow_prefix(&t, &x2, a);
+    ff_sqr_n(&t, &t, 5); ff_mul(&t, &t, a);
+    ff_sqr_n(&t, &t, 3); ff_mul(&t, &t, &x2);
+    ff_sqr_n(&t, &t, 2); ff_mul(r, &t, a);
+}
+static void ff_pow_c1(ff *r, const ff *a) { /* a^((p-3)/4), RFC 9380 F.2.1.2 */
+    ff t, x2;
+    ff_pow_prefix(&t, &x2, a);
+    ff_sqr_n(&t, &t, 5); ff_mul(&t, &t, a);
+    ff_sqr_n(&t, &t, 3); ff_mul(r, &t, &x2);
+}
+static int ff_from_be_checked(ff *r, const uint8_t b[32]) { from_be32(r->l, b); return !ge256(r->l, P_); }
+static void ff_to_be(uint8_t b[32], const ff *a) { ff t = *a; ff_normalize(&t); to_be32(b, t.l); }
+static inline ff ff_of(const fe *a) { ff r; memcpy(&r, a, sizeof r); return r; }
+
+/* ---------------------------------------------------------------------------------------------------------------- group law */
+static void pj_dbl(pj *p) { /* a = 0; no point of order two on this curve */
+    if (p->inf) return;
+    ff a, b, c, d, e, f, t;
+    ff_sqr(&a, &p->x); ff_sqr(&b, &p->y); ff_sqr(&c, &b);
+    ff_add(&t, &p->x, &b); ff_sqr(&t, &t); ff_sub(&t, &t, &a); ff_sub(&t, &t, &c); ff_add(&d, &t, &t);      /* 4XY^2 */
+    ff_add(&e, &a, &a); ff_add(&e, &e, &a);
+    ff_sqr(&f, &e);
+    ff_mul(&p->z, &p->y, &p->z); ff_add(&p->z, &p->z, &p->z);
+    ff_sub(&p->x, &f, &d); ff_sub(&p->x, &p->x, &d);
+    ff_sub(&t, &d, &p->x); ff_mul(&t, &e, &t);
+    ff_mul_small(&c, &c, 8);
+    ff_sub(&p->y, &t, &c);
+}
+static void pj_madd(pj *p, const ff *qx, const ff *qy) { /* p += (qx, qy), every exceptional case handled */
+    if (p->inf) { p->x = *qx; p->y = *qy; p->z = FF_ONE; p->inf = 0; return; }
+    ff z1z1, u2, s2, h, r, hh, hhh, v, t;
+    ff_sqr(&z1z1, &p->z);
+    ff_mul(&u2, qx, &z1z1);
+    ff_mul(&s2, &p->z, &z1z1); ff_mul(&s2, &s2, qy);
+    ff_sub(&h, &u2, &p->x);
+    ff_sub(&r, &s2, &p->y);
+    if (ff_is_zero(&h)) { if (ff_is_zero(&r)) pj_dbl(p); else p->inf = 1; return; }
+    ff_sqr(&hh, &h); ff_mul(&hhh, &hh, &h); ff_mul(&v, &p->x, &hh);
+    ff_mul(&p->z, &p->z, &h);
+    ff_sqr(&t, &r); ff_sub(&t, &t, &hhh); ff_sub(&t, &t, &v); ff_sub(&p->x, &t, &v);
+    ff_sub(&t, &v, &p->x); ff_mul(&t, &t, &r);
+    ff_mul(&hhh, &hhh, &p->y);
+    ff_sub(&p->y, &t, &hhh);
+}
+static void pj_add(pj *p, const pj *q) {
+    if (q->inf) return;
+    if (p->inf) { *p = *q; return; }
+    ff z1z1, z2z2, u1, u2, s1, s2, h, r, hh, hhh, v, t;
+    ff_sqr(&z1z1, &p->z); ff_sqr(&z2z2, &q->z);
+    ff_mul(&u1, &p->x, &z2z2); ff_mul(&u2, &q->x, &z1z1);
+    ff_mul(&s1, &q->z, &z2z2); ff_mul(&s1, &s1, &p->y);
+    ff_mul(&s2, &p->z, &z1z1); ff_mul(&s2, &s2, &q->y);
+    ff_sub(&h, &u2, &u1); ff_sub(&r, &s2, &s1);
+    if (ff_is_zero(&h)) { if (ff_is_zero(&r)) pj_dbl(p); else p->inf = 1; return; }
+    ff_sqr(&hh, &h); ff_mul(&hhh, &hh, &h); ff_mul(&v, &u1, &hh);
+    ff_mul(&p->z, &p->z, &q->z); ff_mul(&p->z, &p->z, &h);
+    ff_sqr(&t, &r); ff_sub(&t, &t, &hhh); ff_sub(&t, &t, &v); ff_sub(&p->x, &t, &v);
+    ff_sub(&t, &v, &p->x); ff_mul(&t, &t, &r);
+    ff_mul(&hhh, &hhh, &s1);
+    ff_sub(&p->y, &t, &hhh);
+}
+static int pj_eq_aff(const pj *p, const ff *ax, const ff *ay) { /* p != infinity */
+    ff z2, z3, t;
+    ff_sqr(&z2, &p->z); ff_mul(&z3, &z2, &p->z);
+    ff_mul(&t, ax, &z2); if (!ff_eq(&t, &p->x)) return 0;
+    ff_mul(&t, ay, &z3); return ff_eq(&t, &p->y);
+}
+static int pa_on_curve(const ff *x, const ff *y) {
+    ff l, r; const ff seven = {{7, 0, 0, 0}};
+    ff_sqr(&l, y); ff_sqr(&r, x); ff_mul(&r, &r, x); ff_add(&r, &r, &seven);
+    return ff_eq(&l, &r);
+}
+
+/* --------------------------------------------------------------------------------------------- GLV split and wNAF recoding */
+/* k = k1 + k2 * lambda (mod n), |k1|, |k2| < 2^128 (standard secp256k1 lattice constants, the same as zk-nullifier-sig_amd/csrc/plume_ec.h) */
+static const uint64_t GLV_G1[4] = {0xE893209A45DBB031ULL, 0x3DAA8A1471E8CA7FULL, 0xE86C90E49284EB15ULL, 0x3086D221A7D46BCDULL};
+static const uint64_t GLV_G2[4] = {0x1571B4AE8AC47F71ULL, 0x221208AC9DF506C6ULL, 0x6F547FA90ABFE4C4ULL, 0xE4437ED6010E8828ULL};
+static const uint64_t GLV_MB1[4] = {0x6F547FA90ABFE4C3ULL, 0xE4437ED6010E8828ULL, 0, 0};
+static const uint64_t GLV_MB2[4] = {0xD765CDA83DB1562CULL, 0x8A280AC50774346DULL, 0xFFFFFFFFFFFFFFFEULL, 0xFFFFFFFFFFFFFFFFULL};
+static const sc GLV_LAMBDA = {{0xDF02967C1B23BD72ULL, 0x122E22EA20816678ULL, 0xA5261C028812645AULL, 0x5363AD4CC05C30E0ULL}};
+typedef struct { uint64_t m[3]; int neg; } half; /* magnitude < 2^129 */
+static void glv_split_fast(half *h1, half *h2, const sc *k) {
+    uint64_t t[8], c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0}, p1[8], p2[8], w[8];
+    mul256(t, k->l, GLV_G1); { u128 c = (u128)t[6] + (t[5] >> 63); c1[0] = (uint64_t)c; c1[1] = t[7] + (uint64_t)(c >> 64); }
+    mul256(t, k->l, GLV_G2); { u128 c = (u128)t[6] + (t[5] >> 63); c2[0] = (uint64_t)c; c2[1] = t[7] + (uint64_t)(c >> 64); }
+    mul256(p1, c1, GLV_MB1); mul256(p2, c2, GLV_MB2);
+    u128 c = 0;
+    for (int i = 0; i < 8; i++) { c += (u128)p1[i] + p2[i]; w[i] = (uint64_t)c; c >>= 64; }
+    sc k2, k1, tmp;
+    sc_reduce512(&k2, w);
+    sc_mul(&tmp, &k2, &GLV_LAMBDA); sc_neg(&tmp, &tmp); sc_add(&k1, k, &tmp);
+    const sc *ks[2] = {&k1, &k2}; half *hs[2] = {h1, h2};
+    for (int j = 0; j < 2; j++) {
+        sc v = *ks[j];
+        hs[j]->neg = (v.l[2] | v.l[3]) != 0 && !(v.l[3] == 0 && v.l[2] <= 1);       /* a "negative" residue is close to n */
+        if (hs[j]->neg) sc_neg(&v, &v);
+        hs[j]->m[0] = v.l[0]; hs[j]->m[1] = v.l[1]; hs[j]->m[2] = v.l[2];
+    }
+}
+#define NAF_LEN 132
+static void wnaf(int8_t naf[NAF_LEN], const half *h, int w) { /* digits odd, |d| < 2^(w-1), or 0 */
+    uint64_t m[3] = {h->m[0], h->m[1], h->m[2]};
+    memset(naf, 0, NAF_LEN);
+    for (int i = 0; (m[0] | m[1] | m[2]) != 0 && i < NAF_LEN; i++) {
+        if (m[0] & 1) {
+            int d = (int)(m[0] & ((1u << w) - 1));
+            if (d >= (1 << (w - 1))) d -= 1 << w;
+            naf[i] = (int8_t)d;
+            if (d > 0) { uint64_t b = m[0] < (uint64_t)d; m[0] -= (uint64_t)d; if (b) { if (m[1]-- == 0) m[2]--; } }
+            else { uint64_t o = m[0]; m[0] += (uint64_t)(-d); if (m[0] < o) { if (++m[1] == 0) m[2]++; } }
+        }
+        m[0] = (m[0] >> 1) | (m[1] << 63); m[1] = (m[1] >> 1) | (m[2] << 63); m[2] >>= 1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ tables */
+#define WV 5                  /* per-signature bases: odd multiples 1, 3, ..., 15 */
+#define TV (1 << (WV - 2))
+#define WG 8                  /* generator: odd multiples 1, 3, ..., 127, built once */
+#define TG (1 << (WG - 2))
+static pa GTAB[TG]; static ff GTAB_BX[TG];
+static int gtab_ready = 0;
+/* odd multiples of a base in Jacobian coordinates (base affine: the first addition is mixed) */
+static void odd_multiples(pj *out, int n, const pj *base) {
+    pj d = *base; pj_dbl(&d);
+    out[0] = *base;
+    for (int i = 1; i < n; i++) { out[i] = out[i - 1]; pj_add(&out[i], &d); }
+}
+/* Jacobian -> affine for n points with ONE inversion (none of them infinite) */
+static void batch_affine(pa *out, const pj *in, int n) {
+    ff pre[3 * TV + TG + 4], acc = FF_ONE, inv;
+    for (int i = 0; i < n; i++) { pre[i] = acc; ff_mul(&acc, &acc, &in[i].z); }
+    ff_inv(&inv, &acc);
+    for (int i = n - 1; i >= 0; i--) {
+        ff zi, zi2;
+        ff_mul(&zi, &inv, &pre[i]); ff_mul(&inv, &inv, &in[i].z);
+        ff_sqr(&zi2, &zi); ff_mul(&out[i].x, &in[i].x, &zi2); ff_mul(&zi2, &zi2, &zi); ff_mul(&out[i].y, &in[i].y, &zi2);
+    }
+}
+static void init_fast(void) {
+    init_consts();
+    if (gtab_ready) return;
+    pj g, t[TG];
+    g.x = ff_of(&FE_GX); g.y = ff_of(&FE_GY); g.z = FF_ONE; g.inf = 0;
+    odd_multiples(t, TG, &g);
+    batch_affine(GTAB, t, TG);
+    for (int i = 0; i < TG; i++) ff_mul(&GTAB_BX[i], &GTAB[i].x, &FF_BETA);
+    __sync_synchronize();
+    gtab_ready = 1;
+}
+
+/* acc = sum of the four streams: stream s has digits naf[s], table tab[s] (affine odd multiples), x-coordinates xs[s] (x or beta*x), flip[s] negates */
+static void strauss(pj *acc, int8_t naf[4][NAF_LEN], const pa *tab[4], const ff *xs[4], const int flip[4]) {
+    acc->inf = 1;
+    int top = NAF_LEN - 1;
+    while (top >= 0 && !(naf[0][top] | naf[1][top] | naf[2][top] | naf[3][top])) top--;
+    for (int i = top; i >= 0; i--) {
+        pj_dbl(acc);
+        for (int s = 0; s < 4; s++) {
+            int d = naf[s][i];
+            if (!d) continue;
+            int neg = (d < 0) != (flip[s] != 0), e = ((d < 0 ? -d : d) - 1) >> 1;
+            ff y = tab[s][e].y;
+            if (neg) ff_neg(&y, &y);
+            pj_madd(acc, &xs[s][e], &y);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ hash_to_curve (inversion-free) */
+static void sswu_frac_fast(ff *xn, ff *xd, ff *y, const ff *u) { /* RFC 9380 F.2 on E' without the final division: x = xn / xd */
+    const ff A = ff_of(&FE_ISO_A), c2 = ff_of(&FE_C2);
+    ff tv1, tv2, tv3, tv4, tv5, tv6, y1, y2, s1, s2, s3, t;
+    ff_sqr(&tv1, u); ff_mul_small(&tv1, &tv1, 11); ff_neg(&tv1, &tv1);
+    ff_sqr(&tv2, &tv1); ff_add(&tv2, &tv2, &tv1);
+    ff_add(&tv3, &tv2, &FF_ONE); ff_mul_small(&tv3, &tv3, 1771);
+    if (ff_is_zero(&tv2)) { const ff el = {{11, 0, 0, 0}}; ff_neg(&tv4, &el); } else ff_neg(&tv4, &tv2);
+    ff_mul(&tv4, &tv4, &A);
+    ff_sqr(&tv2, &tv3); ff_sqr(&tv6, &tv4); ff_mul(&tv5, &tv6, &A); ff_add(&tv2, &tv2, &tv5); ff_mul(&tv2, &tv2, &tv3);
+    ff_mul(&tv6, &tv6, &tv4); ff_mul_small(&tv5, &tv6, 1771); ff_add(&tv2, &tv2, &tv5);
+    ff_mul(xn, &tv1, &tv3);
+    ff_sqr(&s1, &tv6); ff_mul(&s2, &tv2, &tv6); ff_mul(&s1, &s1, &s2);
+    ff_pow_c1(&y1, &s1); ff_mul(&y1, &y1, &s2);
+    ff_sqr(&s3, &y1); ff_mul(&s3, &s3, &tv6);
+    int is_sq = ff_eq(&s3, &tv2);
+    ff_mul(&y2, &y1, &c2);
+    ff_mul(y, &tv1, u); ff_mul(y, y, &y2);
+    if (is_sq) { *xn = tv3; *y = y1; }
+    if (ff_is_odd(u) != ff_is_odd(y)) { ff_neg(&t, y); *y = t; }
+    *xd = tv4;
+}
+static void iso3_frac(pj *q, const ff *xn, const ff *xd, const ff *y) { /* RFC 9380 E.1 on the fraction, Jacobian result with Z = Dx * Dy */
+    ff k[15];
+    for (int i = 0; i < 4; i++) { k[i] = ff_of(&XNUM[i]); k[7 + i] = ff_of(&YNUM[i]); k[11 + i] = ff_of(&YDEN[i]); }
+    for (int i = 0; i < 3; i++) k[4 + i] = ff_of(&XDEN[i]);
+    ff xd2, xd3, xn2, xn3, n2d, nd2, t, nx, dx, ny, dy, w;
+    ff_sqr(&xd2, xd); ff_mul(&xd3, &xd2, xd); ff_sqr(&xn2, xn); ff_mul(&xn3, &xn2, xn); ff_mul(&n2d, &xn2, xd); ff_mul(&nd2, xn, &xd2);
+    ff_mul(&nx, &k[3], &xn3); ff_mul(&t, &k[2], &n2d); ff_add(&nx, &nx, &t); ff_mul(&t, &k[1], &nd2); ff_add(&nx, &nx, &t); ff_mul(&t, &k[0], &xd3); ff_add(&nx, &nx, &t);
+    ff_mul(&dx, &k[5], xn); ff_mul(&dx, &dx, xd); ff_add(&dx, &dx, &xn2); ff_mul(&t, &k[4], &xd2); ff_add(&dx, &dx, &t); ff_mul(&dx, &dx, xd);
+    ff_mul(&ny, &k[10], &xn3); ff_mul(&t, &k[9], &n2d); ff_add(&ny, &ny, &t); ff_mul(&t, &k[8], &nd2); ff_add(&ny, &ny, &t); ff_mul(&t, &k[7], &xd3); ff_add(&ny, &ny, &t);
+    ff_mul(&dy, &k[13], &n2d); ff_add(&dy, &dy, &xn3); ff_mul(&t, &k[12], &nd2); ff_add(&dy, &dy, &t); ff_mul(&t, &k[11], &xd3); ff_add(&dy, &dy, &t);
+    ff dy2;
+    ff_mul(&q->z, &dx, &dy); ff_sqr(&dy2, &dy); ff_mul(&w, &dx, &dy2); ff_mul(&q->x, &nx, &w);
+    ff_sqr(&t, &dx); ff_mul(&w, &w, &t); ff_mul(&t, y, &ny); ff_mul(&q->y, &t, &w);
+    q->inf = ff_is_zero(&q->z);
+}
+static void h2c_fast(pj *h, const uint8_t *msg, size_t mlen, const uint8_t enc[33]) {
+    uint8_t uni[96];
+    fe u0, u1;
+    expand_message_xmd96(uni, msg, mlen, enc, 33);
+    fe_from_be48(&u0, uni); fe_from_be48(&u1, uni + 48);
+    ff u[2] = {ff_of(&u0), ff_of(&u1)}, xn, xd, y;
+    pj q1;
+    sswu_frac_fast(&xn, &xd, &y, &u[0]); iso3_frac(h, &xn, &xd, &y);
+    sswu_frac_fast(&xn, &xd, &y, &u[1]); iso3_frac(&q1, &xn, &xd, &y);
+    pj_add(h, &q1);
+}
+
+/* ------------------------------------------------------------------------------------------------ verify */
+static void enc33(uint8_t out[33], const ff *x, const ff *y) { out[0] = (uint8_t)(2 + ff_is_odd(y)); ff_to_be(out + 1, x); }
+static int verify_fast_one(int version, const uint8_t *msg, size_t mlen, const uint8_t *pk_b, const uint8_t *nul_b, const uint8_t *c_b, const uint8_t *s_b,
+                           const uint8_t *r_b, const uint8_t *hr_b) {
+    static const uint8_t zero64[64] = {0};
+    /* identity inputs: the reference-shaped slow path (encodings of one byte, cryptographically unreachable) */
+    if (!memcmp(pk_b, zero64, 64) || !memcmp(nul_b, zero64, 64) || (version == 1 && (!memcmp(r_b, zero64, 64) || !memcmp(hr_b, zero64, 64))))
+        return verify_one(version, msg, mlen, pk_b, nul_b, c_b, s_b, r_b, hr_b);
+    sc c, s;
+    if (!sc_from_be_nonzero(&c, c_b) || !sc_from_be_nonzero(&s, s_b)) return 0;
+    pa pk, nul, rp, hrp;
+    if (!ff_from_be_checked(&pk.x, pk_b) || !ff_from_be_checked(&pk.y, pk_b + 32) || !pa_on_curve(&pk.x, &pk.y)) return 0;
+    if (!ff_from_be_checked(&nul.x, nul_b) || !ff_from_be_checked(&nul.y, nul_b + 32) || !pa_on_curve(&nul.x, &nul.y)) return 0;
+    if (version == 1) {
+        if (!ff_from_be_checked(&rp.x, r_b) || !ff_from_be_checked(&rp.y, r_b + 32) || !pa_on_curve(&rp.x, &rp.y)) return 0;
+        if (!ff_from_be_checked(&hrp.x, hr_b) || !ff_from_be_checked(&hrp.y, hr_b + 32) || !pa_on_curve(&hrp.x, &hrp.y)) return 0;
+    }
+    uint8_t e_pk[33], e_nul[33];
+    enc33(e_pk, &pk.x, &pk.y); enc33(e_nul, &nul.x, &nul.y);
+    pj hj;
+    h2c_fast(&hj, msg, mlen, e_pk);                                                                  /* lib.rs:103 */
+    if (hj.inf) return verify_one(version, msg, mlen, pk_b, nul_b, c_b, s_b, r_b, hr_b);
+    /* window tables of pk, H, nullifier: odd multiples, one inversion for all of them (and for H itself: entry 0 of its table) */
+    pj tj[3 * TV], base;
+    base.x = pk.x; base.y = pk.y; base.z = FF_ONE; base.inf = 0; odd_multiples(tj, TV, &base);
+    odd_multiples(tj + TV, TV, &hj);
+    base.x = nul.x; base.y = nul.y; odd_multiples(tj + 2 * TV, TV, &base);
+    for (int i = 0; i < 3 * TV; i++) if (tj[i].inf || ff_is_zero(&tj[i].z)) return verify_one(version, msg, mlen, pk_b, nul_b, c_b, s_b, r_b, hr_b);
+    pa ta[3 * TV]; ff bx[3 * TV];
+    batch_affine(ta, tj, 3 * TV);
+    for (int i = 0; i < 3 * TV; i++) ff_mul(&bx[i], &ta[i].x, &FF_BETA);
+    ff tx[3 * TV], gx[TG];
+    for (int i = 0; i < 3 * TV; i++) tx[i] = ta[i].x;
+    for (int i = 0; i < TG; i++) gx[i] = GTAB[i].x;
+    /* scalars: s (positive), c (negated) */
+    half s1, s2, c1, c2;
+    glv_split_fast(&s1, &s2, &s); glv_split_fast(&c1, &c2, &c);
+    int8_t naf[4][NAF_LEN];
+    pj rcalc, hrcalc;
+    {   /* R' = s*G - c*pk   (lib.rs:101) */
+        wnaf(naf[0], &s1, WG); wnaf(naf[1], &s2, WG); wnaf(naf[2], &c1, WV); wnaf(naf[3], &c2, WV);
+        const pa *tab[4] = {GTAB, GTAB, ta, ta}; const ff *xs[4] = {gx, GTAB_BX, tx, bx};
+        const int flip[4] = {s1.neg, s2.neg, !c1.neg, !c2.neg};
+        strauss(&rcalc, naf, tab, xs, flip);
+    }
+    {   /* Hr' = s*H - c*nullifier   (lib.rs:109) */
+        wnaf(naf[0], &s1, WV); wnaf(naf[1], &s2, WV);
+        const pa *tab[4] = {ta + TV, ta + TV, ta + 2 * TV, ta + 2 * TV}; const ff *xs[4] = {tx + TV, bx + TV, tx + 2 * TV, bx + 2 * TV};
+        const int flip[4] = {s1.neg, s2.neg, !c1.neg, !c2.neg};
+        strauss(&hrcalc, naf, tab, xs, flip);
+    }
+    uint8_t pre[198], e[33], d[32];
+    size_t n = 0;
+    if (version == 1) {
+        if (rcalc.inf || hrcalc.inf) return 0;                                                        /* the given R, Hr are not the identity here */
+        if (!pj_eq_aff(&rcalc, &rp.x, &rp.y)) return 0;                                               /* lib.rs:117 */
+        if (!pj_eq_aff(&hrcalc, &hrp.x, &hrp.y)) return 0;                                            /* lib.rs:122 */
+        ff gxx = ff_of(&FE_GX), gyy = ff_of(&FE_GY);
+        enc33(e, &gxx, &gyy); memcpy(pre + n, e, 33); n += 33;
+        memcpy(pre + n, e_pk, 33); n += 33;
+        enc33(e, &ta[TV].x, &ta[TV].y); memcpy(pre + n, e, 33); n += 33;                              /* H = 1 * H of its table */
+        memcpy(pre + n, e_nul, 33); n += 33;
+        enc33(e, &rp.x, &rp.y); memcpy(pre + n, e, 33); n += 33;
+        enc33(e, &hrp.x, &hrp.y); memcpy(pre + n, e, 33); n += 33;
+    } else {
+        if (rcalc.inf || hrcalc.inf) return verify_one(version, msg, mlen, pk_b, nul_b, c_b, s_b, r_b, hr_b);
+        pj two[2] = {rcalc, hrcalc}; pa aff2[2];
+        batch_affine(aff2, two, 2);
+        memcpy(pre + n, e_nul, 33); n += 33;
+        enc33(e, &aff2[0].x, &aff2[0].y); memcpy(pre + n, e, 33); n += 33;
+        enc33(e, &aff2[1].x, &aff2[1].y); memcpy(pre + n, e, 33); n += 33;
+    }
+    sha256_ctx ctx; sha256_init(&ctx); sha256_update(&ctx, pre, n); sha256_final(&ctx, d);          /* lib.rs:127-143 */
+    sc cc; int canon;
+    sc_from_digest(&cc, d, &canon);
+    return memcmp(cc.l, c.l, 32) == 0;
+}
+
+typedef struct { int version; size_t lo, hi; const uint8_t *msgs; const uint64_t *off; const uint8_t *pk, *nul, *c, *s, *r, *hr; uint8_t *ok; } fjob;
+static void *fast_worker(void *arg) {
+    fjob *j = (fjob *)arg;
+    for (size_t i = j->lo; i < j->hi; i++)
+        j->ok[i] = (uint8_t)verify_fast_one(j->version, j->msgs + j->off[i], (size_t)(j->off[i + 1] - j->off[i]), j->pk + 64 * i, j->nul + 64 * i, j->c + 32 * i,
+                                            j->s + 32 * i, j->r ? j->r + 64 * i : 0, j->hr ? j->hr + 64 * i : 0);
+    return 0;
+}
+/* same arguments as oracle_verify_batch / plume_verify_batch (host buffers) */
+int fast_verify_batch(int version, size_t n, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *pk, const uint8_t *nullifier, const uint8_t *c,
+                      const uint8_t *s, const uint8_t *r_point, const uint8_t *hashed_to_curve_r, uint8_t *ok, int nthreads) {
+    if ((version != 1 && version != 2) || (version == 1 && (!r_point || !hashed_to_curve_r))) return -1;
+    init_fast();
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    fjob *jobs = (fjob *)malloc(sizeof(fjob) * nthreads);
+    for (int t = 0; t < nthreads; t++) {
+        fjob j = {version, n * t / nthreads, n * (t + 1) / nthreads, msgs, msg_off, pk, nullifier, c, s, version == 1 ? r_point : 0, version == 1 ? hashed_to_curve_r : 0, ok};
+        jobs[t] = j;
+        if (t > 0) pthread_create(&th[t], 0, fast_worker, &jobs[t]);
+    }
+    fast_worker(&jobs[0]);
+    for (int t = 1; t < nthreads; t++) pthread_join(th[t], 0);
+    free(th); free(jobs);
+    return 0;
+}
+/* test hooks: field operations on big-endian 32-byte values (op 0 mul, 1 sqr, 2 inv, 3 add, 4 sub) and the GLV split */
+void fast_ff_op(int op, const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
+    ff x, y, r;
+    from_be32(x.l, a); from_be32(y.l, b);
+    if (op == 0) ff_mul(&r, &x, &y); else if (op == 1) ff_sqr(&r, &x); else if (op == 2) ff_inv(&r, &x); else if (op == 3) ff_add(&r, &x, &y); else ff_sub(&r, &x, &y);
+    ff_to_be(out, &r);
+}
+void fast_glv(const uint8_t k[32], uint8_t out[50]) { /* |k1| (24 B little-endian), sign, |k2|, sign */
+    sc s; half h1, h2;
+    from_be32(s.l, k);
+    glv_split_fast(&h1, &h2, &s);
+    memcpy(out, h1.m, 24); out[24] = (uint8_t)h1.neg; memcpy(out + 25, h2.m, 24); out[49] = (uint8_t)h2.neg;
+}

@@ -4,7 +4,7 @@
 # then, back in the container:  cp gpurun_out/prof_r01/r01_kernel_{stats,trace}.csv profiles/ ; tail -1 gpurun_out/bench_r01.log > profiles/r01_bench_line.json ;
 #                               python profiles/summarize_pmc.py r01
 # Counters go in their own passes, each with --kernel-trace only (never with sys/hip/hsa traces).
-R=${1:-r01}
+R=${1:-r02}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python3 bench.py > gpurun_out/bench_$R.log 2> gpurun_out/bench_$R.err
