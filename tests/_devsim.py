@@ -166,6 +166,14 @@ def registers_from_be(values):
     return out.view(np.uint64)
 
 
+def tables_raw(points):
+    """window tables (1P..8P as 64-byte records) of raw, UNVALIDATED affine bases built by one lane"""
+    pts = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 64)
+    out = np.zeros((len(pts), 8, 64), dtype=np.uint8)
+    lib().ds_tables_raw(C.c_uint32(len(pts)), _p(pts), _p(out))
+    return out
+
+
 def point_mul(k: bytes, p: bytes):
     out = (C.c_uint8 * 64)()
     ok = lib().ds_point_mul((C.c_uint8 * 32).from_buffer_copy(k), (C.c_uint8 * 64).from_buffer_copy(p), out)

@@ -112,11 +112,32 @@ static void build_gcomb(std::vector<uint32_t>& comb) {
 // host stand-in for launch_tables: the same lane -> jobs mapping and the same lane-interleaved scratch indexing as k_tables
 static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L, stride = ((lanes + 7) / 8) * 8;     // "grid" rounded up like the kernel's
-    std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_ENTRIES * PLUME_TAB_SCR_WORDS);
+    std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_AFF_SCR_WORDS);
     for (size_t lane = 0; lane < lanes; lane++) {
         const size_t j0 = lane * (size_t)L, rem = njobs - j0;
-        table_build(tab, bases, jobflags, njobs, j0, (int)(rem < (size_t)L ? rem : (size_t)L), scr.data(), stride, lane);
+        table_build_affine(tab, bases, jobflags, njobs, j0, (int)(rem < (size_t)L ? rem : (size_t)L), scr.data(), stride, lane);
     }
+}
+
+// window tables of `nb` affine bases given as raw 64-byte records, all flagged usable WITHOUT validation, built by ONE lane (test hook for the
+// zero-denominator guard of table_build_affine); out: nb x 8 x 64 bytes (x || y of 1P..8P)
+void ds_tables_raw(uint32_t nb, const uint8_t* pts, uint8_t* out) {
+    std::vector<uint32_t> bases(PLUME_JAC_WORDS * (size_t)nb), tab((size_t)nb * PLUME_TAB_WORDS);
+    std::vector<uint8_t> flags(nb, (uint8_t)(PLUME_JOB_OK | PLUME_JOB_AFFINE));
+    for (uint32_t j = 0; j < nb; j++) {
+        alignas(16) uint8_t rec[64]; memcpy(rec, pts + 64 * j, 64);
+        jac p; p.inf = 0; p.z = fe_small(1);
+        fe_from_be_aligned(p.x, rec); fe_from_be_aligned(p.y, rec + 32);
+        st_jac_soa(bases.data(), nb, j, p);
+    }
+    run_tables(tab.data(), bases.data(), flags.data(), nb, (int)nb);
+    for (uint32_t j = 0; j < nb; j++)
+        for (int k = 0; k < 8; k++) {
+            fe x, y; alignas(16) uint8_t rec[64];
+            ld_tab_xy(x, y, tab.data() + (size_t)j * PLUME_TAB_WORDS + k * PLUME_TAB_ENTRY_WORDS, false);
+            store_affine_be(rec, x, y, false);
+            memcpy(out + 64 * (8 * (size_t)j + k), rec, 64);
+        }
 }
 
 // simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)

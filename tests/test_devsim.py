@@ -418,3 +418,22 @@ def _check_sec1_der(to_der, from_der, kats):
 
 def test_sec1_der_scalar_marshalling(kats):
     _check_sec1_der(D.scalars_to_der, None, kats)
+
+
+def test_affine_table_chain_and_its_zero_denominator_guard():
+    """table_build_affine: (a) the tables of honest bases are k*P, k = 1..8, whatever else shares the lane; (b) a record that is no curve point and makes a
+    denominator vanish (y = 0: the first doubling divides by 2y) cannot poison the OTHER jobs of its lane -- the level is redone with that denominator
+    replaced.  (Such a record never reaches the builder through the API: bases are validated and replaced by G first.)"""
+    rng = random.Random(12)
+    pts = [O.G, O.pt_mul(rng.randrange(1, N), O.G), O.pt_mul(N - 1, O.G), O.pt_mul(rng.randrange(1, N), O.G)]
+    rec = lambda p: p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")  # noqa: E731
+    good = np.frombuffer(b"".join(rec(p) for p in pts), dtype=np.uint8).reshape(-1, 64)
+    want = [[O.pt_bytes(O.pt_mul(k, p)) for k in range(1, 9)] for p in pts]
+    got = D.tables_raw(good)
+    assert [[got[j, k].tobytes() for k in range(8)] for j in range(len(pts))] == want
+    bogus = (5).to_bytes(32, "big") + bytes(32)                        # y = 0
+    mixed = np.concatenate([good[:2], np.frombuffer(bogus, dtype=np.uint8).reshape(1, 64), good[2:]])
+    got = D.tables_raw(mixed)
+    for j, src in enumerate([0, 1, None, 2, 3]):
+        if src is not None:
+            assert [got[j, k].tobytes() for k in range(8)] == want[src], j

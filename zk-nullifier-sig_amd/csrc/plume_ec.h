@@ -382,6 +382,204 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
     }
 }
 
+// ------------------------------------------------------------------------------ window tables by affine chains (round 2)
+// The window tables of the per-item bases (1P..8P, affine, + beta*x) built WITHOUT Jacobian intermediates: every entry comes from an affine
+// doubling or an affine addition of earlier entries, and the field inversions those need are shared by all jobs of a lane, level by level
+// (Montgomery's trick):
+//     level 1:  P (made affine if the base is Jacobian), 2P = dbl(P)                           denominators 2y            (Jacobian base: Z and 2Y)
+//     level 2:  3P = 2P + P,  4P = dbl(2P)                                                    x2 - x1,  2 y2
+//     level 3:  5P = 4P + P,  6P = dbl(3P),  7P = 4P + 3P,  8P = dbl(4P)                      x4 - x1,  2 y3,  x4 - x3,  2 y4
+// An affine doubling is 2M + 2S and an addition 2M + 1S once the inverse is known (+3M for the inverse's share of the batch), against 3M + 4S /
+// 8M + 3S for the Jacobian forms PLUS the ~7M per entry the Jacobian table paid to become affine afterwards: 54 (affine base) / 64 (Jacobian base)
+// multiplications per table instead of ~125, three inversions per lane instead of one.  Entries are final when they are computed: they are written
+// once, as whole rows, and read back (by the same lane) as operands of the next level; the only scratch is the prefix products of a level
+// (4 x 36 bytes per job, lane-interleaved like the Jacobian builder's), an eighth of what that one streamed through HBM.
+// Denominators cannot vanish for a base of prime order n (kP = +-P needs (k-+1)P = O; the curve has no point with y = 0) and every base that is
+// not such a point (identity, failed validation) is replaced by G before it gets here; should a level's product be zero all the same, the level
+// is redone with zero denominators replaced by 1, so that one item can never poison the other jobs of its lane.
+PLUME_HD void pre_st(uint32_t* scr, size_t sstride, size_t slane, size_t q, const fe& a) {
+    PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) scr[((q * PLUME_FE_W + (size_t)i) * sstride) + slane] = a.v[i];
+}
+PLUME_HD void pre_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, size_t q) {
+    PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = scr[((q * PLUME_FE_W + (size_t)i) * sstride) + slane];
+}
+#define PLUME_TAB_AFF_SCR_WORDS (8 * PLUME_FE_WORDS)       // prefix products per job: two regions (consecutive levels overlap) of at most 4 denominators
+// 2P from affine P = (x, y) (tight) and l = 1 / (2y)
+PLUME_HD void aff_dbl(fe& x3, fe& y3, const fe& x, const fe& y, const fe& l) {
+    fe a, lam, t, t2;
+    fe_sqr(a, x);
+    fe_add_lazy(t, a, a); fe_add_lazy(t, t, a);                 // 3x^2, unreduced
+    fe_mul(lam, t, l);
+    fe_sqr(t, lam);
+    fe_dbl_lazy(t2, x);
+    fe_sub_lazy<3>(x3, t, t2); fe_carry(x3);                    // lambda^2 - 2x
+    fe_sub_lazy<2>(t, x, x3);
+    fe_mul(t, lam, t);
+    fe_sub_lazy<2>(y3, t, y); fe_carry(y3);                     // lambda (x - x3) - y
+}
+// P1 + P2 from affine points (tight) and dinv = 1 / (x2 - x1)
+PLUME_HD void aff_add(fe& x3, fe& y3, const fe& x1, const fe& y1, const fe& x2, const fe& y2, const fe& dinv) {
+    fe lam, t, s;
+    fe_sub_lazy<2>(t, y2, y1);
+    fe_mul(lam, t, dinv);
+    fe_sqr(t, lam);
+    fe_add_lazy(s, x1, x2);
+    fe_sub_lazy<3>(x3, t, s); fe_carry(x3);                     // lambda^2 - x1 - x2
+    fe_sub_lazy<2>(t, x1, x3);
+    fe_mul(t, lam, t);
+    fe_sub_lazy<2>(y3, t, y1); fe_carry(y3);                    // lambda (x1 - x3) - y1
+}
+struct DirectRowSinkSync {                                       // host / single-lane builds: rows are stored by the lane that reads them back
+    PLUME_HD void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const { st_tab_entry(e, x, y, bx); }
+    PLUME_HD void sync() const {}
+};
+template <bool GUARD>
+PLUME_HD void tab_push(fe& acc, uint32_t* scr, size_t sstride, size_t slane, size_t q, fe d) {
+    if (GUARD) { if (fe_is_zero(d)) d = fe_small(1); }
+    pre_st(scr, sstride, slane, q, acc);
+    fe_mul(acc, acc, d);
+}
+PLUME_HD void tab_pop(fe& dinv, fe& inv, const uint32_t* scr, size_t sstride, size_t slane, size_t q, fe d, bool guard) {
+    fe pre;
+    if (guard) { if (fe_is_zero(d)) d = fe_small(1); }
+    pre_ld(pre, scr, sstride, slane, q);
+    fe_mul(dinv, inv, pre);
+    fe_mul(inv, inv, d);
+}
+// the base of a job as the chain sees it: affine (x, y) for Z = 1 bases, Jacobian otherwise; anything that is not a usable point becomes G
+PLUME_HD bool tab_base(jac& b, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t job) {
+    ld_jac_soa(b, bases, njobs, job);
+    b.inf = 0;
+    bool zone = (jobflags[job] & PLUME_JOB_AFFINE) != 0;
+    if (job_state(jobflags[job]) != PLUME_JOB_OK) { b.x = fe_gx(); b.y = fe_gy(); b.z = fe_small(1); zone = true; }
+    return zone;
+}
+// the denominators of level 2 (slots 4jj+4L.., pushed for jj descending) and level 3 (slots 4jj.., pushed for jj ascending) of one job
+template <bool GUARD>
+PLUME_HD void tab_push_l2(fe& acc, uint32_t* scr, size_t sstride, size_t slane, size_t q, const fe& x1, const fe& x2, const fe& y2) {
+    fe d;
+    fe_sub_lazy<2>(d, x2, x1); tab_push<GUARD>(acc, scr, sstride, slane, q, d);
+    fe_dbl_lazy(d, y2); tab_push<GUARD>(acc, scr, sstride, slane, q + 1, d);
+}
+template <bool GUARD>
+PLUME_HD void tab_push_l3(fe& acc, uint32_t* scr, size_t sstride, size_t slane, size_t q, const fe& x1, const fe& x3, const fe& y3, const fe& x4, const fe& y4) {
+    fe d;
+    fe_sub_lazy<2>(d, x4, x1); tab_push<GUARD>(acc, scr, sstride, slane, q, d);
+    fe_dbl_lazy(d, y3); tab_push<GUARD>(acc, scr, sstride, slane, q + 1, d);
+    fe_sub_lazy<2>(d, x4, x3); tab_push<GUARD>(acc, scr, sstride, slane, q + 2, d);
+    fe_dbl_lazy(d, y4); tab_push<GUARD>(acc, scr, sstride, slane, q + 3, d);
+}
+// Level k+1's denominators are formed -- and its prefix products accumulated -- inside level k's finishing pass, while the entries they come from are
+// still in registers: four passes over a lane's jobs instead of six, and no pass that only re-reads rows.  Consecutive levels therefore run through the
+// jobs in opposite directions (a level is finished in the reverse of the order its denominators were pushed in) and use alternating scratch regions.
+template <class RowSink = DirectRowSinkSync>
+PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
+                                 const RowSink& sink = RowSink()) {
+    const fe beta = fe_beta();
+    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
+    const size_t RB = 4 * (size_t)cnt;                           // second scratch region
+    fe acc, inv;
+    bool guard = false;
+    // ------------------------------------------------------------------------------- level 1, forward (jobs ascending): denominators of P -> affine, 2P
+    PLUME_NOUNROLL for (int pass = 0; pass < 2; pass++) {
+        acc = fe_small(1);
+        PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
+            jac b;
+            const bool zone = tab_base(b, bases, jobflags, njobs, j0 + (size_t)jj);
+            fe d;
+            if (!zone) { if (guard) tab_push<true>(acc, scr, sstride, slane, 4 * (size_t)jj, b.z); else tab_push<false>(acc, scr, sstride, slane, 4 * (size_t)jj, b.z); }
+            fe_dbl_lazy(d, b.y);
+            if (guard) tab_push<true>(acc, scr, sstride, slane, 4 * (size_t)jj + 1, d); else tab_push<false>(acc, scr, sstride, slane, 4 * (size_t)jj + 1, d);
+        }
+        if (guard || !fe_is_zero(acc)) break;
+        guard = true;                                            // unreachable for points of prime order: redo with zero denominators replaced by 1
+    }
+    fe_inv(inv, acc);
+    // ------------------------------------------------------------------------------- level 1, finish (jobs descending) + level 2's denominators
+    acc = fe_small(1);
+    PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
+        const size_t job = j0 + (size_t)jj;
+        jac b;
+        const bool zone = tab_base(b, bases, jobflags, njobs, job);
+        fe d, l, x1 = b.x, y1 = b.y;
+        fe_dbl_lazy(d, b.y);
+        tab_pop(l, inv, scr, sstride, slane, 4 * (size_t)jj + 1, d, guard);        // 1 / (2Y)
+        if (!zone) {
+            fe zi, z2, z3, zi2;
+            tab_pop(zi, inv, scr, sstride, slane, 4 * (size_t)jj, b.z, guard);     // 1 / Z
+            fe_sqr(z2, b.z); fe_mul(z3, z2, b.z); fe_mul(l, l, z3);                 // 1 / (2y) = Z^3 / (2Y)
+            fe_sqr(zi2, zi); fe_mul(x1, b.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y1, b.y, zi2);
+        }
+        fe x2, y2, bx;
+        aff_dbl(x2, y2, x1, y1, l);
+        uint32_t* t = tab + job * TW;
+        fe_mul_k(bx, beta, x1); sink(t, x1, y1, bx);
+        fe_mul_k(bx, beta, x2); sink(t + EW, x2, y2, bx);
+        tab_push_l2<false>(acc, scr, sstride, slane, RB + 4 * (size_t)jj, x1, x2, y2);
+    }
+    sink.sync();
+    if (guard || fe_is_zero(acc)) {                              // cold: the same pushes, from the rows, with the zero check
+        guard = true; acc = fe_small(1);
+        PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
+            const uint32_t* t = tab + (j0 + (size_t)jj) * TW;
+            fe x1, y1, x2, y2;
+            ld_tab_xy(x1, y1, t, false); ld_tab_xy(x2, y2, t + EW, false);
+            tab_push_l2<true>(acc, scr, sstride, slane, RB + 4 * (size_t)jj, x1, x2, y2);
+        }
+    }
+    fe_inv(inv, acc);
+    // ------------------------------------------------------------------------------- level 2, finish (jobs ascending): 4P, 3P + level 3's denominators
+    acc = fe_small(1);
+    PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
+        uint32_t* t = tab + (j0 + (size_t)jj) * TW;
+        fe x1, y1, x2, y2, d, l, x3, y3, x4, y4, bx;
+        ld_tab_xy(x1, y1, t, false); ld_tab_xy(x2, y2, t + EW, false);
+        fe_dbl_lazy(d, y2);
+        tab_pop(l, inv, scr, sstride, slane, RB + 4 * (size_t)jj + 1, d, guard);
+        aff_dbl(x4, y4, x2, y2, l);                                                 // 4P
+        fe_mul_k(bx, beta, x4); sink(t + 3 * EW, x4, y4, bx);
+        fe_sub_lazy<2>(d, x2, x1);
+        tab_pop(l, inv, scr, sstride, slane, RB + 4 * (size_t)jj, d, guard);
+        aff_add(x3, y3, x1, y1, x2, y2, l);                                         // 3P
+        fe_mul_k(bx, beta, x3); sink(t + 2 * EW, x3, y3, bx);
+        tab_push_l3<false>(acc, scr, sstride, slane, 4 * (size_t)jj, x1, x3, y3, x4, y4);
+    }
+    sink.sync();
+    if (guard || fe_is_zero(acc)) {
+        guard = true; acc = fe_small(1);
+        PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
+            const uint32_t* t = tab + (j0 + (size_t)jj) * TW;
+            fe x1, y1, x3, y3, x4, y4;
+            ld_tab_xy(x1, y1, t, false); ld_tab_xy(x3, y3, t + 2 * EW, false); ld_tab_xy(x4, y4, t + 3 * EW, false);
+            tab_push_l3<true>(acc, scr, sstride, slane, 4 * (size_t)jj, x1, x3, y3, x4, y4);
+        }
+    }
+    fe_inv(inv, acc);
+    // ------------------------------------------------------------------------------- level 3, finish (jobs descending): 8P, 7P, 6P, 5P
+    PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
+        uint32_t* t = tab + (j0 + (size_t)jj) * TW;
+        fe x1, y1, x3, y3, x4, y4, d, l, xr, yr, bx;
+        ld_tab_xy(x1, y1, t, false); ld_tab_xy(x3, y3, t + 2 * EW, false); ld_tab_xy(x4, y4, t + 3 * EW, false);
+        const size_t q = 4 * (size_t)jj;
+        fe_dbl_lazy(d, y4);
+        tab_pop(l, inv, scr, sstride, slane, q + 3, d, guard);
+        aff_dbl(xr, yr, x4, y4, l);                                                 // 8P
+        fe_mul_k(bx, beta, xr); sink(t + 7 * EW, xr, yr, bx);
+        fe_sub_lazy<2>(d, x4, x3);
+        tab_pop(l, inv, scr, sstride, slane, q + 2, d, guard);
+        aff_add(xr, yr, x3, y3, x4, y4, l);                                         // 7P
+        fe_mul_k(bx, beta, xr); sink(t + 6 * EW, xr, yr, bx);
+        fe_dbl_lazy(d, y3);
+        tab_pop(l, inv, scr, sstride, slane, q + 1, d, guard);
+        aff_dbl(xr, yr, x3, y3, l);                                                 // 6P
+        fe_mul_k(bx, beta, xr); sink(t + 5 * EW, xr, yr, bx);
+        fe_sub_lazy<2>(d, x4, x1);
+        tab_pop(l, inv, scr, sstride, slane, q, d, guard);
+        aff_add(xr, yr, x1, y1, x4, y4, l);                                         // 5P
+        fe_mul_k(bx, beta, xr); sink(t + 4 * EW, xr, yr, bx);
+    }
+}
+
 // ------------------------------------------------------------------------------------ batched affine conversion
 // Jacobian -> affine for the points of a SoA array, PLUME_NORM_K points per lane sharing ONE field inversion
 // (Montgomery's trick, prefix products kept in registers).  Lane `lane` of `nlanes` handles points lane + j*nlanes, so

@@ -60,10 +60,15 @@ __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
 #ifndef PLUME_TABLES_COOP_STORE
 #define PLUME_TABLES_COOP_STORE 1
 #endif
+#ifndef PLUME_TABLES_AFFINE
+#define PLUME_TABLES_AFFINE 1    // 1: affine chains with level-batched inversions (table_build_affine); 0: the round-1 Jacobian builder (A/B runs)
+#endif
 struct CoopRowSink {
     uint4* rows;             // this wavefront's 64 x 8 quads (quad index xor-swizzled by row against bank conflicts)
     uint32_t** ptrs;         // this wavefront's 64 row addresses
     bool full;               // wave-uniform: all 64 lanes build the same number of rows
+    // rows stored by OTHER lanes of the wavefront are read back by their owner in the next level of table_build_affine: order the wave's stores before its loads
+    __device__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     __device__ void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const {
         if (!full) { st_tab_entry(e, x, y, bx); return; }
         const uint32_t lane = threadIdx.x & 63u, sw = lane & 7u;
@@ -105,9 +110,17 @@ __global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* base
     sink.rows = s_rows + (threadIdx.x & ~63u) * 8;
     sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
     sink.full = __ballot(cnt == L) == ~0ull;
+#if PLUME_TABLES_AFFINE
+    if (cnt > 0) table_build_affine<CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane, sink);
+#else
     if (cnt > 0) table_build<PLUME_TAB_ENTRIES, CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane, sink);
+#endif
+#else
+#if PLUME_TABLES_AFFINE
+    if (cnt > 0) table_build_affine(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane);
 #else
     if (cnt > 0) table_build(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane);
+#endif
 #endif
 }
 
@@ -329,7 +342,11 @@ static inline unsigned nblocks(size_t n) { return (unsigned)((n + kBlock - 1) / 
 void launch_verify_ingest(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_ingest, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 size_t tables_scratch_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
+#if PLUME_TABLES_AFFINE
+    return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_AFF_SCR_WORDS * 4;          // prefix products of one level: 4 per job
+#else
     return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_ENTRIES * PLUME_TAB_SCR_WORDS * 4;
+#endif
 }
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st) {
     size_t lanes = (njobs + L - 1) / L;
