@@ -20,6 +20,9 @@ hazard nops inside a statement.  Host builds (tests/devsim) compile the same col
 """
 
 
+SQR_DIAG = "a.v[{i}]"   # second operand of the diagonal products of a squaring ("t3[{i}]" in fe_sqr3)
+
+
 def col_terms(k, sqr, pair=("a", "b")):
     t = []
     x, y = pair
@@ -32,7 +35,7 @@ def col_terms(k, sqr, pair=("a", "b")):
         elif i < j:
             t.append((f"a.v[{i}]", f"d[{j}]"))
         elif i == j:
-            t.append((f"a.v[{i}]", f"a.v[{i}]"))
+            t.append((f"a.v[{i}]", SQR_DIAG.format(i=i)))
     return t
 
 
@@ -65,7 +68,7 @@ def emit_chain(terms, indent="    ", acc="acc", carry=None):
     return (f"{indent}PLUME_FE_CHAIN({acc}, \"{body}\", {ins});\n", f"{indent}{host}\n")
 
 
-def gen(name, sqr, two=False):
+def gen(name, sqr, two=False, scale3=False, expose_d=False):
     """two: r = a*b + c*d with ONE fold -- the two products share their column sums (each column: two chain statements).
 
     Statement order: the high-half chain (columns 9..16, accumulator acch) and the low-half chain (columns 0..8, accumulator acc)
@@ -118,8 +121,13 @@ def gen(name, sqr, two=False):
             host.append(h)
 
     both("    uint32_t h[9], l[9];     // l: result limbs (r may alias a or b)\n    uint64_t acc = 0, acch = 0;\n")
-    if sqr:
+    if sqr and scale3:
+        # r = 3 a^2: the cross products take 6 a_j, the diagonal ones 3 a_i; the column sums are three times a squaring's (27 T^2 < 2^63 for tight a)
+        both("    uint32_t d[9], t3[9];\n    PLUME_UNROLL for (int i = 0; i < 9; i++) { t3[i] = a.v[i] + u32_dbl(a.v[i]); d[i] = u32_dbl(t3[i]); }\n")
+    elif sqr:
         both("    uint32_t d[9];\n    PLUME_UNROLL for (int i = 0; i < 9; i++) d[i] = u32_dbl(a.v[i]);\n")
+        if expose_d:
+            both("    PLUME_UNROLL for (int i = 0; i < 9; i++) dbl.v[i] = d[i];\n")
     # H9, mH9, H10, then per step j: L(j), mH(j+10), H(j+11), mL(j)
     put(stmts_high(9)); both(mask_high(9)); put(stmts_high(10))
     for j in range(0, 9):
@@ -146,6 +154,10 @@ def gen(name, sqr, two=False):
     both("    l[1] = (uint32_t)acc & PLUME_FE_MASK;\n    l[2] += (uint32_t)(acc >> 29) + (t1 << 3);\n    PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = l[i];\n")
     sig = f"PLUME_HD void {name}(fe& r, const fe& a)" if sqr else f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b)"
     check = "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, a));\n" if sqr else "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, b));\n"
+    if scale3:
+        check = "    PLUME_FE_ASSERT(fe_is_tight(a));\n"
+    if expose_d:
+        sig = f"// r = a^2, dbl = 2a: the doubled limbs the squaring forms anyway (group law: Z' = (2Y) Z); dbl must not alias a\nPLUME_HD void {name}(fe& r, fe& dbl, const fe& a)"
     if two:
         sig = f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b, const fe& c, const fe& e)"
         check = "    PLUME_FE_ASSERT(fe_muladd_inputs_ok(a, b, c, e));\n"
@@ -169,6 +181,12 @@ def main():
 """)
     print(gen("fe_mul", False))
     print(gen("fe_sqr", True))
+    print(gen("fe_sqr_d", True, expose_d=True))
+    global SQR_DIAG
+    SQR_DIAG = "t3[{i}]"
+    print("// r = 3 a^2 for a TIGHT a, tight result: the factor rides in the operands (group law: E = 3 X^2 without the tripling and its carry pass)")
+    print(gen("fe_sqr3", True, scale3=True))
+    SQR_DIAG = "a.v[{i}]"
     global A_CONS
     A_CONS_SAVE = A_CONS
     A_CONS = "v"

@@ -47,23 +47,22 @@ PLUME_HD bool affine_on_curve(const fe& x, const fe& y) {
 // (fe_add_lazy / fe_sub_lazy<M>) and spend a carry pass only where a bound would otherwise be exceeded; host builds with
 // PLUME_FE_CHECK assert every bound.
 //
-// 2P, a = 0:  A = X^2, B = Y^2, X' = (3A)^2 - 8XB, Y' = 3A(4XB - X') - 8B^2, Z' = 2YZ   (3M + 4S, 3 carry passes)
+// 2P, a = 0:  A = X^2, B = Y^2, X' = (3A)^2 - 8XB, Y' = 3A(4XB - X') - 8B^2, Z' = 2YZ   (3M + 4S, 2 carry passes)
 // valid for every non-infinity point (the curve has no 2-torsion); the inf flag just rides along.
 PLUME_HD void jac_dbl(jac& p) {
-    fe A, B2, C4, XB2, E, F, D2, D4, t;
-    fe_sqr(A, p.x);
-    fe_sqr(B2, p.y); fe_dbl_lazy(B2, B2);              // 2Y^2
+    fe B2, C4, XB2, E, F, D2, D4, t, dY;
+    fe_sqr3(E, p.x);                                       // 3X^2, tight: the factor rides in the squaring's operands (no tripling, no carry pass)
+    fe_sqr_d(B2, dY, p.y); fe_dbl_lazy(B2, B2);            // 2Y^2;  dY = 2Y comes out of the squaring
     fe_sqr(C4, B2);                                        // 4Y^4
     fe_mul(XB2, p.x, B2);                                  // 2XY^2
-    fe_mul(p.z, p.y, p.z); fe_dbl_lazy(p.z, p.z);     // Z' = 2YZ (unreduced double)
-    fe_add_lazy(E, A, A); fe_add_lazy(E, E, A); fe_carry(E);   // 3X^2
+    fe_mul(p.z, dY, p.z);                                  // Z' = 2YZ
     fe_sqr(F, E);
-    fe_dbl_lazy(D2, XB2);                             // 4XY^2
-    fe_dbl_lazy(D4, D2);                               // 8XY^2
+    fe_dbl_lazy(D2, XB2);                                  // 4XY^2
+    fe_dbl_lazy(D4, D2);                                   // 8XY^2
     fe_sub_lazy<5>(p.x, F, D4); fe_carry(p.x);             // X' = 9X^4 - 8XY^2
     fe_sub_lazy<2>(t, D2, p.x);                            // 4XY^2 - X'
     fe_mul(t, E, t);
-    fe_dbl_lazy(C4, C4);                               // 8Y^4
+    fe_dbl_lazy(C4, C4);                                   // 8Y^4
     fe_sub_lazy<3>(p.y, t, C4); fe_carry(p.y);
 }
 // cold path of the additions (P == Q).  Takes and returns BY VALUE through a local copy at the call site: passing the
@@ -406,9 +405,8 @@ PLUME_HD void pre_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, s
 #define PLUME_TAB_AFF_SCR_WORDS (8 * PLUME_FE_WORDS)       // prefix products per job: two regions (consecutive levels overlap) of at most 4 denominators
 // 2P from affine P = (x, y) (tight) and l = 1 / (2y)
 PLUME_HD void aff_dbl(fe& x3, fe& y3, const fe& x, const fe& y, const fe& l) {
-    fe a, lam, t, t2;
-    fe_sqr(a, x);
-    fe_add_lazy(t, a, a); fe_add_lazy(t, t, a);                 // 3x^2, unreduced
+    fe lam, t, t2;
+    fe_sqr3(t, x);                                              // 3x^2
     fe_mul(lam, t, l);
     fe_sqr(t, lam);
     fe_dbl_lazy(t2, x);
