@@ -67,6 +67,14 @@ def shard_bounds(total: int, rank: int, world: int):
     return (total * rank) // world, (total * (rank + 1)) // world
 
 
+def plan(scaling: str, log2_batch: int, world: int, rank: int):
+    """(items per step over all ranks, this rank's [start, stop)).  weak: every rank owns 2^log2_batch items; strong: 2^log2_batch items in total,
+    contiguous even split (BASELINE config 4 = strong, 2^22, V2)"""
+    total = (1 << log2_batch) * (world if scaling == "weak" else 1)
+    start, stop = shard_bounds(total, rank, world)
+    return total, start, stop
+
+
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json: FETCH_SIZE + WRITE_SIZE,
     separate --pmc runs of this same bench; raw counter values, see the file's _notes for the gfx950 calibration caveat), or None"""
@@ -253,8 +261,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     eng = plume.Engine(local_rank)
     ver = a.version
-    total = (1 << a.log2_batch) * (world if a.scaling == "weak" else 1)      # items per step over all ranks
-    start, stop = shard_bounds(total, rank, world)
+    total, start, stop = plan(a.scaling, a.log2_batch, world, rank)             # items per step over all ranks, this rank's slice
     n = stop - start                                                           # this rank's items per step
     eng.set_chunk(max(n, 1 << 20))
 

@@ -368,3 +368,25 @@ def test_sec1_der_scalar_marshalling(eng, kats):
     sg = eng.sign_batch(2, b["msgs"], b["off"], b["sk"], b["r"])
     der, st = eng.scalars_to_sec1_der_batch(b["sk"])
     assert not st.any() and np.array_equal(der[:, 45:109], sg["pk"]) and np.array_equal(der[:, 7:39], b["sk"])
+
+
+# ------------------------------------------------------------------------------- bench.py contract
+def test_bench_line_contract_on_a_small_preset():
+    """python bench.py --config 2 (2^16 V1 verify): one JSON line with the contract's keys, the binding roof in `roofline`, the HBM view beside it,
+    per-rank values; and the strong-scaling split of config 4's kind (V2) at a size that keeps the test short"""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    for extra, ver in ((["--config", "2"], 1), (["--scaling", "strong", "--log2-batch", "17", "--version", "2"], 2)):
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+        d = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "hbm_view",
+                  "per_rank", "stage_ms"):
+            assert k in d, k
+        assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "verifies/s" and d["vs_baseline"] is None and f"V{ver}" in d["metric"]
+        assert d["roofline"]["bound"] == "int-valu" and d["roofline"]["kernel"] == "k_verify_msm" and 0.05 < d["roofline"]["frac"] < 1.0
+        assert d["hbm_view"]["bound"] == "hbm" and d["hbm_view"]["frac"] < 0.05
+        assert abs(sum(d["per_rank"]["verifies_per_s"]) - d["value"]) / d["value"] < 1e-6
+        assert d["value"] > 1e6

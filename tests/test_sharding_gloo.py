@@ -56,3 +56,56 @@ def test_two_rank_even_split(tmp_path):
     if 37 % 16 == 5 and (37 // 16) % 4 == 2:
         want[37] = 1
     assert np.array_equal(ok, want)
+
+
+def test_bench_plans_weak_strong_and_config4():
+    """bench.py --scaling weak|strong and --config 4 (BASELINE.json configs[3]: 2^22 V2 verifies, even split): every rank's slice, for every world size the
+    driver uses, is contiguous, disjoint, covers the batch, and differs by at most one item between ranks"""
+    import bench
+    for world in (1, 2, 3, 4, 8):
+        for scaling, lg in (("weak", 20), ("strong", 20), ("strong", 22), ("strong", 16)):
+            plans = [bench.plan(scaling, lg, world, r) for r in range(world)]
+            total = plans[0][0]
+            assert total == (1 << lg) * (world if scaling == "weak" else 1) and all(p[0] == total for p in plans)
+            assert plans[0][1] == 0 and plans[-1][2] == total
+            assert all(plans[r][2] == plans[r + 1][1] for r in range(world - 1))
+            sizes = [p[2] - p[1] for p in plans]
+            assert max(sizes) - min(sizes) <= 1
+            if scaling == "weak":
+                assert sizes == [1 << lg] * world
+    assert [bench.plan("strong", 22, 8, r)[2] - bench.plan("strong", 22, 8, r)[1] for r in range(8)] == [1 << 19] * 8      # config 4 on 8 GPUs: 2^19 each
+
+    class A:  # the --config presets
+        pass
+    import sys
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--config", "4", "--gpus", "8"]
+        a = bench.parse()
+        assert (a.scaling, a.log2_batch, a.version, a.gpus) == ("strong", 22, 2, 8)
+        sys.argv = ["bench.py"]
+        a = bench.parse()
+        assert (a.scaling, a.log2_batch, a.version, a.gpus) == ("weak", 20, 1, 1)
+    finally:
+        sys.argv = old
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # bench.py's aggregation: MAX over ranks for the step time, all_gather for the per-rank report
+    mine = torch.tensor([1.0 + 0.25 * rank], dtype=torch.float64)
+    got = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(got, mine.clone())
+    tmax = mine.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        np.save(Path(out_dir) / "agg.npy", np.array([g.item() for g in got] + [tmax.item()]))
+    dist.destroy_process_group()
+
+
+def test_three_rank_timing_aggregation(tmp_path):
+    world = 3
+    mp.start_processes(_gather_worker, args=(world, 29613, str(tmp_path)), nprocs=world, start_method="fork")
+    agg = np.load(tmp_path / "agg.npy")
+    assert list(agg) == [1.0, 1.25, 1.5, 1.5]
