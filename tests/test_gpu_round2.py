@@ -390,3 +390,31 @@ def test_bench_line_contract_on_a_small_preset():
         assert d["hbm_view"]["bound"] == "hbm" and d["hbm_view"]["frac"] < 0.05
         assert abs(sum(d["per_rank"]["verifies_per_s"]) - d["value"]) / d["value"] < 1e-6
         assert d["value"] > 1e6
+
+
+def test_config4_v2_2p22_even_split_over_shards():
+    """BASELINE config 4 at its full size: 2^22 V2 verifies split evenly and contiguously over the shards of a multi-device context (this box has one GPU,
+    so the shards share it — the sharding code does not care), every item's verdict equal to the corruption pattern, a seeded sample equal to the C oracle,
+    and the single-device context agreeing byte for byte"""
+    import zk_nullifier_sig_amd as plume
+    n = 1 << 22
+    b = synth.sign_inputs(n)
+    m = plume.Engine([0, 0, 0, 0])
+    try:
+        sg = m.sign_batch(2, b["msgs"], b["off"], b["sk"], b["r"])
+        assert not sg["status"].any()
+        v = synth.corrupt_for_verify(2, b, sg)
+        ok = m.verify_batch(2, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"])
+    finally:
+        m.close()
+    assert np.array_equal(ok, synth.expected_ok(n))
+    idx = np.sort(np.random.default_rng(11).choice(n, size=2048, replace=False))
+    sub_msgs = np.concatenate([v["msgs"][32 * i:32 * i + 32] for i in idx] + [np.zeros(16, np.uint8)])
+    sub_off = np.arange(len(idx) + 1, dtype=np.uint64) * 32
+    want = OC.verify_batch(2, sub_msgs, sub_off, v["pk"][idx], v["nullifier"][idx], v["c"][idx], v["s"][idx], nthreads=16)
+    assert np.array_equal(ok[idx], want)
+    e = plume.Engine(0)
+    try:
+        assert np.array_equal(e.verify_batch(2, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"]), ok)
+    finally:
+        e.close()
