@@ -8,11 +8,12 @@ from tests import _oracle_c as OC, synth, _fuzz
 seed = int(os.environ.get("SEED", str(int(time.time()))))
 print("seed", seed)
 rng = random.Random(seed)
-eng = plume.Engine(0)
+engines = [plume.Engine(0), plume.Engine([0, 0]), plume.Engine([0, 0, 0])]     # single device, two and three shards on it
 bad = 0
 for rnd in range(int(os.environ.get("ROUNDS", "6"))):
     ver = 1 + rnd % 2
-    n = rng.choice([1, 63, 64, 65, 1000, 4097, 16384])
+    eng = engines[rnd % 3]
+    n = rng.choice([1, 63, 64, 65, 1000, 4097, 16384, 70001])
     b = synth.sign_inputs(n, start=rng.randrange(1 << 40))
     msgs = [bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 31, 32, 33, 55, 56, 64, 119, 120, 200]))) for _ in range(n)]
     mb, off = OC.pack_msgs(msgs)
@@ -27,7 +28,14 @@ for rnd in range(int(os.environ.get("ROUNDS", "6"))):
     wok = OC.verify_batch(*args, nthreads=32)
     if not np.array_equal(ok, wok):
         print("VERIFY MISMATCH", rnd, ver, n, np.nonzero(ok != wok)[0][:8]); bad += 1
-    print(f"round {rnd}: V{ver} n={n} ok ({int(wok.sum())} valid)")
+    z = _fuzz.fuzz_non_zk_batch(ver, want, dict(msgs=mb, off=off), seed=rng.randrange(1 << 30))
+    zargs = (ver, z["msgs"], z["off"], z["pk"], z["nullifier"], z["s"], z["r_point"], z["hashed_to_curve_r"], z["c"])
+    zok = eng.verify_non_zk_batch(*zargs)
+    zwok = OC.verify_non_zk_batch(*zargs, nthreads=32)
+    if not np.array_equal(zok, zwok):
+        print("NON_ZK MISMATCH", rnd, ver, n, np.nonzero(zok != zwok)[0][:8]); bad += 1
+    print(f"round {rnd}: V{ver} n={n} shards={eng.num_shards()} ok ({int(wok.sum())} valid, non-zk {int((zwok == 1).sum())} true / {int((zwok == 2).sum())} err)")
+eng = engines[0]
 for rnd in range(int(os.environ.get("DROUNDS", "20"))):
     n = rng.choice([1, 2, 64, 1000, 65536, 1 << 20])
     g = np.random.default_rng(rng.randrange(1 << 30))
