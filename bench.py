@@ -257,7 +257,8 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PLUME_BENCH_FORCE_DIST") == "1"   # the knob runs the RCCL code path at world size 1 (tests/test_gpu_round2.py)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
     eng = plume.Engine(local_rank)
     ver = a.version
@@ -283,7 +284,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -304,7 +305,7 @@ def main():
 
     tmax = torch.tensor([elapsed_rank], dtype=torch.float64, device=dev)
     per_rank = [elapsed_rank]
-    if world > 1:
+    if use_dist:
         gathered = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
         dist.all_gather(gathered, tmax.clone())
         per_rank = [float(g.item()) for g in gathered]
@@ -391,7 +392,7 @@ def main():
             except Exception as e:
                 line["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

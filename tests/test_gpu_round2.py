@@ -418,3 +418,19 @@ def test_config4_v2_2p22_even_split_over_shards():
         assert np.array_equal(e.verify_batch(2, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"]), ok)
     finally:
         e.close()
+
+
+def test_bench_under_torchrun_takes_the_rccl_path():
+    """the driver's launch line for N > 1 (python -m torch.distributed.run ... bench.py --gpus N) with N = 1 and the RCCL code path forced: process-group init on the
+    device, barrier, MAX, gather of the per-rank times -- everything the multi-GPU run uses except a second GPU"""
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PLUME_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29641",
+                        str(root / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--log2-batch", "16", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and len(d["per_rank"]["verifies_per_s"]) == 1 and d["value"] > 1e6
