@@ -49,7 +49,7 @@ def main():
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(rf"^_ZN\d*plume\d+{kernel}E.*:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith("\t.end_amdhsa_kernel") or lines[i].startswith(".Lfunc_end"))
-    blocks, cur, name = [], collections.Counter(), "entry"
+    blocks, cur, name, nfall = [], collections.Counter(), "entry", 0
     ops = collections.defaultdict(collections.Counter)
     for l in lines[start + 1:end]:
         m = re.match(r"^(\.LBB\d+_\d+):", l)
@@ -66,6 +66,10 @@ def main():
         c = classify(t)
         cur[c] += 1
         ops[name][t.split()[0]] += 1
+        if c == "branch":                      # a block ends at its branch: what follows a loop's back edge is a new (unnamed) block
+            blocks.append((name, cur))
+            nfall += 1
+            cur, name = collections.Counter(), f"{name}+{nfall}"
     blocks.append((name, cur))
     tot = collections.Counter()
     for _, c in blocks:

@@ -13,7 +13,12 @@ v_mad_u64_u32, and the carry into the next column is simply that chain's initial
     tail        bits >= 2^256 of column 8 fold as t*(2^32 + 977) into limbs 0..2; h[8]'s 2^8 part lands on column 9 = 2^261 again and
                 joins the tail: limb 0 += h[8]*(31264 << 8), limb 1 += h[8] << 16 (so the low half never waits for the last high column)
 
-103 multiply-adds + 16 v_lshrrev_b64 + 20 v_and_b32 per multiplication (squaring: 67 multiply-adds).  Each chain is ONE asm
+Round 2: the HIGH columns hand their excess on with one more multiply-add instead of a mask and a 64-bit shift -- h[k] is the column's low 32-bit register as it
+stands, the high register (weight 2^32 = 8 * 2^29 relative to the column) opens the next column's chain as `v_mad_u64_u32 acc, hi, 8, 0`, writing a fresh accumulator
+pair so that nothing is copied; 32-bit h[] are harmless because the fold multiplies them by 31264 and 256 only.  fe_sqr3 (3a^2) and fe_sqr_d (a^2 and 2a) ride factors
+in the squaring's operands for the group law's doubling.
+
+109 multiply-adds + 9 v_lshrrev_b64 + 12 v_and_b32 per multiplication (squaring: 73 multiply-adds; round 1: 103 + 16 + 20, squaring 67).  Each chain is ONE asm
 statement with compiler-allocated registers: hipcc keeps scheduling and register allocation but can neither re-associate the
 chain (that costs a 64-bit add per column) nor strength-reduce the fold constants into shift/add pairs, and it inserts no
 hazard nops inside a statement.  Host builds (tests/devsim) compile the same column algorithm as plain C++.
