@@ -111,13 +111,15 @@ __global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* base
     sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
     sink.full = __ballot(cnt == L) == ~0ull;
 #if PLUME_TABLES_AFFINE
-    if (cnt > 0) table_build_affine<CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane, sink);
+    // scratch interleaved across the lanes of THIS workgroup only (stride kBlock words): the words of one prefix product lie 1 KiB apart inside the workgroup's own
+    // region instead of (lanes x 4) bytes apart across the whole buffer -- same coalescing, but a wave's accesses stay within a few pages
+    if (cnt > 0) table_build_affine<CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kBlock), (size_t)kBlock, threadIdx.x, sink);
 #else
     if (cnt > 0) table_build<PLUME_TAB_ENTRIES, CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane, sink);
 #endif
 #else
 #if PLUME_TABLES_AFFINE
-    if (cnt > 0) table_build_affine(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane);
+    if (cnt > 0) table_build_affine(tab, bases, jobflags, njobs, j0, cnt, scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kBlock), (size_t)kBlock, threadIdx.x);
 #else
     if (cnt > 0) table_build(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane);
 #endif
