@@ -201,10 +201,10 @@ PLUME_HD int booth_digit(const uint32_t m[4], int i) {
 }
 // Booth recoding with a WIDE window for the generator's slots of the verifier: m = sum d_k 2^(W k), d_k in [-2^(W-1), 2^(W-1)].
 // W = PLUME_GW must be a multiple of 4 so that digit k lines up with the 4-bit window i = k * W/4 of the shared doubling chain.
-// W = 12: 11 digits per 128-bit half (22 generator additions per verify instead of 34 with W = 8) from a 2048-entry table
-// (256 KiB, L2-resident).
+// W = 12: 11 digits per 128-bit half (22 generator additions per verify instead of 34 with W = 8) from a 2048-entry table (256 KiB, L2-resident);
+// W = 16: 9 digits per half (18 additions) from 32768 entries (4 MiB: L2 / MALL), built once per context in ~0.2 s.
 #ifndef PLUME_GW
-#define PLUME_GW 12
+#define PLUME_GW 16   // round 2: 32768 entries (4 MiB), 9 digits per half: 18 generator additions per verify (W = 12: 2048 entries, 22 additions; measured -1.1 % on the kernel)
 #endif
 #define PLUME_GWS (PLUME_GW / 4)                          // 4-bit windows per wide digit
 #define PLUME_NDIGW ((128 + PLUME_GW) / PLUME_GW)         // digits covering 129 bits: 11 for W = 12, 17 for W = 8
@@ -234,7 +234,12 @@ PLUME_HD void booth_store_wide(int8_t* dig, uint32_t stride, const glv_half& h, 
         const int pos = PLUME_GWS * k;
         if (pos + 1 < PLUME_NDIG) {
             dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)(mag & 0xFF);
+#if PLUME_GW > 12   // magnitudes up to 2^(W-1) need the whole second byte: the sign moves to a third one (W >= 12 leaves room: W/4 >= 3 positions per digit)
+            dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)((mag >> 8) & 0xFF);
+            dig[(uint32_t)(pos + 2) * stride] = (int8_t)((mag != 0 && dn) ? 1 : 0);
+#else
             dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)(((mag >> 8) & 0xF) | ((mag != 0 && dn) ? 0x80 : 0));
+#endif
         } else {
             dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)((mag & 0x3F) | ((mag != 0 && dn) ? 0x40 : 0));
         }
@@ -678,7 +683,11 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
                 bool dn;
                 if (i + 1 < PLUME_NDIG) {
                     const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
+#if PLUME_GW > 12
+                    mag |= (hi & 0xFF) << 8; dn = dig[(uint32_t)(s * PLUME_NDIG + i + 2) * stride] != 0;
+#else
                     mag |= (hi & 0xF) << 8; dn = (hi & 0x80) != 0;
+#endif
                 } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
                 d = dn ? -mag : mag;
             }
