@@ -307,7 +307,7 @@ PLUME_HD uint32_t job_state(uint8_t f) { return f & 3u; }
 #define PLUME_GTAB_WORDS (PLUME_GTAB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 // the signer's doubling-free comb (below): 2^(W-1) entries per W-bit window
 #ifndef PLUME_COMB_W
-#define PLUME_COMB_W 11
+#define PLUME_COMB_W 14   // round 2: 19 windows x 8192 entries (19.9 MiB), 19 additions per multiplication (W = 11: 24 x 1024, 3 MiB, 24 additions); signer's comb kernel 2.31 -> 1.77 ms
 #endif
 #define PLUME_COMB_ENTRIES (1 << (PLUME_COMB_W - 1))
 #define PLUME_COMB_WINDOW_WORDS (PLUME_COMB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
@@ -619,7 +619,7 @@ PLUME_HD void normalize_points(uint32_t* pts, const uint8_t* inf, size_t npts, s
 
 // ------------------------------------------------------------------------------- fixed-base comb (generator only)
 // k*G with NO doublings: k = sum d_i 2^(W i) (Booth, d_i in [-2^(W-1), 2^(W-1)], i = 0..NW-1) and a precomputed table
-// comb[i][e] = (e+1) * 2^(W i) * G.  W = 11: 24 windows x 1024 entries (3 MiB, L2-resident), 24 mixed additions per
+// comb[i][e] = (e+1) * 2^(W i) * G.  W = 14: 19 windows x 8192 entries (19.9 MiB, read through L2 / MALL), 19 mixed additions per multiplication; W = 11: 24 windows x 1024 entries (3 MiB), 24 mixed additions per
 // multiplication (W = 8: 33 windows x 128 entries, 33 additions); used by the signer's pk = sk*G and R = r*G
 // (rust-k256/src/randomizedsigner.rs:51,53).
 #define PLUME_COMB_WINDOWS ((256 + PLUME_COMB_W) / PLUME_COMB_W)     // windows covering 257 bits
