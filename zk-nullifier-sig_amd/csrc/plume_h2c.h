@@ -161,16 +161,17 @@ PLUME_HD void iso3_frac_to_jac(jac& q, const fe& xn, const fe& xd, const fe& y) 
 
 // H = h2c(msg || enc(pk)) as a Jacobian point; enc: PLUME_ENC_POINT / PLUME_ENC_IDENTITY / PLUME_ENC_NONE
 PLUME_HD void hash_to_curve_jac(jac& h, const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag, uint32_t enc) {
-    fe u[2];
-    hash_to_field2(u[0], u[1], msg, mlen, pkx, tag, enc);
-    jac q[2];
+    fe u0, u1;
+    hash_to_field2(u0, u1, msg, mlen, pkx, tag, enc);
+    // one body for both maps (code size), but no arrays indexed by the loop counter: those would live in scratch memory (round 1: 288 B per lane)
     PLUME_NOUNROLL for (int i = 0; i < 2; i++) {
-        fe xn, xd, y;
-        sswu_frac(xn, xd, y, u[i]);
-        iso3_frac_to_jac(q[i], xn, xd, y);
+        fe u, xn, xd, y;
+        PLUME_UNROLL for (int k = 0; k < 9; k++) u.v[k] = i ? u1.v[k] : u0.v[k];
+        sswu_frac(xn, xd, y, u);
+        jac q;
+        iso3_frac_to_jac(q, xn, xd, y);
+        if (i == 0) h = q; else jac_add(h, q);
     }
-    h = q[0];
-    jac_add(h, q[1]);
 }
 
 }  // namespace plume
