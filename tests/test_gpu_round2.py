@@ -434,3 +434,28 @@ def test_bench_under_torchrun_takes_the_rccl_path():
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and len(d["per_rank"]["verifies_per_s"]) == 1 and d["value"] > 1e6
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_every_item_of_a_fuzzed_2p20_batch_vs_the_cpu(eng, ver):
+    """BASELINE's full size, EVERY item: 2^20 honest-then-mutated signatures (bit flips, garbage records, identities, boundary scalars, negated / foreign / swapped
+    points), ok[] compared item by item with the CPU — the optimised CPU leg (oracle/plume_cpu_fast.c), which tests/test_cpu_fast.py holds to the plain oracle's
+    verdicts and which is fast enough (≈12 k verifies/s per core) to do the whole batch; a 4096-item sample goes through the plain oracle as well"""
+    from tests import _cpu_fast as CF
+    import os
+    n = 1 << 20
+    b = synth.sign_inputs(n, start=5_000_000)
+    signed = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    v = _fuzz.fuzz_verify_batch(ver, signed, b, seed=90 + ver)
+    args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"] if ver == 1 else None, v["hashed_to_curve_r"] if ver == 1 else None)
+    got = eng.verify_batch(*args)
+    threads = min(64, os.cpu_count() or 1)
+    want = CF.verify_batch(*args, nthreads=threads)
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:10]
+    assert 0.2 * n < int(got.sum()) < 0.8 * n
+    idx = np.sort(np.random.default_rng(ver).choice(n, size=4096, replace=False))
+    sub_msgs = np.concatenate([v["msgs"][32 * i:32 * i + 32] for i in idx] + [np.zeros(16, np.uint8)])
+    sub_off = np.arange(len(idx) + 1, dtype=np.uint64) * 32
+    slow = OC.verify_batch(ver, sub_msgs, sub_off, v["pk"][idx], v["nullifier"][idx], v["c"][idx], v["s"][idx],
+                           v["r_point"][idx] if ver == 1 else None, v["hashed_to_curve_r"][idx] if ver == 1 else None, nthreads=threads)
+    assert np.array_equal(got[idx], slow)

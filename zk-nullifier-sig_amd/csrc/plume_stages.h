@@ -35,6 +35,17 @@ PLUME_HD uint32_t load_affine_be(fe& x, fe& y, const uint8_t* p) {
     if (!words_lt_p(wx) || !words_lt_p(wy)) return PLUME_JOB_INVALID;
     return affine_on_curve(x, y) ? PLUME_JOB_OK : PLUME_JOB_INVALID;
 }
+// the same record when an earlier stage of the same call has already validated it (the item would carry a reject flag otherwise): no curve equation
+PLUME_HD uint32_t reload_affine_be(fe& x, fe& y, const uint8_t* p) {
+    uint32_t wx[8], wy[8];
+    words_from_be_aligned(wx, p);
+    words_from_be_aligned(wy, p + 32);
+    fe_from_words(x, wx);
+    fe_from_words(y, wy);
+    uint32_t nz = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) nz |= wx[i] | wy[i];
+    return nz == 0 ? PLUME_JOB_INF : PLUME_JOB_OK;
+}
 PLUME_HD void store_affine_be(uint8_t* p, fe x, fe y, bool inf) {
     fe_normalize(x); fe_normalize(y);
     if (inf) { x = fe_zero(); y = fe_zero(); }
@@ -228,8 +239,8 @@ PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
         ld_jac_soa(rc, a.res, nt, 2 * (size_t)i); rc.inf = a.resinf[2 * (size_t)i];
         ld_jac_soa(hc, a.res, nt, 2 * (size_t)i + 1); hc.inf = a.resinf[2 * (size_t)i + 1];
         fe pkx, pky, nx, ny;
-        uint32_t fpk = load_affine_be(pkx, pky, a.pk + 64 * (size_t)i);
-        uint32_t fnul = load_affine_be(nx, ny, a.nul + 64 * (size_t)i);
+        uint32_t fpk = reload_affine_be(pkx, pky, a.pk + 64 * (size_t)i);     // validated by verify_ingest_h2c (itemflags == 0 here)
+        uint32_t fnul = reload_affine_be(nx, ny, a.nul + 64 * (size_t)i);
         sc c;
         sc_from_be_aligned(c, a.c + 32 * (size_t)i);
         uint32_t dg[8];
