@@ -193,6 +193,31 @@ int plume_sign_batch_sec1(plume_ctx* ctx, int version, size_t n,
 int plume_nullifier_first_occurrence(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live,
                                      const uint64_t* ids, uint8_t* first, uint64_t* n_unique);
 
+/* ---- aggregate pre-filter: one random-linear-combination check of the whole batch   ---------
+ * DIFFERENT SEMANTICS from the verify calls: all-or-nothing and probabilistic -- a fast way to learn that EVERY item of a batch would verify,
+ * never a replacement for the per-item `ok`.  It applies where r_point and hashed_to_curve_r are GIVEN: mode 0 = PlumeSignature::verify of V1
+ * signatures (rust-k256/src/lib.rs:93-135; version must be 1), mode 1 = verify_non_zk, V1 or V2 (rust-arkworks/src/tests.rs:28-78; `c` is
+ * digest_private).  Per item the inputs are validated and the challenge hash is checked EXACTLY (hash_ok); the two group equations
+ * s*G - c*pk == r_point and s*H - c*nullifier == hashed_to_curve_r are checked only in aggregate:
+ *     A = sum_i a_i (s_i G - c_i pk_i - R_i) + b_i (s_i H_i - c_i nul_i - Hr_i) == identity,
+ * one multi-scalar multiplication over 5n points (bucket method), with 127-bit coefficients a_i | b_i = SHA256(seed || be64(i)).  The
+ * producer of the batch must not be able to predict `seed` (draw 32 fresh random bytes per call): a batch holding a false equation then
+ * passes with probability <= 2^-126.  When the check fails, run the per-item verify to find the culprits.
+ *   seed    : 32 bytes, HOST pointer in both forms
+ *   hash_ok : out, optional, n bytes: 1 = the item's inputs are values of the reference's types and c equals the hash
+ *   result  : out, PLUME_AGG_RESULT_BYTES = 72 bytes:
+ *               [0] all_ok (n_bad == 0 and A is the identity)   [1] A is the identity   [2..4) zero   [4..8) n_bad, u32 little-endian
+ *               (items with hash_ok == 0; they take no part in A when their inputs are not representable)
+ *               [8..72) A as an affine point (x||y big-endian, zeros = identity) -- a pure function of the inputs and the seed, whatever
+ *               the piece / shard cut: tests compare it with the oracle's
+ * The multi-device context shards the batch; the shards' sums are added on the first shard's GPU. */
+#define PLUME_AGG_RESULT_BYTES 72
+int plume_aggregate_check(plume_ctx* ctx, int version, int mode, size_t n,
+                          const uint8_t* msgs, const uint64_t* msg_off,
+                          const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s,
+                          const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
+                          const uint8_t seed[32], uint8_t* hash_ok, uint8_t* result);
+
 /* ---- device-resident forms -------------------------------------------------------------------------------
  * Same semantics, but every data pointer is a DEVICE pointer on the context's GPU and the work is enqueued on
  * `stream` (a hipStream_t passed as void*; NULL = the context's own stream) without synchronising: the caller
@@ -239,6 +264,14 @@ int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n,
 /* n_unique, when not NULL, is a DEVICE pointer to one uint64_t */
 int plume_nullifier_first_occurrence_device(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live,
                                             const uint64_t* ids, uint8_t* first, uint64_t* n_unique, void* stream);
+
+/* index_base: coefficient index of item 0 (pieces of one batch checked by separate calls must use disjoint index ranges); hash_ok (optional) and
+ * result are DEVICE pointers, seed is a HOST pointer */
+int plume_aggregate_check_device(plume_ctx* ctx, int version, int mode, size_t n,
+                                 const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
+                                 const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s,
+                                 const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
+                                 const uint8_t seed[32], uint64_t index_base, uint8_t* hash_ok, uint8_t* result, void* stream);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------------------
  * Per-stage device time of the most recent *_device call on this context, measured with HIP events recorded on

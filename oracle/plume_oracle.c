@@ -595,6 +595,93 @@ int oracle_sign_batch(int version, size_t n, const uint8_t *msgs, const uint64_t
     run(&j, n, nthreads);
     return 0;
 }
+/* ---------------------------------------------------------------------------- aggregate check (NOT a reference function)
+ * SURVEY.md §8f rank 4's optional "aggregate-only random-linear-combination batch check".  The reference has no such function; what the oracle
+ * restates here is its DEFINITION (include/plume_hip.h, plume_aggregate_check), item by item on the reference-shaped arithmetic above:
+ *   an item whose inputs are not values of the reference's types (or, mode 1, whose pk is the identity) is "bad" and takes no part in the sum;
+ *   hash_ok = the challenge over the GIVEN encodings equals c (lib.rs:128-135 / tests.rs:40-52);
+ *   E1 = s*G - c*pk - r_point, E2 = s*H - c*nullifier - hashed_to_curve_r  (lib.rs:101,109,117,122 / tests.rs:55-70);
+ *   a | b = SHA256(seed || be64(index_base + i)), each half a big-endian 128-bit integer with its top bit cleared;
+ *   A = sum a*E1 + b*E2;   record = all_ok | A is identity | 0 | 0 | n_bad u32 LE | A affine (zeros = identity).
+ * mode 0: PlumeSignature::verify types (c, s in [1, n-1]); mode 1: verify_non_zk types (Fr elements, zero allowed). */
+typedef struct {
+    int version, mode; size_t lo, hi;
+    const uint8_t *msgs; const uint64_t *msg_off; const uint8_t *pk_b, *nul_b, *c_b, *s_b, *r_b, *hr_b, *seed; uint64_t index_base;
+    uint8_t *hash_ok; jac tot; uint32_t nbad;
+} agg_job;
+static void *agg_worker(void *arg) {
+    agg_job *J = (agg_job *)arg;
+    const int version = J->version, mode = J->mode;
+    jac tot; jac_set_inf(&tot);
+    uint32_t nbad = 0;
+    aff ga; ga.x = FE_GX; ga.y = FE_GY; ga.inf = 0;
+    jac g; jac_from_aff(&g, &ga);
+    for (size_t i = J->lo; i < J->hi; i++) {
+        aff pk, nul, rp, hrp, h;
+        sc c, s, cc;
+        int ok;
+        from_be32(c.l, J->c_b + 32 * i); from_be32(s.l, J->s_b + 32 * i);
+        if (mode == 0) ok = sc_from_be_nonzero(&c, J->c_b + 32 * i) && sc_from_be_nonzero(&s, J->s_b + 32 * i);
+        else ok = !ge256(c.l, N_) && !ge256(s.l, N_);
+        ok = ok && J->msg_off[i + 1] >= J->msg_off[i];
+        ok = ok && aff_from_bytes(&pk, J->pk_b + 64 * i) && aff_from_bytes(&nul, J->nul_b + 64 * i) && aff_from_bytes(&rp, J->r_b + 64 * i) && aff_from_bytes(&hrp, J->hr_b + 64 * i);
+        if (ok && mode == 1 && pk.inf) ok = 0;
+        if (!ok) { if (J->hash_ok) J->hash_ok[i] = 0; nbad++; continue; }
+        plume_h2c(&h, J->msgs + J->msg_off[i], (size_t)(J->msg_off[i + 1] - J->msg_off[i]), &pk);
+        uint8_t d[32]; int canon;
+        c_hash(d, version, &pk, &h, &nul, &rp, &hrp);
+        sc_from_digest(&cc, d, &canon);
+        const int hok = memcmp(cc.l, c.l, 32) == 0;
+        if (J->hash_ok) J->hash_ok[i] = (uint8_t)hok;
+        if (!hok) nbad++;
+        jac pkj, nulj, hj, rj, hrj, t1, t2, e1, e2;
+        jac_from_aff(&pkj, &pk); jac_from_aff(&nulj, &nul); jac_from_aff(&hj, &h); jac_from_aff(&rj, &rp); jac_from_aff(&hrj, &hrp);
+        jac_mul(&t1, &s, &g); jac_mul(&t2, &c, &pkj); jac_neg(&t2, &t2); jac_add(&e1, &t1, &t2); jac_neg(&rj, &rj); jac_add(&e1, &e1, &rj);
+        jac_mul(&t1, &s, &hj); jac_mul(&t2, &c, &nulj); jac_neg(&t2, &t2); jac_add(&e2, &t1, &t2); jac_neg(&hrj, &hrj); jac_add(&e2, &e2, &hrj);
+        uint8_t pre[40], dg[32];
+        memcpy(pre, J->seed, 32);
+        const uint64_t idx = J->index_base + (uint64_t)i;
+        for (int k = 0; k < 8; k++) pre[32 + k] = (uint8_t)(idx >> (8 * (7 - k)));
+        sha256_ctx sh; sha256_init(&sh); sha256_update(&sh, pre, 40); sha256_final(&sh, dg);
+        uint8_t ab[32]; sc a, b;
+        memset(ab, 0, 32); memcpy(ab + 16, dg, 16); ab[16] &= 0x7F; from_be32(a.l, ab);
+        memset(ab, 0, 32); memcpy(ab + 16, dg + 16, 16); ab[16] &= 0x7F; from_be32(b.l, ab);
+        jac_mul(&t1, &a, &e1); jac_add(&tot, &tot, &t1);
+        jac_mul(&t2, &b, &e2); jac_add(&tot, &tot, &t2);
+    }
+    J->tot = tot; J->nbad = nbad;
+    return 0;
+}
+/* nthreads only splits the item range; the partial sums are added in range order */
+int oracle_aggregate_check(int version, int mode, size_t n, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *pk_b, const uint8_t *nul_b,
+                           const uint8_t *c_b, const uint8_t *s_b, const uint8_t *r_b, const uint8_t *hr_b, const uint8_t seed[32], uint64_t index_base,
+                           uint8_t *hash_ok, uint8_t result[72], int nthreads) {
+    if ((version != 1 && version != 2) || (mode != 0 && mode != 1) || (mode == 0 && version != 1)) return -1;
+    init_consts();
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    agg_job *jobs = (agg_job *)malloc(sizeof(agg_job) * nthreads);
+    for (int t = 0; t < nthreads; t++) {
+        agg_job *J = &jobs[t];
+        J->version = version; J->mode = mode; J->lo = n * t / nthreads; J->hi = n * (t + 1) / nthreads;
+        J->msgs = msgs; J->msg_off = msg_off; J->pk_b = pk_b; J->nul_b = nul_b; J->c_b = c_b; J->s_b = s_b; J->r_b = r_b; J->hr_b = hr_b; J->seed = seed;
+        J->index_base = index_base; J->hash_ok = hash_ok;
+        if (t > 0) pthread_create(&th[t], 0, agg_worker, J);
+    }
+    agg_worker(&jobs[0]);
+    jac tot = jobs[0].tot;
+    uint32_t nbad = jobs[0].nbad;
+    for (int t = 1; t < nthreads; t++) { pthread_join(th[t], 0); jac_add(&tot, &tot, &jobs[t].tot); nbad += jobs[t].nbad; }
+    free(th); free(jobs);
+    aff ta; jac_to_aff(&ta, &tot);
+    memset(result, 0, 72);
+    result[0] = (uint8_t)(ta.inf && nbad == 0);
+    result[1] = (uint8_t)(ta.inf != 0);
+    result[4] = (uint8_t)nbad; result[5] = (uint8_t)(nbad >> 8); result[6] = (uint8_t)(nbad >> 16); result[7] = (uint8_t)(nbad >> 24);
+    aff_to_bytes(result + 8, &ta);
+    return 0;
+}
 int oracle_hash_to_curve_batch(size_t n, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *pk, uint8_t *h_out, int nthreads) {
     job j; memset(&j, 0, sizeof j);
     j.kind = 2; j.msgs = msgs; j.off = msg_off; j.a0 = pk; j.o0 = h_out;

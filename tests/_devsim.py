@@ -203,3 +203,24 @@ def nullifier_first_occurrence(nul, live=None, ids=None, order=None):
     order = None if order is None else np.ascontiguousarray(order, dtype=np.uint32)
     lib().ds_nullifier_first_occurrence(C.c_uint32(n), _p(buf), _p(live), _p(ids, u64p), _p(order, u32p), _p(first), C.byref(cnt))
     return first, int(cnt.value)
+
+
+def aggregate_check(version, mode, msgs_buf, msg_off, pk, nul, c, s, r_point, hr, seed: bytes, index_base=0, W=0, carry=None):
+    """plume_aggregate.h's per-lane bodies in the library's launch order; returns (record 72 B, hash_ok)"""
+    n = len(msg_off) - 1
+    hash_ok = np.full(n, 0xEE, dtype=np.uint8)
+    rec = np.zeros(72 + 8, dtype=np.uint8)[:72]
+    pk, nul, c, s, r_point, hr = map(_aligned, (pk, nul, c, s, r_point, hr))
+    sd = np.frombuffer(seed, dtype=np.uint8).copy()
+    cr = None if carry is None else _aligned(np.asarray(carry, dtype=np.uint8).copy())
+    rc = lib().ds_aggregate_check(C.c_int(version), C.c_int(mode), C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), _p(pk), _p(nul), _p(c), _p(s), _p(r_point), _p(hr),
+                                  _p(sd), C.c_uint64(index_base), C.c_int(W), _p(cr), _p(hash_ok), _p(rec))
+    assert rc == 0
+    return rec.copy(), hash_ok
+
+
+def aggregate_combine(records):
+    recs = _aligned(np.concatenate([np.asarray(r, dtype=np.uint8) for r in records]))
+    out = np.zeros(72, dtype=np.uint8)
+    lib().ds_aggregate_combine(_p(recs), C.c_uint32(len(records)), _p(out))
+    return out

@@ -109,3 +109,22 @@ def sha256(data: bytes):
 
 def arr(items, key, width):
     return np.frombuffer(b"".join(bytes.fromhex(it[key]) for it in items), dtype=np.uint8).reshape(len(items), width).copy()
+
+
+def aggregate_check(version, mode, msgs_buf, msg_off, pk, nul, c, s, r_point, hr, seed: bytes, index_base=0, nthreads=1):
+    """the DEFINITION of plume_aggregate_check (include/plume_hip.h), item by item; returns (record 72 B, hash_ok)"""
+    n = len(msg_off) - 1
+    hash_ok = np.full(n, 0xEE, dtype=np.uint8)
+    rec = np.zeros(72, dtype=np.uint8)
+    sd = np.frombuffer(seed, dtype=np.uint8).copy()
+    assert len(sd) == 32
+    lib().oracle_aggregate_check.restype = C.c_int
+    rc = lib().oracle_aggregate_check(C.c_int(version), C.c_int(mode), C.c_size_t(n), _p(msgs_buf), msg_off.ctypes.data_as(C.POINTER(C.c_uint64)), _p(pk), _p(nul), _p(c), _p(s),
+                                      _p(r_point), _p(hr), _p(sd), C.c_uint64(index_base), _p(hash_ok), _p(rec), C.c_int(nthreads))
+    assert rc == 0, rc
+    return rec, hash_ok
+
+
+def parse_aggregate_record(rec):
+    rec = np.asarray(rec, dtype=np.uint8)
+    return dict(all_ok=int(rec[0]), identity=int(rec[1]), n_bad=int.from_bytes(rec[4:8].tobytes(), "little"), point=rec[8:72].tobytes())

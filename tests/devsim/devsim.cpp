@@ -2,12 +2,14 @@
 // Compiles the product's device headers (zk-nullifier-sig_amd/csrc/plume_*.h) as plain host C++ and drives the
 // per-lane stage bodies with the same index mapping the HIP kernels use, so the exact device arithmetic and
 // pipeline logic can be checked against the oracle in a container without a GPU.
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "plume_stages.h"
+#include "plume_aggregate.h"
 #include "plume_dedup.h"
 
 using namespace plume;
@@ -109,6 +111,12 @@ static void build_gcomb(std::vector<uint32_t>& comb) {
     }
 }
 
+static const std::vector<uint32_t>& shared_gcomb() {
+    static std::vector<uint32_t> gcomb;
+    if (gcomb.empty()) build_gcomb(gcomb);
+    return gcomb;
+}
+
 // host stand-in for launch_tables: the same lane -> jobs mapping and the same lane-interleaved scratch indexing as k_tables
 static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L, stride = ((lanes + 7) / 8) * 8;     // "grid" rounded up like the kernel's
@@ -198,11 +206,129 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     return 0;
 }
 
+// The aggregate random-linear-combination check (plume_aggregate.h) through the same per-lane bodies and the same launch sequence as
+// aggregate_device in plume_capi.hip.  W = 0 picks the window width the library would; carry = the record of earlier pieces (or NULL).
+int ds_aggregate_check(int version, int mode, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c, const uint8_t* s,
+                       const uint8_t* rpt, const uint8_t* hr, const uint8_t* seed, uint64_t index_base, int W, const uint8_t* carry, uint8_t* hash_ok, uint8_t* result) {
+    if (version != 1 && version != 2) return -1;
+    AggArgs a; memset(&a, 0, sizeof a);
+    a.version = version; a.mode = mode; a.n = n;
+    if (W == 0) W = n >= (1u << 15) ? 16 : n >= 64 ? 8 : 4;
+    a.W = W; a.nw_long = (256 + W - 1) / W; a.nw_short = (128 + W - 1) / W; a.nbuckets = 1u << (W - 1); a.nkeys = (uint32_t)a.nw_long * a.nbuckets;
+    a.index_base = index_base; memcpy(a.seed, seed, 32);
+    const size_t nn = n ? n : 1, npairs = (size_t)n * (3 * a.nw_long + 2 * a.nw_short);
+    std::vector<uint32_t> bases(PLUME_JAC_WORDS * 3 * nn), scal((size_t)PLUME_AGG_TERMS * 8 * nn), gs(8 * nn, 0), count((size_t)a.nkeys + 1, 0), sorted(npairs + 1),
+        bsum((size_t)PLUME_JAC_WORDS * a.nkeys), nbad(4, 0);
+    std::vector<uint8_t> jobflags(3 * nn), itemflags(nn), haff(64 * nn + 16), flags(2 * nn), bsuminf(a.nkeys), hok(nn);
+    a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr;
+    a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
+    a.haff = haff.data(); a.scal = scal.data(); a.tlive = flags.data(); a.tneg = flags.data() + nn; a.gs = gs.data(); a.hash_ok = hash_ok ? hash_ok : hok.data(); a.nbad = nbad.data();
+    a.count = count.data(); a.sorted = sorted.data(); a.bsum = bsum.data(); a.bsuminf = bsuminf.data();
+    a.gcomb = shared_gcomb().data(); a.result = result;
+    if (n) {
+        VerifyArgs v; memset(&v, 0, sizeof v);
+        v.version = version; v.mode = mode; v.n = n; v.msgs = msgs; v.msg_off = msg_off; v.msgs_bytes = msg_off[n]; v.pk = pk; v.nul = nul; v.c = c; v.s = s; v.rpt = rpt; v.hr = hr;
+        v.bases = bases.data(); v.jobflags = jobflags.data(); v.itemflags = itemflags.data();
+        for (uint32_t i = 0; i < n; i++) verify_ingest_h2c(v, i);
+        const size_t nlanes = ((size_t)n + PLUME_AGG_NORM_K - 1) / PLUME_AGG_NORM_K;
+        for (size_t lane = 0; lane < nlanes; lane++) agg_normalize_h(a, lane, nlanes);
+        for (uint32_t i = 0; i < n; i++) agg_item_terms(a, i);
+        // the tiled counting sort; `tile` small so that several tiles and ragged last tiles occur, 3 cooperating lanes per workgroup
+        const uint32_t tile = n > 40 ? 17 : 5, ntiles = (n + tile - 1) / tile, T = 7, SL = 3;
+        std::vector<uint32_t> tiles((size_t)a.nw_long * ntiles * a.nbuckets, 0), bins(a.nbuckets), part(T);
+        for (uint32_t blk = 0; blk < (uint32_t)a.nw_long * ntiles; blk++) {
+            std::fill(bins.begin(), bins.end(), 0u);
+            for (uint32_t tid = 0; tid < SL; tid++) agg_tile_pairs<false>(a, blk / ntiles, blk % ntiles, tile, tid, SL, bins.data());
+            std::copy(bins.begin(), bins.end(), tiles.begin() + (size_t)blk * a.nbuckets);
+        }
+        for (uint32_t key = 0; key < a.nkeys; key++) agg_tile_totals(a, tiles.data(), ntiles, key);
+        {   // two-level scan as the kernels do it (T range lanes, T2 lanes over their sums)
+            const uint32_t T2 = 3;
+            std::vector<uint32_t> top(T2);
+            for (uint32_t t = 0; t < T; t++) agg_scan_phase0(a.count, a.nkeys + 1, t, T, part.data());
+            for (uint32_t t = 0; t < T2; t++) agg_scan_phase0(part.data(), T, t, T2, top.data());
+            agg_scan_mid(T2, top.data());
+            for (uint32_t t = 0; t < T2; t++) agg_scan_phase1(part.data(), T, t, T2, top.data());
+            for (uint32_t t = 0; t < T; t++) agg_scan_phase1(a.count, a.nkeys + 1, t, T, part.data());
+        }
+        for (uint32_t key = 0; key < a.nkeys; key++) agg_tile_offsets(a, tiles.data(), ntiles, key);
+        for (uint32_t blk = (uint32_t)a.nw_long * ntiles; blk-- > 0;) {     // any workgroup order
+            std::copy(tiles.begin() + (size_t)blk * a.nbuckets, tiles.begin() + (size_t)(blk + 1) * a.nbuckets, bins.begin());
+            for (uint32_t tid = SL; tid-- > 0;) agg_tile_pairs<true>(a, blk / ntiles, blk % ntiles, tile, tid, SL, bins.data());
+        }
+    }
+    // the windows in two groups, upper half first, as aggregate_device does (there the upper group's reduction runs on a second stream)
+    const uint32_t nlo = (uint32_t)a.nw_long / 2, nhi = (uint32_t)a.nw_long - nlo;
+    const uint32_t chunk = a.nbuckets < PLUME_AGG_CHUNK ? a.nbuckets : PLUME_AGG_CHUNK, m0 = (a.nbuckets + chunk - 1) / chunk;
+    std::vector<uint32_t> perm(a.nkeys, 0xFFFFFFFFu);
+    std::vector<uint32_t> red[4]; std::vector<uint8_t> rinf[4];
+    int cur[2] = {0, 0};
+    for (int grp = 1; grp >= 0; grp--) {
+        const uint32_t j0 = grp ? nlo : 0, nwin = grp ? nhi : nlo, k0 = j0 * a.nbuckets, k1 = (j0 + nwin) * a.nbuckets;
+        {   // keys by decreasing run length (3 workgroups of 2 lanes), then one lane per key in that order
+            const uint32_t PB = 3, PL = 2;
+            std::vector<uint32_t> hist((size_t)PB * PLUME_AGG_LEN_BINS, 0), bins(PLUME_AGG_LEN_BINS), part(PLUME_AGG_LEN_BINS);
+            for (uint32_t blk = 0; blk < PB; blk++) {
+                std::fill(bins.begin(), bins.end(), 0u);
+                for (uint32_t tid = 0; tid < PL; tid++) agg_perm_pairs<false>(a, k0, k1, blk, PB, tid, PL, bins.data(), perm.data());
+                std::copy(bins.begin(), bins.end(), hist.begin() + (size_t)blk * PLUME_AGG_LEN_BINS);
+            }
+            for (uint32_t bin = 0; bin < PLUME_AGG_LEN_BINS; bin++) agg_perm_phase0(hist.data(), PB, bin, part.data());
+            agg_perm_mid(part.data());
+            for (uint32_t bin = 0; bin < PLUME_AGG_LEN_BINS; bin++) agg_perm_phase1(hist.data(), PB, bin, part.data());
+            for (uint32_t blk = 0; blk < PB; blk++) {
+                std::copy(hist.begin() + (size_t)blk * PLUME_AGG_LEN_BINS, hist.begin() + (size_t)(blk + 1) * PLUME_AGG_LEN_BINS, bins.begin());
+                for (uint32_t tid = 0; tid < PL; tid++) agg_perm_pairs<true>(a, k0, k1, blk, PB, tid, PL, bins.data(), perm.data());
+            }
+            std::vector<uint8_t> seen(a.nkeys, 0);
+            uint32_t prev = 0xFFFFFFFFu;
+            for (uint32_t lane = k0; lane < k1; lane++) {
+                const uint32_t key = perm[lane];
+                if (key < k0 || key >= k1 || seen[key]) return -2;                // a permutation of the group's keys ...
+                seen[key] = 1;
+                const uint32_t bin = agg_len_bin(a, key);
+                if (bin > prev) return -3;                                        // ... by non-increasing length
+                prev = bin;
+                agg_bucket_sum(a, key);
+            }
+        }
+        uint32_t m = m0;
+        const size_t nred = (size_t)nwin * m;
+        for (int k = 0; k < 2; k++) { red[2 * grp + k].assign((size_t)PLUME_JAC_WORDS * nred, 0); rinf[2 * grp + k].assign(nred, 0); }
+        uint32_t** r = nullptr; (void)r;
+        for (uint32_t lane = 0; lane < nwin * m; lane++) agg_chunk_reduce(a, j0 + lane / m, lane % m, chunk, m, red[2 * grp].data(), rinf[2 * grp].data(), j0, nwin);
+        int c = 0;
+        while (m > 1) {
+            const uint32_t g = m < PLUME_AGG_GROUP ? m : PLUME_AGG_GROUP, mo = (m + g - 1) / g;
+            for (uint32_t lane = 0; lane < nwin * mo; lane++)
+                agg_group_sum(red[2 * grp + c].data(), rinf[2 * grp + c].data(), m, g, red[2 * grp + (c ^ 1)].data(), rinf[2 * grp + (c ^ 1)].data(), mo, nwin, lane / mo, lane % mo);
+            c ^= 1; m = mo;
+        }
+        for (uint32_t k = 0; k < nwin; k++) agg_window_shift(a, red[2 * grp + c].data(), rinf[2 * grp + c].data(), j0 + k, j0, nwin);
+        cur[grp] = c;
+    }
+    std::vector<uint32_t> sbuf[2];
+    const uint32_t* in = gs.data();
+    size_t nin = nn;
+    int sc = 0;
+    do {
+        const size_t nout = (nin + PLUME_AGG_SUM_K - 1) / PLUME_AGG_SUM_K;
+        sbuf[sc].assign(8 * nout, 0);
+        for (size_t lane = 0; lane < nout; lane++) agg_scalar_sum(in, nin, sbuf[sc].data(), nout, lane);
+        in = sbuf[sc].data(); nin = nout; sc ^= 1;
+    } while (nin > 1);
+    std::vector<uint32_t> gpt(PLUME_JAC_WORDS); uint8_t gptinf = 0;
+    agg_gterm(a, in, gpt.data(), &gptinf);
+    agg_final(a, red[cur[0]].data(), rinf[cur[0]].data(), nlo, red[2 + cur[1]].data(), rinf[2 + cur[1]].data(), nhi, gpt.data(), &gptinf, carry);
+    return 0;
+}
+void ds_aggregate_combine(const uint8_t* records, uint32_t m, uint8_t* result) { agg_combine(records, m, result); }
+
 int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,
                   uint8_t* pk, uint8_t* nul, uint8_t* c, uint8_t* s, uint8_t* rpt, uint8_t* hr, uint8_t* h_out, uint8_t* status, int L) {
     if (version != 1 && version != 2) return -1;
     std::vector<uint32_t> gtab; build_gtab(gtab);
-    static std::vector<uint32_t> gcomb; if (gcomb.empty()) build_gcomb(gcomb);
+    const std::vector<uint32_t>& gcomb = shared_gcomb();
     std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_JAC_WORDS * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
     std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(n), itemflags(n);
     SignArgs a; memset(&a, 0, sizeof a);
@@ -267,7 +393,7 @@ int ds_h2c_intermediates(uint32_t n, const uint8_t* msgs, const uint64_t* msg_of
     return 0;
 }
 int ds_scalars_to_der(uint32_t n, const uint8_t* scalars, uint8_t* der, uint8_t* status) {
-    static std::vector<uint32_t> gcomb; if (gcomb.empty()) build_gcomb(gcomb);
+    const std::vector<uint32_t>& gcomb = shared_gcomb();
     DerArgs a; a.n = n; a.scalars = scalars; a.der = der; a.status = status; a.gcomb = gcomb.data();
     for (uint32_t i = 0; i < n; i++) scalar_to_sec1_der(a, i);
     return 0;

@@ -87,13 +87,15 @@ def _load():
     lib.plume_scalars_to_sec1_der_batch_device.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.plume_sec1_der_to_scalars.argtypes = [sz, vp, vp, vp]
     lib.plume_registers_from_be_device.argtypes = [vp, sz, vp, vp, vp]
+    lib.plume_aggregate_check.argtypes = [vp, i, i, sz] + [vp] * 11
+    lib.plume_aggregate_check_device.argtypes = [vp, i, i, sz, vp, vp, sz] + [vp] * 7 + [C.c_uint64, vp, vp, vp]
     _lib = lib
     return lib
 
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
+    return ["plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
             "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
@@ -119,6 +121,15 @@ def _np(a, width, n, name):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+AGG_RESULT_BYTES = 72
+
+
+def parse_aggregate_record(rec):
+    """the 72-byte result of plume_aggregate_check (include/plume_hip.h)"""
+    rec = np.asarray(rec, dtype=np.uint8)
+    return dict(all_ok=bool(rec[0]), identity=bool(rec[1]), n_bad=int.from_bytes(rec[4:8].tobytes(), "little"), point=rec[8:72].tobytes())
 
 
 def registers_from_be(values):
@@ -253,6 +264,29 @@ class Engine:
                                                       _ptr(hashed_to_curve_r), _ptr(digest_private), _ptr(ok)), "plume_verify_non_zk_batch")
         return ok
 
+    def aggregate_check(self, version, msgs, msg_off, pk, nullifier, c, s, r_point, hashed_to_curve_r, seed=None, mode=0):
+        """Aggregate random-linear-combination pre-filter (include/plume_hip.h plume_aggregate_check): all-or-nothing and
+        probabilistic, never a replacement for verify_batch.  mode 0: PlumeSignature::verify of V1 signatures; mode 1: verify_non_zk (c = digest_private).
+        seed: 32 bytes the producer of the batch cannot predict (default: os.urandom).  Returns dict(all_ok, identity, n_bad, point, hash_ok, seed)."""
+        import os
+        n = len(msg_off) - 1
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
+        pk, nullifier, c, s = _np(pk, 64, n, "pk"), _np(nullifier, 64, n, "nullifier"), _np(c, 32, n, "c"), _np(s, 32, n, "s")
+        r_point, hashed_to_curve_r = _np(r_point, 64, n, "r_point"), _np(hashed_to_curve_r, 64, n, "hashed_to_curve_r")
+        seed = os.urandom(32) if seed is None else bytes(seed)
+        if len(seed) != 32:
+            raise ValueError("seed must be 32 bytes")
+        sd = np.frombuffer(seed, dtype=np.uint8).copy()
+        hash_ok = np.zeros(n, dtype=np.uint8)
+        rec = np.zeros(AGG_RESULT_BYTES, dtype=np.uint8)
+        self._chk(self._lib.plume_aggregate_check(self._ctx, int(version), int(mode), n, _ptr(msgs), _ptr(msg_off), _ptr(pk), _ptr(nullifier), _ptr(c), _ptr(s), _ptr(r_point),
+                                                  _ptr(hashed_to_curve_r), _ptr(sd), _ptr(hash_ok), _ptr(rec)), "plume_aggregate_check")
+        out = parse_aggregate_record(rec)
+        out["hash_ok"] = hash_ok
+        out["seed"] = seed
+        return out
+
     def verify_batch(self, version, msgs, msg_off, pk, nullifier, c, s, r_point=None, hashed_to_curve_r=None, out=None):
         n = len(msg_off) - 1
         msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
@@ -382,6 +416,15 @@ class Engine:
         d = self._dp
         self._chk(self._lib.plume_verify_non_zk_batch_device(self._ctx, int(version), int(n), d(msgs), d(msg_off), int(msgs_bytes), d(pk), d(nullifier), d(s), d(r_point),
                                                              d(hashed_to_curve_r), d(digest_private), d(ok), C.c_void_p(st)), "plume_verify_non_zk_batch_device")
+
+    def aggregate_check_device(self, version, mode, n, msgs, msg_off, msgs_bytes, pk, nullifier, c, s, r_point, hashed_to_curve_r, seed, index_base, hash_ok, result, stream=None):
+        """device tensors; seed: 32 host bytes; hash_ok: uint8[n] or None; result: uint8[72] (parse_aggregate_record after synchronising)"""
+        import torch
+        st = (stream or torch.cuda.current_stream(self.device_id)).cuda_stream
+        d = self._dp
+        sd = np.frombuffer(bytes(seed), dtype=np.uint8).copy()
+        self._chk(self._lib.plume_aggregate_check_device(self._ctx, int(version), int(mode), int(n), d(msgs), d(msg_off), int(msgs_bytes), d(pk), d(nullifier), d(c), d(s), d(r_point),
+                                                         d(hashed_to_curve_r), _ptr(sd), int(index_base), d(hash_ok), d(result), C.c_void_p(st)), "plume_aggregate_check_device")
 
     def verify_batch_sec1_device(self, version, n, msgs, msg_off, msgs_bytes, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, ok, stream=None):
         import torch

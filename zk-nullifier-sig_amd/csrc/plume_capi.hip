@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/plume_hip.h"
+#include "plume_agg_launch.h"
 #include "plume_launch.h"
 
 using namespace plume;
@@ -78,6 +79,8 @@ struct Worker {
 struct plume_ctx {
     int device = 0;
     hipStream_t stream = nullptr, up = nullptr, down = nullptr;   // kernels / host->HBM / HBM->host
+    hipStream_t side = nullptr;                                   // aggregate check: the generator term and the upper windows' reduction run beside the main stream
+    hipEvent_t agg_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // terms ready / upper bucket sums ready / generator term ready / upper windows reduced
     hipEvent_t ws_free = nullptr;     // recorded behind the last kernel of every device-resident call: the next call's stream waits on it before it
     bool ws_used = false;             // touches the per-context workspace, so calls on DIFFERENT streams of one context cannot race on that scratch
     size_t chunk = (size_t)1 << 20;
@@ -93,6 +96,8 @@ struct plume_ctx {
     bool jobs_per_lane_forced = false;
     DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink;
     DevBuf dec[4], preflags;
+    DevBuf agg[15];      // aggregate check (plume_aggregate.h): haff, scal, flags, gs, hash_ok, counters, count, sort tiles, sorted, bsum, bsuminf, red, redinf, ssum, perm + its histogram
+    DevBuf agg_record;   // the running record of a host-pointer aggregate call (pieces of one batch)
     DevBuf dslots, dminid, dmyslot, dcount, dblockcnt;   // nullifier-set post-processing (plume_dedup.h)   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
     StageTimer timer;
 };
@@ -123,9 +128,11 @@ static void destroy_single(plume_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->up) (void)hipStreamSynchronize(ctx->up);
     if (ctx->down) (void)hipStreamSynchronize(ctx->down);
+    if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
-                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
+                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
+    for (DevBuf& b : ctx->agg) b.release();
     for (HostSlot& sl : ctx->slot) {
         sl.msgs.release(); sl.off.release();
         for (DevBuf& b : sl.in) b.release();
@@ -137,6 +144,8 @@ static void destroy_single(plume_ctx* ctx) {
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->up) (void)hipStreamDestroy(ctx->up);
     if (ctx->down) (void)hipStreamDestroy(ctx->down);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    for (hipEvent_t e : ctx->agg_ev) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -151,6 +160,8 @@ static int init_single(plume_ctx* ctx) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->down, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    for (hipEvent_t& e : ctx->agg_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ws_free, hipEventDisableTiming));
     for (HostSlot& sl : ctx->slot) {
         HIPCHK(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
@@ -540,6 +551,101 @@ extern "C" int plume_registers_from_be_device(plume_ctx* ctx, size_t nvalues, co
     return 0;
 }
 
+// ------------------------------------------------------------------------------ aggregate check (plume_aggregate.h)
+// Window width.  Only widths that divide 256 keep EVERY window's digits spread over all its buckets (a scalar below 2^255 in 15-bit windows, say, leaves
+// a top window holding nothing but the Booth carry: one bucket would receive half of all terms, one lane would add them up); 16 bits from ~2^15 items
+// (the bucket count, 2^19, is then what the fixed reduction cost buys), 8 bits below, 4 for a handful.  The pre-filter is built for large batches.
+static int agg_window_bits(size_t n) { return n >= ((size_t)1 << 15) ? 16 : n >= 64 ? 8 : 4; }
+// carry: device pointer to the record of the pieces before this one (or null); result: device pointer, PLUME_AGG_RESULT_BYTES
+static int aggregate_device(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk, const uint8_t* nul,
+                            const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, const uint8_t seed[32], uint64_t index_base, uint8_t* hash_ok,
+                            const uint8_t* carry, uint8_t* result, hipStream_t st) {
+    if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    if (int rc = ws_acquire(ctx, st)) return rc;
+    AggArgs a;
+    memset(&a, 0, sizeof a);
+    a.version = version; a.mode = mode; a.n = (uint32_t)n;
+    a.W = agg_window_bits(n);
+    a.nw_long = (256 + a.W - 1) / a.W; a.nw_short = (128 + a.W - 1) / a.W;
+    a.nbuckets = 1u << (a.W - 1); a.nkeys = (uint32_t)a.nw_long * a.nbuckets;
+    a.index_base = index_base;
+    memcpy(a.seed, seed, 32);
+    // the windows go in two groups: the upper half (only the three long scalars reach it) is summed first, and while the lower half is summed on the
+    // caller's stream the upper half's reduction -- a chain of small kernels ending in up to W*(nw-1) serial doublings -- runs beside it on ctx->side, as
+    // does the generator term; the caller's stream picks both up before the last kernel
+    const uint32_t nlo = (uint32_t)a.nw_long / 2, nhi = (uint32_t)a.nw_long - nlo;
+    const size_t npairs = n * (size_t)(3 * a.nw_long + 2 * a.nw_short), nred = agg_reduce_points(a, nhi), sw = agg_scalar_sum_words(n ? n : 1);
+    DevBuf* B = ctx->agg;
+    if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * 3 * n + 16) || ctx->jobflags.ensure(3 * n + 16) || ctx->itemflags.ensure(n + 16) ||
+        B[0].ensure(64 * n + 16) || B[1].ensure((size_t)PLUME_AGG_TERMS * 32 * n + 16) || B[2].ensure(2 * n + 16) || B[3].ensure(32 * n + 32) || B[4].ensure(n + 16) ||
+        B[5].ensure(16 + 4 * (size_t)kAggScanLanes) || B[6].ensure(((size_t)a.nkeys + 1) * 4) || B[7].ensure(agg_sort_tile_words(a) * 4) || B[8].ensure(npairs * 4 + 16) ||
+        B[9].ensure((size_t)PLUME_JAC_WORDS * 4 * a.nkeys) || B[10].ensure(a.nkeys) || B[11].ensure(4 * (size_t)PLUME_JAC_WORDS * 4 * nred) || B[12].ensure(4 * nred) ||
+        B[13].ensure((2 * sw + PLUME_JAC_WORDS + 4) * 4) || B[14].ensure(((size_t)a.nkeys + 2 * (size_t)kAggPermBlocks * PLUME_AGG_LEN_BINS) * 4))
+        return PLUME_ERR_HIP;
+    a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr;
+    a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>(); a.itemflags = ctx->itemflags.as<uint8_t>();
+    a.haff = B[0].as<uint8_t>(); a.scal = B[1].as<uint32_t>(); a.tlive = B[2].as<uint8_t>(); a.tneg = B[2].as<uint8_t>() + n; a.gs = B[3].as<uint32_t>();
+    a.hash_ok = hash_ok ? hash_ok : B[4].as<uint8_t>(); a.nbad = B[5].as<uint32_t>();
+    a.count = B[6].as<uint32_t>(); a.sorted = B[8].as<uint32_t>(); a.bsum = B[9].as<uint32_t>(); a.bsuminf = B[10].as<uint8_t>();
+    a.gcomb = ctx->gcomb.as<uint32_t>(); a.result = result;
+    uint32_t* red[4]; uint8_t* rinf[4];                     // lower group: 0, 1; upper group: 2, 3
+    for (int k = 0; k < 4; k++) { red[k] = B[11].as<uint32_t>() + (size_t)k * PLUME_JAC_WORDS * nred; rinf[k] = B[12].as<uint8_t>() + (size_t)k * nred; }
+    uint32_t* gpt = B[13].as<uint32_t>() + 2 * sw; uint8_t* gptinf = (uint8_t*)(gpt + PLUME_JAC_WORDS);
+    uint32_t* perm = B[14].as<uint32_t>(); uint32_t* hist = perm + a.nkeys;
+    hipStream_t side = ctx->side;
+    StageTimer& t = ctx->timer;
+    t.begin(st);
+    HIPCHK(hipMemsetAsync(a.nbad, 0, 16, st));
+    HIPCHK(hipMemsetAsync(a.count, 0, ((size_t)a.nkeys + 1) * 4, st));
+    if (n) {
+        VerifyArgs v;
+        memset(&v, 0, sizeof v);
+        v.version = version; v.mode = mode; v.n = (uint32_t)n; v.msgs = msgs; v.msg_off = msg_off; v.msgs_bytes = msgs_bytes; v.pk = pk; v.nul = nul; v.c = c; v.s = s; v.rpt = rpt; v.hr = hr;
+        v.bases = ctx->bases.as<uint32_t>(); v.jobflags = ctx->jobflags.as<uint8_t>(); v.itemflags = ctx->itemflags.as<uint8_t>();
+        launch_verify_ingest(v, st); t.stage("verify_ingest_h2c", st);
+        launch_agg_normalize_h(a, st); t.stage("agg_h_affine", st);
+        launch_agg_item_terms(a, st); t.stage("agg_item_terms", st);
+    } else {
+        HIPCHK(hipMemsetAsync(a.gs, 0, 32, st));
+    }
+    HIPCHK(hipEventRecord(ctx->agg_ev[0], st));
+    HIPCHK(hipStreamWaitEvent(side, ctx->agg_ev[0], 0));
+    const uint32_t* gsum = launch_agg_scalar_sum(a.gs, n ? n : 1, B[13].as<uint32_t>(), B[13].as<uint32_t>() + sw, side);
+    launch_agg_gterm(a, gsum, gpt, gptinf, side);
+    HIPCHK(hipEventRecord(ctx->agg_ev[2], side));
+    if (n) { launch_agg_sort(a, B[7].as<uint32_t>(), B[5].as<uint32_t>() + 4, st); t.stage("agg_bucket_sort", st); }
+    launch_agg_bucket_sum(a, nlo, nhi, perm, hist, st); t.stage("agg_bucket_sum_upper", st);
+    HIPCHK(hipEventRecord(ctx->agg_ev[1], st));
+    HIPCHK(hipStreamWaitEvent(side, ctx->agg_ev[1], 0));
+    const int chi = launch_agg_reduce(a, nlo, nhi, red[2], rinf[2], red[3], rinf[3], side);
+    HIPCHK(hipEventRecord(ctx->agg_ev[3], side));
+    launch_agg_bucket_sum(a, 0, nlo, perm, hist + (size_t)kAggPermBlocks * PLUME_AGG_LEN_BINS, st); t.stage("agg_bucket_sum_lower", st);
+    const int clo = launch_agg_reduce(a, 0, nlo, red[0], rinf[0], red[1], rinf[1], st);
+    HIPCHK(hipStreamWaitEvent(st, ctx->agg_ev[2], 0));
+    HIPCHK(hipStreamWaitEvent(st, ctx->agg_ev[3], 0));
+    launch_agg_final(a, red[clo], rinf[clo], nlo, red[2 + chi], rinf[2 + chi], nhi, gpt, gptinf, carry, st); t.stage("agg_reduce", st);
+    HIPCHK(hipGetLastError());
+    return ws_release(ctx, st);
+}
+
+static int agg_args_ok(int version, int mode, size_t n, const void* msgs, const void* off, const void* seed) {
+    if (int rc = args_ok(version, n, msgs, off)) return rc;
+    if (mode != PLUME_MODE_VERIFY && mode != PLUME_MODE_NON_ZK) return fail(PLUME_ERR_ARG, "mode must be 0 (verify) or 1 (verify_non_zk)");
+    if (mode == PLUME_MODE_VERIFY && version != 1) return fail(PLUME_ERR_ARG, "the aggregate check needs the GIVEN r_point / hashed_to_curve_r: V1 verify, or verify_non_zk");
+    if (!seed) return fail(PLUME_ERR_ARG, "null seed");
+    return 0;
+}
+
+extern "C" int plume_aggregate_check_device(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
+                                            const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
+                                            const uint8_t seed[32], uint64_t index_base, uint8_t* hash_ok, uint8_t* result, void* stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = agg_args_ok(version, mode, n, msgs, msg_off, seed)) return rc;
+    if (!result || (n && (!pk || !nullifier || !c || !s || !r_point || !hashed_to_curve_r))) return fail(PLUME_ERR_ARG, "null array");
+    return aggregate_device(ctx, version, mode, n, msgs, msg_off, msgs_bytes, pk, nullifier, c, s, r_point, hashed_to_curve_r, seed, index_base, hash_ok, nullptr, result,
+                            stream ? (hipStream_t)stream : ctx->stream);
+}
+
 // ------------------------------------------------------------------------------ nullifier-set post-processing
 static int dedup_device(plume_ctx* ctx, size_t n, const uint8_t* nul, const uint8_t* live, const uint64_t* ids, uint8_t* first, uint64_t* n_unique_dev, hipStream_t st) {
     if (n == 0) { if (n_unique_dev) HIPCHK(hipMemsetAsync(n_unique_dev, 0, 8, st)); return 0; }
@@ -766,6 +872,74 @@ extern "C" int plume_verify_non_zk_batch(plume_ctx* ctx, int version, size_t n, 
                                          const uint8_t* nullifier, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
                                          const uint8_t* digest_private, uint8_t* ok) {
     return verify_host_any(ctx, version, PLUME_MODE_NON_ZK, false, n, msgs, msg_off, pk, nullifier, digest_private, s, r_point, hashed_to_curve_r, ok);
+}
+
+// aggregate check over host arrays: the pieces of the batch run through the same three-stream pipeline; every piece adds its sum to the running
+// record kept in HBM (coefficients are indexed by the item's position in the WHOLE batch, so the record does not depend on how the batch was cut)
+static int aggregate_host(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nullifier,
+                          const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r, const uint8_t* seed, uint64_t index_base,
+                          uint8_t* hash_ok, uint8_t* record) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->agg_record.ensure(PLUME_AGG_RESULT_BYTES)) return PLUME_ERR_HIP;
+    uint8_t* rec = ctx->agg_record.as<uint8_t>();
+    ScopedPins pins;
+    pins.add(ctx, msgs + msg_off[0], (size_t)(msg_off[n] - msg_off[0]));
+    pins.add(ctx, pk, 64 * n); pins.add(ctx, nullifier, 64 * n); pins.add(ctx, c, 32 * n); pins.add(ctx, s, 32 * n); pins.add(ctx, r_point, 64 * n); pins.add(ctx, hashed_to_curve_r, 64 * n);
+    size_t done = 0;
+    int rc = host_pipeline(
+        ctx, n, false,
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
+            if (int r = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return r;
+            if (int r = h2d(ctx, sl.in[0], pk + 64 * i0, 64 * cnt)) return r;
+            if (int r = h2d(ctx, sl.in[1], nullifier + 64 * i0, 64 * cnt)) return r;
+            if (int r = h2d(ctx, sl.in[2], c + 32 * i0, 32 * cnt)) return r;
+            if (int r = h2d(ctx, sl.in[3], s + 32 * i0, 32 * cnt)) return r;
+            if (int r = h2d(ctx, sl.in[4], r_point + 64 * i0, 64 * cnt)) return r;
+            if (int r = h2d(ctx, sl.in[5], hashed_to_curve_r + 64 * i0, 64 * cnt)) return r;
+            return sl.out[0].ensure(cnt);
+        },
+        [&](HostSlot& sl, size_t cnt) -> int {
+            const int r = aggregate_device(ctx, version, mode, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
+                                           sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), sl.in[4].as<uint8_t>(), sl.in[5].as<uint8_t>(), seed, index_base + done, sl.out[0].as<uint8_t>(),
+                                           done ? rec : nullptr, rec, ctx->stream);
+            done += cnt;
+            return r;
+        },
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return hash_ok ? d2h(ctx, hash_ok + i0, sl.out[0], cnt) : 0; });
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(record, rec, PLUME_AGG_RESULT_BYTES, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int plume_aggregate_check(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nullifier,
+                                     const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r, const uint8_t seed[32], uint8_t* hash_ok,
+                                     uint8_t* result) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "null context");
+    if (int rc = agg_args_ok(version, mode, n, msgs, msg_off, seed)) return rc;
+    if (!result || (n && (!pk || !nullifier || !c || !s || !r_point || !hashed_to_curve_r))) return fail(PLUME_ERR_ARG, "null array");
+    if (n == 0) { memset(result, 0, PLUME_AGG_RESULT_BYTES); result[0] = result[1] = 1; return 0; }
+    if (ctx->shards.empty()) return aggregate_host(ctx, version, mode, n, msgs, msg_off, pk, nullifier, c, s, r_point, hashed_to_curve_r, seed, 0, hash_ok, result);
+    const size_t g = ctx->shards.size();
+    std::vector<uint8_t> records(PLUME_AGG_RESULT_BYTES * g, 0);       // an empty shard leaves zeros: the identity, no bad item
+    uint8_t* recs = records.data();
+    plume_ctx* const* shards = ctx->shards.data();
+    int rc = for_shards(ctx, n, [=](plume_ctx* sh, size_t lo, size_t hi) -> int {
+        size_t d = 0;
+        while (shards[d] != sh) d++;
+        return aggregate_host(sh, version, mode, hi - lo, msgs, msg_off + lo, pk + 64 * lo, nullifier + 64 * lo, c + 32 * lo, s + 32 * lo, r_point + 64 * lo,
+                              hashed_to_curve_r + 64 * lo, seed, (uint64_t)lo, hash_ok ? hash_ok + lo : nullptr, recs + PLUME_AGG_RESULT_BYTES * d);
+    });
+    if (rc) return rc;
+    // the shards' records are added up on the first shard's GPU
+    plume_ctx* sh0 = ctx->shards[0];
+    HIPCHK(hipSetDevice(sh0->device));
+    if (sh0->agg_record.ensure(PLUME_AGG_RESULT_BYTES) || sh0->sink.ensure(PLUME_AGG_RESULT_BYTES * g)) return PLUME_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(sh0->sink.p, recs, PLUME_AGG_RESULT_BYTES * g, hipMemcpyHostToDevice, sh0->stream));
+    launch_agg_combine(sh0->sink.as<uint8_t>(), (uint32_t)g, sh0->agg_record.as<uint8_t>(), sh0->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(result, sh0->agg_record.p, PLUME_AGG_RESULT_BYTES, hipMemcpyDeviceToHost, sh0->stream));
+    HIPCHK(hipStreamSynchronize(sh0->stream));
+    return 0;
 }
 
 static int sign_host(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
