@@ -223,6 +223,15 @@ def extras(eng, dev, n, b, signed_v1):
         dt = timed(lambda: eng.verify_batch_sec1_device(1, n, msgs, off, mbytes, c33["pk"], c33["nullifier"], cc, ss, c33["r_point"], c33["hashed_to_curve_r"], ok))
         assert bool(ok.all())
         out["verify_v1_sec1_compressed"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
+    # aggregate random-linear-combination pre-filter over the V1 batch (all-or-nothing, probabilistic -- NOT the headline metric's semantics)
+    if signed_v1 is not None:
+        s1 = {k: t(signed_v1[k]) for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+        rec = torch.zeros(72, dtype=torch.uint8, device=dev)
+        seed = os.urandom(32)
+        dt = timed(lambda: eng.aggregate_check_device(1, 0, n, msgs, off, mbytes, s1["pk"], s1["nullifier"], s1["c"], s1["s"], s1["r_point"], s1["hashed_to_curve_r"], seed, 0, None, rec), reps=3)
+        assert int(rec[0].item()) == 1
+        out["aggregate_check_v1"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()},
+                                     "semantics": "all-or-nothing pre-filter: exact per-item hash check + one 5n-point multi-scalar multiplication (bucket method, 16-bit windows)"}
     # nullifier-set post-processing on the nullifiers just produced: first occurrences among 2^20 records, 1/16 of them
     # made repeats of an earlier item; HBM view = 66 algorithmic bytes per item (64-byte record + live flag in, first flag out)
     nul = o["nullifier"].clone()

@@ -78,6 +78,8 @@ extern "C" {
     fn plume_sign_batch(ctx: *mut plume_ctx, version: c_int, n: usize, msgs: *const u8, msg_off: *const u64, sk: *const u8, r: *const u8, pk_in: *const u8,
         pk: *mut u8, nullifier: *mut u8, c: *mut u8, s: *mut u8, r_point: *mut u8, hashed_to_curve_r: *mut u8, status: *mut u8) -> c_int;
     fn plume_scalars_to_sec1_der_batch(ctx: *mut plume_ctx, n: usize, scalars: *const u8, der109: *mut u8, status: *mut u8) -> c_int;
+    fn plume_aggregate_check(ctx: *mut plume_ctx, version: c_int, mode: c_int, n: usize, msgs: *const u8, msg_off: *const u64, pk: *const u8, nullifier: *const u8, c: *const u8,
+                             s: *const u8, r_point: *const u8, hashed_to_curve_r: *const u8, seed: *const u8, hash_ok: *mut u8, result: *mut u8) -> c_int;
 }
 
 fn last_error() -> HipError { HipError(unsafe { std::ffi::CStr::from_ptr(plume_last_error()) }.to_string_lossy().into_owned()) }
@@ -145,6 +147,20 @@ impl HipEngine {
                                              p.s.as_ptr(), if p.v1 { p.rp.as_ptr() } else { null }, if p.v1 { p.hr.as_ptr() } else { null }, ok.as_mut_ptr()) };
         if rc != 0 { return Err(last_error()); }
         Ok(ok.into_iter().map(|b| b == 1).collect())
+    }
+
+    /// Aggregate pre-filter (no reference counterpart; include/plume_hip.h `plume_aggregate_check`): `Ok(true)` iff every V1 signature of the batch would
+    /// `verify()` — up to a false-accept probability of 2^-126 over `seed`, which must be 32 fresh random bytes the signers could not predict.  All-or-nothing:
+    /// on `Ok(false)` call `verify_batch` to find the culprits.  Per item the challenge hash is checked exactly; the two group equations (lib.rs:101,109,117,122)
+    /// only in one random linear combination (a single 5n-point multi-scalar multiplication on the GPU).
+    pub fn aggregate_check_v1(&self, sigs: &[PlumeSignature], seed: &[u8; 32]) -> Result<bool, HipError> {
+        let p = pack(sigs);
+        assert!(p.v1 || sigs.is_empty(), "the aggregate check needs the V1 fields r_point / hashed_to_curve_r");
+        let mut rec = [0u8; 72];
+        let rc = unsafe { plume_aggregate_check(self.0, 1, 0, sigs.len(), p.msgs.as_ptr(), p.off.as_ptr(), p.pk.as_ptr(), p.nul.as_ptr(), p.c.as_ptr(), p.s.as_ptr(),
+                                                p.rp.as_ptr(), p.hr.as_ptr(), seed.as_ptr(), std::ptr::null_mut(), rec.as_mut_ptr()) };
+        if rc != 0 { return Err(last_error()); }
+        Ok(rec[0] == 1)
     }
 
     /// The wire format of the serde / wasm layer (javascript/src/lib.rs:95-118,147-184): points as 33-byte SEC1-compressed records, decompressed and

@@ -72,7 +72,21 @@ static void run(plume_ctx* ctx, int pinned, const char* label) {
         s[32 + 31] ^= 1;   /* tamper with item 1 only */
         rc = plume_verify_batch(ctx, ver, N, msgs, off, pk, nul, c, s, ver == 1 ? rp : NULL, ver == 1 ? hr : NULL, ok);
         CHECK(rc == PLUME_OK && ok[0] == 1 && ok[1] == 0 && ok[2] == 1, "verify rejects exactly the tampered item");
-        s[32 + 31] ^= 1;
+        {   /* the aggregate pre-filter: the tampered batch fails as a whole (all hashes still match: s is not hashed), the honest one passes */
+            uint8_t seed[32], rec[PLUME_AGG_RESULT_BYTES], hok[N];
+            for (int i = 0; i < 32; i++) seed[i] = (uint8_t)(17 * i + ver);
+            rc = plume_aggregate_check(ctx, ver, 1, N, msgs, off, pk, nul, c, s, rp, hr, seed, hok, rec);
+            CHECK(rc == PLUME_OK && rec[0] == 0 && rec[1] == 0 && rec[4] == 0 && hok[0] == 1 && hok[1] == 1 && hok[2] == 1, "aggregate check rejects the tampered batch");
+            s[32 + 31] ^= 1;
+            rc = plume_aggregate_check(ctx, ver, 1, N, msgs, off, pk, nul, c, s, rp, hr, seed, hok, rec);
+            CHECK(rc == PLUME_OK && rec[0] == 1 && rec[1] == 1 && rec[4] == 0, "aggregate check accepts the reference signatures (verify_non_zk types)");
+            if (ver == 1) {
+                rc = plume_aggregate_check(ctx, 1, 0, N, msgs, off, pk, nul, c, s, rp, hr, seed, NULL, rec);
+                CHECK(rc == PLUME_OK && rec[0] == 1, "aggregate check, PlumeSignature::verify types");
+            } else {
+                CHECK(plume_aggregate_check(ctx, 2, 0, N, msgs, off, pk, nul, c, s, rp, hr, seed, NULL, rec) == PLUME_ERR_ARG, "V2 verify has no given R / Hr to aggregate over");
+            }
+        }
         /* arkworks shape: pk supplied, identical bytes */
         uint8_t c2[32 * N], s2[32 * N], nul2[64 * N], rp2[64 * N], hr2[64 * N];
         rc = plume_sign_batch(ctx, ver, N, msgs, off, sk, r, pk, NULL, nul2, c2, s2, rp2, hr2, status);
