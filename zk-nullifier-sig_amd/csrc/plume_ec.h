@@ -435,6 +435,8 @@ PLUME_HD void aff_add(fe& x3, fe& y3, const fe& x1, const fe& y1, const fe& x2, 
 struct DirectRowSinkSync {                                       // host / single-lane builds: rows are stored by the lane that reads them back
     PLUME_HD void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const { st_tab_entry(e, x, y, bx); }
     PLUME_HD void sync() const {}
+    // the inversion of one level's product (never zero, see the guard); the table kernel's sink shares one inversion between the wavefronts of a workgroup
+    PLUME_HD void inv(fe& r, const fe& a, int) const { fe_inv(r, a); }
 };
 template <bool GUARD>
 PLUME_HD void tab_push(fe& acc, uint32_t* scr, size_t sstride, size_t slane, size_t q, fe d) {
@@ -497,7 +499,7 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
         if (guard || !fe_is_zero(acc)) break;
         guard = true;                                            // unreachable for points of prime order: redo with zero denominators replaced by 1
     }
-    fe_inv(inv, acc);
+    sink.inv(inv, acc, 1);
     // ------------------------------------------------------------------------------- level 1, finish (jobs descending) + level 2's denominators
     acc = fe_small(1);
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
@@ -530,7 +532,7 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
             tab_push_l2<true>(acc, scr, sstride, slane, RB + 4 * (size_t)jj, x1, x2, y2);
         }
     }
-    fe_inv(inv, acc);
+    sink.inv(inv, acc, 2);
     // ------------------------------------------------------------------------------- level 2, finish (jobs ascending): 4P, 3P + level 3's denominators
     acc = fe_small(1);
     PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
@@ -557,7 +559,7 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
             tab_push_l3<true>(acc, scr, sstride, slane, 4 * (size_t)jj, x1, x3, y3, x4, y4);
         }
     }
-    fe_inv(inv, acc);
+    sink.inv(inv, acc, 3);
     // ------------------------------------------------------------------------------- level 3, finish (jobs descending): 8P, 7P, 6P, 5P
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
         uint32_t* t = tab + (j0 + (size_t)jj) * TW;

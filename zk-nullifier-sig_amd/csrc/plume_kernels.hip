@@ -63,10 +63,47 @@ __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
 #ifndef PLUME_TABLES_AFFINE
 #define PLUME_TABLES_AFFINE 1    // 1: affine chains with level-batched inversions (table_build_affine); 0: the round-1 Jacobian builder (A/B runs)
 #endif
+#ifndef PLUME_TABLES_SHARED_INV
+#define PLUME_TABLES_SHARED_INV 1   // 1: one wavefront of the workgroup inverts for all four (below); 0: every lane inverts its own product (A/B runs)
+#endif
 struct CoopRowSink {
     uint4* rows;             // this wavefront's 64 x 8 quads (quad index xor-swizzled by row against bank conflicts)
     uint32_t** ptrs;         // this wavefront's 64 row addresses
     bool full;               // wave-uniform: all 64 lanes build the same number of rows
+    uint32_t* xch;           // the workgroup's row area, reused between levels as the exchange area of the shared inversion
+    // One level's inversion, shared by the wavefronts of the workgroup.  In SIMT an inversion costs a wavefront the same ~20 k instructions whether one lane
+    // or all 64 need it, so Montgomery's trick across LANES saves nothing -- across WAVEFRONTS it does: every lane parks its product in LDS, lane l of ONE
+    // wavefront multiplies the kWaves products of column l, inverts once, and peels the kWaves inverses off again (3 (kWaves - 1) multiplications), the other
+    // wavefronts wait at the barrier while the SIMDs run other workgroups.  The inverting wavefront rotates with the level and the workgroup so that the
+    // inversions spread over the four SIMDs of a CU.  A lane's slot lies inside its own wavefront's row area: rows are only staged there between the
+    // wave-level barriers of operator(), never across a workgroup barrier.  Every thread of the workgroup must get here (k_tables calls the builder with cnt = 0
+    // for lanes past the end); the products are never zero (table_build_affine's guard).
+    __device__ void inv(fe& r, const fe& a, int level) const {
+#if PLUME_TABLES_SHARED_INV
+        constexpr uint32_t kWaves = kBlock / 64, kWaveWords = 64 * 8 * 4;
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        uint32_t* mine = xch + wave * kWaveWords + lane;
+        PLUME_UNROLL for (int i = 0; i < PLUME_FE_WORDS; i++) mine[i * 64] = a.v[i];
+        __syncthreads();
+        if (wave == (((uint32_t)level + blockIdx.x) % kWaves)) {
+            fe v[kWaves], pre[kWaves], t;
+            PLUME_UNROLL for (uint32_t k = 0; k < kWaves; k++) {
+                PLUME_UNROLL for (int i = 0; i < PLUME_FE_WORDS; i++) v[k].v[i] = xch[k * kWaveWords + lane + i * 64];
+                if (k == 0) pre[0] = v[0]; else fe_mul(pre[k], pre[k - 1], v[k]);
+            }
+            fe_inv(t, pre[kWaves - 1]);
+            PLUME_UNROLL for (int k = (int)kWaves - 1; k >= 0; k--) {
+                fe o;
+                if (k > 0) { fe_mul(o, t, pre[k - 1]); fe_mul(t, t, v[k]); } else o = t;
+                PLUME_UNROLL for (int i = 0; i < PLUME_FE_WORDS; i++) xch[(uint32_t)k * kWaveWords + lane + i * 64] = o.v[i];
+            }
+        }
+        __syncthreads();
+        PLUME_UNROLL for (int i = 0; i < PLUME_FE_WORDS; i++) r.v[i] = mine[i * 64];
+#else
+        (void)level; fe_inv(r, a);
+#endif
+    }
     // rows stored by OTHER lanes of the wavefront are read back by their owner in the next level of table_build_affine: order the wave's stores before its loads
     __device__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     __device__ void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const {
@@ -110,10 +147,12 @@ __global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* base
     sink.rows = s_rows + (threadIdx.x & ~63u) * 8;
     sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
     sink.full = __ballot(cnt == L) == ~0ull;
+    sink.xch = reinterpret_cast<uint32_t*>(s_rows);
 #if PLUME_TABLES_AFFINE
     // scratch interleaved across the lanes of THIS workgroup only (stride kBlock words): the words of one prefix product lie 1 KiB apart inside the workgroup's own
     // region instead of (lanes x 4) bytes apart across the whole buffer -- same coalescing, but a wave's accesses stay within a few pages
-    if (cnt > 0) table_build_affine<CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kBlock), (size_t)kBlock, threadIdx.x, sink);
+    // (every lane calls it, also with cnt = 0: the shared inversion has workgroup barriers)
+    table_build_affine<CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kBlock), (size_t)kBlock, threadIdx.x, sink);
 #else
     if (cnt > 0) table_build<PLUME_TAB_ENTRIES, CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane, sink);
 #endif
