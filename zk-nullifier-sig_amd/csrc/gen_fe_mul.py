@@ -25,7 +25,8 @@ hazard nops inside a statement.  Host builds (tests/devsim) compile the same col
 """
 
 
-SQR_DIAG = "a.v[{i}]"   # second operand of the diagonal products of a squaring ("t3[{i}]" in fe_sqr3)
+SQR_DIAG = "a.v[{i}]"   # second operand of the diagonal products of a squaring ("t3[{i}]" in fe_sqr3, "d[{i}]" in fe_sqr2)
+SQR_CROSS = "a.v[{i}]"  # first operand of the cross products of a squaring ("d[{i}]" in fe_sqr2: d_i d_j = 4 a_i a_j)
 
 
 def col_terms(k, sqr, pair=("a", "b")):
@@ -38,7 +39,7 @@ def col_terms(k, sqr, pair=("a", "b")):
         if not sqr:
             t.append((f"{x}.v[{i}]", f"{y}.v[{j}]"))
         elif i < j:
-            t.append((f"a.v[{i}]", f"d[{j}]"))
+            t.append((SQR_CROSS.format(i=i), f"d[{j}]"))
         elif i == j:
             t.append((f"a.v[{i}]", SQR_DIAG.format(i=i)))
     return t
@@ -73,7 +74,7 @@ def emit_chain(terms, indent="    ", acc="acc", carry=None):
     return (f"{indent}PLUME_FE_CHAIN({acc}, \"{body}\", {ins});\n", f"{indent}{host}\n")
 
 
-def gen(name, sqr, two=False, scale3=False, expose_d=False):
+def gen(name, sqr, two=False, scale3=False, expose_d=False, scale2=False):
     """two: r = a*b + c*d with ONE fold -- the two products share their column sums (each column: two chain statements).
 
     Statement order: the high-half chain (columns 9..16, accumulator acch) and the low-half chain (columns 0..8, accumulator acc)
@@ -159,9 +160,11 @@ def gen(name, sqr, two=False, scale3=False, expose_d=False):
     both("    l[1] = (uint32_t)acc & PLUME_FE_MASK;\n    l[2] += (uint32_t)(acc >> 29) + (t1 << 3);\n    PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = l[i];\n")
     sig = f"PLUME_HD void {name}(fe& r, const fe& a)" if sqr else f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b)"
     check = "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, a));\n" if sqr else "    PLUME_FE_ASSERT(fe_mul_inputs_ok(a, b));\n"
-    if scale3:
+    if scale3 or scale2:
         check = "    PLUME_FE_ASSERT(fe_is_tight(a));\n"
-    if expose_d:
+    if expose_d and scale2:
+        sig = f"// r = 2 a^2, dbl = 2a (group law: 2Y^2 and Z' = (2Y) Z from one squaring); dbl must not alias a\nPLUME_HD void {name}(fe& r, fe& dbl, const fe& a)"
+    elif expose_d:
         sig = f"// r = a^2, dbl = 2a: the doubled limbs the squaring forms anyway (group law: Z' = (2Y) Z); dbl must not alias a\nPLUME_HD void {name}(fe& r, fe& dbl, const fe& a)"
     if two:
         sig = f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b, const fe& c, const fe& e)"
@@ -191,7 +194,13 @@ def main():
     SQR_DIAG = "t3[{i}]"
     print("// r = 3 a^2 for a TIGHT a, tight result: the factor rides in the operands (group law: E = 3 X^2 without the tripling and its carry pass)")
     print(gen("fe_sqr3", True, scale3=True))
-    SQR_DIAG = "a.v[{i}]"
+    global SQR_CROSS
+    SQR_DIAG, SQR_CROSS = "d[{i}]", "d[{i}]"
+    print("// r = 2 a^2 for a TIGHT a, tight result, at the cost of a plain squaring: the cross products are d_i d_j = 4 a_i a_j, the diagonal ones a_i d_i = 2 a_i^2 (d = 2a, which every")
+    print("// squaring forms anyway); column sums 18 T^2 < 2^63.  The group law's doubling takes 2Y^2 and 8Y^4 = 2 (2Y^2)^2 from these instead of doubling afterwards.")
+    print(gen("fe_sqr2", True, scale2=True))
+    print(gen("fe_sqr2_d", True, scale2=True, expose_d=True))
+    SQR_DIAG, SQR_CROSS = "a.v[{i}]", "a.v[{i}]"
     global A_CONS
     A_CONS_SAVE = A_CONS
     A_CONS = "v"

@@ -47,13 +47,13 @@ PLUME_HD bool affine_on_curve(const fe& x, const fe& y) {
 // (fe_add_lazy / fe_sub_lazy<M>) and spend a carry pass only where a bound would otherwise be exceeded; host builds with
 // PLUME_FE_CHECK assert every bound.
 //
-// 2P, a = 0:  A = X^2, B = Y^2, X' = (3A)^2 - 8XB, Y' = 3A(4XB - X') - 8B^2, Z' = 2YZ   (3M + 4S, 2 carry passes)
+// 2P, a = 0:  A = X^2, B = Y^2, X' = (3A)^2 - 8XB, Y' = 3A(4XB - X') - 8B^2, Z' = 2YZ   (3M + 4S, 2 carry passes; the factors 3, 2, 2 of 3A, 2B, 8B^2 ride in the squarings)
 // valid for every non-infinity point (the curve has no 2-torsion); the inf flag just rides along.
 PLUME_HD void jac_dbl(jac& p) {
     fe B2, C4, XB2, E, F, D2, D4, t, dY;
     fe_sqr3(E, p.x);                                       // 3X^2, tight: the factor rides in the squaring's operands (no tripling, no carry pass)
-    fe_sqr_d(B2, dY, p.y); fe_dbl_lazy(B2, B2);            // 2Y^2;  dY = 2Y comes out of the squaring
-    fe_sqr(C4, B2);                                        // 4Y^4
+    fe_sqr2_d(B2, dY, p.y);                                // 2Y^2 straight out of the squaring (cross products d_i d_j, diagonal a_i d_i);  dY = 2Y
+    fe_sqr2(C4, B2);                                       // 8Y^4 = 2 (2Y^2)^2 likewise
     fe_mul(XB2, p.x, B2);                                  // 2XY^2
     fe_mul(p.z, dY, p.z);                                  // Z' = 2YZ
     fe_sqr(F, E);
@@ -62,7 +62,6 @@ PLUME_HD void jac_dbl(jac& p) {
     fe_sub_lazy<5>(p.x, F, D4); fe_carry(p.x);             // X' = 9X^4 - 8XY^2
     fe_sub_lazy<2>(t, D2, p.x);                            // 4XY^2 - X'
     fe_mul(t, E, t);
-    fe_dbl_lazy(C4, C4);                                   // 8Y^4
     fe_sub_lazy<3>(p.y, t, C4); fe_carry(p.y);
 }
 // cold path of the additions (P == Q).  Takes and returns BY VALUE through a local copy at the call site: passing the
