@@ -133,6 +133,39 @@ def build_abi_smoke(tmp_path):
     return exe
 
 
+def build_reference_tests(tmp_path):
+    """compile tests/abi_cpp/reference_tests.cpp (the reference's own tests restated against include/plume.hpp, the C++ host side) with plain g++"""
+    import subprocess
+    import zk_nullifier_sig_amd as plume
+    exe = tmp_path / "reference_tests"
+    libdir = plume.library_path().parent
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", str(ROOT / "include"), str(ROOT / "tests" / "abi_cpp" / "reference_tests.cpp"), "-L", str(libdir),
+                    "-lplume_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True, capture_output=True, text=True)
+    return exe
+
+
+def write_kg_vectors(tmp_path):
+    """the reference's 100 k*G SEC1 vectors (rust-arkworks/src/tests/test_vectors.rs, extracted into tests/golden/reference_kats.json) as `k compressed-hex` lines"""
+    import json
+    kats = json.loads((ROOT / "tests" / "golden" / "reference_kats.json").read_text())
+    path = tmp_path / "kg_vectors.txt"
+    path.write_text("".join(f"{k} {comp}\n" for k, comp, _ in kats["sec1_kG"]["vectors"]))
+    return path
+
+
+@needs_lib
+def test_cpp_host_side_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/plume.hpp (plume_rustcrypto / plume_arkworks shapes in C++ over the C ABI) compiles warning-free with g++ -std=c++17 and, without a GPU, its
+    engine reports PLUME_ERR_NODEV instead of computing anywhere else"""
+    import subprocess
+    import torch
+    exe = build_reference_tests(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (the GPU suite runs the program)")
+    r = subprocess.run([str(exe), str(write_kg_vectors(tmp_path))], capture_output=True, text=True)
+    assert r.returncode == 3 and "no CPU fallback" in r.stdout
+
+
 @needs_lib
 def test_c_caller_builds_against_the_header_and_fails_loudly_without_a_gpu(tmp_path):
     """a non-Python FFI caller: the header is valid C, every symbol it uses links, and without a GPU plume_init reports PLUME_ERR_NODEV"""

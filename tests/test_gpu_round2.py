@@ -357,6 +357,17 @@ def test_c_program_reproduces_the_reference_vector(tmp_path):
     assert r.returncode == 0 and "abi_smoke ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_cpp_host_side_passes_the_references_own_tests(tmp_path):
+    """tests/abi_cpp/reference_tests.cpp: rust-k256/tests/{signing,verification}.rs and rust-arkworks/src/tests.rs restated test by test against include/plume.hpp
+    (C++17, g++, -lplume_hip only) -- the host side a caller of the Rust crates would switch to; plus rejection cases, batch twins and error behaviour"""
+    import subprocess
+    from tests.test_abi_cpu import build_reference_tests, write_kg_vectors
+    exe = build_reference_tests(tmp_path)
+    r = subprocess.run([str(exe), str(write_kg_vectors(tmp_path))], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "reference_tests ok" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "arkworks::test_point_sec1_encoding ... ok" in r.stdout and "signing::test_sign_v1 ... ok" in r.stdout
+
+
 def test_sec1_der_scalar_marshalling(eng, kats):
     """plume_scalars_to_sec1_der_batch (public keys by the GPU comb) + plume_sec1_der_to_scalars against the wasm README's records"""
     from zk_nullifier_sig_amd import capi
