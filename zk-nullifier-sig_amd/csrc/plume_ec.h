@@ -406,7 +406,7 @@ PLUME_HD void pre_st(uint32_t* scr, size_t sstride, size_t slane, size_t q, cons
 PLUME_HD void pre_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, size_t q) {
     PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = scr[((q * PLUME_FE_W + (size_t)i) * sstride) + slane];
 }
-#define PLUME_TAB_AFF_SCR_WORDS (8 * PLUME_FE_WORDS)       // prefix products per job: two regions (consecutive levels overlap) of at most 4 denominators
+#define PLUME_TAB_AFF_SCR_WORDS (2 * PLUME_FE_WORDS)       // prefix products per job: ONE per level (below), two alternating regions (consecutive levels overlap)
 // 2P from affine P = (x, y) (tight) and l = 1 / (2y)
 PLUME_HD void aff_dbl(fe& x3, fe& y3, const fe& x, const fe& y, const fe& l) {
     fe lam, t, t2;
@@ -437,51 +437,59 @@ struct DirectRowSinkSync {                                       // host / singl
     // the inversion of one level's product (never zero, see the guard); the table kernel's sink shares one inversion between the wavefronts of a workgroup
     PLUME_HD void inv(fe& r, const fe& a, int) const { fe_inv(r, a); }
 };
-template <bool GUARD>
-PLUME_HD void tab_push(fe& acc, uint32_t* scr, size_t sstride, size_t slane, size_t q, fe d) {
-    if (GUARD) { if (fe_is_zero(d)) d = fe_small(1); }
+// Montgomery's trick in two tiers, so that a level costs ONE scratch slot per job instead of one per denominator (the table kernel is bandwidth-bound: 36 bytes
+// written and read per job and level instead of up to 144).  A job's denominators of a level are multiplied together first (D = d1 d2 [d3 d4]); the lane's running
+// product is parked before D joins it.  The finishing pass gets 1/D from the chain and splits it with the denominators themselves, which it recomputes from the
+// entries it has to load anyway (x2 - x1, 2 y2, ...): 1 / d1 = (1/D) d2 for a pair, two such steps for four.
+PLUME_HD void guard_one(fe& d, bool guard) { if (guard) { if (fe_is_zero(d)) d = fe_small(1); } }
+// park the running product, then acc *= D
+PLUME_HD void tab_park(fe& acc, uint32_t* scr, size_t sstride, size_t slane, size_t q, const fe& D) {
     pre_st(scr, sstride, slane, q, acc);
-    fe_mul(acc, acc, d);
+    fe_mul(acc, acc, D);
 }
-PLUME_HD void tab_pop(fe& dinv, fe& inv, const uint32_t* scr, size_t sstride, size_t slane, size_t q, fe d, bool guard) {
+// 1/D of the job whose product was parked at q; inv moves on to the jobs parked before it
+PLUME_HD void tab_unpark(fe& Dinv, fe& inv, const uint32_t* scr, size_t sstride, size_t slane, size_t q, const fe& D) {
     fe pre;
-    if (guard) { if (fe_is_zero(d)) d = fe_small(1); }
     pre_ld(pre, scr, sstride, slane, q);
-    fe_mul(dinv, inv, pre);
-    fe_mul(inv, inv, d);
+    fe_mul(Dinv, inv, pre);
+    fe_mul(inv, inv, D);
 }
-// the base of a job as the chain sees it: affine (x, y) for Z = 1 bases, Jacobian otherwise; anything that is not a usable point becomes G
+// the base of a job as the chain sees it: affine (x, y) for Z = 1 bases, Jacobian otherwise; anything that is not a usable point becomes G.  The Z words of an
+// affine base are not even loaded.
 PLUME_HD bool tab_base(jac& b, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t job) {
-    ld_jac_soa(b, bases, njobs, job);
-    b.inf = 0;
     bool zone = (jobflags[job] & PLUME_JOB_AFFINE) != 0;
+    ld_fe_soa(b.x, bases, njobs, job); ld_fe_soa(b.y, bases + PLUME_FE_W * njobs, njobs, job);
+    if (zone) b.z = fe_small(1); else ld_fe_soa(b.z, bases + 2 * PLUME_FE_W * njobs, njobs, job);
+    b.inf = 0;
     if (job_state(jobflags[job]) != PLUME_JOB_OK) { b.x = fe_gx(); b.y = fe_gy(); b.z = fe_small(1); zone = true; }
     return zone;
 }
-// the denominators of level 2 (slots 4jj+4L.., pushed for jj descending) and level 3 (slots 4jj.., pushed for jj ascending) of one job
-template <bool GUARD>
-PLUME_HD void tab_push_l2(fe& acc, uint32_t* scr, size_t sstride, size_t slane, size_t q, const fe& x1, const fe& x2, const fe& y2) {
-    fe d;
-    fe_sub_lazy<2>(d, x2, x1); tab_push<GUARD>(acc, scr, sstride, slane, q, d);
-    fe_dbl_lazy(d, y2); tab_push<GUARD>(acc, scr, sstride, slane, q + 1, d);
+// level 1 of one job: denominators Z (Jacobian base only) and 2Y
+PLUME_HD void tab_den_l1(fe& dz, fe& dy, fe& D, const jac& b, bool zone, bool guard) {
+    fe_dbl_lazy(dy, b.y); guard_one(dy, guard);
+    if (zone) { D = dy; dz = fe_small(1); } else { dz = b.z; guard_one(dz, guard); fe_mul(D, dz, dy); }
 }
-template <bool GUARD>
-PLUME_HD void tab_push_l3(fe& acc, uint32_t* scr, size_t sstride, size_t slane, size_t q, const fe& x1, const fe& x3, const fe& y3, const fe& x4, const fe& y4) {
-    fe d;
-    fe_sub_lazy<2>(d, x4, x1); tab_push<GUARD>(acc, scr, sstride, slane, q, d);
-    fe_dbl_lazy(d, y3); tab_push<GUARD>(acc, scr, sstride, slane, q + 1, d);
-    fe_sub_lazy<2>(d, x4, x3); tab_push<GUARD>(acc, scr, sstride, slane, q + 2, d);
-    fe_dbl_lazy(d, y4); tab_push<GUARD>(acc, scr, sstride, slane, q + 3, d);
+// level 2: x2 - x1, 2 y2
+PLUME_HD void tab_den_l2(fe& da, fe& db, fe& D, const fe& x1, const fe& x2, const fe& y2, bool guard) {
+    fe_sub_lazy<2>(da, x2, x1); guard_one(da, guard);
+    fe_dbl_lazy(db, y2); guard_one(db, guard);
+    fe_mul(D, da, db);
 }
-// Level k+1's denominators are formed -- and its prefix products accumulated -- inside level k's finishing pass, while the entries they come from are
+// level 3: x4 - x1, 2 y3, x4 - x3, 2 y4;  p01 = d0 d1, p23 = d2 d3, D = p01 p23
+PLUME_HD void tab_den_l3(fe d[4], fe& p01, fe& p23, fe& D, const fe& x1, const fe& x3, const fe& y3, const fe& x4, const fe& y4, bool guard) {
+    fe_sub_lazy<2>(d[0], x4, x1); fe_dbl_lazy(d[1], y3); fe_sub_lazy<2>(d[2], x4, x3); fe_dbl_lazy(d[3], y4);
+    PLUME_UNROLL for (int k = 0; k < 4; k++) guard_one(d[k], guard);
+    fe_mul(p01, d[0], d[1]); fe_mul(p23, d[2], d[3]); fe_mul(D, p01, p23);
+}
+// Level k+1's denominators are formed -- and their product joins the lane's chain -- inside level k's finishing pass, while the entries they come from are
 // still in registers: four passes over a lane's jobs instead of six, and no pass that only re-reads rows.  Consecutive levels therefore run through the
-// jobs in opposite directions (a level is finished in the reverse of the order its denominators were pushed in) and use alternating scratch regions.
+// jobs in opposite directions (a level is finished in the reverse of the order its products were parked in) and use alternating scratch regions.
 template <class RowSink = DirectRowSinkSync>
 PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
                                  const RowSink& sink = RowSink()) {
     const fe beta = fe_beta();
     constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
-    const size_t RB = 4 * (size_t)cnt;                           // second scratch region
+    const size_t RB = (size_t)cnt;                               // second scratch region
     fe acc, inv;
     bool guard = false;
     // ------------------------------------------------------------------------------- level 1, forward (jobs ascending): denominators of P -> affine, 2P
@@ -490,10 +498,9 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
         PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
             jac b;
             const bool zone = tab_base(b, bases, jobflags, njobs, j0 + (size_t)jj);
-            fe d;
-            if (!zone) { if (guard) tab_push<true>(acc, scr, sstride, slane, 4 * (size_t)jj, b.z); else tab_push<false>(acc, scr, sstride, slane, 4 * (size_t)jj, b.z); }
-            fe_dbl_lazy(d, b.y);
-            if (guard) tab_push<true>(acc, scr, sstride, slane, 4 * (size_t)jj + 1, d); else tab_push<false>(acc, scr, sstride, slane, 4 * (size_t)jj + 1, d);
+            fe dz, dy, D;
+            tab_den_l1(dz, dy, D, b, zone, guard);
+            tab_park(acc, scr, sstride, slane, (size_t)jj, D);
         }
         if (guard || !fe_is_zero(acc)) break;
         guard = true;                                            // unreachable for points of prime order: redo with zero denominators replaced by 1
@@ -505,12 +512,13 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
         const size_t job = j0 + (size_t)jj;
         jac b;
         const bool zone = tab_base(b, bases, jobflags, njobs, job);
-        fe d, l, x1 = b.x, y1 = b.y;
-        fe_dbl_lazy(d, b.y);
-        tab_pop(l, inv, scr, sstride, slane, 4 * (size_t)jj + 1, d, guard);        // 1 / (2Y)
+        fe dz, dy, D, l, x1 = b.x, y1 = b.y;
+        tab_den_l1(dz, dy, D, b, zone, guard);
+        tab_unpark(l, inv, scr, sstride, slane, (size_t)jj, D);                     // 1 / D:  1 / (2Y) for an affine base,  1 / (Z 2Y) otherwise
         if (!zone) {
             fe zi, z2, z3, zi2;
-            tab_pop(zi, inv, scr, sstride, slane, 4 * (size_t)jj, b.z, guard);     // 1 / Z
+            fe_mul(zi, l, dy);                                                      // 1 / Z
+            fe_mul(l, l, dz);                                                       // 1 / (2Y)
             fe_sqr(z2, b.z); fe_mul(z3, z2, b.z); fe_mul(l, l, z3);                 // 1 / (2y) = Z^3 / (2Y)
             fe_sqr(zi2, zi); fe_mul(x1, b.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y1, b.y, zi2);
         }
@@ -519,16 +527,19 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
         uint32_t* t = tab + job * TW;
         fe_mul_k(bx, beta, x1); sink(t, x1, y1, bx);
         fe_mul_k(bx, beta, x2); sink(t + EW, x2, y2, bx);
-        tab_push_l2<false>(acc, scr, sstride, slane, RB + 4 * (size_t)jj, x1, x2, y2);
+        fe da, db;
+        tab_den_l2(da, db, D, x1, x2, y2, false);
+        tab_park(acc, scr, sstride, slane, RB + (size_t)jj, D);
     }
     sink.sync();
-    if (guard || fe_is_zero(acc)) {                              // cold: the same pushes, from the rows, with the zero check
+    if (guard || fe_is_zero(acc)) {                                                 // cold: the same products, from the rows, with the zero check
         guard = true; acc = fe_small(1);
         PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
             const uint32_t* t = tab + (j0 + (size_t)jj) * TW;
-            fe x1, y1, x2, y2;
+            fe x1, y1, x2, y2, da, db, D;
             ld_tab_xy(x1, y1, t, false); ld_tab_xy(x2, y2, t + EW, false);
-            tab_push_l2<true>(acc, scr, sstride, slane, RB + 4 * (size_t)jj, x1, x2, y2);
+            tab_den_l2(da, db, D, x1, x2, y2, true);
+            tab_park(acc, scr, sstride, slane, RB + (size_t)jj, D);
         }
     }
     sink.inv(inv, acc, 2);
@@ -536,49 +547,51 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
     acc = fe_small(1);
     PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
         uint32_t* t = tab + (j0 + (size_t)jj) * TW;
-        fe x1, y1, x2, y2, d, l, x3, y3, x4, y4, bx;
+        fe x1, y1, x2, y2, da, db, D, Dinv, l, x3, y3, x4, y4, bx;
         ld_tab_xy(x1, y1, t, false); ld_tab_xy(x2, y2, t + EW, false);
-        fe_dbl_lazy(d, y2);
-        tab_pop(l, inv, scr, sstride, slane, RB + 4 * (size_t)jj + 1, d, guard);
+        tab_den_l2(da, db, D, x1, x2, y2, guard);
+        tab_unpark(Dinv, inv, scr, sstride, slane, RB + (size_t)jj, D);
+        fe_mul(l, Dinv, da);                                                        // 1 / (2 y2)
         aff_dbl(x4, y4, x2, y2, l);                                                 // 4P
         fe_mul_k(bx, beta, x4); sink(t + 3 * EW, x4, y4, bx);
-        fe_sub_lazy<2>(d, x2, x1);
-        tab_pop(l, inv, scr, sstride, slane, RB + 4 * (size_t)jj, d, guard);
+        fe_mul(l, Dinv, db);                                                        // 1 / (x2 - x1)
         aff_add(x3, y3, x1, y1, x2, y2, l);                                         // 3P
         fe_mul_k(bx, beta, x3); sink(t + 2 * EW, x3, y3, bx);
-        tab_push_l3<false>(acc, scr, sstride, slane, 4 * (size_t)jj, x1, x3, y3, x4, y4);
+        fe d[4], p01, p23;
+        tab_den_l3(d, p01, p23, D, x1, x3, y3, x4, y4, false);
+        tab_park(acc, scr, sstride, slane, (size_t)jj, D);
     }
     sink.sync();
     if (guard || fe_is_zero(acc)) {
         guard = true; acc = fe_small(1);
         PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
             const uint32_t* t = tab + (j0 + (size_t)jj) * TW;
-            fe x1, y1, x3, y3, x4, y4;
+            fe x1, y1, x3, y3, x4, y4, d[4], p01, p23, D;
             ld_tab_xy(x1, y1, t, false); ld_tab_xy(x3, y3, t + 2 * EW, false); ld_tab_xy(x4, y4, t + 3 * EW, false);
-            tab_push_l3<true>(acc, scr, sstride, slane, 4 * (size_t)jj, x1, x3, y3, x4, y4);
+            tab_den_l3(d, p01, p23, D, x1, x3, y3, x4, y4, true);
+            tab_park(acc, scr, sstride, slane, (size_t)jj, D);
         }
     }
     sink.inv(inv, acc, 3);
     // ------------------------------------------------------------------------------- level 3, finish (jobs descending): 8P, 7P, 6P, 5P
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
         uint32_t* t = tab + (j0 + (size_t)jj) * TW;
-        fe x1, y1, x3, y3, x4, y4, d, l, xr, yr, bx;
+        fe x1, y1, x3, y3, x4, y4, d[4], p01, p23, D, Dinv, i01, i23, l, xr, yr, bx;
         ld_tab_xy(x1, y1, t, false); ld_tab_xy(x3, y3, t + 2 * EW, false); ld_tab_xy(x4, y4, t + 3 * EW, false);
-        const size_t q = 4 * (size_t)jj;
-        fe_dbl_lazy(d, y4);
-        tab_pop(l, inv, scr, sstride, slane, q + 3, d, guard);
+        tab_den_l3(d, p01, p23, D, x1, x3, y3, x4, y4, guard);
+        tab_unpark(Dinv, inv, scr, sstride, slane, (size_t)jj, D);
+        fe_mul(i01, Dinv, p23);                                                     // 1 / (d0 d1)
+        fe_mul(i23, Dinv, p01);                                                     // 1 / (d2 d3)
+        fe_mul(l, i23, d[2]);                                                       // 1 / (2 y4)
         aff_dbl(xr, yr, x4, y4, l);                                                 // 8P
         fe_mul_k(bx, beta, xr); sink(t + 7 * EW, xr, yr, bx);
-        fe_sub_lazy<2>(d, x4, x3);
-        tab_pop(l, inv, scr, sstride, slane, q + 2, d, guard);
+        fe_mul(l, i23, d[3]);                                                       // 1 / (x4 - x3)
         aff_add(xr, yr, x3, y3, x4, y4, l);                                         // 7P
         fe_mul_k(bx, beta, xr); sink(t + 6 * EW, xr, yr, bx);
-        fe_dbl_lazy(d, y3);
-        tab_pop(l, inv, scr, sstride, slane, q + 1, d, guard);
+        fe_mul(l, i01, d[0]);                                                       // 1 / (2 y3)
         aff_dbl(xr, yr, x3, y3, l);                                                 // 6P
         fe_mul_k(bx, beta, xr); sink(t + 5 * EW, xr, yr, bx);
-        fe_sub_lazy<2>(d, x4, x1);
-        tab_pop(l, inv, scr, sstride, slane, q, d, guard);
+        fe_mul(l, i01, d[1]);                                                       // 1 / (x4 - x1)
         aff_add(xr, yr, x1, y1, x4, y4, l);                                         // 5P
         fe_mul_k(bx, beta, xr); sink(t + 4 * EW, xr, yr, bx);
     }

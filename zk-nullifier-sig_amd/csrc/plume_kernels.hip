@@ -384,7 +384,7 @@ void launch_verify_ingest(const VerifyArgs& a, hipStream_t st) { hipLaunchKernel
 size_t tables_scratch_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
 #if PLUME_TABLES_AFFINE
-    return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_AFF_SCR_WORDS * 4;          // prefix products of one level: 4 per job
+    return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_AFF_SCR_WORDS * 4;          // one parked product per job and level, two regions
 #else
     return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_ENTRIES * PLUME_TAB_SCR_WORDS * 4;
 #endif
