@@ -12,6 +12,7 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <memory>
 #include <vector>
 
 #include "../../include/plume_hip.h"
@@ -119,6 +120,23 @@ static int ws_release(plume_ctx* ctx, hipStream_t st) {
     ctx->ws_used = true;
     return 0;
 }
+// Holds the workspace from a successful ws_acquire to the end of the call.  A call that fails half way (an allocation, a launch) must still leave ws_free behind
+// whatever it has already enqueued -- on the caller's stream and on the context's side stream -- or the next call, on another stream, would run into it.
+struct WsHold {
+    plume_ctx* ctx;
+    hipStream_t st;
+    bool released = false;
+    WsHold(plume_ctx* c, hipStream_t s) : ctx(c), st(s) {}
+    WsHold(const WsHold&) = delete;
+    WsHold& operator=(const WsHold&) = delete;
+    int release() { released = true; return ws_release(ctx, st); }
+    ~WsHold() {
+        if (released) return;
+        if (ctx->side) (void)hipStreamSynchronize(ctx->side);      // failure path only: side-stream work the caller's stream never joined
+        (void)hipEventRecord(ctx->ws_free, st);
+        ctx->ws_used = true;
+    }
+};
 
 extern "C" const char* plume_last_error(void) { return g_err.c_str(); }
 extern "C" const char* plume_version(void) { return "plume_hip 0.1 gfx950"; }
@@ -366,7 +384,8 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
                          const uint8_t* preflags = nullptr, bool continue_timer = false, const uint8_t* rpt33 = nullptr, const uint8_t* hr33 = nullptr) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
-    if (!continue_timer) { if (int rc = ws_acquire(ctx, st)) return rc; }
+    if (!continue_timer) { if (int rc = ws_acquire(ctx, st)) return rc; }     // continue_timer: the caller (SEC1 ingest) holds the workspace already
+    std::unique_ptr<WsHold> hold(continue_timer ? nullptr : new WsHold(ctx, st));
     const int jpl = pick_jobs_per_lane(ctx, 3 * n, true);
     if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
         ctx->tabscr.ensure(tables_scratch_bytes(3 * n, jpl)) ||
@@ -385,7 +404,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     if (version == 2 && mode == PLUME_MODE_VERIFY) { launch_normalize(a.res, a.resinf, 2 * n, st); t.stage("to_affine", st); }   // V2 hashes the computed R', Hr'
     launch_verify_finalize(a, st); t.stage("verify_finalize", st);
     HIPCHK(hipGetLastError());
-    return ws_release(ctx, st);
+    return hold ? hold->release() : 0;
 }
 
 static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk, const uint8_t* r,
@@ -394,6 +413,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
     if (int rc = ws_acquire(ctx, st)) return rc;
+    WsHold hold(ctx, st);
     const int jpl = pick_jobs_per_lane(ctx, n, false);
     if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * n) || ctx->jobflags.ensure(n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * n) ||
         ctx->tabscr.ensure(tables_scratch_bytes(n, jpl)) ||
@@ -417,7 +437,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     // the reference zeroizes secrets: wipe the device-side images derived from sk / r
     HIPCHK(hipMemsetAsync(ctx->res.p, 0, (size_t)PLUME_JAC_WORDS * 4 * 2 * n, st));
     HIPCHK(hipGetLastError());
-    return ws_release(ctx, st);
+    return hold.release();
 }
 
 static int args_ok(int version, size_t n, const void* msgs, const void* off) {
@@ -455,6 +475,7 @@ static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
     if (int rc = ws_acquire(ctx, st)) return rc;
+    WsHold hold(ctx, st);
     // only pk and the nullifier are decompressed (they become bases of scalar multiplications); V1's r_point and hashed_to_curve_r stay
     // in their 33-byte form and are compared / hashed as x + parity by the finalize stage
     const int npts = 2;
@@ -467,8 +488,9 @@ static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8
     d.preflags = ctx->preflags.as<uint8_t>();
     ctx->timer.begin(st);
     launch_decompress(d, st); ctx->timer.stage("sec1_decompress", st);
-    return verify_device(ctx, version, PLUME_MODE_VERIFY, n, msgs, msg_off, msgs_bytes, d.out[0], d.out[1], c, s, nullptr, nullptr, ok, st, d.preflags, true,
-                         version == 1 ? r33 : nullptr, version == 1 ? hr33 : nullptr);
+    if (int rc = verify_device(ctx, version, PLUME_MODE_VERIFY, n, msgs, msg_off, msgs_bytes, d.out[0], d.out[1], c, s, nullptr, nullptr, ok, st, d.preflags, true,
+                         version == 1 ? r33 : nullptr, version == 1 ? hr33 : nullptr)) return rc;
+    return hold.release();
 }
 
 extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
@@ -562,6 +584,7 @@ static int aggregate_device(plume_ctx* ctx, int version, int mode, size_t n, con
                             const uint8_t* carry, uint8_t* result, hipStream_t st) {
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
     if (int rc = ws_acquire(ctx, st)) return rc;
+    WsHold hold(ctx, st);
     AggArgs a;
     memset(&a, 0, sizeof a);
     a.version = version; a.mode = mode; a.n = (uint32_t)n;
@@ -625,7 +648,7 @@ static int aggregate_device(plume_ctx* ctx, int version, int mode, size_t n, con
     HIPCHK(hipStreamWaitEvent(st, ctx->agg_ev[3], 0));
     launch_agg_final(a, red[clo], rinf[clo], nlo, red[2 + chi], rinf[2 + chi], nhi, gpt, gptinf, carry, st); t.stage("agg_reduce", st);
     HIPCHK(hipGetLastError());
-    return ws_release(ctx, st);
+    return hold.release();
 }
 
 static int agg_args_ok(int version, int mode, size_t n, const void* msgs, const void* off, const void* seed) {
@@ -659,11 +682,12 @@ static int dedup_device(plume_ctx* ctx, size_t n, const uint8_t* nul, const uint
     a.slots = ctx->dslots.as<uint32_t>(); a.minid = ctx->dminid.as<unsigned long long>(); a.myslot = ctx->dmyslot.as<uint32_t>();
     a.n_unique = ctx->dcount.as<unsigned long long>(); a.blockcnt = ctx->dblockcnt.as<uint32_t>();
     if (int rc = ws_acquire(ctx, st)) return rc;
+    WsHold hold(ctx, st);
     ctx->timer.begin(st);
     launch_dedup(a, st); ctx->timer.stage("nullifier_first_occurrence", st);
     HIPCHK(hipGetLastError());
     if (n_unique_dev) HIPCHK(hipMemcpyAsync(n_unique_dev, ctx->dcount.p, 8, hipMemcpyDeviceToDevice, st));
-    return ws_release(ctx, st);
+    return hold.release();
 }
 extern "C" int plume_nullifier_first_occurrence_device(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live, const uint64_t* ids, uint8_t* first,
                                                        uint64_t* n_unique, void* stream) {
