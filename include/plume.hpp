@@ -8,7 +8,8 @@
 //   namespace plume_rustcrypto   rust-k256/src/lib.rs:43-156, rust-k256/src/randomizedsigner.rs:25-112
 //       DST, AffinePoint, NonZeroScalar, SecretKey, PlumeSignature{message, pk, nullifier, c, s, v1specific}, PlumeSignatureV1Fields,
 //       PlumeSignature::verify / sign_v1 / sign_v2, PlumeSigner{secret_key, v1}::try_sign_with_rng / sign_with_rng, hash_to_curve, encode_pt
-//       + batch twins: verify_batch, sign_batch, sign_batch_with_nonces
+//       + batch twins: verify_batch, sign_batch, sign_batch_with_nonces;  the steps either side: verify_batch_sec1 (33-byte SEC1 records), aggregate_check_v1,
+//         nullifier_first_occurrence, scalars_to_sec1_der / scalar_from_sec1_der
 //   namespace plume_arkworks     rust-arkworks/src/lib.rs:60-291, rust-arkworks/src/tests.rs:28-78,119-124
 //       Affine, Fr, PlumeVersion, PlumeSignaturePublic / PlumeSignaturePrivate (zeroized on drop), sec1_affine, hash_to_curve, sign_with_r, sign,
 //       keygen, verify_non_zk
@@ -365,6 +366,79 @@ template <class Rng>
 PlumeSignature PlumeSignature::sign_v1(const SecretKey& secret_key, const Bytes& msg, Rng& rng, Engine& eng) { return PlumeSigner(secret_key, true).sign_with_rng(rng, msg, eng); }
 template <class Rng>
 PlumeSignature PlumeSignature::sign_v2(const SecretKey& secret_key, const Bytes& msg, Rng& rng, Engine& eng) { return PlumeSigner(secret_key, false).sign_with_rng(rng, msg, eng); }
+
+// ---- the steps either side of sign / verify, as the Rust binding has them (bindings/rust/plume-hip) ----
+// The serde / wasm wire format (javascript/src/lib.rs:95-118,147-184): points as 33-byte SEC1-compressed records (02|03 || x; a record starting with 00 is the
+// identity), decompressed and validated on the GPU; a record that would fail AffinePoint::from_encoded_point gives false.  Arrays hold n records each; r_point33 /
+// hashed_to_curve_r33 are used for v1 only.
+inline std::vector<bool> verify_batch_sec1(bool v1, const std::vector<Bytes>& msgs, const Bytes& pk33, const Bytes& nullifier33, const Bytes& c, const Bytes& s, const Bytes& r_point33,
+                                           const Bytes& hashed_to_curve_r33, Engine& eng = Engine::shared()) {
+    const size_t n = msgs.size();
+    if (pk33.size() != 33 * n || nullifier33.size() != 33 * n || c.size() != 32 * n || s.size() != 32 * n || (v1 && (r_point33.size() != 33 * n || hashed_to_curve_r33.size() != 33 * n)))
+        throw std::invalid_argument("verify_batch_sec1: arrays must hold one record per message");
+    plume_hip::PackedMessages m;
+    for (const Bytes& x : msgs) m.push(x.data(), x.size());
+    Bytes ok(n);
+    if (n) plume_hip::check(plume_verify_batch_sec1(eng.ctx(), v1 ? 1 : 2, n, m.data(), m.off.data(), pk33.data(), nullifier33.data(), c.data(), s.data(), v1 ? r_point33.data() : nullptr,
+                                                    v1 ? hashed_to_curve_r33.data() : nullptr, ok.data()), "plume_verify_batch_sec1");
+    return std::vector<bool>(ok.begin(), ok.end());
+}
+// AffinePoint::to_encoded_point(true) as the fixed 33-byte record of that wire format (identity: 00 followed by zeros)
+inline std::array<uint8_t, 33> sec1_record(const AffinePoint& p) {
+    std::array<uint8_t, 33> r{};
+    if (!p.is_identity()) { r[0] = (uint8_t)(2 + (p.xy[63] & 1)); std::memcpy(r.data() + 1, p.xy.data(), 32); }
+    return r;
+}
+// Aggregate pre-filter (no reference counterpart; plume_hip.h plume_aggregate_check): true iff every V1 signature of the batch would verify() -- up to a false-accept
+// probability of 2^-126 over `seed`, 32 fresh random bytes the signers could not predict.  All-or-nothing: on false, verify_batch finds the culprits.
+inline bool aggregate_check_v1(const std::vector<PlumeSignature>& sigs, const Bytes32& seed, Engine& eng = Engine::shared()) {
+    plume_hip::PackedMessages m;
+    Bytes pk, nul, c, s, rp, hr;
+    for (const PlumeSignature& g : sigs) {
+        if (!g.v1specific) throw std::invalid_argument("the aggregate check needs the V1 fields r_point / hashed_to_curve_r");
+        m.push(g.message.data(), g.message.size());
+        pk.insert(pk.end(), g.pk.xy.begin(), g.pk.xy.end());
+        nul.insert(nul.end(), g.nullifier.xy.begin(), g.nullifier.xy.end());
+        c.insert(c.end(), g.c.to_bytes().begin(), g.c.to_bytes().end());
+        s.insert(s.end(), g.s.to_bytes().begin(), g.s.to_bytes().end());
+        rp.insert(rp.end(), g.v1specific->r_point.xy.begin(), g.v1specific->r_point.xy.end());
+        hr.insert(hr.end(), g.v1specific->hashed_to_curve_r.xy.begin(), g.v1specific->hashed_to_curve_r.xy.end());
+    }
+    uint8_t rec[PLUME_AGG_RESULT_BYTES];
+    static const uint8_t none[64] = {0};
+    const bool e = sigs.empty();
+    plume_hip::check(plume_aggregate_check(eng.ctx(), 1, 0, sigs.size(), m.data(), m.off.data(), e ? none : pk.data(), e ? none : nul.data(), e ? none : c.data(), e ? none : s.data(),
+                                           e ? none : rp.data(), e ? none : hr.data(), seed.data(), nullptr, rec), "plume_aggregate_check");
+    return rec[0] == 1;
+}
+// The application step after verification (reference README.md:5: one nullifier per (pk, message)): first[i] is true iff item i is live and no live item with the
+// same nullifier comes before it.  `live` may be empty (all items take part), e.g. pass verify_batch's result.
+inline std::vector<bool> nullifier_first_occurrence(const std::vector<AffinePoint>& nullifiers, const std::vector<bool>& live = {}, Engine& eng = Engine::shared()) {
+    const size_t n = nullifiers.size();
+    if (!live.empty() && live.size() != n) throw std::invalid_argument("live must be empty or hold one flag per nullifier");
+    Bytes nul(64 * n), lv(live.begin(), live.end()), first(n);
+    for (size_t i = 0; i < n; i++) std::memcpy(&nul[64 * i], nullifiers[i].xy.data(), 64);
+    if (n) plume_hip::check(plume_nullifier_first_occurrence(eng.ctx(), n, nul.data(), live.empty() ? nullptr : lv.data(), nullptr, first.data(), nullptr), "plume_nullifier_first_occurrence");
+    return std::vector<bool>(first.begin(), first.end());
+}
+// SecretKey::from(scalar).to_sec1_der() for a batch -- the encoding the wasm wrapper uses for `s` and `digest_private` (javascript/src/lib.rs:98-110): the 109-byte
+// SEC1 ECPrivateKey with publicKey = scalar * G, the generator multiplications on the GPU
+inline std::vector<std::array<uint8_t, 109>> scalars_to_sec1_der(const std::vector<NonZeroScalar>& scalars, Engine& eng = Engine::shared()) {
+    const size_t n = scalars.size();
+    Bytes flat(32 * n), der(109 * n), st(n);
+    for (size_t i = 0; i < n; i++) std::memcpy(&flat[32 * i], scalars[i].to_bytes().data(), 32);
+    if (n) plume_hip::check(plume_scalars_to_sec1_der_batch(eng.ctx(), n, flat.data(), der.data(), st.data()), "plume_scalars_to_sec1_der_batch");
+    std::vector<std::array<uint8_t, 109>> out(n);
+    for (size_t i = 0; i < n; i++) std::memcpy(out[i].data(), &der[109 * i], 109);
+    return out;
+}
+// SecretKey::from_sec1_der for that fixed form: nullopt where the reference returns Err
+inline std::optional<NonZeroScalar> scalar_from_sec1_der(const std::array<uint8_t, 109>& der) {
+    Bytes32 k; uint8_t ok = 0;
+    plume_hip::check(plume_sec1_der_to_scalars(1, der.data(), k.data(), &ok), "plume_sec1_der_to_scalars");
+    if (!ok) return std::nullopt;
+    return NonZeroScalar::from_repr(k);
+}
 
 // hash_to_curve(m, pk) (rust-k256/src/utils.rs:11-20): RFC 9380 hash_to_curve over m || SEC1c(pk)
 inline AffinePoint hash_to_curve(const Bytes& m, const AffinePoint& pk, Engine& eng = Engine::shared()) {

@@ -179,6 +179,52 @@ static void batch_twins() {
         ASSERT(one.c == out[4].c && one.s == out[4].s && one.nullifier == out[4].nullifier);
     }
 }
+// the steps either side of sign / verify: the 33-byte wire format, the aggregate pre-filter, first occurrences of nullifiers, SEC1-DER scalars
+static void neighbouring_steps() {
+    std::vector<SecretKey> keys;
+    std::vector<Bytes> msgs;
+    for (int i = 0; i < 40; i++) {
+        Bytes32 k{}; k[31] = (uint8_t)(i % 7 + 1); k[5] = 9;                            // 7 distinct signers ...
+        keys.push_back(SecretKey::from_bytes(k).value());
+        msgs.push_back(Bytes((size_t)(1 + i % 3), (uint8_t)('m' + i % 3)));             // ... x 3 distinct messages: 21 distinct (pk, message) pairs among 40 items
+    }
+    Mock rng;
+    std::vector<PlumeSignature> sigs = sign_batch(keys, msgs, true, rng);
+    // SEC1 wire format: the same verdicts as the 64-byte form, and a record that does not decode is `false`
+    Bytes pk33, nul33, c, s, r33, h33;
+    for (const PlumeSignature& g : sigs) {
+        auto a = sec1_record(g.pk), b = sec1_record(g.nullifier), r = sec1_record(g.v1specific->r_point), h = sec1_record(g.v1specific->hashed_to_curve_r);
+        pk33.insert(pk33.end(), a.begin(), a.end()); nul33.insert(nul33.end(), b.begin(), b.end()); r33.insert(r33.end(), r.begin(), r.end()); h33.insert(h33.end(), h.begin(), h.end());
+        c.insert(c.end(), g.c.to_bytes().begin(), g.c.to_bytes().end()); s.insert(s.end(), g.s.to_bytes().begin(), g.s.to_bytes().end());
+    }
+    ASSERT(verify_batch_sec1(true, msgs, pk33, nul33, c, s, r33, h33) == std::vector<bool>(sigs.size(), true));
+    Bytes bad = nul33; bad[33 * 3] = 4;                                                  // tag 04 in a 33-byte record
+    bad[33 * 5] ^= 1;                                                                    // the other root: a different (valid) point
+    std::vector<bool> want(sigs.size(), true); want[3] = false; want[5] = false;
+    ASSERT(verify_batch_sec1(true, msgs, pk33, bad, c, s, r33, h33) == want);
+    // aggregate pre-filter: an honest batch passes, one changed item fails it
+    Bytes32 seed; for (size_t i = 0; i < 32; i++) seed[i] = (uint8_t)(i * 7 + 1);
+    ASSERT(aggregate_check_v1(sigs, seed));
+    std::vector<PlumeSignature> forged = sigs;
+    std::swap(forged[11].v1specific->hashed_to_curve_r, forged[12].v1specific->hashed_to_curve_r);   // (every nonce is R here, so the r_points are all equal)
+    ASSERT(!aggregate_check_v1(forged, seed));
+    ASSERT(verify_batch(forged) == [&] { std::vector<bool> w(forged.size(), true); w[11] = w[12] = false; return w; }());
+    // first occurrences: item i repeats the (key, message) pair of item i - 21 (7 x 3 pairs, period lcm(7, 3) = 21)
+    std::vector<AffinePoint> nuls;
+    for (const PlumeSignature& g : sigs) nuls.push_back(g.nullifier);
+    std::vector<bool> first = nullifier_first_occurrence(nuls);
+    for (size_t i = 0; i < first.size(); i++) ASSERT(first[i] == (i < 21));
+    std::vector<bool> live(nuls.size(), true); live[2] = false;                         // item 2 takes no part: its repeat (item 23) becomes the first
+    first = nullifier_first_occurrence(nuls, live);
+    ASSERT(!first[2] && first[23] && !first[24]);
+    // SEC1-DER: the record embeds scalar * G and round-trips
+    const auto der = scalars_to_sec1_der({sigs[0].s, keys[3].to_nonzero_scalar()});
+    ASSERT(der.size() == 2 && der[1][0] == 0x30 && der[1][1] == 0x6b);
+    ASSERT(AffinePoint::from_bytes64(der[1].data() + 45) == keys[3].public_key());
+    ASSERT(scalar_from_sec1_der(der[0]).value() == sigs[0].s);
+    auto broken = der[0]; broken[2] ^= 1;
+    ASSERT(!scalar_from_sec1_der(broken).has_value());
+}
 // invariants of the Rust types at the boundary of this API
 static void type_invariants() {
     ASSERT(!NonZeroScalar::from_repr(Bytes32{}).has_value());                                          // zero
@@ -315,7 +361,7 @@ int main(int argc, char** argv) {
         {"verification::plume_v1_test", verification::plume_v1_test}, {"verification::plume_v2_test", verification::plume_v2_test},
         {"verification::test_hash_to_curve", verification::test_hash_to_curve}, {"lib::test_encode_pt", verification::test_encode_pt},
         {"verification::verify_rejects_changed_fields", verification::verify_rejects_changed_fields}, {"verification::batch_twins", verification::batch_twins},
-        {"verification::type_invariants", verification::type_invariants},
+        {"verification::type_invariants", verification::type_invariants}, {"verification::neighbouring_steps", verification::neighbouring_steps},
         {"arkworks::test_keygen", arkworks::test_keygen}, {"arkworks::test_sign_and_verify", arkworks::test_sign_and_verify},
         {"arkworks::test_against_zk_nullifier_sig_pk", arkworks::test_against_zk_nullifier_sig_pk}, {"arkworks::test_against_zk_nullifier_sig_g_r", arkworks::test_against_zk_nullifier_sig_g_r},
         {"arkworks::test_against_zk_nullifier_sig_h", arkworks::test_against_zk_nullifier_sig_h},
