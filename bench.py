@@ -75,13 +75,18 @@ def plan(scaling: str, log2_batch: int, world: int, rank: int):
     return total, start, stop
 
 
+FETCH_SIZE_FACTOR = 2.0   # gfx950: FETCH_SIZE tallies a 128-byte request at 64 bytes (MI355X_MICROARCH.md, HBM).  The guide calibrated that on wide coalesced streams and asks for a
+                          # calibration "in your own access pattern": profiles/r02_fetch_calibration.json (tests/gpu_debug/fetch_calibration.py, the library's table-gather probe:
+                          # 63.9 bytes reported per gather of one 128-byte row) confirms the factor for the multi-scalar kernel's per-lane table gathers.  WRITE_SIZE is taken as reported.
+
+
 def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json: FETCH_SIZE + WRITE_SIZE,
-    separate --pmc runs of this same bench; raw counter values, see the file's _notes for the gfx950 calibration caveat), or None"""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json: separate --pmc runs of this same bench for FETCH_SIZE and
+    WRITE_SIZE), corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2, calibrated on this access pattern), or None"""
     try:
         f = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))[-1]
         d = json.loads(f.read_text())[kernel]
-        return int((d["FETCH_SIZE_KB_raw"] + d["WRITE_SIZE_KB_raw"]) * 1024), f"profiles/{f.name} (2^20-item launch)"
+        return int((FETCH_SIZE_FACTOR * d["FETCH_SIZE_KB_raw"] + d["WRITE_SIZE_KB_raw"]) * 1024), f"profiles/{f.name} (2^20-item launch)"
     except Exception:
         return None, None
 
@@ -366,15 +371,15 @@ def main():
                                     "unit": "32-bit MAC/s", "frac": round(msm / mad_rate, 4),
                                     "peak_measured_this_run": round(mad_measured, 1) if mad_measured else None, "peak_spec_half_rate": MAD_PEAK_SPEC,
                                     "frac_of_spec_half_rate": round(msm / MAD_PEAK_SPEC, 4),
-                                    "traffic": traffic_bytes, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, raw)",
+                                    "traffic": traffic_bytes, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE; the factor 2 of gfx950's FETCH_SIZE calibrated on this kernel's access pattern, profiles/r02_fetch_calibration.json)",
                                     "accounting": f"{FPMUL_MSM_PER_ITEM} Fp-mult per verify in this kernel (s*G - c*pk: 1900, s*H - c*nul: 2260) x {MACS_PER_FPMUL} MACs x {n} items per launch "
                                                   f"(SURVEY.md §8d, frozen in BASELINE.md §4); the 9x29-limb code issues 103 multiply-adds per Fp-mult, the accounting stays on the frozen 72"}
             line["hbm_view"] = {"bound": "hbm", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(hbm_achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": BYTES_PER_ITEM[ver] * n,
                                 "traffic": round(traffic_bytes / dom_s / 1e9, 1) if traffic_bytes else None, "traffic_bytes_per_launch": traffic_bytes,
                                 "traffic_over_algorithmic": round(traffic_bytes / (BYTES_PER_ITEM[ver] * n), 1) if traffic_bytes else None,
-                                "traffic_note": (f"raw FETCH_SIZE+WRITE_SIZE of {tsrc}: the per-lane gathers of the HBM-resident window tables; uncorrected (the guide's 2x FETCH_SIZE "
-                                                 f"correction is calibrated for wide coalesced streams, these are 16-byte per-lane gathers)") if tb else None,
+                                "traffic_note": (f"2 x FETCH_SIZE + WRITE_SIZE of {tsrc}: the per-lane gathers of the HBM-resident window tables (one 128-byte row per table addition, counted by gfx950's "
+                                                 f"FETCH_SIZE as 64 bytes: calibrated with the library's gather probe, profiles/r02_fetch_calibration.json)") if tb else None,
                                 "note": "the path is integer-VALU bound (SURVEY.md §8d): see roofline"}
             if mad_measured:
                 step_s = sum(stages.values()) * 1e-3

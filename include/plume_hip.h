@@ -280,7 +280,10 @@ int plume_aggregate_check_device(plume_ctx* ctx, int version, int mode, size_t n
 int plume_last_stage_times(plume_ctx* ctx, const char** names, float* ms, int cap);
 /* VALU issue-rate microbenchmark (32 waves per CU, 8 independent chains per lane, `iters` x 8 instructions per lane):
  * returns operations per second chip-wide (<= 0 on error).  kind: 0 v_mad_u64_u32, 1 v_addc_co_u32, 2 v_mul_lo_u32,
- * 3 v_mad_u32_u24, 4 v_add_u32, 5 one Fp multiplication, 6 one Fp squaring, 7 v_fma_f64, 8 v_lshl_add_u64. */
+ * 3 v_mad_u32_u24, 4 v_add_u32, 5 one Fp multiplication, 6 one Fp squaring, 7 v_fma_f64, 8 v_lshl_add_u64.
+ * kind 9 is the calibration probe of the HBM counters: 2048 x CUs lanes each gather, `iters` times, the five 16-byte quads of a table addition from a
+ * pseudo-random 128-byte row of the context's window-table buffer (needs a verify of >= 2^19 items on the context first); returns gathers per second.  Run under
+ * `rocprofv3 --pmc FETCH_SIZE` it tells what the counter reports per gather of this access pattern (profiles/README.md). */
 double plume_microbench(plume_ctx* ctx, int kind, int iters);
 /* s_memtime ticks that workgroup 0 spent inside the last microbenchmark kernel (and its event duration in ms). */
 double plume_microbench_last_ticks(float* ms);

@@ -12,6 +12,7 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <algorithm>
 #include <memory>
 #include <vector>
 
@@ -1173,11 +1174,27 @@ extern "C" double plume_microbench_last_ticks(float* ms) { if (ms) *ms = g_micro
 extern "C" double plume_microbench(plume_ctx* ctx, int kind, int iters) {
     if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
     if (bind(ctx)) return -1.0;
-    if (iters <= 0 || kind < 0 || kind > 8) { fail(PLUME_ERR_ARG, "plume_microbench: bad argument"); return -1.0; }
+    if (iters <= 0 || kind < 0 || kind > 9) { fail(PLUME_ERR_ARG, "plume_microbench: bad argument"); return -1.0; }
     if (ctx->sink.ensure(128 * 4)) return -1.0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return -1.0;
     const int blocks = prop.multiProcessorCount * 8;  // 32 waves per CU
+    if (kind == 9) {
+        // the table-gather probe runs over the context's window-table buffer, which must dwarf the caches (a 2^20-item verify leaves 3 GiB there)
+        if (ctx->tab.cap < ((size_t)1 << 30)) { fail(PLUME_ERR_ARG, "plume_microbench(9): run a verify of >= 2^19 items on this context first (the probe gathers from its window-table buffer)"); return -1.0; }
+        const uint32_t nrows = (uint32_t)std::min<size_t>(ctx->tab.cap / 128, 0xFFFFFFF0u);
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+        (void)hipEventRecord(e0, ctx->stream);
+        launch_gather_probe(ctx->tab.as<uint32_t>(), nrows, iters, ctx->sink.as<uint32_t>(), blocks, ctx->stream);
+        (void)hipEventRecord(e1, ctx->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) return -1.0;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        g_microbench_ms = ms;
+        return (double)iters * (double)blocks * kBlock / ((double)ms * 1e-3);   // gathers (of 80 bytes from one 128-byte row) per second
+    }
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
     launch_microbench(kind, 16, ctx->sink.as<uint32_t>(), blocks, ctx->stream);  // warm-up

@@ -377,6 +377,25 @@ __global__ __launch_bounds__(kBlock) void k_microbench(int kind, int iters, uint
     if (out == 0x12345678u) sink[tid & 63] = out;  // keep the chains live without measurable traffic
 }
 
+// Calibration probe for the HBM counters (MI355X_MICROARCH.md: FETCH_SIZE is calibrated for wide coalesced streams only -- "calibrate on a known byte count in
+// your own access pattern"): the multi-scalar kernel's access pattern with a known count.  Every lane gathers the five 16-byte quads of a table addition (x, y and
+// the top-limb quad: quads 0, 1, 2, 3, 6 of ONE 128-byte row) from a pseudo-random row of a buffer far larger than the caches, `iters` times.
+__global__ __launch_bounds__(kBlock) void k_gather_probe(const uint4* tab, uint32_t nrows, int iters, uint32_t* sink) {
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t h = tid * 2654435761u + 0x9E3779B9u, acc = 0;
+    for (int it = 0; it < iters; it++) {
+        h = h * 1664525u + 1013904223u;
+        const uint4* row = tab + (size_t)((h >> 4) % nrows) * 8;
+        const uint4 a = row[0], b = row[1], c = row[2], d = row[3], e = row[6];
+        acc ^= a.x ^ b.y ^ c.z ^ d.w ^ e.x;
+        h ^= acc & 1u;                                  // the next address depends on the data: no run-ahead beyond what a table addition has either
+    }
+    if (acc == 0x12345678u) sink[tid & 63] = acc;
+}
+void launch_gather_probe(const uint32_t* tab, uint32_t nrows, int iters, uint32_t* sink, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_gather_probe, dim3(blocks), dim3(kBlock), 0, st, reinterpret_cast<const uint4*>(tab), nrows, iters, sink);
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static inline unsigned nblocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 

@@ -37,5 +37,6 @@ void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, uint32_t* scr
 size_t dedup_blockcnt_bytes(size_t n);                    // size of DedupArgs::blockcnt
 void launch_dedup(const DedupArgs& a, hipStream_t st);   // clear, insert, mark, sum (plume_dedup.h)
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st);
+void launch_gather_probe(const uint32_t* tab, uint32_t nrows, int iters, uint32_t* sink, int blocks, hipStream_t st);   // HBM-counter calibration (plume_microbench kind 9)
 
 }  // namespace plume
