@@ -59,11 +59,18 @@ def glv(ks):
     dig = np.zeros((len(ks), 66), dtype=np.int8)
     lib().ds_glv(C.c_size_t(len(ks)), _p(K, u32p), _p(out, u32p), dig.ctypes.data_as(C.POINTER(C.c_int8)))
     res = []
+    nd = (128 + wbits()) // wbits()                    # PLUME_NDIG: 33 digits per half for 4-bit windows
     for r in range(len(ks)):
         m1 = sum(int(out[r, i]) << (32 * i) for i in range(4))
         m2 = sum(int(out[r, 5 + i]) << (32 * i) for i in range(4))
-        res.append((m1, int(out[r, 4]), m2, int(out[r, 9]), dig[r, :33].tolist(), dig[r, 33:].tolist()))
+        res.append((m1, int(out[r, 4]), m2, int(out[r, 9]), dig[r, :nd].tolist(), dig[r, nd:2 * nd].tolist()))
     return res
+
+
+def wbits():
+    """window width of the build under test (PLUME_WBITS)"""
+    lib().ds_wbits.restype = C.c_uint32
+    return int(lib().ds_wbits())
 
 
 def sha256(data: bytes):
@@ -167,9 +174,10 @@ def registers_from_be(values):
 
 
 def tables_raw(points):
-    """window tables (1P..8P as 64-byte records) of raw, UNVALIDATED affine bases built by one lane"""
+    """window tables (1P..8P as 64-byte records; 1P..16P in the 5-bit-window build) of raw, UNVALIDATED affine bases built by one lane"""
     pts = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 64)
-    out = np.zeros((len(pts), 8, 64), dtype=np.uint8)
+    lib().ds_tab_entries.restype = C.c_uint32
+    out = np.zeros((len(pts), int(lib().ds_tab_entries()), 64), dtype=np.uint8)
     lib().ds_tables_raw(C.c_uint32(len(pts)), _p(pts), _p(out))
     return out
 

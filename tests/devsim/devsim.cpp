@@ -65,7 +65,8 @@ void ds_sc_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32
         for (int k = 0; k < 8; k++) out[8 * i + k] = r.v[k];
     }
 }
-// k (8 limbs) -> m1[4], neg1, m2[4], neg2 (10 words) and 66 digits (int8)
+uint32_t ds_wbits() { return PLUME_WBITS; }                  // window width of this build (4; 5 in the A/B build)
+// k (8 limbs) -> m1[4], neg1, m2[4], neg2 (10 words) and 2 x PLUME_NDIG digits (int8) in rows of 66
 void ds_glv(size_t count, const uint32_t* k, uint32_t* out, int8_t* digits) {
     for (size_t i = 0; i < count; i++) {
         sc x; for (int j = 0; j < 8; j++) x.v[j] = k[8 * i + j];
@@ -74,7 +75,7 @@ void ds_glv(size_t count, const uint32_t* k, uint32_t* out, int8_t* digits) {
         for (int j = 0; j < 4; j++) { out[10 * i + j] = h1.m[j]; out[10 * i + 5 + j] = h2.m[j]; }
         out[10 * i + 4] = h1.neg; out[10 * i + 9] = h2.neg;
         booth_store(digits + 66 * i, 1, h1, false);
-        booth_store(digits + 66 * i + 33, 1, h2, false);
+        booth_store(digits + 66 * i + PLUME_NDIG, 1, h2, false);
     }
 }
 void ds_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
@@ -128,7 +129,7 @@ static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobf
 }
 
 // window tables of `nb` affine bases given as raw 64-byte records, all flagged usable WITHOUT validation, built by ONE lane (test hook for the
-// zero-denominator guard of table_build_affine); out: nb x 8 x 64 bytes (x || y of 1P..8P)
+// zero-denominator guard of table_build_affine); out: nb x PLUME_TAB_ENTRIES x 64 bytes (x || y of 1P..)
 void ds_tables_raw(uint32_t nb, const uint8_t* pts, uint8_t* out) {
     std::vector<uint32_t> bases(PLUME_JAC_WORDS * (size_t)nb), tab((size_t)nb * PLUME_TAB_WORDS);
     std::vector<uint8_t> flags(nb, (uint8_t)(PLUME_JOB_OK | PLUME_JOB_AFFINE));
@@ -140,13 +141,14 @@ void ds_tables_raw(uint32_t nb, const uint8_t* pts, uint8_t* out) {
     }
     run_tables(tab.data(), bases.data(), flags.data(), nb, (int)nb);
     for (uint32_t j = 0; j < nb; j++)
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < PLUME_TAB_ENTRIES; k++) {
             fe x, y; alignas(16) uint8_t rec[64];
             ld_tab_xy(x, y, tab.data() + (size_t)j * PLUME_TAB_WORDS + k * PLUME_TAB_ENTRY_WORDS, false);
             store_affine_be(rec, x, y, false);
-            memcpy(out + 64 * (8 * (size_t)j + k), rec, 64);
+            memcpy(out + 64 * (PLUME_TAB_ENTRIES * (size_t)j + k), rec, 64);
         }
 }
+uint32_t ds_tab_entries() { return PLUME_TAB_ENTRIES; }     // rows per window table of this build (8: 4-bit windows; 16: the 5-bit A/B build)
 
 // simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)
 static const uint32_t B = 8;

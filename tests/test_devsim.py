@@ -84,9 +84,10 @@ def test_glv_and_booth():
         k1 = -m1 if n1 else m1
         k2 = -m2 if n2 else m2
         assert (k1 + k2 * lam) % N == k
+        w = D.wbits()
         for m, neg, d in ((m1, n1, d1), (m2, n2, d2)):
-            assert all(-8 <= x <= 8 for x in d)
-            assert sum(x * 16**i for i, x in enumerate(d)) == (-m if neg else m)
+            assert len(d) == (128 + w) // w and all(-(1 << (w - 1)) <= x <= 1 << (w - 1) for x in d)
+            assert sum(x << (w * i) for i, x in enumerate(d)) == (-m if neg else m)
 
 
 def test_sha256_generic():
@@ -428,12 +429,13 @@ def test_affine_table_chain_and_its_zero_denominator_guard():
     pts = [O.G, O.pt_mul(rng.randrange(1, N), O.G), O.pt_mul(N - 1, O.G), O.pt_mul(rng.randrange(1, N), O.G)]
     rec = lambda p: p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")  # noqa: E731
     good = np.frombuffer(b"".join(rec(p) for p in pts), dtype=np.uint8).reshape(-1, 64)
-    want = [[O.pt_bytes(O.pt_mul(k, p)) for k in range(1, 9)] for p in pts]
     got = D.tables_raw(good)
-    assert [[got[j, k].tobytes() for k in range(8)] for j in range(len(pts))] == want
+    E = got.shape[1]                                                   # 8 rows (16 in the 5-bit-window build)
+    want = [[O.pt_bytes(O.pt_mul(k, p)) for k in range(1, E + 1)] for p in pts]
+    assert [[got[j, k].tobytes() for k in range(E)] for j in range(len(pts))] == want
     bogus = (5).to_bytes(32, "big") + bytes(32)                        # y = 0
     mixed = np.concatenate([good[:2], np.frombuffer(bogus, dtype=np.uint8).reshape(1, 64), good[2:]])
     got = D.tables_raw(mixed)
     for j, src in enumerate([0, 1, None, 2, 3]):
         if src is not None:
-            assert [got[j, k].tobytes() for k in range(8)] == want[src], j
+            assert [got[j, k].tobytes() for k in range(E)] == want[src], j

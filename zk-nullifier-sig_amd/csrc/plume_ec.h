@@ -183,29 +183,39 @@ PLUME_HD void glv_split(glv_half& h1, glv_half& h2, const sc& k) {
     PLUME_UNROLL for (int i = 0; i < 4; i++) { h1.m[i] = h1.neg ? n1.v[i] : k1.v[i]; h2.m[i] = h2.neg ? n2.v[i] : k2.v[i]; }
 }
 
-// Booth recoding, w = 4: m = sum d_i 16^i, d_i in [-8, 8], i = 0..32.  d_i = k_{4i-1} + k_{4i} + 2k_{4i+1} + 4k_{4i+2} - 8k_{4i+3}.
-#define PLUME_NDIG 33
+// Booth recoding, window w = PLUME_WBITS (4; 5 is the A/B build of DESIGN.md §10): m = sum d_i 2^(w i), d_i in [-2^(w-1), 2^(w-1)], i = 0..NDIG-1 covering 129 bits.
+// w = 4: d_i = k_{4i-1} + k_{4i} + 2k_{4i+1} + 4k_{4i+2} - 8k_{4i+3}.
+#ifndef PLUME_WBITS
+#define PLUME_WBITS 4
+#endif
+#define PLUME_NDIG ((128 + PLUME_WBITS) / PLUME_WBITS)       // 33 for w = 4, 26 for w = 5
 PLUME_HD int booth_digit(const uint32_t m[4], int i) {
-    // u = bits [4i-1, 4i+3] of m (bit -1 = 0); i is a compile-time constant after unrolling
-    int lo = 4 * i - 1;
+    // u = bits [w i - 1, w i + w - 1] of m (bit -1 = 0); i is a compile-time constant after unrolling
+    const int W = PLUME_WBITS, lo = W * i - 1;
+    const uint32_t mask = (1u << (W + 1)) - 1u;
     uint32_t u;
     if (lo < 0) {
-        u = (m[0] << 1) & 0x1F;
+        u = (m[0] << 1) & mask;
     } else {
         int wi = lo >> 5, sh = lo & 31;
         uint32_t a = wi < 4 ? m[wi] : 0u, b = (wi + 1) < 4 ? m[wi + 1] : 0u;
-        u = (sh == 0 ? a : ((a >> sh) | (sh > 27 ? (b << (32 - sh)) : 0u))) & 0x1F;
+        u = (sh == 0 ? a : ((a >> sh) | (sh > 31 - W ? (b << (32 - sh)) : 0u))) & mask;
     }
-    return (int)(u & 1) + (int)((u >> 1) & 7) - (int)((u >> 4) << 3);
+    return (int)(u & 1) + (int)((u >> 1) & ((1u << (W - 1)) - 1u)) - (int)((u >> W) << (W - 1));
 }
 // Booth recoding with a WIDE window for the generator's slots of the verifier: m = sum d_k 2^(W k), d_k in [-2^(W-1), 2^(W-1)].
 // W = PLUME_GW must be a multiple of 4 so that digit k lines up with the 4-bit window i = k * W/4 of the shared doubling chain.
 // W = 12: 11 digits per 128-bit half (22 generator additions per verify instead of 34 with W = 8) from a 2048-entry table (256 KiB, L2-resident);
 // W = 16: 9 digits per half (18 additions) from 32768 entries (4 MiB: L2 / MALL), built once per context in ~0.2 s.
 #ifndef PLUME_GW
+#if PLUME_WBITS == 5
+#define PLUME_GW 15   // the widest multiple of 5 whose magnitudes (<= 2^14) still fit the two-byte digit form: 16384 entries (2 MiB), 9 digits per half
+#else
 #define PLUME_GW 16   // round 2: 32768 entries (4 MiB), 9 digits per half: 18 generator additions per verify (W = 12: 2048 entries, 22 additions; measured -1.1 % on the kernel)
 #endif
-#define PLUME_GWS (PLUME_GW / 4)                          // 4-bit windows per wide digit
+#endif
+static_assert(PLUME_GW % PLUME_WBITS == 0, "a wide digit must line up with the windows of the shared doubling chain");
+#define PLUME_GWS (PLUME_GW / PLUME_WBITS)                // windows per wide digit
 #define PLUME_NDIGW ((128 + PLUME_GW) / PLUME_GW)         // digits covering 129 bits: 11 for W = 12, 17 for W = 8
 #define PLUME_GTAB_ENTRIES (1 << (PLUME_GW - 1))
 PLUME_HD int booth_digit_w(const uint32_t m[4], int k) {
@@ -233,11 +243,12 @@ PLUME_HD void booth_store_wide(int8_t* dig, uint32_t stride, const glv_half& h, 
         const int pos = PLUME_GWS * k;
         if (pos + 1 < PLUME_NDIG) {
             dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)(mag & 0xFF);
-#if PLUME_GW > 12   // magnitudes up to 2^(W-1) need the whole second byte: the sign moves to a third one (W >= 12 leaves room: W/4 >= 3 positions per digit)
+#if PLUME_GW > 15   // magnitudes up to 2^15 need the whole second byte: the sign moves to a third one (3 positions per digit are there)
+            static_assert(PLUME_GW <= 15 || PLUME_GWS >= 3, "three digit-row positions per wide digit");
             dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)((mag >> 8) & 0xFF);
             dig[(uint32_t)(pos + 2) * stride] = (int8_t)((mag != 0 && dn) ? 1 : 0);
 #else
-            dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)(((mag >> 8) & 0xF) | ((mag != 0 && dn) ? 0x80 : 0));
+            dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)(((mag >> 8) & 0x7F) | ((mag != 0 && dn) ? 0x80 : 0));
 #endif
         } else {
             dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)((mag & 0x3F) | ((mag != 0 && dn) ? 0x40 : 0));
@@ -258,7 +269,7 @@ PLUME_HD void booth_store(int8_t* dig, uint32_t stride, const glv_half& h, bool 
 //     [ x0..x7 | y0..y7 | b0..b7 | x8 y8 b8 0 | 0 0 0 0 ]        b = beta * x (the x of lambda*P)
 // i.e. eight 16-byte quads; one table addition gathers five of them (x or b, y, the top limbs) with aligned 16-byte loads from
 // ONE line, and the table kernel writes whole lines (112-byte rows, without the padding quad, measured 6 % slower there).
-#define PLUME_TAB_ENTRIES 8
+#define PLUME_TAB_ENTRIES (1 << (PLUME_WBITS - 1))       // 8 (w = 4) or 16 (w = 5) rows per table
 #define PLUME_FE_W PLUME_FE_WORDS
 #define PLUME_JAC_WORDS (3 * PLUME_FE_WORDS)      // Jacobian point in HBM scratch: x | y | z
 #ifndef PLUME_TAB_ENTRY_WORDS
@@ -406,7 +417,11 @@ PLUME_HD void pre_st(uint32_t* scr, size_t sstride, size_t slane, size_t q, cons
 PLUME_HD void pre_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, size_t q) {
     PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = scr[((q * PLUME_FE_W + (size_t)i) * sstride) + slane];
 }
+#if PLUME_TAB_ENTRIES == 16
+#define PLUME_TAB_AFF_SCR_WORDS (3 * PLUME_FE_WORDS)       // ... and two for level 4 (its eight denominators go in two halves)
+#else
 #define PLUME_TAB_AFF_SCR_WORDS (2 * PLUME_FE_WORDS)       // prefix products per job: ONE per level (below), two alternating regions (consecutive levels overlap)
+#endif
 // 2P from affine P = (x, y) (tight) and l = 1 / (2y)
 PLUME_HD void aff_dbl(fe& x3, fe& y3, const fe& x, const fe& y, const fe& l) {
     fe lam, t, t2;
@@ -481,6 +496,16 @@ PLUME_HD void tab_den_l3(fe d[4], fe& p01, fe& p23, fe& D, const fe& x1, const f
     PLUME_UNROLL for (int k = 0; k < 4; k++) guard_one(d[k], guard);
     fe_mul(p01, d[0], d[1]); fe_mul(p23, d[2], d[3]); fe_mul(D, p01, p23);
 }
+// level 4 (16-row tables only), in two halves of four denominators each, same shape as level 3:
+//   half A  9P = 8P + P, 10P = 2 * 5P, 11P = 8P + 3P, 12P = 2 * 6P:   x8 - x1, 2 y5, x8 - x3, 2 y6
+//   half B 13P = 8P + 5P, 14P = 2 * 7P, 15P = 8P + 7P, 16P = 2 * 8P:  x8 - x5, 2 y7, x8 - x7, 2 y8
+PLUME_HD void tab_den_l4(fe d[4], fe& p01, fe& p23, fe& D, const fe& xa, const fe& ya, const fe& xb, const fe& yb, const fe& x8, bool guard) {
+    fe_sub_lazy<2>(d[0], x8, xa); fe_dbl_lazy(d[1], ya); fe_sub_lazy<2>(d[2], x8, xb); fe_dbl_lazy(d[3], yb);
+    PLUME_UNROLL for (int k = 0; k < 4; k++) guard_one(d[k], guard);
+    fe_mul(p01, d[0], d[1]); fe_mul(p23, d[2], d[3]); fe_mul(D, p01, p23);
+}
+PLUME_HD void ld_tab_x(fe& x, const uint32_t* e) { PLUME_UNROLL for (int i = 0; i < 8; i++) x.v[i] = e[i]; x.v[8] = e[24]; }
+PLUME_HD void ld_tab_y(fe& y, const uint32_t* e) { PLUME_UNROLL for (int i = 0; i < 8; i++) y.v[i] = e[8 + i]; y.v[8] = e[25]; }
 // Level k+1's denominators are formed -- and their product joins the lane's chain -- inside level k's finishing pass, while the entries they come from are
 // still in registers: four passes over a lane's jobs instead of six, and no pass that only re-reads rows.  Consecutive levels therefore run through the
 // jobs in opposite directions (a level is finished in the reverse of the order its products were parked in) and use alternating scratch regions.
@@ -573,7 +598,10 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
         }
     }
     sink.inv(inv, acc, 3);
-    // ------------------------------------------------------------------------------- level 3, finish (jobs descending): 8P, 7P, 6P, 5P
+    // ------------------------------------------------------------------------------- level 3, finish (jobs descending): 8P, 7P, 6P, 5P  [+ level 4's denominators]
+#if PLUME_TAB_ENTRIES == 16
+    acc = fe_small(1);
+#endif
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
         uint32_t* t = tab + (j0 + (size_t)jj) * TW;
         fe x1, y1, x3, y3, x4, y4, d[4], p01, p23, D, Dinv, i01, i23, l, xr, yr, bx;
@@ -585,16 +613,98 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
         fe_mul(l, i23, d[2]);                                                       // 1 / (2 y4)
         aff_dbl(xr, yr, x4, y4, l);                                                 // 8P
         fe_mul_k(bx, beta, xr); sink(t + 7 * EW, xr, yr, bx);
+#if PLUME_TAB_ENTRIES == 16
+        // level 4's two products grow as the entries appear (the entries themselves are not kept): PA = (x8-x1)(2y5)(x8-x3)(2y6), PB = (x8-x5)(2y7)(x8-x7)(2y8)
+        fe x8 = xr, PA, PB, dd;
+        fe_dbl_lazy(PB, yr);                                                        // 2 y8
+#endif
         fe_mul(l, i23, d[3]);                                                       // 1 / (x4 - x3)
         aff_add(xr, yr, x3, y3, x4, y4, l);                                         // 7P
         fe_mul_k(bx, beta, xr); sink(t + 6 * EW, xr, yr, bx);
+#if PLUME_TAB_ENTRIES == 16
+        fe_dbl_lazy(dd, yr); fe_mul(PB, PB, dd);                                    // 2 y7
+        fe_sub_lazy<2>(dd, x8, xr); fe_mul(PB, PB, dd);                             // x8 - x7
+#endif
         fe_mul(l, i01, d[0]);                                                       // 1 / (2 y3)
         aff_dbl(xr, yr, x3, y3, l);                                                 // 6P
         fe_mul_k(bx, beta, xr); sink(t + 5 * EW, xr, yr, bx);
+#if PLUME_TAB_ENTRIES == 16
+        fe_dbl_lazy(PA, yr);                                                        // 2 y6
+#endif
         fe_mul(l, i01, d[1]);                                                       // 1 / (x4 - x1)
         aff_add(xr, yr, x1, y1, x4, y4, l);                                         // 5P
         fe_mul_k(bx, beta, xr); sink(t + 4 * EW, xr, yr, bx);
+#if PLUME_TAB_ENTRIES == 16
+        fe_dbl_lazy(dd, yr); fe_mul(PA, PA, dd);                                    // 2 y5
+        fe_sub_lazy<2>(dd, x8, xr); fe_mul(PB, PB, dd);                             // x8 - x5
+        fe_sub_lazy<2>(dd, x8, x1); fe_mul(PA, PA, dd);                             // x8 - x1
+        fe_sub_lazy<2>(dd, x8, x3); fe_mul(PA, PA, dd);                             // x8 - x3
+        tab_park(acc, scr, sstride, slane, RB + 2 * (size_t)jj, PA);
+        tab_park(acc, scr, sstride, slane, RB + 2 * (size_t)jj + 1, PB);
+#endif
     }
+#if PLUME_TAB_ENTRIES == 16
+    sink.sync();
+    if (guard || fe_is_zero(acc)) {                                                 // cold: the same products, from the rows, with the zero check
+        guard = true; acc = fe_small(1);
+        PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
+            const uint32_t* t = tab + (j0 + (size_t)jj) * TW;
+            fe xa, ya, xb, yb, x8, d[4], p01, p23, D;
+            ld_tab_x(x8, t + 7 * EW);
+            ld_tab_x(xa, t); ld_tab_y(ya, t + 4 * EW); ld_tab_x(xb, t + 2 * EW); ld_tab_y(yb, t + 5 * EW);
+            tab_den_l4(d, p01, p23, D, xa, ya, xb, yb, x8, true);
+            tab_park(acc, scr, sstride, slane, RB + 2 * (size_t)jj, D);
+            ld_tab_x(xa, t + 4 * EW); ld_tab_y(ya, t + 6 * EW); ld_tab_x(xb, t + 6 * EW); ld_tab_y(yb, t + 7 * EW);
+            tab_den_l4(d, p01, p23, D, xa, ya, xb, yb, x8, true);
+            tab_park(acc, scr, sstride, slane, RB + 2 * (size_t)jj + 1, D);
+        }
+    }
+    sink.inv(inv, acc, 4);
+    // ------------------------------------------------------------------------------- level 4, finish (jobs ascending; per job half B, then half A: the reverse of the parking order)
+    PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
+        uint32_t* t = tab + (j0 + (size_t)jj) * TW;
+        fe x8, y8, xa, ya, xb, yb, d[4], p01, p23, D, Dinv, i01, i23, l, xr, yr, bx;
+        ld_tab_xy(x8, y8, t + 7 * EW, false);
+        // half B: 13P = 8P + 5P, 14P = 2 * 7P, 15P = 8P + 7P, 16P = 2 * 8P
+        ld_tab_xy(xa, ya, t + 4 * EW, false); ld_tab_xy(xb, yb, t + 6 * EW, false);          // 5P, 7P
+        tab_den_l4(d, p01, p23, D, xa, yb, xb, y8, x8, guard);                        // x8 - x5, 2 y7, x8 - x7, 2 y8
+        tab_unpark(Dinv, inv, scr, sstride, slane, RB + 2 * (size_t)jj + 1, D);
+        fe_mul(i01, Dinv, p23); fe_mul(i23, Dinv, p01);
+        fe_mul(l, i01, d[1]);                                                       // 1 / (x8 - x5)
+        aff_add(xr, yr, xa, ya, x8, y8, l);                                         // 13P
+        fe_mul_k(bx, beta, xr); sink(t + 12 * EW, xr, yr, bx);
+        fe_mul(l, i01, d[0]);                                                       // 1 / (2 y7)
+        aff_dbl(xr, yr, xb, yb, l);                                                 // 14P
+        fe_mul_k(bx, beta, xr); sink(t + 13 * EW, xr, yr, bx);
+        fe_mul(l, i23, d[3]);                                                       // 1 / (x8 - x7)
+        aff_add(xr, yr, xb, yb, x8, y8, l);                                         // 15P
+        fe_mul_k(bx, beta, xr); sink(t + 14 * EW, xr, yr, bx);
+        fe_mul(l, i23, d[2]);                                                       // 1 / (2 y8)
+        aff_dbl(xr, yr, x8, y8, l);                                                 // 16P
+        fe_mul_k(bx, beta, xr); sink(t + 15 * EW, xr, yr, bx);
+        // half A: 9P = 8P + P, 10P = 2 * 5P, 11P = 8P + 3P, 12P = 2 * 6P
+        fe y5, y6;
+        ld_tab_xy(xa, ya, t, false); ld_tab_xy(xb, yb, t + 2 * EW, false);                   // P, 3P
+        ld_tab_y(y5, t + 4 * EW); ld_tab_y(y6, t + 5 * EW);
+        tab_den_l4(d, p01, p23, D, xa, y5, xb, y6, x8, guard);                        // x8 - x1, 2 y5, x8 - x3, 2 y6
+        tab_unpark(Dinv, inv, scr, sstride, slane, RB + 2 * (size_t)jj, D);
+        fe_mul(i01, Dinv, p23); fe_mul(i23, Dinv, p01);
+        fe_mul(l, i01, d[1]);                                                       // 1 / (x8 - x1)
+        aff_add(xr, yr, xa, ya, x8, y8, l);                                         // 9P
+        fe_mul_k(bx, beta, xr); sink(t + 8 * EW, xr, yr, bx);
+        fe_mul(l, i23, d[3]);                                                       // 1 / (x8 - x3)
+        aff_add(xr, yr, xb, yb, x8, y8, l);                                         // 11P
+        fe_mul_k(bx, beta, xr); sink(t + 10 * EW, xr, yr, bx);
+        fe_mul(i01, i01, d[0]);                                                     // 1 / (2 y5)
+        fe_mul(i23, i23, d[2]);                                                     // 1 / (2 y6)
+        ld_tab_xy(xa, ya, t + 4 * EW, false);                                       // 5P
+        aff_dbl(xr, yr, xa, ya, i01);                                               // 10P
+        fe_mul_k(bx, beta, xr); sink(t + 9 * EW, xr, yr, bx);
+        ld_tab_xy(xa, ya, t + 5 * EW, false);                                       // 6P
+        aff_dbl(xr, yr, xa, ya, i23);                                               // 12P
+        fe_mul_k(bx, beta, xr); sink(t + 11 * EW, xr, yr, bx);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ batched affine conversion
@@ -686,7 +796,7 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
     PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
         if (i != PLUME_NDIG - 1) {
-            PLUME_NOUNROLL for (int d = 0; d < 4; d++) jac_dbl(acc);
+            PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl(acc);
         }
         PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
             const uint32_t* tab = (s & 2) ? tab1 : tab0;
@@ -697,10 +807,10 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
                 bool dn;
                 if (i + 1 < PLUME_NDIG) {
                     const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
-#if PLUME_GW > 12
+#if PLUME_GW > 15
                     mag |= (hi & 0xFF) << 8; dn = dig[(uint32_t)(s * PLUME_NDIG + i + 2) * stride] != 0;
 #else
-                    mag |= (hi & 0xF) << 8; dn = (hi & 0x80) != 0;
+                    mag |= (hi & 0x7F) << 8; dn = (hi & 0x80) != 0;
 #endif
                 } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
                 d = dn ? -mag : mag;
