@@ -215,6 +215,7 @@ PLUME_HD int booth_digit(const uint32_t m[4], int i) {
 #endif
 #endif
 static_assert(PLUME_GW % PLUME_WBITS == 0, "a wide digit must line up with the windows of the shared doubling chain");
+static_assert(PLUME_GW <= 16, "the digit rows hold a wide digit as a 16-bit magnitude (two bytes) plus its sign");
 #define PLUME_GWS (PLUME_GW / PLUME_WBITS)                // windows per wide digit
 #define PLUME_NDIGW ((128 + PLUME_GW) / PLUME_GW)         // digits covering 129 bits: 11 for W = 12, 17 for W = 8
 #define PLUME_GTAB_ENTRIES (1 << (PLUME_GW - 1))
