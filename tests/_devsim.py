@@ -17,6 +17,10 @@ u64p = C.POINTER(C.c_uint64)
 def lib():
     global _lib
     if _lib is None:
+        import os
+        if os.environ.get("PLUME_DEVSIM_SO"):           # another build of the same harness (tests/test_devsim.py: the 5-bit-window build)
+            _lib = C.CDLL(os.environ["PLUME_DEVSIM_SO"])
+            return _lib
         srcs = [_DIR / "devsim.cpp"] + list((ROOT / "zk-nullifier-sig_amd" / "csrc").glob("*.h"))
         if not _SO.exists() or _SO.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
             subprocess.check_call(["make", "-s", "-C", str(_DIR)])

@@ -13,6 +13,7 @@ from tests import _devsim as D
 from tests import _oracle_c as OC
 from tests import synth
 
+ROOT = Path(__file__).resolve().parent.parent
 GOLD = json.loads((Path(__file__).parent / "golden" / "golden_batches.json").read_text())
 P, N = O.P, O.N
 PC = 2**32 + 977
@@ -439,3 +440,20 @@ def test_affine_table_chain_and_its_zero_denominator_guard():
     for j, src in enumerate([0, 1, None, 2, 3]):
         if src is not None:
             assert [got[j, k].tobytes() for k in range(E)] == want[src], j
+
+
+def test_five_bit_window_build_of_the_device_headers(tmp_path):
+    """-DPLUME_WBITS=5 (the A/B build of DESIGN.md §10: 26 Booth digits per half, 16-row tables with a fourth chain level, 15-bit generator window) stays correct: the
+    same harness built with that option passes the recoding, table-chain and whole-pipeline tests of this file (run in a child process: the harness is loaded once per process)"""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("PLUME_DEVSIM_SO"):
+        pytest.skip("already inside the child run")
+    so = tmp_path / "libplume_devsim_w5.so"
+    csrc = ROOT / "zk-nullifier-sig_amd" / "csrc"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DPLUME_FE_CHECK", "-DPLUME_WBITS=5", f"-I{csrc}", "-o", str(so), str(ROOT / "tests" / "devsim" / "devsim.cpp")],
+                   check=True, capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", str(Path(__file__)), "-k", "glv_and_booth or table or verify or sign or msm or golden"],
+                       env=dict(os.environ, PLUME_DEVSIM_SO=str(so)), capture_output=True, text=True, cwd=str(ROOT))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
