@@ -62,8 +62,13 @@ void plume_destroy(plume_ctx* ctx);
 const char* plume_last_error(void);
 /* Library / build information, e.g. "plume_hip 0.1 gfx950". */
 const char* plume_version(void);
-/* Upper bound on items processed per internal pass (workspace is ~7.1 KB per in-flight item). Default 1<<20. */
+/* Upper bound on items processed per internal pass (workspace is ~3.9 KB per in-flight item). Default 1<<20. */
 int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
+/* Device-resident verify / sign calls of >= 2^17 items are cut into `sub_batches` slices (default 4): validation + hash_to_curve and the window
+ * tables of slice k+1 run on a second stream of the context beside the multi-scalar kernel of slice k (that kernel saturates the vector ALUs and
+ * leaves HBM idle; the table kernel is the other way round).  Results do not depend on it.  1 = strictly serial launch order on the caller's
+ * stream, the mode in which plume_last_stage_times reports one time per kernel (env PLUME_SERIAL=1 makes it the default). */
+int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (three streams,
  * two staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each
  * following piece up to three times the one before, up to the largest piece (default 1<<19, capped by the chunk size); calls with large

@@ -1,4 +1,4 @@
-/* PLUME verify on the CPU, OPTIMISED — the second CPU leg of bench.py's cpu_baseline.  TEST / MEASUREMENT INFRASTRUCTURE, NOT PRODUCT CODE.
+/* PLUME verify, verify_non_zk and sign on the CPU, OPTIMISED — the second CPU leg of bench.py's cpu_baseline.  TEST / MEASUREMENT INFRASTRUCTURE, NOT PRODUCT CODE.
  *
  * The plain oracle (plume_oracle.c) is written to be read: no endomorphism, squaring = multiplication, exponentiation-ladder inversions, one
  * inversion per encoded point.  That understates what a tuned CPU library does (rust-k256 itself cannot be built here: no rustc / cargo), so this
@@ -8,8 +8,9 @@
  *     one interleaved (Strauss) doubling chain of 128 steps per equation with mixed Jacobian-affine additions;
  *   - ONE field inversion per signature for all window-table entries and the affine H (Montgomery's trick);
  *   - hash_to_curve with the inversion-free simplified SWU / isogeny (x kept as a fraction) and one square-root exponentiation per map.
- * Inputs with an identity point take the plain oracle's path (unreachable for honest signatures).  Every result is checked item by item against the
- * plain oracle in tests/test_cpu_fast.py; only tests/ and bench.py's cpu_baseline load this library.
+ * Inputs with an identity point take the plain oracle's path (unreachable for honest signatures).  Round 3: the signer (sign_fast_one: wNAF for the generator
+ * and for H, three shared inversions per signature), verify_non_zk and the SEC1 decompression, so that the GPU's 2^20-item batches can be checked item by item
+ * in seconds.  Every result is checked item by item against the plain oracle in tests/test_cpu_fast.py; only tests/ and bench.py's cpu_baseline load this library.
  */
 #include "plume_oracle.c" /* SHA-256, expand_message_xmd, Fn arithmetic, byte helpers, the reference-shaped slow path */
 
@@ -343,18 +344,23 @@ static void h2c_fast(pj *h, const uint8_t *msg, size_t mlen, const uint8_t enc[3
 
 /* ------------------------------------------------------------------------------------------------ verify */
 static void enc33(uint8_t out[33], const ff *x, const ff *y) { out[0] = (uint8_t)(2 + ff_is_odd(y)); ff_to_be(out + 1, x); }
-static int verify_fast_one(int version, const uint8_t *msg, size_t mlen, const uint8_t *pk_b, const uint8_t *nul_b, const uint8_t *c_b, const uint8_t *s_b,
-                           const uint8_t *r_b, const uint8_t *hr_b) {
-    static const uint8_t zero64[64] = {0};
+/* mode 0: PlumeSignature::verify (rust-k256/src/lib.rs:93-145); mode 1: plume_arkworks' verify_non_zk (rust-arkworks/src/tests.rs:28-78: the challenge hashed from
+ * the GIVEN r_point / hashed_to_curve_r, both equations for V1 and V2, c = digest_private; zero scalars and identity points take the plain oracle's path) */
+#define SLOW_VERIFY() (mode ? verify_non_zk_one(version, msg, mlen, pk_b, nul_b, s_b, r_b, hr_b, c_b) : verify_one(version, msg, mlen, pk_b, nul_b, c_b, s_b, r_b, hr_b))
+static int verify_fast_mode(int version, int mode, const uint8_t *msg, size_t mlen, const uint8_t *pk_b, const uint8_t *nul_b, const uint8_t *c_b, const uint8_t *s_b,
+                            const uint8_t *r_b, const uint8_t *hr_b) {
+    static const uint8_t zero64[64] = {0}, zero32[32] = {0};
+    const int given = version == 1 || mode;       /* r_point / hashed_to_curve_r are inputs */
     /* identity inputs: the reference-shaped slow path (encodings of one byte, cryptographically unreachable) */
-    if (!memcmp(pk_b, zero64, 64) || !memcmp(nul_b, zero64, 64) || (version == 1 && (!memcmp(r_b, zero64, 64) || !memcmp(hr_b, zero64, 64))))
-        return verify_one(version, msg, mlen, pk_b, nul_b, c_b, s_b, r_b, hr_b);
+    if (!memcmp(pk_b, zero64, 64) || !memcmp(nul_b, zero64, 64) || (given && (!memcmp(r_b, zero64, 64) || !memcmp(hr_b, zero64, 64))))
+        return SLOW_VERIFY();
+    if (mode && (!memcmp(c_b, zero32, 32) || !memcmp(s_b, zero32, 32))) return SLOW_VERIFY();   /* Fr elements: zero is a value there */
     sc c, s;
     if (!sc_from_be_nonzero(&c, c_b) || !sc_from_be_nonzero(&s, s_b)) return 0;
     pa pk, nul, rp, hrp;
     if (!ff_from_be_checked(&pk.x, pk_b) || !ff_from_be_checked(&pk.y, pk_b + 32) || !pa_on_curve(&pk.x, &pk.y)) return 0;
     if (!ff_from_be_checked(&nul.x, nul_b) || !ff_from_be_checked(&nul.y, nul_b + 32) || !pa_on_curve(&nul.x, &nul.y)) return 0;
-    if (version == 1) {
+    if (given) {
         if (!ff_from_be_checked(&rp.x, r_b) || !ff_from_be_checked(&rp.y, r_b + 32) || !pa_on_curve(&rp.x, &rp.y)) return 0;
         if (!ff_from_be_checked(&hrp.x, hr_b) || !ff_from_be_checked(&hrp.y, hr_b + 32) || !pa_on_curve(&hrp.x, &hrp.y)) return 0;
     }
@@ -362,13 +368,13 @@ static int verify_fast_one(int version, const uint8_t *msg, size_t mlen, const u
     enc33(e_pk, &pk.x, &pk.y); enc33(e_nul, &nul.x, &nul.y);
     pj hj;
     h2c_fast(&hj, msg, mlen, e_pk);                                                                  /* lib.rs:103 */
-    if (hj.inf) return verify_one(version, msg, mlen, pk_b, nul_b, c_b, s_b, r_b, hr_b);
+    if (hj.inf) return SLOW_VERIFY();
     /* window tables of pk, H, nullifier: odd multiples, one inversion for all of them (and for H itself: entry 0 of its table) */
     pj tj[3 * TV], base;
     base.x = pk.x; base.y = pk.y; base.z = FF_ONE; base.inf = 0; odd_multiples(tj, TV, &base);
     odd_multiples(tj + TV, TV, &hj);
     base.x = nul.x; base.y = nul.y; odd_multiples(tj + 2 * TV, TV, &base);
-    for (int i = 0; i < 3 * TV; i++) if (tj[i].inf || ff_is_zero(&tj[i].z)) return verify_one(version, msg, mlen, pk_b, nul_b, c_b, s_b, r_b, hr_b);
+    for (int i = 0; i < 3 * TV; i++) if (tj[i].inf || ff_is_zero(&tj[i].z)) return SLOW_VERIFY();
     pa ta[3 * TV]; ff bx[3 * TV];
     batch_affine(ta, tj, 3 * TV);
     for (int i = 0; i < 3 * TV; i++) ff_mul(&bx[i], &ta[i].x, &FF_BETA);
@@ -394,19 +400,21 @@ static int verify_fast_one(int version, const uint8_t *msg, size_t mlen, const u
     }
     uint8_t pre[198], e[33], d[32];
     size_t n = 0;
-    if (version == 1) {
+    if (given) {
         if (rcalc.inf || hrcalc.inf) return 0;                                                        /* the given R, Hr are not the identity here */
-        if (!pj_eq_aff(&rcalc, &rp.x, &rp.y)) return 0;                                               /* lib.rs:117 */
-        if (!pj_eq_aff(&hrcalc, &hrp.x, &hrp.y)) return 0;                                            /* lib.rs:122 */
-        ff gxx = ff_of(&FE_GX), gyy = ff_of(&FE_GY);
-        enc33(e, &gxx, &gyy); memcpy(pre + n, e, 33); n += 33;
-        memcpy(pre + n, e_pk, 33); n += 33;
-        enc33(e, &ta[TV].x, &ta[TV].y); memcpy(pre + n, e, 33); n += 33;                              /* H = 1 * H of its table */
+        if (!pj_eq_aff(&rcalc, &rp.x, &rp.y)) return 0;                                               /* lib.rs:117; tests.rs:59-61 */
+        if (!pj_eq_aff(&hrcalc, &hrp.x, &hrp.y)) return 0;                                            /* lib.rs:122; tests.rs:68-70 */
+        if (version == 1) {
+            ff gxx = ff_of(&FE_GX), gyy = ff_of(&FE_GY);
+            enc33(e, &gxx, &gyy); memcpy(pre + n, e, 33); n += 33;
+            memcpy(pre + n, e_pk, 33); n += 33;
+            enc33(e, &ta[TV].x, &ta[TV].y); memcpy(pre + n, e, 33); n += 33;                          /* H = 1 * H of its table */
+        }
         memcpy(pre + n, e_nul, 33); n += 33;
         enc33(e, &rp.x, &rp.y); memcpy(pre + n, e, 33); n += 33;
         enc33(e, &hrp.x, &hrp.y); memcpy(pre + n, e, 33); n += 33;
     } else {
-        if (rcalc.inf || hrcalc.inf) return verify_one(version, msg, mlen, pk_b, nul_b, c_b, s_b, r_b, hr_b);
+        if (rcalc.inf || hrcalc.inf) return SLOW_VERIFY();
         pj two[2] = {rcalc, hrcalc}; pa aff2[2];
         batch_affine(aff2, two, 2);
         memcpy(pre + n, e_nul, 33); n += 33;
@@ -419,29 +427,177 @@ static int verify_fast_one(int version, const uint8_t *msg, size_t mlen, const u
     return memcmp(cc.l, c.l, 32) == 0;
 }
 
-typedef struct { int version; size_t lo, hi; const uint8_t *msgs; const uint64_t *off; const uint8_t *pk, *nul, *c, *s, *r, *hr; uint8_t *ok; } fjob;
+static int verify_fast_one(int version, const uint8_t *msg, size_t mlen, const uint8_t *pk_b, const uint8_t *nul_b, const uint8_t *c_b, const uint8_t *s_b,
+                           const uint8_t *r_b, const uint8_t *hr_b) {
+    return verify_fast_mode(version, 0, msg, mlen, pk_b, nul_b, c_b, s_b, r_b, hr_b);
+}
+
+/* ------------------------------------------------------------------------------------------------ sign
+ * PlumeSigner::try_sign_with_rng with the nonce given (rust-k256/src/randomizedsigner.rs:43-112), or plume_arkworks::sign_with_r when pk_in is supplied
+ * (rust-arkworks/src/lib.rs:229-278); same outputs and status bits as the plain oracle's sign_one, which also serves every input outside the common case
+ * (a scalar that is zero or >= n, a supplied pk that is the identity or no curve point, an identity anywhere). */
+static void mul_glv(pj *out, const sc *k, const pa *tab, const ff *tx, const ff *bx, int w) {   /* k * (the base whose odd multiples are tab), k in [1, n-1] */
+    half h1, h2;
+    glv_split_fast(&h1, &h2, k);
+    int8_t naf[4][NAF_LEN];
+    wnaf(naf[0], &h1, w); wnaf(naf[1], &h2, w); memset(naf[2], 0, NAF_LEN); memset(naf[3], 0, NAF_LEN);
+    const pa *tabs[4] = {tab, tab, tab, tab}; const ff *xs[4] = {tx, bx, tx, bx};
+    const int flip[4] = {h1.neg, h2.neg, 0, 0};
+    strauss(out, naf, tabs, xs, flip);
+}
+static void sign_fast_one(int version, const uint8_t *msg, size_t mlen, const uint8_t *sk_b, const uint8_t *r_b, const uint8_t *pk_in,
+                          uint8_t *pk_o, uint8_t *nul_o, uint8_t *c_o, uint8_t *s_o, uint8_t *r_o, uint8_t *hr_o, uint8_t *status) {
+    static const uint8_t zero64[64] = {0};
+#define SLOW_SIGN() do { sign_one(version, msg, mlen, sk_b, r_b, pk_in, pk_o, nul_o, c_o, s_o, r_o, hr_o, 0, status); return; } while (0)
+    sc sk, r;
+    if (!sc_from_be_nonzero(&sk, sk_b) || !sc_from_be_nonzero(&r, r_b)) SLOW_SIGN();
+    pa pk;
+    if (pk_in && (!memcmp(pk_in, zero64, 64) || !ff_from_be_checked(&pk.x, pk_in) || !ff_from_be_checked(&pk.y, pk_in + 32) || !pa_on_curve(&pk.x, &pk.y))) SLOW_SIGN();
+    ff gx[TG];
+    for (int i = 0; i < TG; i++) gx[i] = GTAB[i].x;
+    pj gj[2]; pa ga[2];
+    mul_glv(&gj[0], &r, GTAB, gx, GTAB_BX, WG);                                                      /* randomizedsigner.rs:51 */
+    if (pk_in) gj[1] = gj[0]; else mul_glv(&gj[1], &sk, GTAB, gx, GTAB_BX, WG);                      /* :53 */
+    if (gj[0].inf || gj[1].inf) SLOW_SIGN();
+    batch_affine(ga, gj, 2);
+    if (!pk_in) pk = ga[1];
+    uint8_t e_pk[33];
+    enc33(e_pk, &pk.x, &pk.y);
+    pj hj;
+    h2c_fast(&hj, msg, mlen, e_pk);                                                                  /* :57-61 */
+    if (hj.inf) SLOW_SIGN();
+    pj tj[TV]; pa ta[TV]; ff tx[TV], bx[TV];
+    odd_multiples(tj, TV, &hj);
+    for (int i = 0; i < TV; i++) if (tj[i].inf || ff_is_zero(&tj[i].z)) SLOW_SIGN();
+    batch_affine(ta, tj, TV);
+    for (int i = 0; i < TV; i++) { tx[i] = ta[i].x; ff_mul(&bx[i], &ta[i].x, &FF_BETA); }
+    pj hm[2]; pa ha[2];
+    mul_glv(&hm[0], &r, ta, tx, bx, WV);                                                             /* :67 */
+    mul_glv(&hm[1], &sk, ta, tx, bx, WV);                                                            /* :70 */
+    if (hm[0].inf || hm[1].inf) SLOW_SIGN();
+    batch_affine(ha, hm, 2);
+    uint8_t pre[198], e[33], d[32];
+    size_t n = 0;
+    if (version == 1) {
+        ff gxx = ff_of(&FE_GX), gyy = ff_of(&FE_GY);
+        enc33(e, &gxx, &gyy); memcpy(pre + n, e, 33); n += 33;
+        memcpy(pre + n, e_pk, 33); n += 33;
+        enc33(e, &ta[0].x, &ta[0].y); memcpy(pre + n, e, 33); n += 33;
+    }
+    enc33(e, &ha[1].x, &ha[1].y); memcpy(pre + n, e, 33); n += 33;
+    enc33(e, &ga[0].x, &ga[0].y); memcpy(pre + n, e, 33); n += 33;
+    enc33(e, &ha[0].x, &ha[0].y); memcpy(pre + n, e, 33); n += 33;
+    sha256_ctx ctx; sha256_init(&ctx); sha256_update(&ctx, pre, n); sha256_final(&ctx, d);          /* :73-89 */
+    sc c, s, t; int canon; uint8_t st = 0;
+    sc_from_digest(&c, d, &canon);
+    if (!canon) st |= 1;                                                                             /* :90-91 */
+    sc_mul(&t, &c, &sk); sc_add(&s, &r, &t);                                                         /* :94 */
+    if (is_zero256(s.l)) st |= 4;                                                                    /* :95 */
+    if (pk_o) { ff_to_be(pk_o, &pk.x); ff_to_be(pk_o + 32, &pk.y); }
+    ff_to_be(nul_o, &ha[1].x); ff_to_be(nul_o + 32, &ha[1].y);
+    to_be32(c_o, c.l); to_be32(s_o, s.l);
+    ff_to_be(r_o, &ga[0].x); ff_to_be(r_o + 32, &ga[0].y);
+    ff_to_be(hr_o, &ha[0].x); ff_to_be(hr_o + 32, &ha[0].y);
+    *status = st;
+#undef SLOW_SIGN
+}
+
+typedef struct { int kind, version; size_t lo, hi; const uint8_t *msgs; const uint64_t *off; const uint8_t *pk, *nul, *c, *s, *r, *hr; uint8_t *ok;
+                 const uint8_t *sk, *nonce, *pk_in; uint8_t *o_pk, *o_nul, *o_c, *o_s, *o_r, *o_hr, *o_status; } fjob;
 static void *fast_worker(void *arg) {
     fjob *j = (fjob *)arg;
-    for (size_t i = j->lo; i < j->hi; i++)
-        j->ok[i] = (uint8_t)verify_fast_one(j->version, j->msgs + j->off[i], (size_t)(j->off[i + 1] - j->off[i]), j->pk + 64 * i, j->nul + 64 * i, j->c + 32 * i,
-                                            j->s + 32 * i, j->r ? j->r + 64 * i : 0, j->hr ? j->hr + 64 * i : 0);
+    for (size_t i = j->lo; i < j->hi; i++) {
+        const uint8_t *m = j->msgs + j->off[i];
+        const size_t ml = (size_t)(j->off[i + 1] - j->off[i]);
+        if (j->kind == 2)
+            sign_fast_one(j->version, m, ml, j->sk + 32 * i, j->nonce + 32 * i, j->pk_in ? j->pk_in + 64 * i : 0, j->o_pk ? j->o_pk + 64 * i : 0, j->o_nul + 64 * i,
+                          j->o_c + 32 * i, j->o_s + 32 * i, j->o_r + 64 * i, j->o_hr + 64 * i, j->o_status + i);
+        else
+            j->ok[i] = (uint8_t)verify_fast_mode(j->version, j->kind, m, ml, j->pk + 64 * i, j->nul + 64 * i, j->c + 32 * i, j->s + 32 * i, j->r ? j->r + 64 * i : 0,
+                                                 j->hr ? j->hr + 64 * i : 0);
+    }
     return 0;
 }
-/* same arguments as oracle_verify_batch / plume_verify_batch (host buffers) */
-int fast_verify_batch(int version, size_t n, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *pk, const uint8_t *nullifier, const uint8_t *c,
-                      const uint8_t *s, const uint8_t *r_point, const uint8_t *hashed_to_curve_r, uint8_t *ok, int nthreads) {
-    if ((version != 1 && version != 2) || (version == 1 && (!r_point || !hashed_to_curve_r))) return -1;
+static void fast_run(const fjob *proto, size_t n, int nthreads) {
     init_fast();
     if (nthreads < 1) nthreads = 1;
     if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
     fjob *jobs = (fjob *)malloc(sizeof(fjob) * nthreads);
     for (int t = 0; t < nthreads; t++) {
-        fjob j = {version, n * t / nthreads, n * (t + 1) / nthreads, msgs, msg_off, pk, nullifier, c, s, version == 1 ? r_point : 0, version == 1 ? hashed_to_curve_r : 0, ok};
-        jobs[t] = j;
+        jobs[t] = *proto; jobs[t].lo = n * t / nthreads; jobs[t].hi = n * (t + 1) / nthreads;
         if (t > 0) pthread_create(&th[t], 0, fast_worker, &jobs[t]);
     }
     fast_worker(&jobs[0]);
+    for (int t = 1; t < nthreads; t++) pthread_join(th[t], 0);
+    free(th); free(jobs);
+}
+/* same arguments as oracle_verify_batch / plume_verify_batch (host buffers) */
+int fast_verify_batch(int version, size_t n, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *pk, const uint8_t *nullifier, const uint8_t *c,
+                      const uint8_t *s, const uint8_t *r_point, const uint8_t *hashed_to_curve_r, uint8_t *ok, int nthreads) {
+    if ((version != 1 && version != 2) || (version == 1 && (!r_point || !hashed_to_curve_r))) return -1;
+    fjob j; memset(&j, 0, sizeof j);
+    j.kind = 0; j.version = version; j.msgs = msgs; j.off = msg_off; j.pk = pk; j.nul = nullifier; j.c = c; j.s = s;
+    j.r = version == 1 ? r_point : 0; j.hr = version == 1 ? hashed_to_curve_r : 0; j.ok = ok;
+    fast_run(&j, n, nthreads);
+    return 0;
+}
+/* same arguments as oracle_verify_non_zk_batch / plume_verify_non_zk_batch; ok: 1 Ok(true), 0 Ok(false), 2 Err */
+int fast_verify_non_zk_batch(int version, size_t n, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *pk, const uint8_t *nullifier, const uint8_t *s,
+                             const uint8_t *r_point, const uint8_t *hashed_to_curve_r, const uint8_t *digest_private, uint8_t *ok, int nthreads) {
+    if ((version != 1 && version != 2) || !r_point || !hashed_to_curve_r) return -1;
+    fjob j; memset(&j, 0, sizeof j);
+    j.kind = 1; j.version = version; j.msgs = msgs; j.off = msg_off; j.pk = pk; j.nul = nullifier; j.c = digest_private; j.s = s; j.r = r_point; j.hr = hashed_to_curve_r; j.ok = ok;
+    fast_run(&j, n, nthreads);
+    return 0;
+}
+/* same arguments as oracle_sign_batch / plume_sign_batch (no h_out) */
+int fast_sign_batch(int version, size_t n, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sk, const uint8_t *r, const uint8_t *pk_in, uint8_t *pk,
+                    uint8_t *nullifier, uint8_t *c, uint8_t *s, uint8_t *r_point, uint8_t *hashed_to_curve_r, uint8_t *status, int nthreads) {
+    if (version != 1 && version != 2) return -1;
+    fjob j; memset(&j, 0, sizeof j);
+    j.kind = 2; j.version = version; j.msgs = msgs; j.off = msg_off; j.sk = sk; j.nonce = r; j.pk_in = pk_in;
+    j.o_pk = pk; j.o_nul = nullifier; j.o_c = c; j.o_s = s; j.o_r = r_point; j.o_hr = hashed_to_curve_r; j.o_status = status;
+    fast_run(&j, n, nthreads);
+    return 0;
+}
+/* SEC1-compressed records (02|03 || x, or a first byte 00 for the identity) -> 64-byte affine records, the reference's deserialization semantics
+ * (javascript/src/lib.rs:95-118, rust-arkworks/src/lib.rs:76-88): ok[i] = 0 for any other tag, x >= p, or an x with no curve point (out = zeros then). */
+static void ff_sqrt_cand(ff *r, const ff *a) { /* a^((p+1)/4) */
+    ff t, x2;
+    ff_pow_prefix(&t, &x2, a);
+    ff_sqr_n(&t, &t, 6); ff_mul(&t, &t, &x2);
+    ff_sqr_n(r, &t, 2);
+}
+typedef struct { size_t lo, hi; const uint8_t *in; uint8_t *out, *ok; } djob;
+static void *dec_worker(void *arg) {
+    djob *j = (djob *)arg;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        const uint8_t *b = j->in + 33 * i; uint8_t *o = j->out + 64 * i;
+        memset(o, 0, 64); j->ok[i] = 0;
+        if (b[0] == 0) { j->ok[i] = 1; continue; }
+        ff x, y, rhs, t; const ff seven = {{7, 0, 0, 0}};
+        if ((b[0] != 2 && b[0] != 3) || !ff_from_be_checked(&x, b + 1)) continue;
+        ff_sqr(&rhs, &x); ff_mul(&rhs, &rhs, &x); ff_add(&rhs, &rhs, &seven);
+        ff_sqrt_cand(&y, &rhs); ff_sqr(&t, &y);
+        if (!ff_eq(&t, &rhs)) continue;
+        if (ff_is_odd(&y) != (b[0] & 1)) ff_neg(&y, &y);
+        ff_to_be(o, &x); ff_to_be(o + 32, &y); j->ok[i] = 1;
+    }
+    return 0;
+}
+int fast_sec1_decompress_batch(size_t n, const uint8_t *in33, uint8_t *out64, uint8_t *ok, int nthreads) {
+    init_fast();
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    djob *jobs = (djob *)malloc(sizeof(djob) * nthreads);
+    for (int t = 0; t < nthreads; t++) {
+        djob j = {n * t / nthreads, n * (t + 1) / nthreads, in33, out64, ok};
+        jobs[t] = j;
+        if (t > 0) pthread_create(&th[t], 0, dec_worker, &jobs[t]);
+    }
+    dec_worker(&jobs[0]);
     for (int t = 1; t < nthreads; t++) pthread_join(th[t], 0);
     free(th); free(jobs);
     return 0;

@@ -38,6 +38,41 @@ def verify_batch(version, msgs_buf, msg_off, pk, nul, c, s, r_point=None, hr=Non
     return ok
 
 
+def verify_non_zk_batch(version, msgs_buf, msg_off, pk, nul, s, r_point, hr, digest_private, nthreads=1):
+    """rust-arkworks/src/tests.rs:28-78; 1 Ok(true), 0 Ok(false), 2 Err(HashToCurveError)"""
+    n = len(msg_off) - 1
+    ok = np.zeros(n, dtype=np.uint8)
+    lib().fast_verify_non_zk_batch.restype = C.c_int
+    rc = lib().fast_verify_non_zk_batch(C.c_int(version), C.c_size_t(n), _p(msgs_buf), msg_off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        _p(pk), _p(nul), _p(s), _p(r_point), _p(hr), _p(digest_private), _p(ok), C.c_int(nthreads))
+    assert rc == 0, rc
+    return ok
+
+
+def sign_batch(version, msgs_buf, msg_off, sk, r, pk_in=None, nthreads=1):
+    """same outputs as tests/_oracle_c.sign_batch (without h)"""
+    n = len(msg_off) - 1
+    o = {k: np.zeros((n, w), dtype=np.uint8) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
+    status = np.zeros(n, dtype=np.uint8)
+    lib().fast_sign_batch.restype = C.c_int
+    rc = lib().fast_sign_batch(C.c_int(version), C.c_size_t(n), _p(msgs_buf), msg_off.ctypes.data_as(C.POINTER(C.c_uint64)), _p(sk), _p(r), _p(pk_in),
+                               _p(o["pk"]), _p(o["nullifier"]), _p(o["c"]), _p(o["s"]), _p(o["r_point"]), _p(o["hashed_to_curve_r"]), _p(status), C.c_int(nthreads))
+    assert rc == 0, rc
+    o["status"] = status
+    return o
+
+
+def sec1_decompress_batch(rec33, nthreads=1):
+    """33-byte SEC1 records -> (64-byte affine records, ok flags): the reference's deserialization (00 = identity; bad tag / x >= p / no curve point = ok 0)"""
+    rec33 = np.ascontiguousarray(rec33, dtype=np.uint8).reshape(-1, 33)
+    n = len(rec33)
+    out, ok = np.zeros((n, 64), dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    lib().fast_sec1_decompress_batch.restype = C.c_int
+    rc = lib().fast_sec1_decompress_batch(C.c_size_t(n), _p(rec33), _p(out), _p(ok), C.c_int(nthreads))
+    assert rc == 0, rc
+    return out, ok
+
+
 def ff_op(op, a: int, b: int = 0) -> int:
     out = (C.c_uint8 * 32)()
     lib().fast_ff_op(C.c_int(op), (C.c_uint8 * 32).from_buffer_copy(a.to_bytes(32, "big")), (C.c_uint8 * 32).from_buffer_copy(b.to_bytes(32, "big")), out)

@@ -332,6 +332,7 @@ def test_host_pieces_do_not_change_results(eng, ver):
     """host-pointer calls are pipelined in pieces (plume_set_host_piece): 3001 ragged items through 1 / 5 / 47 pieces, and 40 items
     through pieces of ONE item, give the C oracle's bytes every time, for sign, verify, SEC1 verify and hash_to_curve"""
     from tests import _sec1
+    from zk_nullifier_sig_amd import capi
     rng = random.Random(4242 + ver)
     n = 3001
     b = synth.sign_inputs(n, start=77000)
@@ -365,7 +366,7 @@ def test_host_pieces_do_not_change_results(eng, ver):
             h = eng.hash_to_curve_batch(m2, o2, rows(want["pk"], 64, cnt))
             assert np.array_equal(np.asarray(h).reshape(cnt, 64), want_h[:cnt]), piece
     finally:
-        eng.set_host_piece(1 << 18)
+        eng.set_host_piece(capi.DEFAULT_HOST_PIECE)          # the shipped default (plume_capi.hip), so that later tests of this module run what ships
 
 
 @pytest.mark.parametrize("ver", [1, 2])

@@ -258,10 +258,12 @@ def test_pinned_host_buffers_give_the_same_bytes(eng):
         eng.set_host_register_min(0)
     for k in OUT_KEYS:
         assert np.array_equal(got[k], want[k]), k
-    for first in (1, 1000, 1 << 16):                        # the first piece's size does not change results
-        eng.set_host_first_piece(first)
-        assert np.array_equal(eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])["s"], want["s"])
-    eng.set_host_first_piece(1 << 17)
+    try:
+        for first in (1, 1000, 1 << 17):                    # the first piece's size does not change results
+            eng.set_host_first_piece(first)
+            assert np.array_equal(eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])["s"], want["s"])
+    finally:
+        eng.set_host_first_piece(capi.DEFAULT_HOST_FIRST_PIECE)   # the shipped default (plume_capi.hip)
 
 
 # ------------------------------------------------------------------------------- error paths of the boundary
@@ -278,10 +280,12 @@ def test_error_paths(eng):
     ok = torch.zeros(n, dtype=torch.uint8, device=dev)
     # n > chunk
     eng.set_chunk(256)
-    with pytest.raises(plume.PlumeHipError, match="chunk"):
-        eng.verify_batch_device(1, n, msgs, off, 32 * n, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok)
-    assert bool(eng.verify_batch(1, b["msgs"], b["off"], sg["pk"], sg["nullifier"], sg["c"], sg["s"], sg["r_point"], sg["hashed_to_curve_r"]).all())  # host path chunks by itself
-    eng.set_chunk(1 << 20)
+    try:
+        with pytest.raises(plume.PlumeHipError, match="chunk"):
+            eng.verify_batch_device(1, n, msgs, off, 32 * n, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok)
+        assert bool(eng.verify_batch(1, b["msgs"], b["off"], sg["pk"], sg["nullifier"], sg["c"], sg["s"], sg["r_point"], sg["hashed_to_curve_r"]).all())  # host path chunks by itself
+    finally:
+        eng.set_chunk(1 << 20)
     # null arrays / bad version
     with pytest.raises(plume.PlumeHipError, match="null"):
         eng.verify_batch_device(1, n, msgs, off, 32 * n, None, d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok)

@@ -1,0 +1,240 @@
+"""GPU parity tests added in round 3 (run on the MI355X box: `pytest -m gpu`).
+
+BASELINE.md §3's criteria taken literally at full size — EVERY item of a 2^20 batch against the CPU, for the signer (config 3: all six output arrays + status), the
+SEC1-compressed ingest and plume_arkworks' verify_non_zk — plus the sub-batch overlap of the device-resident calls (results must not depend on it).  The CPU side is
+oracle/plume_cpu_fast.c, which tests/test_cpu_fast.py holds to the plain oracle item by item; a sample of every batch goes through the plain oracle as well.
+Everything goes through the C ABI of libplume_hip.so."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from tests import _cpu_fast as CF
+from tests import _fuzz, _sec1, synth
+from tests import _oracle_c as OC
+
+pytestmark = pytest.mark.gpu
+N, P = synth.N, _fuzz.P
+OUT = ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r", "status")
+THREADS = min(64, os.cpu_count() or 1)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import zk_nullifier_sig_amd as plume
+    e = plume.Engine(0)
+    yield e
+    e.close()
+
+
+def _rows_differing(a, b):
+    a, b = a.reshape(len(a), -1), b.reshape(len(b), -1)
+    return np.nonzero((a != b).any(axis=1))[0][:10]
+
+
+def _salt_sign_inputs(b, n, rng):
+    """what the reference's types cannot hold (status bits), tiny / huge keys (pk = +-kG: the checked-addition fallback), r = sk"""
+    vals = [0, 1, 2, 3, 7, 8, 9, 16, 17, 255, 256, 257, 32767, 32768, 32769, N - 1, N - 2, N - 8, N - 32768, N, N + 1, 2**256 - 1, 2**255]
+    idx = rng.sample(range(n), 4096)
+    for k, i in enumerate(idx):
+        b["sk" if k % 3 else "r"][i] = np.frombuffer(vals[k % len(vals)].to_bytes(32, "big"), dtype=np.uint8)
+    for i in rng.sample(range(n), 512):
+        b["r"][i] = b["sk"][i]
+    return idx
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_every_item_of_a_2p20_sign_vs_the_cpu(eng, ver):
+    """BASELINE config 3 taken literally: 2^20 signs, all six output arrays and the status byte of EVERY item equal to the CPU's (randomizedsigner.rs:43-112)"""
+    n = 1 << 20
+    b = synth.sign_inputs(n, start=7_000_000)
+    salted = _salt_sign_inputs(b, n, random.Random(ver))
+    got = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    want = CF.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"], nthreads=THREADS)
+    for k in OUT:
+        assert np.array_equal(got[k], want[k]), (k, _rows_differing(got[k], want[k]))
+    assert int((got["status"] != 0).sum()) > 300
+    # the salted items and a random sample through the PLAIN oracle too
+    idx = np.sort(np.unique(np.concatenate([np.array(salted[:1024]), np.random.default_rng(ver).choice(n, size=1024, replace=False)])))
+    sub_msgs = np.concatenate([b["msgs"][32 * i:32 * i + 32] for i in idx] + [np.zeros(16, np.uint8)])
+    sub_off = np.arange(len(idx) + 1, dtype=np.uint64) * 32
+    slow = OC.sign_batch(ver, sub_msgs, sub_off, b["sk"][idx], b["r"][idx], nthreads=THREADS)
+    for k in OUT:
+        assert np.array_equal(got[k][idx], slow[k]), (k, _rows_differing(got[k][idx], slow[k]))
+
+
+def test_config5_every_item_pk_supplied_2p20(eng):
+    """BASELINE config 5 (the arkworks shape: pk supplied, rust-arkworks/src/lib.rs:229-278) at 2^20, every item against the CPU — including supplied keys that are
+    somebody else's, the identity, or no curve point"""
+    n = 1 << 20
+    b = synth.sign_inputs(n, start=9_000_000)
+    base = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    pk_in = base["pk"].copy()
+    pk_in[7::64] = 0
+    pk_in[9::64, 5] ^= 1
+    pk_in[11::64] = np.roll(base["pk"], 1, axis=0)[11::64]
+    got = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"], pk_in=pk_in)
+    want = CF.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"], pk_in=pk_in, nthreads=THREADS)
+    for k in OUT:
+        assert np.array_equal(got[k], want[k]), (k, _rows_differing(got[k], want[k]))
+    honest = np.ones(n, dtype=bool); honest[7::64] = honest[9::64] = honest[11::64] = False
+    for k in OUT:
+        assert np.array_equal(got[k][honest], base[k][honest]), k
+
+
+def _fuzz_sec1_records(rec, rng, frac=24):
+    """mutations at the level of the 33-byte records: tags, parity, non-canonical x, x with no point, identities"""
+    n = len(rec)
+    for i in range(n):
+        k = rng.randrange(frac)
+        if k == 0:
+            rec[i, 0] = rng.choice([1, 4, 5, 6, 7, 0x82, 0xFF])
+        elif k == 1:
+            rec[i, 0] ^= 1                                   # the other root: a valid point, the wrong one
+        elif k == 2:
+            rec[i, 1:] = np.frombuffer(rng.choice([P, P + 1, 2**256 - 1]).to_bytes(32, "big"), dtype=np.uint8)
+        elif k == 3:
+            rec[i, 1:] = np.frombuffer(rng.randbytes(32), dtype=np.uint8)   # half of these have no curve point
+        elif k == 4:
+            rec[i, 0] = 0                                    # identity, junk behind it
+        elif k == 5:
+            rec[i] = 0
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_every_item_sec1_ingest_2p20_vs_the_cpu(eng, ver):
+    """the SEC1-compressed entry point at full size: 2^20 fuzzed signatures presented as 33-byte records, additionally mutated at the record level; expected = the
+    reference's semantics, a record that does not deserialize means no signature object, i.e. false (javascript/src/lib.rs:95-118,147-184) — else verify() of the decoded record"""
+    n = 1 << 20
+    b = synth.sign_inputs(n, start=11_000_000)
+    signed = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    v = _fuzz.fuzz_verify_batch(ver, signed, b, seed=70 + ver)
+    fields = ["pk", "nullifier"] + (["r_point", "hashed_to_curve_r"] if ver == 1 else [])
+    # 64-byte records that are not curve points (garbage, bit flips) have no SEC1 form: such items keep their honest point, the record-level fuzz below covers bad records
+    for f in fields:
+        dec, okd = CF.sec1_decompress_batch(_sec1.compress(v[f]), nthreads=THREADS)
+        bad = (okd == 0) | (dec != v[f]).any(axis=1)
+        v[f][bad] = signed[f][bad]
+    rec = {f: _sec1.compress(v[f]) for f in fields}
+    rng = random.Random(170 + ver)
+    for f in fields:
+        _fuzz_sec1_records(rec[f], rng, frac=24 * len(fields))
+    got = eng.verify_batch_sec1(ver, v["msgs"], v["off"], rec["pk"], rec["nullifier"], v["c"], v["s"], rec.get("r_point"), rec.get("hashed_to_curve_r"))
+    dec, decodes = {}, np.ones(n, dtype=bool)
+    for f in fields:
+        dec[f], okd = CF.sec1_decompress_batch(rec[f], nthreads=THREADS)
+        decodes &= okd != 0
+    want = CF.verify_batch(ver, v["msgs"], v["off"], dec["pk"], dec["nullifier"], v["c"], v["s"], dec.get("r_point"), dec.get("hashed_to_curve_r"), nthreads=THREADS)
+    want = np.where(decodes, want, 0).astype(np.uint8)
+    assert np.array_equal(got, want), [(int(i), int(got[i]), int(want[i])) for i in np.nonzero(got != want)[0][:10]]
+    assert 0.2 * n < int(got.sum()) < 0.85 * n and int((~decodes).sum()) > 0.02 * n
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_every_item_verify_non_zk_2p20_vs_the_cpu(eng, ver):
+    """plume_arkworks' verify_non_zk (rust-arkworks/src/tests.rs:28-78) at full size on a fuzzed batch: honest items, every mutation kind of the verify fuzz, zero scalars,
+    identity pk (Err -> 2); every item against the CPU, a sample against the plain oracle"""
+    n = 1 << 20
+    b = synth.sign_inputs(n, start=13_000_000)
+    signed = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    v = _fuzz.fuzz_non_zk_batch(ver, signed, b, seed=80 + ver)
+    args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["s"], v["r_point"], v["hashed_to_curve_r"], v["c"])
+    got = eng.verify_non_zk_batch(*args)
+    want = CF.verify_non_zk_batch(*args, nthreads=THREADS)
+    assert np.array_equal(got, want), [(int(i), int(got[i]), int(want[i])) for i in np.nonzero(got != want)[0][:10]]
+    assert {int(x) for x in np.unique(got)} == {0, 1, 2} and 0.15 * n < int((got == 1).sum()) < 0.8 * n
+    idx = np.sort(np.random.default_rng(ver).choice(n, size=3072, replace=False))
+    sub_msgs = np.concatenate([v["msgs"][32 * i:32 * i + 32] for i in idx] + [np.zeros(16, np.uint8)])
+    sub_off = np.arange(len(idx) + 1, dtype=np.uint64) * 32
+    slow = OC.verify_non_zk_batch(ver, sub_msgs, sub_off, v["pk"][idx], v["nullifier"][idx], v["s"][idx], v["r_point"][idx], v["hashed_to_curve_r"][idx], v["c"][idx], nthreads=THREADS)
+    assert np.array_equal(got[idx], slow)
+
+
+# ------------------------------------------------------------------------------------------- sub-batch overlap
+def test_sub_batches_do_not_change_results(eng):
+    """device-resident verify (V1, V2, SEC1, non-zk) and sign cut into 1 / 2 / 3 / 4 / 7 / 16 overlapped sub-batches: byte-identical outputs, for sizes that do and do not
+    divide, ragged messages across the cuts, rejected items and identities on both sides of a cut"""
+    import torch
+    dev = torch.device("cuda:0")
+    n = (1 << 17) + 4321
+    rng = random.Random(3)
+    b = synth.sign_inputs(n, start=15_000_000)
+    msgs = [rng.randbytes(rng.choice([0, 1, 31, 32, 33, 64, 100])) for _ in range(n)]
+    b["msgs"], b["off"] = OC.pack_msgs(msgs)
+    _salt_sign_inputs(b, n, rng)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    d = {k: t(b[k]) for k in ("msgs", "sk", "r")}
+    d["off"] = t(b["off"].view(np.int64))
+    mb = int(b["off"][-1])
+    ref = {}
+    try:
+        for subs in (1, 2, 3, 4, 7, 16):
+            eng.set_sub_batches(subs)
+            for ver in (1, 2):
+                o = {k: torch.zeros((n, w), dtype=torch.uint8, device=dev) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
+                st = torch.zeros(n, dtype=torch.uint8, device=dev)
+                eng.sign_batch_device(ver, n, d["msgs"], d["off"], mb, d["sk"], d["r"], None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], st)
+                torch.cuda.synchronize()
+                sg = {k: x.cpu().numpy() for k, x in o.items()}
+                sg["status"] = st.cpu().numpy()
+                if subs == 1:
+                    ref["sign", ver] = sg
+                    v = _fuzz.fuzz_verify_batch(ver, sg, b, seed=5 + ver)
+                    ref["v", ver] = {k: t(v[k]) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+                    ref["v33", ver] = {k: t(_sec1.compress(sg[k])) for k in ("pk", "nullifier", "r_point", "hashed_to_curve_r")}
+                else:
+                    for k in OUT:
+                        assert np.array_equal(sg[k], ref["sign", ver][k]), (subs, ver, k)
+                vd, v33 = ref["v", ver], ref["v33", ver]
+                ok = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+                eng.verify_batch_device(ver, n, vd["msgs"], d["off"], mb, vd["pk"], vd["nullifier"], vd["c"], vd["s"], vd["r_point"] if ver == 1 else None,
+                                        vd["hashed_to_curve_r"] if ver == 1 else None, ok)
+                ok2 = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+                eng.verify_non_zk_batch_device(ver, n, vd["msgs"], d["off"], mb, vd["pk"], vd["nullifier"], vd["s"], vd["r_point"], vd["hashed_to_curve_r"], vd["c"], ok2)
+                ok3 = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+                sref = ref["sign", ver]
+                eng.verify_batch_sec1_device(ver, n, d["msgs"], d["off"], mb, v33["pk"], v33["nullifier"], t(sref["c"]), t(sref["s"]), v33["r_point"] if ver == 1 else None,
+                                             v33["hashed_to_curve_r"] if ver == 1 else None, ok3)
+                torch.cuda.synchronize()
+                res = (ok.cpu().numpy(), ok2.cpu().numpy(), ok3.cpu().numpy())
+                if subs == 1:
+                    ref["ok", ver] = res
+                    assert 0.2 * n < int(res[0].sum()) < 0.8 * n and set(np.unique(res[1])) == {0, 1, 2}
+                    assert bool(res[2][sref["status"] == 0].all())                                 # every signature the reference's types can hold verifies
+                else:
+                    for a, w in zip(res, ref["ok", ver]):
+                        assert np.array_equal(a, w), (subs, ver)
+        # and the serial mode's verdicts are the oracle's (a sample)
+        idx = np.sort(np.random.default_rng(1).choice(n, size=1024, replace=False))
+        v = _fuzz.fuzz_verify_batch(1, ref["sign", 1], b, seed=6)
+        mm, oo = OC.pack_msgs([bytes(v["msgs"][int(b["off"][i]):int(b["off"][i + 1])]) for i in idx])
+        slow = OC.verify_batch(1, mm, oo, v["pk"][idx], v["nullifier"][idx], v["c"][idx], v["s"][idx], v["r_point"][idx], v["hashed_to_curve_r"][idx], nthreads=THREADS)
+        assert np.array_equal(ref["ok", 1][0][idx], slow)
+    finally:
+        eng.set_sub_batches(4)
+
+
+def test_stage_times_serial_and_overlapped(eng):
+    """plume_last_stage_times: one entry per kernel in the serial mode, one entry for the whole call when sub-batches overlap"""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 1 << 18
+    b = synth.sign_inputs(n, start=16_000_000)
+    sg = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    a = (1, n, t(b["msgs"]), t(b["off"].view(np.int64)), int(b["off"][-1]), t(sg["pk"]), t(sg["nullifier"]), t(sg["c"]), t(sg["s"]), t(sg["r_point"]), t(sg["hashed_to_curve_r"]), ok)
+    try:
+        eng.set_sub_batches(1)
+        eng.verify_batch_device(*a); torch.cuda.synchronize()
+        serial = dict(eng.last_stage_times())
+        assert list(serial) == ["verify_ingest_h2c", "tables", "verify_msm", "verify_finalize"] and bool(ok.all())
+        eng.set_sub_batches(4)
+        ok.zero_()
+        eng.verify_batch_device(*a); torch.cuda.synchronize()
+        over = dict(eng.last_stage_times())
+        assert list(over) == ["verify_overlapped"] and bool(ok.all())
+        assert over["verify_overlapped"] < 1.05 * sum(serial.values())
+    finally:
+        eng.set_sub_batches(4)

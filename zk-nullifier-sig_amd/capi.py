@@ -15,6 +15,14 @@ _u8p = C.POINTER(C.c_uint8)
 _u64p = C.POINTER(C.c_uint64)
 
 
+# the library's shipped defaults (plume_capi.hip, struct plume_ctx) -- tests that turn a knob restore these
+DEFAULT_CHUNK = 1 << 20
+DEFAULT_HOST_PIECE = 1 << 19
+DEFAULT_HOST_FIRST_PIECE = 1 << 16
+DEFAULT_HOST_TAIL_PIECE = 1 << 17
+DEFAULT_SUB_BATCHES = 4
+
+
 class PlumeHipError(RuntimeError):
     pass
 
@@ -63,6 +71,7 @@ def _load():
     lib.plume_host_unregister.argtypes = [C.c_void_p]
     lib.plume_destroy.argtypes = [C.c_void_p]
     lib.plume_set_chunk.argtypes = [C.c_void_p, C.c_size_t]
+    lib.plume_set_sub_batches.argtypes = [C.c_void_p, C.c_int]
     lib.plume_set_host_piece.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_last_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
@@ -95,7 +104,7 @@ def _load():
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
+    return ["plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
             "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
@@ -235,6 +244,10 @@ class Engine:
 
     def set_chunk(self, n):
         self._chk(self._lib.plume_set_chunk(self._ctx, int(n)), "plume_set_chunk")
+
+    def set_sub_batches(self, k):
+        """device-resident verify / sign: number of overlapped sub-batches per call; 1 = strictly serial launch order (per-kernel stage times)"""
+        self._chk(self._lib.plume_set_sub_batches(self._ctx, int(k)), "plume_set_sub_batches")
 
     def set_host_piece(self, n):
         """host-pointer calls: items per pipelined piece (upload / compute / download overlap across pieces)"""

@@ -30,6 +30,8 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (e__ != hipSuccess) return fail(PLUME_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
     } while (0)
 
+constexpr int kMaxSubBatches = 64;
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -82,6 +84,11 @@ struct plume_ctx {
     int device = 0;
     hipStream_t stream = nullptr, up = nullptr, down = nullptr;   // kernels / host->HBM / HBM->host
     hipStream_t side = nullptr;                                   // aggregate check: the generator term and the upper windows' reduction run beside the main stream
+    hipStream_t pre = nullptr;                                    // overlapped verify / sign: the stages BEFORE the multi-scalar kernel of sub-batch k+1 run here, beside that kernel of sub-batch k
+    hipEvent_t pre_begin = nullptr;                               // ... the caller's stream has reached the call (inputs are there, the workspace is free)
+    std::vector<hipEvent_t> pre_ready;                            // ... sub-batch k's window tables are built
+    int sub_batches = 4;                                          // device-resident verify / sign: number of sub-batches (1 = strictly serial launch order, the mode per-stage times are measured in)
+    size_t overlap_min = (size_t)1 << 17;                         // ... batches below this many items always run serial (a sub-batch must still fill the chip)
     hipEvent_t agg_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // terms ready / upper bucket sums ready / generator term ready / upper windows reduced
     hipEvent_t ws_free = nullptr;     // recorded behind the last kernel of every device-resident call: the next call's stream waits on it before it
     bool ws_used = false;             // touches the per-context workspace, so calls on DIFFERENT streams of one context cannot race on that scratch
@@ -134,6 +141,7 @@ struct WsHold {
     ~WsHold() {
         if (released) return;
         if (ctx->side) (void)hipStreamSynchronize(ctx->side);      // failure path only: side-stream work the caller's stream never joined
+        if (ctx->pre) (void)hipStreamSynchronize(ctx->pre);
         (void)hipEventRecord(ctx->ws_free, st);
         ctx->ws_used = true;
     }
@@ -148,6 +156,7 @@ static void destroy_single(plume_ctx* ctx) {
     if (ctx->up) (void)hipStreamSynchronize(ctx->up);
     if (ctx->down) (void)hipStreamSynchronize(ctx->down);
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
+    if (ctx->pre) (void)hipStreamSynchronize(ctx->pre);
     for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
                       &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
@@ -164,6 +173,9 @@ static void destroy_single(plume_ctx* ctx) {
     if (ctx->up) (void)hipStreamDestroy(ctx->up);
     if (ctx->down) (void)hipStreamDestroy(ctx->down);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->pre) (void)hipStreamDestroy(ctx->pre);
+    if (ctx->pre_begin) (void)hipEventDestroy(ctx->pre_begin);
+    for (hipEvent_t e : ctx->pre_ready) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->agg_ev) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -180,6 +192,11 @@ static int init_single(plume_ctx* ctx) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->down, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->pre, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->pre_begin, hipEventDisableTiming));
+    if (const char* e = std::getenv("PLUME_SERIAL")) { if (std::atoi(e) != 0) ctx->sub_batches = 1; }                                  // strictly serial launch order (per-kernel measurements)
+    if (const char* e = std::getenv("PLUME_SUB_BATCHES")) { int v = std::atoi(e); if (v >= 1 && v <= kMaxSubBatches) ctx->sub_batches = v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_OVERLAP_MIN")) { long v = std::atol(e); if (v >= 1) ctx->overlap_min = (size_t)v; }         // tuning knob
     for (hipEvent_t& e : ctx->agg_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ws_free, hipEventDisableTiming));
     for (HostSlot& sl : ctx->slot) {
@@ -344,6 +361,14 @@ extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
     return 0;
 }
 
+// device-resident verify / sign: how many sub-batches a call is cut into (verify_device); 1 = strictly serial launch order
+extern "C" int plume_set_sub_batches(plume_ctx* ctx, int sub_batches) {
+    if (!ctx || sub_batches < 1 || sub_batches > kMaxSubBatches) return fail(PLUME_ERR_ARG, "plume_set_sub_batches: bad argument");
+    ctx->sub_batches = sub_batches;
+    for (plume_ctx* sh : ctx->shards) sh->sub_batches = sub_batches;
+    return 0;
+}
+
 extern "C" int plume_set_host_piece(plume_ctx* ctx, size_t items) {
     if (!ctx || items == 0 || items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_host_piece: bad argument");
     ctx->host_piece = items;
@@ -380,6 +405,28 @@ static int pick_jobs_per_lane(const plume_ctx* ctx, size_t njobs, bool kinds_of_
 }
 
 // ------------------------------------------------------------------------------------------ device pipelines
+// How a device-resident call of n items is cut into sub-batches: the stages in front of the multi-scalar kernel (validation + hash_to_curve, window tables) of sub-batch
+// k+1 run on ctx->pre beside the multi-scalar kernel of sub-batch k on the caller's stream.  The multi-scalar kernel saturates the vector ALUs but leaves HBM idle, the
+// table kernel is bound by the critical path of its workgroups and leaves half of the issue slots idle: side by side they fill each other's gaps, one
+// after the other they cannot.  Slices are multiples of 1024 items (whole workgroups, aligned records).  One sub-batch = the strictly serial order.
+static std::vector<size_t> sub_batch_bounds(const plume_ctx* ctx, size_t n) {
+    size_t k = (ctx->sub_batches > 1 && n >= ctx->overlap_min) ? (size_t)ctx->sub_batches : 1;
+    while (k > 1 && n / k < 8192) k--;
+    size_t per = (n + k - 1) / k;
+    per = (per + 1023) & ~(size_t)1023;
+    std::vector<size_t> b{0};
+    while (b.back() < n) b.push_back(b.back() + per < n ? b.back() + per : n);
+    return b;
+}
+static int pre_events(plume_ctx* ctx, size_t k) {
+    while (ctx->pre_ready.size() < k) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->pre_ready.push_back(e);
+    }
+    return 0;
+}
+
 static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk, const uint8_t* nul,
                          const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, hipStream_t st,
                          const uint8_t* preflags = nullptr, bool continue_timer = false, const uint8_t* rpt33 = nullptr, const uint8_t* hr33 = nullptr) {
@@ -387,23 +434,43 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
     if (!continue_timer) { if (int rc = ws_acquire(ctx, st)) return rc; }     // continue_timer: the caller (SEC1 ingest) holds the workspace already
     std::unique_ptr<WsHold> hold(continue_timer ? nullptr : new WsHold(ctx, st));
-    const int jpl = pick_jobs_per_lane(ctx, 3 * n, true);
+    const std::vector<size_t> cut = sub_batch_bounds(ctx, n);
+    const size_t nsub = cut.size() - 1;
+    const bool overlapped = nsub > 1;
+    size_t scr_bytes = 0;
+    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, tables_scratch_bytes(3 * (cut[k + 1] - cut[k]), pick_jobs_per_lane(ctx, 3 * (cut[k + 1] - cut[k]), true)));
     if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
-        ctx->tabscr.ensure(tables_scratch_bytes(3 * n, jpl)) ||
+        ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n))
         return PLUME_ERR_HIP;
-    VerifyArgs a;
-    a.version = version; a.mode = mode; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msgs_bytes; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok;
-    a.preflags = preflags; a.rpt33 = rpt33; a.hr33 = hr33;
-    a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>(); a.itemflags = ctx->itemflags.as<uint8_t>();
-    a.tab = ctx->tab.as<uint32_t>(); a.res = ctx->res.as<uint32_t>(); a.resinf = ctx->resinf.as<uint8_t>(); a.gtab = ctx->gtab.as<uint32_t>();
+    if (overlapped) { if (int rc = pre_events(ctx, nsub)) return rc; }
     StageTimer& t = ctx->timer;
     if (!continue_timer) t.begin(st);
-    launch_verify_ingest(a, st); t.stage("verify_ingest_h2c", st);
-    launch_tables(a.tab, a.bases, a.jobflags, 3 * n, jpl, ctx->tabscr.as<uint32_t>(), st); t.stage("tables", st);
-    launch_verify_msm(a, st); t.stage("verify_msm", st);
-    if (version == 2 && mode == PLUME_MODE_VERIFY) { launch_normalize(a.res, a.resinf, 2 * n, st); t.stage("to_affine", st); }   // V2 hashes the computed R', Hr'
-    launch_verify_finalize(a, st); t.stage("verify_finalize", st);
+    hipStream_t pre = overlapped ? ctx->pre : st;
+    if (overlapped) {
+        HIPCHK(hipEventRecord(ctx->pre_begin, st));                           // everything the caller's stream holds in front of this call (inputs, the SEC1 decompression, the workspace's last user)
+        HIPCHK(hipStreamWaitEvent(pre, ctx->pre_begin, 0));
+    }
+    for (size_t k = 0; k < nsub; k++) {
+        const size_t lo = cut[k], cnt = cut[k + 1] - cut[k];
+        VerifyArgs a;                                                         // the slice [lo, lo + cnt) as a batch of its own: every array and every scratch region starts at the slice
+        a.version = version; a.mode = mode; a.n = (uint32_t)cnt; a.msgs = msgs; a.msg_off = msg_off + lo; a.msgs_bytes = msgs_bytes;
+        a.pk = pk + 64 * lo; a.nul = nul + 64 * lo; a.c = c + 32 * lo; a.s = s + 32 * lo; a.rpt = rpt ? rpt + 64 * lo : nullptr; a.hr = hr ? hr + 64 * lo : nullptr; a.ok = ok + lo;
+        a.preflags = preflags ? preflags + lo : nullptr; a.rpt33 = rpt33 ? rpt33 + 33 * lo : nullptr; a.hr33 = hr33 ? hr33 + 33 * lo : nullptr;
+        a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 3 * lo; a.jobflags = ctx->jobflags.as<uint8_t>() + 3 * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo;
+        a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * 3 * lo; a.res = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.resinf = ctx->resinf.as<uint8_t>() + 2 * lo;
+        a.gtab = ctx->gtab.as<uint32_t>();
+        launch_verify_ingest(a, pre); if (!overlapped) t.stage("verify_ingest_h2c", st);
+        launch_tables(a.tab, a.bases, a.jobflags, 3 * cnt, pick_jobs_per_lane(ctx, 3 * cnt, true), ctx->tabscr.as<uint32_t>(), pre); if (!overlapped) t.stage("tables", st);   // the table kernels of all sub-batches follow one another on one stream: one scratch
+        if (overlapped) {
+            HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));
+            HIPCHK(hipStreamWaitEvent(st, ctx->pre_ready[k], 0));
+        }
+        launch_verify_msm(a, st); if (!overlapped) t.stage("verify_msm", st);
+        if (version == 2 && mode == PLUME_MODE_VERIFY) { launch_normalize(a.res, a.resinf, 2 * cnt, st); if (!overlapped) t.stage("to_affine", st); }   // V2 hashes the computed R', Hr'
+        launch_verify_finalize(a, st); if (!overlapped) t.stage("verify_finalize", st);
+    }
+    if (overlapped) t.stage("verify_overlapped", st);                         // per-stage times exist in the serial mode only (plume_set_sub_batches(ctx, 1) / PLUME_SERIAL=1)
     HIPCHK(hipGetLastError());
     return hold ? hold->release() : 0;
 }
@@ -415,26 +482,47 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
     if (int rc = ws_acquire(ctx, st)) return rc;
     WsHold hold(ctx, st);
-    const int jpl = pick_jobs_per_lane(ctx, n, false);
+    const std::vector<size_t> cut = sub_batch_bounds(ctx, n);
+    const size_t nsub = cut.size() - 1;
+    const bool overlapped = nsub > 1;
+    size_t scr_bytes = 0;
+    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, tables_scratch_bytes(cut[k + 1] - cut[k], pick_jobs_per_lane(ctx, cut[k + 1] - cut[k], false)));
     if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * n) || ctx->jobflags.ensure(n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * n) ||
-        ctx->tabscr.ensure(tables_scratch_bytes(n, jpl)) ||
+        ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->res2.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->res2inf.ensure(2 * n) || ctx->pkaff.ensure((size_t)2 * PLUME_FE_WORDS * 4 * n))
         return PLUME_ERR_HIP;
-    SignArgs a;
-    a.version = version; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msgs_bytes; a.sk = sk; a.r = r; a.pk_in = pk_in;
-    a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out; a.out33 = out33 ? 1 : 0;
-    a.gres = ctx->res.as<uint32_t>(); a.gresinf = ctx->resinf.as<uint8_t>(); a.bases = ctx->bases.as<uint32_t>(); a.jobflags = ctx->jobflags.as<uint8_t>();
-    a.itemflags = ctx->itemflags.as<uint8_t>(); a.pkaff = ctx->pkaff.as<uint32_t>(); a.tab = ctx->tab.as<uint32_t>();
-    a.hres = ctx->res2.as<uint32_t>(); a.hresinf = ctx->res2inf.as<uint8_t>(); a.gtab = ctx->gtab.as<uint32_t>(); a.gcomb = ctx->gcomb.as<uint32_t>();
+    if (overlapped) { if (int rc = pre_events(ctx, nsub)) return rc; }
     StageTimer& t = ctx->timer;
     t.begin(st);
-    launch_sign_gmul(a, st); t.stage("sign_gmul", st);
-    launch_normalize(a.gres, a.gresinf, 2 * n, st); t.stage("to_affine_g", st);
-    launch_sign_h2c(a, st); t.stage("sign_h2c", st);
-    launch_tables(a.tab, a.bases, a.jobflags, n, jpl, ctx->tabscr.as<uint32_t>(), st); t.stage("tables", st);
-    launch_sign_hmul(a, st); t.stage("sign_hmul", st);
-    launch_normalize(a.hres, a.hresinf, 2 * n, st); t.stage("to_affine_h", st);
-    launch_sign_final(a, st); t.stage("sign_final", st);
+    hipStream_t pre = overlapped ? ctx->pre : st;                               // the stages in front of the H multiplications of sub-batch k+1 run beside those of sub-batch k (verify_device)
+    if (overlapped) {
+        HIPCHK(hipEventRecord(ctx->pre_begin, st));
+        HIPCHK(hipStreamWaitEvent(pre, ctx->pre_begin, 0));
+    }
+    const size_t P = out33 ? 33 : 64;
+    for (size_t k = 0; k < nsub; k++) {
+        const size_t lo = cut[k], cnt = cut[k + 1] - cut[k];
+        SignArgs a;
+        a.version = version; a.n = (uint32_t)cnt; a.msgs = msgs; a.msg_off = msg_off + lo; a.msgs_bytes = msgs_bytes; a.sk = sk + 32 * lo; a.r = r + 32 * lo; a.pk_in = pk_in ? pk_in + 64 * lo : nullptr;
+        a.pk = pk ? pk + P * lo : nullptr; a.nul = nul + P * lo; a.c = c + 32 * lo; a.s = s + 32 * lo; a.rpt = rpt + P * lo; a.hr = hr + P * lo; a.status = status + lo;
+        a.h_out = h_out ? h_out + 64 * lo : nullptr; a.out33 = out33 ? 1 : 0;
+        a.gres = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.gresinf = ctx->resinf.as<uint8_t>() + 2 * lo; a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * lo;
+        a.jobflags = ctx->jobflags.as<uint8_t>() + lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo; a.pkaff = ctx->pkaff.as<uint32_t>() + (size_t)2 * PLUME_FE_WORDS * lo;
+        a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * lo; a.hres = ctx->res2.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.hresinf = ctx->res2inf.as<uint8_t>() + 2 * lo;
+        a.gtab = ctx->gtab.as<uint32_t>(); a.gcomb = ctx->gcomb.as<uint32_t>();
+        launch_sign_gmul(a, pre); if (!overlapped) t.stage("sign_gmul", st);
+        launch_normalize(a.gres, a.gresinf, 2 * cnt, pre); if (!overlapped) t.stage("to_affine_g", st);
+        launch_sign_h2c(a, pre); if (!overlapped) t.stage("sign_h2c", st);
+        launch_tables(a.tab, a.bases, a.jobflags, cnt, pick_jobs_per_lane(ctx, cnt, false), ctx->tabscr.as<uint32_t>(), pre); if (!overlapped) t.stage("tables", st);
+        if (overlapped) {
+            HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));
+            HIPCHK(hipStreamWaitEvent(st, ctx->pre_ready[k], 0));
+        }
+        launch_sign_hmul(a, st); if (!overlapped) t.stage("sign_hmul", st);
+        launch_normalize(a.hres, a.hresinf, 2 * cnt, st); if (!overlapped) t.stage("to_affine_h", st);
+        launch_sign_final(a, st); if (!overlapped) t.stage("sign_final", st);
+    }
+    if (overlapped) t.stage("sign_overlapped", st);
     // the reference zeroizes secrets: wipe the device-side images derived from sk / r
     HIPCHK(hipMemsetAsync(ctx->res.p, 0, (size_t)PLUME_JAC_WORDS * 4 * 2 * n, st));
     HIPCHK(hipGetLastError());
