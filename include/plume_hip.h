@@ -64,10 +64,12 @@ const char* plume_last_error(void);
 const char* plume_version(void);
 /* Upper bound on items processed per internal pass (workspace is ~3.9 KB per in-flight item). Default 1<<20. */
 int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
-/* Device-resident verify / sign calls of >= 2^17 items are cut into `sub_batches` slices (default 4): validation + hash_to_curve and the window
- * tables of slice k+1 run on a second stream of the context beside the multi-scalar kernel of slice k (that kernel saturates the vector ALUs and
- * leaves HBM idle; the table kernel is the other way round).  Results do not depend on it.  1 = strictly serial launch order on the caller's
- * stream, the mode in which plume_last_stage_times reports one time per kernel (env PLUME_SERIAL=1 makes it the default). */
+/* Device-resident verify / sign calls of >= 2^17 items can be cut into `sub_batches` slices: validation + hash_to_curve and the window tables of
+ * slice k+1 then run on a second stream of the context beside the multi-scalar kernel of slice k.  Results do not depend on it.  Default 1 =
+ * strictly serial launch order on the caller's stream, which is also the mode in which plume_last_stage_times reports one time per kernel:
+ * on the MI355X the overlapped order measured 1-3 % SLOWER than the serial one (round 3, DESIGN.md §6: kernels of two streams sharing the
+ * compute units cost more than the table kernel's idle issue slots give back), so the knob is an experiment's record, not a recommendation.
+ * Env PLUME_SUB_BATCHES=k sets the default of new contexts, PLUME_SERIAL=1 forces 1. */
 int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (three streams,
  * two staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each

@@ -4,6 +4,7 @@
 // pipeline logic can be checked against the oracle in a container without a GPU.
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -89,9 +90,9 @@ static void build_gtab(std::vector<uint32_t>& gtab) {
     static std::vector<uint32_t> cached;           // the table only depends on G: build it once per process (2048 entries for W = 12)
     if (!cached.empty()) { gtab = cached; return; }
     gtab.assign(PLUME_GTAB_WORDS, 0);
-    std::vector<uint32_t> bases(PLUME_JAC_WORDS, 0);
+    std::vector<uint32_t> bases(PLUME_BASE_WORDS, 0);      // (base records hold 16-byte quads: operator new / malloc align to 16 bytes on this platform)
     jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
-    st_jac_soa(bases.data(), 1, 0, g);
+    st_base(bases.data(), 0, g);
     uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
     std::vector<uint32_t> scr((size_t)PLUME_GTAB_ENTRIES * PLUME_TAB_SCR_WORDS);
     table_build<PLUME_GTAB_ENTRIES>(gtab.data(), bases.data(), &flag, 1, 0, 1, scr.data(), 1, 0);
@@ -100,13 +101,13 @@ static void build_gtab(std::vector<uint32_t>& gtab) {
 
 static void build_gcomb(std::vector<uint32_t>& comb) {
     comb.assign(PLUME_COMB_WORDS, 0);
-    std::vector<uint32_t> bases(PLUME_JAC_WORDS * PLUME_COMB_WINDOWS, 0);
+    std::vector<uint32_t> bases(PLUME_BASE_WORDS * PLUME_COMB_WINDOWS, 0);
     std::vector<uint8_t> flags(PLUME_COMB_WINDOWS, 0);
     std::vector<uint32_t> scr((size_t)PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES * PLUME_TAB_SCR_WORDS);
     for (uint32_t i = 0; i < PLUME_COMB_WINDOWS; i++) {      // mirrors k_gcomb
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
         for (uint32_t d = 0; d < PLUME_COMB_W * i; d++) jac_dbl(g);
-        st_jac_soa(bases.data(), PLUME_COMB_WINDOWS, i, g);
+        st_base(bases.data(), i, g);
         flags[i] = PLUME_JOB_OK;
         table_build<PLUME_COMB_ENTRIES>(comb.data(), bases.data(), flags.data(), PLUME_COMB_WINDOWS, i, 1, scr.data(), PLUME_COMB_WINDOWS, i);
     }
@@ -118,26 +119,50 @@ static const std::vector<uint32_t>& shared_gcomb() {
     return gcomb;
 }
 
-// host stand-in for launch_tables: the same lane -> jobs mapping and the same lane-interleaved scratch indexing as k_tables
+// host stand-in for launch_tables: the same lane -> jobs mapping, the same lane-interleaved scratch indexing and the same PASS sequence as the multi-kernel form of
+// k_tables (one loop over the lanes per pass, the lanes' running products in a word-major array, tab_invert_group between two passes); a batch of one lane also runs
+// the one-function form (table_build_affine) and the two must agree
 static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L, stride = ((lanes + 7) / 8) * 8;     // "grid" rounded up like the kernel's
-    std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_AFF_SCR_WORDS);
-    for (size_t lane = 0; lane < lanes; lane++) {
-        const size_t j0 = lane * (size_t)L, rem = njobs - j0;
-        table_build_affine(tab, bases, jobflags, njobs, j0, (int)(rem < (size_t)L ? rem : (size_t)L), scr.data(), stride, lane);
+    std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_AFF_SCR_WORDS), carry(stride * PLUME_FE_WORDS);
+    std::vector<uint8_t> guardf(stride, 0);
+    constexpr int K = 8, NPASS = PLUME_TAB_ENTRIES == 16 ? 5 : 4;
+    const size_t T = (stride + K - 1) / K;
+    const DirectRowSinkSync sink;
+    for (int pass = 0; pass < NPASS; pass++) {
+        for (size_t lane = 0; lane < stride; lane++) {
+            const size_t j0 = lane * (size_t)L;
+            const int cnt = j0 < njobs ? (int)(njobs - j0 < (size_t)L ? njobs - j0 : (size_t)L) : 0;
+            fe c; bool g = false;
+            if (pass > 0) { ld_fe_soa(c, carry.data(), stride, lane); g = guardf[lane] != 0; }
+            if (pass == 0) tab_pass_a<DirectRowSinkSync>(bases, jobflags, njobs, j0, cnt, scr.data(), stride, lane, c, g);
+            else if (pass == 1) tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr.data(), stride, lane, c, g, sink);
+            else if (pass == 2) tab_pass_c(tab, j0, cnt, scr.data(), stride, lane, c, g, sink);
+            else if (pass == 3) tab_pass_d(tab, j0, cnt, scr.data(), stride, lane, c, g, sink);
+#if PLUME_TAB_ENTRIES == 16
+            else tab_pass_e(tab, j0, cnt, scr.data(), stride, lane, c, g, sink);
+#endif
+            if (pass < NPASS - 1) { st_fe_soa(carry.data(), stride, lane, c); guardf[lane] = g ? 1 : 0; }
+        }
+        if (pass < NPASS - 1) for (size_t t = 0; t < T; t++) tab_invert_group<K>(carry.data(), stride, T, t);
+    }
+    if (lanes == 1) {                                                              // the one-function form on the same input
+        std::vector<uint32_t> tab2((size_t)njobs * PLUME_TAB_WORDS), scr2((size_t)L * PLUME_TAB_AFF_SCR_WORDS);
+        table_build_affine(tab2.data(), bases, jobflags, njobs, 0, (int)njobs, scr2.data(), 1, 0);
+        if (memcmp(tab2.data(), tab, tab2.size() * 4) != 0) { fprintf(stderr, "devsim: table_build_affine and the pass sequence disagree\n"); abort(); }
     }
 }
 
 // window tables of `nb` affine bases given as raw 64-byte records, all flagged usable WITHOUT validation, built by ONE lane (test hook for the
 // zero-denominator guard of table_build_affine); out: nb x PLUME_TAB_ENTRIES x 64 bytes (x || y of 1P..)
 void ds_tables_raw(uint32_t nb, const uint8_t* pts, uint8_t* out) {
-    std::vector<uint32_t> bases(PLUME_JAC_WORDS * (size_t)nb), tab((size_t)nb * PLUME_TAB_WORDS);
+    std::vector<uint32_t> bases(PLUME_BASE_WORDS * (size_t)nb), tab((size_t)nb * PLUME_TAB_WORDS);
     std::vector<uint8_t> flags(nb, (uint8_t)(PLUME_JOB_OK | PLUME_JOB_AFFINE));
     for (uint32_t j = 0; j < nb; j++) {
         alignas(16) uint8_t rec[64]; memcpy(rec, pts + 64 * j, 64);
         jac p; p.inf = 0; p.z = fe_small(1);
         fe_from_be_aligned(p.x, rec); fe_from_be_aligned(p.y, rec + 32);
-        st_jac_soa(bases.data(), nb, j, p);
+        st_base(bases.data(), j, p);
     }
     run_tables(tab.data(), bases.data(), flags.data(), nb, (int)nb);
     for (uint32_t j = 0; j < nb; j++)
@@ -187,7 +212,7 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
                        uint64_t msgs_bytes) {
     if (version != 1 && version != 2) return -1;
     std::vector<uint32_t> gtab; build_gtab(gtab);
-    std::vector<uint32_t> bases(PLUME_JAC_WORDS * 3 * (size_t)n), tab((size_t)3 * n * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2 * (size_t)n);
+    std::vector<uint32_t> bases(PLUME_BASE_WORDS * 3 * (size_t)n), tab((size_t)3 * n * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2 * (size_t)n);
     std::vector<uint8_t> jobflags(3 * (size_t)n), itemflags(n), resinf(2 * (size_t)n);
     VerifyArgs a;
     a.mode = mode; a.msgs_bytes = msgs_bytes == ~0ull ? msg_off[n] : msgs_bytes;
@@ -219,7 +244,7 @@ int ds_aggregate_check(int version, int mode, uint32_t n, const uint8_t* msgs, c
     a.W = W; a.nw_long = (256 + W - 1) / W; a.nw_short = (128 + W - 1) / W; a.nbuckets = 1u << (W - 1); a.nkeys = (uint32_t)a.nw_long * a.nbuckets;
     a.index_base = index_base; memcpy(a.seed, seed, 32);
     const size_t nn = n ? n : 1, npairs = (size_t)n * (3 * a.nw_long + 2 * a.nw_short);
-    std::vector<uint32_t> bases(PLUME_JAC_WORDS * 3 * nn), scal((size_t)PLUME_AGG_TERMS * 8 * nn), gs(8 * nn, 0), count((size_t)a.nkeys + 1, 0), sorted(npairs + 1),
+    std::vector<uint32_t> bases(PLUME_BASE_WORDS * 3 * nn), scal((size_t)PLUME_AGG_TERMS * 8 * nn), gs(8 * nn, 0), count((size_t)a.nkeys + 1, 0), sorted(npairs + 1),
         bsum((size_t)PLUME_JAC_WORDS * a.nkeys), nbad(4, 0);
     std::vector<uint8_t> jobflags(3 * nn), itemflags(nn), haff(64 * nn + 16), flags(2 * nn), bsuminf(a.nkeys), hok(nn);
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr;
@@ -331,7 +356,7 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     if (version != 1 && version != 2) return -1;
     std::vector<uint32_t> gtab; build_gtab(gtab);
     const std::vector<uint32_t>& gcomb = shared_gcomb();
-    std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_JAC_WORDS * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
+    std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_BASE_WORDS * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
     std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(n), itemflags(n);
     SignArgs a; memset(&a, 0, sizeof a);
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msg_off[n]; a.sk = sk; a.r = r; a.pk_in = pk_in;
@@ -365,13 +390,13 @@ int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[6
     fe x, y;
     uint32_t f = load_affine_be(x, y, pb);
     if (f == PLUME_JOB_INVALID) return 0;
-    std::vector<uint32_t> bases(PLUME_JAC_WORDS * 3), tab(3 * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2);
+    std::vector<uint32_t> bases(PLUME_BASE_WORDS * 3), tab(3 * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2);
     std::vector<uint8_t> jobflags(3), itemflags(1, 0), resinf(2);
     VerifyArgs a; memset(&a, 0, sizeof a);
     a.version = 2; a.mode = PLUME_MODE_VERIFY; a.n = 1; a.c = cb; a.s = sb; a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
     a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data(); a.gtab = gtab.data();
     jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
-    for (int j = 0; j < 3; j++) { st_jac_soa(a.bases, 3, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
+    for (int j = 0; j < 3; j++) { st_base(a.bases, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
     run_tables(a.tab, a.bases, a.jobflags, 3, 3);
     std::vector<int8_t> dig(4 * PLUME_NDIG);
     verify_msm(a, 0, 0, a.gtab, dig.data(), 1);
@@ -411,9 +436,9 @@ int ds_point_mul(const uint8_t k_be[32], const uint8_t p_be[64], uint8_t out[64]
     if (f == PLUME_JOB_INVALID) return 0;
     alignas(16) uint8_t ob[64];
     if (f == PLUME_JOB_INF) { memset(out, 0, 64); return 1; }
-    std::vector<uint32_t> bases(PLUME_JAC_WORDS), tab(PLUME_TAB_WORDS);
+    std::vector<uint32_t> bases(PLUME_BASE_WORDS), tab(PLUME_TAB_WORDS);
     jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
-    st_jac_soa(bases.data(), 1, 0, p);
+    st_base(bases.data(), 0, p);
     uint8_t flag = 0;
     run_tables(tab.data(), bases.data(), &flag, 1, 1);
     sc k; sc_from_be_aligned(k, kb);

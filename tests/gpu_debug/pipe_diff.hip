@@ -20,7 +20,7 @@ __host__ __device__ inline void run_item(const uint32_t* in, uint32_t* out, uint
     to_aff(out, out + 8, h);
     // B: k * H via table + msm
     h.inf = 0;
-    st_jac_soa(bases, 1, 0, h);
+    st_base(bases, 0, h);
     uint8_t flag = 0;
     table_build(tab, bases, &flag, 1, 0, 1, scr, 1, 0);
     sc k; for (int i = 0; i < 8; i++) k.v[i] = in[8 + i]; k.v[7] &= 0x7FFFFFFFu;

@@ -20,7 +20,7 @@ DEFAULT_CHUNK = 1 << 20
 DEFAULT_HOST_PIECE = 1 << 19
 DEFAULT_HOST_FIRST_PIECE = 1 << 16
 DEFAULT_HOST_TAIL_PIECE = 1 << 17
-DEFAULT_SUB_BATCHES = 4
+DEFAULT_SUB_BATCHES = 1
 
 
 class PlumeHipError(RuntimeError):
@@ -464,12 +464,13 @@ class Engine:
 
     # ------------------------------------------------------------------ measurement
     def last_stage_times(self):
-        names = (C.c_char_p * 16)()
-        ms = (C.c_float * 16)()
-        k = self._lib.plume_last_stage_times(self._ctx, names, ms, 16)
+        cap = 512
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        k = self._lib.plume_last_stage_times(self._ctx, names, ms, cap)
         if k < 0:
             raise PlumeHipError(f"plume_last_stage_times failed ({k}): {self._lib.plume_last_error().decode()}")
-        return [(names[i].decode(), float(ms[i])) for i in range(k)]
+        return [(names[i].decode(), float(ms[i])) for i in range(min(k, cap))]
 
     def microbench(self, kind, iters=4096):
         v = self._lib.plume_microbench(self._ctx, int(kind), int(iters))

@@ -72,7 +72,6 @@ PLUME_HD const uint8_t* agg_term_point(const AggArgs& a, uint32_t item, uint32_t
 // ---------------------------------------------------------------------------------------- stage 1: H -> affine
 // lane handles items lane + j*nlanes (coalesced), one inversion for PLUME_AGG_NORM_K values of Z (Montgomery's trick)
 PLUME_HD void agg_normalize_h(const AggArgs& a, size_t lane, size_t nlanes) {
-    const size_t nj = 3 * (size_t)a.n;
     fe z[PLUME_AGG_NORM_K], pre[PLUME_AGG_NORM_K];
     fe acc = fe_small(1);
     bool live[PLUME_AGG_NORM_K];
@@ -80,7 +79,7 @@ PLUME_HD void agg_normalize_h(const AggArgs& a, size_t lane, size_t nlanes) {
         const size_t idx = lane + (size_t)j * nlanes;
         const size_t safe = idx < a.n ? idx : 0;
         live[j] = idx < a.n && !a.itemflags[safe] && job_state(a.jobflags[3 * safe + 1]) == PLUME_JOB_OK;
-        if (live[j]) ld_fe_soa(z[j], a.bases + 2 * PLUME_FE_W * nj, nj, 3 * idx + 1); else z[j] = fe_small(1);
+        if (live[j]) { jac hz; ld_base(hz, a.bases, 3 * idx + 1, true); z[j] = hz.z; } else z[j] = fe_small(1);
         pre[j] = acc;
         fe_mul(acc, acc, z[j]);
     }
@@ -92,7 +91,7 @@ PLUME_HD void agg_normalize_h(const AggArgs& a, size_t lane, size_t nlanes) {
         fe_mul(zi, inv, pre[j]);
         fe_mul(inv, inv, z[j]);
         if (live[j]) {
-            ld_fe_soa(x, a.bases, nj, 3 * idx + 1); ld_fe_soa(y, a.bases + PLUME_FE_W * nj, nj, 3 * idx + 1);
+            jac hxy; ld_base(hxy, a.bases, 3 * idx + 1, false); x = hxy.x; y = hxy.y;
             fe_sqr(zi2, zi);
             fe_mul(x, x, zi2);
             fe_mul(zi2, zi2, zi); fe_mul(y, y, zi2);

@@ -87,7 +87,8 @@ struct plume_ctx {
     hipStream_t pre = nullptr;                                    // overlapped verify / sign: the stages BEFORE the multi-scalar kernel of sub-batch k+1 run here, beside that kernel of sub-batch k
     hipEvent_t pre_begin = nullptr;                               // ... the caller's stream has reached the call (inputs are there, the workspace is free)
     std::vector<hipEvent_t> pre_ready;                            // ... sub-batch k's window tables are built
-    int sub_batches = 4;                                          // device-resident verify / sign: number of sub-batches (1 = strictly serial launch order, the mode per-stage times are measured in)
+    int sub_batches = 1;                                          // device-resident verify / sign: number of sub-batches; 1 = strictly serial launch order (the default: measured on the MI355X, r03, kernels of two
+                                                                  // streams sharing the CUs cost MORE than the table kernel's idle issue slots give back -- 21.85 ms serial vs 22.1-22.4 ms for 2..16 sub-batches)
     size_t overlap_min = (size_t)1 << 17;                         // ... batches below this many items always run serial (a sub-batch must still fill the chip)
     hipEvent_t agg_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // terms ready / upper bucket sums ready / generator term ready / upper windows reduced
     hipEvent_t ws_free = nullptr;     // recorded behind the last kernel of every device-resident call: the next call's stream waits on it before it
@@ -205,13 +206,13 @@ static int init_single(plume_ctx* ctx) {
         HIPCHK(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
     }
     // the generator's tables: the verifier's wide window table (1..2^(W-1))*G and the signer's doubling-free comb, built once on the device
-    if (ctx->gtab.ensure((size_t)PLUME_GTAB_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(PLUME_JAC_WORDS * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64) ||
+    if (ctx->gtab.ensure((size_t)PLUME_GTAB_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(PLUME_BASE_WORDS * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64) ||
         ctx->tabscr.ensure((size_t)(PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES > PLUME_GTAB_ENTRIES ? PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES : PLUME_GTAB_ENTRIES) * PLUME_TAB_SCR_WORDS * 4))
         return PLUME_ERR_HIP;
-    uint32_t hb[PLUME_JAC_WORDS];
+    alignas(16) uint32_t hb[PLUME_BASE_WORDS];
     {
         jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
-        st_jac_soa(hb, 1, 0, g);
+        st_base(hb, 0, g);
     }
     uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
     HIPCHK(hipMemcpyAsync(ctx->bases.p, hb, sizeof hb, hipMemcpyHostToDevice, ctx->stream));
@@ -439,7 +440,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     const bool overlapped = nsub > 1;
     size_t scr_bytes = 0;
     for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, tables_scratch_bytes(3 * (cut[k + 1] - cut[k]), pick_jobs_per_lane(ctx, 3 * (cut[k + 1] - cut[k]), true)));
-    if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
+    if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
         ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n))
         return PLUME_ERR_HIP;
@@ -457,7 +458,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         a.version = version; a.mode = mode; a.n = (uint32_t)cnt; a.msgs = msgs; a.msg_off = msg_off + lo; a.msgs_bytes = msgs_bytes;
         a.pk = pk + 64 * lo; a.nul = nul + 64 * lo; a.c = c + 32 * lo; a.s = s + 32 * lo; a.rpt = rpt ? rpt + 64 * lo : nullptr; a.hr = hr ? hr + 64 * lo : nullptr; a.ok = ok + lo;
         a.preflags = preflags ? preflags + lo : nullptr; a.rpt33 = rpt33 ? rpt33 + 33 * lo : nullptr; a.hr33 = hr33 ? hr33 + 33 * lo : nullptr;
-        a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 3 * lo; a.jobflags = ctx->jobflags.as<uint8_t>() + 3 * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo;
+        a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * 3 * lo; a.jobflags = ctx->jobflags.as<uint8_t>() + 3 * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo;
         a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * 3 * lo; a.res = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.resinf = ctx->resinf.as<uint8_t>() + 2 * lo;
         a.gtab = ctx->gtab.as<uint32_t>();
         launch_verify_ingest(a, pre); if (!overlapped) t.stage("verify_ingest_h2c", st);
@@ -487,7 +488,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     const bool overlapped = nsub > 1;
     size_t scr_bytes = 0;
     for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, tables_scratch_bytes(cut[k + 1] - cut[k], pick_jobs_per_lane(ctx, cut[k + 1] - cut[k], false)));
-    if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * n) || ctx->jobflags.ensure(n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * n) ||
+    if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * n) || ctx->jobflags.ensure(n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * n) ||
         ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->res2.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->res2inf.ensure(2 * n) || ctx->pkaff.ensure((size_t)2 * PLUME_FE_WORDS * 4 * n))
         return PLUME_ERR_HIP;
@@ -506,7 +507,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
         a.version = version; a.n = (uint32_t)cnt; a.msgs = msgs; a.msg_off = msg_off + lo; a.msgs_bytes = msgs_bytes; a.sk = sk + 32 * lo; a.r = r + 32 * lo; a.pk_in = pk_in ? pk_in + 64 * lo : nullptr;
         a.pk = pk ? pk + P * lo : nullptr; a.nul = nul + P * lo; a.c = c + 32 * lo; a.s = s + 32 * lo; a.rpt = rpt + P * lo; a.hr = hr + P * lo; a.status = status + lo;
         a.h_out = h_out ? h_out + 64 * lo : nullptr; a.out33 = out33 ? 1 : 0;
-        a.gres = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.gresinf = ctx->resinf.as<uint8_t>() + 2 * lo; a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * lo;
+        a.gres = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.gresinf = ctx->resinf.as<uint8_t>() + 2 * lo; a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * lo;
         a.jobflags = ctx->jobflags.as<uint8_t>() + lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo; a.pkaff = ctx->pkaff.as<uint32_t>() + (size_t)2 * PLUME_FE_WORDS * lo;
         a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * lo; a.hres = ctx->res2.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.hresinf = ctx->res2inf.as<uint8_t>() + 2 * lo;
         a.gtab = ctx->gtab.as<uint32_t>(); a.gcomb = ctx->gcomb.as<uint32_t>();
@@ -688,7 +689,7 @@ static int aggregate_device(plume_ctx* ctx, int version, int mode, size_t n, con
     const uint32_t nlo = (uint32_t)a.nw_long / 2, nhi = (uint32_t)a.nw_long - nlo;
     const size_t npairs = n * (size_t)(3 * a.nw_long + 2 * a.nw_short), nred = agg_reduce_points(a, nhi), sw = agg_scalar_sum_words(n ? n : 1);
     DevBuf* B = ctx->agg;
-    if (ctx->bases.ensure((size_t)PLUME_JAC_WORDS * 4 * 3 * n + 16) || ctx->jobflags.ensure(3 * n + 16) || ctx->itemflags.ensure(n + 16) ||
+    if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * 3 * n + 16) || ctx->jobflags.ensure(3 * n + 16) || ctx->itemflags.ensure(n + 16) ||
         B[0].ensure(64 * n + 16) || B[1].ensure((size_t)PLUME_AGG_TERMS * 32 * n + 16) || B[2].ensure(2 * n + 16) || B[3].ensure(32 * n + 32) || B[4].ensure(n + 16) ||
         B[5].ensure(16 + 4 * (size_t)kAggScanLanes) || B[6].ensure(((size_t)a.nkeys + 1) * 4) || B[7].ensure(agg_sort_tile_words(a) * 4) || B[8].ensure(npairs * 4 + 16) ||
         B[9].ensure((size_t)PLUME_JAC_WORDS * 4 * a.nkeys) || B[10].ensure(a.nkeys) || B[11].ensure(4 * (size_t)PLUME_JAC_WORDS * 4 * nred) || B[12].ensure(4 * nred) ||

@@ -305,6 +305,33 @@ PLUME_HD void ld_jac_soa(jac& p, const uint32_t* base, size_t stride, size_t j) 
 PLUME_HD void st_jac_soa(uint32_t* base, size_t stride, size_t j, const jac& p) {
     st_fe_soa(base, stride, j, p.x); st_fe_soa(base + PLUME_FE_W * stride, stride, j, p.y); st_fe_soa(base + 2 * PLUME_FE_W * stride, stride, j, p.z);
 }
+// The base of a table job in HBM: ONE 112-byte record per job, job-major -- x0..x8 | y0..y8 | z0..z8 | 0 -- seven 16-byte quads.  (Rounds 1-2 kept the bases word-major,
+// word w of job j at bases[w * njobs + j].  The table kernel's lanes walk L CONSECUTIVE jobs each, so a wavefront's load of one word touched 64 words L * 4 bytes apart: every
+// 128-byte line was fetched L times over -- FETCH_SIZE of the two passes that read the bases: 2.3 GB per 2^20 verifies for 0.38 GB of records -- and the ingest kernel's
+// stores, 3 words apart per lane, wrote every line in pieces: WRITE_SIZE 1.5 GB for 0.34 GB.  With one record per job a lane reads its job with five or seven aligned
+// 16-byte loads from at most two lines nobody else needs, and a wavefront of the ingest kernel writes one contiguous 21 KB stretch.)
+#define PLUME_BASE_WORDS 28
+struct alignas(16) quad32 { uint32_t a, b, c, d; };
+PLUME_HD void st_base(uint32_t* bases, size_t job, const jac& p) {
+    quad32* q = reinterpret_cast<quad32*>(bases + job * PLUME_BASE_WORDS);
+    q[0] = quad32{p.x.v[0], p.x.v[1], p.x.v[2], p.x.v[3]}; q[1] = quad32{p.x.v[4], p.x.v[5], p.x.v[6], p.x.v[7]};
+    q[2] = quad32{p.x.v[8], p.y.v[0], p.y.v[1], p.y.v[2]}; q[3] = quad32{p.y.v[3], p.y.v[4], p.y.v[5], p.y.v[6]};
+    q[4] = quad32{p.y.v[7], p.y.v[8], p.z.v[0], p.z.v[1]}; q[5] = quad32{p.z.v[2], p.z.v[3], p.z.v[4], p.z.v[5]};
+    q[6] = quad32{p.z.v[6], p.z.v[7], p.z.v[8], 0u};
+}
+// x, y (five quads) and, for a Jacobian base, z (two more)
+PLUME_HD void ld_base(jac& p, const uint32_t* bases, size_t job, bool with_z) {
+    const quad32* q = reinterpret_cast<const quad32*>(bases + job * PLUME_BASE_WORDS);
+    const quad32 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+    p.x.v[0] = q0.a; p.x.v[1] = q0.b; p.x.v[2] = q0.c; p.x.v[3] = q0.d; p.x.v[4] = q1.a; p.x.v[5] = q1.b; p.x.v[6] = q1.c; p.x.v[7] = q1.d; p.x.v[8] = q2.a;
+    p.y.v[0] = q2.b; p.y.v[1] = q2.c; p.y.v[2] = q2.d; p.y.v[3] = q3.a; p.y.v[4] = q3.b; p.y.v[5] = q3.c; p.y.v[6] = q3.d; p.y.v[7] = q4.a; p.y.v[8] = q4.b;
+    if (with_z) {
+        const quad32 q5 = q[5], q6 = q[6];
+        p.z.v[0] = q4.c; p.z.v[1] = q4.d; p.z.v[2] = q5.a; p.z.v[3] = q5.b; p.z.v[4] = q5.c; p.z.v[5] = q5.d; p.z.v[6] = q6.a; p.z.v[7] = q6.b; p.z.v[8] = q6.c;
+    } else {
+        p.z = fe_small(1);
+    }
+}
 
 #ifndef PLUME_TABLE_MADD
 #define PLUME_TABLE_MADD 1   // mixed additions for Z = 1 bases (pk, nullifier) in table_build: 8M+3S instead of 12M+4S per odd multiple
@@ -323,7 +350,7 @@ PLUME_HD uint32_t job_state(uint8_t f) { return f & 3u; }
 #define PLUME_COMB_ENTRIES (1 << (PLUME_COMB_W - 1))
 #define PLUME_COMB_WINDOW_WORDS (PLUME_COMB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 
-// Build the tables of jobs [j0, j0+cnt) (cnt <= L, one lane).  Bases are Jacobian SoA (stride = njobs).
+// Build the tables of jobs [j0, j0+cnt) (cnt <= L, one lane).  Bases are job-major records (st_base).
 // Pass 1 writes (X_k, Y_k, Z_k, running product before Z_k) for k = 1..8 of every job to the lane's slice of `scr`; one
 // inversion of the total product; pass 2 walks back, peels off each 1/Z_k, and writes the affine entry (x, y, beta*x) to `tab`.
 // scr is lane-interleaved: word w of the lane's q-th scratch entry lives at scr[(q * PLUME_TAB_SCR_WORDS + w) * sstride + slane],
@@ -348,7 +375,7 @@ PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* j
     PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
         size_t job = j0 + (size_t)jj;
         jac b;
-        ld_jac_soa(b, bases, njobs, job);
+        ld_base(b, bases, job, true);
         b.inf = 0;
         const bool zone = (jobflags[job] & PLUME_JOB_AFFINE) != 0;   // wave-uniform when job kinds repeat with period | cnt
         (void)zone;
@@ -474,8 +501,8 @@ PLUME_HD void tab_unpark(fe& Dinv, fe& inv, const uint32_t* scr, size_t sstride,
 // affine base are not even loaded.
 PLUME_HD bool tab_base(jac& b, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t job) {
     bool zone = (jobflags[job] & PLUME_JOB_AFFINE) != 0;
-    ld_fe_soa(b.x, bases, njobs, job); ld_fe_soa(b.y, bases + PLUME_FE_W * njobs, njobs, job);
-    if (zone) b.z = fe_small(1); else ld_fe_soa(b.z, bases + 2 * PLUME_FE_W * njobs, njobs, job);
+    (void)njobs;
+    ld_base(b, bases, job, !zone);
     b.inf = 0;
     if (job_state(jobflags[job]) != PLUME_JOB_OK) { b.x = fe_gx(); b.y = fe_gy(); b.z = fe_small(1); zone = true; }
     return zone;
@@ -510,15 +537,17 @@ PLUME_HD void ld_tab_y(fe& y, const uint32_t* e) { PLUME_UNROLL for (int i = 0; 
 // Level k+1's denominators are formed -- and their product joins the lane's chain -- inside level k's finishing pass, while the entries they come from are
 // still in registers: four passes over a lane's jobs instead of six, and no pass that only re-reads rows.  Consecutive levels therefore run through the
 // jobs in opposite directions (a level is finished in the reverse of the order its products were parked in) and use alternating scratch regions.
-template <class RowSink = DirectRowSinkSync>
-PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
-                                 const RowSink& sink = RowSink()) {
-    const fe beta = fe_beta();
-    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
-    const size_t RB = (size_t)cnt;                               // second scratch region
-    fe acc, inv;
-    bool guard = false;
-    // ------------------------------------------------------------------------------- level 1, forward (jobs ascending): denominators of P -> affine, 2P
+// The chain as PASSES (round 3).  Each pass walks the lane's jobs once; between two passes stands ONE field inversion of the lane's running product.  The passes share
+// no registers: what a lane carries from one to the next is that product / its inverse (`carry`, 9 words) and the guard flag, so the same code serves
+//   * table_build_affine below: all passes in one function, the inversion through the sink (host builds, single-lane builds, the one-kernel form of k_tables), and
+//   * the multi-kernel form of k_tables: one launch per pass with a small batched-inversion kernel (k_tab_invert) in between, `carry` parked in HBM.  No pass then
+//     contains an inversion or a workgroup barrier: in the one-kernel form a workgroup's waves idle through three serial 20 k-instruction inversions (VALUBusy 0.50,
+//     DESIGN.md §5); here every pass is a plain streaming kernel and the inversions of the whole batch run as one dense launch.
+// Pass A (jobs ascending): denominators of level 1 -> carry = their product.
+template <class RowSink>
+PLUME_HD void tab_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane, fe& carry, bool& guard) {
+    fe acc;
+    guard = false;
     PLUME_NOUNROLL for (int pass = 0; pass < 2; pass++) {
         acc = fe_small(1);
         PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
@@ -531,9 +560,16 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
         if (guard || !fe_is_zero(acc)) break;
         guard = true;                                            // unreachable for points of prime order: redo with zero denominators replaced by 1
     }
-    sink.inv(inv, acc, 1);
-    // ------------------------------------------------------------------------------- level 1, finish (jobs descending) + level 2's denominators
-    acc = fe_small(1);
+    carry = acc;
+}
+// Pass B (jobs descending): carry = 1 / (level 1's product) in; P -> affine, 2P; level 2's denominators -> carry = their product out.
+template <class RowSink>
+PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
+                         fe& carry, bool& guard, const RowSink& sink) {
+    const fe beta = fe_beta();
+    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
+    const size_t RB = (size_t)cnt;                               // second scratch region
+    fe inv = carry, acc = fe_small(1);
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
         const size_t job = j0 + (size_t)jj;
         jac b;
@@ -568,9 +604,15 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
             tab_park(acc, scr, sstride, slane, RB + (size_t)jj, D);
         }
     }
-    sink.inv(inv, acc, 2);
-    // ------------------------------------------------------------------------------- level 2, finish (jobs ascending): 4P, 3P + level 3's denominators
-    acc = fe_small(1);
+    carry = acc;
+}
+// Pass C (jobs ascending): carry = 1 / (level 2's product) in; 4P, 3P; level 3's denominators -> carry out.
+template <class RowSink>
+PLUME_HD void tab_pass_c(uint32_t* tab, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane, fe& carry, bool& guard, const RowSink& sink) {
+    const fe beta = fe_beta();
+    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
+    const size_t RB = (size_t)cnt;
+    fe inv = carry, acc = fe_small(1);
     PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
         uint32_t* t = tab + (j0 + (size_t)jj) * TW;
         fe x1, y1, x2, y2, da, db, D, Dinv, l, x3, y3, x4, y4, bx;
@@ -598,10 +640,17 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
             tab_park(acc, scr, sstride, slane, (size_t)jj, D);
         }
     }
-    sink.inv(inv, acc, 3);
-    // ------------------------------------------------------------------------------- level 3, finish (jobs descending): 8P, 7P, 6P, 5P  [+ level 4's denominators]
+    carry = acc;
+}
+// Pass D (jobs descending): carry = 1 / (level 3's product) in; 8P, 7P, 6P, 5P  [16-row tables: + level 4's denominators -> carry out].
+template <class RowSink>
+PLUME_HD void tab_pass_d(uint32_t* tab, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane, fe& carry, bool& guard, const RowSink& sink) {
+    const fe beta = fe_beta();
+    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
+    fe inv = carry;
 #if PLUME_TAB_ENTRIES == 16
-    acc = fe_small(1);
+    const size_t RB = (size_t)cnt;
+    fe acc = fe_small(1);
 #endif
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
         uint32_t* t = tab + (j0 + (size_t)jj) * TW;
@@ -660,8 +709,19 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
             tab_park(acc, scr, sstride, slane, RB + 2 * (size_t)jj + 1, D);
         }
     }
-    sink.inv(inv, acc, 4);
-    // ------------------------------------------------------------------------------- level 4, finish (jobs ascending; per job half B, then half A: the reverse of the parking order)
+    carry = acc;
+#else
+    (void)scr; (void)sstride; (void)slane; (void)guard;
+#endif
+}
+#if PLUME_TAB_ENTRIES == 16
+// Pass E (16-row tables; jobs ascending; per job half B, then half A: the reverse of the parking order): carry = 1 / (level 4's product) in; 9P..16P.
+template <class RowSink>
+PLUME_HD void tab_pass_e(uint32_t* tab, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane, fe& carry, bool& guard, const RowSink& sink) {
+    const fe beta = fe_beta();
+    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
+    const size_t RB = (size_t)cnt;
+    fe inv = carry;
     PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
         uint32_t* t = tab + (j0 + (size_t)jj) * TW;
         fe x8, y8, xa, ya, xb, yb, d[4], p01, p23, D, Dinv, i01, i23, l, xr, yr, bx;
@@ -705,6 +765,45 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
         aff_dbl(xr, yr, xa, ya, i23);                                               // 12P
         fe_mul_k(bx, beta, xr); sink(t + 11 * EW, xr, yr, bx);
     }
+}
+#endif
+// The inversion between two passes of the multi-kernel form: thread t of T takes the lane products t, t + T, ..., t + (K-1) T of the nl lanes (word-major array: coalesced)
+// and spends ONE inversion on their product (Montgomery's trick); in place.  The products are never zero (the passes' guard).
+template <int K>
+PLUME_HD void tab_invert_group(uint32_t* carry, size_t nl, size_t T, size_t t) {
+    fe v[K], pre[K], acc = fe_small(1), inv;
+    PLUME_UNROLL for (int j = 0; j < K; j++) {
+        const size_t l = t + (size_t)j * T;
+        if (l < nl) ld_fe_soa(v[j], carry, nl, l); else v[j] = fe_small(1);
+        pre[j] = acc;
+        fe_mul(acc, acc, v[j]);
+    }
+    fe_inv(inv, acc);
+    PLUME_UNROLL for (int j = K - 1; j >= 0; j--) {
+        const size_t l = t + (size_t)j * T;
+        fe o;
+        fe_mul(o, inv, pre[j]);
+        fe_mul(inv, inv, v[j]);
+        if (l < nl) st_fe_soa(carry, nl, l, o);
+    }
+}
+// All passes in one function: host builds, single-lane builds and the one-kernel form of k_tables (the sink supplies the inversion: DirectRowSinkSync inverts in place,
+// the table kernel's CoopRowSink shares one inversion between the wavefronts of a workgroup).
+template <class RowSink = DirectRowSinkSync>
+PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
+                                 const RowSink& sink = RowSink()) {
+    fe carry, inv;
+    bool guard;
+    tab_pass_a<RowSink>(bases, jobflags, njobs, j0, cnt, scr, sstride, slane, carry, guard);
+    sink.inv(inv, carry, 1); carry = inv;
+    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr, sstride, slane, carry, guard, sink);
+    sink.inv(inv, carry, 2); carry = inv;
+    tab_pass_c(tab, j0, cnt, scr, sstride, slane, carry, guard, sink);
+    sink.inv(inv, carry, 3); carry = inv;
+    tab_pass_d(tab, j0, cnt, scr, sstride, slane, carry, guard, sink);
+#if PLUME_TAB_ENTRIES == 16
+    sink.inv(inv, carry, 4); carry = inv;
+    tab_pass_e(tab, j0, cnt, scr, sstride, slane, carry, guard, sink);
 #endif
 }
 

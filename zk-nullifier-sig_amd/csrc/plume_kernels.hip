@@ -165,6 +165,72 @@ __global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* base
 #endif
 }
 
+// ---- the table kernel as one launch per PASS (round 3; plume_ec.h tab_pass_a..e) -------------------------------------------------------------------------------
+// k_tables above keeps a workgroup's four wavefronts waiting through three serial inversions (one wavefront inverts for all four: VALUBusy 0.50, and the kernel's time
+// is the critical path of a workgroup times the workgroups a CU can hold).  Here the chain's passes are separate launches over the same grid, a lane's running product
+// travels through HBM (9 words per lane, word-major: coalesced), and ALL the inversions of a level run as one dense launch of k_tab_invert in between (Montgomery's
+// trick over 8 lanes' products: one inversion per 48 jobs at 6 jobs per lane).  No pass holds an inversion or a workgroup barrier.
+#ifndef PLUME_TABLES_MULTIKERNEL
+#define PLUME_TABLES_MULTIKERNEL 1
+#endif
+#ifndef PLUME_TABPASS_WAVES_AB
+#define PLUME_TABPASS_WAVES_AB 3   // (r03 A/B on one box, table stage of a 2^20 verify: 4/3 waves 1.93 ms, 3/3 1.86, 3/2 1.83, 4/4 2.32; the one-kernel form 1.89)
+#endif
+#ifndef PLUME_TABPASS_WAVES_CD
+#define PLUME_TABPASS_WAVES_CD 2
+#endif
+#ifndef PLUME_TABINV_K
+#define PLUME_TABINV_K 8          // lane products per inversion
+#endif
+struct WaveRowSink : CoopRowSink {
+    __device__ void inv(fe&, const fe&, int) const {}      // never called: the inversions are k_tab_invert's
+};
+template <int PASS>
+__device__ __forceinline__ void tab_pass_body(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, uint8_t* guardf, uint4* s_rows, uint32_t** s_ptrs) {
+    const size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x, nl = (size_t)gridDim.x * kBlock;
+    const size_t j0 = lane * (size_t)L;
+    const int cnt = j0 < njobs ? (int)((njobs - j0) < (size_t)L ? (njobs - j0) : (size_t)L) : 0;
+    WaveRowSink sink;
+    sink.rows = s_rows + (threadIdx.x & ~63u) * 8;
+    sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
+    sink.full = __ballot(cnt == L) == ~0ull;
+    sink.xch = nullptr;
+    uint32_t* myscr = scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kBlock);
+    fe c;
+    bool g = false;
+    if (PASS > 0) { ld_fe_soa(c, carry, nl, lane); g = guardf[lane] != 0; }
+    if (PASS == 0) tab_pass_a<WaveRowSink>(bases, jobflags, njobs, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g);
+    else if (PASS == 1) tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
+    else if (PASS == 2) tab_pass_c(tab, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
+    else if (PASS == 3) tab_pass_d(tab, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
+#if PLUME_TAB_ENTRIES == 16
+    else tab_pass_e(tab, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
+#endif
+    if (PASS < (PLUME_TAB_ENTRIES == 16 ? 4 : 3)) { st_fe_soa(carry, nl, lane, c); guardf[lane] = g ? 1 : 0; }
+}
+__global__ __launch_bounds__(kBlock, PLUME_TABPASS_WAVES_AB) void k_tab_pass_a(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, uint8_t* guardf) {
+    tab_pass_body<0>(tab, bases, jobflags, njobs, L, scr, carry, guardf, nullptr, nullptr);
+}
+#define PLUME_TAB_PASS_KERNEL(NAME, PASS, WAVES)                                                                                                                              \
+    __global__ __launch_bounds__(kBlock, WAVES) void NAME(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, \
+                                                          uint8_t* guardf) {                                                                                                  \
+        __shared__ uint4 s_rows[kBlock * 8];                                                                                                                                  \
+        __shared__ uint32_t* s_ptrs[kBlock];                                                                                                                                  \
+        tab_pass_body<PASS>(tab, bases, jobflags, njobs, L, scr, carry, guardf, s_rows, s_ptrs);                                                                              \
+    }
+PLUME_TAB_PASS_KERNEL(k_tab_pass_b, 1, PLUME_TABPASS_WAVES_AB)
+PLUME_TAB_PASS_KERNEL(k_tab_pass_c, 2, PLUME_TABPASS_WAVES_CD)
+PLUME_TAB_PASS_KERNEL(k_tab_pass_d, 3, PLUME_TABPASS_WAVES_CD)
+#if PLUME_TAB_ENTRIES == 16
+PLUME_TAB_PASS_KERNEL(k_tab_pass_e, 4, PLUME_TABPASS_WAVES_CD)
+#endif
+// carry[.] <- 1 / carry[.] for the nl lane products of a level: thread t takes lanes t, t + T, ..., t + (K-1) T (coalesced) and spends ONE inversion on their product.
+// The products are never zero (the passes' guard).
+__global__ PLUME_NORM_BOUNDS void k_tab_invert(uint32_t* carry, size_t nl, size_t T) {
+    const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t < T) tab_invert_group<PLUME_TABINV_K>(carry, nl, T, t);
+}
+
 // LDS is not cleared between workgroups: a lane overwrites its digit rows before it leaves (the reference zeroizes what it derives from
 // secrets, rust-arkworks/src/lib.rs:202-214)
 template <int ROWS>
@@ -212,12 +278,12 @@ __global__ PLUME_BOUNDS void k_sign_gmul(SignArgs a) {
 
 // one-time: comb[i] = table of 2^(W i) * G, i = 0..NW-1.  Lane i first walks W*i doublings from G, then builds its window
 // (2^(W-1) entries; ~10 ms once per context for W = 11).
-__global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* PLUME_JAC_WORDS x 33 words scratch */, uint8_t* flags /* 33 */, uint32_t* scr /* windows x entries scratch entries */) {
+__global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* one base record per window, scratch */, uint8_t* flags /* 33 */, uint32_t* scr /* windows x entries scratch entries */) {
     const uint32_t i = threadIdx.x;
     if (blockIdx.x != 0 || i >= PLUME_COMB_WINDOWS) return;
     jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
     for (uint32_t d = 0; d < PLUME_COMB_W * i; d++) jac_dbl(g);
-    st_jac_soa(bases, PLUME_COMB_WINDOWS, i, g);
+    st_base(bases, i, g);
     flags[i] = PLUME_JOB_OK;
     table_build<PLUME_COMB_ENTRIES>(comb, bases, flags, PLUME_COMB_WINDOWS, i, 1, scr, PLUME_COMB_WINDOWS, i);
 }
@@ -400,17 +466,40 @@ void launch_gather_probe(const uint32_t* tab, uint32_t nrows, int iters, uint32_
 static inline unsigned nblocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 void launch_verify_ingest(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_ingest, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
+static size_t tables_park_bytes(size_t njobs, int L) {
+    const size_t lanes = (njobs + L - 1) / L;
+    return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_AFF_SCR_WORDS * 4;          // one parked product per job and level, two regions
+}
 size_t tables_scratch_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
 #if PLUME_TABLES_AFFINE
-    return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_AFF_SCR_WORDS * 4;          // one parked product per job and level, two regions
+    return tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16;   // ... + the multi-kernel form's lane state: carry (9 words) and guard flag per lane
 #else
     return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_ENTRIES * PLUME_TAB_SCR_WORDS * 4;
 #endif
 }
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st) {
     size_t lanes = (njobs + L - 1) / L;
+#if PLUME_TABLES_MULTIKERNEL && PLUME_TABLES_AFFINE && PLUME_TABLES_COOP_STORE
+    const dim3 grid(nblocks(lanes)), block(kBlock);
+    const size_t nl = (size_t)grid.x * kBlock, T = (nl + PLUME_TABINV_K - 1) / PLUME_TABINV_K;
+    uint32_t* carry = scr + tables_park_bytes(njobs, L) / 4;
+    uint8_t* guardf = reinterpret_cast<uint8_t*>(carry + nl * PLUME_FE_WORDS);
+    const dim3 igrid(nblocks(T));
+    hipLaunchKernelGGL(k_tab_pass_a, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
+    hipLaunchKernelGGL(k_tab_invert, igrid, block, 0, st, carry, nl, T);
+    hipLaunchKernelGGL(k_tab_pass_b, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
+    hipLaunchKernelGGL(k_tab_invert, igrid, block, 0, st, carry, nl, T);
+    hipLaunchKernelGGL(k_tab_pass_c, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
+    hipLaunchKernelGGL(k_tab_invert, igrid, block, 0, st, carry, nl, T);
+    hipLaunchKernelGGL(k_tab_pass_d, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
+#if PLUME_TAB_ENTRIES == 16
+    hipLaunchKernelGGL(k_tab_invert, igrid, block, 0, st, carry, nl, T);
+    hipLaunchKernelGGL(k_tab_pass_e, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
+#endif
+#else
     hipLaunchKernelGGL(k_tables, dim3(nblocks(lanes)), dim3(kBlock), 0, st, tab, bases, jobflags, njobs, L, scr);
+#endif
 }
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_msm, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_finalize, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }

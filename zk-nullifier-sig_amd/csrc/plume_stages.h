@@ -153,7 +153,7 @@ struct VerifyArgs {
     const uint8_t *rpt33, *hr33;   // optional (V1, SEC1 ingest): r_point / hashed_to_curve_r as 33-byte records, used INSTEAD of rpt / hr:
                                    // they are only compared with computed points and hashed, which needs x and the parity -- no square root
     // scratch (device memory)
-    uint32_t* bases;      // PLUME_JAC_WORDS x (3n) words, Jacobian SoA, job j = word-row w at bases[w*3n + j]
+    uint32_t* bases;      // 3n job-major records of PLUME_BASE_WORDS words (plume_ec.h st_base): jobs 3i, 3i+1, 3i+2 = pk, H, nullifier of item i
     uint8_t* jobflags;    // 3n
     uint8_t* itemflags;   // n : 1 = rejected at ingest (bad scalar / invalid point)
     uint32_t* tab;        // 3n tables of PLUME_TAB_WORDS
@@ -163,7 +163,6 @@ struct VerifyArgs {
 };
 
 PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
-    const size_t nj = 3 * (size_t)a.n;
     fe pkx, pky, nx, ny;
     uint32_t fpk = load_affine_be(pkx, pky, a.pk + 64 * (size_t)i);
     uint32_t fnul = load_affine_be(nx, ny, a.nul + 64 * (size_t)i);
@@ -184,10 +183,10 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     }
     jac p; p.inf = 0; p.z = fe_small(1);
     p.x = pkx; p.y = pky;
-    st_jac_soa(a.bases, nj, 3 * (size_t)i + 0, p); a.jobflags[3 * (size_t)i + 0] = (uint8_t)(fpk | PLUME_JOB_AFFINE);
-    st_jac_soa(a.bases, nj, 3 * (size_t)i + 1, h); a.jobflags[3 * (size_t)i + 1] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
+    st_base(a.bases, 3 * (size_t)i + 0, p); a.jobflags[3 * (size_t)i + 0] = (uint8_t)(fpk | PLUME_JOB_AFFINE);
+    st_base(a.bases, 3 * (size_t)i + 1, h); a.jobflags[3 * (size_t)i + 1] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
     p.x = nx; p.y = ny;
-    st_jac_soa(a.bases, nj, 3 * (size_t)i + 2, p); a.jobflags[3 * (size_t)i + 2] = (uint8_t)(fnul | PLUME_JOB_AFFINE);
+    st_base(a.bases, 3 * (size_t)i + 2, p); a.jobflags[3 * (size_t)i + 2] = (uint8_t)(fnul | PLUME_JOB_AFFINE);
 }
 
 // digits of one double-base task a*A + b*B into dig (4 slots x 33): slots 0,1 = a's halves, 2,3 = b's halves
@@ -413,7 +412,7 @@ PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
     if (!msg_span(o0, mlen, a.msg_off, i, a.msgs_bytes)) st |= PLUME_ST_BAD_SCALAR;   // malformed offsets: flagged, the (empty) span is hashed
     hash_to_curve_jac(h, a.msgs + o0, mlen, px, 2u + (fe_is_odd(py) ? 1u : 0u), pinf ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
     if (h.inf) st |= PLUME_ST_IDENTITY;
-    st_jac_soa(a.bases, a.n, i, h);
+    st_base(a.bases, i, h);
     a.jobflags[i] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
     a.itemflags[i] = (uint8_t)(st | (pinf ? 0x80u : 0u));
 }
