@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — PLUME V1 verifies/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--config 4] [--log2-batch 20] [--version 1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--config 2|3|4] [--log2-batch 20] [--version 1] [--multi-ctx]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of the verify pipeline (ingest+h2c -> window tables -> multi-scalar loop -> finalize) over one batch of synthetic
@@ -11,6 +11,10 @@ over ranks and the gather of the per-rank times (backend nccl = RCCL).
   --scaling weak   (default) every rank verifies its own 2^log2-batch items per step: items [rank*2^k, (rank+1)*2^k) of the BASELINE.md §3 generator
   --scaling strong 2^log2-batch items per step IN TOTAL, contiguous even split [floor(rT/W), floor((r+1)T/W)) over the ranks
   --config 4       BASELINE.json configs[3]: 2^22 V2 verifies in total, even split over the ranks (= --scaling strong --log2-batch 22 --version 2)
+  --config 3       BASELINE.json configs[2]: the step is one 2^20 V1 SIGN pass (metric signs/s); --config 2: 2^16 V1 verify
+  --multi-ctx      ONE process drives all --gpus N devices through one plume_init_multi context and the HOST-POINTER entry point (page-locked caller arrays,
+                   the library shards the batch): the other way to use a node.  PCIe-inclusive, so the number is reported as `e2e_multi_ctx`
+                   beside a `value` that says so in `config.form`; the driver's --gpus N launch (one process per GPU, inputs resident) is the headline form
 
 Objects on the line besides the contract's keys:
   roofline         the BINDING roof of the dominant kernel (k_verify_msm): integer VALU.  achieved = accounting 32-bit MACs of the two double-base
@@ -37,6 +41,9 @@ sys.path.insert(0, str(ROOT))
 BYTES_PER_ITEM = {1: 353, 2: 225}                 # SURVEY.md §8d / BASELINE.md §4 (in + out)
 FPMUL_PER_ITEM = {1: 5460, 2: 5460}               # accounting algorithm, whole verify
 FPMUL_MSM_PER_ITEM = 1900 + 2260                  # the two double-base multiplications (dominant kernel)
+FPMUL_SIGN_PER_ITEM = 4920                        # accounting algorithm, whole V1 sign
+FPMUL_SIGN_HMUL_PER_ITEM = 3168                   # r*H, sk*H: the signer's dominant kernel
+BYTES_PER_SIGN = 416
 MACS_PER_FPMUL = 72
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s spec
 MAD_PEAK_REF = 3.5e13                             # v_mad_u64_u32 lane-ops/s measured on this pool: 1024 SIMDs x 64 lanes / 1.83 ns (tests/gpu_debug/instr_rates_r01.txt)
@@ -51,14 +58,18 @@ def parse():
     ap.add_argument("--log2-batch", type=int, default=20, help="weak: items per GPU per step = 2^this; strong: items per step in total (BASELINE: 20)")
     ap.add_argument("--version", type=int, default=1, choices=(1, 2))
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4), help="BASELINE.json preset: 2 = 2^16 V1 verify; 4 = 2^22 V2 verify split over the ranks")
+    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4), help="BASELINE.json preset: 2 = 2^16 V1 verify; 3 = 2^20 V1 SIGN; 4 = 2^22 V2 verify split over the ranks")
+    ap.add_argument("--multi-ctx", action="store_true", help="one process, one plume_init_multi context over --gpus devices, host-pointer calls from page-locked arrays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (V2 verify, V1 sign, SEC1 ingest, e2e) reported at N=1")
     a = ap.parse_args()
+    a.workload = "verify"
     if a.config == 4:
         a.scaling, a.log2_batch, a.version = "strong", 22, 2
     elif a.config == 2:
         a.log2_batch, a.version = 16, 1
+    elif a.config == 3:
+        a.log2_batch, a.version, a.workload = 20, 1, "sign"
     return a
 
 
@@ -80,18 +91,49 @@ FETCH_SIZE_FACTOR = 2.0   # gfx950: FETCH_SIZE tallies a 128-byte request at 64 
                           # 63.9 bytes reported per gather of one 128-byte row) confirms the factor for the multi-scalar kernel's per-lane table gathers.  WRITE_SIZE is taken as reported.
 
 
-def pmc_traffic(kernel: str):
+def pmc_traffic(kernel: str, build: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json: separate --pmc runs of this same bench for FETCH_SIZE and
-    WRITE_SIZE), corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2, calibrated on this access pattern), or None"""
+    WRITE_SIZE), corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2, calibrated on this access pattern) -- or None.  The counters cannot be read
+    inside a timed run (gpurun refuses --pmc beside the traces a bench needs, and a counter pass serialises the kernels), so the line carries the bytes of the newest
+    committed summary and says which library build they were collected from: `same_build` false means the kernels changed since and the figure is history, not this run."""
     try:
         f = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))[-1]
-        d = json.loads(f.read_text())[kernel]
-        return int((FETCH_SIZE_FACTOR * d["FETCH_SIZE_KB_raw"] + d["WRITE_SIZE_KB_raw"]) * 1024), f"profiles/{f.name} (2^20-item launch)"
+        j = json.loads(f.read_text())
+        d = j[kernel]
+        src = {"file": f"profiles/{f.name}", "launch": "2^20 items", "collected_from_build": j.get("_build"), "this_build": build, "same_build": j.get("_build") == build}
+        return int((FETCH_SIZE_FACTOR * d["FETCH_SIZE_KB_raw"] + d["WRITE_SIZE_KB_raw"]) * 1024), src
     except Exception:
         return None, None
 
 
-def cpu_baseline(version: int):
+def cpu_baseline_sign(version: int, cores: int, visible: int, quota):
+    """config 3's CPU leg: the plain-C oracle's signer on all host cores over the first 2^15 items of the same batch, the optimised CPU signer beside it"""
+    import numpy as np
+
+    from tests import _cpu_fast as CF
+    from tests import _oracle_c as OC
+    from tests import synth
+    n, n1 = 1 << 15, 1024
+    b = synth.sign_inputs(n)
+    t0 = time.perf_counter(); want = OC.sign_batch(version, b["msgs"], b["off"], b["sk"], b["r"], nthreads=cores); t_mt = time.perf_counter() - t0
+    t0 = time.perf_counter(); OC.sign_batch(version, b["msgs"], b["off"][: n1 + 1], b["sk"][:n1], b["r"][:n1], nthreads=1); t_1 = time.perf_counter() - t0
+    out = {"value": round(n / t_mt, 1), "unit": "signs/s", "cores": cores, "cores_visible": visible, "kind": "port", "single_thread_value": round(n1 / t_1, 1),
+           "sample": f"first {n} items of the same synthetic V{version} batch, plain-C oracle signer (4x64-bit limbs, 4-bit window, no endomorphism, four generic scalar multiplications and one "
+                     f"inversion per encoded point), {cores} threads (os.cpu_count() = {visible}, cgroup CPU quota = {quota if quota else 'none'}); single thread: {n1} items. "
+                     f"rust-k256 itself cannot be built here (no rustc/cargo)."}
+    try:
+        t0 = time.perf_counter(); got = CF.sign_batch(version, b["msgs"], b["off"], b["sk"], b["r"], nthreads=cores); t_f = time.perf_counter() - t0
+        t0 = time.perf_counter(); CF.sign_batch(version, b["msgs"], b["off"][: n1 + 1], b["sk"][:n1], b["r"][:n1], nthreads=1); t_f1 = time.perf_counter() - t0
+        assert all(np.array_equal(got[k], want[k]) for k in got)
+        out["optimized"] = {"value": round(n / t_f, 1), "unit": "signs/s", "cores": cores, "kind": "port (optimised)", "single_thread_value": round(n1 / t_f1, 1),
+                            "sample": "same items; oracle/plume_cpu_fast.c: GLV + wNAF (width 8 for G, 5 for H), lazy 4x64-bit limbs, three shared inversions per signature; "
+                                      "equal to the plain oracle's bytes on these items (asserted)"}
+    except Exception as e:
+        out["optimized"] = {"error": str(e)[:200]}
+    return out
+
+
+def cpu_baseline(version: int, sign: bool = False):
     """plain-C oracle on ALL host cores over the first 2^16 items of the same synthetic batch, one core beside it, and the
     optimised CPU leg (oracle/plume_cpu_fast.c) when it is built"""
     import numpy as np  # noqa: F401
@@ -117,6 +159,8 @@ def cpu_baseline(version: int):
         pass
     if quota:
         cores = max(1, min(cores, int(quota + 0.999)))
+    if sign:
+        return cpu_baseline_sign(version, cores, visible, quota)
     n = 1 << 16
     b = synth.sign_inputs(n)
     signed = OC.sign_batch(version, b["msgs"], b["off"], b["sk"], b["r"], nthreads=cores)
@@ -185,7 +229,7 @@ def e2e_host_pinned(eng, n, b, signed_v1):
     # the same call with pageable caller arrays (the runtime stages them), for comparison
     tb, tm = best(lambda: eng.verify_batch(1, v["msgs"], b["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"]), reps=2)
     out["verify_v1_pageable"] = {"items_per_s": round(n / tm, 1), "ms_per_call": round(tm * 1e3, 3)}
-    out["note"] = "median of 3 calls after one warm-up; page-locked arrays from plume_host_alloc; pieces of 2^18 items (first 2^17), three streams"
+    out["note"] = "median of 3 calls after one warm-up; page-locked arrays from plume_host_alloc; pieces of up to 2^19 items (first 2^16, then x3 per piece; the signer's last piece 2^17), three streams"
     return out
 
 
@@ -250,9 +294,80 @@ def extras(eng, dev, n, b, signed_v1):
     return out
 
 
+def small_batch_entry(eng, dev, log2n=16):
+    """BASELINE config 2 (2^16 V1 verify, device-resident) as a secondary entry of the default line: ms per call and the stage times of one call"""
+    import numpy as np
+    import torch
+
+    from tests import synth
+    n = 1 << log2n
+    b = synth.sign_inputs(n)
+    signed = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    v = synth.corrupt_for_verify(1, b, signed)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    d = {k: t(v[k]) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+    off, ok = t(v["off"].view(np.int64)), torch.zeros(n, dtype=torch.uint8, device=dev)
+    mb = int(v["off"][-1])
+    fn = lambda: eng.verify_batch_device(1, n, d["msgs"], off, mb, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok)  # noqa: E731
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert bool((ok.cpu() == torch.from_numpy(synth.expected_ok(n))).all())
+    return {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "stage_ms": {k: round(x, 4) for k, x in eng.last_stage_times()},
+            "workload": f"BASELINE.json configs[1]: 2^{log2n} V1 verifies per call, inputs resident in HBM, {reps} calls back to back"}
+
+
+def multi_ctx_main(a):
+    """--multi-ctx: ONE process, one plume_init_multi context over a.gpus devices, whole batches through the host-pointer entry point from page-locked arrays"""
+    import numpy as np
+
+    import zk_nullifier_sig_amd as plume
+    from tests import synth
+    from zk_nullifier_sig_amd import capi
+    g, ver = a.gpus, a.version
+    total = (1 << a.log2_batch) * (g if a.scaling == "weak" else 1)
+    eng = plume.Engine(list(range(g)))
+    b = synth.sign_inputs(total)
+    signed = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+    v = synth.corrupt_for_verify(ver, b, signed)
+    keys = ("msgs", "pk", "nullifier", "c", "s") + (("r_point", "hashed_to_curve_r") if ver == 1 else ())
+    vp = {k: capi.pinned_copy(v[k]) for k in keys}
+    off = capi.pinned_copy(v["off"])
+    ok = capi.pinned_empty(total)
+    step = lambda: eng.verify_batch(ver, vp["msgs"], off, vp["pk"], vp["nullifier"], vp["c"], vp["s"], vp.get("r_point"), vp.get("hashed_to_curve_r"), out=ok)  # noqa: E731
+    for _ in range(a.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    elapsed = time.perf_counter() - t0                       # the host-pointer call returns when its results are in the caller's array
+    assert np.array_equal(ok, synth.expected_ok(total)), "verify results differ from the expected corruption pattern"
+    value = total * a.steps / elapsed
+    line = {"metric": f"PLUME verifies/sec (secp256k1 V{ver}) at batch=2^{a.log2_batch}" + (" per GPU" if a.scaling == "weak" else " total") + ", host-pointer calls (PCIe-inclusive)",
+            "value": round(value, 1), "unit": "verifies/s", "n_gpus": g, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{total} PLUME V{ver} verifies per step from page-locked HOST arrays ({BYTES_PER_ITEM[ver] - 1} B in, 1 B out per item over PCIe), 1/16 corrupted",
+                       "form": "ONE process, one plume_init_multi context: the library splits every array evenly and contiguously over the devices, one worker thread + three streams per device; "
+                               "NOT the inputs-resident form of the headline metric (bench.py --gpus N without --multi-ctx)",
+                       "global_items_per_step": total, "parallelism": f"in-library shard x{g}, no collective", "shards": eng.num_shards()},
+            "e2e_multi_ctx": {"items_per_s": round(value, 1), "ms_per_call": round(1e3 * elapsed / a.steps, 3), "bytes_in_per_call": (BYTES_PER_ITEM[ver] - 1) * total, "bytes_out_per_call": total}}
+    print(json.dumps(line), flush=True)
+    eng.close()
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.multi_ctx:
+        if world > 1:
+            sys.exit("--multi-ctx is the one-process form: run it bare (python bench.py --gpus N --multi-ctx), not under torch.distributed.run")
+        return multi_ctx_main(a)
     if a.gpus > 1 and world == 1:
         # convenience: launched bare with --gpus N -> re-launch under torch.distributed.run as a CHILD (nothing has touched the GPU yet)
         port = os.environ.get("MASTER_PORT", "29533")
@@ -275,7 +390,7 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
     eng = plume.Engine(local_rank)
-    ver = a.version
+    ver, sign = a.version, a.workload == "sign"
     total, start, stop = plan(a.scaling, a.log2_batch, world, rank)             # items per step over all ranks, this rank's slice
     n = stop - start                                                           # this rank's items per step
     eng.set_chunk(max(n, 1 << 20))
@@ -283,18 +398,28 @@ def main():
     # ---- synthetic shard of this rank, signed on the GPU (setup, untimed), corrupted 1/16 as BASELINE.md §3
     b = synth.sign_inputs(n, start=start)
     signed = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
-    v = synth.corrupt_for_verify(ver, b, signed, start=start)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
-    d = {k: t(v[k]) for k in ("msgs", "pk", "nullifier", "c", "s")}
-    d["off"] = t(v["off"].view(np.int64))
-    d["r_point"] = t(v["r_point"]) if ver == 1 else None
-    d["hashed_to_curve_r"] = t(v["hashed_to_curve_r"]) if ver == 1 else None
-    ok = torch.zeros(n, dtype=torch.uint8, device=dev)
-    msgs_bytes = int(v["off"][-1])
-    expected = torch.from_numpy(synth.expected_ok(n, start)).to(dev)
+    if sign:
+        d = {k: t(b[k]) for k in ("msgs", "sk", "r")}
+        d["off"] = t(b["off"].view(np.int64))
+        o = {k: torch.zeros((n, w), dtype=torch.uint8, device=dev) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
+        status = torch.zeros(n, dtype=torch.uint8, device=dev)
+        msgs_bytes = int(b["off"][-1])
 
-    def step():
-        eng.verify_batch_device(ver, n, d["msgs"], d["off"], msgs_bytes, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok)
+        def step():
+            eng.sign_batch_device(ver, n, d["msgs"], d["off"], msgs_bytes, d["sk"], d["r"], None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], status)
+    else:
+        v = synth.corrupt_for_verify(ver, b, signed, start=start)
+        d = {k: t(v[k]) for k in ("msgs", "pk", "nullifier", "c", "s")}
+        d["off"] = t(v["off"].view(np.int64))
+        d["r_point"] = t(v["r_point"]) if ver == 1 else None
+        d["hashed_to_curve_r"] = t(v["hashed_to_curve_r"]) if ver == 1 else None
+        ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+        msgs_bytes = int(v["off"][-1])
+        expected = torch.from_numpy(synth.expected_ok(n, start)).to(dev)
+
+        def step():
+            eng.verify_batch_device(ver, n, d["msgs"], d["off"], msgs_bytes, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok)
 
     def fence():
         torch.cuda.synchronize()
@@ -309,13 +434,24 @@ def main():
     stage_acc = {}
     for _ in range(a.steps):
         step()
-        if a.steps <= 64:  # per-stage HIP-event times (events are recorded on the launch stream inside the library)
+        if a.steps <= 64:  # per-stage HIP-event times (events are recorded on the launch stream inside the library; the library's default launch order is strictly serial)
             torch.cuda.current_stream().synchronize()
             for name, ms in eng.last_stage_times():
                 stage_acc[name] = stage_acc.get(name, 0.0) + ms
     fence()
     elapsed_rank = time.perf_counter() - t0
-    assert bool((ok == expected).all()), "verify results differ from the expected corruption pattern"
+    if sign:
+        # the timed passes' outputs: equal to the setup pass's (host-pointer entry point) and, on a sample, to the CPU oracle's
+        for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r"):
+            assert np.array_equal(o[k].cpu().numpy(), signed[k]), f"sign outputs differ between passes: {k}"
+        assert not bool(status.any())
+        if rank == 0:
+            from tests import _oracle_c as OC
+            m = 256
+            want = OC.sign_batch(ver, b["msgs"], b["off"][: m + 1], b["sk"][:m], b["r"][:m], nthreads=8)
+            assert all(np.array_equal(signed[k][:m], want[k]) for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")), "sign outputs differ from the CPU oracle"
+    else:
+        assert bool((ok == expected).all()), "verify results differ from the expected corruption pattern"
 
     tmax = torch.tensor([elapsed_rank], dtype=torch.float64, device=dev)
     per_rank = [elapsed_rank]
@@ -331,24 +467,29 @@ def main():
         value = total * a.steps / elapsed
         stages = {k: round(vv / a.steps, 4) for k, vv in stage_acc.items()}
         what = f"2^{a.log2_batch} per GPU" if a.scaling == "weak" else f"2^{a.log2_batch} in total, even split over {world} GPU(s)"
+        op, unit = ("sign", "signs/s") if sign else ("verify", "verifies/s")
+        cfg_idx = {None: 1, 2: 1, 3: 2, 4: 3}[a.config]
         line = {
-            "metric": f"PLUME verifies/sec (secp256k1 V{ver}) at batch=2^{a.log2_batch}" + (" per GPU" if a.scaling == "weak" else " total"), "value": round(value, 1), "unit": "verifies/s",
+            "metric": f"PLUME {'signs' if sign else 'verifies'}/sec (secp256k1 V{ver}) at batch=2^{a.log2_batch}" + (" per GPU" if a.scaling == "weak" else " total"), "value": round(value, 1), "unit": unit,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{3 if a.config == 4 else 1}]/metric: batch {what}, PLUME V{ver} verify (secp256k1 + SHA-256), 32-byte messages, 1/16 corrupted, "
-                                   f"inputs resident in HBM; Fp arithmetic on 9x29-bit limbs through chains of v_mad_u64_u32 (32x32+64)",
+            "config": {"workload": f"BASELINE.json configs[{cfg_idx}]" + ("/metric" if cfg_idx == 1 and a.log2_batch == 20 else "") + f": batch {what}, PLUME V{ver} {op} (secp256k1 + SHA-256), 32-byte messages, "
+                                   + ("" if sign else "1/16 corrupted, ") + "inputs resident in HBM; Fp arithmetic on 9x29-bit limbs through chains of v_mad_u64_u32 (32x32+64)",
+                       "form": "one process per GPU (torch.distributed ranks), device-resident entry point plume_" + op + "_batch_device on torch's current stream, launch order strictly serial "
+                               f"(sub_batches = 1); library {eng.version()}",
                        "items_per_gpu": n, "global_items_per_step": total, "parallelism": f"shard x{world}, no collective on the data path",
                        "world_size": world, "collective_backend": "nccl (RCCL): barrier + MAX + gather of the timings only" if world > 1 else None},
             "per_rank": {"items_per_step": [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)],
-                         "verifies_per_s": [round((shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]) * a.steps / per_rank[r], 1) for r in range(world)]},
+                         ("signs_per_s" if sign else "verifies_per_s"): [round((shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]) * a.steps / per_rank[r], 1) for r in range(world)]},
             "stage_ms": stages,
         }
         if stages:
             dom = max(stages, key=stages.get)
             dom_s = stages[dom] * 1e-3
-            hbm_achieved = BYTES_PER_ITEM[ver] * n / dom_s / 1e9
+            bytes_item = BYTES_PER_SIGN if sign else BYTES_PER_ITEM[ver]
+            hbm_achieved = bytes_item * n / dom_s / 1e9
             # HBM bytes per launch from the committed PMC passes (2^20-item launch, scaled to this batch)
-            tb, tsrc = pmc_traffic("plume::k_" + dom)
+            tb, tsrc = pmc_traffic("plume::k_" + dom, eng.version())
             traffic_bytes = int(tb * (n / float(1 << 20))) if tb else None
             try:
                 # long enough (tens of ms each) for the clocks to settle where the real kernels run
@@ -364,37 +505,46 @@ def main():
             # some boxes of the pool throttle a pure multiply-add stream (a power virus) far below what the real kernels sustain: the
             # roof is the larger of this run's measurement and the pool's reference rate, so a throttled probe cannot inflate the fraction
             mad_rate = max(mad_measured or 0.0, MAD_PEAK_REF)
-            msm_ms = stages.get("verify_msm")
-            if dom == "verify_msm":
-                msm = FPMUL_MSM_PER_ITEM * MACS_PER_FPMUL * n / dom_s
+            msm_ms = stages.get("sign_hmul" if sign else "verify_msm")
+            dom_fpmul = {"verify_msm": FPMUL_MSM_PER_ITEM, "sign_hmul": FPMUL_SIGN_HMUL_PER_ITEM}.get(dom)
+            if dom_fpmul:
+                msm = dom_fpmul * MACS_PER_FPMUL * n / dom_s
                 line["roofline"] = {"bound": "int-valu", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(msm, 1), "peak": round(mad_rate, 1),
                                     "unit": "32-bit MAC/s", "frac": round(msm / mad_rate, 4),
                                     "peak_measured_this_run": round(mad_measured, 1) if mad_measured else None, "peak_spec_half_rate": MAD_PEAK_SPEC,
                                     "frac_of_spec_half_rate": round(msm / MAD_PEAK_SPEC, 4),
-                                    "traffic": traffic_bytes, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE; the factor 2 of gfx950's FETCH_SIZE calibrated on this kernel's access pattern, profiles/r02_fetch_calibration.json)",
-                                    "accounting": f"{FPMUL_MSM_PER_ITEM} Fp-mult per verify in this kernel (s*G - c*pk: 1900, s*H - c*nul: 2260) x {MACS_PER_FPMUL} MACs x {n} items per launch "
-                                                  f"(SURVEY.md §8d, frozen in BASELINE.md §4); the 9x29-limb code issues 103 multiply-adds per Fp-mult, the accounting stays on the frozen 72"}
+                                    "traffic": traffic_bytes, "traffic_source": tsrc,
+                                    "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE; the factor 2 of gfx950's FETCH_SIZE calibrated on this kernel's access pattern, "
+                                                    "profiles/r02_fetch_calibration.json); read from the committed counter passes, not measured in this run: see traffic_source.same_build",
+                                    "accounting": (f"{dom_fpmul} Fp-mult per {op} in this kernel " + ("(r*H, sk*H: 2 x 1584)" if sign else "(s*G - c*pk: 1900, s*H - c*nul: 2260)") +
+                                                   f" x {MACS_PER_FPMUL} MACs x {n} items per launch (SURVEY.md §8d, frozen in BASELINE.md §4); the 9x29-limb code issues 110 multiply-adds per "
+                                                   f"Fp-mult (81 products + 22 fold + 7 column hand-offs), 73 per squaring; the accounting stays on the frozen 72")}
             line["hbm_view"] = {"bound": "hbm", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(hbm_achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": BYTES_PER_ITEM[ver] * n,
+                                "frac": round(hbm_achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": bytes_item * n,
                                 "traffic": round(traffic_bytes / dom_s / 1e9, 1) if traffic_bytes else None, "traffic_bytes_per_launch": traffic_bytes,
-                                "traffic_over_algorithmic": round(traffic_bytes / (BYTES_PER_ITEM[ver] * n), 1) if traffic_bytes else None,
-                                "traffic_note": (f"2 x FETCH_SIZE + WRITE_SIZE of {tsrc}: the per-lane gathers of the HBM-resident window tables (one 128-byte row per table addition, counted by gfx950's "
-                                                 f"FETCH_SIZE as 64 bytes: calibrated with the library's gather probe, profiles/r02_fetch_calibration.json)") if tb else None,
+                                "traffic_over_algorithmic": round(traffic_bytes / (bytes_item * n), 1) if traffic_bytes else None,
+                                "traffic_source": tsrc,
+                                "traffic_note": ("2 x FETCH_SIZE + WRITE_SIZE: the per-lane gathers of the HBM-resident window tables (one 128-byte row per table addition, counted by gfx950's "
+                                                 "FETCH_SIZE as 64 bytes: calibrated with the library's gather probe, profiles/r02_fetch_calibration.json)") if tb else None,
                                 "note": "the path is integer-VALU bound (SURVEY.md §8d): see roofline"}
             if mad_measured:
                 step_s = sum(stages.values()) * 1e-3
-                whole = FPMUL_PER_ITEM[ver] * MACS_PER_FPMUL * n / step_s
+                whole = (FPMUL_SIGN_PER_ITEM if sign else FPMUL_PER_ITEM[ver]) * MACS_PER_FPMUL * n / step_s
                 line["valu_roofline"] = {"bound": "int-valu", "unit": "32-bit MAC/s", "peak_v_mad_u64_u32": round(mad_rate, 1), "peak_v_mad_u64_u32_measured_this_run": round(mad_measured, 1),
                                          "peak_spec_half_rate": MAD_PEAK_SPEC, "peak_v_add_u32": round(add_rate, 1),
                                          "fp_mul_per_s": round(fpmul_rate, 1), "fp_sqr_per_s": round(fpsqr_rate, 1), "other_issue_rates_per_s": other,
                                          "achieved_whole_path": round(whole, 1), "frac_whole_path": round(whole / mad_rate, 4),
                                          "msm_kernel_ms": msm_ms,
-                                         "accounting": "5460 Fp-mult/verify x 72 MACs (SURVEY.md §8d, frozen in BASELINE.md §4)"}
-        if world == 1 and not a.no_extras and a.scaling == "weak" and a.log2_batch == 20:
+                                         "accounting": f"{FPMUL_SIGN_PER_ITEM if sign else FPMUL_PER_ITEM[ver]} Fp-mult/{op} x 72 MACs (SURVEY.md §8d, frozen in BASELINE.md §4)"}
+        if world == 1 and not a.no_extras and a.scaling == "weak" and a.log2_batch == 20 and not sign:
             try:
                 line["other_workloads"] = extras(eng, dev, n, b, signed if ver == 1 else None)
             except Exception as e:
                 line["other_workloads"] = {"error": str(e)}
+            try:
+                line["other_workloads"]["verify_v1_2p16"] = small_batch_entry(eng, dev, 16)
+            except Exception as e:
+                line["other_workloads"]["verify_v1_2p16"] = {"error": str(e)}
             if ver == 1:
                 try:
                     line["e2e_host_pinned"] = e2e_host_pinned(eng, n, b, signed)
@@ -402,7 +552,7 @@ def main():
                     line["e2e_host_pinned"] = {"error": str(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(ver)
+                line["cpu_baseline"] = cpu_baseline(ver, sign)
             except Exception as e:
                 line["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(line), flush=True)

@@ -169,6 +169,10 @@ impl HipEngine {
     pub fn verify_batch_sec1(&self, v1: bool, msgs: &[&[u8]], pk33: &[u8], nullifier33: &[u8], c: &[u8], s: &[u8], r_point33: &[u8], hashed_to_curve_r33: &[u8])
         -> Result<Vec<bool>, HipError> {
         let n = msgs.len();
+        // the library reads 33 n / 32 n bytes through these pointers: a short slice must never reach it (this is a safe fn)
+        let lens_ok = pk33.len() == 33 * n && nullifier33.len() == 33 * n && c.len() == 32 * n && s.len() == 32 * n
+            && (!v1 || (r_point33.len() == 33 * n && hashed_to_curve_r33.len() == 33 * n));
+        if !lens_ok { return Err(HipError(format!("verify_batch_sec1: array lengths do not match {n} items (33 n bytes per point array, 32 n per scalar array)"))); }
         let (mut buf, mut off) = (Vec::new(), vec![0u64]);
         for m in msgs { buf.extend_from_slice(m); off.push(buf.len() as u64); }
         buf.push(0);

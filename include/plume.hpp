@@ -432,10 +432,11 @@ inline std::vector<std::array<uint8_t, 109>> scalars_to_sec1_der(const std::vect
     for (size_t i = 0; i < n; i++) std::memcpy(out[i].data(), &der[109 * i], 109);
     return out;
 }
-// SecretKey::from_sec1_der for that fixed form: nullopt where the reference returns Err
-inline std::optional<NonZeroScalar> scalar_from_sec1_der(const std::array<uint8_t, 109>& der) {
+// SecretKey::from_sec1_der for that fixed form: nullopt where the reference returns Err -- a record of another shape, a scalar outside [1, n-1], or an embedded
+// public key that is not scalar * G (elliptic-curve's TryFrom<EcPrivateKey> validates it; here the GPU recomputes it)
+inline std::optional<NonZeroScalar> scalar_from_sec1_der(const std::array<uint8_t, 109>& der, Engine& eng = Engine::shared()) {
     Bytes32 k; uint8_t ok = 0;
-    plume_hip::check(plume_sec1_der_to_scalars(1, der.data(), k.data(), &ok), "plume_sec1_der_to_scalars");
+    plume_hip::check(plume_sec1_der_to_scalars_checked(eng.ctx(), 1, der.data(), k.data(), &ok), "plume_sec1_der_to_scalars_checked");
     if (!ok) return std::nullopt;
     return NonZeroScalar::from_repr(k);
 }

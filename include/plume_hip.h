@@ -175,8 +175,12 @@ int plume_registers_from_be(size_t nvalues, const uint8_t* be32, uint64_t* regis
  * The generator multiplications run on the GPU (doubling-free comb).  status[i] = 0, or PLUME_STATUS_BAD_SCALAR with an all-zero
  * record when the scalar is outside [1, n-1] (no SecretKey holds it). */
 int plume_scalars_to_sec1_der_batch(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status);
-/* SecretKey::from_sec1_der for that fixed form: ok[i] = 1 iff record i has exactly this structure and a scalar in [1, n-1] (then
- * scalars[i] holds it, else zeros).  The embedded public key is not recomputed.  Host memory; no context needed. */
+/* SecretKey::from_sec1_der for that fixed form, with the reference's semantics (elliptic-curve's TryFrom<EcPrivateKey> validates the embedded public key): ok[i] = 1
+ * iff record i has exactly this structure, a scalar in [1, n-1], AND a public-key field equal to scalar * G (recomputed on the GPU by the comb and compared byte for
+ * byte); scalars[i] = the 32-byte scalar then, zeros otherwise. */
+int plume_sec1_der_to_scalars_checked(plume_ctx* ctx, size_t n, const uint8_t* der109, uint8_t* scalars, uint8_t* ok);
+/* The structure half alone (host memory, no context, no GPU): shape + scalar range.  The public-key field is NOT checked against the scalar, so a record with a
+ * tampered public key passes here where the reference returns Err -- use the _checked form wherever the record comes from outside. */
 int plume_sec1_der_to_scalars(size_t n, const uint8_t* der109, uint8_t* scalars, uint8_t* ok);
 
 /* plume_sign_batch with the point outputs as 33-byte SEC1-compressed records (02|03 || x; identity = 00 followed by 32 zero
@@ -210,7 +214,8 @@ int plume_nullifier_first_occurrence(plume_ctx* ctx, size_t n, const uint8_t* nu
  * one multi-scalar multiplication over 5n points (bucket method), with 127-bit coefficients a_i | b_i = SHA256(seed || be64(i)).  The
  * producer of the batch must not be able to predict `seed` (draw 32 fresh random bytes per call): a batch holding a false equation then
  * passes with probability <= 2^-126.  When the check fails, run the per-item verify to find the culprits.
- *   seed    : 32 bytes, HOST pointer in both forms
+ *   seed    : 32 bytes, HOST pointer in both forms; NULL = the library draws 32 bytes from the OS generator for this call (callers without fresh randomness of
+ *             their own should pass NULL rather than anything constant, reused or known to the signers: the check is only as sound as the seed is unpredictable)
  *   hash_ok : out, optional, n bytes: 1 = the item's inputs are values of the reference's types and c equals the hash
  *   result  : out, PLUME_AGG_RESULT_BYTES = 72 bytes:
  *               [0] all_ok (n_bad == 0 and A is the identity)   [1] A is the identity   [2..4) zero   [4..8) n_bad, u32 little-endian

@@ -224,6 +224,12 @@ static void neighbouring_steps() {
     ASSERT(scalar_from_sec1_der(der[0]).value() == sigs[0].s);
     auto broken = der[0]; broken[2] ^= 1;
     ASSERT(!scalar_from_sec1_der(broken).has_value());
+    // a valid scalar with SOMEBODY ELSE'S public key: the reference's from_sec1_der validates the key and returns Err
+    auto foreign = der[0];
+    std::copy(der[1].begin() + 45, der[1].end(), foreign.begin() + 45);
+    ASSERT(!scalar_from_sec1_der(foreign).has_value());
+    auto flipped = der[0]; flipped[108] ^= 1;                                                        // ... or a point that is not even on the curve
+    ASSERT(!scalar_from_sec1_der(flipped).has_value());
 }
 // invariants of the Rust types at the boundary of this API
 static void type_invariants() {

@@ -86,33 +86,23 @@ void ds_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
     for (int i = 0; i < 8; i++) { out[4 * i] = st[i] >> 24; out[4 * i + 1] = st[i] >> 16; out[4 * i + 2] = st[i] >> 8; out[4 * i + 3] = st[i]; }
 }
 
+// the generator's fixed tables exactly as the library builds them at plume_init (plume_ec.h fixed_window_base / fixed_table_lane: one entry per "lane")
 static void build_gtab(std::vector<uint32_t>& gtab) {
-    static std::vector<uint32_t> cached;           // the table only depends on G: build it once per process (2048 entries for W = 12)
+    static std::vector<uint32_t> cached;           // the table only depends on G: build it once per process
     if (!cached.empty()) { gtab = cached; return; }
     gtab.assign(PLUME_GTAB_WORDS, 0);
-    std::vector<uint32_t> bases(PLUME_BASE_WORDS, 0);      // (base records hold 16-byte quads: operator new / malloc align to 16 bytes on this platform)
-    jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
-    st_base(bases.data(), 0, g);
-    uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
-    std::vector<uint32_t> scr((size_t)PLUME_GTAB_ENTRIES * PLUME_TAB_SCR_WORDS);
-    table_build<PLUME_GTAB_ENTRIES>(gtab.data(), bases.data(), &flag, 1, 0, 1, scr.data(), 1, 0);
+    uint32_t base18[2 * PLUME_FE_WORDS];
+    fixed_window_base(base18, 0);
+    for (size_t lane = 0; lane < (size_t)PLUME_GTAB_ENTRIES; lane++) fixed_table_lane(gtab.data(), base18, PLUME_GTAB_ENTRIES, lane);
     cached = gtab;
 }
 
 static void build_gcomb(std::vector<uint32_t>& comb) {
     comb.assign(PLUME_COMB_WORDS, 0);
-    std::vector<uint32_t> bases(PLUME_BASE_WORDS * PLUME_COMB_WINDOWS, 0);
-    std::vector<uint8_t> flags(PLUME_COMB_WINDOWS, 0);
-    std::vector<uint32_t> scr((size_t)PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES * PLUME_TAB_SCR_WORDS);
-    for (uint32_t i = 0; i < PLUME_COMB_WINDOWS; i++) {      // mirrors k_gcomb
-        jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
-        for (uint32_t d = 0; d < PLUME_COMB_W * i; d++) jac_dbl(g);
-        st_base(bases.data(), i, g);
-        flags[i] = PLUME_JOB_OK;
-        table_build<PLUME_COMB_ENTRIES>(comb.data(), bases.data(), flags.data(), PLUME_COMB_WINDOWS, i, 1, scr.data(), PLUME_COMB_WINDOWS, i);
-    }
+    std::vector<uint32_t> base18((size_t)PLUME_COMB_WINDOWS * 2 * PLUME_FE_WORDS);
+    for (uint32_t w = 0; w < PLUME_COMB_WINDOWS; w++) fixed_window_base(base18.data() + (size_t)w * 2 * PLUME_FE_WORDS, PLUME_COMB_W * w);      // mirrors k_fixed_bases
+    for (size_t lane = 0; lane < (size_t)PLUME_COMB_ENTRIES * PLUME_COMB_WINDOWS; lane++) fixed_table_lane(comb.data(), base18.data(), PLUME_COMB_ENTRIES, lane);
 }
-
 static const std::vector<uint32_t>& shared_gcomb() {
     static std::vector<uint32_t> gcomb;
     if (gcomb.empty()) build_gcomb(gcomb);

@@ -383,6 +383,18 @@ def test_sec1_der_scalar_marshalling(eng, kats):
     sg = eng.sign_batch(2, b["msgs"], b["off"], b["sk"], b["r"])
     der, st = eng.scalars_to_sec1_der_batch(b["sk"])
     assert not st.any() and np.array_equal(der[:, 45:109], sg["pk"]) and np.array_equal(der[:, 7:39], b["sk"])
+    # from_sec1_der with the reference's semantics (elliptic-curve validates the embedded public key): records whose key is somebody else's, off the curve,
+    # or whose scalar was changed under an unchanged key are rejected; the structure-only host function accepts them (documented difference)
+    bad = der.copy()
+    bad[1::8, 45:109] = np.roll(der, 1, axis=0)[1::8, 45:109]
+    bad[3::8, 108] ^= 1
+    bad[5::8, 38] ^= 1
+    bad[7::8, 2] ^= 1                                        # framing
+    sc, ok = eng.sec1_der_to_scalars(bad)
+    want = np.ones(n, dtype=np.uint8); want[1::8] = want[3::8] = want[5::8] = want[7::8] = 0
+    assert np.array_equal(ok, want) and np.array_equal(sc[want == 1], b["sk"][want == 1]) and not sc[want == 0].any()
+    sc0, ok0 = capi.sec1_der_to_scalars(bad)
+    assert ok0[1::8].all() and ok0[3::8].all() and not ok0[7::8].any()
 
 
 # ------------------------------------------------------------------------------- bench.py contract

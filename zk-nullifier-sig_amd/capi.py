@@ -95,6 +95,7 @@ def _load():
     lib.plume_scalars_to_sec1_der_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.plume_scalars_to_sec1_der_batch_device.argtypes = [vp, sz, vp, vp, vp, vp]
     lib.plume_sec1_der_to_scalars.argtypes = [sz, vp, vp, vp]
+    lib.plume_sec1_der_to_scalars_checked.argtypes = [vp, sz, vp, vp, vp]
     lib.plume_registers_from_be_device.argtypes = [vp, sz, vp, vp, vp]
     lib.plume_aggregate_check.argtypes = [vp, i, i, sz] + [vp] * 11
     lib.plume_aggregate_check_device.argtypes = [vp, i, i, sz, vp, vp, sz] + [vp] * 7 + [C.c_uint64, vp, vp, vp]
@@ -106,7 +107,7 @@ def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
     return ["plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
-            "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars",
+            "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars", "plume_sec1_der_to_scalars_checked",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
             "plume_hash_to_curve_batch", "plume_nullifier_first_occurrence", "plume_nullifier_first_occurrence_device", "plume_verify_batch_device", "plume_sign_batch_device", "plume_hash_to_curve_batch_device",
             "plume_last_stage_times", "plume_microbench", "plume_microbench_last_ticks"]
@@ -155,7 +156,8 @@ def registers_from_be(values):
 
 
 def sec1_der_to_scalars(der109):
-    """(n, 109) SEC1-DER secret-key records (the wasm layer's `s` / `digest_private`) -> (scalars (n, 32), ok (n,)); SecretKey::from_sec1_der's structure check"""
+    """(n, 109) SEC1-DER secret-key records (the wasm layer's `s` / `digest_private`) -> (scalars (n, 32), ok (n,)); the STRUCTURE half of SecretKey::from_sec1_der only
+    (shape + scalar range, no GPU): Engine.sec1_der_to_scalars also checks the embedded public key against scalar * G, as the reference does"""
     lib = _load()
     d = np.ascontiguousarray(der109, dtype=np.uint8).reshape(-1, 109)
     sc, ok = np.zeros((len(d), 32), dtype=np.uint8), np.zeros(len(d), dtype=np.uint8)
@@ -396,6 +398,13 @@ class Engine:
         der, status = np.zeros((n, 109), dtype=np.uint8), np.zeros(n, dtype=np.uint8)
         self._chk(self._lib.plume_scalars_to_sec1_der_batch(self._ctx, n, _ptr(scalars), _ptr(der), _ptr(status)), "plume_scalars_to_sec1_der_batch")
         return der, status
+
+    def sec1_der_to_scalars(self, der109):
+        """SecretKey::from_sec1_der with the reference's semantics: structure, scalar range and public key == scalar * G (recomputed on the GPU) -> (scalars (n, 32), ok (n,))"""
+        d = np.ascontiguousarray(der109, dtype=np.uint8).reshape(-1, 109)
+        sc, ok = np.zeros((len(d), 32), dtype=np.uint8), np.zeros(len(d), dtype=np.uint8)
+        self._chk(self._lib.plume_sec1_der_to_scalars_checked(self._ctx, len(d), _ptr(d), _ptr(sc), _ptr(ok)), "plume_sec1_der_to_scalars_checked")
+        return sc, ok
 
     def nullifier_first_occurrence(self, nullifier, live=None, ids=None):
         """first[i] = 1 iff item i is live and holds the smallest id (default: position) among the live items with the same 64-byte

@@ -149,7 +149,10 @@ struct WsHold {
 };
 
 extern "C" const char* plume_last_error(void) { return g_err.c_str(); }
-extern "C" const char* plume_version(void) { return "plume_hip 0.1 gfx950"; }
+#ifndef PLUME_BUILD_ID
+#define PLUME_BUILD_ID "unknown"
+#endif
+extern "C" const char* plume_version(void) { return "plume_hip 0.3 gfx950 build=" PLUME_BUILD_ID; }
 
 static void destroy_single(plume_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
@@ -205,22 +208,10 @@ static int init_single(plume_ctx* ctx) {
         HIPCHK(hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
     }
-    // the generator's tables: the verifier's wide window table (1..2^(W-1))*G and the signer's doubling-free comb, built once on the device
-    if (ctx->gtab.ensure((size_t)PLUME_GTAB_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->bases.ensure(PLUME_BASE_WORDS * 4 * PLUME_COMB_WINDOWS) || ctx->jobflags.ensure(64) ||
-        ctx->tabscr.ensure((size_t)(PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES > PLUME_GTAB_ENTRIES ? PLUME_COMB_WINDOWS * PLUME_COMB_ENTRIES : PLUME_GTAB_ENTRIES) * PLUME_TAB_SCR_WORDS * 4))
+    // the generator's tables: the verifier's wide window table (1..2^(W-1))*G and the signer's doubling-free comb, built once on the device, one entry per lane
+    if (ctx->gtab.ensure((size_t)PLUME_GTAB_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->sink.ensure((size_t)(1 + PLUME_COMB_WINDOWS) * 2 * PLUME_FE_WORDS * 4 + 512))
         return PLUME_ERR_HIP;
-    alignas(16) uint32_t hb[PLUME_BASE_WORDS];
-    {
-        jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
-        st_base(hb, 0, g);
-    }
-    uint8_t flag = PLUME_JOB_OK | PLUME_JOB_AFFINE;
-    HIPCHK(hipMemcpyAsync(ctx->bases.p, hb, sizeof hb, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->jobflags.p, &flag, 1, hipMemcpyHostToDevice, ctx->stream));
-    launch_gtab(ctx->gtab.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->tabscr.as<uint32_t>(), ctx->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    launch_gcomb(ctx->gcomb.as<uint32_t>(), ctx->bases.as<uint32_t>(), ctx->jobflags.as<uint8_t>(), ctx->tabscr.as<uint32_t>(), ctx->stream);   // fixed-base comb for the signer
+    launch_fixed_tables(ctx->gtab.as<uint32_t>(), ctx->gcomb.as<uint32_t>(), ctx->sink.as<uint32_t>(), ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -313,12 +304,20 @@ extern "C" int plume_init_multi(plume_ctx** out, const int* device_ids, int n_de
     for (int d = 0; d < n_devices; d++) if (int rc = check_device(device_ids[d])) return rc;
     plume_ctx* ctx = new plume_ctx();
     ctx->device = device_ids[0];
+    // the shards are independent contexts on (usually) different devices: create them side by side (streams, events, the generator's tables), one thread each
+    std::vector<int> rcs((size_t)n_devices, 0);
+    std::vector<std::string> errs((size_t)n_devices);
+    std::vector<std::thread> builders;
     for (int d = 0; d < n_devices; d++) {
         plume_ctx* sh = new plume_ctx();
         sh->device = device_ids[d];
         ctx->shards.push_back(sh);
-        if (int rc = init_single(sh)) { const std::string keep = g_err; destroy_multi(ctx); g_err = keep; return rc; }
     }
+    for (int d = 0; d < n_devices; d++)
+        builders.emplace_back([&, d]() { g_err.clear(); rcs[(size_t)d] = init_single(ctx->shards[(size_t)d]); errs[(size_t)d] = g_err; });
+    for (std::thread& b : builders) b.join();
+    for (int d = 0; d < n_devices; d++)
+        if (rcs[(size_t)d]) { const std::string keep = "shard " + std::to_string(d) + " (device " + std::to_string(device_ids[d]) + "): " + errs[(size_t)d]; const int rc = rcs[(size_t)d]; destroy_multi(ctx); g_err = keep; return rc; }
     for (int d = 0; d < n_devices; d++) {
         Worker* w = new Worker();
         ctx->workers.push_back(w);
@@ -673,6 +672,9 @@ static int aggregate_device(plume_ctx* ctx, int version, int mode, size_t n, con
                             const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, const uint8_t seed[32], uint64_t index_base, uint8_t* hash_ok,
                             const uint8_t* carry, uint8_t* result, hipStream_t st) {
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    // positions in the sorted pair array are 32-bit: 64 (term, window) pairs per item (69 for 8-bit windows) must stay far below 2^32, and the pair array itself (4 bytes
+    // per pair) below what one pass should hold; larger batches go through the host-pointer form, which cuts them into pieces and carries the running record
+    if (n > ((size_t)1 << 24)) return fail(PLUME_ERR_ARG, "plume_aggregate_check_device: at most 2^24 items per call (the host-pointer form cuts larger batches into pieces)");
     if (int rc = ws_acquire(ctx, st)) return rc;
     WsHold hold(ctx, st);
     AggArgs a;
@@ -745,8 +747,15 @@ static int agg_args_ok(int version, int mode, size_t n, const void* msgs, const 
     if (int rc = args_ok(version, n, msgs, off)) return rc;
     if (mode != PLUME_MODE_VERIFY && mode != PLUME_MODE_NON_ZK) return fail(PLUME_ERR_ARG, "mode must be 0 (verify) or 1 (verify_non_zk)");
     if (mode == PLUME_MODE_VERIFY && version != 1) return fail(PLUME_ERR_ARG, "the aggregate check needs the GIVEN r_point / hashed_to_curve_r: V1 verify, or verify_non_zk");
-    if (!seed) return fail(PLUME_ERR_ARG, "null seed");
+    (void)seed;                                                     // NULL = the library draws 32 bytes from the OS (agg_seed)
     return 0;
+}
+// the coefficients a_i, b_i are only as unpredictable as the seed: a caller that has no fresh randomness of its own passes NULL and gets 32 bytes of the OS generator
+static const uint8_t* agg_seed(const uint8_t* seed, uint8_t drawn[32]) {
+    if (seed) return seed;
+    std::random_device rd;
+    for (int i = 0; i < 32; i += 4) { const uint32_t v = rd(); std::memcpy(drawn + i, &v, 4); }
+    return drawn;
 }
 
 extern "C" int plume_aggregate_check_device(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
@@ -755,7 +764,8 @@ extern "C" int plume_aggregate_check_device(plume_ctx* ctx, int version, int mod
     if (int rc = bind(ctx)) return rc;
     if (int rc = agg_args_ok(version, mode, n, msgs, msg_off, seed)) return rc;
     if (!result || (n && (!pk || !nullifier || !c || !s || !r_point || !hashed_to_curve_r))) return fail(PLUME_ERR_ARG, "null array");
-    return aggregate_device(ctx, version, mode, n, msgs, msg_off, msgs_bytes, pk, nullifier, c, s, r_point, hashed_to_curve_r, seed, index_base, hash_ok, nullptr, result,
+    uint8_t drawn[32];
+    return aggregate_device(ctx, version, mode, n, msgs, msg_off, msgs_bytes, pk, nullifier, c, s, r_point, hashed_to_curve_r, agg_seed(seed, drawn), index_base, hash_ok, nullptr, result,
                             stream ? (hipStream_t)stream : ctx->stream);
 }
 
@@ -1032,6 +1042,8 @@ extern "C" int plume_aggregate_check(plume_ctx* ctx, int version, int mode, size
     if (int rc = agg_args_ok(version, mode, n, msgs, msg_off, seed)) return rc;
     if (!result || (n && (!pk || !nullifier || !c || !s || !r_point || !hashed_to_curve_r))) return fail(PLUME_ERR_ARG, "null array");
     if (n == 0) { memset(result, 0, PLUME_AGG_RESULT_BYTES); result[0] = result[1] = 1; return 0; }
+    uint8_t drawn[32];
+    seed = agg_seed(seed, drawn);                                   // one seed for all pieces and shards of the call
     if (ctx->shards.empty()) return aggregate_host(ctx, version, mode, n, msgs, msg_off, pk, nullifier, c, s, r_point, hashed_to_curve_r, seed, 0, hash_ok, result);
     const size_t g = ctx->shards.size();
     std::vector<uint8_t> records(PLUME_AGG_RESULT_BYTES * g, 0);       // an empty shard leaves zeros: the identity, no bad item
@@ -1206,9 +1218,9 @@ extern "C" int plume_scalars_to_sec1_der_batch(plume_ctx* ctx, size_t n, const u
     if (ctx->shards.empty()) return der_host(ctx, n, scalars, der109, status);
     return for_shards(ctx, n, [=](plume_ctx* sh, size_t lo, size_t hi) -> int { return der_host(sh, hi - lo, scalars + 32 * lo, der109 + PLUME_DER_LEN * lo, status + lo); });
 }
-// SecretKey::from_sec1_der for the fixed 109-byte form above (what the wasm layer emits): structure check + the scalar; ok[i] = 1 iff the record has
-// that exact shape and its scalar is in [1, n-1].  The embedded public key is NOT recomputed here (run plume_scalars_to_sec1_der_batch on the
-// result and compare the records where that matters).  Host memory; no context needed.
+// The STRUCTURE half of SecretKey::from_sec1_der for the fixed 109-byte form above (what the wasm layer emits): ok[i] = 1 iff the record has that exact shape and
+// its scalar is in [1, n-1].  The embedded public key is NOT compared with scalar * G here -- the reference does compare it and returns Err on a mismatch:
+// plume_sec1_der_to_scalars_checked below is the function with the reference's semantics.  Host memory; no context needed.
 extern "C" int plume_sec1_der_to_scalars(size_t n, const uint8_t* der109, uint8_t* scalars, uint8_t* ok) {
     if (n && (!der109 || !scalars || !ok)) return fail(PLUME_ERR_ARG, "null array");
     static const uint8_t head[7] = {0x30, 0x6b, 0x02, 0x01, 0x01, 0x04, 0x20}, mid[6] = {0xa1, 0x44, 0x03, 0x42, 0x00, 0x04};
@@ -1225,6 +1237,22 @@ extern "C" int plume_sec1_der_to_scalars(size_t n, const uint8_t* der109, uint8_
         ok[i] = good ? 1 : 0;
     }
     return 0;
+}
+// SecretKey::from_sec1_der as the reference performs it (elliptic-curve's TryFrom<EcPrivateKey>: the embedded public key must be scalar * G, or the result is Err):
+// the structure check above, then the records are rebuilt from the scalars on the GPU (plume_scalars_to_sec1_der_batch: one comb multiplication each) and compared
+// byte for byte -- a record whose public key is not its scalar's gets ok = 0 and a zeroed scalar
+extern "C" int plume_sec1_der_to_scalars_checked(plume_ctx* ctx, size_t n, const uint8_t* der109, uint8_t* scalars, uint8_t* ok) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "null context");
+    if (int rc = plume_sec1_der_to_scalars(n, der109, scalars, ok)) return rc;
+    if (n == 0) return 0;
+    std::vector<uint8_t> again(PLUME_DER_LEN * n), st(n);
+    const int rc = plume_scalars_to_sec1_der_batch(ctx, n, scalars, again.data(), st.data());
+    if (rc == 0)
+        for (size_t i = 0; i < n; i++)
+            if (ok[i] && (st[i] != 0 || std::memcmp(again.data() + PLUME_DER_LEN * i, der109 + PLUME_DER_LEN * i, PLUME_DER_LEN) != 0)) { ok[i] = 0; std::memset(scalars + 32 * i, 0, 32); }
+    volatile uint8_t* w = again.data();                                  // the records hold secret scalars: wipe the host copy
+    for (size_t k = 0; k < again.size(); k++) w[k] = 0;
+    return rc;
 }
 // host form of the register packing: a byte reversal, done on the host (no reason to cross PCIe for it)
 extern "C" int plume_registers_from_be(size_t nvalues, const uint8_t* be32, uint64_t* registers) {

@@ -807,6 +807,43 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
 #endif
 }
 
+// ------------------------------------------------------------------------------ the generator's fixed tables, one entry per lane (round 3)
+// Rounds 1-2 built the verifier's window table of G and the signer's comb with the chained builder above, ONE lane per table: 175.6 + 56.7 ms per context once the
+// tables had grown to 32768 and 19 x 8192 entries.  Every entry is independent: lane (w, e) computes (e + 1) * B_w by MSB-first double-and-add
+// (<= 15 doublings + 15 mixed additions for a multiplier below 2^16) from the affine window base B_w = 2^(W w) * G and pays its own inversion -- ~45 k instructions per
+// lane, all lanes in parallel.  The additions are the checked ones: a multiplier k < 2^16 never meets k' P = +-P on the way (the order is ~2^256), the checks are there
+// because nothing here is hot.
+PLUME_HD void fixed_table_entry(uint32_t* row, const fe& px, const fe& py, uint32_t k /* 1 <= k < 2^16 */) {
+    jac acc; acc.x = px; acc.y = py; acc.z = fe_small(1); acc.inf = 0;
+    int top = 15;
+    while (top > 0 && !((k >> top) & 1u)) top--;
+    PLUME_NOUNROLL for (int b = top - 1; b >= 0; b--) {
+        jac_dbl(acc);
+        if ((k >> b) & 1u) jac_madd<true>(acc, px, py);
+    }
+    fe zi, zi2, x, y, bx;
+    fe_inv(zi, acc.z); fe_sqr(zi2, zi);
+    fe_mul(x, acc.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y, acc.y, zi2);
+    fe_mul_k(bx, fe_beta(), x);
+    st_tab_entry(row, x, y, bx);
+}
+// B = 2^doublings * G in affine form: out18 = x | y (limbs)
+PLUME_HD void fixed_window_base(uint32_t* out18, uint32_t doublings) {
+    jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
+    PLUME_NOUNROLL for (uint32_t d = 0; d < doublings; d++) jac_dbl(g);
+    fe zi, zi2, x, y;
+    fe_inv(zi, g.z); fe_sqr(zi2, zi);
+    fe_mul(x, g.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y, g.y, zi2);
+    st_fe(out18, x); st_fe(out18 + PLUME_FE_W, y);
+}
+// entry e of window w of a fixed table with `entries` rows per window: (e + 1) * 2^(W w) * G
+PLUME_HD void fixed_table_lane(uint32_t* rows, const uint32_t* base18, uint32_t entries, size_t lane) {
+    const size_t w = lane / entries, e = lane % entries;
+    fe px, py;
+    ld_fe(px, base18 + w * 2 * PLUME_FE_W); ld_fe(py, base18 + w * 2 * PLUME_FE_W + PLUME_FE_W);
+    fixed_table_entry(rows + lane * PLUME_TAB_ENTRY_WORDS, px, py, (uint32_t)e + 1u);
+}
+
 // ------------------------------------------------------------------------------------ batched affine conversion
 // Jacobian -> affine for the points of a SoA array, PLUME_NORM_K points per lane sharing ONE field inversion
 // (Montgomery's trick, prefix products kept in registers).  Lane `lane` of `nlanes` handles points lane + j*nlanes, so

@@ -43,9 +43,16 @@ namespace plume {
 
 
 
-// one-time: (1..2^(W-1))*G, affine + beta*x, by a single lane (plume_init; ~15 ms for W = 12)
-__global__ void k_gtab(uint32_t* gtab, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) table_build<PLUME_GTAB_ENTRIES>(gtab, base_g, flag, 1, 0, 1, scr, 1, 0);
+// one-time, per context: the generator's fixed tables, one entry per lane (plume_ec.h fixed_table_entry).  k_fixed_bases: lane w -> 2^(W w) * G affine;
+// k_fixed_table: lane (w, e) -> row of (e + 1) * 2^(W w) * G.  The verifier's wide window table is the one-window case (W irrelevant), the signer's comb has
+// PLUME_COMB_WINDOWS windows of PLUME_COMB_W bits.
+__global__ PLUME_BOUNDS void k_fixed_bases(uint32_t* base18, uint32_t nwin, uint32_t W) {
+    const uint32_t w = blockIdx.x * kBlock + threadIdx.x;
+    if (w < nwin) fixed_window_base(base18 + (size_t)w * 2 * PLUME_FE_W, W * w);
+}
+__global__ PLUME_BOUNDS void k_fixed_table(uint32_t* rows, const uint32_t* base18, uint32_t entries, uint32_t nwin) {
+    const size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (lane < (size_t)entries * nwin) fixed_table_lane(rows, base18, entries, lane);
 }
 
 __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
@@ -274,18 +281,6 @@ __global__ PLUME_BOUNDS void k_sign_gmul(SignArgs a) {
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
     if (i < a.n) sign_gmul(a, i, which);
-}
-
-// one-time: comb[i] = table of 2^(W i) * G, i = 0..NW-1.  Lane i first walks W*i doublings from G, then builds its window
-// (2^(W-1) entries; ~10 ms once per context for W = 11).
-__global__ void k_gcomb(uint32_t* comb, uint32_t* bases /* one base record per window, scratch */, uint8_t* flags /* 33 */, uint32_t* scr /* windows x entries scratch entries */) {
-    const uint32_t i = threadIdx.x;
-    if (blockIdx.x != 0 || i >= PLUME_COMB_WINDOWS) return;
-    jac g; g.x = fe_gx(); g.y = fe_gy(); g.z = fe_small(1); g.inf = 0;
-    for (uint32_t d = 0; d < PLUME_COMB_W * i; d++) jac_dbl(g);
-    st_base(bases, i, g);
-    flags[i] = PLUME_JOB_OK;
-    table_build<PLUME_COMB_ENTRIES>(comb, bases, flags, PLUME_COMB_WINDOWS, i, 1, scr, PLUME_COMB_WINDOWS, i);
 }
 
 __global__ PLUME_H2C_BOUNDS void k_sign_h2c(SignArgs a) {
@@ -518,8 +513,13 @@ void launch_scalars_der(const DerArgs& a, hipStream_t st) { hipLaunchKernelGGL(k
 void launch_registers_from_be(uint8_t* out, const uint8_t* in, size_t nvalues, hipStream_t st) {
     hipLaunchKernelGGL(k_registers_from_be, dim3(nblocks(nvalues)), dim3(kBlock), 0, st, out, in, nvalues);
 }
-void launch_gtab(uint32_t* gtab, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gtab, dim3(1), dim3(64), 0, st, gtab, base_g, flag, scr); }
-void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, uint32_t* scr, hipStream_t st) { hipLaunchKernelGGL(k_gcomb, dim3(1), dim3(64), 0, st, comb, bases, flags, scr); }
+void launch_fixed_tables(uint32_t* gtab, uint32_t* gcomb, uint32_t* base18 /* (1 + PLUME_COMB_WINDOWS) x 18 words */, hipStream_t st) {
+    uint32_t* cb = base18 + 2 * PLUME_FE_WORDS;
+    hipLaunchKernelGGL(k_fixed_bases, dim3(1), dim3(kBlock), 0, st, base18, 1u, 0u);
+    hipLaunchKernelGGL(k_fixed_bases, dim3(1), dim3(kBlock), 0, st, cb, (uint32_t)PLUME_COMB_WINDOWS, (uint32_t)PLUME_COMB_W);
+    hipLaunchKernelGGL(k_fixed_table, dim3(nblocks((size_t)PLUME_GTAB_ENTRIES)), dim3(kBlock), 0, st, gtab, base18, (uint32_t)PLUME_GTAB_ENTRIES, 1u);
+    hipLaunchKernelGGL(k_fixed_table, dim3(nblocks((size_t)PLUME_COMB_ENTRIES * PLUME_COMB_WINDOWS)), dim3(kBlock), 0, st, gcomb, cb, (uint32_t)PLUME_COMB_ENTRIES, (uint32_t)PLUME_COMB_WINDOWS);
+}
 void launch_dedup(const DedupArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_dedup_clear, dim3(nblocks((size_t)a.mask + 1)), dim3(kBlock), 0, st, a);
     hipLaunchKernelGGL(k_dedup_insert, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a);

@@ -32,8 +32,8 @@ void launch_h2c_only(const H2cArgs& a, hipStream_t st);
 void launch_h2c_intermediates(const H2cInterArgs& a, hipStream_t st);
 void launch_scalars_der(const DerArgs& a, hipStream_t st);
 void launch_registers_from_be(uint8_t* out, const uint8_t* in, size_t nvalues, hipStream_t st);
-void launch_gtab(uint32_t* gtab, const uint32_t* base_g, const uint8_t* flag, uint32_t* scr /* PLUME_GTAB_ENTRIES scratch entries */, hipStream_t st);
-void launch_gcomb(uint32_t* comb, uint32_t* bases, uint8_t* flags, uint32_t* scr /* 33 x 128 scratch entries */, hipStream_t st);
+// the generator's fixed tables (once per context): gtab = (1..2^(GW-1)) * G, gcomb = the signer's doubling-free comb; base18: scratch for the window bases
+void launch_fixed_tables(uint32_t* gtab, uint32_t* gcomb, uint32_t* base18 /* (1 + PLUME_COMB_WINDOWS) x 18 words */, hipStream_t st);
 size_t dedup_blockcnt_bytes(size_t n);                    // size of DedupArgs::blockcnt
 void launch_dedup(const DedupArgs& a, hipStream_t st);   // clear, insert, mark, sum (plume_dedup.h)
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st);
