@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log2-batch", type=int, default=20, help="weak: items per GPU per step = 2^this; strong: items per step in total (BASELINE: 20)")
+    ap.add_argument("--log2-batch", type=int, default=None, help="weak: items per GPU per step = 2^this; strong: items per step in total (default: the preset's, else 20 = BASELINE)")
     ap.add_argument("--version", type=int, default=1, choices=(1, 2))
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4), help="BASELINE.json preset: 2 = 2^16 V1 verify; 3 = 2^20 V1 SIGN; 4 = 2^22 V2 verify split over the ranks")
@@ -64,12 +64,15 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (V2 verify, V1 sign, SEC1 ingest, e2e) reported at N=1")
     a = ap.parse_args()
     a.workload = "verify"
+    preset_log2 = 20
     if a.config == 4:
-        a.scaling, a.log2_batch, a.version = "strong", 22, 2
+        a.scaling, preset_log2, a.version = "strong", 22, 2
     elif a.config == 2:
-        a.log2_batch, a.version = 16, 1
+        preset_log2, a.version = 16, 1
     elif a.config == 3:
-        a.log2_batch, a.version, a.workload = 20, 1, "sign"
+        preset_log2, a.version, a.workload = 20, 1, "sign"
+    if a.log2_batch is None:                      # an explicit --log2-batch overrides the preset's size (smaller smoke runs of the same workload)
+        a.log2_batch = preset_log2
     return a
 
 

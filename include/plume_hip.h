@@ -57,6 +57,10 @@ int plume_init(plume_ctx** out, int device_id);
 int plume_init_multi(plume_ctx** out, const int* device_ids, int n_devices);
 /* 1 for plume_init contexts, n_devices for plume_init_multi contexts */
 int plume_num_shards(const plume_ctx* ctx);
+/* Each shard's worker thread (it issues all copies between the caller's arrays and its GPU) is bound to the CPUs of the NUMA node its GPU hangs off, found through the
+ * device's PCI address in sysfs and cut to the CPUs the process may use; where that cannot be determined the thread is left alone (PLUME_NO_AFFINITY=1 switches the
+ * binding off).  Returns the node shard `shard` was bound to, or -1.  Callers should allocate / page-lock their arrays on the same nodes. */
+int plume_shard_numa_node(const plume_ctx* ctx, int shard);
 void plume_destroy(plume_ctx* ctx);
 /* Last error text of this thread (valid until the next failing call on the thread). */
 const char* plume_last_error(void);
@@ -159,12 +163,25 @@ int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n,
  *   h       n x 64  : H = Q0 + Q1
  * Any output may be NULL.  registers = 0: every value is 32 big-endian bytes; registers = 1: every value is the circuit's 4 x 64-bit
  * little-endian registers (circuits/circom/utils.ts:11-17 scalarToCircuitValue), i.e. out + 32*k is a uint64_t[4].
- * NOT produced: q*_gx1_sqrt, q*_gx2_sqrt, q*_y_pos -- their definitions live in the un-vendored npm package
- * secp256k1_hash_to_curve_circom (ts/generate_inputs; circuits/circom/test/v1.test.ts:5,38-40) and cannot be pinned here.
+ * q*_gx1_sqrt, q*_gx2_sqrt, q*_y_pos come from plume_h2c_hints_batch below (UNPINNED definitions).
  * An invalid pk (or malformed message offsets) zeroes the item's outputs. */
 int plume_h2c_intermediates_batch(plume_ctx* ctx, size_t n,
                                   const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk,
                                   int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h);
+/* The remaining hash_to_curve inputs of the circuit: q{0,1}_gx1_sqrt, q{0,1}_gx2_sqrt, q{0,1}_y_pos (verify_nullifier.circom:21-23,27-29).
+ * UNPINNED: the reference obtains them from secp256k1_hash_to_curve_circom's ts/generate_inputs (circuits/circom/test/v1.test.ts:5,38-40), a package that is not in
+ * the reference tree, and holds no vector of them -- so nothing here can be checked against the reference.  They are DEFINED as follows from RFC 9380 F.2 / F.2.1.2,
+ * for each of the two maps k = 0, 1 with u = u_k, Z = -11, E': y^2 = x^3 + A'x + B':
+ *     x1 = (-B'/A')(1 + 1/(Z^2 u^4 + Z u^2))   (B'/(Z A') when the denominator vanishes),   gx1 = x1^3 + A' x1 + B'
+ *     x2 = Z u^2 x1,                                                                        gx2 = x2^3 + A' x2 + B'  ( = (Z u^2)^3 gx1: exactly one of gx1, gx2 is a square)
+ *     qk_gx1_sqrt = the EVEN root r (r mod 2 = 0, 0 <= r < p) of  r^2 = gx1  if gx1 is a square,  of  r^2 = Z gx1  if it is not
+ *     qk_gx2_sqrt = the EVEN root of  r^2 = gx2  if gx2 is a square,  of  r^2 = Z gx2  if it is not
+ *                   (the second form is sqrt_ratio's return value for a non-residue, RFC 9380 F.2.1.2: a witness that gx is NOT a square, Z being a non-residue)
+ *     qk_y_pos    = the root y of  y^2 = (gx1 if it is a square, else gx2)  with sgn0(y) = sgn0(u): the y the map returns, i.e. qk_y_mapped
+ * A consumer whose generator fixes these choices differently (the other root; 1 in place of the non-residue witness) derives its values from these with a negation /
+ * a constant.  hints: n x 192 bytes, q0_gx1_sqrt | q0_gx2_sqrt | q0_y_pos | q1_gx1_sqrt | q1_gx2_sqrt | q1_y_pos, each 32 bytes (registers as above).
+ * tests: the algebraic definitions above against the Python oracle's big-integer restatement (oracle/plume_oracle.py h2c_hints), incl. RFC 9380 J.8.1's messages. */
+int plume_h2c_hints_batch(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* hints);
 /* 32-byte big-endian values (c, s, pk.x, pk.y, nullifier.x, ... of a signature) -> 4 x 64-bit little-endian registers each
  * (circuits/circom/utils.ts:11-17, verify_nullifier.circom:380-385).  Host memory; no context needed. */
 int plume_registers_from_be(size_t nvalues, const uint8_t* be32, uint64_t* registers);
@@ -266,6 +283,8 @@ int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n,
 int plume_h2c_intermediates_batch_device(plume_ctx* ctx, size_t n,
                                          const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
                                          int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h, void* stream);
+int plume_h2c_hints_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk, int registers,
+                                 uint8_t* hints, void* stream);
 int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status, void* stream);
 int plume_registers_from_be_device(plume_ctx* ctx, size_t nvalues, const uint8_t* be32, uint64_t* registers, void* stream);
 int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n,

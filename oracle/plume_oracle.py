@@ -199,6 +199,31 @@ def map_to_curve_sswu(u: int) -> Tuple[int, int]:
     return x, y
 
 
+def sswu_hints(u: int) -> Tuple[int, int, int]:
+    """(gx1_sqrt, gx2_sqrt, y_pos) of one simplified-SWU map as include/plume_hip.h DEFINES them for plume_h2c_hints_batch (UNPINNED: the reference's generator of these
+    circuit inputs, secp256k1_hash_to_curve_circom/ts/generate_inputs, is not in the reference tree).  Written from RFC 9380 F.2's (non-straight-line) description,
+    independently of map_to_curve_sswu above: x1, gx1, x2, gx2 by their formulas, roots by exponentiation, every choice explicit."""
+    A, Bc = ISO_A, ISO_B
+    d = (Z * Z * pow(u, 4, P) + Z * u * u) % P
+    x1 = Bc * pow(Z * A % P, -1, P) % P if d == 0 else (-Bc) * pow(A, -1, P) % P * (1 + pow(d, -1, P)) % P
+    gx = lambda x: (pow(x, 3, P) + A * x + Bc) % P  # noqa: E731
+    x2 = Z * u * u % P * x1 % P
+    g1, g2 = gx(x1), gx(x2)
+    is_sq = lambda v: v == 0 or pow(v, (P - 1) // 2, P) == 1  # noqa: E731
+
+    def even_root(v):
+        r = pow(v, (P + 1) // 4, P)
+        assert r * r % P == v % P
+        return r if r % 2 == 0 else P - r
+    assert is_sq(g1) != is_sq(g2) or g1 == 0
+    r1 = even_root(g1) if is_sq(g1) else even_root(Z * g1 % P)
+    r2 = even_root(g2) if is_sq(g2) else even_root(Z * g2 % P)
+    y = even_root(g1 if is_sq(g1) else g2)
+    if y % 2 != u % 2:
+        y = P - y
+    return r1, r2, y
+
+
 def _poly(coeffs: List[int], x: int) -> int:
     acc = 0
     for c in reversed(coeffs):

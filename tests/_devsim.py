@@ -157,8 +157,9 @@ def h2c_batch(msgs_buf, msg_off, pk):
 
 def h2c_intermediates(msgs_buf, msg_off, pk=None, registers=False):
     n = len(msg_off) - 1
-    o = {k: np.zeros((n, w, 32), dtype=np.uint8) for k, w in [("u", 2), ("mapped", 4), ("q", 4), ("h", 2)]}
-    rc = lib().ds_h2c_intermediates(C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), _p(_aligned(pk)), C.c_int(1 if registers else 0), _p(o["u"]), _p(o["mapped"]), _p(o["q"]), _p(o["h"]))
+    o = {k: np.zeros((n, w, 32), dtype=np.uint8) for k, w in [("u", 2), ("mapped", 4), ("q", 4), ("h", 2), ("hints", 6)]}
+    rc = lib().ds_h2c_intermediates(C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), _p(_aligned(pk)), C.c_int(1 if registers else 0), _p(o["u"]), _p(o["mapped"]), _p(o["q"]), _p(o["h"]),
+                                    _p(o["hints"]))
     assert rc == 0
     return {k: v.view(np.uint64) for k, v in o.items()} if registers else o
 

@@ -404,8 +404,8 @@ int ds_h2c_batch(uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const
     return 0;
 }
 
-int ds_h2c_intermediates(uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h) {
-    H2cInterArgs a; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msg_off[n]; a.pk = pk; a.registers = registers; a.u = u; a.mapped = mapped; a.q = q; a.h = h;
+int ds_h2c_intermediates(uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h, uint8_t* hints) {
+    H2cInterArgs a; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msg_off[n]; a.pk = pk; a.registers = registers; a.u = u; a.mapped = mapped; a.q = q; a.h = h; a.hints = hints;
     for (uint32_t i = 0; i < n; i++) h2c_intermediates(a, i);
     return 0;
 }

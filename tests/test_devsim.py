@@ -396,6 +396,51 @@ def test_h2c_intermediates_and_registers(kats):
     _check_h2c_intermediates(lambda mb, off, pk, regs: D.h2c_intermediates(mb, off, pk, regs), D.registers_from_be, kats)
 
 
+def _check_h2c_hints(get_hints, get_inter):
+    """the square-root hints (UNPINNED: no reference vector exists; include/plume_hip.h defines them).  Checked (a) against the definitions themselves -- algebra on the
+    values the pinned outputs give: gx1, gx2 from u (RFC 9380 F.2), root^2 = gx or Z gx, evenness, y_pos = y_mapped with sgn0 = sgn0(u) -- and (b) against the Python
+    oracle's independent big-integer restatement (O.sswu_hints), on RFC 9380 J.8.1's messages and ragged PLUME inputs"""
+    rng = random.Random(77)
+    items = GOLD["sign_v1"][:24]
+    cases = [(OC.pack_msgs([b"", b"abc", b"abcdef0123456789", b"q128_" + b"q" * 128, b"a512_" + b"a" * 512]), None),
+             (OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items]), OC.arr(items, "pk", 64)),
+             (OC.pack_msgs([rng.randbytes(rng.randrange(0, 200)) for _ in range(40)]), None)]
+    val = lambda a: int(a.tobytes().hex(), 16)  # noqa: E731
+    branches = set()
+    for (mb, off), pk in cases:
+        hints, inter = get_hints(mb, off, pk, False), get_inter(mb, off, pk, False)
+        regs = get_hints(mb, off, pk, True)
+        for i in range(len(off) - 1):
+            for k in range(2):
+                u = val(inter["u"][i, k])
+                g1s, g2s, ypos = (val(hints[f"q{k}_{nm}"][i]) for nm in ("gx1_sqrt", "gx2_sqrt", "y_pos"))
+                assert (g1s, g2s, ypos) == O.sswu_hints(u)
+                # the definitions, from u alone
+                A, B, Zc = O.ISO_A, O.ISO_B, O.Z % P
+                d = (Zc * Zc * pow(u, 4, P) + Zc * u * u) % P
+                x1 = (-B) * pow(A, -1, P) % P * (1 + pow(d, -1, P)) % P
+                x2 = Zc * u * u % P * x1 % P
+                gx1, gx2 = (pow(x1, 3, P) + A * x1 + B) % P, (pow(x2, 3, P) + A * x2 + B) % P
+                sq1 = pow(gx1, (P - 1) // 2, P) == 1
+                branches.add(sq1)
+                assert g1s % 2 == 0 and g2s % 2 == 0 and g1s < P and g2s < P
+                assert g1s * g1s % P == (gx1 if sq1 else Zc * gx1 % P) and g2s * g2s % P == (Zc * gx2 % P if sq1 else gx2)
+                assert ypos * ypos % P == (gx1 if sq1 else gx2) and ypos % 2 == u % 2
+                assert ypos == val(inter["mapped"][i, 2 * k + 1]) and val(inter["mapped"][i, 2 * k]) == (x1 if sq1 else x2)
+                for nm in ("gx1_sqrt", "gx2_sqrt", "y_pos"):                          # register form
+                    assert sum(int(x) << (64 * t) for t, x in enumerate(regs[f"q{k}_{nm}"][i])) == val(hints[f"q{k}_{nm}"][i])
+    assert branches == {True, False}
+
+
+def test_h2c_hints_unpinned_definitions():
+    names = ["q0_gx1_sqrt", "q0_gx2_sqrt", "q0_y_pos", "q1_gx1_sqrt", "q1_gx2_sqrt", "q1_y_pos"]
+
+    def hints(mb, off, pk, regs):
+        h = D.h2c_intermediates(mb, off, pk, regs)["hints"]
+        return {nm: h[:, k] for k, nm in enumerate(names)}
+    _check_h2c_hints(hints, lambda mb, off, pk, regs: D.h2c_intermediates(mb, off, pk, regs))
+
+
 def _check_sec1_der(to_der, from_der, kats):
     """SecretKey::to_sec1_der / from_sec1_der as the wasm layer uses them (javascript/src/lib.rs:98-110,124-140), against the README's records: the whole
     109-byte secret-key record (javascript/README.md:26-32) and the first 100 bytes of the sample output's `s` (README :58-72, cut there by the listing)"""

@@ -348,6 +348,10 @@ def test_h2c_intermediates_and_registers(eng, kats):
     u0, u1 = O.hash_to_field2(vv["msg_utf8"].encode() + O.sec1_compress((int(vv["pk_x"], 16), int(vv["pk_y"], 16))))
     assert (val(ci["q0_x_mapped"]), val(ci["q0_y_mapped"])) == O.map_to_curve_sswu(u0)
     assert (val(ci["q1_x_mapped"]), val(ci["q1_y_mapped"])) == O.map_to_curve_sswu(u1)
+    # the full input set of plume_v1 (verify_nullifier.circom:14-31): the square-root hints are there too (unpinned definitions, O.sswu_hints restates them)
+    assert (val(ci["q0_gx1_sqrt"]), val(ci["q0_gx2_sqrt"]), val(ci["q0_y_pos"])) == O.sswu_hints(u0)
+    assert (val(ci["q1_gx1_sqrt"]), val(ci["q1_gx2_sqrt"]), val(ci["q1_y_pos"])) == O.sswu_hints(u1)
+    assert set(ci) == {"c", "s", "plume_message", "pk", "nullifier"} | {f"q{k}_{nm}" for k in (0, 1) for nm in ("gx1_sqrt", "gx2_sqrt", "y_pos", "x_mapped", "y_mapped")}
 
 
 # ------------------------------------------------------------------------------- f2: a non-Python caller of the C ABI

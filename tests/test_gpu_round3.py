@@ -240,3 +240,76 @@ def test_stage_times_serial_and_overlapped(eng):
         assert over["verify_overlapped"] < 1.25 * sum(serial.values())       # (measured: the overlapped order is 1-6 % slower than the serial one)
     finally:
         eng.set_sub_batches(capi.DEFAULT_SUB_BATCHES)
+
+
+# ------------------------------------------------------------------------------------------- multi-GPU readiness
+def test_two_distinct_devices_match_one(eng):
+    """Engine([0, 1]) against Engine(0): the first use of two DISTINCT device ids.  Skips on the one-GPU boxes of this pool; runs wherever two devices are visible."""
+    import torch
+    import zk_nullifier_sig_amd as plume
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible devices")
+    n = 100_003
+    b = synth.sign_inputs(n, start=17_000_000)
+    one = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    two = plume.Engine([0, 1])
+    try:
+        got = two.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+        for k in OUT:
+            assert np.array_equal(got[k], one[k]), k
+        v = _fuzz.fuzz_verify_batch(1, one, b, seed=9)
+        a = (1, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"])
+        assert np.array_equal(two.verify_batch(*a), eng.verify_batch(*a))
+        assert len(two.shard_numa_nodes()) == 2
+    finally:
+        two.close()
+
+
+def test_worker_threads_numa_binding_is_reported_and_harmless(eng):
+    """every shard's worker thread is bound to its GPU's NUMA node when sysfs knows it (and left alone otherwise); either way results are the single context's"""
+    import zk_nullifier_sig_amd as plume
+    n = 20_000
+    b = synth.sign_inputs(n, start=18_000_000)
+    want = eng.sign_batch(2, b["msgs"], b["off"], b["sk"], b["r"])
+    e2 = plume.Engine([0, 0])
+    try:
+        nodes = e2.shard_numa_nodes()
+        assert len(nodes) == 2 and nodes[0] == nodes[1] and nodes[0] >= -1
+        got = e2.sign_batch(2, b["msgs"], b["off"], b["sk"], b["r"])
+        for k in OUT:
+            assert np.array_equal(got[k], want[k]), k
+    finally:
+        e2.close()
+    assert eng.shard_numa_nodes() == [-1]                    # a single-device context has no worker thread
+
+
+def test_bench_multi_ctx_form_and_config3():
+    """bench.py --multi-ctx (one process, plume_init_multi, host-pointer calls from page-locked arrays) and --config 3 (the sign workload) produce contract lines"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--multi-ctx", "--gpus", "1", "--log2-batch", "17", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "plume_init_multi" in d["config"]["form"] and d["e2e_multi_ctx"]["items_per_s"] == d["value"] and d["value"] > 1e6
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--config", "3", "--log2-batch", "16", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["unit"] == "signs/s" and "configs[2]" in d["config"]["workload"] and d["roofline"]["kernel"] == "k_sign_hmul" and list(d["stage_ms"])[0] == "sign_gmul"
+
+
+# ------------------------------------------------------------------------------------------- circuit hints, the unpinned rest (SURVEY.md §8f rank 3)
+def test_h2c_hints_unpinned_definitions_on_the_gpu(eng):
+    """plume_h2c_hints_batch: q{0,1}_gx1_sqrt / gx2_sqrt / y_pos as include/plume_hip.h defines them (no reference vector exists): the algebraic definitions and the
+    Python oracle's independent restatement, through the C ABI; then 2^16 items for internal consistency with the pinned intermediates"""
+    from tests.test_devsim import _check_h2c_hints
+    _check_h2c_hints(lambda mb, off, pk, regs: eng.h2c_hints_batch(mb, off, pk, regs), lambda mb, off, pk, regs: eng.h2c_intermediates_batch(mb, off, pk, regs))
+    n = 1 << 16
+    b = synth.sign_inputs(n, start=19_000_000)
+    hints, inter = eng.h2c_hints_batch(b["msgs"], b["off"]), eng.h2c_intermediates_batch(b["msgs"], b["off"])
+    assert np.array_equal(hints["q0_y_pos"], inter["mapped"][:, 1]) and np.array_equal(hints["q1_y_pos"], inter["mapped"][:, 3])
+    assert not (hints["q0_gx1_sqrt"][:, 31] & 1).any() and not (hints["q1_gx2_sqrt"][:, 31] & 1).any()

@@ -61,6 +61,7 @@ def _load():
     lib.plume_init.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     lib.plume_init_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]
     lib.plume_num_shards.argtypes = [C.c_void_p]
+    lib.plume_shard_numa_node.argtypes = [C.c_void_p, C.c_int]
     lib.plume_set_host_first_piece.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_set_host_register_min.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_set_host_tail_piece.argtypes = [C.c_void_p, C.c_size_t]
@@ -91,6 +92,8 @@ def _load():
     lib.plume_hash_to_curve_batch_device.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp]
     lib.plume_h2c_intermediates_batch.argtypes = [vp, sz, vp, vp, vp, i, vp, vp, vp, vp]
     lib.plume_h2c_intermediates_batch_device.argtypes = [vp, sz, vp, vp, sz, vp, i, vp, vp, vp, vp, vp]
+    lib.plume_h2c_hints_batch.argtypes = [vp, sz, vp, vp, vp, i, vp]
+    lib.plume_h2c_hints_batch_device.argtypes = [vp, sz, vp, vp, sz, vp, i, vp, vp]
     lib.plume_registers_from_be.argtypes = [sz, vp, vp]
     lib.plume_scalars_to_sec1_der_batch.argtypes = [vp, sz, vp, vp, vp]
     lib.plume_scalars_to_sec1_der_batch_device.argtypes = [vp, sz, vp, vp, vp, vp]
@@ -105,7 +108,7 @@ def _load():
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
+    return ["plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
             "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars", "plume_sec1_der_to_scalars_checked",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
@@ -225,6 +228,10 @@ class Engine:
 
     def num_shards(self):
         return int(self._lib.plume_num_shards(self._ctx))
+
+    def shard_numa_nodes(self):
+        """per shard: the NUMA node its worker thread was bound to (-1 = not bound)"""
+        return [int(self._lib.plume_shard_numa_node(self._ctx, d)) for d in range(self.num_shards())]
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -389,6 +396,17 @@ class Engine:
         if registers:
             o = {k: v.view(np.uint64) for k, v in o.items()}
         return o
+
+    def h2c_hints_batch(self, msgs, msg_off, pk=None, registers=False):
+        """the circuit's square-root hints (UNPINNED definitions, include/plume_hip.h): dict q0_gx1_sqrt, q0_gx2_sqrt, q0_y_pos, q1_... -> (n, 32) bytes or (n, 4) uint64 registers"""
+        msg_off = np.ascontiguousarray(msg_off, dtype=np.uint64)
+        n = len(msg_off) - 1
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        pk = None if pk is None else _np(pk, 64, n, "pk")
+        out = np.zeros((n, 6, 32), dtype=np.uint8)
+        self._chk(self._lib.plume_h2c_hints_batch(self._ctx, n, _ptr(msgs), _ptr(msg_off), _ptr(pk), 1 if registers else 0, _ptr(out)), "plume_h2c_hints_batch")
+        names = ["q0_gx1_sqrt", "q0_gx2_sqrt", "q0_y_pos", "q1_gx1_sqrt", "q1_gx2_sqrt", "q1_y_pos"]
+        return {nm: (np.ascontiguousarray(out[:, k]).view(np.uint64) if registers else np.ascontiguousarray(out[:, k])) for k, nm in enumerate(names)}
 
     def scalars_to_sec1_der_batch(self, scalars):
         """SecretKey::from(scalar).to_sec1_der() for a batch (javascript/src/lib.rs:98-110): (n, 109) records incl. the public key scalar*G computed on the GPU,

@@ -3,6 +3,9 @@
 // fallback of any kind in this library.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
+#include <cctype>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -75,8 +78,9 @@ struct Worker {
     std::mutex m;
     std::condition_variable cv;
     std::function<int()> job;
-    bool has_job = false, done = false, quit = false;
+    bool has_job = false, done = false, quit = false, ready = false;
     int rc = 0;
+    int numa_node = -1;      // the node the thread was bound to (bind_thread_to_device_node), -1 = left alone
     std::string err;
 };
 
@@ -242,9 +246,56 @@ extern "C" int plume_init(plume_ctx** out, int device_id) {
 }
 
 // ------------------------------------------------------------------------------------------- multi-device contexts
+// A shard's worker thread issues every copy between the caller's arrays and its GPU; on a two-socket node it should run on the socket the GPU hangs off (SURVEY.md §8e
+// names host-side placement as the scaling risk).  The device's PCI address gives the NUMA node through sysfs; the thread's affinity becomes that node's CPUs, cut to the
+// CPUs the process may use.  Anything missing on the way (no sysfs, node -1, a container cpuset that excludes the node) leaves the thread where it was.
+// PLUME_NO_AFFINITY=1 switches it off.  Returns the node, or -1.
+static int bind_thread_to_device_node(int device) {
+    if (const char* e = std::getenv("PLUME_NO_AFFINITY")) { if (std::atoi(e) != 0) return -1; }
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char* c = bus; *c; c++) *c = (char)std::tolower((unsigned char)*c);
+    int node = -1;
+    {
+        const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+        FILE* f = std::fopen(path.c_str(), "r");
+        if (!f) return -1;
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    if (node < 0) return -1;
+    char list[4096] = {0};
+    {
+        const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
+        FILE* f = std::fopen(path.c_str(), "r");
+        if (!f) return -1;
+        const bool got = std::fgets(list, (int)sizeof list, f) != nullptr;
+        std::fclose(f);
+        if (!got) return -1;
+    }
+    cpu_set_t allowed, want;
+    CPU_ZERO(&allowed); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return -1;
+    int any = 0;
+    for (const char* q = list; *q && *q != '\n';) {                        // "0-15,128-143"
+        char* end = nullptr;
+        long lo = std::strtol(q, &end, 10), hi = lo;
+        if (end == q) break;
+        if (*end == '-') { q = end + 1; hi = std::strtol(q, &end, 10); }
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; c++) if (c >= 0 && CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, &want); any++; }
+        q = (*end == ',') ? end + 1 : end;
+        if (*end != ',' ) break;
+    }
+    if (!any) return -1;
+    return sched_setaffinity(0, sizeof want, &want) == 0 ? node : -1;
+}
+
 static void worker_main(Worker* w, int device) {
     (void)hipSetDevice(device);
+    const int node = bind_thread_to_device_node(device);
     std::unique_lock<std::mutex> lk(w->m);
+    w->numa_node = node; w->ready = true;
+    w->cv.notify_all();
     for (;;) {
         w->cv.wait(lk, [&] { return w->has_job || w->quit; });
         if (w->quit) return;
@@ -323,10 +374,16 @@ extern "C" int plume_init_multi(plume_ctx** out, const int* device_ids, int n_de
         ctx->workers.push_back(w);
         w->th = std::thread(worker_main, w, device_ids[d]);
     }
+    for (Worker* w : ctx->workers) { std::unique_lock<std::mutex> lk(w->m); w->cv.wait(lk, [&] { return w->ready; }); }   // bound to their devices (and NUMA nodes) before the first call
     *out = ctx;
     return 0;
 }
 
+// the NUMA node shard d's worker thread was bound to, -1 = not bound (single-device context, unknown node, PLUME_NO_AFFINITY)
+extern "C" int plume_shard_numa_node(const plume_ctx* ctx, int shard) {
+    if (!ctx || shard < 0 || (size_t)shard >= ctx->workers.size()) return -1;
+    return ctx->workers[(size_t)shard]->numa_node;
+}
 extern "C" int plume_num_shards(const plume_ctx* ctx) { return ctx ? (ctx->shards.empty() ? 1 : (int)ctx->shards.size()) : 0; }
 
 extern "C" void plume_destroy(plume_ctx* ctx) {
@@ -627,19 +684,29 @@ extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const 
 }
 
 // ------------------------------------------------------------------------------ circuit witness hints
-extern "C" int plume_h2c_intermediates_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
-                                                    int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h, void* stream) {
+static int h2c_inter_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk, int registers, uint8_t* u,
+                            uint8_t* mapped, uint8_t* q, uint8_t* h, uint8_t* hints, void* stream) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
     if (registers != 0 && registers != 1) return fail(PLUME_ERR_ARG, "registers must be 0 or 1");
     if (n == 0) return 0;
     H2cInterArgs a;
-    a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msgs_bytes; a.pk = pk; a.registers = registers; a.u = u; a.mapped = mapped; a.q = q; a.h = h;
+    a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msgs_bytes; a.pk = pk; a.registers = registers; a.u = u; a.mapped = mapped; a.q = q; a.h = h; a.hints = hints;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->timer.begin(st);
     launch_h2c_intermediates(a, st); ctx->timer.stage("h2c_intermediates", st);
     HIPCHK(hipGetLastError());
     return 0;
+}
+extern "C" int plume_h2c_intermediates_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
+                                                    int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h, void* stream) {
+    return h2c_inter_device(ctx, n, msgs, msg_off, msgs_bytes, pk, registers, u, mapped, q, h, nullptr, stream);
+}
+// the square-root hints of the two maps (UNPINNED definitions, include/plume_hip.h): n x 192 bytes
+extern "C" int plume_h2c_hints_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk, int registers,
+                                            uint8_t* hints, void* stream) {
+    if (n && !hints) return fail(PLUME_ERR_ARG, "null array");
+    return h2c_inter_device(ctx, n, msgs, msg_off, msgs_bytes, pk, registers, nullptr, nullptr, nullptr, nullptr, hints, stream);
 }
 extern "C" int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status, void* stream) {
     if (int rc = bind(ctx)) return rc;
@@ -1160,39 +1227,48 @@ extern "C" int plume_hash_to_curve_batch(plume_ctx* ctx, size_t n, const uint8_t
 }
 
 static int h2c_inter_host(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* u, uint8_t* mapped, uint8_t* q,
-                          uint8_t* h) {
+                          uint8_t* h, uint8_t* hints) {
     HIPCHK(hipSetDevice(ctx->device));
     return host_pipeline(
         ctx, n, true,
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
             if (int rc = stage_msgs(ctx, sl, msgs, msg_off, i0, cnt)) return rc;
             if (pk) { if (int rc = h2d(ctx, sl.in[0], pk + 64 * i0, 64 * cnt)) return rc; }
-            return sl.out[0].ensure(64 * cnt) || sl.out[1].ensure(128 * cnt) || sl.out[2].ensure(128 * cnt) || sl.out[3].ensure(64 * cnt) ? PLUME_ERR_HIP : 0;
+            return sl.out[0].ensure(64 * cnt) || sl.out[1].ensure(128 * cnt) || sl.out[2].ensure(128 * cnt) || sl.out[3].ensure(64 * cnt) || sl.out[4].ensure(192 * cnt) ? PLUME_ERR_HIP : 0;
         },
         [&](HostSlot& sl, size_t cnt) -> int {
-            return plume_h2c_intermediates_batch_device(ctx, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], pk ? sl.in[0].as<uint8_t>() : nullptr, registers,
-                                                        u ? sl.out[0].as<uint8_t>() : nullptr, mapped ? sl.out[1].as<uint8_t>() : nullptr, q ? sl.out[2].as<uint8_t>() : nullptr,
-                                                        h ? sl.out[3].as<uint8_t>() : nullptr, ctx->stream);
+            return h2c_inter_device(ctx, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], pk ? sl.in[0].as<uint8_t>() : nullptr, registers,
+                                    u ? sl.out[0].as<uint8_t>() : nullptr, mapped ? sl.out[1].as<uint8_t>() : nullptr, q ? sl.out[2].as<uint8_t>() : nullptr,
+                                    h ? sl.out[3].as<uint8_t>() : nullptr, hints ? sl.out[4].as<uint8_t>() : nullptr, ctx->stream);
         },
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
             if (u) { if (int rc = d2h(ctx, u + 64 * i0, sl.out[0], 64 * cnt)) return rc; }
             if (mapped) { if (int rc = d2h(ctx, mapped + 128 * i0, sl.out[1], 128 * cnt)) return rc; }
             if (q) { if (int rc = d2h(ctx, q + 128 * i0, sl.out[2], 128 * cnt)) return rc; }
             if (h) { if (int rc = d2h(ctx, h + 64 * i0, sl.out[3], 64 * cnt)) return rc; }
+            if (hints) { if (int rc = d2h(ctx, hints + 192 * i0, sl.out[4], 192 * cnt)) return rc; }
             return 0;
         });
 }
-extern "C" int plume_h2c_intermediates_batch(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* u,
-                                             uint8_t* mapped, uint8_t* q, uint8_t* h) {
+static int h2c_inter_any(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* u, uint8_t* mapped, uint8_t* q, uint8_t* h,
+                         uint8_t* hints) {
     if (!ctx) return fail(PLUME_ERR_ARG, "null context");
     if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
     if (registers != 0 && registers != 1) return fail(PLUME_ERR_ARG, "registers must be 0 or 1");
     if (n == 0) return 0;
-    if (ctx->shards.empty()) return h2c_inter_host(ctx, n, msgs, msg_off, pk, registers, u, mapped, q, h);
+    if (ctx->shards.empty()) return h2c_inter_host(ctx, n, msgs, msg_off, pk, registers, u, mapped, q, h, hints);
     return for_shards(ctx, n, [=](plume_ctx* sh, size_t lo, size_t hi) -> int {
         return h2c_inter_host(sh, hi - lo, msgs, msg_off + lo, pk ? pk + 64 * lo : nullptr, registers, u ? u + 64 * lo : nullptr, mapped ? mapped + 128 * lo : nullptr,
-                              q ? q + 128 * lo : nullptr, h ? h + 64 * lo : nullptr);
+                              q ? q + 128 * lo : nullptr, h ? h + 64 * lo : nullptr, hints ? hints + 192 * lo : nullptr);
     });
+}
+extern "C" int plume_h2c_intermediates_batch(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* u,
+                                             uint8_t* mapped, uint8_t* q, uint8_t* h) {
+    return h2c_inter_any(ctx, n, msgs, msg_off, pk, registers, u, mapped, q, h, nullptr);
+}
+extern "C" int plume_h2c_hints_batch(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, int registers, uint8_t* hints) {
+    if (n && !hints) return fail(PLUME_ERR_ARG, "null array");
+    return h2c_inter_any(ctx, n, msgs, msg_off, pk, registers, nullptr, nullptr, nullptr, nullptr, hints);
 }
 static int der_host(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status) {
     HIPCHK(hipSetDevice(ctx->device));

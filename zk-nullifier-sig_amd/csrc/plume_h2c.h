@@ -77,8 +77,15 @@ PLUME_HD void hash_to_field2(fe& u0, fe& u1, const uint8_t* msg, uint32_t mlen, 
     fe_from_be48_words(u1, uni + 12);
 }
 
+// What the straight-line map knows beyond its result, for the circuit witness hints (plume_stages.h h2c_intermediates): tv1 = Z u^2, the square-root candidate of
+// sqrt_ratio and which branch was taken
+struct sswu_extra {
+    fe tv1;        // Z * u^2
+    fe root;       // is_sq ? sqrt(gx1) : sqrt(Z * gx1)      (RFC 9380 F.2.1.2 sqrt_ratio's second return value; sign as the exponentiation gives it)
+    bool is_sq;    // gx1 is a square
+};
 // RFC 9380 F.2 straight-line SSWU without the final division: x = xn/xd, y affine on E'
-PLUME_HD void sswu_frac(fe& xn, fe& xd, fe& y, const fe& u) {
+PLUME_HD void sswu_frac(fe& xn, fe& xd, fe& y, const fe& u, sswu_extra* extra = nullptr) {
     const fe A = fe_iso_a();
     fe tv1, tv2, tv3, tv4, tv5, tv6, y1, t;
     fe_sqr(tv1, u);
@@ -110,6 +117,7 @@ PLUME_HD void sswu_frac(fe& xn, fe& xd, fe& y, const fe& u) {
     bool is_sq = fe_eq(s3, tv2);
     fe y2; fe_mul_k(y2, fe_sqrt_neg_z(), y1);
     fe_cmov(y1, y2, !is_sq);
+    if (extra) { extra->tv1 = tv1; extra->root = y1; extra->is_sq = is_sq; }
     fe_mul(y, tv1, u);
     fe_mul(y, y, y1);
     fe_cmov(xn, tv3, is_sq);

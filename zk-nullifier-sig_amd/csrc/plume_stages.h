@@ -544,7 +544,24 @@ struct H2cInterArgs {
     uint8_t* mapped;       // optional, n x 128: q0_x_mapped | q0_y_mapped | q1_x_mapped | q1_y_mapped   (affine, on E')
     uint8_t* q;            // optional, n x 128: Q0.x | Q0.y | Q1.x | Q1.y   (affine, on secp256k1; identity = zeros)
     uint8_t* h;            // optional, n x 64 : H.x | H.y
+    uint8_t* hints;        // optional, n x 192: q0_gx1_sqrt | q0_gx2_sqrt | q0_y_pos | q1_gx1_sqrt | q1_gx2_sqrt | q1_y_pos   (UNPINNED definitions: include/plume_hip.h)
 };
+// The three square-root hints of one map (circuits/circom/verify_nullifier.circom:21-23,27-29).  UNPINNED: their generator (secp256k1_hash_to_curve_circom/ts/
+// generate_inputs) is not in the reference tree, so these follow RFC 9380 F.2 / F.2.1.2 with every free choice fixed here and stated in include/plume_hip.h:
+//   gx1 = x1^3 + A' x1 + B',  gx2 = x2^3 + A' x2 + B' with x2 = Z u^2 x1  (so gx2 = (Z u^2)^3 gx1: exactly one of gx1, gx2 is a square, Z being a non-residue)
+//   gxk_sqrt = the EVEN square root (sgn0 = 0) of gxk when gxk is a square, of Z * gxk when it is not (sqrt_ratio's second return value: the witness that gxk is a non-residue)
+//   y_pos    = the square root of the chosen gx (gx1 if it is a square, else gx2) whose sgn0 equals sgn0(u): the y the map returns on E'
+// All four roots come out of the map's ONE exponentiation: with r = sqrt_ratio's candidate, sqrt(gx1) = r and sqrt(Z gx2) = Z u tv1 r on the square branch,
+// sqrt(Z gx1) = r and sqrt(gx2) = tv1 u r on the other (tv1 = Z u^2).
+PLUME_HD void fe_even_root(fe& r) { if (fe_is_odd(r)) fe_neg(r, r); }
+PLUME_HD void sswu_hints(fe& gx1_sqrt, fe& gx2_sqrt, const fe& u, const sswu_extra& e) {
+    fe t;
+    gx1_sqrt = e.root;
+    fe_mul(t, e.tv1, u); fe_mul(t, t, e.root);                   // tv1 u r
+    if (e.is_sq) { fe_mul_small(t, t, 11); fe_neg(gx2_sqrt, t); }   // Z = -11:  Z u tv1 r
+    else gx2_sqrt = t;
+    fe_even_root(gx1_sqrt); fe_even_root(gx2_sqrt);
+}
 // one 256-bit value: canonical, big-endian bytes or little-endian registers (= little-endian bytes); dst is 4-byte aligned
 PLUME_HD void store_value(uint8_t* dst, fe v, int registers) {
     fe_normalize(v);
@@ -567,17 +584,25 @@ PLUME_HD void h2c_intermediates(const H2cInterArgs& a, uint32_t i) {
     jac q[2], h;
     if (bad) {   // all outputs zero
         const fe z = fe_zero();
-        PLUME_NOUNROLL for (int k = 0; k < 4; k++) {
+        PLUME_NOUNROLL for (int k = 0; k < 6; k++) {
             if (a.u && k < 2) store_value(a.u + 64 * (size_t)i + 32 * k, z, a.registers);
-            if (a.mapped) store_value(a.mapped + 128 * (size_t)i + 32 * k, z, a.registers);
-            if (a.q) store_value(a.q + 128 * (size_t)i + 32 * k, z, a.registers);
+            if (a.mapped && k < 4) store_value(a.mapped + 128 * (size_t)i + 32 * k, z, a.registers);
+            if (a.q && k < 4) store_value(a.q + 128 * (size_t)i + 32 * k, z, a.registers);
             if (a.h && k < 2) store_value(a.h + 64 * (size_t)i + 32 * k, z, a.registers);
+            if (a.hints) store_value(a.hints + 192 * (size_t)i + 32 * k, z, a.registers);
         }
         return;
     }
     hash_to_field2(u[0], u[1], a.msgs + o0, mlen, px, 2u + (fe_is_odd(py) ? 1u : 0u), enc);
     PLUME_NOUNROLL for (int k = 0; k < 2; k++) {
-        sswu_frac(xn[k], xd[k], y[k], u[k]);
+        sswu_extra ex;
+        sswu_frac(xn[k], xd[k], y[k], u[k], &ex);
+        if (a.hints) {
+            fe g1, g2;
+            sswu_hints(g1, g2, u[k], ex);
+            uint8_t* dst = a.hints + 192 * (size_t)i + 96 * k;
+            store_value(dst, g1, a.registers); store_value(dst + 32, g2, a.registers); store_value(dst + 64, y[k], a.registers);   // y_pos: the map's y (sgn0 = sgn0(u))
+        }
         iso3_frac_to_jac(q[k], xn[k], xd[k], y[k]);
     }
     h = q[0];

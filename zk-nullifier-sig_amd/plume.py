@@ -234,9 +234,9 @@ def verify_non_zk(sig: Tuple[PlumeSignaturePublic, PlumeSignaturePrivate], pk: A
 
 
 def circuit_inputs(sig: "PlumeSignature", engine: Optional[Engine] = None) -> dict:
-    """The pinnable inputs of the circom verifier (circuits/circom/verify_nullifier.circom:14-31; test/v1.test.ts:68-78) for one signature, as lists of four
-    64-bit little-endian registers (circuits/circom/utils.ts:11-17): c, s, pk, nullifier from the signature, q{0,1}_x_mapped / q{0,1}_y_mapped from the
-    GPU hash_to_curve.  q*_gx1_sqrt, q*_gx2_sqrt and q*_y_pos are not produced (their generator is not vendored in the reference tree)."""
+    """All inputs of the circom verifier (circuits/circom/verify_nullifier.circom:14-31; test/v1.test.ts:68-78) for one signature, as lists of four 64-bit
+    little-endian registers (circuits/circom/utils.ts:11-17): c, s, pk, nullifier from the signature, q{0,1}_x_mapped / q{0,1}_y_mapped from the GPU hash_to_curve
+    (pinned), and q{0,1}_gx1_sqrt / gx2_sqrt / y_pos as include/plume_hip.h DEFINES them (UNPINNED: their generator is not vendored in the reference tree)."""
     from .capi import registers_from_be
     eng = engine or default_engine()
     msgs, off = pack_messages([bytes(sig.message)])
@@ -245,7 +245,8 @@ def circuit_inputs(sig: "PlumeSignature", engine: Optional[Engine] = None) -> di
     reg = lambda b: [int(x) for x in registers_from_be(a(b).reshape(1, 32))[0]]  # noqa: E731
     pt = lambda p: [reg(p.to_bytes64()[:32]), reg(p.to_bytes64()[32:])]  # noqa: E731
     m = o["mapped"][0]
-    return {"c": reg(sig.c.to_bytes()), "s": reg(sig.s.to_bytes()), "plume_message": list(bytes(sig.message)), "pk": pt(sig.pk), "nullifier": pt(sig.nullifier),
+    hints = {k: [int(x) for x in v[0]] for k, v in eng.h2c_hints_batch(msgs, off, a(sig.pk.to_bytes64()), registers=True).items()}
+    return {**hints, "c": reg(sig.c.to_bytes()), "s": reg(sig.s.to_bytes()), "plume_message": list(bytes(sig.message)), "pk": pt(sig.pk), "nullifier": pt(sig.nullifier),
             "q0_x_mapped": [int(x) for x in m[0]], "q0_y_mapped": [int(x) for x in m[1]], "q1_x_mapped": [int(x) for x in m[2]], "q1_y_mapped": [int(x) for x in m[3]]}
 
 
