@@ -309,6 +309,10 @@ int plume_aggregate_check_device(plume_ctx* ctx, int version, int mode, size_t n
  * the stream the kernels were launched on.  Fills up to `cap` entries: names[i] (static strings) and ms[i];
  * returns the number of stages, or a negative error.  Synchronises the recorded events. */
 int plume_last_stage_times(plume_ctx* ctx, const char** names, float* ms, int cap);
+/* Measurement / test hook: the number of multi-scalar tasks (two per item) of the last verify call on this context whose unchecked addition chain met p == +-q and that
+ * the second, dense launch redid with checked additions (k_verify_msm_redo).  Honest batches: 0.  Crafted items (pk = +-k G for small k with s = +-c, ...) file one or two
+ * tasks each: that is all they cost -- their wavefront neighbours no longer wait for them.  Synchronises with the device. */
+int plume_last_redo_tasks(plume_ctx* ctx, uint64_t* count);
 /* VALU issue-rate microbenchmark (32 waves per CU, 8 independent chains per lane, `iters` x 8 instructions per lane):
  * returns operations per second chip-wide (<= 0 on error).  kind: 0 v_mad_u64_u32, 1 v_addc_co_u32, 2 v_mul_lo_u32,
  * 3 v_mad_u32_u24, 4 v_add_u32, 5 one Fp multiplication, 6 one Fp squaring, 7 v_fma_f64, 8 v_lshl_add_u64.

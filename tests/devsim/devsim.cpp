@@ -213,8 +213,11 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     const size_t nj = 3 * (size_t)n;
     run_tables(a.tab, a.bases, a.jobflags, nj, L);
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);
+    std::vector<uint32_t> redo(2 * (size_t)n + 1, 0);
+    a.redo = redo.data();
     for (uint32_t eq = 0; eq < 2; eq++)
-        for (uint32_t i = 0; i < n; i++) verify_msm(a, i, eq, a.gtab, dig.data() + (i % B), B);
+        for (uint32_t i = 0; i < n; i++) verify_msm<false>(a, i, eq, a.gtab, dig.data() + (i % B), B);
+    for (uint32_t k = 0; k < redo[0]; k++) verify_msm<true>(a, redo[1 + k] >> 1, redo[1 + k] & 1u, a.gtab, dig.data() + (k % B), B);      // mirrors k_verify_msm_redo
     if (version == 2 && mode == PLUME_MODE_VERIFY) {      // mirrors launch_normalize
         const size_t npts = 2 * (size_t)n, nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;
         for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.res, a.resinf, npts, lane, nlanes);
@@ -389,7 +392,10 @@ int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[6
     for (int j = 0; j < 3; j++) { st_base(a.bases, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
     run_tables(a.tab, a.bases, a.jobflags, 3, 3);
     std::vector<int8_t> dig(4 * PLUME_NDIG);
-    verify_msm(a, 0, 0, a.gtab, dig.data(), 1);
+    uint32_t redo[3] = {0, 0, 0};
+    a.redo = redo;
+    verify_msm<false>(a, 0, 0, a.gtab, dig.data(), 1);
+    if (redo[0]) verify_msm<true>(a, 0, 0, a.gtab, dig.data(), 1);
     jac r; ld_jac_soa(r, a.res, 2, 0); r.inf = a.resinf[0];
     fe ox = fe_zero(), oy = fe_zero();
     if (!r.inf) { fe zi, zi2; fe_inv(zi, r.z); fe_sqr(zi2, zi); fe_mul(ox, r.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(oy, r.y, zi2); }

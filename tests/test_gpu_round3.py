@@ -313,3 +313,36 @@ def test_h2c_hints_unpinned_definitions_on_the_gpu(eng):
     hints, inter = eng.h2c_hints_batch(b["msgs"], b["off"]), eng.h2c_intermediates_batch(b["msgs"], b["off"])
     assert np.array_equal(hints["q0_y_pos"], inter["mapped"][:, 1]) and np.array_equal(hints["q1_y_pos"], inter["mapped"][:, 3])
     assert not (hints["q0_gx1_sqrt"][:, 31] & 1).any() and not (hints["q1_gx2_sqrt"][:, 31] & 1).any()
+
+
+def test_crafted_items_are_redone_by_the_second_launch_and_cost_only_themselves(eng):
+    """items built to hit p == +-q inside an unchecked addition (pk = G, s = +-c = d small: tests/test_devsim.py::test_crafted_collisions_take_the_checked_fallback) are filed
+    and redone by k_verify_msm_redo: the verdicts of the whole batch equal the CPU's, honest batches file nothing, every crafted item files its task"""
+    import torch
+    from oracle import plume_oracle as O
+    dev = torch.device("cuda:0")
+    n = (1 << 17) + 777
+    b = synth.sign_inputs(n, start=21_000_000)
+    sg = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+    msgs, off, ok = t(b["msgs"]), t(b["off"].view(np.int64)), torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    def run(v):                                               # one device-resident call = one multi-scalar launch pair: the counter covers the whole batch
+        d = {k: t(v[k]) for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+        eng.verify_batch_device(1, n, msgs, off, int(b["off"][-1]), d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok)
+        torch.cuda.synchronize()
+        return ok.cpu().numpy().copy(), eng.last_redo_tasks()
+    got, redone = run(sg)
+    assert bool(got.all()) and redone == 0
+    v = {k: sg[k].copy() for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+    idx = np.arange(5, n, 64)
+    d = (idx % 8 + 1).astype(np.uint8)
+    v["pk"][idx] = np.frombuffer(O.pt_bytes(O.G), dtype=np.uint8)
+    v["c"][idx] = 0; v["c"][idx, 31] = d
+    v["s"][idx] = 0; v["s"][idx, 31] = d
+    minus = idx[::2]                                          # s = -c: the p == q case (the result is 2d*G), the others p == -q (identity)
+    v["s"][minus] = np.frombuffer(b"".join((N - int(x)).to_bytes(32, "big") for x in d[::2]), dtype=np.uint8).reshape(-1, 32)
+    got, redone = run(v)
+    assert redone >= len(idx), (redone, len(idx))
+    want = CF.verify_batch(1, b["msgs"], b["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"], nthreads=THREADS)
+    assert np.array_equal(got, want) and int(got.sum()) == n - len(idx)

@@ -74,6 +74,7 @@ def _load():
     lib.plume_set_chunk.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_set_sub_batches.argtypes = [C.c_void_p, C.c_int]
     lib.plume_set_host_piece.argtypes = [C.c_void_p, C.c_size_t]
+    lib.plume_last_redo_tasks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.plume_last_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
     lib.plume_verify_batch.argtypes = [vp, i, sz] + [vp] * 9
@@ -108,7 +109,7 @@ def _load():
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
+    return ["plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
             "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars", "plume_sec1_der_to_scalars_checked",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
@@ -498,6 +499,12 @@ class Engine:
         if k < 0:
             raise PlumeHipError(f"plume_last_stage_times failed ({k}): {self._lib.plume_last_error().decode()}")
         return [(names[i].decode(), float(ms[i])) for i in range(min(k, cap))]
+
+    def last_redo_tasks(self):
+        """multi-scalar tasks of the last verify call that met p == +-q in an unchecked addition and were redone with checked additions (0 for honest batches)"""
+        c = C.c_uint64(0)
+        self._chk(self._lib.plume_last_redo_tasks(self._ctx, C.byref(c)), "plume_last_redo_tasks")
+        return int(c.value)
 
     def microbench(self, kind, iters=4096):
         v = self._lib.plume_microbench(self._ctx, int(kind), int(iters))

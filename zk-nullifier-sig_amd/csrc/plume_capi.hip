@@ -91,6 +91,7 @@ struct plume_ctx {
     hipStream_t pre = nullptr;                                    // overlapped verify / sign: the stages BEFORE the multi-scalar kernel of sub-batch k+1 run here, beside that kernel of sub-batch k
     hipEvent_t pre_begin = nullptr;                               // ... the caller's stream has reached the call (inputs are there, the workspace is free)
     std::vector<hipEvent_t> pre_ready;                            // ... sub-batch k's window tables are built
+    std::vector<size_t> redo_counters;                            // word offsets (in `redo`) of the last verify call's redo counters, one per sub-batch (plume_last_redo_tasks)
     int sub_batches = 1;                                          // device-resident verify / sign: number of sub-batches; 1 = strictly serial launch order (the default: measured on the MI355X, r03, kernels of two
                                                                   // streams sharing the CUs cost MORE than the table kernel's idle issue slots give back -- 21.85 ms serial vs 22.1-22.4 ms for 2..16 sub-batches)
     size_t overlap_min = (size_t)1 << 17;                         // ... batches below this many items always run serial (a sub-batch must still fill the chip)
@@ -108,7 +109,7 @@ struct plume_ctx {
     HostSlot slot[2];
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
-    DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink;
+    DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo;
     DevBuf dec[4], preflags;
     DevBuf agg[15];      // aggregate check (plume_aggregate.h): haff, scal, flags, gs, hash_ok, counters, count, sort tiles, sorted, bsum, bsuminf, red, redinf, ssum, perm + its histogram
     DevBuf agg_record;   // the running record of a host-pointer aggregate call (pieces of one batch)
@@ -166,7 +167,7 @@ static void destroy_single(plume_ctx* ctx) {
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     if (ctx->pre) (void)hipStreamSynchronize(ctx->pre);
     for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
-                      &ctx->sink, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
+                      &ctx->sink, &ctx->redo, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
     for (DevBuf& b : ctx->agg) b.release();
     for (HostSlot& sl : ctx->slot) {
@@ -498,7 +499,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, tables_scratch_bytes(3 * (cut[k + 1] - cut[k]), pick_jobs_per_lane(ctx, 3 * (cut[k + 1] - cut[k]), true)));
     if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
         ctx->tabscr.ensure(scr_bytes) ||
-        ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n))
+        ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->redo.ensure((2 * n + nsub) * 4))
         return PLUME_ERR_HIP;
     if (overlapped) { if (int rc = pre_events(ctx, nsub)) return rc; }
     StageTimer& t = ctx->timer;
@@ -517,6 +518,9 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * 3 * lo; a.jobflags = ctx->jobflags.as<uint8_t>() + 3 * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo;
         a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * 3 * lo; a.res = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.resinf = ctx->resinf.as<uint8_t>() + 2 * lo;
         a.gtab = ctx->gtab.as<uint32_t>();
+        a.redo = ctx->redo.as<uint32_t>() + 2 * lo + k;                      // the slice's redo list: counter + up to 2 * cnt tasks
+        if (k == 0) ctx->redo_counters.clear();
+        ctx->redo_counters.push_back(2 * lo + k);
         launch_verify_ingest(a, pre); if (!overlapped) t.stage("verify_ingest_h2c", st);
         launch_tables(a.tab, a.bases, a.jobflags, 3 * cnt, pick_jobs_per_lane(ctx, 3 * cnt, true), ctx->tabscr.as<uint32_t>(), pre); if (!overlapped) t.stage("tables", st);   // the table kernels of all sub-batches follow one another on one stream: one scratch
         if (overlapped) {
@@ -1357,6 +1361,23 @@ extern "C" int plume_last_stage_times(plume_ctx* ctx, const char** names, float*
         if (ms) ms[i] = v;
     }
     return ns;
+}
+
+// measurement / test hook: how many multi-scalar tasks of the last verify call on this context met p == +-q in an unchecked addition and were redone by the second launch
+// (0 for honest batches; crafted items -- pk = +-k G with small k and s = +-c -- file one or two tasks each).  Synchronises with the device.
+extern "C" int plume_last_redo_tasks(plume_ctx* ctx, uint64_t* count) {
+    if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
+    if (int rc = bind(ctx)) return rc;
+    if (!count) return fail(PLUME_ERR_ARG, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    uint64_t total = 0;
+    for (size_t off : ctx->redo_counters) {
+        uint32_t c = 0;
+        HIPCHK(hipMemcpy(&c, ctx->redo.as<uint32_t>() + off, 4, hipMemcpyDeviceToHost));
+        total += c;
+    }
+    *count = total;
+    return 0;
 }
 
 static thread_local uint64_t g_microbench_cycles = 0;

@@ -963,6 +963,16 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
         }
     }
 }
+// the same chain with the checked additions only (the redo kernel of the verifier: tasks whose unchecked chain met p == +-q)
+PLUME_HD void msm_run_checked(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
+    PLUME_COUNT_FALLBACK();
+    msm_run_impl<true>(acc, tab0, tab1, nslots, dig, stride, wide0);
+}
+// the unchecked chain; returns false when the accumulator met p == +-q on the way (Z = 0 mod p: the result is garbage and the task has to be redone with checked additions)
+PLUME_HD bool msm_run_unchecked(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
+    msm_run_impl<false>(acc, tab0, tab1, nslots, dig, stride, wide0);
+    return acc.inf || !fe_is_zero(acc.z);
+}
 PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
     msm_run_impl<false>(acc, tab0, tab1, nslots, dig, stride, wide0);
     // an accumulator that met p == +-q inside an unchecked addition has Z = 0 (mod p) forever after (see jac_madd): redo that lane

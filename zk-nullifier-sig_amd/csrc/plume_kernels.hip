@@ -8,6 +8,8 @@
 // are whole cache lines.  The generator's tables (256 KiB / 3 MiB) are read through L1/L2, the per-lane tables of the variable
 // bases live in HBM: 1 KiB per base is far more than LDS can hold at any useful occupancy, and their traffic (~10 KiB per
 // verify) is negligible next to the ~7 * 10^5 VALU instructions per item.
+#include <algorithm>
+
 #include "plume_launch.h"
 #include "plume_dedup.h"
 
@@ -267,7 +269,18 @@ __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
 #endif
     const uint32_t* gt = a.gtab;   // read through L1/L2 (a 128-entry table staged in LDS was 10 % slower: bank conflicts on per-lane random rows)
     const uint32_t i = blk * kBlock + threadIdx.x;
-    if (i < a.n) verify_msm(a, i, eq, gt, s_dig + threadIdx.x, kBlock);
+    if (i < a.n) verify_msm<false>(a, i, eq, gt, s_dig + threadIdx.x, kBlock);
+    wipe_digits<4 * PLUME_NDIG>(s_dig);
+}
+// the tasks k_verify_msm filed (their unchecked chain met p == +-q), one per lane, with the checked additions; grid-stride over the filed count, so an honest batch's
+// launch finds nothing and returns
+__global__ PLUME_MSM_BOUNDS void k_verify_msm_redo(VerifyArgs a) {
+    __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
+    const uint32_t count = a.redo[0];
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
+        const uint32_t t = a.redo[1 + k];
+        verify_msm<true>(a, t >> 1, t & 1u, a.gtab, s_dig + threadIdx.x, kBlock);
+    }
     wipe_digits<4 * PLUME_NDIG>(s_dig);
 }
 
@@ -496,7 +509,12 @@ void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags
     hipLaunchKernelGGL(k_tables, dim3(nblocks(lanes)), dim3(kBlock), 0, st, tab, bases, jobflags, njobs, L, scr);
 #endif
 }
-void launch_verify_msm(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_msm, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {
+    (void)hipMemsetAsync(a.redo, 0, 4, st);
+    hipLaunchKernelGGL(k_verify_msm, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    const unsigned redo_blocks = std::min(2 * nblocks(a.n), 1024u);                      // grid-stride: enough lanes for a wholly crafted batch to fill the chip
+    hipLaunchKernelGGL(k_verify_msm_redo, dim3(redo_blocks), dim3(kBlock), 0, st, a);
+}
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_finalize, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_gmul(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_gmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_h2c(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_h2c, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }

@@ -160,7 +160,22 @@ struct VerifyArgs {
     uint32_t* res;        // PLUME_JAC_WORDS x (2n) words, Jacobian SoA of R' (task 2i) and Hr' (task 2i+1)
     uint8_t* resinf;      // 2n
     const uint32_t* gtab; // wide table of G (PLUME_GTAB_WORDS): (1..2^(W-1))*G
+    uint32_t* redo;       // redo[0] = number of tasks whose unchecked chain met p == +-q, redo[1 + k] = the k-th such task (2i + eq); capacity 2n; zeroed before the multi-scalar kernel
 };
+// One crafted item (pk = +-k G with small k, s = +-c, ...) steers its accumulator into p == +-q inside an UNCHECKED addition.  Rounds 1-2 redid such a lane on the spot with
+// the checked additions -- and its 63 neighbours waited: one crafted item per wavefront doubled the kernel.  Now the lane only files its task; a second,
+// dense launch (k_verify_msm_redo: one filed task per lane, grid-stride) redoes the filed tasks.  Honest batches file nothing and the second launch costs its launch; a batch
+// salted with one crafted item per wavefront pays 1/64 of the kernel again instead of all of it; a batch made ENTIRELY of crafted items pays the checked chain once more
+// (the worst case is bounded by ~2.2x, and that batch is all rejects or all self-inflicted).
+PLUME_HD uint32_t redo_file(uint32_t* redo, uint32_t task) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t k = atomicAdd(redo, 1u);
+#else
+    const uint32_t k = redo[0]++;
+#endif
+    redo[1 + k] = task;
+    return k;
+}
 
 PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     fe pkx, pky, nx, ny;
@@ -205,7 +220,9 @@ PLUME_HD void task_digits(int8_t* dig, uint32_t stride, const sc& ka, bool flip_
     booth_store(dig + 3 * PLUME_NDIG * stride, stride, h2, flip_b);
 }
 
-// task t = 2*item + eq;  eq 0: s*G - c*pk, eq 1: s*H - c*nul.   dig: this lane's digit area (LDS), element stride
+// task t = 2*item + eq;  eq 0: s*G - c*pk, eq 1: s*H - c*nul.   dig: this lane's digit area (LDS), element stride.
+// CHECKED = false: the hot form; a task whose chain met p == +-q is filed in a.redo and stores nothing.  CHECKED = true: the redo launch's form.
+template <bool CHECKED>
 PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const uint32_t* gtab, int8_t* dig, uint32_t stride) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + eq;
     jac acc;
@@ -219,7 +236,12 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
         const size_t ja = 3 * (size_t)item + 1, jb = 3 * (size_t)item + (eq ? 2 : 0);
         const uint32_t* tab0 = eq ? (job_state(a.jobflags[ja]) == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr) : gtab;
         const uint32_t* tab1 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
-        msm_run(acc, tab0, tab1, 4, dig, stride, eq == 0);
+        if (CHECKED) {
+            msm_run_checked(acc, tab0, tab1, 4, dig, stride, eq == 0);
+        } else if (!msm_run_unchecked(acc, tab0, tab1, 4, dig, stride, eq == 0)) {
+            redo_file(a.redo, (uint32_t)t);
+            return;
+        }
     }
     st_jac_soa(a.res, nt, t, acc);
     a.resinf[t] = (uint8_t)acc.inf;
