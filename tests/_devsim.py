@@ -164,6 +164,12 @@ def h2c_intermediates(msgs_buf, msg_off, pk=None, registers=False):
     return {k: v.view(np.uint64) for k, v in o.items()} if registers else o
 
 
+def map2_to_curve(u0: int, u1: int) -> bytes:
+    out = (C.c_uint8 * 64)()
+    lib().ds_map2_to_curve((C.c_uint8 * 32).from_buffer_copy(u0.to_bytes(32, "big")), (C.c_uint8 * 32).from_buffer_copy(u1.to_bytes(32, "big")), out)
+    return bytes(out)
+
+
 def scalars_to_der(scalars):
     sc = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
     der, st = np.zeros((len(sc), 109), dtype=np.uint8), np.zeros(len(sc), dtype=np.uint8)

@@ -415,6 +415,19 @@ int ds_h2c_intermediates(uint32_t n, const uint8_t* msgs, const uint64_t* msg_of
     for (uint32_t i = 0; i < n; i++) h2c_intermediates(a, i);
     return 0;
 }
+// map_to_curve(u0) + map_to_curve(u1) through the device code's one-isogeny path (and its equal-x fallback): u big-endian 32 bytes each, out = affine x || y (zeros = identity)
+void ds_map2_to_curve(const uint8_t* u0b, const uint8_t* u1b, uint8_t* out) {
+    alignas(16) uint8_t ua[32], ub[32], ob[64];
+    memcpy(ua, u0b, 32); memcpy(ub, u1b, 32);
+    fe u0, u1;
+    fe_from_be_aligned(u0, ua); fe_from_be_aligned(u1, ub);
+    jac h;
+    map2_to_curve_jac(h, u0, u1);
+    fe x = fe_zero(), y = fe_zero();
+    if (!h.inf) { fe zi, zi2; fe_inv(zi, h.z); fe_sqr(zi2, zi); fe_mul(x, h.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y, h.y, zi2); }
+    store_affine_be(ob, x, y, h.inf != 0);
+    memcpy(out, ob, 64);
+}
 int ds_scalars_to_der(uint32_t n, const uint8_t* scalars, uint8_t* der, uint8_t* status) {
     const std::vector<uint32_t>& gcomb = shared_gcomb();
     DerArgs a; a.n = n; a.scalars = scalars; a.der = der; a.status = status; a.gcomb = gcomb.data();

@@ -29,13 +29,18 @@ def child(lib, data, subs):
     o = {k: torch.zeros((n, w), dtype=torch.uint8, device=dev) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
     status = torch.zeros(n, dtype=torch.uint8, device=dev)
 
+    acc_stages = {}
+
     def timed(fn, reps):
         fn(); torch.cuda.synchronize()
         ts = []
+        acc_stages.clear()
         for _ in range(reps):
             torch.cuda.synchronize()
             t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) * 1e3)
+            for name, ms in eng.last_stage_times():          # mean over the timed calls (same-stream sub-batches repeat the stage names: summed per call)
+                acc_stages[name] = acc_stages.get(name, 0.0) + ms / reps
         # back to back (what bench.py times)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -45,19 +50,16 @@ def child(lib, data, subs):
         return min(ts), (time.perf_counter() - t0) * 1e3 / reps
 
     def stages():
-        acc = {}
-        for name, ms in eng.last_stage_times():          # same-stream sub-batches repeat the stage names: sum them
-            acc[name] = acc.get(name, 0.0) + ms
-        return acc
+        return dict(acc_stages)
 
     for k in subs:
         eng.set_sub_batches(k)
         ok.zero_()
-        v = timed(lambda: eng.verify_batch_device(1, n, t["msgs"], t["off"], mb, t["pk"], t["nullifier"], t["c"], t["s"], t["r_point"], t["hashed_to_curve_r"], ok), 6)
+        v = timed(lambda: eng.verify_batch_device(1, n, t["msgs"], t["off"], mb, t["pk"], t["nullifier"], t["c"], t["s"], t["r_point"], t["hashed_to_curve_r"], ok), 10)
         vst = stages()
         assert bool((ok.cpu().numpy() == d["expected"]).all()), "wrong verdicts"
         o["nullifier"].zero_()
-        s = timed(lambda: eng.sign_batch_device(1, n, t["msgs"], t["off"], mb, t["sk"], t["r"], None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], status), 4)
+        s = timed(lambda: eng.sign_batch_device(1, n, t["msgs"], t["off"], mb, t["sk"], t["r"], None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], status), 8)
         sst = stages()
         assert bool((o["nullifier"].cpu().numpy() == d["nullifier_signed"]).all()) and bool((o["s"].cpu().numpy() == d["s_signed"]).all()), "wrong signatures"
         print(json.dumps({"lib": pathlib.Path(lib).name, "sub_batches": k, "verify_best_ms": round(v[0], 3), "verify_b2b_ms": round(v[1], 3), "sign_best_ms": round(s[0], 3),

@@ -396,6 +396,19 @@ def test_h2c_intermediates_and_registers(kats):
     _check_h2c_intermediates(lambda mb, off, pk, regs: D.h2c_intermediates(mb, off, pk, regs), D.registers_from_be, kats)
 
 
+def test_one_isogeny_after_adding_on_the_isogenous_curve():
+    """hash_to_curve evaluates the 3-isogeny ONCE, on Q0' + Q1' added on E' (RFC 9380 section 6.6.3; plume_h2c.h map2_to_curve_jac): equal to iso(Q0') + iso(Q1') from the
+    Python oracle for random pairs and for the pairs the chord formula cannot take -- u1 = u0 (a doubling) and u1 = -u0 (opposite points: the identity) -- which go through
+    the two-isogeny fallback"""
+    rng = random.Random(99)
+    us = [rng.randrange(P) for _ in range(24)] + [0, 1, 2, P - 1]
+    pairs = [(rng.choice(us), rng.choice(us)) for _ in range(40)] + [(u, u) for u in us[:6]] + [(u, (P - u) % P) for u in us[:6]]
+    for u0, u1 in pairs:
+        want = O.pt_add(O.iso_map(O.map_to_curve_sswu(u0)), O.iso_map(O.map_to_curve_sswu(u1)))
+        assert D.map2_to_curve(u0, u1) == O.pt_bytes(want), (u0, u1)
+    assert D.map2_to_curve(5, P - 5) == bytes(64)
+
+
 def _check_h2c_hints(get_hints, get_inter):
     """the square-root hints (UNPINNED: no reference vector exists; include/plume_hip.h defines them).  Checked (a) against the definitions themselves -- algebra on the
     values the pinned outputs give: gx1, gx2 from u (RFC 9380 F.2), root^2 = gx or Z gx, evenness, y_pos = y_mapped with sgn0 = sgn0(u) -- and (b) against the Python

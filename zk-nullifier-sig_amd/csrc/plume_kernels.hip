@@ -26,7 +26,7 @@
 #define PLUME_TABLES_WAVES 3   // the table kernel streams ~3.6 KB per job through HBM; 3 waves with fewer spills measured 9 % faster than 4
 #endif
 #ifndef PLUME_H2C_WAVES
-#define PLUME_H2C_WAVES PLUME_MIN_WAVES
+#define PLUME_H2C_WAVES 3      // round 3, after the one-isogeny hash_to_curve: 3 waves (168 VGPRs, fewer spills) 2.54 ms, 4 waves 2.58, 2 waves 2.65 per 2^20 items (one box)
 #endif
 #ifndef PLUME_FINAL_WAVES
 #define PLUME_FINAL_WAVES 2    // the finalize kernels hold six encodings + SHA state: at 4 waves they spill ~200 VGPRs (measured 0.48 -> 0.33 ms at 2)

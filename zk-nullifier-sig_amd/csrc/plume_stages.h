@@ -190,18 +190,23 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     const bool err = a.mode == PLUME_MODE_NON_ZK && !bad && fpk == PLUME_JOB_INF;      // hash_to_curve(message, pk)? -> Err
     a.itemflags[i] = (uint8_t)(bad ? PLUME_ITEM_REJECT : err ? PLUME_ITEM_ERR : 0u);
     bad = bad || err;
+    // the records of pk and the nullifier go out BEFORE hash_to_curve: nothing below needs y(nullifier) or more of pk than its x and parity, and 27 registers less are
+    // live through the two exponentiations (the kernel spills at its 128-register budget)
+    {
+        jac p; p.inf = 0; p.z = fe_small(1);
+        p.x = nx; p.y = ny;
+        st_base(a.bases, 3 * (size_t)i + 2, p); a.jobflags[3 * (size_t)i + 2] = (uint8_t)(fnul | PLUME_JOB_AFFINE);
+        p.x = pkx; p.y = pky;
+        st_base(a.bases, 3 * (size_t)i + 0, p); a.jobflags[3 * (size_t)i + 0] = (uint8_t)(fpk | PLUME_JOB_AFFINE);
+    }
+    const uint32_t pktag = 2u + (fe_is_odd(pky) ? 1u : 0u);
     jac h;
     if (!bad) {
-        hash_to_curve_jac(h, a.msgs + o0, mlen, pkx, 2u + (fe_is_odd(pky) ? 1u : 0u), fpk == PLUME_JOB_INF ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
+        hash_to_curve_jac(h, a.msgs + o0, mlen, pkx, pktag, fpk == PLUME_JOB_INF ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
     } else {
         h.x = fe_gx(); h.y = fe_gy(); h.z = fe_small(1); h.inf = 0;
     }
-    jac p; p.inf = 0; p.z = fe_small(1);
-    p.x = pkx; p.y = pky;
-    st_base(a.bases, 3 * (size_t)i + 0, p); a.jobflags[3 * (size_t)i + 0] = (uint8_t)(fpk | PLUME_JOB_AFFINE);
     st_base(a.bases, 3 * (size_t)i + 1, h); a.jobflags[3 * (size_t)i + 1] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
-    p.x = nx; p.y = ny;
-    st_base(a.bases, 3 * (size_t)i + 2, p); a.jobflags[3 * (size_t)i + 2] = (uint8_t)(fnul | PLUME_JOB_AFFINE);
 }
 
 // digits of one double-base task a*A + b*B into dig (4 slots x 33): slots 0,1 = a's halves, 2,3 = b's halves
