@@ -1,12 +1,13 @@
 #!/bin/bash
 # Collect the round's measurements on the GPU box (run through gpurun from the repo root):
-#     gpurun -- 'bash profiles/collect.sh r01'
-# then, back in the container:  cp gpurun_out/prof_r01/r01_kernel_{stats,trace}.csv profiles/ ; tail -1 gpurun_out/bench_r01.log > profiles/r01_bench_line.json ;
-#                               python profiles/summarize_pmc.py r01
+#     gpurun -- 'bash profiles/collect.sh r03'
+# then, back in the container:  cp gpurun_out/prof_r03/r03_kernel_{stats,trace}.csv profiles/ ; tail -1 gpurun_out/bench_r03.log > profiles/r03_bench_line.json ;
+#                               python profiles/summarize_pmc.py r03
 # Counters go in their own passes, each with --kernel-trace only (never with sys/hip/hsa traces).
-R=${1:-r02}
+R=${1:-r03}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+python3 -c "import zk_nullifier_sig_amd as p; print(p.Engine(0).version())" > gpurun_out/build_$R.txt 2>/dev/null
 python3 bench.py > gpurun_out/bench_$R.log 2> gpurun_out/bench_$R.err
 # the metric workload alone (every k_verify_* / k_tables launch is a 2^20-item V1 launch, so the per-kernel averages are comparable with bench.py's stage_ms) ...
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/bench_${R}_prof.log 2>&1

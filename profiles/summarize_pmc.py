@@ -22,14 +22,14 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = {}
 for tag in ("sq", "sq2"):
     for k, v in load(f"gpurun_out/pmc_{tag}/{tag}_counter_collection.csv").items():
-        if not (k.startswith("plume::k_verify") or k == "plume::k_tables"):
+        if not (k.startswith("plume::k_verify") or k.startswith("plume::k_tab")):
             continue
         d = out.setdefault(k, {})
         for c, x in v.items():
             if c == "_dur_ns":
                 d.setdefault("_dur_ns_max", max(x))
             else:
-                d[c] = max(x) if k == "plume::k_tables" else sum(x) / len(x)
+                d[c] = max(x) if k.startswith("plume::k_tab") else sum(x) / len(x)      # the table kernels also run for the setup signer's smaller launches: the verify launch is the largest
 fe, wr = load("gpurun_out/pmc_fetch/fetch_counter_collection.csv"), load("gpurun_out/pmc_write/write_counter_collection.csv")
 for k in out:
     if k in fe:
@@ -37,17 +37,21 @@ for k in out:
     if k in wr:
         out[k]["WRITE_SIZE_KB_raw"] = max(wr[k]["WRITE_SIZE"])
 for k, d in out.items():
-    if "SQ_ACTIVE_INST_VALU" in d and d.get("GRBM_GUI_ACTIVE"):
+    if isinstance(d, dict) and "SQ_ACTIVE_INST_VALU" in d and d.get("GRBM_GUI_ACTIVE"):
         # rocprof's derived VALUBusy: 4 cycles per wave64 VALU instruction, 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
         d["VALUBusy"] = round(d["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (d["GRBM_GUI_ACTIVE"] / 8), 3)
+try:
+    out["_build"] = open(f"gpurun_out/build_{rnd}.txt").read().strip()      # plume_version() of the library the counters were collected from (bench.py compares it with its own)
+except OSError:
+    pass
 out["_notes"] = {
     "collection": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv, separate passes (sq, sq2, FETCH_SIZE, WRITE_SIZE); "
                   "command: python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras",
     "units": "FETCH_SIZE / WRITE_SIZE in KB as reported (raw). MI355X_MICROARCH.md: FETCH_SIZE tallies a 128-byte request at 64 bytes on gfx950 (x2 for wide coalesced streams); "
              "calibrated for the multi-scalar kernel's access pattern (five 16-byte quads of one 128-byte table row per lane) in profiles/r02_fetch_calibration.json: 63.9 bytes "
              "reported per row, i.e. the same factor 2, which bench.py applies; WRITE_SIZE is uncalibrated and taken as reported",
-    "k_tables": "max over launches (the first launch of each process is the one-off generator table)"}
+    "k_tab*": "max over launches (the setup signer launches the table passes with a third of the jobs)"}
 json.dump(out, open(f"profiles/{rnd}_pmc_summary.json", "w"), indent=1)
 for k, d in out.items():
-    if not k.startswith("_"):
+    if not k.startswith("_") and isinstance(d, dict):
         print(k, {c: "%.3g" % x for c, x in sorted(d.items()) if c in ("FETCH_SIZE_KB_raw", "WRITE_SIZE_KB_raw", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE", "_vgpr", "_scratch", "_dur_ns_max")})
