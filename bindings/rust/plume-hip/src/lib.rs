@@ -78,6 +78,10 @@ extern "C" {
     fn plume_sign_batch(ctx: *mut plume_ctx, version: c_int, n: usize, msgs: *const u8, msg_off: *const u64, sk: *const u8, r: *const u8, pk_in: *const u8,
         pk: *mut u8, nullifier: *mut u8, c: *mut u8, s: *mut u8, r_point: *mut u8, hashed_to_curve_r: *mut u8, status: *mut u8) -> c_int;
     fn plume_scalars_to_sec1_der_batch(ctx: *mut plume_ctx, n: usize, scalars: *const u8, der109: *mut u8, status: *mut u8) -> c_int;
+    fn plume_sec1_der_to_scalars_checked(ctx: *mut plume_ctx, n: usize, der109: *const u8, scalars: *mut u8, ok: *mut u8) -> c_int;
+    fn plume_h2c_hints_batch(ctx: *mut plume_ctx, n: usize, msgs: *const u8, msg_off: *const u64, pk: *const u8, registers: c_int, hints: *mut u8) -> c_int;
+    fn plume_set_sub_batches(ctx: *mut plume_ctx, sub_batches: c_int) -> c_int;
+    fn plume_shard_numa_node(ctx: *const plume_ctx, shard: c_int) -> c_int;
     fn plume_aggregate_check(ctx: *mut plume_ctx, version: c_int, mode: c_int, n: usize, msgs: *const u8, msg_off: *const u64, pk: *const u8, nullifier: *const u8, c: *const u8,
                              s: *const u8, r_point: *const u8, hashed_to_curve_r: *const u8, seed: *const u8, hash_ok: *mut u8, result: *mut u8) -> c_int;
 }
@@ -153,12 +157,13 @@ impl HipEngine {
     /// `verify()` — up to a false-accept probability of 2^-126 over `seed`, which must be 32 fresh random bytes the signers could not predict.  All-or-nothing:
     /// on `Ok(false)` call `verify_batch` to find the culprits.  Per item the challenge hash is checked exactly; the two group equations (lib.rs:101,109,117,122)
     /// only in one random linear combination (a single 5n-point multi-scalar multiplication on the GPU).
-    pub fn aggregate_check_v1(&self, sigs: &[PlumeSignature], seed: &[u8; 32]) -> Result<bool, HipError> {
+    /// `seed = None` lets the library draw the 32 bytes from the OS generator (prefer it over anything constant, reused or known to the signers).
+    pub fn aggregate_check_v1(&self, sigs: &[PlumeSignature], seed: Option<&[u8; 32]>) -> Result<bool, HipError> {
         let p = pack(sigs);
         assert!(p.v1 || sigs.is_empty(), "the aggregate check needs the V1 fields r_point / hashed_to_curve_r");
         let mut rec = [0u8; 72];
         let rc = unsafe { plume_aggregate_check(self.0, 1, 0, sigs.len(), p.msgs.as_ptr(), p.off.as_ptr(), p.pk.as_ptr(), p.nul.as_ptr(), p.c.as_ptr(), p.s.as_ptr(),
-                                                p.rp.as_ptr(), p.hr.as_ptr(), seed.as_ptr(), std::ptr::null_mut(), rec.as_mut_ptr()) };
+                                                p.rp.as_ptr(), p.hr.as_ptr(), seed.map_or(std::ptr::null(), |s| s.as_ptr()), std::ptr::null_mut(), rec.as_mut_ptr()) };
         if rc != 0 { return Err(last_error()); }
         Ok(rec[0] == 1)
     }
@@ -237,6 +242,43 @@ impl HipEngine {
         if rc != 0 { return Err(last_error()); }
         Ok(der.chunks_exact(109).map(|ch| { let mut a = [0u8; 109]; a.copy_from_slice(ch); a }).collect())
     }
+
+    /// `SecretKey::from_sec1_der` for the 109-byte records of `scalars_to_sec1_der`, with the reference's semantics: `None` for a record of another shape, a scalar outside
+    /// [1, n-1], or an embedded public key that is not scalar * G (elliptic-curve's `TryFrom<EcPrivateKey>` validates it; here the GPU recomputes it).
+    pub fn scalars_from_sec1_der(&self, der: &[[u8; 109]]) -> Result<Vec<Option<NonZeroScalar>>, HipError> {
+        let n = der.len();
+        let flat: Vec<u8> = der.iter().flat_map(|d| d.iter().copied()).collect();
+        let (mut sc, mut ok) = (vec![0u8; 32 * n], vec![0u8; n]);
+        let rc = unsafe { plume_sec1_der_to_scalars_checked(self.0, n, flat.as_ptr(), sc.as_mut_ptr(), ok.as_mut_ptr()) };
+        if rc != 0 { return Err(last_error()); }
+        Ok((0..n).map(|i| if ok[i] == 1 { get_scalar(&sc[32 * i..]) } else { None }).collect())
+    }
+
+    /// The circuit's square-root hints for `h2c(msg || SEC1c(pk))` (circuits/circom/verify_nullifier.circom:21-23,27-29) as 4 x 64-bit little-endian registers each:
+    /// `[q0_gx1_sqrt, q0_gx2_sqrt, q0_y_pos, q1_gx1_sqrt, q1_gx2_sqrt, q1_y_pos]` per item.  UNPINNED: include/plume_hip.h defines them (the reference's generator
+    /// of these inputs is not in its tree).
+    pub fn h2c_hints(&self, msgs: &[&[u8]], pks: &[AffinePoint]) -> Result<Vec<[[u64; 4]; 6]>, HipError> {
+        let n = msgs.len();
+        assert!(pks.len() == n);
+        let (mut buf, mut off) = (Vec::new(), vec![0u64]);
+        for m in msgs { buf.extend_from_slice(m); off.push(buf.len() as u64); }
+        buf.push(0);
+        let mut pk = vec![0u8; 64 * n];
+        for (i, p) in pks.iter().enumerate() { put_point(&mut pk[64 * i..], p); }
+        let mut out = vec![0u8; 192 * n];
+        let rc = unsafe { plume_h2c_hints_batch(self.0, n, buf.as_ptr(), off.as_ptr(), pk.as_ptr(), 1, out.as_mut_ptr()) };
+        if rc != 0 { return Err(last_error()); }
+        Ok(out.chunks_exact(192).map(|it| {
+            let mut r = [[0u64; 4]; 6];
+            for k in 0..6 { for j in 0..4 { r[k][j] = u64::from_le_bytes(it[32 * k + 8 * j..32 * k + 8 * j + 8].try_into().unwrap()); } }
+            r
+        }).collect())
+    }
+
+    /// Device-resident calls only (`plume_set_sub_batches`): 1 = strictly serial launch order (the default and, on the MI355X, the fastest: DESIGN.md section 6)
+    pub fn set_sub_batches(&self, k: i32) -> Result<(), HipError> { if unsafe { plume_set_sub_batches(self.0, k) } == 0 { Ok(()) } else { Err(last_error()) } }
+    /// The NUMA node shard `d`'s worker thread bound itself to (`None`: not bound) — allocate / pin the caller arrays of that shard's slice there
+    pub fn shard_numa_node(&self, d: usize) -> Option<i32> { let v = unsafe { plume_shard_numa_node(self.0, d as c_int) }; if v >= 0 { Some(v) } else { None } }
 
     /// Page-lock a long-lived buffer once (`plume_host_register`): the copy engines then read / write it directly and the library's
     /// upload / compute / download pipeline overlaps fully.  Pair with `unpin`.
