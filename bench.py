@@ -199,6 +199,26 @@ def cpu_baseline(version: int, sign: bool = False):
                                       "inversion by addition chain, checked item by item against the plain oracle in tests/"}
     except Exception as e:  # the optimised leg is optional
         out["optimized"] = {"error": str(e)[:200]}
+    try:                                                   # SURVEY.md §8d's optional third-party leg: OpenSSL's secp256k1 arithmetic under the oracle's hash_to_curve
+        from tests import _openssl_leg as OL
+        if OL.available():
+            m = 1 << 13
+            am = (version, v["msgs"], v["off"][: m + 1], v["pk"][:m], v["nullifier"][:m], v["c"][:m], v["s"][:m],
+                  v["r_point"][:m] if version == 1 else None, v["hashed_to_curve_r"][:m] if version == 1 else None)
+            t0 = time.perf_counter()
+            ok_o = OL.verify_batch(*am, nthreads=cores)
+            t_o = time.perf_counter() - t0
+            q = 256
+            a1o = (version, v["msgs"], v["off"][: q + 1], v["pk"][:q], v["nullifier"][:q], v["c"][:q], v["s"][:q],
+                   v["r_point"][:q] if version == 1 else None, v["hashed_to_curve_r"][:q] if version == 1 else None)
+            t0 = time.perf_counter()
+            OL.verify_batch(*a1o, nthreads=1)
+            t_o1 = time.perf_counter() - t0
+            assert list(ok_o) == list(ok_mt[:m])
+            out["openssl"] = {"value": round(m / t_o, 1), "unit": "verifies/s", "cores": cores, "kind": "third party (OpenSSL libcrypto EC_POINT_mul / add / cmp on NID_secp256k1; hash_to_curve and "
+                              "SHA-256 from the oracle)", "single_thread_value": round(256 / t_o1, 1), "sample": f"first {m} items of the same batch; verdicts equal the oracle's (asserted)"}
+    except Exception as e:
+        out["openssl"] = {"error": str(e)[:200]}
     return out
 
 
