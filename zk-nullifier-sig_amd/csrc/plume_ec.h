@@ -928,40 +928,89 @@ PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
 // halves (beta*x).  dig: digits of slot s, window i at dig[(s*PLUME_NDIG + i)*stride].  A NULL table (or a
 // job flagged INF) contributes nothing.
 // wide0: slots 0,1 use the generator's wide table with W-bit digits (stored by booth_store_wide).
+#ifndef PLUME_MSM_PREFETCH
+#define PLUME_MSM_PREFETCH 0   // 1: the row of the NEXT table addition is gathered while the current addition (or the window's doublings) runs; 0: gather, wait, add.
+                               // Round 3 built and measured the pipelined form (125 VGPRs, no spills, bit-exact): multi-scalar kernel 17.61 vs 17.48 ms on one box, the signer's
+                               // 13.20 vs 13.29 -- nothing: the SIMD's other three wavefronts already cover a gather's latency (VALUBusy 1.0).  Kept as the experiment's record.
+#endif
+// digit of slot s at window i (wide generator digits decoded); 0 = nothing to add
+PLUME_HD int msm_digit(const int8_t* dig, uint32_t stride, int i, int s, bool wide0) {
+    int d = dig[(uint32_t)(s * PLUME_NDIG + i) * stride];
+    if (wide0 && s < 2) {
+        int mag = d & 0xFF;
+        bool dn;
+        if (i + 1 < PLUME_NDIG) {
+            const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
+#if PLUME_GW > 15
+            mag |= (hi & 0xFF) << 8; dn = dig[(uint32_t)(s * PLUME_NDIG + i + 2) * stride] != 0;
+#else
+            mag |= (hi & 0x7F) << 8; dn = (hi & 0x80) != 0;
+#endif
+        } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
+        d = dn ? -mag : mag;
+    }
+    return d;
+}
+// wave-uniform: slots 0, 1 of a wide-digit task hold a digit at every (W/4)-th window only
+PLUME_HD bool msm_slot_used(int i, int s, bool wide0) { return !(wide0 && s < 2 && (i % PLUME_GWS) != 0); }
+// gather the operand of step (i, s): digit and, for a non-zero digit of a live table, the row's x (or beta x) and y -- the loads are only ISSUED here, whoever
+// reads qx / qy first waits for them
+PLUME_HD int msm_fetch(fe& qx, fe& qy, const uint32_t* tab0, const uint32_t* tab1, const int8_t* dig, uint32_t stride, int i, int s, bool wide0) {
+    const uint32_t* tab = (s & 2) ? tab1 : tab0;
+    int d = msm_digit(dig, stride, i, s, wide0);
+    if (tab == nullptr) d = 0;
+    if (d != 0) {
+        const int ad = d < 0 ? -d : d;
+        ld_tab_xy(qx, qy, tab + (ad - 1) * PLUME_TAB_ENTRY_WORDS, (s & 1) != 0);
+    }
+    return d;
+}
 template <bool CHECKED>
 PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
+#if PLUME_MSM_PREFETCH
+    // software pipeline over the steps (window i descending, slot s ascending, unused wide slots skipped): the operand of the step after the current one is in flight
+    // while the current addition -- or the four doublings between two windows -- runs.  (Rounds 1-2 gathered, waited and added: every addition exposed an HBM / L2 round
+    // trip to its wavefront, hidden only as far as the SIMD's other wavefronts were not waiting themselves.)
+    fe nx = fe_small(0), ny = fe_small(0);
+    int ni = PLUME_NDIG - 1, ns = 0;
+    while (ns < nslots && !msm_slot_used(ni, ns, wide0)) ns++;                       // first step (window NDIG-1 always holds slot 0 .. for wide digits NDIG-1 is a multiple of GWS)
+    int nd = ns < nslots ? msm_fetch(nx, ny, tab0, tab1, dig, stride, ni, ns, wide0) : 0;
     PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
         if (i != PLUME_NDIG - 1) {
             PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl(acc);
         }
         PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
-            const uint32_t* tab = (s & 2) ? tab1 : tab0;
-            int d = dig[(uint32_t)(s * PLUME_NDIG + i) * stride];
-            if (wide0 && s < 2) {
-                if (i % PLUME_GWS) continue;              // wave-uniform: a wide digit sits at every (W/4)-th window only
-                int mag = d & 0xFF;
-                bool dn;
-                if (i + 1 < PLUME_NDIG) {
-                    const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
-#if PLUME_GW > 15
-                    mag |= (hi & 0xFF) << 8; dn = dig[(uint32_t)(s * PLUME_NDIG + i + 2) * stride] != 0;
-#else
-                    mag |= (hi & 0x7F) << 8; dn = (hi & 0x80) != 0;
-#endif
-                } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
-                d = dn ? -mag : mag;
-            }
-            if (d != 0 && tab != nullptr) {
-                int ad = d < 0 ? -d : d;
-                const uint32_t* e = tab + (ad - 1) * PLUME_TAB_ENTRY_WORDS;
-                fe qx, qy;
-                ld_tab_xy(qx, qy, e, (s & 1) != 0);
+            if (!msm_slot_used(i, s, wide0)) continue;                              // wave-uniform
+            fe qx = nx, qy = ny;
+            const int d = nd;
+            // successor step
+            ni = i; ns = s + 1;
+            while (ns < nslots && !msm_slot_used(ni, ns, wide0)) ns++;
+            if (ns >= nslots) { ni = i - 1; ns = 0; while (ni >= 0 && ns < nslots && !msm_slot_used(ni, ns, wide0)) ns++; }
+            nd = (ni >= 0 && ns < nslots) ? msm_fetch(nx, ny, tab0, tab1, dig, stride, ni, ns, wide0) : 0;
+            if (d != 0) {
                 if (d < 0) fe_neg_lazy(qy, qy);
                 jac_madd<CHECKED>(acc, qx, qy);
             }
         }
     }
+#else
+    PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
+        if (i != PLUME_NDIG - 1) {
+            PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl(acc);
+        }
+        PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
+            if (!msm_slot_used(i, s, wide0)) continue;              // wave-uniform: a wide digit sits at every (W/4)-th window only
+            fe qx, qy;
+            const int d = msm_fetch(qx, qy, tab0, tab1, dig, stride, i, s, wide0);
+            if (d != 0) {
+                if (d < 0) fe_neg_lazy(qy, qy);
+                jac_madd<CHECKED>(acc, qx, qy);
+            }
+        }
+    }
+#endif
 }
 // the same chain with the checked additions only (the redo kernel of the verifier: tasks whose unchecked chain met p == +-q)
 PLUME_HD void msm_run_checked(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
