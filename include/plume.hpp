@@ -9,7 +9,7 @@
 //       DST, AffinePoint, NonZeroScalar, SecretKey, PlumeSignature{message, pk, nullifier, c, s, v1specific}, PlumeSignatureV1Fields,
 //       PlumeSignature::verify / sign_v1 / sign_v2, PlumeSigner{secret_key, v1}::try_sign_with_rng / sign_with_rng, hash_to_curve, encode_pt
 //       + batch twins: verify_batch, sign_batch, sign_batch_with_nonces;  the steps either side: verify_batch_sec1 (33-byte SEC1 records), aggregate_check_v1,
-//         nullifier_first_occurrence, scalars_to_sec1_der / scalar_from_sec1_der
+//         nullifier_first_occurrence, scalars_to_sec1_der / scalar_from_sec1_der, circuit_h2c_inputs
 //   namespace plume_arkworks     rust-arkworks/src/lib.rs:60-291, rust-arkworks/src/tests.rs:28-78,119-124
 //       Affine, Fr, PlumeVersion, PlumeSignaturePublic / PlumeSignaturePrivate (zeroized on drop), sec1_affine, hash_to_curve, sign_with_r, sign,
 //       keygen, verify_non_zk
@@ -456,6 +456,28 @@ inline AffinePoint hash_to_secp(const Bytes& s, Engine& eng = Engine::shared()) 
     AffinePoint h;
     plume_hip::check(plume_hash_to_curve_batch(eng.ctx(), 1, pm.data(), pm.off.data(), nullptr, h.xy.data()), "plume_hash_to_curve_batch");
     return h;
+}
+
+// The circom verifier's hash_to_curve inputs for one signature (circuits/circom/verify_nullifier.circom:14-31), every value as the circuit's four 64-bit little-endian
+// registers (circuits/circom/utils.ts:11-17): q{0,1}_x_mapped / q{0,1}_y_mapped from plume_h2c_intermediates_batch (pinned to the reference's vectors) and
+// q{0,1}_gx1_sqrt / gx2_sqrt / y_pos from plume_h2c_hints_batch (UNPINNED definitions: include/plume_hip.h).
+struct CircuitH2cInputs {
+    using Reg = std::array<uint64_t, 4>;
+    Reg q0_gx1_sqrt, q0_gx2_sqrt, q0_y_pos, q0_x_mapped, q0_y_mapped, q1_gx1_sqrt, q1_gx2_sqrt, q1_y_pos, q1_x_mapped, q1_y_mapped;
+};
+inline CircuitH2cInputs circuit_h2c_inputs(const Bytes& m, const AffinePoint& pk, Engine& eng = Engine::shared()) {
+    plume_hip::PackedMessages pm;
+    pm.push(m.data(), m.size());
+    uint64_t hints[24], mapped[16];
+    plume_hip::check(plume_h2c_hints_batch(eng.ctx(), 1, pm.data(), pm.off.data(), pk.xy.data(), 1, reinterpret_cast<uint8_t*>(hints)), "plume_h2c_hints_batch");
+    plume_hip::check(plume_h2c_intermediates_batch(eng.ctx(), 1, pm.data(), pm.off.data(), pk.xy.data(), 1, nullptr, reinterpret_cast<uint8_t*>(mapped), nullptr, nullptr),
+                     "plume_h2c_intermediates_batch");
+    auto reg = [](const uint64_t* p) { return CircuitH2cInputs::Reg{p[0], p[1], p[2], p[3]}; };
+    CircuitH2cInputs o;
+    o.q0_gx1_sqrt = reg(hints); o.q0_gx2_sqrt = reg(hints + 4); o.q0_y_pos = reg(hints + 8);
+    o.q1_gx1_sqrt = reg(hints + 12); o.q1_gx2_sqrt = reg(hints + 16); o.q1_y_pos = reg(hints + 20);
+    o.q0_x_mapped = reg(mapped); o.q0_y_mapped = reg(mapped + 4); o.q1_x_mapped = reg(mapped + 8); o.q1_y_mapped = reg(mapped + 12);
+    return o;
 }
 
 }  // namespace plume_rustcrypto

@@ -100,6 +100,26 @@ static void run(plume_ctx* ctx, int pinned, const char* label) {
     uint8_t be[32]; uint64_t regs[4];
     unhex(be, C_V1);
     CHECK(plume_registers_from_be(1, be, regs) == PLUME_OK && regs[0] == 0xfe3b32edbce83254ull && regs[3] == 0xc6a7fc2c926ddbafull, "register packing");
+    {   /* round 3: NULL seed = the library draws it; the circuit's square-root hints (UNPINNED definitions: y_pos must be the mapped y of the pinned intermediates);
+           from_sec1_der with the embedded public key checked; the redo counter of an honest batch; the sub-batch knob */
+        uint8_t rec[PLUME_AGG_RESULT_BYTES], hints[192 * N], mapped[128 * N], der[109 * N], st[N], back[32 * N], okd[N];
+        uint64_t redone = 99;
+        CHECK(plume_aggregate_check(ctx, 2, 1, N, msgs, off, pk, nul, c, s, rp, hr, NULL, NULL, rec) == PLUME_OK && rec[0] == 1, "aggregate check with a library-drawn seed");   /* the arrays hold the V2 signatures of the last pass */
+        CHECK(plume_h2c_hints_batch(ctx, N, msgs, off, pk, 0, hints) == PLUME_OK && plume_h2c_intermediates_batch(ctx, N, msgs, off, pk, 0, NULL, mapped, NULL, NULL) == PLUME_OK, "h2c hints");
+        CHECK(!memcmp(hints + 64, mapped + 32, 32) && !memcmp(hints + 160, mapped + 96, 32) && (hints[31] & 1) == 0 && (hints[63] & 1) == 0, "y_pos = y_mapped, even roots");
+        CHECK(plume_scalars_to_sec1_der_batch(ctx, N, s, der, st) == PLUME_OK && st[0] == 0, "scalars_to_sec1_der");
+        CHECK(plume_sec1_der_to_scalars_checked(ctx, N, der, back, okd) == PLUME_OK && okd[0] == 1 && okd[1] == 1 && !memcmp(back, s, 32 * N), "from_sec1_der round trip");
+        der[109 + 108] ^= 1;                                                   /* item 1: a public key that is not scalar * G */
+        CHECK(plume_sec1_der_to_scalars_checked(ctx, N, der, back, okd) == PLUME_OK && okd[0] == 1 && okd[1] == 0 && okd[2] == 1, "from_sec1_der rejects a foreign public key");
+        CHECK(plume_sec1_der_to_scalars(N, der, back, okd) == PLUME_OK && okd[1] == 1, "the structure-only form does not look at the key (documented)");
+        if (plume_num_shards(ctx) == 1) {
+            CHECK(plume_set_sub_batches(ctx, 4) == PLUME_OK && plume_set_sub_batches(ctx, 1) == PLUME_OK && plume_set_sub_batches(ctx, 0) == PLUME_ERR_ARG, "plume_set_sub_batches");
+            CHECK(plume_verify_batch(ctx, 2, N, msgs, off, pk, nul, c, s, NULL, NULL, ok) == PLUME_OK && ok[0] == 1 && plume_last_redo_tasks(ctx, &redone) == PLUME_OK && redone == 0, "honest batches file no redo task");
+            CHECK(plume_shard_numa_node(ctx, 0) == -1, "a single-device context has no worker thread");
+        } else {
+            CHECK(plume_shard_numa_node(ctx, 0) >= -1 && plume_shard_numa_node(ctx, 0) == plume_shard_numa_node(ctx, 1), "both shards sit on one device: one NUMA node");
+        }
+    }
     if (pinned) plume_host_free(base); else free(base);
     printf("  %s: done\n", label);
 }

@@ -230,6 +230,11 @@ static void neighbouring_steps() {
     ASSERT(!scalar_from_sec1_der(foreign).has_value());
     auto flipped = der[0]; flipped[108] ^= 1;                                                        // ... or a point that is not even on the curve
     ASSERT(!scalar_from_sec1_der(flipped).has_value());
+    // the circuit's hash_to_curve inputs: y_pos is the mapped y (definition), the square-root hints are the even roots
+    const auto ci = circuit_h2c_inputs(sigs[0].message, sigs[0].pk);
+    ASSERT(ci.q0_y_pos == ci.q0_y_mapped && ci.q1_y_pos == ci.q1_y_mapped);
+    ASSERT((ci.q0_gx1_sqrt[0] & 1) == 0 && (ci.q0_gx2_sqrt[0] & 1) == 0 && (ci.q1_gx1_sqrt[0] & 1) == 0 && (ci.q1_gx2_sqrt[0] & 1) == 0);
+    ASSERT(ci.q0_x_mapped != ci.q1_x_mapped);
 }
 // invariants of the Rust types at the boundary of this API
 static void type_invariants() {
