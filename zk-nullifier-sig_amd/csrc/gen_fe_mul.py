@@ -49,26 +49,42 @@ HICARRY = True   # high-half hand-off by one multiply-add (carry = high word * 8
 A_CONS = "v"   # constraint of the a.v[i] operands: "s" in fe_mul_k (a is a wave-uniform constant held in SGPRs)
 
 
-def emit_chain(terms, indent="    ", acc="acc", carry=None):
+SHIFT_IN_ASM = False  # round 3 experiment (--shift-in-asm): the low columns' 64-bit shift rides at the end of the column's asm statement and writes a FRESH pair, so that the limb
+                      # mask need not follow the statement.  It halves the s_nop hipcc pads asm results with (mixed addition body 143 -> 71, doubling 54 -> 24; 110 VGPRs, bit-exact) and
+                      # changes NOTHING measurable: multi-scalar kernel 18.69 / 18.58 vs 18.67 ms on one (slow) box.  The nops are absorbed while other wavefronts issue (round 1 saw
+                      # the same with its interleaving); the instruction-diet item of VERDICT r2 that named them was chasing a cost the kernel does not pay.  Off: the shipped file is round 2's.
+
+
+def emit_chain(terms, indent="    ", acc="acc", carry=None, shift_out=None):
     """carry: name of a 32-bit variable holding the previous column's high word: the chain then STARTS a fresh accumulator with carry * 8 (the
-    hand-off multiply-add) instead of continuing in place."""
+    hand-off multiply-add) instead of continuing in place.
+    shift_out: name of a 64-bit variable that receives acc >> 29 from a v_lshrrev_b64 appended to the statement.  The column's own pair stays as it is, so the limb mask
+    (a plain v_and on its low half) no longer has to follow the statement directly -- hipcc pads every instruction that reads an asm statement's result right behind it
+    with an s_nop -- and becomes filler the scheduler can place between other statements."""
     regs = []
+    base = 3 if shift_out else 2
 
     def idx(name, cons):
         key = (name, cons)
         if key not in regs:
             regs.append(key)
-        return regs.index(key) + 2
+        return regs.index(key) + base
 
     lines = []
     if carry:
         lines.append(f"v_mad_u64_u32 %0, %1, %{idx(carry, 'v')}, 8, 0")
+    cy = "%2" if shift_out else "%1"
     for (x, y, ys) in terms:
         xc = A_CONS if x.startswith("a.v[") else "v"
-        lines.append(f"v_mad_u64_u32 %0, %1, %{idx(x, xc)}, %{idx(y, 's' if ys else 'v')}, %0")
+        lines.append(f"v_mad_u64_u32 %0, {cy}, %{idx(x, xc)}, %{idx(y, 's' if ys else 'v')}, %0")
+    if shift_out:
+        lines.append("v_lshrrev_b64 %1, 29, %0")
     body = "\\n\\t".join(lines)
     ins = ", ".join(f'"{c}"({n})' for (n, c) in regs)
     host = " ".join(f"{acc} += (uint64_t){x} * {y};" for (x, y, ys) in terms)
+    if shift_out:
+        assert not carry
+        return (f"{indent}PLUME_FE_CHAIN_SHIFT({acc}, {shift_out}, \"{body}\", {ins});\n", f"{indent}{host} {shift_out} = {acc} >> 29;\n")
     if carry:
         return (f"{indent}PLUME_FE_CHAIN_NEW({acc}, \"{body}\", {ins});\n", f"{indent}{acc} = (uint64_t){carry} * 8u; {host}\n")
     return (f"{indent}PLUME_FE_CHAIN({acc}, \"{body}\", {ins});\n", f"{indent}{host}\n")
@@ -115,10 +131,12 @@ def gen(name, sqr, two=False, scale3=False, expose_d=False, scale2=False):
         t.append((f"h[{k}]", "K0H" if (HICARRY and k == 8) else "K0", True))
         if k > 0:
             t.append((f"h[{k - 1}]", "K1", True))
-        out.append(emit_chain(t))
+        out.append(emit_chain(t, shift_out=(f"accn{k}" if (SHIFT_IN_ASM and k < 8) else None)))
         return out
 
     def mask_low(k):
+        if SHIFT_IN_ASM:
+            return f"    l[{k}] = (uint32_t)acc & PLUME_FE_MASK; acc = accn{k};\n"
         return f"    l[{k}] = (uint32_t)acc & PLUME_FE_MASK; acc >>= 29;\n"
 
     def put(pairs):
@@ -127,6 +145,8 @@ def gen(name, sqr, two=False, scale3=False, expose_d=False, scale2=False):
             host.append(h)
 
     both("    uint32_t h[9], l[9];     // l: result limbs (r may alias a or b)\n    uint64_t acc = 0, acch = 0;\n")
+    if SHIFT_IN_ASM:
+        both("    uint64_t accn0, accn1, accn2, accn3, accn4, accn5, accn6, accn7;\n")
     if sqr and scale3:
         # r = 3 a^2: the cross products take 6 a_j, the diagonal ones 3 a_i; the column sums are three times a squaring's (27 T^2 < 2^63 for tight a)
         both("    uint32_t d[9], t3[9];\n    PLUME_UNROLL for (int i = 0; i < 9; i++) { t3[i] = a.v[i] + u32_dbl(a.v[i]); d[i] = u32_dbl(t3[i]); }\n")
@@ -180,12 +200,17 @@ def main():
     global HICARRY
     if "--no-hicarry" in sys.argv:
         HICARRY = False
+    global SHIFT_IN_ASM
+    if "--shift-in-asm" in sys.argv:
+        SHIFT_IN_ASM = True
     print("""// GENERATED by gen_fe_mul.py -- do not edit (see that script for the design and the measurements behind it).
 // Included by plume_field.h inside namespace plume.
 // one chain of multiply-adds on `acc`; the carry-out pair of v_mad_u64_u32 is a dead SGPR pair the compiler picks
 #define PLUME_FE_CHAIN(ACC, TEXT, ...) do { uint64_t cy_; asm(TEXT : "+v"(ACC), "=&s"(cy_) : __VA_ARGS__); } while (0)
 // the same, but the chain's first instruction starts a fresh accumulator (previous column's high word * 8: a 29-bit limb step is 2^29 = 2^32 / 8)
 #define PLUME_FE_CHAIN_NEW(ACC, TEXT, ...) do { uint64_t cy_; asm(TEXT : "=&v"(ACC), "=&s"(cy_) : __VA_ARGS__); } while (0)
+// a low column: the chain, then NEXT = ACC >> 29 into a fresh pair (ACC keeps the column: its low half is masked into the limb whenever the scheduler likes)
+#define PLUME_FE_CHAIN_SHIFT(ACC, NEXT, TEXT, ...) do { uint64_t cy_; asm(TEXT : "+v"(ACC), "=&v"(NEXT), "=&s"(cy_) : __VA_ARGS__); } while (0)
 """)
     print(gen("fe_mul", False))
     print(gen("fe_sqr", True))
@@ -211,6 +236,7 @@ def main():
     print(gen("fe_mul_k", False))
     print("#undef PLUME_FE_CHAIN")
     print("#undef PLUME_FE_CHAIN_NEW")
+    print("#undef PLUME_FE_CHAIN_SHIFT")
 
 
 if __name__ == "__main__":
