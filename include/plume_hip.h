@@ -311,7 +311,8 @@ int plume_aggregate_check_device(plume_ctx* ctx, int version, int mode, size_t n
 int plume_last_stage_times(plume_ctx* ctx, const char** names, float* ms, int cap);
 /* Measurement / test hook: the number of multi-scalar tasks (two per item) of the last verify call on this context whose unchecked addition chain met p == +-q and that
  * the second, dense launch redid with checked additions (k_verify_msm_redo).  Honest batches: 0.  Crafted items (pk = +-k G for small k with s = +-c, ...) file one or two
- * tasks each: that is all they cost -- their wavefront neighbours no longer wait for them.  Synchronises with the device. */
+ * tasks each: that is all they cost -- their wavefront neighbours no longer wait for them.  Counts the last device-resident call (for a host-pointer call: its last piece;
+ * for a multi-device context: the first shard).  Synchronises with the device. */
 int plume_last_redo_tasks(plume_ctx* ctx, uint64_t* count);
 /* VALU issue-rate microbenchmark (32 waves per CU, 8 independent chains per lane, `iters` x 8 instructions per lane):
  * returns operations per second chip-wide (<= 0 on error).  kind: 0 v_mad_u64_u32, 1 v_addc_co_u32, 2 v_mul_lo_u32,
