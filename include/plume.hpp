@@ -391,7 +391,8 @@ inline std::array<uint8_t, 33> sec1_record(const AffinePoint& p) {
 }
 // Aggregate pre-filter (no reference counterpart; plume_hip.h plume_aggregate_check): true iff every V1 signature of the batch would verify() -- up to a false-accept
 // probability of 2^-126 over `seed`, 32 fresh random bytes the signers could not predict.  All-or-nothing: on false, verify_batch finds the culprits.
-inline bool aggregate_check_v1(const std::vector<PlumeSignature>& sigs, const Bytes32& seed, Engine& eng = Engine::shared()) {
+// `seed == nullptr`: the library draws the 32 bytes from the OS generator for this call -- what a caller without fresh randomness of its own should do.
+inline bool aggregate_check_v1(const std::vector<PlumeSignature>& sigs, const Bytes32* seed, Engine& eng = Engine::shared()) {
     plume_hip::PackedMessages m;
     Bytes pk, nul, c, s, rp, hr;
     for (const PlumeSignature& g : sigs) {
@@ -408,9 +409,11 @@ inline bool aggregate_check_v1(const std::vector<PlumeSignature>& sigs, const By
     static const uint8_t none[64] = {0};
     const bool e = sigs.empty();
     plume_hip::check(plume_aggregate_check(eng.ctx(), 1, 0, sigs.size(), m.data(), m.off.data(), e ? none : pk.data(), e ? none : nul.data(), e ? none : c.data(), e ? none : s.data(),
-                                           e ? none : rp.data(), e ? none : hr.data(), seed.data(), nullptr, rec), "plume_aggregate_check");
+                                           e ? none : rp.data(), e ? none : hr.data(), seed ? seed->data() : nullptr, nullptr, rec), "plume_aggregate_check");
     return rec[0] == 1;
 }
+inline bool aggregate_check_v1(const std::vector<PlumeSignature>& sigs, const Bytes32& seed, Engine& eng = Engine::shared()) { return aggregate_check_v1(sigs, &seed, eng); }
+inline bool aggregate_check_v1(const std::vector<PlumeSignature>& sigs, Engine& eng = Engine::shared()) { return aggregate_check_v1(sigs, static_cast<const Bytes32*>(nullptr), eng); }
 // The application step after verification (reference README.md:5: one nullifier per (pk, message)): first[i] is true iff item i is live and no live item with the
 // same nullifier comes before it.  `live` may be empty (all items take part), e.g. pass verify_batch's result.
 inline std::vector<bool> nullifier_first_occurrence(const std::vector<AffinePoint>& nullifiers, const std::vector<bool>& live = {}, Engine& eng = Engine::shared()) {

@@ -208,6 +208,7 @@ static void neighbouring_steps() {
     std::vector<PlumeSignature> forged = sigs;
     std::swap(forged[11].v1specific->hashed_to_curve_r, forged[12].v1specific->hashed_to_curve_r);   // (every nonce is R here, so the r_points are all equal)
     ASSERT(!aggregate_check_v1(forged, seed));
+    ASSERT(aggregate_check_v1(sigs) && !aggregate_check_v1(forged));                               // the library draws the seed
     ASSERT(verify_batch(forged) == [&] { std::vector<bool> w(forged.size(), true); w[11] = w[12] = false; return w; }());
     // first occurrences: item i repeats the (key, message) pair of item i - 21 (7 x 3 pairs, period lcm(7, 3) = 21)
     std::vector<AffinePoint> nuls;
