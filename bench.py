@@ -407,12 +407,16 @@ def main():
     import zk_nullifier_sig_amd as plume
     from tests import synth
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible (this library has no CPU fallback)")
+    local_dev = local_rank % ndev          # a launcher that narrows every rank's view to its own GPU leaves each rank with device 0
+    torch.cuda.set_device(local_dev)
+    dev = torch.device(f"cuda:{local_dev}")
     use_dist = world > 1 or os.environ.get("PLUME_BENCH_FORCE_DIST") == "1"   # the knob runs the RCCL code path at world size 1 (tests/test_gpu_round2.py)
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
-    eng = plume.Engine(local_rank)
+    eng = plume.Engine(local_dev)
     ver, sign = a.version, a.workload == "sign"
     total, start, stop = plan(a.scaling, a.log2_batch, world, rank)             # items per step over all ranks, this rank's slice
     n = stop - start                                                           # this rank's items per step
