@@ -23,7 +23,8 @@ extern "C" {
 unsigned long ds_fallback_count(void) { return fallback_counter(); }
 
 // op: 0 mul, 1 sqr, 2 add, 3 sub, 4 neg, 5 inv, 6 pow_c1, 7 normalize, 8 mul_small(b[0]), 9 is_zero->out[0], 10 eq->out[0], 11 is_odd->out[0],
-//     12 (a+b)*(a+2p-b) on unreduced operands, 13 (a+4p-2b)^2 through fe_carry, 14 words round trip, 15 inversion by divsteps
+//     12 (a+b)*(a+2p-b) on unreduced operands, 13 (a+4p-2b)^2 through fe_carry, 14 words round trip, 15 inversion by divsteps,
+//     16..20 the fused multiply-subtract forms of the group law (round 3): xy - x, x^2 - (2y + x), x^2 - 2y, x(y - x) - 2y^2, (x - y)(x + y) - y
 // operands/outputs: 256-bit integers as 8 little-endian 32-bit words (outputs canonical); count elements
 void ds_fe_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     for (size_t i = 0; i < count; i++) {
@@ -48,6 +49,11 @@ void ds_fe_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32
             case 13: { fe t; fe_add_lazy(t, y, y); fe_sub_lazy<4>(t, x, t); fe_carry(t); fe_sqr(r, t); break; }  // (a-2b)^2
             case 14: r = x; break;
             case 15: fe_inv_gcd(r, x); break;
+            case 16: fe_mul_sub<2>(r, x, y, x); break;                                                               // xy - x
+            case 17: { fe hh; fe_dbl_lazy(hh, y); fe_add_lazy(hh, hh, x); fe_sqr_sub<4>(r, x, hh); break; }           // x^2 - (2y + x): the mixed addition's X3
+            case 18: fe_sqr_sub2<2>(r, x, y); break;                                                                 // x^2 - 2y: the doubling's X'
+            case 19: { fe t, nb, db; fe_sub_lazy<2>(t, y, x); fe_neg_lazy(nb, y); fe_dbl_lazy(db, y); fe_muladd(r, x, t, nb, db); break; }   // x(y - x) - 2y^2: the doubling's Y' at its operand bounds
+            case 20: { fe d, sm; fe_add_lazy(sm, x, y); fe_sub_lazy<2>(d, x, y); fe_mul_sub<2>(r, d, sm, y); break; }  // (x - y)(x + y) - y, unreduced factors
         }
         if (op >= 9 && op <= 11) { for (int k = 0; k < 8; k++) out[8 * i + k] = k == 0 ? (uint32_t)flag : 0u; continue; }
         fe_normalize(r);

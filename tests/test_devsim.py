@@ -52,6 +52,12 @@ def test_fe_arith():
     assert [g for g in D.fe_op(9, a)] == [int(x % P == 0) for x in a]
     assert [g for g in D.fe_op(10, a, b)] == [int((x - y) % P == 0) for x, y in zip(a, b)]
     assert [g for g in D.fe_op(11, a)] == [(x % P) & 1 for x in a]
+    # round 3: products with a subtraction riding in their fold (plume_fe_mul.inc fe_mul_sub / fe_sqr_sub / fe_sqr_sub2) and the doubling's two-product Y'
+    for op, fn in [(16, lambda x, y: x * y - x), (17, lambda x, y: x * x - 2 * y - x), (18, lambda x, y: x * x - 2 * y), (19, lambda x, y: x * (y - x) - 2 * y * y),
+                   (20, lambda x, y: (x - y) * (x + y) - y)]:
+        got = D.fe_op(op, a, b)
+        for x, y, g in zip(a, b, got):
+            assert g == fn(x, y) % P, (op, hex(x), hex(y), hex(g))
 
 
 def test_fe_inv_pow():

@@ -45,6 +45,7 @@ def col_terms(k, sqr, pair=("a", "b")):
     return t
 
 
+ZERO_START = True   # the two chains that open a multiplication (column 9, column 0) start from the literal 0 instead of a zeroed register pair; --no-zero-start for the A/B build
 HICARRY = True   # high-half hand-off by one multiply-add (carry = high word * 8) instead of mask + 64-bit shift; --no-hicarry for the A/B build
 A_CONS = "v"   # constraint of the a.v[i] operands: "s" in fe_mul_k (a is a wave-uniform constant held in SGPRs)
 
@@ -55,8 +56,10 @@ SHIFT_IN_ASM = False  # round 3 experiment (--shift-in-asm): the low columns' 64
                       # the same with its interleaving); the instruction-diet item of VERDICT r2 that named them was chasing a cost the kernel does not pay.  Off: the shipped file is round 2's.
 
 
-def emit_chain(terms, indent="    ", acc="acc", carry=None, shift_out=None):
-    """carry: name of a 32-bit variable holding the previous column's high word: the chain then STARTS a fresh accumulator with carry * 8 (the
+def emit_chain(terms, indent="    ", acc="acc", carry=None, shift_out=None, zero=False):
+    """zero: the accumulator starts at 0: the first multiply-add takes the literal 0 as its addend and writes a fresh pair (round 3: no `v_mov_b64 acc, 0` in front
+    of the multiplication's two opening chains -- 2 of its 131 instructions).
+    carry: name of a 32-bit variable holding the previous column's high word: the chain then STARTS a fresh accumulator with carry * 8 (the
     hand-off multiply-add) instead of continuing in place.
     shift_out: name of a 64-bit variable that receives acc >> 29 from a v_lshrrev_b64 appended to the statement.  The column's own pair stays as it is, so the limb mask
     (a plain v_and on its low half) no longer has to follow the statement directly -- hipcc pads every instruction that reads an asm statement's result right behind it
@@ -74,24 +77,32 @@ def emit_chain(terms, indent="    ", acc="acc", carry=None, shift_out=None):
     if carry:
         lines.append(f"v_mad_u64_u32 %0, %1, %{idx(carry, 'v')}, 8, 0")
     cy = "%2" if shift_out else "%1"
-    for (x, y, ys) in terms:
+    for n, (x, y, ys) in enumerate(terms):
         xc = A_CONS if x.startswith("a.v[") else "v"
-        lines.append(f"v_mad_u64_u32 %0, {cy}, %{idx(x, xc)}, %{idx(y, 's' if ys else 'v')}, %0")
+        xop = f"%{idx(x, xc)}"
+        yop = y if ys == "lit" else f"%{idx(y, 's' if ys else 'v')}"
+        lines.append(f"v_mad_u64_u32 %0, {cy}, {xop}, {yop}, " + ("0" if (zero and n == 0) else "%0"))
     if shift_out:
         lines.append("v_lshrrev_b64 %1, 29, %0")
     body = "\\n\\t".join(lines)
     ins = ", ".join(f'"{c}"({n})' for (n, c) in regs)
-    host = " ".join(f"{acc} += (uint64_t){x} * {y};" for (x, y, ys) in terms)
+    host = " ".join(f"{acc} += (uint64_t){x} * {y}{'u' if ys == 'lit' else ''};" for (x, y, ys) in terms)
     if shift_out:
         assert not carry
         return (f"{indent}PLUME_FE_CHAIN_SHIFT({acc}, {shift_out}, \"{body}\", {ins});\n", f"{indent}{host} {shift_out} = {acc} >> 29;\n")
     if carry:
         return (f"{indent}PLUME_FE_CHAIN_NEW({acc}, \"{body}\", {ins});\n", f"{indent}{acc} = (uint64_t){carry} * 8u; {host}\n")
+    if zero:
+        assert not shift_out
+        return (f"{indent}PLUME_FE_CHAIN_NEW({acc}, \"{body}\", {ins});\n", f"{indent}{acc} = 0; {host}\n")
     return (f"{indent}PLUME_FE_CHAIN({acc}, \"{body}\", {ins});\n", f"{indent}{host}\n")
 
 
-def gen(name, sqr, two=False, scale3=False, expose_d=False, scale2=False):
-    """two: r = a*b + c*d with ONE fold -- the two products share their column sums (each column: two chain statements).
+def gen(name, sqr, two=False, scale3=False, expose_d=False, scale2=False, sub=None):
+    """sub (1 or 2): r = a*b + sub * (M*p - s) for a template parameter M: the group law's "product minus something, then a carry pass" in ONE fold -- the unreduced
+    difference w[k] = M*p[k] - s[k] (one v_sub per limb) joins low column k as the multiply-add w[k] * sub, so the subtraction costs 18 instructions instead of the 47
+    of fe_sub_lazy + fe_carry, and the result is as tight as any product.
+    two: r = a*b + c*d with ONE fold -- the two products share their column sums (each column: two chain statements).
 
     Statement order: the high-half chain (columns 9..16, accumulator acch) and the low-half chain (columns 0..8, accumulator acc)
     are INTERLEAVED, the low half lagging by two columns (column k needs h[k] and h[k-1]): every asm statement is followed by an
@@ -104,7 +115,7 @@ def gen(name, sqr, two=False, scale3=False, expose_d=False, scale2=False):
         host.append(s)
 
     def stmts_high(k):
-        out = [emit_chain([(x, y, False) for (x, y) in col_terms(k, sqr)], acc="acch", carry=(f"hw{k - 1}" if (HICARRY and k > 9) else None))]
+        out = [emit_chain([(x, y, False) for (x, y) in col_terms(k, sqr)], acc="acch", carry=(f"hw{k - 1}" if (HICARRY and k > 9) else None), zero=(ZERO_START and k == 9))]
         if two:
             out.append(emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))], acc="acch"))
         return out
@@ -125,13 +136,17 @@ def gen(name, sqr, two=False, scale3=False, expose_d=False, scale2=False):
 
     def stmts_low(k):
         out = []
+        z = ZERO_START and k == 0 and not SHIFT_IN_ASM
         if two:
-            out.append(emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))]))
+            out.append(emit_chain([(x, y, False) for (x, y) in col_terms(k, False, ("c", "e"))], zero=z))
+            z = False
         t = [(x, y, False) for (x, y) in col_terms(k, sqr)]
         t.append((f"h[{k}]", "K0H" if (HICARRY and k == 8) else "K0", True))
         if k > 0:
             t.append((f"h[{k - 1}]", "K1", True))
-        out.append(emit_chain(t, shift_out=(f"accn{k}" if (SHIFT_IN_ASM and k < 8) else None)))
+        if sub:
+            t.append((f"w[{k}]", str(sub), "lit"))
+        out.append(emit_chain(t, shift_out=(f"accn{k}" if (SHIFT_IN_ASM and k < 8) else None), zero=z))
         return out
 
     def mask_low(k):
@@ -147,6 +162,8 @@ def gen(name, sqr, two=False, scale3=False, expose_d=False, scale2=False):
     both("    uint32_t h[9], l[9];     // l: result limbs (r may alias a or b)\n    uint64_t acc = 0, acch = 0;\n")
     if SHIFT_IN_ASM:
         both("    uint64_t accn0, accn1, accn2, accn3, accn4, accn5, accn6, accn7;\n")
+    if sub:
+        both("    uint32_t w[9];\n    PLUME_UNROLL for (int i = 0; i < 9; i++) { PLUME_FE_ASSERT(s.v[i] <= (uint32_t)M * fe_p(i)); w[i] = (uint32_t)M * fe_p(i) - s.v[i]; }\n")
     if sqr and scale3:
         # r = 3 a^2: the cross products take 6 a_j, the diagonal ones 3 a_i; the column sums are three times a squaring's (27 T^2 < 2^63 for tight a)
         both("    uint32_t d[9], t3[9];\n    PLUME_UNROLL for (int i = 0; i < 9; i++) { t3[i] = a.v[i] + u32_dbl(a.v[i]); d[i] = u32_dbl(t3[i]); }\n")
@@ -189,6 +206,9 @@ def gen(name, sqr, two=False, scale3=False, expose_d=False, scale2=False):
     if two:
         sig = f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b, const fe& c, const fe& e)"
         check = "    PLUME_FE_ASSERT(fe_muladd_inputs_ok(a, b, c, e));\n"
+    if sub:
+        sig = "template <int M>\n" + (f"PLUME_HD void {name}(fe& r, const fe& a, const fe& s)" if sqr else f"PLUME_HD void {name}(fe& r, const fe& a, const fe& b, const fe& s)")
+        check += "    static_assert(M >= 1 && M <= 7, \"M*p limbs must fit 32 bits\");\n"
     consts = "    const uint32_t K0 = 31264u, K1 = 256u, K2 = 31264u << 8, K3 = 65536u, K4 = 977u, K5 = 8u;\n"
     if HICARRY:
         consts = "    const uint32_t K0 = 31264u, K1 = 256u, K0H = 31264u << 3, K2H = 31264u << 11, K3H = 65536u << 3, K4 = 977u, K5 = 8u;\n"
@@ -200,6 +220,9 @@ def main():
     global HICARRY
     if "--no-hicarry" in sys.argv:
         HICARRY = False
+    global ZERO_START
+    if "--no-zero-start" in sys.argv:
+        ZERO_START = False
     global SHIFT_IN_ASM
     if "--shift-in-asm" in sys.argv:
         SHIFT_IN_ASM = True
@@ -231,6 +254,13 @@ def main():
     A_CONS = "v"
     print("// r = a*b + c*e with one fold: the 17 column sums of both products accumulate in the same chains (bound: fe_muladd_inputs_ok)")
     print(gen("fe_muladd", False, True))
+    print("// r = a*b - s = a*b + (M*p - s): the difference is formed limbwise (needs s[i] <= M*p[i]: M = 2 for a tight s) and joins the low columns, so the result is as tight as a")
+    print("// product's and the subtraction needs no carry pass of its own (group law: H = U2 - X1, r = S2 - Y1)")
+    print(gen("fe_mul_sub", False, sub=1))
+    print("// r = a^2 - s (group law: X3 = r^2 - (2V + H^3), M = 4)")
+    print(gen("fe_sqr_sub", True, sub=1))
+    print("// r = a^2 - 2s (doubling: X' = E^2 - 2 * 4XY^2, M = 2 for a tight s)")
+    print(gen("fe_sqr_sub2", True, sub=2))
     A_CONS = "s"
     print("// a is a compile-time constant (curve / isogeny coefficients): its limbs stay in SGPRs instead of occupying 9 VGPRs each")
     print(gen("fe_mul_k", False))

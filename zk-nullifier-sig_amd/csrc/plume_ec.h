@@ -47,22 +47,24 @@ PLUME_HD bool affine_on_curve(const fe& x, const fe& y) {
 // (fe_add_lazy / fe_sub_lazy<M>) and spend a carry pass only where a bound would otherwise be exceeded; host builds with
 // PLUME_FE_CHECK assert every bound.
 //
-// 2P, a = 0:  A = X^2, B = Y^2, X' = (3A)^2 - 8XB, Y' = 3A(4XB - X') - 8B^2, Z' = 2YZ   (3M + 4S, 2 carry passes; the factors 3, 2, 2 of 3A, 2B, 8B^2 ride in the squarings)
+// unreduced negation of a tight value, limbs <= 2p (also a legal qy of jac_madd)
+PLUME_HD void fe_neg_lazy(fe& r, const fe& a) { fe z = fe_zero(); fe_sub_lazy<2>(r, z, a); }
+// 2P, a = 0:  E = 3X^2, B = 2Y^2, D = 4XY^2 = X * 2B, X' = E^2 - 2D, Y' = E (D - X') - 8Y^4 = E (D - X') + (-B) * 2B, Z' = 2YZ.
+// Round 3: 3S + 2M + one two-product multiplication with a shared fold, NO carry pass and no separate 8Y^4: the subtraction of X' rides in the squaring's low
+// columns (fe_sqr_sub2), 8Y^4 = B * 2B joins Y' as the second product of fe_muladd (81 multiply-adds more, a squaring + a subtraction + a carry pass less), and
+// 4XY^2 comes out of its multiplication already doubled (the operand 2B): 1009 -> ~880 instructions per doubling.  (Rounds 1-2: 3M + 4S, 2 carry passes.)
 // valid for every non-infinity point (the curve has no 2-torsion); the inf flag just rides along.
 PLUME_HD void jac_dbl(jac& p) {
-    fe B2, C4, XB2, E, F, D2, D4, t, dY;
+    fe B, dB, nB, E, D, t, dY;
     fe_sqr3(E, p.x);                                       // 3X^2, tight: the factor rides in the squaring's operands (no tripling, no carry pass)
-    fe_sqr2_d(B2, dY, p.y);                                // 2Y^2 straight out of the squaring (cross products d_i d_j, diagonal a_i d_i);  dY = 2Y
-    fe_sqr2(C4, B2);                                       // 8Y^4 = 2 (2Y^2)^2 likewise
-    fe_mul(XB2, p.x, B2);                                  // 2XY^2
+    fe_sqr2_d(B, dY, p.y);                                 // 2Y^2 straight out of the squaring (cross products d_i d_j, diagonal a_i d_i);  dY = 2Y
     fe_mul(p.z, dY, p.z);                                  // Z' = 2YZ
-    fe_sqr(F, E);
-    fe_dbl_lazy(D2, XB2);                                  // 4XY^2
-    fe_dbl_lazy(D4, D2);                                   // 8XY^2
-    fe_sub_lazy<5>(p.x, F, D4); fe_carry(p.x);             // X' = 9X^4 - 8XY^2
-    fe_sub_lazy<2>(t, D2, p.x);                            // 4XY^2 - X'
-    fe_mul(t, E, t);
-    fe_sub_lazy<3>(p.y, t, C4); fe_carry(p.y);
+    fe_dbl_lazy(dB, B);                                    // 4Y^2, limbs <= 2^30 + 2^20
+    fe_mul(D, p.x, dB);                                    // 4XY^2, tight
+    fe_sqr_sub2<2>(p.x, E, D);                             // X' = 9X^4 - 8XY^2, tight
+    fe_sub_lazy<2>(t, D, p.x);                             // 4XY^2 - X', limbs <= 3 * 2^29 + 2^19
+    fe_neg_lazy(nB, B);                                    // -2Y^2, unreduced (limbs <= 2p)
+    fe_muladd(p.y, E, t, nB, dB);                          // Y' = E (D - X') - 8Y^4; bound: 9 (2^29 * 3 * 2^29 + 2^30 * 2^30) (1 + 2^-9) < 2^64 - 2^57
 }
 // cold path of the additions (P == Q).  Takes and returns BY VALUE through a local copy at the call site: passing the
 // accumulator by reference would make its address escape and pin it in scratch memory for the whole hot loop
@@ -70,26 +72,23 @@ PLUME_HD void jac_dbl(jac& p) {
 PLUME_HD_NOINLINE void jac_dbl_cold_impl(jac* p) { jac_dbl(*p); }
 PLUME_HD void jac_dbl_cold(jac& p) { jac tmp = p; jac_dbl_cold_impl(&tmp); p = tmp; }
 
-// p += (qx, qy) affine, q != infinity; qx tight, qy tight or an unreduced negation (limbs <= 2p).  8M + 3S, 4 carry passes.
+// p += (qx, qy) affine, q != infinity; qx tight, qy tight or an unreduced negation (limbs <= 2p).  8M + 3S, no carry pass (round 3: the three subtractions ride in their products' folds).
 // CHECKED = true handles every exceptional case (p infinite, p == q, p == -q).
-// (fe_neg_lazy: unreduced negation of a tight value, limbs <= 2p -- also a legal qy)
 // CHECKED = false is the hot-loop form: it handles p infinite but does NOT test for p == +-q.  In that case H = 0 (mod p)
 // and Z' = Z*H = 0 (mod p), and every later doubling / addition keeps Z = 0 (mod p) (Z only ever gets multiplied), so
 // the caller detects the event ONCE at the end (fe_is_zero(Z)) and recomputes that lane with CHECKED = true.  No other
 // path reaches Z = 0: a legitimate identity is carried in the inf flag, and the curve has no point with Y = 0.
-PLUME_HD void fe_neg_lazy(fe& r, const fe& a) { fe z = fe_zero(); fe_sub_lazy<2>(r, z, a); }
 template <bool CHECKED = true>
 PLUME_HD void jac_madd(jac& p, const fe& qx, const fe& qy) {
     if (p.inf) {
         p.x = qx; p.y = qy; fe_carry(p.y); p.z = fe_small(1); p.inf = 0;
         return;
     }
-    fe z1z1, u2, s2, h, r, hh, hhh, v, t;
+    fe z1z1, s2, h, r, hh, hhh, v, t;
     fe_sqr(z1z1, p.z);
-    fe_mul(u2, qx, z1z1);
-    fe_mul(s2, p.z, z1z1); fe_mul(s2, s2, qy);
-    fe_sub_lazy<2>(h, u2, p.x); fe_carry(h);
-    fe_sub_lazy<2>(r, s2, p.y); fe_carry(r);
+    fe_mul_sub<2>(h, qx, z1z1, p.x);                       // H = U2 - X1: the subtraction rides in the product's low columns (round 3; rounds 1-2: fe_sub_lazy + fe_carry, 47 instructions instead of 18)
+    fe_mul(s2, p.z, z1z1);
+    fe_mul_sub<2>(r, s2, qy, p.y);                         // r = S2 - Y1
     if (CHECKED) {
         if (fe_is_zero(h)) {
             if (fe_is_zero(r)) { jac_dbl_cold(p); } else { p.inf = 1; }
@@ -98,9 +97,8 @@ PLUME_HD void jac_madd(jac& p, const fe& qx, const fe& qy) {
     }
     fe_sqr(hh, h); fe_mul(hhh, hh, h); fe_mul(v, p.x, hh);
     fe_mul(p.z, p.z, h);
-    fe_sqr(t, r);
-    fe_dbl_lazy(hh, v); fe_add_lazy(hh, hh, hhh);       // 2V + H^3
-    fe_sub_lazy<4>(p.x, t, hh); fe_carry(p.x);             // X' = r^2 - H^3 - 2V
+    fe_dbl_lazy(hh, v); fe_add_lazy(hh, hh, hhh);          // 2V + H^3, limbs <= 3 * (2^29 + 2^19) <= 4p
+    fe_sqr_sub<4>(p.x, r, hh);                             // X' = r^2 - H^3 - 2V
     fe_sub_lazy<2>(t, v, p.x);                             // V - X'
     fe_neg_lazy(v, p.y);                                   // -Y1, unreduced
     fe_muladd(p.y, r, t, v, hhh);                          // Y' = r(V - X') - Y1*H^3: both products share one fold
@@ -110,20 +108,21 @@ PLUME_HD void jac_madd(jac& p, const fe& qx, const fe& qy) {
 PLUME_HD void jac_add(jac& p, const jac& q) {
     if (q.inf) return;
     if (p.inf) { p = q; return; }
-    fe z1z1, z2z2, u1, u2, s1, s2, h, r, hh, hhh, v, t;
+    fe z1z1, z2z2, u1, s1, s2, h, r, hh, hhh, v, t;
     fe_sqr(z1z1, p.z); fe_sqr(z2z2, q.z);
-    fe_mul(u1, p.x, z2z2); fe_mul(u2, q.x, z1z1);
+    fe_mul(u1, p.x, z2z2);
     fe_mul(s1, q.z, z2z2); fe_mul(s1, s1, p.y);
-    fe_mul(s2, p.z, z1z1); fe_mul(s2, s2, q.y);
-    fe_sub(h, u2, u1);
-    fe_sub(r, s2, s1);
+    fe_mul_sub<2>(h, q.x, z1z1, u1);                       // H = U2 - U1 (the subtraction rides in the product's fold)
+    fe_mul(s2, p.z, z1z1);
+    fe_mul_sub<2>(r, s2, q.y, s1);                         // r = S2 - S1
     if (fe_is_zero(h)) {
         if (fe_is_zero(r)) { jac_dbl_cold(p); } else { p.inf = 1; }
         return;
     }
     fe_sqr(hh, h); fe_mul(hhh, hh, h); fe_mul(v, u1, hh);
     fe_mul(p.z, p.z, q.z); fe_mul(p.z, p.z, h);
-    fe_sqr(t, r); fe_sub(t, t, hhh); fe_sub(t, t, v); fe_sub(p.x, t, v);
+    fe_dbl_lazy(hh, v); fe_add_lazy(hh, hh, hhh);          // 2V + H^3
+    fe_sqr_sub<4>(p.x, r, hh);                             // X' = r^2 - H^3 - 2V
     fe_sub_lazy<2>(t, v, p.x);
     fe_neg_lazy(v, s1);
     fe_muladd(p.y, r, t, v, hhh);                          // r(V - X') - S1*H^3 with one fold
@@ -452,27 +451,22 @@ PLUME_HD void pre_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, s
 #endif
 // 2P from affine P = (x, y) (tight) and l = 1 / (2y)
 PLUME_HD void aff_dbl(fe& x3, fe& y3, const fe& x, const fe& y, const fe& l) {
-    fe lam, t, t2;
+    fe lam, t;
     fe_sqr3(t, x);                                              // 3x^2
     fe_mul(lam, t, l);
-    fe_sqr(t, lam);
-    fe_dbl_lazy(t2, x);
-    fe_sub_lazy<3>(x3, t, t2); fe_carry(x3);                    // lambda^2 - 2x
+    fe_sqr_sub2<2>(x3, lam, x);                                 // lambda^2 - 2x   (round 3: the subtractions ride in the products' folds, no carry passes)
     fe_sub_lazy<2>(t, x, x3);
-    fe_mul(t, lam, t);
-    fe_sub_lazy<2>(y3, t, y); fe_carry(y3);                     // lambda (x - x3) - y
+    fe_mul_sub<2>(y3, lam, t, y);                               // lambda (x - x3) - y
 }
 // P1 + P2 from affine points (tight) and dinv = 1 / (x2 - x1)
 PLUME_HD void aff_add(fe& x3, fe& y3, const fe& x1, const fe& y1, const fe& x2, const fe& y2, const fe& dinv) {
     fe lam, t, s;
     fe_sub_lazy<2>(t, y2, y1);
     fe_mul(lam, t, dinv);
-    fe_sqr(t, lam);
     fe_add_lazy(s, x1, x2);
-    fe_sub_lazy<3>(x3, t, s); fe_carry(x3);                     // lambda^2 - x1 - x2
+    fe_sqr_sub<3>(x3, lam, s);                                  // lambda^2 - x1 - x2
     fe_sub_lazy<2>(t, x1, x3);
-    fe_mul(t, lam, t);
-    fe_sub_lazy<2>(y3, t, y1); fe_carry(y3);                    // lambda (x1 - x3) - y1
+    fe_mul_sub<2>(y3, lam, t, y1);                              // lambda (x1 - x3) - y1
 }
 struct DirectRowSinkSync {                                       // host / single-lane builds: rows are stored by the lane that reads them back
     PLUME_HD void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const { st_tab_entry(e, x, y, bx); }
