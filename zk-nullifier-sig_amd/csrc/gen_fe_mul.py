@@ -18,7 +18,13 @@ stands, the high register (weight 2^32 = 8 * 2^29 relative to the column) opens 
 pair so that nothing is copied; 32-bit h[] are harmless because the fold multiplies them by 31264 and 256 only.  fe_sqr3 (3a^2) and fe_sqr_d (a^2 and 2a) ride factors
 in the squaring's operands for the group law's doubling.
 
-109 multiply-adds + 9 v_lshrrev_b64 + 12 v_and_b32 per multiplication (squaring: 73 multiply-adds; round 1: 103 + 16 + 20, squaring 67).  Each chain is ONE asm
+Round 3: (1) the chains that open a multiplication start from the literal 0 (no zeroed register pair); (2) fe_mul_sub / fe_sqr_sub / fe_sqr_sub2 take the group law's
+"product minus something" into the product's own fold: the unreduced difference M*p - s joins the low columns as one more multiply-add per limb, so the subtraction needs no
+carry pass of its own (18 instructions instead of 47) and the result is as tight as any product.  What an instruction costs in the kernels is the SUM of the single-kind
+issue costs (multiply-add 1.83 ns, other VOP3 1.77, plain VOP1/VOP2 1.05, s_nop 0 per wave-instruction per SIMD -- DESIGN.md section 6), so trading 29 plain / VOP3
+instructions for 9 multiply-adds pays.
+
+110 multiply-adds (81 products + 18 fold + 7 hand-offs + 4 tail) + 9 v_lshrrev_b64 + 12 v_and_b32 per multiplication (squaring: 74 multiply-adds; round 1: 103 + 16 + 20, squaring 67).  Each chain is ONE asm
 statement with compiler-allocated registers: hipcc keeps scheduling and register allocation but can neither re-associate the
 chain (that costs a 64-bit add per column) nor strength-reduce the fold constants into shift/add pairs, and it inserts no
 hazard nops inside a statement.  Host builds (tests/devsim) compile the same column algorithm as plain C++.
