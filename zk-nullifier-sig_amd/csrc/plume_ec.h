@@ -210,11 +210,14 @@ PLUME_HD int booth_digit(const uint32_t m[4], int i) {
 #if PLUME_WBITS == 5
 #define PLUME_GW 15   // the widest multiple of 5 whose magnitudes (<= 2^14) still fit the two-byte digit form: 16384 entries (2 MiB), 9 digits per half
 #else
-#define PLUME_GW 16   // round 2: 32768 entries (4 MiB), 9 digits per half: 18 generator additions per verify (W = 12: 2048 entries, 22 additions; measured -1.1 % on the kernel)
+#define PLUME_GW 24   // round 3: 2^23 entries (1 GiB of the 288), 6 digits per half: 12 generator additions per verify -- multi-scalar kernel -1.1 %, a verify -1.3 % against W = 16 (32768 entries, 4 MiB, 18
+                      // additions; W = 20: 64 MiB, 14 additions, -0.4 %; W = 12: 2048 entries, 22 additions).  The rows of a 1 GiB table come from HBM, not from L2 / MALL; the kernel's other wavefronts cover it.
+                      // Host builds of these headers (tests/devsim) take -DPLUME_GW=16: a CPU cannot build 8 M rows per test run
 #endif
 #endif
 static_assert(PLUME_GW % PLUME_WBITS == 0, "a wide digit must line up with the windows of the shared doubling chain");
-static_assert(PLUME_GW <= 16, "the digit rows hold a wide digit as a 16-bit magnitude (two bytes) plus its sign");
+static_assert(PLUME_GW <= 24, "the digit rows hold a wide digit as a magnitude of up to three bytes plus its sign");
+#define PLUME_GW_BYTES (PLUME_GW > 16 ? 3 : 2)          // magnitude bytes of a wide digit in its full form (W <= 15: the sign shares the second byte)
 #define PLUME_GWS (PLUME_GW / PLUME_WBITS)                // windows per wide digit
 #define PLUME_NDIGW ((128 + PLUME_GW) / PLUME_GW)         // digits covering 129 bits: 11 for W = 12, 17 for W = 8
 #define PLUME_GTAB_ENTRIES (1 << (PLUME_GW - 1))
@@ -241,18 +244,26 @@ PLUME_HD void booth_store_wide(int8_t* dig, uint32_t stride, const glv_half& h, 
         bool dn = (d < 0) != neg;
         int mag = d < 0 ? -d : d;
         const int pos = PLUME_GWS * k;
+        const int8_t sgn = (int8_t)((mag != 0 && dn) ? 1 : 0);
+#if PLUME_GW > 15   // full form: PLUME_GW_BYTES magnitude bytes, then a sign byte (W / 4 >= 4 positions per digit are there)
+        static_assert(PLUME_GW <= 15 || PLUME_GWS >= PLUME_GW_BYTES + 1, "a wide digit's bytes fit its positions");
+        if (pos + PLUME_GW_BYTES < PLUME_NDIG) {
+            PLUME_UNROLL for (int b = 0; b < PLUME_GW_BYTES; b++) dig[(uint32_t)(pos + b) * stride] = (int8_t)(uint8_t)((mag >> (8 * b)) & 0xFF);
+            dig[(uint32_t)(pos + PLUME_GW_BYTES) * stride] = sgn;
+        } else if (pos + 1 < PLUME_NDIG) {          // the top digit of a 129-bit half when the row ends early (W = 20, 24: bits 120.., at most 2^9): two bytes, sign in bit 7 of the second
+            dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)(mag & 0xFF);
+            dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)(((mag >> 8) & 0x7F) | (sgn ? 0x80 : 0));
+        } else {                                    // W = 16: the top digit (0 or 1) sits on the row's last position
+            dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)((mag & 0x3F) | (sgn ? 0x40 : 0));
+        }
+#else
         if (pos + 1 < PLUME_NDIG) {
             dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)(mag & 0xFF);
-#if PLUME_GW > 15   // magnitudes up to 2^15 need the whole second byte: the sign moves to a third one (3 positions per digit are there)
-            static_assert(PLUME_GW <= 15 || PLUME_GWS >= 3, "three digit-row positions per wide digit");
-            dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)((mag >> 8) & 0xFF);
-            dig[(uint32_t)(pos + 2) * stride] = (int8_t)((mag != 0 && dn) ? 1 : 0);
-#else
-            dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)(((mag >> 8) & 0x7F) | ((mag != 0 && dn) ? 0x80 : 0));
-#endif
+            dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)(((mag >> 8) & 0x7F) | (sgn ? 0x80 : 0));
         } else {
-            dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)((mag & 0x3F) | ((mag != 0 && dn) ? 0x40 : 0));
+            dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)((mag & 0x3F) | (sgn ? 0x40 : 0));
         }
+#endif
     }
 }
 // writes the 33 signed digits of one half-scalar to dig[i*stride], sign applied
@@ -344,7 +355,8 @@ PLUME_HD uint32_t job_state(uint8_t f) { return f & 3u; }
 #define PLUME_GTAB_WORDS (PLUME_GTAB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 // the signer's doubling-free comb (below): 2^(W-1) entries per W-bit window
 #ifndef PLUME_COMB_W
-#define PLUME_COMB_W 14   // round 2: 19 windows x 8192 entries (19.9 MiB), 19 additions per multiplication (W = 11: 24 x 1024, 3 MiB, 24 additions); signer's comb kernel 2.31 -> 1.77 ms
+#define PLUME_COMB_W 18   // round 3: 15 windows x 131072 entries (252 MiB), 15 additions per multiplication: signer's comb kernel 1.59 -> 1.26 ms (W = 20: 13 x 524288 entries, 872 MiB, 1.10 ms -- but the
+                          // kernels after it lose what it gains, the table sweeps the MALL); round 2: W = 14, 19 x 8192 entries (19.9 MiB), 1.77 ms; W = 11: 24 x 1024, 3 MiB, 2.31 ms.  Host builds: -DPLUME_COMB_W=14
 #endif
 #define PLUME_COMB_ENTRIES (1 << (PLUME_COMB_W - 1))
 #define PLUME_COMB_WINDOW_WORDS (PLUME_COMB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
@@ -807,9 +819,9 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
 // (<= 15 doublings + 15 mixed additions for a multiplier below 2^16) from the affine window base B_w = 2^(W w) * G and pays its own inversion -- ~45 k instructions per
 // lane, all lanes in parallel.  The additions are the checked ones: a multiplier k < 2^16 never meets k' P = +-P on the way (the order is ~2^256), the checks are there
 // because nothing here is hot.
-PLUME_HD void fixed_table_entry(uint32_t* row, const fe& px, const fe& py, uint32_t k /* 1 <= k < 2^16 */) {
+PLUME_HD void fixed_table_entry(uint32_t* row, const fe& px, const fe& py, uint32_t k /* 1 <= k < 2^31 */) {
     jac acc; acc.x = px; acc.y = py; acc.z = fe_small(1); acc.inf = 0;
-    int top = 15;
+    int top = 30;
     while (top > 0 && !((k >> top) & 1u)) top--;
     PLUME_NOUNROLL for (int b = top - 1; b >= 0; b--) {
         jac_dbl(acc);
@@ -933,14 +945,20 @@ PLUME_HD int msm_digit(const int8_t* dig, uint32_t stride, int i, int s, bool wi
     if (wide0 && s < 2) {
         int mag = d & 0xFF;
         bool dn;
+#if PLUME_GW > 15
+        if (i + PLUME_GW_BYTES < PLUME_NDIG) {
+            PLUME_UNROLL for (int b = 1; b < PLUME_GW_BYTES; b++) mag |= (dig[(uint32_t)(s * PLUME_NDIG + i + b) * stride] & 0xFF) << (8 * b);
+            dn = dig[(uint32_t)(s * PLUME_NDIG + i + PLUME_GW_BYTES) * stride] != 0;
+        } else if (i + 1 < PLUME_NDIG) {
+            const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
+            mag |= (hi & 0x7F) << 8; dn = (hi & 0x80) != 0;
+        } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
+#else
         if (i + 1 < PLUME_NDIG) {
             const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
-#if PLUME_GW > 15
-            mag |= (hi & 0xFF) << 8; dn = dig[(uint32_t)(s * PLUME_NDIG + i + 2) * stride] != 0;
-#else
             mag |= (hi & 0x7F) << 8; dn = (hi & 0x80) != 0;
-#endif
         } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
+#endif
         d = dn ? -mag : mag;
     }
     return d;
