@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4), help="BASELINE.json preset: 2 = 2^16 V1 verify; 3 = 2^20 V1 SIGN; 4 = 2^22 V2 verify split over the ranks")
     ap.add_argument("--multi-ctx", action="store_true", help="one process, one plume_init_multi context over --gpus devices, host-pointer calls from page-locked arrays")
+    ap.add_argument("--in-flight", type=int, default=2, choices=(1, 2, 3, 4),
+                    help="batches in flight per GPU: step i goes to context i mod F on stream i mod F (F contexts, F streams).  1 = one call after the other on one stream, the mode "
+                         "the per-kernel stage times and the roofline are measured in (with F > 1 a serial pass after the timed region supplies them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (V2 verify, V1 sign, SEC1 ingest, e2e) reported at N=1")
     a = ap.parse_args()
@@ -443,6 +446,14 @@ def main():
     total, start, stop = plan(a.scaling, a.log2_batch, world, rank)             # items per step over all ranks, this rank's slice
     n = stop - start                                                           # this rank's items per step
     eng.set_chunk(max(n, 1 << 20))
+    # F batches in flight: F contexts (each with its own workspace and fixed tables) on F streams, steps dealt out in turn.  Every kernel of a 2^20 batch fills the chip, yet the
+    # memory-bound table passes and the ramps / tails of one batch's kernels do fit beside the issue-bound multi-scalar kernel of another: 20.1 vs 20.8 ms per batch on one box
+    # (tests/gpu_debug/two_inflight.py) -- with NO slicing cost, which is what sank the in-library sub-batch pipeline.
+    F = max(1, a.in_flight)
+    engines = [eng] + [plume.Engine(local_dev) for _ in range(F - 1)]
+    for e in engines[1:]:
+        e.set_chunk(max(n, 1 << 20))
+    streams = [None] if F == 1 else [torch.cuda.Stream(device=dev) for _ in range(F)]
 
     # ---- synthetic shard of this rank, signed on the GPU (setup, untimed), corrupted 1/16 as BASELINE.md §3
     b = synth.sign_inputs(n, start=start)
@@ -451,24 +462,29 @@ def main():
     if sign:
         d = {k: t(b[k]) for k in ("msgs", "sk", "r")}
         d["off"] = t(b["off"].view(np.int64))
-        o = {k: torch.zeros((n, w), dtype=torch.uint8, device=dev) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
-        status = torch.zeros(n, dtype=torch.uint8, device=dev)
+        outs = [{k: torch.zeros((n, w), dtype=torch.uint8, device=dev) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]} for _ in range(F)]
+        statuses = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(F)]
+        o, status = outs[0], statuses[0]
         msgs_bytes = int(b["off"][-1])
 
-        def step():
-            eng.sign_batch_device(ver, n, d["msgs"], d["off"], msgs_bytes, d["sk"], d["r"], None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], status)
+        def step(i=0):
+            k = i % F
+            engines[k].sign_batch_device(ver, n, d["msgs"], d["off"], msgs_bytes, d["sk"], d["r"], None, outs[k]["pk"], outs[k]["nullifier"], outs[k]["c"], outs[k]["s"], outs[k]["r_point"],
+                                         outs[k]["hashed_to_curve_r"], statuses[k], stream=streams[k])
     else:
         v = synth.corrupt_for_verify(ver, b, signed, start=start)
         d = {k: t(v[k]) for k in ("msgs", "pk", "nullifier", "c", "s")}
         d["off"] = t(v["off"].view(np.int64))
         d["r_point"] = t(v["r_point"]) if ver == 1 else None
         d["hashed_to_curve_r"] = t(v["hashed_to_curve_r"]) if ver == 1 else None
-        ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+        oks = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(F)]
+        ok = oks[0]
         msgs_bytes = int(v["off"][-1])
         expected = torch.from_numpy(synth.expected_ok(n, start)).to(dev)
 
-        def step():
-            eng.verify_batch_device(ver, n, d["msgs"], d["off"], msgs_bytes, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok)
+        def step(i=0):
+            k = i % F
+            engines[k].verify_batch_device(ver, n, d["msgs"], d["off"], msgs_bytes, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], oks[k], stream=streams[k])
 
     def fence():
         torch.cuda.synchronize()
@@ -476,31 +492,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    for i in range(a.warmup):
+        step(i)
     fence()
     t0 = time.perf_counter()
     stage_acc = {}
-    for _ in range(a.steps):
-        step()
-        if a.steps <= 64:  # per-stage HIP-event times (events are recorded on the launch stream inside the library; the library's default launch order is strictly serial)
+    for i in range(a.steps):
+        step(i)
+        if F == 1 and a.steps <= 64:  # per-stage HIP-event times (events are recorded on the launch stream inside the library; the library's default launch order is strictly serial)
             torch.cuda.current_stream().synchronize()
             for name, ms in eng.last_stage_times():
                 stage_acc[name] = stage_acc.get(name, 0.0) + ms
     fence()
     elapsed_rank = time.perf_counter() - t0
+    stage_div = a.steps
+    in_flight_info = None
+    if F > 1:
+        # what the kernels took IN the timed region (two batches in flight: kernels of the streams share the SIMDs, so each is stretched): the last call of every context
+        infl = {}
+        for e in engines:
+            for name, ms in e.last_stage_times():
+                infl[name] = infl.get(name, 0.0) + ms / F
+        # ... and the serial pass the per-kernel figures come from: the same calls, one after the other on one stream
+        S = max(2, min(a.steps, 5))
+        step(0); torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(S):
+            eng.verify_batch_device(ver, n, d["msgs"], d["off"], msgs_bytes, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok) if not sign else \
+                eng.sign_batch_device(ver, n, d["msgs"], d["off"], msgs_bytes, d["sk"], d["r"], None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], status)
+            torch.cuda.current_stream().synchronize()
+            for name, ms in eng.last_stage_times():
+                stage_acc[name] = stage_acc.get(name, 0.0) + ms
+        serial_s = (time.perf_counter() - ts) / S
+        stage_div = S
+        in_flight_info = {"batches_in_flight": F, "stage_ms_in_flight": {k: round(x, 4) for k, x in infl.items()},
+                          "serial": {"steps": S, "ms_per_step": round(serial_s * 1e3, 3), ("signs_per_s" if sign else "verifies_per_s"): round(n / serial_s, 1),
+                                     "note": "the same calls one after the other on one stream, after the timed region: stage_ms and roofline.kernel_ms are this pass's"}}
     if sign:
         # the timed passes' outputs: equal to the setup pass's (host-pointer entry point) and, on a sample, to the CPU oracle's
-        for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r"):
-            assert np.array_equal(o[k].cpu().numpy(), signed[k]), f"sign outputs differ between passes: {k}"
-        assert not bool(status.any())
+        for oo, st_ in zip(outs, statuses):
+            for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r"):
+                assert np.array_equal(oo[k].cpu().numpy(), signed[k]), f"sign outputs differ between passes: {k}"
+            assert not bool(st_.any())
         if rank == 0:
             from tests import _oracle_c as OC
             m = 256
             want = OC.sign_batch(ver, b["msgs"], b["off"][: m + 1], b["sk"][:m], b["r"][:m], nthreads=8)
             assert all(np.array_equal(signed[k][:m], want[k]) for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")), "sign outputs differ from the CPU oracle"
     else:
-        assert bool((ok == expected).all()), "verify results differ from the expected corruption pattern"
+        for okk in oks[: max(1, min(F, a.steps + a.warmup))]:
+            assert bool((okk == expected).all()), "verify results differ from the expected corruption pattern"
 
     tmax = torch.tensor([elapsed_rank], dtype=torch.float64, device=dev)
     per_rank = [elapsed_rank]
@@ -514,7 +555,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / a.steps
         value = total * a.steps / elapsed
-        stages = {k: round(vv / a.steps, 4) for k, vv in stage_acc.items()}
+        stages = {k: round(vv / stage_div, 4) for k, vv in stage_acc.items()}
         what = f"2^{a.log2_batch} per GPU" if a.scaling == "weak" else f"2^{a.log2_batch} in total, even split over {world} GPU(s)"
         op, unit = ("sign", "signs/s") if sign else ("verify", "verifies/s")
         cfg_idx = {None: 1, 2: 1, 3: 2, 4: 3}[a.config]
@@ -524,14 +565,18 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{cfg_idx}]" + ("/metric" if cfg_idx == 1 and a.log2_batch == 20 else "") + f": batch {what}, PLUME V{ver} {op} (secp256k1 + SHA-256), 32-byte messages, "
                                    + ("" if sign else "1/16 corrupted, ") + "inputs resident in HBM; Fp arithmetic on 9x29-bit limbs through chains of v_mad_u64_u32 (32x32+64)",
-                       "form": "one process per GPU (torch.distributed ranks), device-resident entry point plume_" + op + "_batch_device on torch's current stream, launch order strictly serial "
-                               f"(sub_batches = 1); library {eng.version()}",
+                       "form": "one process per GPU (torch.distributed ranks), device-resident entry point plume_" + op + "_batch_device; " +
+                               (f"{F} batches in flight per GPU: step i goes to context i mod {F} on stream i mod {F}, each call's launch order strictly serial (sub_batches = 1); "
+                                "stage_ms and roofline from a serial pass after the timed region (in_flight.serial)" if F > 1 else
+                                "one call after the other on torch's current stream, launch order strictly serial (sub_batches = 1)") + f"; library {eng.version()}",
                        "items_per_gpu": n, "global_items_per_step": total, "parallelism": f"shard x{world}, no collective on the data path",
                        "world_size": world, "collective_backend": "nccl (RCCL): barrier + MAX + gather of the timings only" if world > 1 else None},
             "per_rank": {"items_per_step": [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)],
                          ("signs_per_s" if sign else "verifies_per_s"): [round((shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]) * a.steps / per_rank[r], 1) for r in range(world)]},
             "stage_ms": stages,
         }
+        if in_flight_info:
+            line["in_flight"] = in_flight_info
         if stages:
             dom = max(stages, key=stages.get)
             dom_s = stages[dom] * 1e-3
@@ -568,6 +613,12 @@ def main():
                                     "accounting": (f"{dom_fpmul} Fp-mult per {op} in this kernel " + ("(r*H, sk*H: 2 x 1584)" if sign else "(s*G - c*pk: 1900, s*H - c*nul: 2260)") +
                                                    f" x {MACS_PER_FPMUL} MACs x {n} items per launch (SURVEY.md §8d, frozen in BASELINE.md §4); the 9x29-limb code issues 110 multiply-adds per "
                                                    f"Fp-mult (81 products + 22 fold + 7 column hand-offs), 73 per squaring; the accounting stays on the frozen 72")}
+            if dom_fpmul and in_flight_info and in_flight_info["stage_ms_in_flight"].get(dom):
+                kin = in_flight_info["stage_ms_in_flight"][dom]
+                line["roofline"]["kernel_ms_in_timed_region"] = kin
+                line["roofline"]["frac_in_timed_region"] = round(dom_fpmul * MACS_PER_FPMUL * n / (kin * 1e-3) / mad_rate, 4)
+                line["roofline"]["note"] = (f"kernel_ms / frac: the serial pass (one call after the other).  In the timed region {F} batches are in flight and the kernels of the streams share the "
+                                            "SIMDs: each launch is stretched (kernel_ms_in_timed_region, HIP events on its own stream) while the step gets shorter")
             line["hbm_view"] = {"bound": "hbm", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(hbm_achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": bytes_item * n,
                                 "traffic": round(traffic_bytes / dom_s / 1e9, 1) if traffic_bytes else None, "traffic_bytes_per_launch": traffic_bytes,
