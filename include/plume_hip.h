@@ -46,7 +46,8 @@ typedef struct plume_ctx plume_ctx;
 #define PLUME_STATUS_IDENTITY 4        /* H == identity (randomizedsigner.rs:61) or s == 0 (randomizedsigner.rs:95) */
 
 /* Create a context bound to HIP device `device_id` (>= 0).  Builds the generator's fixed tables on the device: (1..2^23)*G for the verifier's 24-bit windows (1 GiB)
- * and the signer's doubling-free comb, 15 windows of 2^17 rows (252 MiB) -- about 18 ms and 1.25 GiB of HBM per context, before any per-batch workspace. */
+ * and the signer's doubling-free comb, 15 windows of 2^17 rows (252 MiB) -- about 18 ms and 1.25 GiB of HBM, ONCE per device and process: the tables are read-only and every
+ * context of the process on that device shares them (a further context takes ~1.5 ms and its per-batch workspace only; the last one to go frees them). */
 int plume_init(plume_ctx** out, int device_id);
 /* Create a multi-device context: one shard (a complete single-device context with its own streams and workspace, driven by its own
  * worker thread) per entry of device_ids (SURVEY.md §8b sketch, §8e).  Every HOST-POINTER entry point below then splits its batch

@@ -29,4 +29,4 @@ for _ in range(8): call()
 torch.cuda.synchronize()
 print(f"8 calls back to back: {1e3*(time.perf_counter()-t0)/8:6.2f} ms per call")
 t0 = time.perf_counter(); e2 = plume.Engine(0); t1 = time.perf_counter()
-print(f"plume_init (second context, includes the 2048-entry generator table and the comb): {1e3*(t1-t0):.1f} ms")
+print(f"plume_init (second context on the device: the generator's fixed tables are shared): {1e3*(t1-t0):.1f} ms")

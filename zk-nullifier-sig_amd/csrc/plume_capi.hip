@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <random>
 #include <string>
@@ -84,6 +85,16 @@ struct Worker {
     std::string err;
 };
 
+// The generator's fixed tables (the verifier's 2^23-row window table, the signer's comb: 1.25 GiB, 18 ms to build) depend on nothing but G: every context of a process on
+// the same device shares ONE read-only copy, built by the first and freed with the last (a second batch in flight -- a second context -- then costs its workspace only).
+struct FixedTables {
+    DevBuf gtab, gcomb;
+    int refs = 0;
+    bool built = false;
+};
+static std::mutex g_fixed_mutex;
+static std::map<int, FixedTables> g_fixed;
+
 struct plume_ctx {
     int device = 0;
     hipStream_t stream = nullptr, up = nullptr, down = nullptr;   // kernels / host->HBM / HBM->host
@@ -109,7 +120,8 @@ struct plume_ctx {
     HostSlot slot[2];
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
-    DevBuf gcomb, gtab, bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo;
+    FixedTables* fixed = nullptr;                                 // this device's shared generator tables (g_fixed)
+    DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo;
     DevBuf dec[4], preflags;
     DevBuf agg[15];      // aggregate check (plume_aggregate.h): haff, scal, flags, gs, hash_ok, counters, count, sort tiles, sorted, bsum, bsuminf, red, redinf, ssum, perm + its histogram
     DevBuf agg_record;   // the running record of a host-pointer aggregate call (pieces of one batch)
@@ -166,10 +178,15 @@ static void destroy_single(plume_ctx* ctx) {
     if (ctx->down) (void)hipStreamSynchronize(ctx->down);
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     if (ctx->pre) (void)hipStreamSynchronize(ctx->pre);
-    for (DevBuf* b : {&ctx->gcomb, &ctx->gtab, &ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
+    for (DevBuf* b : {&ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
                       &ctx->sink, &ctx->redo, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
     for (DevBuf& b : ctx->agg) b.release();
+    if (ctx->fixed) {
+        std::lock_guard<std::mutex> lk(g_fixed_mutex);
+        if (--ctx->fixed->refs == 0) { ctx->fixed->gtab.release(); ctx->fixed->gcomb.release(); ctx->fixed->built = false; }
+        ctx->fixed = nullptr;
+    }
     for (HostSlot& sl : ctx->slot) {
         sl.msgs.release(); sl.off.release();
         for (DevBuf& b : sl.in) b.release();
@@ -214,11 +231,22 @@ static int init_single(plume_ctx* ctx) {
         HIPCHK(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
     }
     // the generator's tables: the verifier's wide window table (1..2^(W-1))*G and the signer's doubling-free comb, built once on the device, one entry per lane
-    if (ctx->gtab.ensure((size_t)PLUME_GTAB_WORDS * 4) || ctx->gcomb.ensure((size_t)PLUME_COMB_WORDS * 4) || ctx->sink.ensure((size_t)(1 + PLUME_COMB_WINDOWS) * 2 * PLUME_FE_WORDS * 4 + 512))
-        return PLUME_ERR_HIP;
-    launch_fixed_tables(ctx->gtab.as<uint32_t>(), ctx->gcomb.as<uint32_t>(), ctx->sink.as<uint32_t>(), ctx->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->sink.ensure((size_t)(1 + PLUME_COMB_WINDOWS) * 2 * PLUME_FE_WORDS * 4 + 512)) return PLUME_ERR_HIP;
+    {
+        // built under the lock: contexts created side by side on one device (plume_init_multi's shards, a second batch in flight) wait for the first one's build
+        std::lock_guard<std::mutex> lk(g_fixed_mutex);
+        FixedTables& ft = g_fixed[ctx->device];
+        if (!ft.built) {
+            if (ft.gtab.ensure((size_t)PLUME_GTAB_WORDS * 4) || ft.gcomb.ensure((size_t)PLUME_COMB_WORDS * 4)) { ft.gtab.release(); ft.gcomb.release(); return PLUME_ERR_HIP; }
+            launch_fixed_tables(ft.gtab.as<uint32_t>(), ft.gcomb.as<uint32_t>(), ctx->sink.as<uint32_t>(), ctx->stream);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ft.gtab.release(); ft.gcomb.release(); return fail(PLUME_ERR_HIP, std::string("fixed tables: ") + hipGetErrorString(e)); }
+            ft.built = true;
+        }
+        ft.refs++;
+        ctx->fixed = &ft;
+    }
     return 0;
 }
 
@@ -517,7 +545,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         a.preflags = preflags ? preflags + lo : nullptr; a.rpt33 = rpt33 ? rpt33 + 33 * lo : nullptr; a.hr33 = hr33 ? hr33 + 33 * lo : nullptr;
         a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * 3 * lo; a.jobflags = ctx->jobflags.as<uint8_t>() + 3 * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo;
         a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * 3 * lo; a.res = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.resinf = ctx->resinf.as<uint8_t>() + 2 * lo;
-        a.gtab = ctx->gtab.as<uint32_t>();
+        a.gtab = ctx->fixed->gtab.as<uint32_t>();
         a.redo = ctx->redo.as<uint32_t>() + 2 * lo + k;                      // the slice's redo list: counter + up to 2 * cnt tasks
         if (k == 0) ctx->redo_counters.clear();
         ctx->redo_counters.push_back(2 * lo + k);
@@ -570,7 +598,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
         a.gres = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.gresinf = ctx->resinf.as<uint8_t>() + 2 * lo; a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * lo;
         a.jobflags = ctx->jobflags.as<uint8_t>() + lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo; a.pkaff = ctx->pkaff.as<uint32_t>() + (size_t)2 * PLUME_FE_WORDS * lo;
         a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * lo; a.hres = ctx->res2.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.hresinf = ctx->res2inf.as<uint8_t>() + 2 * lo;
-        a.gtab = ctx->gtab.as<uint32_t>(); a.gcomb = ctx->gcomb.as<uint32_t>();
+        a.gtab = ctx->fixed->gtab.as<uint32_t>(); a.gcomb = ctx->fixed->gcomb.as<uint32_t>();
         launch_sign_gmul(a, pre); if (!overlapped) t.stage("sign_gmul", st);
         launch_normalize(a.gres, a.gresinf, 2 * cnt, pre); if (!overlapped) t.stage("to_affine_g", st);
         launch_sign_h2c(a, pre); if (!overlapped) t.stage("sign_h2c", st);
@@ -717,7 +745,7 @@ extern "C" int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, 
     if (n && (!scalars || !der109 || !status)) return fail(PLUME_ERR_ARG, "null array");
     if (n > 0xFFFFFFF0u) return fail(PLUME_ERR_ARG, "n too large");
     if (n == 0) return 0;
-    DerArgs a; a.n = (uint32_t)n; a.scalars = scalars; a.der = der109; a.status = status; a.gcomb = ctx->gcomb.as<uint32_t>();
+    DerArgs a; a.n = (uint32_t)n; a.scalars = scalars; a.der = der109; a.status = status; a.gcomb = ctx->fixed->gcomb.as<uint32_t>();
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->timer.begin(st);
     launch_scalars_der(a, st); ctx->timer.stage("scalars_to_sec1_der", st);
@@ -773,7 +801,7 @@ static int aggregate_device(plume_ctx* ctx, int version, int mode, size_t n, con
     a.haff = B[0].as<uint8_t>(); a.scal = B[1].as<uint32_t>(); a.tlive = B[2].as<uint8_t>(); a.tneg = B[2].as<uint8_t>() + n; a.gs = B[3].as<uint32_t>();
     a.hash_ok = hash_ok ? hash_ok : B[4].as<uint8_t>(); a.nbad = B[5].as<uint32_t>();
     a.count = B[6].as<uint32_t>(); a.sorted = B[8].as<uint32_t>(); a.bsum = B[9].as<uint32_t>(); a.bsuminf = B[10].as<uint8_t>();
-    a.gcomb = ctx->gcomb.as<uint32_t>(); a.result = result;
+    a.gcomb = ctx->fixed->gcomb.as<uint32_t>(); a.result = result;
     uint32_t* red[4]; uint8_t* rinf[4];                     // lower group: 0, 1; upper group: 2, 3
     for (int k = 0; k < 4; k++) { red[k] = B[11].as<uint32_t>() + (size_t)k * PLUME_JAC_WORDS * nred; rinf[k] = B[12].as<uint8_t>() + (size_t)k * nred; }
     uint32_t* gpt = B[13].as<uint32_t>() + 2 * sw; uint8_t* gptinf = (uint8_t*)(gpt + PLUME_JAC_WORDS);
