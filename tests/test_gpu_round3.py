@@ -346,3 +346,36 @@ def test_crafted_items_are_redone_by_the_second_launch_and_cost_only_themselves(
     assert redone >= len(idx), (redone, len(idx))
     want = CF.verify_batch(1, b["msgs"], b["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"], nthreads=THREADS)
     assert np.array_equal(got, want) and int(got.sum()) == n - len(idx)
+
+
+def test_contexts_of_one_device_share_the_fixed_tables_and_outlive_each_other(eng):
+    """The generator's fixed tables are built once per device and process and shared by its contexts (plume_capi.hip FixedTables, reference-counted): a context keeps working
+    after the one that built the tables is gone, the last one frees them, and a context created afterwards builds them again -- signatures identical throughout; two contexts
+    driven side by side (two batches in flight, what bench.py does) give the verdicts one context gives."""
+    import torch
+    plume = pytest.importorskip("zk_nullifier_sig_amd")
+    n = 3000
+    b = synth.sign_inputs(n, start=77)
+    want = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    a = plume.Engine(0)
+    c = plume.Engine(0)
+    got = a.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    a.close()                                              # the module's engine and c still hold the tables
+    got2 = c.sign_batch(2, b["msgs"], b["off"], b["sk"], b["r"])
+    assert all(np.array_equal(got[k], want[k]) for k in want)
+    assert np.array_equal(got2["pk"], want["pk"]) and np.array_equal(got2["nullifier"], want["nullifier"])
+    # two contexts, two streams, calls alternating
+    v = synth.corrupt_for_verify(1, b, want, start=77)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(np.ascontiguousarray(v[k])).to(dev) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+    off = torch.from_numpy(v["off"].view(np.int64)).to(dev)
+    oks = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(2)]
+    st = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for i in range(6):
+        e = (eng, c)[i % 2]
+        e.verify_batch_device(1, n, t["msgs"], off, int(v["off"][-1]), t["pk"], t["nullifier"], t["c"], t["s"], t["r_point"], t["hashed_to_curve_r"], oks[i % 2], stream=st[i % 2])
+    torch.cuda.synchronize()
+    exp = synth.expected_ok(n, 77)
+    assert np.array_equal(oks[0].cpu().numpy(), exp) and np.array_equal(oks[1].cpu().numpy(), exp)
+    c.close()
