@@ -26,6 +26,8 @@ KINDS = [
     ("v_cndmask_b32 e64 (sgpr pair mask)", "u32", "v_cndmask_b32 {c}, {c}, %8, s[20:21]"),
     ("v_cndmask_b32 (vcc), dst != src", "u32", None),
     ("v_cmp_lt_u32 + v_cndmask (vcc)", "u32", None),
+    ("v_cmp_lt_u32 + 7 v_cndmask (vcc)", "u32", None),
+    ("v_addc_co_u32 (writes vcc) + 7 v_cndmask (vcc)", "u32", None),
     ("v_bfi_b32", "u32", "v_bfi_b32 {c}, %8, {c}, %9"),
     ("v_sub_u32", "u32", "v_sub_u32 {c}, %8, {c}"),
     ("v_lshlrev_b32", "u32", "v_lshlrev_b32 {c}, 1, {c}"),
@@ -70,6 +72,17 @@ def block(kind):
         for r in range(2):
             for i in range(8):
                 lines += [f"v_cmp_lt_u32 vcc, %8, %{i}", f"v_cndmask_b32 %{i}, %{i}, %9, vcc"]
+    elif name == "v_cmp_lt_u32 + 7 v_cndmask (vcc)":
+        # what a compiled select of a multi-limb value looks like: one compare, then a run of selects on its VCC
+        for r in range(4):
+            lines.append(f"v_cmp_lt_u32 vcc, %8, %{r}")
+            for i in range(7):
+                lines.append(f"v_cndmask_b32 %{(r + i + 1) % 8}, %{(r + i + 1) % 8}, %9, vcc")
+    elif name == "v_addc_co_u32 (writes vcc) + 7 v_cndmask (vcc)":
+        for r in range(4):
+            lines.append(f"v_addc_co_u32 %{r}, vcc, %8, %{r}, vcc")
+            for i in range(7):
+                lines.append(f"v_cndmask_b32 %{(r + i + 1) % 8}, %{(r + i + 1) % 8}, %9, vcc")
     elif name == "v_cvt_f64_u32 + back":
         # 16 x (u32 -> f64 -> u32) on 8 chains, temp pair v[100:101] .. per chain
         for r in range(2):

@@ -179,7 +179,8 @@ PLUME_HD void glv_split(glv_half& h1, glv_half& h2, const sc& k) {
     sc_neg(n1, k1); sc_neg(n2, k2);
     h1.neg = (k1.v[4] | k1.v[5] | k1.v[6] | k1.v[7]) != 0;
     h2.neg = (k2.v[4] | k2.v[5] | k2.v[6] | k2.v[7]) != 0;
-    PLUME_UNROLL for (int i = 0; i < 4; i++) { h1.m[i] = h1.neg ? n1.v[i] : k1.v[i]; h2.m[i] = h2.neg ? n2.v[i] : k2.v[i]; }
+    const uint32_t m1 = sel_mask(h1.neg != 0), m2 = sel_mask(h2.neg != 0);
+    PLUME_UNROLL for (int i = 0; i < 4; i++) { h1.m[i] = sel32(m1, n1.v[i], k1.v[i]); h2.m[i] = sel32(m2, n2.v[i], k2.v[i]); }
 }
 
 // Booth recoding, window w = PLUME_WBITS (4; 5 is the A/B build of DESIGN.md §10): m = sum d_i 2^(w i), d_i in [-2^(w-1), 2^(w-1)], i = 0..NDIG-1 covering 129 bits.

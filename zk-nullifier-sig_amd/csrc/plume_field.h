@@ -81,6 +81,26 @@ PLUME_HD uint32_t opaque_u32(uint32_t x) {
 #endif
     return x;
 }
+// Selects.  hipcc compiles `flag ? a : b` on 32-bit values to v_cndmask_b32 with the condition in VCC, and a RUN of those -- a multi-limb select, a select chain -- is the
+// slowest thing the SIMD does: tests/gpu_debug/instr_rates_r03.txt, one compare + 7 v_cndmask on its VCC = 6.7 ns per instruction at ANY occupancy (a multiply-add: 1.8).
+// A select through an opaque all-ones / all-zeros mask compiles to one v_bfi_b32 (1.8 ns) instead; the mask costs two instructions per condition.
+#ifndef PLUME_SELECT_BY_MASK
+#define PLUME_SELECT_BY_MASK 1
+#endif
+PLUME_HD uint32_t sel_mask(bool flag) {
+    uint32_t m = 0u - (uint32_t)flag;
+#if defined(__HIP_DEVICE_COMPILE__) && PLUME_SELECT_BY_MASK
+    asm("" : "+v"(m));              // or the compiler turns the mask arithmetic back into a select
+#endif
+    return m;
+}
+PLUME_HD uint32_t sel32(uint32_t mask, uint32_t a, uint32_t b) {      // mask all ones: a, all zeros: b
+#if defined(__HIP_DEVICE_COMPILE__) && PLUME_SELECT_BY_MASK
+    return (a & mask) | (b & ~mask);
+#else
+    return mask ? a : b;
+#endif
+}
 PLUME_HD uint32_t addc0(uint32_t a, uint32_t& c) { return addc(a, opaque_zero(), c); }
 PLUME_HD uint32_t subb0(uint32_t a, uint32_t& bw) { return subb(a, opaque_zero(), bw); }
 
@@ -213,7 +233,8 @@ PLUME_HD void fe_normalize(fe& a) {
     fe_ripple(u);
     const bool ge = (u.v[8] >> 24) != 0;
     u.v[8] &= 0x00FFFFFFu;
-    PLUME_UNROLL for (int i = 0; i < 9; i++) a.v[i] = ge ? u.v[i] : a.v[i];
+    const uint32_t gm = sel_mask(ge);
+    PLUME_UNROLL for (int i = 0; i < 9; i++) a.v[i] = sel32(gm, u.v[i], a.v[i]);
 }
 PLUME_HD bool fe_is_zero(const fe& a) {  // a == 0 (mod p), any limbs < 2^32
     fe t = a;
@@ -226,7 +247,7 @@ PLUME_HD bool fe_is_zero(const fe& a) {  // a == 0 (mod p), any limbs < 2^32
 }
 PLUME_HD bool fe_eq(const fe& a, const fe& b) { fe d; fe_sub(d, a, b); return fe_is_zero(d); }
 PLUME_HD bool fe_is_odd(const fe& a) { fe t = a; fe_normalize(t); return t.v[0] & 1; }
-PLUME_HD void fe_cmov(fe& r, const fe& a, bool flag) { PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = flag ? a.v[i] : r.v[i]; }
+PLUME_HD void fe_cmov(fe& r, const fe& a, bool flag) { const uint32_t m = sel_mask(flag); PLUME_UNROLL for (int i = 0; i < 9; i++) r.v[i] = sel32(m, a.v[i], r.v[i]); }
 // true iff the 256-bit integer in 8 little-endian words is < p (canonical encoding check for caller-supplied coordinates)
 PLUME_HD bool words_lt_p(const uint32_t w[8]) {
     uint32_t c = 0;
@@ -507,7 +528,8 @@ PLUME_HD bool sc_lt_n(const sc& a) {  // a < n
 PLUME_HD void sc_cond_sub_n(sc& a) {  // a in [0, 2n) -> [0, n) ... (only one subtraction)
     sc t; uint32_t bw = 0;
     PLUME_UNROLL for (int i = 0; i < 8; i++) t.v[i] = subb(a.v[i], sc_n(i), bw);
-    PLUME_UNROLL for (int i = 0; i < 8; i++) a.v[i] = bw ? a.v[i] : t.v[i];
+    const uint32_t bm = sel_mask(bw != 0);
+    PLUME_UNROLL for (int i = 0; i < 8; i++) a.v[i] = sel32(bm, a.v[i], t.v[i]);
 }
 PLUME_HD void sc_from_be(sc& r, const uint8_t* b) {
     PLUME_UNROLL for (int i = 0; i < 8; i++) {
@@ -530,12 +552,14 @@ PLUME_HD void sc_add(sc& r, const sc& a, const sc& b) {  // canonical inputs
     sc t; uint32_t bw = 0;
     PLUME_UNROLL for (int i = 0; i < 8; i++) t.v[i] = subb(r.v[i], sc_n(i), bw);
     bool take = c || !bw;
-    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = take ? t.v[i] : r.v[i];
+    const uint32_t tm = sel_mask(take);
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = sel32(tm, t.v[i], r.v[i]);
 }
 PLUME_HD void sc_neg(sc& r, const sc& a) {  // n - a, 0 -> 0
     uint32_t bw = 0; bool z = sc_is_zero(a);
     PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = subb(sc_n(i), a.v[i], bw);
-    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = z ? 0u : r.v[i];
+    const uint32_t zm = sel_mask(z);
+    PLUME_UNROLL for (int i = 0; i < 8; i++) r.v[i] = r.v[i] & ~zm;
 }
 // generic NxM limb product (small helper for the scalar side)
 template <int NA, int NB>

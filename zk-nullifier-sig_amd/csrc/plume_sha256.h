@@ -85,7 +85,7 @@ PLUME_HD void sha256_absorb_pad(uint32_t st[8], uint32_t prefix_len, uint32_t le
 PLUME_HD uint32_t be_byte_of_limbs(const uint32_t v[8], uint32_t k) {
     uint32_t limb = 7 - (k >> 2);
     uint32_t w = v[0];
-    PLUME_UNROLL for (int i = 1; i < 8; i++) w = (limb == (uint32_t)i) ? v[i] : w;
+    PLUME_UNROLL for (int i = 1; i < 8; i++) w = sel32(sel_mask(limb == (uint32_t)i), v[i], w);
     return (w >> (8 * (3 - (k & 3)))) & 0xFF;
 }
 
