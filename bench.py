@@ -346,29 +346,30 @@ def small_batch_entry(eng, dev, log2n=16):
     dt = (time.perf_counter() - t0) / reps
     assert bool((ok.cpu() == torch.from_numpy(synth.expected_ok(n))).all())
     stages = {k: round(x, 4) for k, x in eng.last_stage_times()}
-    # The same calls with TWO batches in flight: a second context (its own workspace) on a second stream, calls alternating.  A 2^16 batch leaves most SIMDs one or two
+    # The same calls with TWO batches in flight: two lanes of the context (plume_set_in_flight) on two streams, calls alternating.  A 2^16 batch leaves most SIMDs one or two
     # wavefronts (the kernels run on latency, not on issue slots), so the validation / table kernels of one call fit beside the multi-scalar kernel of the other.
     # A throughput figure for a server holding several small batches -- NOT the latency of one call, which is the entry above.
-    import zk_nullifier_sig_amd as plume
-    eng2 = plume.Engine(eng.device_id)
     ok2 = torch.zeros(n, dtype=torch.uint8, device=dev)
     s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-    fn2 = lambda e, o, st: e.verify_batch_device(1, n, d["msgs"], off, mb, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], o, stream=st)  # noqa: E731
+    fn2 = lambda o, st: eng.verify_batch_device(1, n, d["msgs"], off, mb, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], o, stream=st)  # noqa: E731
     torch.cuda.synchronize()
-    for _ in range(2):
-        fn2(eng, ok, s1); fn2(eng2, ok2, s2)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn2(eng, ok, s1); fn2(eng2, ok2, s2)
-    torch.cuda.synchronize()
-    dt2 = (time.perf_counter() - t0) / (2 * reps)
+    eng.set_in_flight(2)
+    try:
+        for _ in range(2):
+            fn2(ok, s1); fn2(ok2, s2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn2(ok, s1); fn2(ok2, s2)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / (2 * reps)
+    finally:
+        eng.set_in_flight(1)
     assert bool((ok2.cpu() == torch.from_numpy(synth.expected_ok(n))).all()) and bool((ok.cpu() == torch.from_numpy(synth.expected_ok(n))).all())
-    eng2.close()
     return {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "stage_ms": stages,
             "workload": f"BASELINE.json configs[1]: 2^{log2n} V1 verifies per call, inputs resident in HBM, {reps} calls back to back",
             "two_batches_in_flight": {"items_per_s": round(n / dt2, 1), "ms_per_batch": round(dt2 * 1e3, 4),
-                                      "note": "two contexts on two streams, calls alternating: throughput with two small batches in flight, not one call's latency"}}
+                                      "note": "plume_set_in_flight(2), two streams, calls alternating: throughput with two small batches in flight, not one call's latency"}}
 
 
 def multi_ctx_main(a):
@@ -446,13 +447,12 @@ def main():
     total, start, stop = plan(a.scaling, a.log2_batch, world, rank)             # items per step over all ranks, this rank's slice
     n = stop - start                                                           # this rank's items per step
     eng.set_chunk(max(n, 1 << 20))
-    # F batches in flight: F contexts (each with its own workspace and fixed tables) on F streams, steps dealt out in turn.  Every kernel of a 2^20 batch fills the chip, yet the
+    # F batches in flight: F lanes of the context (each with its own workspace) on F streams, steps dealt out in turn.  Every kernel of a 2^20 batch fills the chip, yet the
     # memory-bound table passes and the ramps / tails of one batch's kernels do fit beside the issue-bound multi-scalar kernel of another: 20.1 vs 20.8 ms per batch on one box
     # (tests/gpu_debug/two_inflight.py) -- with NO slicing cost, which is what sank the in-library sub-batch pipeline.
     F = max(1, a.in_flight)
-    engines = [eng] + [plume.Engine(local_dev) for _ in range(F - 1)]
-    for e in engines[1:]:
-        e.set_chunk(max(n, 1 << 20))
+    eng.set_in_flight(F)                   # plume_set_in_flight: the context's device-resident calls go in turn to F lanes (workspace, streams, events each; fixed tables shared)
+    engines = [eng] * F
     streams = [None] if F == 1 else [torch.cuda.Stream(device=dev) for _ in range(F)]
 
     # ---- synthetic shard of this rank, signed on the GPU (setup, untimed), corrupted 1/16 as BASELINE.md §3
@@ -508,11 +508,10 @@ def main():
     stage_div = a.steps
     in_flight_info = None
     if F > 1:
-        # what the kernels took IN the timed region (two batches in flight: kernels of the streams share the SIMDs, so each is stretched): the last call of every context
-        infl = {}
-        for e in engines:
-            for name, ms in e.last_stage_times():
-                infl[name] = infl.get(name, 0.0) + ms / F
+        # what the kernels of the timed region's LAST call took (its predecessor's multi-scalar kernel ran beside its first stages; its own multi-scalar kernel finishes with the
+        # machine nearly to itself -- calls in the middle of the stream are stretched more, up to +0.4 ms on that kernel by tests with two contexts)
+        infl = {name: ms for name, ms in eng.last_stage_times()}        # the lane of the last call
+        eng.set_in_flight(1)                                             # the serial pass: one lane, one stream
         # ... and the serial pass the per-kernel figures come from: the same calls, one after the other on one stream
         S = max(2, min(a.steps, 5))
         step(0); torch.cuda.synchronize()
@@ -566,7 +565,7 @@ def main():
             "config": {"workload": f"BASELINE.json configs[{cfg_idx}]" + ("/metric" if cfg_idx == 1 and a.log2_batch == 20 else "") + f": batch {what}, PLUME V{ver} {op} (secp256k1 + SHA-256), 32-byte messages, "
                                    + ("" if sign else "1/16 corrupted, ") + "inputs resident in HBM; Fp arithmetic on 9x29-bit limbs through chains of v_mad_u64_u32 (32x32+64)",
                        "form": "one process per GPU (torch.distributed ranks), device-resident entry point plume_" + op + "_batch_device; " +
-                               (f"{F} batches in flight per GPU: step i goes to context i mod {F} on stream i mod {F}, each call's launch order strictly serial (sub_batches = 1); "
+                               (f"{F} batches in flight per GPU (plume_set_in_flight): step i goes to lane i mod {F} of the context on stream i mod {F}, each call's launch order strictly serial (sub_batches = 1); "
                                 "stage_ms and roofline from a serial pass after the timed region (in_flight.serial)" if F > 1 else
                                 "one call after the other on torch's current stream, launch order strictly serial (sub_batches = 1)") + f"; library {eng.version()}",
                        "items_per_gpu": n, "global_items_per_step": total, "parallelism": f"shard x{world}, no collective on the data path",
@@ -618,7 +617,7 @@ def main():
                 line["roofline"]["kernel_ms_in_timed_region"] = kin
                 line["roofline"]["frac_in_timed_region"] = round(dom_fpmul * MACS_PER_FPMUL * n / (kin * 1e-3) / mad_rate, 4)
                 line["roofline"]["note"] = (f"kernel_ms / frac: the serial pass (one call after the other).  In the timed region {F} batches are in flight and the kernels of the streams share the "
-                                            "SIMDs: each launch is stretched (kernel_ms_in_timed_region, HIP events on its own stream) while the step gets shorter")
+                                            "SIMDs: launches are stretched while the step gets shorter (kernel_ms_in_timed_region: the LAST call's launch, the one figure the library's stage events of a lane keep)")
             line["hbm_view"] = {"bound": "hbm", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(hbm_achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": bytes_item * n,
                                 "traffic": round(traffic_bytes / dom_s / 1e9, 1) if traffic_bytes else None, "traffic_bytes_per_launch": traffic_bytes,

@@ -81,6 +81,7 @@ extern "C" {
     fn plume_sec1_der_to_scalars_checked(ctx: *mut plume_ctx, n: usize, der109: *const u8, scalars: *mut u8, ok: *mut u8) -> c_int;
     fn plume_h2c_hints_batch(ctx: *mut plume_ctx, n: usize, msgs: *const u8, msg_off: *const u64, pk: *const u8, registers: c_int, hints: *mut u8) -> c_int;
     fn plume_set_sub_batches(ctx: *mut plume_ctx, sub_batches: c_int) -> c_int;
+    fn plume_set_in_flight(ctx: *mut plume_ctx, batches: c_int) -> c_int;
     fn plume_shard_numa_node(ctx: *const plume_ctx, shard: c_int) -> c_int;
     fn plume_aggregate_check(ctx: *mut plume_ctx, version: c_int, mode: c_int, n: usize, msgs: *const u8, msg_off: *const u64, pk: *const u8, nullifier: *const u8, c: *const u8,
                              s: *const u8, r_point: *const u8, hashed_to_curve_r: *const u8, seed: *const u8, hash_ok: *mut u8, result: *mut u8) -> c_int;
@@ -277,6 +278,8 @@ impl HipEngine {
 
     /// Device-resident calls only (`plume_set_sub_batches`): 1 = strictly serial launch order (the default and, on the MI355X, the fastest: DESIGN.md section 6)
     pub fn set_sub_batches(&self, k: i32) -> Result<(), HipError> { if unsafe { plume_set_sub_batches(self.0, k) } == 0 { Ok(()) } else { Err(last_error()) } }
+    /// Batches in flight (`plume_set_in_flight`): with 2, device-resident calls issued on different streams run side by side (two lanes of the context); default 1
+    pub fn set_in_flight(&self, k: i32) -> Result<(), HipError> { if unsafe { plume_set_in_flight(self.0, k) } == 0 { Ok(()) } else { Err(last_error()) } }
     /// The NUMA node shard `d`'s worker thread bound itself to (`None`: not bound) — allocate / pin the caller arrays of that shard's slice there
     pub fn shard_numa_node(&self, d: usize) -> Option<i32> { let v = unsafe { plume_shard_numa_node(self.0, d as c_int) }; if v >= 0 { Some(v) } else { None } }
 

@@ -77,6 +77,13 @@ int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
  * compute units cost more than the table kernel's idle issue slots give back), so the knob is an experiment's record, not a recommendation.
  * Env PLUME_SUB_BATCHES=k sets the default of new contexts, PLUME_SERIAL=1 forces 1. */
 int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
+/* Batches in flight (default 1).  A context runs its device-resident calls one at a time: they share its workspace, so calls issued on different streams queue.  With
+ * batches = 2 the calls go in turn to two lanes of the context (each with a workspace, streams and events of its own; the generator's fixed tables are shared), and calls the
+ * caller issues on DIFFERENT streams run side by side: the memory-bound table passes and the ramps / tails of one batch's kernels fit beside the issue-bound multi-scalar
+ * kernel of the other -- 20.1 instead of 20.8 ms per 2^20 verifies, 1.37 instead of 1.77 ms per 2^16 on the MI355X; a third lane gains nothing more (1..4 accepted).
+ * Results do not depend on it; calls on one stream keep that stream's order.  Costs a second per-batch workspace.  Single-device contexts only (a multi-device context
+ * already runs its shards side by side).  plume_last_stage_times / plume_last_redo_tasks then report the lane of the last device-resident call. */
+int plume_set_in_flight(plume_ctx* ctx, int batches);
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (three streams,
  * two staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each
  * following piece up to three times the one before, up to the largest piece (default 1<<19, capped by the chunk size); calls with large

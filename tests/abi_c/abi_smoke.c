@@ -114,6 +114,7 @@ static void run(plume_ctx* ctx, int pinned, const char* label) {
         CHECK(plume_sec1_der_to_scalars(N, der, back, okd) == PLUME_OK && okd[1] == 1, "the structure-only form does not look at the key (documented)");
         if (plume_num_shards(ctx) == 1) {
             CHECK(plume_set_sub_batches(ctx, 4) == PLUME_OK && plume_set_sub_batches(ctx, 1) == PLUME_OK && plume_set_sub_batches(ctx, 0) == PLUME_ERR_ARG, "plume_set_sub_batches");
+            CHECK(plume_set_in_flight(ctx, 2) == PLUME_OK && plume_set_in_flight(ctx, 1) == PLUME_OK && plume_set_in_flight(ctx, 0) == PLUME_ERR_ARG, "plume_set_in_flight");
             CHECK(plume_verify_batch(ctx, 2, N, msgs, off, pk, nul, c, s, NULL, NULL, ok) == PLUME_OK && ok[0] == 1 && plume_last_redo_tasks(ctx, &redone) == PLUME_OK && redone == 0, "honest batches file no redo task");
             CHECK(plume_shard_numa_node(ctx, 0) == -1, "a single-device context has no worker thread");
         } else {

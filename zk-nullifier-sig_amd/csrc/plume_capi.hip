@@ -121,6 +121,11 @@ struct plume_ctx {
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
     FixedTables* fixed = nullptr;                                 // this device's shared generator tables (g_fixed)
+    // batches in flight (plume_set_in_flight): device-resident calls are dealt out in turn to this context and to `lanes`, complete single-device contexts of their own
+    // (workspace, streams, events; the fixed tables are shared), so that calls the caller issues on DIFFERENT streams run side by side instead of queueing for one workspace
+    std::vector<plume_ctx*> lanes;
+    size_t lane_next = 0;
+    plume_ctx* lane_last = nullptr;                               // the lane the last device-resident call went to (plume_last_stage_times, plume_last_redo_tasks)
     DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo;
     DevBuf dec[4], preflags;
     DevBuf agg[15];      // aggregate check (plume_aggregate.h): haff, scal, flags, gs, hash_ok, counters, count, sort tiles, sorted, bsum, bsuminf, red, redinf, ssum, perm + its histogram
@@ -134,6 +139,14 @@ static int bind(plume_ctx* ctx) {
     if (!ctx->shards.empty()) return fail(PLUME_ERR_ARG, "device-resident entry points need a single-device context (plume_init): device pointers belong to one GPU");
     HIPCHK(hipSetDevice(ctx->device));
     return 0;
+}
+// the lane a device-resident call runs on: the context itself, or one of its in-flight lanes in turn
+static plume_ctx* route(plume_ctx* ctx) {
+    if (!ctx || ctx->lanes.empty()) { if (ctx) ctx->lane_last = ctx; return ctx; }
+    const size_t k = ctx->lanes.size() + 1, i = ctx->lane_next++ % k;
+    plume_ctx* t = i == 0 ? ctx : ctx->lanes[i - 1];
+    ctx->lane_last = t;
+    return t;
 }
 // Workspace ordering for the device-resident entry points: every call leaves ws_free behind its last kernel, and the next call's stream
 // waits on it first.  Calls on one stream are ordered anyway; this makes calls on DIFFERENT streams of one context safe too.
@@ -172,6 +185,8 @@ extern "C" const char* plume_last_error(void) { return g_err.c_str(); }
 extern "C" const char* plume_version(void) { return "plume_hip 0.3 gfx950 build=" PLUME_BUILD_ID; }
 
 static void destroy_single(plume_ctx* ctx) {
+    for (plume_ctx* l : ctx->lanes) destroy_single(l);
+    ctx->lanes.clear();
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->up) (void)hipStreamSynchronize(ctx->up);
@@ -444,6 +459,7 @@ extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
     if (!ctx || max_items == 0 || max_items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_chunk: bad argument");
     ctx->chunk = max_items;
     for (plume_ctx* sh : ctx->shards) sh->chunk = max_items;
+    for (plume_ctx* l : ctx->lanes) l->chunk = max_items;
     return 0;
 }
 
@@ -452,6 +468,28 @@ extern "C" int plume_set_sub_batches(plume_ctx* ctx, int sub_batches) {
     if (!ctx || sub_batches < 1 || sub_batches > kMaxSubBatches) return fail(PLUME_ERR_ARG, "plume_set_sub_batches: bad argument");
     ctx->sub_batches = sub_batches;
     for (plume_ctx* sh : ctx->shards) sh->sub_batches = sub_batches;
+    for (plume_ctx* l : ctx->lanes) l->sub_batches = sub_batches;
+    return 0;
+}
+
+// Batches in flight: with k > 1 the device-resident calls of this context go in turn to k lanes -- the context itself and k - 1 further single-device contexts of its own
+// (each with its workspace, streams and events; the generator's fixed tables are shared) -- so that calls the caller issues on DIFFERENT streams run side by side instead
+// of queueing for one workspace: the memory-bound table passes and the ramps / tails of one batch's kernels fit beside the issue-bound multi-scalar kernel of another
+// (2^20 verifies: 20.1 instead of 20.8 ms per batch with two in flight, 2^16: 1.37 instead of 1.77 ms; three gain nothing more).  Results do not depend on it.  Calls on ONE
+// stream stay in that stream's order whatever k is.  Default 1.
+extern "C" int plume_set_in_flight(plume_ctx* ctx, int batches) {
+    if (!ctx || batches < 1 || batches > 4) return fail(PLUME_ERR_ARG, "plume_set_in_flight: bad argument");
+    if (!ctx->shards.empty()) return fail(PLUME_ERR_ARG, "plume_set_in_flight: a multi-device context runs its shards side by side already");
+    while ((int)ctx->lanes.size() + 1 > batches) { destroy_single(ctx->lanes.back()); ctx->lanes.pop_back(); }
+    while ((int)ctx->lanes.size() + 1 < batches) {
+        plume_ctx* l = new plume_ctx();
+        l->device = ctx->device;
+        if (int rc = init_single(l)) { const std::string keep = g_err; destroy_single(l); g_err = keep; return rc; }
+        l->chunk = ctx->chunk; l->sub_batches = ctx->sub_batches; l->overlap_min = ctx->overlap_min;
+        l->jobs_per_lane = ctx->jobs_per_lane; l->jobs_per_lane_forced = ctx->jobs_per_lane_forced;
+        ctx->lanes.push_back(l);
+    }
+    ctx->lane_next = 0; ctx->lane_last = nullptr;
     return 0;
 }
 
@@ -628,6 +666,7 @@ static int args_ok(int version, size_t n, const void* msgs, const void* off) {
 extern "C" int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                          const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point,
                                          const uint8_t* hashed_to_curve_r, uint8_t* ok, void* stream) {
+    ctx = route(ctx);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk || !nullifier || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
@@ -640,6 +679,7 @@ extern "C" int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n, 
 extern "C" int plume_verify_non_zk_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                                 const uint8_t* pk, const uint8_t* nullifier, const uint8_t* s, const uint8_t* r_point,
                                                 const uint8_t* hashed_to_curve_r, const uint8_t* digest_private, uint8_t* ok, void* stream) {
+    ctx = route(ctx);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk || !nullifier || !s || !r_point || !hashed_to_curve_r || !digest_private || !ok)) return fail(PLUME_ERR_ARG, "null array");
@@ -674,6 +714,7 @@ static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8
 extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                               const uint8_t* pk33, const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s, const uint8_t* r_point33,
                                               const uint8_t* hashed_to_curve_r33, uint8_t* ok, void* stream) {
+    ctx = route(ctx);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk33 || !nullifier33 || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
@@ -684,6 +725,7 @@ extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_
 extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
                                        const uint8_t* r, const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point,
                                        uint8_t* hashed_to_curve_r, uint8_t* status, void* stream) {
+    ctx = route(ctx);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
@@ -694,6 +736,7 @@ extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, co
 extern "C" int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
                                             const uint8_t* r, const uint8_t* pk_in, uint8_t* pk33, uint8_t* nullifier33, uint8_t* c, uint8_t* s, uint8_t* r_point33,
                                             uint8_t* hashed_to_curve_r33, uint8_t* status, void* stream) {
+    ctx = route(ctx);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier33 || !c || !s || !r_point33 || !hashed_to_curve_r33 || !status)) return fail(PLUME_ERR_ARG, "null array");
@@ -703,6 +746,7 @@ extern "C" int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t 
 
 extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
                                                 uint8_t* h_out, void* stream) {
+    ctx = route(ctx);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
     if (n && !h_out) return fail(PLUME_ERR_ARG, "null array");
@@ -741,6 +785,7 @@ extern "C" int plume_h2c_hints_batch_device(plume_ctx* ctx, size_t n, const uint
     return h2c_inter_device(ctx, n, msgs, msg_off, msgs_bytes, pk, registers, nullptr, nullptr, nullptr, nullptr, hints, stream);
 }
 extern "C" int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status, void* stream) {
+    ctx = route(ctx);
     if (int rc = bind(ctx)) return rc;
     if (n && (!scalars || !der109 || !status)) return fail(PLUME_ERR_ARG, "null array");
     if (n > 0xFFFFFFF0u) return fail(PLUME_ERR_ARG, "n too large");
@@ -753,6 +798,7 @@ extern "C" int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, 
     return 0;
 }
 extern "C" int plume_registers_from_be_device(plume_ctx* ctx, size_t nvalues, const uint8_t* be32, uint64_t* registers, void* stream) {
+    ctx = route(ctx);
     if (int rc = bind(ctx)) return rc;
     if (nvalues && (!be32 || !registers)) return fail(PLUME_ERR_ARG, "null array");
     if (nvalues == 0) return 0;
@@ -860,6 +906,7 @@ static const uint8_t* agg_seed(const uint8_t* seed, uint8_t drawn[32]) {
 extern "C" int plume_aggregate_check_device(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
                                             const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
                                             const uint8_t seed[32], uint64_t index_base, uint8_t* hash_ok, uint8_t* result, void* stream) {
+    ctx = route(ctx);
     if (int rc = bind(ctx)) return rc;
     if (int rc = agg_args_ok(version, mode, n, msgs, msg_off, seed)) return rc;
     if (!result || (n && (!pk || !nullifier || !c || !s || !r_point || !hashed_to_curve_r))) return fail(PLUME_ERR_ARG, "null array");
@@ -890,6 +937,7 @@ static int dedup_device(plume_ctx* ctx, size_t n, const uint8_t* nul, const uint
 }
 extern "C" int plume_nullifier_first_occurrence_device(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live, const uint64_t* ids, uint8_t* first,
                                                        uint64_t* n_unique, void* stream) {
+    ctx = route(ctx);
     if (int rc = bind(ctx)) return rc;
     if (n && (!nullifier || !first)) return fail(PLUME_ERR_ARG, "null array");
     return dedup_device(ctx, n, nullifier, live, ids, first, n_unique, stream ? (hipStream_t)stream : ctx->stream);
@@ -994,6 +1042,7 @@ static std::vector<size_t> piece_schedule(const plume_ctx* ctx, size_t n, bool o
 
 template <class Up, class Run, class Down>
 static int host_pipeline(plume_ctx* ctx, size_t n, bool out_heavy, Up up, Run run, Down down) {
+    ctx->lane_last = nullptr;            // host-pointer calls run on the context itself: its own stage timer is the one to report
     const std::vector<size_t> sched = piece_schedule(ctx, n, out_heavy);
     struct { HostSlot* sl = nullptr; size_t i0 = 0, cnt = 0; } prev;
     auto drain = [&]() -> int {
@@ -1377,6 +1426,7 @@ extern "C" int plume_registers_from_be(size_t nvalues, const uint8_t* be32, uint
 // ------------------------------------------------------------------------------------------------ measurement
 extern "C" int plume_last_stage_times(plume_ctx* ctx, const char** names, float* ms, int cap) {
     if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];   // a multi-device context reports its first shard
+    if (ctx && ctx->lane_last) ctx = ctx->lane_last;           // ... a context with batches in flight the lane of its last device-resident call
     if (int rc = bind(ctx)) return rc;
     StageTimer& t = ctx->timer;
     const int ns = (int)t.names.size();
@@ -1395,6 +1445,7 @@ extern "C" int plume_last_stage_times(plume_ctx* ctx, const char** names, float*
 // (0 for honest batches; crafted items -- pk = +-k G with small k and s = +-c -- file one or two tasks each).  Synchronises with the device.
 extern "C" int plume_last_redo_tasks(plume_ctx* ctx, uint64_t* count) {
     if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
+    if (ctx && ctx->lane_last) ctx = ctx->lane_last;
     if (int rc = bind(ctx)) return rc;
     if (!count) return fail(PLUME_ERR_ARG, "null argument");
     HIPCHK(hipDeviceSynchronize());
