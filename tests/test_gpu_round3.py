@@ -379,3 +379,47 @@ def test_contexts_of_one_device_share_the_fixed_tables_and_outlive_each_other(en
     exp = synth.expected_ok(n, 77)
     assert np.array_equal(oks[0].cpu().numpy(), exp) and np.array_equal(oks[1].cpu().numpy(), exp)
     c.close()
+
+
+def test_batches_in_flight_do_not_change_results(eng):
+    """plume_set_in_flight(ctx, 2): device-resident calls go in turn to two lanes of the context; issued on two streams they run side by side.  Verdicts and signatures are
+    those of the one-lane context, the stage times of the last call stay readable, and the knob can be turned back"""
+    import torch
+    n = 5000
+    b = synth.sign_inputs(n, start=901)
+    want = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    v = synth.corrupt_for_verify(1, b, want, start=901)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(np.ascontiguousarray(v[k])).to(dev) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+    off = torch.from_numpy(v["off"].view(np.int64)).to(dev)
+    sk, r = torch.from_numpy(b["sk"]).to(dev), torch.from_numpy(b["r"]).to(dev)
+    msgs_s, off_s = torch.from_numpy(b["msgs"]).to(dev), torch.from_numpy(b["off"].view(np.int64)).to(dev)
+    exp = synth.expected_ok(n, 901)
+    st = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    try:
+        for k in (2, 3):
+            eng.set_in_flight(k)
+            oks = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(k)]
+            outs = [{f: torch.zeros((n, w), dtype=torch.uint8, device=dev) for f, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]} for _ in range(k)]
+            status = [torch.ones(n, dtype=torch.uint8, device=dev) for _ in range(k)]
+            for i in range(3 * k):
+                j = i % k
+                eng.verify_batch_device(1, n, t["msgs"], off, int(v["off"][-1]), t["pk"], t["nullifier"], t["c"], t["s"], t["r_point"], t["hashed_to_curve_r"], oks[j], stream=st[j])
+            for i in range(k):
+                o = outs[i]
+                eng.sign_batch_device(1, n, msgs_s, off_s, int(b["off"][-1]), sk, r, None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], status[i], stream=st[i])
+            torch.cuda.synchronize()
+            assert len(eng.last_stage_times()) >= 4
+            for j in range(k):
+                assert np.array_equal(oks[j].cpu().numpy(), exp), (k, j)
+                assert not bool(status[j].any())
+                assert all(np.array_equal(outs[j][f].cpu().numpy(), want[f]) for f in outs[j]), (k, j)
+        with pytest.raises(Exception):
+            eng.set_in_flight(0)
+    finally:
+        eng.set_in_flight(1)
+    ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    eng.verify_batch_device(1, n, t["msgs"], off, int(v["off"][-1]), t["pk"], t["nullifier"], t["c"], t["s"], t["r_point"], t["hashed_to_curve_r"], ok)
+    torch.cuda.synchronize()
+    assert np.array_equal(ok.cpu().numpy(), exp)
