@@ -492,7 +492,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(F if F > 1 else 0):      # every lane allocates its workspace on its first call: keep that out of the timed region whatever --warmup is (untimed, not counted as warm-up)
+    for i in range(F):                      # every lane allocates its workspace on its first call: keep that out of the timed region whatever --warmup is (untimed, not counted as warm-up)
         step(i)
     for i in range(a.warmup):
         step(i)
