@@ -49,6 +49,15 @@ def fe_op(op, a, b=None):
     return from_limbs(out)
 
 
+def fe_raw(op, a, b=None, c=None, e=None):
+    """products on raw 9 x 29-bit limb vectors (lists of 9 ints per element, any magnitude the contract allows) -> raw result limbs"""
+    n = len(a)
+    arrs = [np.ascontiguousarray(np.array(v if v is not None else [[0] * 9] * n, dtype=np.uint32).reshape(n, 9)) for v in (a, b, c, e)]
+    out = np.zeros((n, 9), dtype=np.uint32)
+    lib().ds_fe_raw(C.c_int(op), C.c_size_t(n), *[_p(x, u32p) for x in arrs], _p(out, u32p))
+    return [[int(w) for w in row] for row in out]
+
+
 def sc_op(op, a, b=None):
     A = to_limbs(a)
     Bm = to_limbs(b if b is not None else [0] * len(a))

@@ -60,6 +60,26 @@ void ds_fe_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32
         fe_to_words(out + 8 * i, r);
     }
 }
+// The products on RAW limbs (9 words per operand, NOT canonical: whatever magnitudes the caller's contract allows) -> raw result limbs, so that a test can drive the
+// column sums to their bounds and look at the tightness of what comes back.  op: 0 fe_mul(a, b), 1 fe_sqr(a), 2 fe_muladd(a, b, c, e), 3 fe_mul_sub<2>(a, b, c), 4 fe_sqr_sub<4>(a, c),
+// 5 fe_sqr_sub2<2>(a, c), 6 fe_sqr3(a), 7 fe_sqr2(a)
+void ds_fe_raw(int op, size_t count, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* e, uint32_t* out) {
+    for (size_t i = 0; i < count; i++) {
+        fe x, y, z, w, r = fe_zero();
+        for (int k = 0; k < 9; k++) { x.v[k] = a[9 * i + k]; y.v[k] = b[9 * i + k]; z.v[k] = c[9 * i + k]; w.v[k] = e[9 * i + k]; }
+        switch (op) {
+            case 0: fe_mul(r, x, y); break;
+            case 1: fe_sqr(r, x); break;
+            case 2: fe_muladd(r, x, y, z, w); break;
+            case 3: fe_mul_sub<2>(r, x, y, z); break;
+            case 4: fe_sqr_sub<4>(r, x, z); break;
+            case 5: fe_sqr_sub2<2>(r, x, z); break;
+            case 6: fe_sqr3(r, x); break;
+            case 7: fe_sqr2(r, x); break;
+        }
+        for (int k = 0; k < 9; k++) out[9 * i + k] = r.v[k];
+    }
+}
 // op: 0 mul, 1 add, 2 neg, 3 reduce of 512-bit a|b (a low)
 void ds_sc_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     for (size_t i = 0; i < count; i++) {

@@ -60,6 +60,50 @@ def test_fe_arith():
             assert g == fn(x, y) % P, (op, hex(x), hex(y), hex(g))
 
 
+def test_products_at_their_operand_bounds_come_back_tight():
+    """Round 4: the product's top columns run first (gen_fe_mul.py), so the excess over 2^256 is folded into limbs 0..2 before they are formed and limb 8 takes a
+    remainder at the end.  Drive the column sums to the contract's bounds (plume_field.h: tight = limbs <= 2^29 + 2^19, limb 8 <= 2^24 + 2^10; multiplication inputs up
+    to 9 * max(a) * max(b) < 2^64 - 2^50 with limb 8 <= 2^26) and check value and tightness of every form; the host build asserts the intermediate bounds."""
+    val = lambda L: sum(x << (29 * i) for i, x in enumerate(L))
+    tight = lambda L: all(x <= 2**29 + 2**19 for x in L[:8]) and L[8] <= 2**24 + 2**10
+    T = 2**29 + 2**19
+    rng = random.Random(44)
+    big = int(((2**64 - 2**50) // 9) ** 0.5) - 1                       # both operands at the square root of the bound (~1.33 * 2^30)
+    shapes = [([T] * 8 + [2**24 + 2**10], [T] * 8 + [2**24 + 2**10]), ([big] * 8 + [2**26], [big] * 8 + [2**26]), ([2**31 - 1] * 8 + [2**26], [T] * 8 + [2**26]),
+              ([0] * 9, [big] * 8 + [2**26]), ([big] * 8 + [0], [0] * 8 + [2**26])]
+    for _ in range(200):
+        m = rng.choice([T, big, 2**29 - 1])
+        shapes.append(([rng.randrange(m + 1) for _ in range(8)] + [rng.randrange(2**26 + 1)], [rng.randrange(m + 1) for _ in range(8)] + [rng.randrange(2**26 + 1)]))
+    a, b = [s[0] for s in shapes], [s[1] for s in shapes]
+    for got, x, y in zip(D.fe_raw(0, a, b), a, b):
+        assert tight(got) and val(got) % P == val(x) * val(y) % P
+    sq = [x for x in a if max(x[:8]) <= big]
+    for got, x in zip(D.fe_raw(1, sq), sq):
+        assert tight(got) and val(got) % P == val(x) ** 2 % P
+    # tight operands for the scaled squarings; subtrahends up to 2p / 4p limbwise for the fused forms
+    ta = [x for x in a if tight(x)] + [[rng.randrange(T + 1) for _ in range(8)] + [rng.randrange(2**24 + 2**10 + 1)] for _ in range(100)]
+    for op, f in [(6, 3), (7, 2)]:
+        for got, x in zip(D.fe_raw(op, ta), ta):
+            assert tight(got) and val(got) % P == f * val(x) ** 2 % P
+    p_l = [0x1FFFFC2F, 0x1FFFFFF7] + [0x1FFFFFFF] * 6 + [0x00FFFFFF]
+    sub2 = [[rng.choice([0, 2 * q, rng.randrange(2 * q + 1)]) for q in p_l] for _ in a]
+    sub4 = [[rng.choice([0, 4 * q, rng.randrange(4 * q + 1)]) for q in p_l] for _ in a]
+    for got, x, y, s in zip(D.fe_raw(3, a, b, sub2), a, b, sub2):
+        assert tight(got) and val(got) % P == (val(x) * val(y) - val(s)) % P
+    for got, x, s in zip(D.fe_raw(4, sq, None, sub4[:len(sq)]), sq, sub4):
+        assert tight(got) and val(got) % P == (val(x) ** 2 - val(s)) % P
+    for got, x, s in zip(D.fe_raw(5, sq, None, sub2[:len(sq)]), sq, sub2):
+        assert tight(got) and val(got) % P == (val(x) ** 2 - 2 * val(s)) % P
+    # two products, one fold: the doubling's Y' at its bound (E * (D - X') + (-B) * 2B: 2^29 * 3 * 2^29 + 2^30 * 2^30 per column term)
+    e1, e2, e3, e4 = [T] * 8 + [2**24], [3 * 2**29 + 2**19] * 8 + [2**26], [2**30 - 2000] * 8 + [2**25], [2**30 + 2**20] * 8 + [2**25]
+    qa = [e1] + [[rng.randrange(v + 1) for v in e1] for _ in range(100)]
+    qb = [e2] + [[rng.randrange(v + 1) for v in e2] for _ in range(100)]
+    qc = [e3] + [[rng.randrange(v + 1) for v in e3] for _ in range(100)]
+    qe = [e4] + [[rng.randrange(v + 1) for v in e4] for _ in range(100)]
+    for got, x, y, z, w in zip(D.fe_raw(2, qa, qb, qc, qe), qa, qb, qc, qe):
+        assert tight(got) and val(got) % P == (val(x) * val(y) + val(z) * val(w)) % P
+
+
 def test_fe_inv_pow():
     rng = random.Random(2)
     a = [1, 2, P - 1, P + 1, 2**256 - 1, PC] + [rng.randrange(1, 2**256) for _ in range(40)]

@@ -113,7 +113,7 @@ PLUME_HD uint32_t subb0(uint32_t a, uint32_t& bw) { return subb(a, opaque_zero()
 //
 // Limb bounds ("magnitudes") are the caller's contract, checked by assertions in host builds with PLUME_FE_CHECK:
 //   tight      limbs 0..7 <= 2^29 + 2^19, limb 8 <= 2^24 + 2^10        what fe_mul / fe_sqr / fe_carry / fe_add / fe_sub return
-//   fe_mul, fe_sqr inputs: 9 * max(a[0..7]) * max(b[0..7]) < 2^64 - 2^50 and limb 8 <= 2^27 on both sides, i.e. both
+//   fe_mul, fe_sqr inputs: 9 * max(a[0..7]) * max(b[0..7]) < 2^64 - 2^50 and limb 8 <= 2^26 on both sides, i.e. both
 //              operands up to ~1.3 * 2^30 (sums of two tight values), or one up to 2^31 and the other tight
 //   fe_add_lazy / fe_sub_lazy<M> return unreduced sums: limb bounds add (a + M*p - b), no carry pass
 //   fe_normalize gives the canonical representative (limbs < 2^29, value < p) where one is needed (comparisons, parity,
@@ -144,7 +144,7 @@ PLUME_HD bool fe_is_tight(const fe& a) {
 PLUME_HD bool fe_mul_inputs_ok(const fe& a, const fe& b) {
     uint64_t ma = 0, mb = 0;
     PLUME_UNROLL for (int i = 0; i < 8; i++) { if (a.v[i] > ma) ma = a.v[i]; if (b.v[i] > mb) mb = b.v[i]; }
-    if (a.v[8] > (1u << 27) || b.v[8] > (1u << 27) || ma >= (1ull << 31) || mb >= (1ull << 31)) return false;
+    if (a.v[8] > (1u << 26) || b.v[8] > (1u << 26) || ma >= (1ull << 31) || mb >= (1ull << 31)) return false;   // limb 8: the product's top column takes h[8] << 8 on its high word (gen_fe_mul.py)
     const uint64_t prod = ma * mb;                                     // < 2^62
     return prod < ((0xFFFFFFFFFFFFFFFFull - (1ull << 50)) / 9);
 }
@@ -257,21 +257,10 @@ PLUME_HD bool words_lt_p(const uint32_t w[8]) {
     return c == 0;
 }
 
-// r = 2a limbwise, no carry pass.  hipcc turns a + a into v_lshlrev_b32, which the issue-rate probe puts at the multiply-add's cost on gfx950.
-// Forcing a plain-rate v_add_u32 through inline asm (-DPLUME_DBL_BY_ADD=1) was measured 0.9 % SLOWER on the multi-scalar kernel (r02 A/B, same box:
-// 20.0 vs 19.9 ms): the asm statement costs the compiler its folding of the doubling into neighbouring v_lshl_add / v_add3 forms.  Kept as the experiment's record.
-#ifndef PLUME_DBL_BY_ADD
-#define PLUME_DBL_BY_ADD 0
-#endif
-PLUME_HD uint32_t u32_dbl(uint32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__) && PLUME_DBL_BY_ADD
-    uint32_t r;
-    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
-    return r;
-#else
-    return x + x;
-#endif
-}
+// r = 2a limbwise, no carry pass.  hipcc turns a + a into v_lshlrev_b32, which the issue-rate probe puts at the multiply-add's cost on gfx950.  Naming v_add_u32 instead
+// (plain-rate by the same probe) bought nothing either time it was tried: for every doubling (round 2: -0.9 %, the asm statement blocks the compiler's v_lshl_add_u32 /
+// v_add3_u32 fusions) and for the squarings' doubled limbs only (round 4: multi-scalar kernel 15.505 vs 15.504 ms on one box).  LABNOTES.md.
+PLUME_HD uint32_t u32_dbl(uint32_t x) { return x + x; }
 PLUME_HD void fe_dbl_lazy(fe& r, const fe& a) {
     PLUME_UNROLL for (int i = 0; i < 9; i++) { PLUME_FE_ASSERT((uint64_t)a.v[i] * 2 < (1ull << 32)); r.v[i] = u32_dbl(a.v[i]); }
 }
