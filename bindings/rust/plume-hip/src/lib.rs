@@ -15,7 +15,7 @@
 use k256::elliptic_curve::sec1::{FromEncodedPoint, ToEncodedPoint};
 use k256::elliptic_curve::rand_core::CryptoRngCore;
 use k256::{AffinePoint, EncodedPoint, FieldBytes, NonZeroScalar, SecretKey};
-use std::os::raw::{c_char, c_int};
+use std::os::raw::{c_char, c_int, c_void};
 
 /// `plume_rustcrypto::PlumeSignatureV1Fields` (rust-k256/src/lib.rs:84-89)
 #[derive(Clone, Debug, PartialEq)]
@@ -69,8 +69,8 @@ extern "C" {
     fn plume_num_shards(ctx: *const plume_ctx) -> c_int;
     fn plume_destroy(ctx: *mut plume_ctx);
     fn plume_last_error() -> *const c_char;
-    fn plume_host_register(p: *mut u8, bytes: usize) -> c_int;
-    fn plume_host_unregister(p: *mut u8) -> c_int;
+    fn plume_host_register(p: *mut c_void, bytes: usize) -> c_int;
+    fn plume_host_unregister(p: *mut c_void) -> c_int;
     fn plume_verify_batch(ctx: *mut plume_ctx, version: c_int, n: usize, msgs: *const u8, msg_off: *const u64,
         pk: *const u8, nullifier: *const u8, c: *const u8, s: *const u8, r_point: *const u8, hashed_to_curve_r: *const u8, ok: *mut u8) -> c_int;
     fn plume_verify_batch_sec1(ctx: *mut plume_ctx, version: c_int, n: usize, msgs: *const u8, msg_off: *const u64,
@@ -285,8 +285,8 @@ impl HipEngine {
 
     /// Page-lock a long-lived buffer once (`plume_host_register`): the copy engines then read / write it directly and the library's
     /// upload / compute / download pipeline overlaps fully.  Pair with `unpin`.
-    pub fn pin(buf: &mut [u8]) -> Result<(), HipError> { if unsafe { plume_host_register(buf.as_mut_ptr(), buf.len()) } == 0 { Ok(()) } else { Err(last_error()) } }
-    pub fn unpin(buf: &mut [u8]) -> Result<(), HipError> { if unsafe { plume_host_unregister(buf.as_mut_ptr()) } == 0 { Ok(()) } else { Err(last_error()) } }
+    pub fn pin(buf: &mut [u8]) -> Result<(), HipError> { if unsafe { plume_host_register(buf.as_mut_ptr() as *mut c_void, buf.len()) } == 0 { Ok(()) } else { Err(last_error()) } }
+    pub fn unpin(buf: &mut [u8]) -> Result<(), HipError> { if unsafe { plume_host_unregister(buf.as_mut_ptr() as *mut c_void) } == 0 { Ok(()) } else { Err(last_error()) } }
 }
 
 // ------------------------------------------------------------------------------------------------ the reference's single-item surface

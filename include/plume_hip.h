@@ -45,9 +45,12 @@ typedef struct plume_ctx plume_ctx;
                                           (device-resident calls) message offsets that decrease or reach past msgs_bytes */
 #define PLUME_STATUS_IDENTITY 4        /* H == identity (randomizedsigner.rs:61) or s == 0 (randomizedsigner.rs:95) */
 
-/* Create a context bound to HIP device `device_id` (>= 0).  Builds the generator's fixed tables on the device: (1..2^23)*G for the verifier's 24-bit windows (1 GiB)
- * and the signer's doubling-free comb, 15 windows of 2^17 rows (252 MiB) -- about 18 ms and 1.25 GiB of HBM, ONCE per device and process: the tables are read-only and every
- * context of the process on that device shares them (a further context takes ~1.5 ms and its per-batch workspace only; the last one to go frees them). */
+/* Create a context bound to HIP device `device_id` (>= 0): streams, events and a small scratch area; about 1.5 ms.  The generator's fixed tables are built by the first call
+ * that needs them, ONCE per device and process -- (1..2^23)*G for the verifier's 24-bit windows (1 GiB, first verify / verify_non_zk call) and the signer's doubling-free
+ * comb, 15 windows of 2^17 rows (252 MiB, first sign / SEC1-DER export / aggregate check) -- about 18 ms for both, synchronously inside that call.  They are read-only and
+ * shared by every context of the process on that device; the last context to go frees them.  A verify-only process never holds the comb, a sign-only one never the 1 GiB table.
+ * plume_destroy (and plume_set_in_flight when it takes lanes away) waits for the whole device (hipDeviceSynchronize) before releasing anything: device-resident calls may
+ * have left work on caller streams. */
 int plume_init(plume_ctx** out, int device_id);
 /* Create a multi-device context: one shard (a complete single-device context with its own streams and workspace, driven by its own
  * worker thread) per entry of device_ids (SURVEY.md §8b sketch, §8e).  Every HOST-POINTER entry point below then splits its batch
@@ -75,13 +78,14 @@ int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
  * strictly serial launch order on the caller's stream, which is also the mode in which plume_last_stage_times reports one time per kernel:
  * on the MI355X the overlapped order measured 1-3 % SLOWER than the serial one (round 3, DESIGN.md §6: kernels of two streams sharing the
  * compute units cost more than the table kernel's idle issue slots give back), so the knob is an experiment's record, not a recommendation.
- * Env PLUME_SUB_BATCHES=k sets the default of new contexts, PLUME_SERIAL=1 forces 1. */
+ * Env PLUME_SUB_BATCHES=k sets the default of new contexts, PLUME_SERIAL=1 forces 1 (and wins when both are set). */
 int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
 /* Batches in flight (default 1).  A context runs its device-resident calls one at a time: they share its workspace, so calls issued on different streams queue.  With
  * batches = 2 the calls go in turn to two lanes of the context (each with a workspace, streams and events of its own; the generator's fixed tables are shared), and calls the
  * caller issues on DIFFERENT streams run side by side: the memory-bound table passes and the ramps / tails of one batch's kernels fit beside the issue-bound multi-scalar
  * kernel of the other -- 20.1 instead of 20.8 ms per 2^20 verifies, 1.37 instead of 1.77 ms per 2^16 on the MI355X; a third lane gains nothing more (1..4 accepted).
- * Results do not depend on it; calls on one stream keep that stream's order.  Costs a second per-batch workspace.  Single-device contexts only (a multi-device context
+ * Results do not depend on it; calls on one stream keep that stream's order -- including NULL, which always means the stream of the context the caller holds,
+ * whichever lane serves the call (so a sign followed by a verify of its outputs, both with stream = NULL, stay ordered).  Costs a second per-batch workspace.  Single-device contexts only (a multi-device context
  * already runs its shards side by side).  plume_last_stage_times / plume_last_redo_tasks then report the lane of the last device-resident call. */
 int plume_set_in_flight(plume_ctx* ctx, int batches);
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (three streams,

@@ -40,6 +40,36 @@ for k, d in out.items():
     if isinstance(d, dict) and "SQ_ACTIVE_INST_VALU" in d and d.get("GRBM_GUI_ACTIVE"):
         # rocprof's derived VALUBusy: 4 cycles per wave64 VALU instruction, 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
         d["VALUBusy"] = round(d["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (d["GRBM_GUI_ACTIVE"] / 8), 3)
+for k, d in out.items():
+    if isinstance(d, dict) and d.get("GRBM_GUI_ACTIVE") and d.get("_dur_ns_max"):
+        d["clock_ghz"] = round(d["GRBM_GUI_ACTIVE"] / 8 / d["_dur_ns_max"], 3)       # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the counter pass's own launch duration
+
+
+def isa_mad_share(path):
+    """share of v_mad_u64_u32 among the VALU instructions the multi-scalar kernels execute, from the ISA mix of their loop bodies (profiles/isa_mix.py output): the two largest
+    blocks of a kernel's section are the mixed-addition body and the doubling body; a verify lane runs 128 doublings and ~98 additions (78 / 132 slots per equation, 15/16 non-zero),
+    a signer lane 128 doublings and ~124 additions"""
+    share, cur, blocks = {}, None, {}
+    try:
+        lines = open(path).read().splitlines()
+    except OSError:
+        return share
+    for ln in lines + ["# end: 0 basic blocks"]:
+        if ln.startswith("# ") and "basic blocks" in ln:
+            if cur and len(blocks) >= 2:
+                top = sorted(blocks.values(), key=lambda t: -t[0])[:2]          # (mad64, VALU): addition body first, doubling body second
+                w_add = 124.0 if "sign" in cur else 98.5
+                mad = w_add * top[0][0] + 128.0 * top[1][0]
+                valu = w_add * top[0][1] + 128.0 * top[1][1]
+                share["plume::" + cur] = round(mad / valu, 4)
+            cur, blocks = ln[2:].split(":")[0].strip(), {}
+        elif cur and ln[:1] in "._e" and len(ln.split()) >= 12 and ln.split()[1].isdigit():
+            f = ln.split()
+            blocks[f[0]] = (int(f[1]), int(f[-2]))
+    return share
+
+
+out["_isa_mad_share"] = isa_mad_share(f"profiles/{rnd}_isa_mix.txt")
 try:
     out["_build"] = open(f"gpurun_out/build_{rnd}.txt").read().strip()      # plume_version() of the library the counters were collected from (bench.py compares it with its own)
 except OSError:

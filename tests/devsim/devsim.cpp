@@ -373,7 +373,7 @@ void ds_aggregate_combine(const uint8_t* records, uint32_t m, uint8_t* result) {
 int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,
                   uint8_t* pk, uint8_t* nul, uint8_t* c, uint8_t* s, uint8_t* rpt, uint8_t* hr, uint8_t* h_out, uint8_t* status, int L) {
     if (version != 1 && version != 2) return -1;
-    std::vector<uint32_t> gtab; build_gtab(gtab);
+    // (the signer reads the comb only)
     const std::vector<uint32_t>& gcomb = shared_gcomb();
     std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_BASE_WORDS * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
     std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(n), itemflags(n);
@@ -381,7 +381,7 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msg_off[n]; a.sk = sk; a.r = r; a.pk_in = pk_in;
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
     a.gres = gres.data(); a.gresinf = gresinf.data(); a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
-    a.pkaff = pkaff.data(); a.tab = tab.data(); a.hres = hres.data(); a.hresinf = hresinf.data(); a.gtab = gtab.data(); a.gcomb = gcomb.data();
+    a.pkaff = pkaff.data(); a.tab = tab.data(); a.hres = hres.data(); a.hresinf = hresinf.data(); a.gcomb = gcomb.data();
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);
     for (uint32_t w = 0; w < 2; w++)
         for (uint32_t i = 0; i < n; i++) sign_gmul(a, i, w);

@@ -13,7 +13,8 @@
 #include <functional>
 #include <map>
 #include <mutex>
-#include <random>
+#include <cerrno>
+#include <sys/random.h>
 #include <string>
 #include <thread>
 #include <algorithm>
@@ -85,12 +86,14 @@ struct Worker {
     std::string err;
 };
 
-// The generator's fixed tables (the verifier's 2^23-row window table, the signer's comb: 1.25 GiB, 18 ms to build) depend on nothing but G: every context of a process on
-// the same device shares ONE read-only copy, built by the first and freed with the last (a second batch in flight -- a second context -- then costs its workspace only).
+// The generator's fixed tables (the verifier's 2^23-row window table, 1 GiB; the signer's comb, 252 MiB; 18 ms to build both) depend on nothing but G: every context of a
+// process on the same device shares ONE read-only copy, freed with the last context (a second batch in flight -- a second context -- then costs its workspace only).
+// Round 4: each table is built by the first call that needs it (need_gtab: verify, verify_non_zk; need_gcomb: sign, SEC1-DER export, the aggregate check), so a
+// verify-only process never holds the comb, a sign-only one never the 1 GiB window table, and plume_init itself allocates neither.
 struct FixedTables {
     DevBuf gtab, gcomb;
     int refs = 0;
-    bool built = false;
+    bool gtab_built = false, gcomb_built = false;
 };
 static std::mutex g_fixed_mutex;
 static std::map<int, FixedTables> g_fixed;
@@ -140,8 +143,12 @@ static int bind(plume_ctx* ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     return 0;
 }
-// the lane a device-resident call runs on: the context itself, or one of its in-flight lanes in turn
-static plume_ctx* route(plume_ctx* ctx) {
+// The lane a device-resident call runs on -- the context itself, or one of its in-flight lanes in turn -- and the stream it runs on.  The stream is resolved against the
+// context the CALLER holds before the call is dealt out: NULL means "that context's own stream" whichever lane serves the call, so successive NULL-stream calls stay
+// ordered against each other (a sign followed by a verify of its outputs) exactly as they are without lanes.  (Round 3 resolved NULL after routing, i.e. to the lane's
+// private stream, which changes from call to call: ADVICE r3.)  A lane's workspace is guarded by its ws_free event, so running it on a stream it does not own is safe.
+static plume_ctx* route(plume_ctx* ctx, void* stream, hipStream_t& st) {
+    st = stream ? (hipStream_t)stream : (ctx ? ctx->stream : nullptr);
     if (!ctx || ctx->lanes.empty()) { if (ctx) ctx->lane_last = ctx; return ctx; }
     const size_t k = ctx->lanes.size() + 1, i = ctx->lane_next++ % k;
     plume_ctx* t = i == 0 ? ctx : ctx->lanes[i - 1];
@@ -188,18 +195,18 @@ static void destroy_single(plume_ctx* ctx) {
     for (plume_ctx* l : ctx->lanes) destroy_single(l);
     ctx->lanes.clear();
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->up) (void)hipStreamSynchronize(ctx->up);
-    if (ctx->down) (void)hipStreamSynchronize(ctx->down);
-    if (ctx->side) (void)hipStreamSynchronize(ctx->side);
-    if (ctx->pre) (void)hipStreamSynchronize(ctx->pre);
+    (void)hipDeviceSynchronize();   // the context's workspace, events and lanes may still be in use by kernels queued on CALLER streams (device-resident calls run on whatever
+                                    // stream they were given): wait for the whole device, not only for the context's own streams (plume_destroy, plume_set_in_flight shrinking)
     for (DevBuf* b : {&ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
                       &ctx->sink, &ctx->redo, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
     for (DevBuf& b : ctx->agg) b.release();
     if (ctx->fixed) {
         std::lock_guard<std::mutex> lk(g_fixed_mutex);
-        if (--ctx->fixed->refs == 0) { ctx->fixed->gtab.release(); ctx->fixed->gcomb.release(); ctx->fixed->built = false; }
+        if (--ctx->fixed->refs == 0) {
+            (void)hipDeviceSynchronize();          // the tables are read by kernels on CALLER streams too: nothing may still be running when they go
+            ctx->fixed->gtab.release(); ctx->fixed->gcomb.release(); ctx->fixed->gtab_built = ctx->fixed->gcomb_built = false;
+        }
         ctx->fixed = nullptr;
     }
     for (HostSlot& sl : ctx->slot) {
@@ -235,8 +242,8 @@ static int init_single(plume_ctx* ctx) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->pre, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->pre_begin, hipEventDisableTiming));
-    if (const char* e = std::getenv("PLUME_SERIAL")) { if (std::atoi(e) != 0) ctx->sub_batches = 1; }                                  // strictly serial launch order (per-kernel measurements)
     if (const char* e = std::getenv("PLUME_SUB_BATCHES")) { int v = std::atoi(e); if (v >= 1 && v <= kMaxSubBatches) ctx->sub_batches = v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_SERIAL")) { if (std::atoi(e) != 0) ctx->sub_batches = 1; }                                  // ... and PLUME_SERIAL=1 wins over it: strictly serial launch order (per-kernel measurements)
     if (const char* e = std::getenv("PLUME_OVERLAP_MIN")) { long v = std::atol(e); if (v >= 1) ctx->overlap_min = (size_t)v; }         // tuning knob
     for (hipEvent_t& e : ctx->agg_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ws_free, hipEventDisableTiming));
@@ -245,25 +252,41 @@ static int init_single(plume_ctx* ctx) {
         HIPCHK(hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
     }
-    // the generator's tables: the verifier's wide window table (1..2^(W-1))*G and the signer's doubling-free comb, built once on the device, one entry per lane
     if (ctx->sink.ensure((size_t)(1 + PLUME_COMB_WINDOWS) * 2 * PLUME_FE_WORDS * 4 + 512)) return PLUME_ERR_HIP;
     {
-        // built under the lock: contexts created side by side on one device (plume_init_multi's shards, a second batch in flight) wait for the first one's build
         std::lock_guard<std::mutex> lk(g_fixed_mutex);
         FixedTables& ft = g_fixed[ctx->device];
-        if (!ft.built) {
-            if (ft.gtab.ensure((size_t)PLUME_GTAB_WORDS * 4) || ft.gcomb.ensure((size_t)PLUME_COMB_WORDS * 4)) { ft.gtab.release(); ft.gcomb.release(); return PLUME_ERR_HIP; }
-            launch_fixed_tables(ft.gtab.as<uint32_t>(), ft.gcomb.as<uint32_t>(), ctx->sink.as<uint32_t>(), ctx->stream);
-            hipError_t e = hipGetLastError();
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) { ft.gtab.release(); ft.gcomb.release(); return fail(PLUME_ERR_HIP, std::string("fixed tables: ") + hipGetErrorString(e)); }
-            ft.built = true;
-        }
         ft.refs++;
         ctx->fixed = &ft;
     }
     return 0;
 }
+// The generator's tables, built once per device and process on the first call that needs them, one entry per lane (k_fixed_bases + k_fixed_table), under the lock: contexts
+// that meet here side by side (plume_init_multi's shards, a second batch in flight) wait for the first one's build.  The build is synchronous (18 ms for both, once).
+static int need_fixed(plume_ctx* ctx, bool gtab, bool gcomb) {
+    std::lock_guard<std::mutex> lk(g_fixed_mutex);
+    FixedTables& ft = *ctx->fixed;
+    const bool bt = gtab && !ft.gtab_built, bc = gcomb && !ft.gcomb_built;
+    if (!bt && !bc) return 0;
+    if ((bt && ft.gtab.ensure((size_t)PLUME_GTAB_WORDS * 4)) || (bc && ft.gcomb.ensure((size_t)PLUME_COMB_WORDS * 4))) {
+        if (bt) ft.gtab.release();
+        if (bc) ft.gcomb.release();
+        return PLUME_ERR_HIP;
+    }
+    launch_fixed_tables(bt ? ft.gtab.as<uint32_t>() : nullptr, bc ? ft.gcomb.as<uint32_t>() : nullptr, ctx->sink.as<uint32_t>(), ctx->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        if (bt) ft.gtab.release();
+        if (bc) ft.gcomb.release();
+        return fail(PLUME_ERR_HIP, std::string("fixed tables: ") + hipGetErrorString(e));
+    }
+    if (bt) ft.gtab_built = true;
+    if (bc) ft.gcomb_built = true;
+    return 0;
+}
+static int need_gtab(plume_ctx* ctx) { return need_fixed(ctx, true, false); }
+static int need_gcomb(plume_ctx* ctx) { return need_fixed(ctx, false, true); }
 
 static int check_device(int device_id) {
     if (device_id < 0) return fail(PLUME_ERR_ARG, "negative device id");
@@ -556,6 +579,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
                          const uint8_t* preflags = nullptr, bool continue_timer = false, const uint8_t* rpt33 = nullptr, const uint8_t* hr33 = nullptr) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    if (int rc = need_gtab(ctx)) return rc;
     if (!continue_timer) { if (int rc = ws_acquire(ctx, st)) return rc; }     // continue_timer: the caller (SEC1 ingest) holds the workspace already
     std::unique_ptr<WsHold> hold(continue_timer ? nullptr : new WsHold(ctx, st));
     const std::vector<size_t> cut = sub_batch_bounds(ctx, n);
@@ -607,6 +631,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
                        hipStream_t st, bool out33 = false) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    if (int rc = need_gcomb(ctx)) return rc;
     if (int rc = ws_acquire(ctx, st)) return rc;
     WsHold hold(ctx, st);
     const std::vector<size_t> cut = sub_batch_bounds(ctx, n);
@@ -636,7 +661,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
         a.gres = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.gresinf = ctx->resinf.as<uint8_t>() + 2 * lo; a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * lo;
         a.jobflags = ctx->jobflags.as<uint8_t>() + lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo; a.pkaff = ctx->pkaff.as<uint32_t>() + (size_t)2 * PLUME_FE_WORDS * lo;
         a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * lo; a.hres = ctx->res2.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.hresinf = ctx->res2inf.as<uint8_t>() + 2 * lo;
-        a.gtab = ctx->fixed->gtab.as<uint32_t>(); a.gcomb = ctx->fixed->gcomb.as<uint32_t>();
+        a.gcomb = ctx->fixed->gcomb.as<uint32_t>();
         launch_sign_gmul(a, pre); if (!overlapped) t.stage("sign_gmul", st);
         launch_normalize(a.gres, a.gresinf, 2 * cnt, pre); if (!overlapped) t.stage("to_affine_g", st);
         launch_sign_h2c(a, pre); if (!overlapped) t.stage("sign_h2c", st);
@@ -666,25 +691,25 @@ static int args_ok(int version, size_t n, const void* msgs, const void* off) {
 extern "C" int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                          const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point,
                                          const uint8_t* hashed_to_curve_r, uint8_t* ok, void* stream) {
-    ctx = route(ctx);
+    hipStream_t st_; ctx = route(ctx, stream, st_);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk || !nullifier || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
     if (n && version == 1 && (!r_point || !hashed_to_curve_r)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
     return verify_device(ctx, version, PLUME_MODE_VERIFY, n, msgs, msg_off, msgs_bytes, pk, nullifier, c, s, version == 1 ? r_point : nullptr,
-                         version == 1 ? hashed_to_curve_r : nullptr, ok, stream ? (hipStream_t)stream : ctx->stream);
+                         version == 1 ? hashed_to_curve_r : nullptr, ok, st_);
 }
 
 // plume_arkworks' verify_non_zk (rust-arkworks/src/tests.rs:28-78): same pipeline, PLUME_MODE_NON_ZK
 extern "C" int plume_verify_non_zk_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                                 const uint8_t* pk, const uint8_t* nullifier, const uint8_t* s, const uint8_t* r_point,
                                                 const uint8_t* hashed_to_curve_r, const uint8_t* digest_private, uint8_t* ok, void* stream) {
-    ctx = route(ctx);
+    hipStream_t st_; ctx = route(ctx, stream, st_);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk || !nullifier || !s || !r_point || !hashed_to_curve_r || !digest_private || !ok)) return fail(PLUME_ERR_ARG, "null array");
     return verify_device(ctx, version, PLUME_MODE_NON_ZK, n, msgs, msg_off, msgs_bytes, pk, nullifier, digest_private, s, r_point, hashed_to_curve_r, ok,
-                         stream ? (hipStream_t)stream : ctx->stream);
+                         st_);
 }
 
 // SEC1-compressed ingest: decompress on the GPU into the context's 64-byte staging arrays, then the normal pipeline
@@ -714,49 +739,52 @@ static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8
 extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                               const uint8_t* pk33, const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s, const uint8_t* r_point33,
                                               const uint8_t* hashed_to_curve_r33, uint8_t* ok, void* stream) {
-    ctx = route(ctx);
+    hipStream_t st_; ctx = route(ctx, stream, st_);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk33 || !nullifier33 || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
     if (n && version == 1 && (!r_point33 || !hashed_to_curve_r33)) return fail(PLUME_ERR_ARG, "V1 needs r_point and hashed_to_curve_r");
-    return verify_sec1_device(ctx, version, n, msgs, msg_off, msgs_bytes, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, ok, stream ? (hipStream_t)stream : ctx->stream);
+    return verify_sec1_device(ctx, version, n, msgs, msg_off, msgs_bytes, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, ok, st_);
 }
 
 extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
                                        const uint8_t* r, const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point,
                                        uint8_t* hashed_to_curve_r, uint8_t* status, void* stream) {
-    ctx = route(ctx);
+    hipStream_t st_; ctx = route(ctx, stream, st_);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
     return sign_device(ctx, version, n, msgs, msg_off, msgs_bytes, sk, r, pk_in, pk, nullifier, c, s, r_point, hashed_to_curve_r, status, nullptr,
-                       stream ? (hipStream_t)stream : ctx->stream);
+                       st_);
 }
 
 extern "C" int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
                                             const uint8_t* r, const uint8_t* pk_in, uint8_t* pk33, uint8_t* nullifier33, uint8_t* c, uint8_t* s, uint8_t* r_point33,
                                             uint8_t* hashed_to_curve_r33, uint8_t* status, void* stream) {
-    ctx = route(ctx);
+    hipStream_t st_; ctx = route(ctx, stream, st_);
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier33 || !c || !s || !r_point33 || !hashed_to_curve_r33 || !status)) return fail(PLUME_ERR_ARG, "null array");
     return sign_device(ctx, version, n, msgs, msg_off, msgs_bytes, sk, r, pk_in, pk33, nullifier33, c, s, r_point33, hashed_to_curve_r33, status, nullptr,
-                       stream ? (hipStream_t)stream : ctx->stream, true);
+                       st_, true);
 }
 
-extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
-                                                uint8_t* h_out, void* stream) {
-    ctx = route(ctx);
+// unrouted bodies: the host-pointer paths call these on the context itself (host calls never go to a lane: host_pipeline), the extern "C" wrappers route first
+static int h2c_only_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk, uint8_t* h_out, hipStream_t st) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(1, n, msgs, msg_off)) return rc;
     if (n && !h_out) return fail(PLUME_ERR_ARG, "null array");
     if (n == 0) return 0;
     H2cArgs a; a.n = (uint32_t)n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msgs_bytes; a.pk = pk; a.h_out = h_out;
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->timer.begin(st);
     launch_h2c_only(a, st); ctx->timer.stage("h2c_only", st);
     HIPCHK(hipGetLastError());
     return 0;
+}
+extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
+                                                uint8_t* h_out, void* stream) {
+    hipStream_t st_; ctx = route(ctx, stream, st_);
+    return h2c_only_device(ctx, n, msgs, msg_off, msgs_bytes, pk, h_out, st_);
 }
 
 // ------------------------------------------------------------------------------ circuit witness hints
@@ -784,25 +812,28 @@ extern "C" int plume_h2c_hints_batch_device(plume_ctx* ctx, size_t n, const uint
     if (n && !hints) return fail(PLUME_ERR_ARG, "null array");
     return h2c_inter_device(ctx, n, msgs, msg_off, msgs_bytes, pk, registers, nullptr, nullptr, nullptr, nullptr, hints, stream);
 }
-extern "C" int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status, void* stream) {
-    ctx = route(ctx);
+static int der_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status, hipStream_t st) {
     if (int rc = bind(ctx)) return rc;
     if (n && (!scalars || !der109 || !status)) return fail(PLUME_ERR_ARG, "null array");
     if (n > 0xFFFFFFF0u) return fail(PLUME_ERR_ARG, "n too large");
     if (n == 0) return 0;
+    if (int rc = need_gcomb(ctx)) return rc;
     DerArgs a; a.n = (uint32_t)n; a.scalars = scalars; a.der = der109; a.status = status; a.gcomb = ctx->fixed->gcomb.as<uint32_t>();
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     ctx->timer.begin(st);
     launch_scalars_der(a, st); ctx->timer.stage("scalars_to_sec1_der", st);
     HIPCHK(hipGetLastError());
     return 0;
 }
+extern "C" int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status, void* stream) {
+    hipStream_t st_; ctx = route(ctx, stream, st_);
+    return der_device(ctx, n, scalars, der109, status, st_);
+}
 extern "C" int plume_registers_from_be_device(plume_ctx* ctx, size_t nvalues, const uint8_t* be32, uint64_t* registers, void* stream) {
-    ctx = route(ctx);
+    hipStream_t st_; ctx = route(ctx, stream, st_);
     if (int rc = bind(ctx)) return rc;
     if (nvalues && (!be32 || !registers)) return fail(PLUME_ERR_ARG, "null array");
     if (nvalues == 0) return 0;
-    launch_registers_from_be((uint8_t*)registers, be32, nvalues, stream ? (hipStream_t)stream : ctx->stream);
+    launch_registers_from_be((uint8_t*)registers, be32, nvalues, st_);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -817,6 +848,7 @@ static int aggregate_device(plume_ctx* ctx, int version, int mode, size_t n, con
                             const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, const uint8_t seed[32], uint64_t index_base, uint8_t* hash_ok,
                             const uint8_t* carry, uint8_t* result, hipStream_t st) {
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
+    if (int rc = need_gcomb(ctx)) return rc;
     // positions in the sorted pair array are 32-bit: 64 (term, window) pairs per item (69 for 8-bit windows) must stay far below 2^32, and the pair array itself (4 bytes
     // per pair) below what one pass should hold; larger batches go through the host-pointer form, which cuts them into pieces and carries the running record
     if (n > ((size_t)1 << 24)) return fail(PLUME_ERR_ARG, "plume_aggregate_check_device: at most 2^24 items per call (the host-pointer form cuts larger batches into pieces)");
@@ -896,23 +928,32 @@ static int agg_args_ok(int version, int mode, size_t n, const void* msgs, const 
     return 0;
 }
 // the coefficients a_i, b_i are only as unpredictable as the seed: a caller that has no fresh randomness of its own passes NULL and gets 32 bytes of the OS generator
-static const uint8_t* agg_seed(const uint8_t* seed, uint8_t drawn[32]) {
+// Drawn with getrandom(2) and checked: nothing here can throw across the C ABI (std::random_device may), and a short read is an error, not a weaker seed.
+static bool os_random(void* out, size_t len) {
+    uint8_t* p = (uint8_t*)out;
+    while (len) {
+        const ssize_t k = getrandom(p, len, 0);
+        if (k < 0) { if (errno == EINTR) continue; return false; }
+        p += k; len -= (size_t)k;
+    }
+    return true;
+}
+static const uint8_t* agg_seed(const uint8_t* seed, uint8_t drawn[32]) {      // nullptr: the OS generator failed
     if (seed) return seed;
-    std::random_device rd;
-    for (int i = 0; i < 32; i += 4) { const uint32_t v = rd(); std::memcpy(drawn + i, &v, 4); }
-    return drawn;
+    return os_random(drawn, 32) ? drawn : nullptr;
 }
 
 extern "C" int plume_aggregate_check_device(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
                                             const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
                                             const uint8_t seed[32], uint64_t index_base, uint8_t* hash_ok, uint8_t* result, void* stream) {
-    ctx = route(ctx);
+    hipStream_t st_; ctx = route(ctx, stream, st_);
     if (int rc = bind(ctx)) return rc;
     if (int rc = agg_args_ok(version, mode, n, msgs, msg_off, seed)) return rc;
     if (!result || (n && (!pk || !nullifier || !c || !s || !r_point || !hashed_to_curve_r))) return fail(PLUME_ERR_ARG, "null array");
     uint8_t drawn[32];
-    return aggregate_device(ctx, version, mode, n, msgs, msg_off, msgs_bytes, pk, nullifier, c, s, r_point, hashed_to_curve_r, agg_seed(seed, drawn), index_base, hash_ok, nullptr, result,
-                            stream ? (hipStream_t)stream : ctx->stream);
+    seed = agg_seed(seed, drawn);
+    if (!seed) return fail(PLUME_ERR_HIP, "getrandom failed: no seed for the aggregate check's coefficients");
+    return aggregate_device(ctx, version, mode, n, msgs, msg_off, msgs_bytes, pk, nullifier, c, s, r_point, hashed_to_curve_r, seed, index_base, hash_ok, nullptr, result, st_);
 }
 
 // ------------------------------------------------------------------------------ nullifier-set post-processing
@@ -923,7 +964,8 @@ static int dedup_device(plume_ctx* ctx, size_t n, const uint8_t* nul, const uint
     a.n = (uint32_t)n; a.nul = nul; a.live = live; a.ids = ids; a.first = first;
     const uint32_t m = dedup_table_size(a.n);
     a.mask = m - 1;
-    { static thread_local std::random_device rd; a.key[0] = rd(); a.key[1] = rd() | 1u; }   // fresh hash key per call (plume_dedup.h)
+    if (!os_random(a.key, sizeof a.key)) return fail(PLUME_ERR_HIP, "getrandom failed: no hash key for the nullifier table");   // fresh hash key per call (plume_dedup.h)
+    a.key[1] |= 1u;
     if (ctx->dslots.ensure((size_t)m * 4) || ctx->dminid.ensure((size_t)m * 8) || ctx->dmyslot.ensure(n * 4) || ctx->dcount.ensure(8) || ctx->dblockcnt.ensure(dedup_blockcnt_bytes(n))) return PLUME_ERR_HIP;
     a.slots = ctx->dslots.as<uint32_t>(); a.minid = ctx->dminid.as<unsigned long long>(); a.myslot = ctx->dmyslot.as<uint32_t>();
     a.n_unique = ctx->dcount.as<unsigned long long>(); a.blockcnt = ctx->dblockcnt.as<uint32_t>();
@@ -937,10 +979,10 @@ static int dedup_device(plume_ctx* ctx, size_t n, const uint8_t* nul, const uint
 }
 extern "C" int plume_nullifier_first_occurrence_device(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live, const uint64_t* ids, uint8_t* first,
                                                        uint64_t* n_unique, void* stream) {
-    ctx = route(ctx);
+    hipStream_t st_; ctx = route(ctx, stream, st_);
     if (int rc = bind(ctx)) return rc;
     if (n && (!nullifier || !first)) return fail(PLUME_ERR_ARG, "null array");
-    return dedup_device(ctx, n, nullifier, live, ids, first, n_unique, stream ? (hipStream_t)stream : ctx->stream);
+    return dedup_device(ctx, n, nullifier, live, ids, first, n_unique, st_);
 }
 // host-pointer form: one pass (every record has to be resident to be compared), staged through slot 0
 extern "C" int plume_nullifier_first_occurrence(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live, const uint64_t* ids, uint8_t* first,
@@ -1192,6 +1234,7 @@ extern "C" int plume_aggregate_check(plume_ctx* ctx, int version, int mode, size
     if (n == 0) { memset(result, 0, PLUME_AGG_RESULT_BYTES); result[0] = result[1] = 1; return 0; }
     uint8_t drawn[32];
     seed = agg_seed(seed, drawn);                                   // one seed for all pieces and shards of the call
+    if (!seed) return fail(PLUME_ERR_HIP, "getrandom failed: no seed for the aggregate check's coefficients");
     if (ctx->shards.empty()) return aggregate_host(ctx, version, mode, n, msgs, msg_off, pk, nullifier, c, s, r_point, hashed_to_curve_r, seed, 0, hash_ok, result);
     const size_t g = ctx->shards.size();
     std::vector<uint8_t> records(PLUME_AGG_RESULT_BYTES * g, 0);       // an empty shard leaves zeros: the identity, no bad item
@@ -1293,8 +1336,7 @@ static int h2c_host(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_
             return sl.out[0].ensure(64 * cnt);
         },
         [&](HostSlot& sl, size_t cnt) -> int {
-            return plume_hash_to_curve_batch_device(ctx, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], pk ? sl.in[0].as<uint8_t>() : nullptr,
-                                                    sl.out[0].as<uint8_t>(), ctx->stream);
+            return h2c_only_device(ctx, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], pk ? sl.in[0].as<uint8_t>() : nullptr, sl.out[0].as<uint8_t>(), ctx->stream);
         },
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, h_out + 64 * i0, sl.out[0], 64 * cnt); });
 }
@@ -1359,7 +1401,7 @@ static int der_host(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* d
         const size_t cnt = n - i0 < ctx->chunk ? n - i0 : ctx->chunk;
         if (sl.in[0].ensure(32 * cnt) || sl.out[0].ensure(PLUME_DER_LEN * cnt) || sl.out[1].ensure(cnt)) return PLUME_ERR_HIP;
         HIPCHK(hipMemcpyAsync(sl.in[0].p, scalars + 32 * i0, 32 * cnt, hipMemcpyHostToDevice, st));
-        if (int rc = plume_scalars_to_sec1_der_batch_device(ctx, cnt, sl.in[0].as<uint8_t>(), sl.out[0].as<uint8_t>(), sl.out[1].as<uint8_t>(), st)) return rc;
+        if (int rc = der_device(ctx, cnt, sl.in[0].as<uint8_t>(), sl.out[0].as<uint8_t>(), sl.out[1].as<uint8_t>(), st)) return rc;
         HIPCHK(hipMemsetAsync(sl.in[0].p, 0, 32 * cnt, st));                       // the scalars may be secret keys: wipe the staged copy
         HIPCHK(hipMemcpyAsync(der109 + PLUME_DER_LEN * i0, sl.out[0].p, PLUME_DER_LEN * cnt, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(status + i0, sl.out[1].p, cnt, hipMemcpyDeviceToHost, st));

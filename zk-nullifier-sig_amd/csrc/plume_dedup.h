@@ -33,7 +33,7 @@ struct DedupArgs {
     unsigned long long* minid;       // mask+1 entries: smallest id among the items sharing the slot
     uint32_t* myslot;                // n entries
     uint32_t mask;                   // table size - 1 (power of two >= 2n)
-    uint32_t key[2];                 // per-call hash key (plume_capi.hip draws it from std::random_device): records ground to collide under one key
+    uint32_t key[2];                 // per-call hash key (plume_capi.hip draws it with getrandom): records ground to collide under one key
                                      // do not collide under the next, so a crafted batch cannot pin the probe length at O(n).  Results do not depend on it.
 };
 

@@ -531,12 +531,17 @@ void launch_scalars_der(const DerArgs& a, hipStream_t st) { hipLaunchKernelGGL(k
 void launch_registers_from_be(uint8_t* out, const uint8_t* in, size_t nvalues, hipStream_t st) {
     hipLaunchKernelGGL(k_registers_from_be, dim3(nblocks(nvalues)), dim3(kBlock), 0, st, out, in, nvalues);
 }
+// gtab / gcomb may be null: only the table asked for is built (plume_capi.hip builds each on its first use)
 void launch_fixed_tables(uint32_t* gtab, uint32_t* gcomb, uint32_t* base18 /* (1 + PLUME_COMB_WINDOWS) x 18 words */, hipStream_t st) {
     uint32_t* cb = base18 + 2 * PLUME_FE_WORDS;
-    hipLaunchKernelGGL(k_fixed_bases, dim3(1), dim3(kBlock), 0, st, base18, 1u, 0u);
-    hipLaunchKernelGGL(k_fixed_bases, dim3(1), dim3(kBlock), 0, st, cb, (uint32_t)PLUME_COMB_WINDOWS, (uint32_t)PLUME_COMB_W);
-    hipLaunchKernelGGL(k_fixed_table, dim3(nblocks((size_t)PLUME_GTAB_ENTRIES)), dim3(kBlock), 0, st, gtab, base18, (uint32_t)PLUME_GTAB_ENTRIES, 1u);
-    hipLaunchKernelGGL(k_fixed_table, dim3(nblocks((size_t)PLUME_COMB_ENTRIES * PLUME_COMB_WINDOWS)), dim3(kBlock), 0, st, gcomb, cb, (uint32_t)PLUME_COMB_ENTRIES, (uint32_t)PLUME_COMB_WINDOWS);
+    if (gtab) {
+        hipLaunchKernelGGL(k_fixed_bases, dim3(1), dim3(kBlock), 0, st, base18, 1u, 0u);
+        hipLaunchKernelGGL(k_fixed_table, dim3(nblocks((size_t)PLUME_GTAB_ENTRIES)), dim3(kBlock), 0, st, gtab, base18, (uint32_t)PLUME_GTAB_ENTRIES, 1u);
+    }
+    if (gcomb) {
+        hipLaunchKernelGGL(k_fixed_bases, dim3(1), dim3(kBlock), 0, st, cb, (uint32_t)PLUME_COMB_WINDOWS, (uint32_t)PLUME_COMB_W);
+        hipLaunchKernelGGL(k_fixed_table, dim3(nblocks((size_t)PLUME_COMB_ENTRIES * PLUME_COMB_WINDOWS)), dim3(kBlock), 0, st, gcomb, cb, (uint32_t)PLUME_COMB_ENTRIES, (uint32_t)PLUME_COMB_WINDOWS);
+    }
 }
 void launch_dedup(const DedupArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_dedup_clear, dim3(nblocks((size_t)a.mask + 1)), dim3(kBlock), 0, st, a);

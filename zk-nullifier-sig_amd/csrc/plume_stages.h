@@ -378,7 +378,6 @@ struct SignArgs {
     uint32_t* pkaff;                     // 2 * PLUME_FE_WORDS x n words SoA: affine pk (x, y), canonical, for the final stage
     uint32_t* tab;                       // n tables
     uint32_t* hres;  uint8_t* hresinf;   // 2n tasks: sk*H, r*H
-    const uint32_t* gtab;
     const uint32_t* gcomb;               // fixed-base comb of G (PLUME_COMB_WORDS)
 };
 
