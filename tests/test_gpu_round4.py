@@ -96,7 +96,7 @@ def test_generator_tables_are_built_by_the_first_call_that_needs_them():
     assert d["init"] < 128, d                      # streams, events, a few KiB of scratch
     assert 252 <= d["sign"] < 700, d               # the comb + a small workspace, not the 1 GiB window table
     assert 1024 <= d["verify"] < 1500, d           # the window table
-    assert d["closed"] < 128, d
+    assert d["closed"] < 256, d                    # the tables and the workspace are back (what stays is the runtime's own: code objects, pools)
 
 
 def _two_rank_bench(args, timeout=900):
