@@ -88,10 +88,14 @@ int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
  * whichever lane serves the call (so a sign followed by a verify of its outputs, both with stream = NULL, stay ordered).  Costs a second per-batch workspace.  Single-device contexts only (a multi-device context
  * already runs its shards side by side).  plume_last_stage_times / plume_last_redo_tasks then report the lane of the last device-resident call. */
 int plume_set_in_flight(plume_ctx* ctx, int batches);
-/* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (three streams,
- * two staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each
- * following piece up to three times the one before, up to the largest piece (default 1<<19, capped by the chunk size); calls with large
- * outputs (the signer) end on a small piece (default 1<<17).  Results do not depend on any of this. */
+/* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (an upload, a download and the compute streams,
+ * four staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each following piece up to three times
+ * the one before, up to the largest piece (default 1<<19, capped by the chunk size); calls with large outputs (the signer) end on a small piece (default 1<<16).
+ * Round 4: the pieces of a VERIFY call alternate between the context and a second lane of its own (workspace + stream, created on the first such call), so that the ingest and
+ * table stages of piece k+1 run beside the multi-scalar kernel of piece k, and the message offsets the library prepares go up from page-locked memory: 2^20 V1 verifies from
+ * page-locked arrays 21.4-21.9 ms against 22.3-23.2 ms on the same boxes (0.90-0.92 of the device-resident serial rate, 0.85-0.88 before).  The GPU is busy from the first
+ * piece's arrival to the end (kernel + copy trace, tests/gpu_debug/e2e_trace.py); what remains is the first upload (0.57 ms) and the pieces' smaller launches.  Env
+ * PLUME_HOST_LANES=1 restores the one-lane pipeline.  Results do not depend on any of this. */
 int plume_set_host_piece(plume_ctx* ctx, size_t largest_piece_items);
 int plume_set_host_first_piece(plume_ctx* ctx, size_t items);
 int plume_set_host_tail_piece(plume_ctx* ctx, size_t items);

@@ -53,6 +53,23 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// page-locked host scratch (hipHostMalloc): the source of uploads the library itself prepares.  A pageable source would make the runtime stage the copy and move it with a
+// blit KERNEL, which then queues behind the saturating multi-scalar kernel and stalls the upload stream (seen in the round-4 pipeline trace: tests/gpu_debug/e2e_trace.py)
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail(PLUME_ERR_HIP, std::string("hipHostMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e)); }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct StageTimer {
     std::vector<const char*> names;
     std::vector<hipEvent_t> ev;   // ev[0] start, ev[i+1] after stage i
@@ -69,7 +86,8 @@ struct StageTimer {
 // staging for one piece of a host-pointer call
 struct HostSlot {
     DevBuf msgs, off, in[6], out[7];
-    std::vector<uint64_t> rel;                                        // piece-relative message offsets (source of an upload: lives until the slot is reused)
+    PinnedBuf relbuf;                                                 // piece-relative message offsets (source of an upload: lives until the slot is reused), page-locked
+    uint64_t* rel = nullptr;
     hipEvent_t ready = nullptr, computed = nullptr, drained = nullptr;   // uploads landed / kernels finished / downloads landed
     bool in_flight = false;
 };
@@ -115,12 +133,14 @@ struct plume_ctx {
     size_t chunk = (size_t)1 << 20;
     size_t host_piece = (size_t)1 << 19;                            // host-pointer calls: largest pipelined piece
     size_t host_first_piece = (size_t)1 << 16;                      // ... the first piece (its upload is the only one no kernel hides); pieces then grow 3x per step
-    size_t host_tail_piece = (size_t)1 << 17;                       // ... the last piece of calls with large outputs (its download is the only one no kernel hides)
+    size_t host_tail_piece = (size_t)1 << 16;                       // ... the last piece of calls with large outputs (its download is the only one no kernel hides)
     size_t host_register_min = 0;                                   // host-pointer calls: page-lock caller arrays of at least this many bytes for the call (0 = never)
     // multi-device parent (plume_init_multi): the shards are complete single-device contexts, one worker thread each; a parent owns no GPU state
     std::vector<plume_ctx*> shards;
     std::vector<Worker*> workers;
-    HostSlot slot[2];
+    HostSlot slot[4];                                              // host-pointer calls: staging slots (two for the one-lane pipeline, four when two lanes take the pieces in turn)
+    plume_ctx* host_lane = nullptr;                                // ... the second lane of the host-pointer pipeline: a complete single-device context (workspace, streams), created on first use
+    int host_lanes = 2;                                            // ... 1 = every piece on the context itself (rounds 1-3), 2 = pieces alternate between the context and host_lane
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
     FixedTables* fixed = nullptr;                                 // this device's shared generator tables (g_fixed)
@@ -194,6 +214,7 @@ extern "C" const char* plume_version(void) { return "plume_hip 0.3 gfx950 build=
 static void destroy_single(plume_ctx* ctx) {
     for (plume_ctx* l : ctx->lanes) destroy_single(l);
     ctx->lanes.clear();
+    if (ctx->host_lane) { destroy_single(ctx->host_lane); ctx->host_lane = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();   // the context's workspace, events and lanes may still be in use by kernels queued on CALLER streams (device-resident calls run on whatever
                                     // stream they were given): wait for the whole device, not only for the context's own streams (plume_destroy, plume_set_in_flight shrinking)
@@ -210,7 +231,7 @@ static void destroy_single(plume_ctx* ctx) {
         ctx->fixed = nullptr;
     }
     for (HostSlot& sl : ctx->slot) {
-        sl.msgs.release(); sl.off.release();
+        sl.msgs.release(); sl.off.release(); sl.relbuf.release(); sl.rel = nullptr;
         for (DevBuf& b : sl.in) b.release();
         for (DevBuf& b : sl.out) b.release();
         for (hipEvent_t e : {sl.ready, sl.computed, sl.drained}) if (e) (void)hipEventDestroy(e);
@@ -236,6 +257,7 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_HOST_FIRST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_first_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_TAIL_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_tail_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_HOST_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_lanes = v; }   // 1 = the one-lane host-pointer pipeline of rounds 1-3 (A/B)
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->down, hipStreamNonBlocking));
@@ -483,6 +505,7 @@ extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
     ctx->chunk = max_items;
     for (plume_ctx* sh : ctx->shards) sh->chunk = max_items;
     for (plume_ctx* l : ctx->lanes) l->chunk = max_items;
+    if (ctx->host_lane) ctx->host_lane->chunk = max_items;
     return 0;
 }
 
@@ -1016,8 +1039,8 @@ extern "C" int plume_nullifier_first_occurrence(plume_ctx* ctx, size_t n, const 
 // the calling thread, which is why piece k-1 is drained only AFTER piece k has been submitted: the thread then waits on work that is
 // already behind it in the queue.
 static int stage_msgs(plume_ctx* ctx, HostSlot& sl, const uint8_t* msgs, const uint64_t* off, size_t i0, size_t cnt) {
-    std::vector<uint64_t>& rel = sl.rel;
-    rel.resize(cnt + 1);
+    if (sl.relbuf.ensure((cnt + 1) * 8)) return PLUME_ERR_HIP;
+    uint64_t* rel = sl.rel = (uint64_t*)sl.relbuf.p;
     const uint64_t base = off[i0];
     for (size_t k = 0; k <= cnt; k++) {
         if (off[i0 + k] < base || (k && off[i0 + k] < off[i0 + k - 1])) return fail(PLUME_ERR_ARG, "msg_off is not non-decreasing");
@@ -1026,7 +1049,7 @@ static int stage_msgs(plume_ctx* ctx, HostSlot& sl, const uint8_t* msgs, const u
     if (rel[cnt] > 0xFFFFFF00ull) return fail(PLUME_ERR_ARG, "message bytes per pass exceed 4 GiB");
     if (sl.msgs.ensure((size_t)rel[cnt] + 16) || sl.off.ensure((cnt + 1) * 8)) return PLUME_ERR_HIP;
     if (rel[cnt]) HIPCHK(hipMemcpyAsync(sl.msgs.p, msgs + base, (size_t)rel[cnt], hipMemcpyHostToDevice, ctx->up));
-    HIPCHK(hipMemcpyAsync(sl.off.p, rel.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->up));
+    HIPCHK(hipMemcpyAsync(sl.off.p, rel, (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->up));
     return 0;
 }
 static int h2d(plume_ctx* ctx, DevBuf& b, const uint8_t* src, size_t bytes) {
@@ -1042,7 +1065,8 @@ static void quiesce(plume_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->up);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->down);
-    ctx->slot[0].in_flight = ctx->slot[1].in_flight = false;
+    if (ctx->host_lane) (void)hipStreamSynchronize(ctx->host_lane->stream);
+    for (HostSlot& sl : ctx->slot) sl.in_flight = false;
 }
 
 // Page-locks caller arrays for the duration of one host-pointer call when ctx->host_register_min asks for it (arrays that are already
@@ -1069,6 +1093,12 @@ struct ScopedPins {
 static std::vector<size_t> piece_schedule(const plume_ctx* ctx, size_t n, bool out_heavy) {
     const size_t piece = ctx->host_piece < ctx->chunk ? ctx->host_piece : ctx->chunk;
     std::vector<size_t> sched;
+    if (const char* e = std::getenv("PLUME_HOST_SCHEDULE")) {     // experiment knob: an explicit comma-separated piece list (used only when it adds up to n and fits the chunk)
+        size_t sum = 0; bool ok = true;
+        for (const char* q = e; *q;) { char* end; const unsigned long long v = std::strtoull(q, &end, 10); if (end == q || v == 0 || v > ctx->chunk) { ok = false; break; } sched.push_back((size_t)v); sum += (size_t)v; q = *end ? end + 1 : end; }
+        if (ok && sum == n) return sched;
+        sched.clear();
+    }
     size_t rem = n, cur = ctx->host_first_piece < piece ? ctx->host_first_piece : piece;
     if (n <= piece && n <= 2 * cur) { sched.push_back(n); return sched; }   // small calls: one piece
     while (rem) {
@@ -1082,10 +1112,27 @@ static std::vector<size_t> piece_schedule(const plume_ctx* ctx, size_t n, bool o
     return sched;
 }
 
+// The second lane of the host-pointer pipeline (round 4).  Rounds 1-3 ran every piece of a call on the context's one workspace and stream: the kernels of piece k+1 queued
+// behind those of piece k, the small first pieces ran at small-batch efficiency (a 2^16-item verify alone reaches 0.70 of the 2^20 rate) and the whole call delivered 0.85 of
+// the device-resident rate.  Now the pieces alternate between the context and a lane of its own kind (workspace, streams; the generator tables are shared): the ingest and
+// table stages of piece k+1 run beside the multi-scalar kernel of piece k exactly as two device-resident batches in flight do, which needs four staging slots (k-2 is still
+// downloading from its slot when k+2 wants to upload).
+static plume_ctx* host_lane_of(plume_ctx* ctx) {
+    if (ctx->host_lane) return ctx->host_lane;
+    plume_ctx* l = new plume_ctx();
+    l->device = ctx->device;
+    if (init_single(l)) { destroy_single(l); return nullptr; }
+    ctx->host_lane = l;
+    return l;
+}
+
 template <class Up, class Run, class Down>
-static int host_pipeline(plume_ctx* ctx, size_t n, bool out_heavy, Up up, Run run, Down down) {
-    ctx->lane_last = nullptr;            // host-pointer calls run on the context itself: its own stage timer is the one to report
+static int host_pipeline(plume_ctx* ctx, size_t n, bool out_heavy, Up up, Run run, Down down, bool may_use_two_lanes = false) {
     const std::vector<size_t> sched = piece_schedule(ctx, n, out_heavy);
+    plume_ctx* lane2 = (may_use_two_lanes && ctx->host_lanes > 1 && sched.size() > 1) ? host_lane_of(ctx) : nullptr;
+    if (lane2) { lane2->chunk = ctx->chunk; lane2->sub_batches = 1; lane2->jobs_per_lane = ctx->jobs_per_lane; lane2->jobs_per_lane_forced = ctx->jobs_per_lane_forced; }
+    const size_t nslots = lane2 ? 4 : 2;
+    ctx->lane_last = nullptr;            // host-pointer calls report the stage timer of the lane their last piece ran on (set below)
     struct { HostSlot* sl = nullptr; size_t i0 = 0, cnt = 0; } prev;
     auto drain = [&]() -> int {
         HIPCHK(hipStreamWaitEvent(ctx->down, prev.sl->computed, 0));
@@ -1097,14 +1144,16 @@ static int host_pipeline(plume_ctx* ctx, size_t n, bool out_heavy, Up up, Run ru
         size_t i0 = 0;
         for (size_t k = 0; k < sched.size(); k++) {
             const size_t cnt = sched[k];
-            HostSlot& sl = ctx->slot[k & 1];
-            if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.drained)); sl.in_flight = false; }   // piece k-2 has left this slot
+            HostSlot& sl = ctx->slot[k % nslots];
+            plume_ctx* on = (lane2 && (k & 1)) ? lane2 : ctx;
+            if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.drained)); sl.in_flight = false; }   // the piece that used this slot last has left it
             if (int rc = up(sl, i0, cnt)) return rc;
             HIPCHK(hipEventRecord(sl.ready, ctx->up));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, sl.ready, 0));
-            if (int rc = run(sl, cnt)) return rc;
-            HIPCHK(hipEventRecord(sl.computed, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(on->stream, sl.ready, 0));
+            if (int rc = run(sl, cnt, on)) return rc;
+            HIPCHK(hipEventRecord(sl.computed, on->stream));
             sl.in_flight = true;
+            ctx->lane_last = on == ctx ? nullptr : on;
             if (prev.sl) { if (int rc = drain()) return rc; }
             prev.sl = &sl; prev.i0 = i0; prev.cnt = cnt;
             i0 += cnt;
@@ -1145,15 +1194,15 @@ static int verify_host(plume_ctx* ctx, int version, int mode, bool sec1, size_t 
             }
             return sl.out[0].ensure(cnt);
         },
-        [&](HostSlot& sl, size_t cnt) -> int {
+        [&](HostSlot& sl, size_t cnt, plume_ctx* on) -> int {
             const uint8_t *rp = pts ? sl.in[4].as<uint8_t>() : nullptr, *hp = pts ? sl.in[5].as<uint8_t>() : nullptr;
             if (sec1)
-                return verify_sec1_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
-                                          sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), rp, hp, sl.out[0].as<uint8_t>(), ctx->stream);
-            return verify_device(ctx, version, mode, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
-                                 sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), rp, hp, sl.out[0].as<uint8_t>(), ctx->stream);
+                return verify_sec1_device(on, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
+                                          sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), rp, hp, sl.out[0].as<uint8_t>(), on->stream);
+            return verify_device(on, version, mode, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
+                                 sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), rp, hp, sl.out[0].as<uint8_t>(), on->stream);
         },
-        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); });
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); }, true);
 }
 
 static int verify_host_any(plume_ctx* ctx, int version, int mode, bool sec1, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nullifier,
@@ -1212,7 +1261,7 @@ static int aggregate_host(plume_ctx* ctx, int version, int mode, size_t n, const
             if (int r = h2d(ctx, sl.in[5], hashed_to_curve_r + 64 * i0, 64 * cnt)) return r;
             return sl.out[0].ensure(cnt);
         },
-        [&](HostSlot& sl, size_t cnt) -> int {
+        [&](HostSlot& sl, size_t cnt, plume_ctx* on) -> int {
             const int r = aggregate_device(ctx, version, mode, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
                                            sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), sl.in[4].as<uint8_t>(), sl.in[5].as<uint8_t>(), seed, index_base + done, sl.out[0].as<uint8_t>(),
                                            done ? rec : nullptr, rec, ctx->stream);
@@ -1281,14 +1330,14 @@ static int sign_host(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs,
                        ? PLUME_ERR_HIP
                        : 0;
         },
-        [&](HostSlot& sl, size_t cnt) -> int {
-            if (int rc = sign_device(ctx, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
+        [&](HostSlot& sl, size_t cnt, plume_ctx* on) -> int {
+            if (int rc = sign_device(on, version, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
                                      pk_in ? sl.in[2].as<uint8_t>() : nullptr, sl.out[0].as<uint8_t>(), sl.out[1].as<uint8_t>(), sl.out[2].as<uint8_t>(),
-                                     sl.out[3].as<uint8_t>(), sl.out[4].as<uint8_t>(), sl.out[5].as<uint8_t>(), sl.out[6].as<uint8_t>(), nullptr, ctx->stream, P == 33))
+                                     sl.out[3].as<uint8_t>(), sl.out[4].as<uint8_t>(), sl.out[5].as<uint8_t>(), sl.out[6].as<uint8_t>(), nullptr, on->stream, P == 33))
                 return rc;
             // wipe the staged secrets before the slot is reused or freed
-            HIPCHK(hipMemsetAsync(sl.in[0].p, 0, 32 * cnt, ctx->stream));
-            HIPCHK(hipMemsetAsync(sl.in[1].p, 0, 32 * cnt, ctx->stream));
+            HIPCHK(hipMemsetAsync(sl.in[0].p, 0, 32 * cnt, on->stream));
+            HIPCHK(hipMemsetAsync(sl.in[1].p, 0, 32 * cnt, on->stream));
             return 0;
         },
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
@@ -1299,7 +1348,7 @@ static int sign_host(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs,
             if (int rc = d2h(ctx, r_point + P * i0, sl.out[4], P * cnt)) return rc;
             if (int rc = d2h(ctx, hashed_to_curve_r + P * i0, sl.out[5], P * cnt)) return rc;
             return d2h(ctx, status + i0, sl.out[6], cnt);
-        });
+        });      // one lane: measured on the MI355X (round 4, tests/gpu_debug/host_sign_sweep.py) two lanes gain the signer nothing (19.98 vs 19.82 ms per 2^20) -- its call is bound by the 336 MB of outputs going down
 }
 static int sign_host_any(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
                          const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point, uint8_t* hashed_to_curve_r,
@@ -1335,7 +1384,7 @@ static int h2c_host(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_
             if (pk) { if (int rc = h2d(ctx, sl.in[0], pk + 64 * i0, 64 * cnt)) return rc; }
             return sl.out[0].ensure(64 * cnt);
         },
-        [&](HostSlot& sl, size_t cnt) -> int {
+        [&](HostSlot& sl, size_t cnt, plume_ctx* on) -> int {
             return h2c_only_device(ctx, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], pk ? sl.in[0].as<uint8_t>() : nullptr, sl.out[0].as<uint8_t>(), ctx->stream);
         },
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, h_out + 64 * i0, sl.out[0], 64 * cnt); });
@@ -1359,7 +1408,7 @@ static int h2c_inter_host(plume_ctx* ctx, size_t n, const uint8_t* msgs, const u
             if (pk) { if (int rc = h2d(ctx, sl.in[0], pk + 64 * i0, 64 * cnt)) return rc; }
             return sl.out[0].ensure(64 * cnt) || sl.out[1].ensure(128 * cnt) || sl.out[2].ensure(128 * cnt) || sl.out[3].ensure(64 * cnt) || sl.out[4].ensure(192 * cnt) ? PLUME_ERR_HIP : 0;
         },
-        [&](HostSlot& sl, size_t cnt) -> int {
+        [&](HostSlot& sl, size_t cnt, plume_ctx* on) -> int {
             return h2c_inter_device(ctx, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], pk ? sl.in[0].as<uint8_t>() : nullptr, registers,
                                     u ? sl.out[0].as<uint8_t>() : nullptr, mapped ? sl.out[1].as<uint8_t>() : nullptr, q ? sl.out[2].as<uint8_t>() : nullptr,
                                     h ? sl.out[3].as<uint8_t>() : nullptr, hints ? sl.out[4].as<uint8_t>() : nullptr, ctx->stream);
