@@ -92,7 +92,7 @@ void ds_sc_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32
         for (int k = 0; k < 8; k++) out[8 * i + k] = r.v[k];
     }
 }
-uint32_t ds_wbits() { return PLUME_WBITS; }                  // window width of this build (4; 5 in the A/B build)
+uint32_t ds_wbits() { return PLUME_WBITS; }                  // window width (4)
 // k (8 limbs) -> m1[4], neg1, m2[4], neg2 (10 words) and 2 x PLUME_NDIG digits (int8) in rows of 66
 void ds_glv(size_t count, const uint32_t* k, uint32_t* out, int8_t* digits) {
     for (size_t i = 0; i < count; i++) {
@@ -136,13 +136,13 @@ static const std::vector<uint32_t>& shared_gcomb() {
 }
 
 // host stand-in for launch_tables: the same lane -> jobs mapping, the same lane-interleaved scratch indexing and the same PASS sequence as the multi-kernel form of
-// k_tables (one loop over the lanes per pass, the lanes' running products in a word-major array, tab_invert_group between two passes); a batch of one lane also runs
+// the table stage (one loop over the lanes per pass, the lanes' running products in a word-major array, tab_invert_group between two passes); a batch of one lane also runs
 // the one-function form (table_build_affine) and the two must agree
 static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L, stride = ((lanes + 7) / 8) * 8;     // "grid" rounded up like the kernel's
     std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_AFF_SCR_WORDS), carry(stride * PLUME_FE_WORDS);
     std::vector<uint8_t> guardf(stride, 0);
-    constexpr int K = 8, NPASS = PLUME_TAB_ENTRIES == 16 ? 5 : 4;
+    constexpr int K = 8, NPASS = 4;
     const size_t T = (stride + K - 1) / K;
     const DirectRowSinkSync sink;
     for (int pass = 0; pass < NPASS; pass++) {
@@ -155,9 +155,6 @@ static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobf
             else if (pass == 1) tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr.data(), stride, lane, c, g, sink);
             else if (pass == 2) tab_pass_c(tab, j0, cnt, scr.data(), stride, lane, c, g, sink);
             else if (pass == 3) tab_pass_d(tab, j0, cnt, scr.data(), stride, lane, c, g, sink);
-#if PLUME_TAB_ENTRIES == 16
-            else tab_pass_e(tab, j0, cnt, scr.data(), stride, lane, c, g, sink);
-#endif
             if (pass < NPASS - 1) { st_fe_soa(carry.data(), stride, lane, c); guardf[lane] = g ? 1 : 0; }
         }
         if (pass < NPASS - 1) for (size_t t = 0; t < T; t++) tab_invert_group<K>(carry.data(), stride, T, t);
@@ -189,7 +186,7 @@ void ds_tables_raw(uint32_t nb, const uint8_t* pts, uint8_t* out) {
             memcpy(out + 64 * (PLUME_TAB_ENTRIES * (size_t)j + k), rec, 64);
         }
 }
-uint32_t ds_tab_entries() { return PLUME_TAB_ENTRIES; }     // rows per window table of this build (8: 4-bit windows; 16: the 5-bit A/B build)
+uint32_t ds_tab_entries() { return PLUME_TAB_ENTRIES; }     // rows per window table (8)
 
 // simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)
 static const uint32_t B = 8;

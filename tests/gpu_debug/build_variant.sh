@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build zk-nullifier-sig_amd/libplume_hip_<name>.so from the current sources with extra flags for plume_kernels.hip only (the other objects are reused
-# from the default build when the flags do not concern them):   tests/gpu_debug/build_variant.sh tab1k "-DPLUME_TABLES_MULTIKERNEL=0" [all]
-# A third argument "all" recompiles every translation unit with the flags (flags that change shared headers' layout, e.g. -DPLUME_WBITS=5).
+# from the default build when the flags do not concern them):   tests/gpu_debug/build_variant.sh gw20 "-DPLUME_GW=20" [all]
+# A third argument "all" recompiles every translation unit with the flags (flags that change shared headers' layout, e.g. -DPLUME_GW=20).
 set -e
 name=$1; flags=$2; all=$3
 root=$(cd "$(dirname "$0")/../.." && pwd)

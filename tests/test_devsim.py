@@ -550,23 +550,6 @@ def test_affine_table_chain_and_its_zero_denominator_guard():
             assert [got[j, k].tobytes() for k in range(E)] == want[src], j
 
 
-def test_five_bit_window_build_of_the_device_headers(tmp_path):
-    """-DPLUME_WBITS=5 (the A/B build of DESIGN.md §10: 26 Booth digits per half, 16-row tables with a fourth chain level, 15-bit generator window) stays correct: the
-    same harness built with that option passes the recoding, table-chain and whole-pipeline tests of this file (run in a child process: the harness is loaded once per process)"""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("PLUME_DEVSIM_SO"):
-        pytest.skip("already inside the child run")
-    so = tmp_path / "libplume_devsim_w5.so"
-    csrc = ROOT / "zk-nullifier-sig_amd" / "csrc"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DPLUME_FE_CHECK", "-DPLUME_WBITS=5", "-DPLUME_COMB_W=14", f"-I{csrc}", "-o", str(so), str(ROOT / "tests" / "devsim" / "devsim.cpp")],
-                   check=True, capture_output=True, text=True)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", str(Path(__file__)), "-k", "glv_and_booth or table or verify or sign or msm or golden"],
-                       env=dict(os.environ, PLUME_DEVSIM_SO=str(so)), capture_output=True, text=True, cwd=str(ROOT))
-    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
-
-
 def test_twenty_bit_generator_window_build_of_the_device_headers(tmp_path):
     """The GPU build ships a 24-bit generator window (2^23 rows, 1 GiB: no CPU builds that per test run) whose digits travel in the THREE-byte form of the digit rows; the
     harness built with -DPLUME_GW=20 (2^19 rows, the same three-byte form, the same two-byte top digit) passes the recoding and whole-pipeline tests of this file

@@ -183,12 +183,11 @@ PLUME_HD void glv_split(glv_half& h1, glv_half& h2, const sc& k) {
     PLUME_UNROLL for (int i = 0; i < 4; i++) { h1.m[i] = sel32(m1, n1.v[i], k1.v[i]); h2.m[i] = sel32(m2, n2.v[i], k2.v[i]); }
 }
 
-// Booth recoding, window w = PLUME_WBITS (4; 5 is the A/B build of DESIGN.md §10): m = sum d_i 2^(w i), d_i in [-2^(w-1), 2^(w-1)], i = 0..NDIG-1 covering 129 bits.
-// w = 4: d_i = k_{4i-1} + k_{4i} + 2k_{4i+1} + 4k_{4i+2} - 8k_{4i+3}.
-#ifndef PLUME_WBITS
+// Booth recoding, window w = PLUME_WBITS = 4: m = sum d_i 2^(w i), d_i in [-2^(w-1), 2^(w-1)], i = 0..NDIG-1 covering 129 bits:
+// d_i = k_{4i-1} + k_{4i} + 2k_{4i+1} + 4k_{4i+2} - 8k_{4i+3}.  (5-bit windows -- 26 digits, 16-row tables with a fourth chain level -- were built and measured in
+// rounds 2 and 3: the multi-scalar kernel gains 9 %, the HBM-bound table stage loses more; LABNOTES.md.  The build option is gone with round 4.)
 #define PLUME_WBITS 4
-#endif
-#define PLUME_NDIG ((128 + PLUME_WBITS) / PLUME_WBITS)       // 33 for w = 4, 26 for w = 5
+#define PLUME_NDIG ((128 + PLUME_WBITS) / PLUME_WBITS)       // 33
 PLUME_HD int booth_digit(const uint32_t m[4], int i) {
     // u = bits [w i - 1, w i + w - 1] of m (bit -1 = 0); i is a compile-time constant after unrolling
     const int W = PLUME_WBITS, lo = W * i - 1;
@@ -207,18 +206,15 @@ PLUME_HD int booth_digit(const uint32_t m[4], int i) {
 // W = PLUME_GW must be a multiple of 4 so that digit k lines up with the 4-bit window i = k * W/4 of the shared doubling chain.
 // W = 12: 11 digits per 128-bit half (22 generator additions per verify instead of 34 with W = 8) from a 2048-entry table (256 KiB, L2-resident);
 // W = 16: 9 digits per half (18 additions) from 32768 entries (4 MiB: L2 / MALL), built once per context in ~0.2 s.
-#ifndef PLUME_GW
-#if PLUME_WBITS == 5
-#define PLUME_GW 15   // the widest multiple of 5 whose magnitudes (<= 2^14) still fit the two-byte digit form: 16384 entries (2 MiB), 9 digits per half
-#else
+#ifndef PLUME_GW   // (the one width knob that stays: host builds of these headers take -DPLUME_GW=16 / 20, a CPU cannot build 8 M rows per test run)
 #define PLUME_GW 24   // round 3: 2^23 entries (1 GiB of the 288), 6 digits per half: 12 generator additions per verify -- multi-scalar kernel -1.1 %, a verify -1.3 % against W = 16 (32768 entries, 4 MiB, 18
                       // additions; W = 20: 64 MiB, 14 additions, -0.4 %; W = 12: 2048 entries, 22 additions).  The rows of a 1 GiB table come from HBM, not from L2 / MALL; the kernel's other wavefronts cover it.
                       // Host builds of these headers (tests/devsim) take -DPLUME_GW=16: a CPU cannot build 8 M rows per test run
 #endif
-#endif
 static_assert(PLUME_GW % PLUME_WBITS == 0, "a wide digit must line up with the windows of the shared doubling chain");
 static_assert(PLUME_GW <= 24, "the digit rows hold a wide digit as a magnitude of up to three bytes plus its sign");
-#define PLUME_GW_BYTES (PLUME_GW > 16 ? 3 : 2)          // magnitude bytes of a wide digit in its full form (W <= 15: the sign shares the second byte)
+static_assert(PLUME_GW >= 16, "wide digits are stored as magnitude bytes + a sign byte: needs W / 4 >= 4 positions per digit");
+#define PLUME_GW_BYTES (PLUME_GW > 16 ? 3 : 2)          // magnitude bytes of a wide digit in its full form
 #define PLUME_GWS (PLUME_GW / PLUME_WBITS)                // windows per wide digit
 #define PLUME_NDIGW ((128 + PLUME_GW) / PLUME_GW)         // digits covering 129 bits: 11 for W = 12, 17 for W = 8
 #define PLUME_GTAB_ENTRIES (1 << (PLUME_GW - 1))
@@ -246,8 +242,7 @@ PLUME_HD void booth_store_wide(int8_t* dig, uint32_t stride, const glv_half& h, 
         int mag = d < 0 ? -d : d;
         const int pos = PLUME_GWS * k;
         const int8_t sgn = (int8_t)((mag != 0 && dn) ? 1 : 0);
-#if PLUME_GW > 15   // full form: PLUME_GW_BYTES magnitude bytes, then a sign byte (W / 4 >= 4 positions per digit are there)
-        static_assert(PLUME_GW <= 15 || PLUME_GWS >= PLUME_GW_BYTES + 1, "a wide digit's bytes fit its positions");
+        static_assert(PLUME_GWS >= PLUME_GW_BYTES + 1, "a wide digit's bytes fit its positions");
         if (pos + PLUME_GW_BYTES < PLUME_NDIG) {
             PLUME_UNROLL for (int b = 0; b < PLUME_GW_BYTES; b++) dig[(uint32_t)(pos + b) * stride] = (int8_t)(uint8_t)((mag >> (8 * b)) & 0xFF);
             dig[(uint32_t)(pos + PLUME_GW_BYTES) * stride] = sgn;
@@ -257,14 +252,6 @@ PLUME_HD void booth_store_wide(int8_t* dig, uint32_t stride, const glv_half& h, 
         } else {                                    // W = 16: the top digit (0 or 1) sits on the row's last position
             dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)((mag & 0x3F) | (sgn ? 0x40 : 0));
         }
-#else
-        if (pos + 1 < PLUME_NDIG) {
-            dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)(mag & 0xFF);
-            dig[(uint32_t)(pos + 1) * stride] = (int8_t)(uint8_t)(((mag >> 8) & 0x7F) | (sgn ? 0x80 : 0));
-        } else {
-            dig[(uint32_t)pos * stride] = (int8_t)(uint8_t)((mag & 0x3F) | (sgn ? 0x40 : 0));
-        }
-#endif
     }
 }
 // writes the 33 signed digits of one half-scalar to dig[i*stride], sign applied
@@ -281,13 +268,10 @@ PLUME_HD void booth_store(int8_t* dig, uint32_t stride, const glv_half& h, bool 
 //     [ x0..x7 | y0..y7 | b0..b7 | x8 y8 b8 0 | 0 0 0 0 ]        b = beta * x (the x of lambda*P)
 // i.e. eight 16-byte quads; one table addition gathers five of them (x or b, y, the top limbs) with aligned 16-byte loads from
 // ONE line, and the table kernel writes whole lines (112-byte rows, without the padding quad, measured 6 % slower there).
-#define PLUME_TAB_ENTRIES (1 << (PLUME_WBITS - 1))       // 8 (w = 4) or 16 (w = 5) rows per table
+#define PLUME_TAB_ENTRIES (1 << (PLUME_WBITS - 1))       // 8 rows per table
 #define PLUME_FE_W PLUME_FE_WORDS
 #define PLUME_JAC_WORDS (3 * PLUME_FE_WORDS)      // Jacobian point in HBM scratch: x | y | z
-#ifndef PLUME_TAB_ENTRY_WORDS
-#define PLUME_TAB_ENTRY_WORDS 32
-#endif
-#define PLUME_TAB_SCR_WORDS (4 * PLUME_FE_WORDS)  // pass-1 scratch per entry: X | Y | Z | running product
+#define PLUME_TAB_ENTRY_WORDS 32                 // 128-byte rows (112-byte rows without the padding quad: 6 % slower in the table passes, round 2)
 #define PLUME_TAB_WORDS (PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 
 // table entry access (layout above)
@@ -300,9 +284,7 @@ PLUME_HD void ld_tab_xy(fe& x, fe& y, const uint32_t* e, bool lambda_half) {
 PLUME_HD void st_tab_entry(uint32_t* e, const fe& x, const fe& y, const fe& bx) {   // (non-temporal stores here: 3.6x slower, they defeat write combining)
     PLUME_UNROLL for (int i = 0; i < 8; i++) { e[i] = x.v[i]; e[8 + i] = y.v[i]; e[16 + i] = bx.v[i]; }
     e[24] = x.v[8]; e[25] = y.v[8]; e[26] = bx.v[8]; e[27] = 0;
-#if PLUME_TAB_ENTRY_WORDS == 32
     e[28] = 0; e[29] = 0; e[30] = 0; e[31] = 0;     // padding quad: the row is written as a whole cache line
-#endif
 }
 PLUME_HD void ld_fe(fe& r, const uint32_t* p) { PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = p[i]; }
 PLUME_HD void st_fe(uint32_t* p, const fe& a) { PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) p[i] = a.v[i]; }
@@ -344,9 +326,6 @@ PLUME_HD void ld_base(jac& p, const uint32_t* bases, size_t job, bool with_z) {
     }
 }
 
-#ifndef PLUME_TABLE_MADD
-#define PLUME_TABLE_MADD 1   // mixed additions for Z = 1 bases (pk, nullifier) in table_build: 8M+3S instead of 12M+4S per odd multiple
-#endif
 #define PLUME_JOB_OK 0u
 #define PLUME_JOB_INF 1u      // base is the identity: its slots are skipped
 #define PLUME_JOB_INVALID 2u  // base failed validation: a dummy (G) table is built, the item is rejected elsewhere
@@ -361,80 +340,6 @@ PLUME_HD uint32_t job_state(uint8_t f) { return f & 3u; }
 #endif
 #define PLUME_COMB_ENTRIES (1 << (PLUME_COMB_W - 1))
 #define PLUME_COMB_WINDOW_WORDS (PLUME_COMB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
-
-// Build the tables of jobs [j0, j0+cnt) (cnt <= L, one lane).  Bases are job-major records (st_base).
-// Pass 1 writes (X_k, Y_k, Z_k, running product before Z_k) for k = 1..8 of every job to the lane's slice of `scr`; one
-// inversion of the total product; pass 2 walks back, peels off each 1/Z_k, and writes the affine entry (x, y, beta*x) to `tab`.
-// scr is lane-interleaved: word w of the lane's q-th scratch entry lives at scr[(q * PLUME_TAB_SCR_WORDS + w) * sstride + slane],
-// so the 64 lanes of a wavefront (which walk their entries in lock step) touch 64 consecutive words per instruction -- the
-// pass-1 traffic (288 B per entry, written once and read once or twice) is fully coalesced; only the final 128-byte rows,
-// which the multi-scalar kernel gathers per lane, are scattered.  A single-lane build passes sstride = 1, slane = 0.
-PLUME_HD void scr_st(uint32_t* scr, size_t sstride, size_t slane, size_t q, int f, const fe& a) {
-    PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) scr[((q * PLUME_TAB_SCR_WORDS + (size_t)(f * PLUME_FE_W + i)) * sstride) + slane] = a.v[i];
-}
-PLUME_HD void scr_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, size_t q, int f) {
-    PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = scr[((q * PLUME_TAB_SCR_WORDS + (size_t)(f * PLUME_FE_W + i)) * sstride) + slane];
-}
-// how pass 2 writes a finished row: directly (each lane its own 128 bytes), or through a kernel-supplied sink (plume_kernels.hip
-// transposes the rows of a wavefront through LDS so that every store instruction writes whole cache lines)
-struct DirectRowSink {
-    PLUME_HD void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const { st_tab_entry(e, x, y, bx); }
-};
-template <int ENTRIES = PLUME_TAB_ENTRIES, class RowSink = DirectRowSink>
-PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
-                          const RowSink& sink = RowSink()) {
-    fe acc = fe_small(1);
-    PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
-        size_t job = j0 + (size_t)jj;
-        jac b;
-        ld_base(b, bases, job, true);
-        b.inf = 0;
-        const bool zone = (jobflags[job] & PLUME_JOB_AFFINE) != 0;   // wave-uniform when job kinds repeat with period | cnt
-        (void)zone;
-        if (job_state(jobflags[job]) != PLUME_JOB_OK) { b.x = fe_gx(); b.y = fe_gy(); b.z = fe_small(1); }
-        jac cur = b;
-        PLUME_NOUNROLL for (int k = 0; k < ENTRIES; k++) {
-            // entry k holds (k+1)P.  Even multiples are doublings of an earlier entry (3M+4S instead of a 12M+4S addition):
-            // 2P = 2*P, 3P = 2P+P, 4P = 2*(2P), 5P = 4P+P, 6P = 2*(3P), ...  The half entry is re-read from the scratch this lane
-            // has just written (Jacobian coordinates).
-            const size_t q = (size_t)jj * ENTRIES + (size_t)k;
-            if (k >= 1 && (k & 1)) {
-                if (k > 1) {
-                    const size_t qh = (size_t)jj * ENTRIES + (size_t)((k + 1) / 2 - 1);
-                    scr_ld(cur.x, scr, sstride, slane, qh, 0); scr_ld(cur.y, scr, sstride, slane, qh, 1); scr_ld(cur.z, scr, sstride, slane, qh, 2);
-                }
-                jac_dbl(cur);
-            }
-#if PLUME_TABLE_MADD
-            else if (k > 1) { if (zone) jac_madd(cur, b.x, b.y); else jac_add(cur, b); }
-#else
-            else if (k > 1) jac_add(cur, b);
-#endif
-            scr_st(scr, sstride, slane, q, 0, cur.x); scr_st(scr, sstride, slane, q, 1, cur.y); scr_st(scr, sstride, slane, q, 2, cur.z); scr_st(scr, sstride, slane, q, 3, acc);
-            fe_mul(acc, acc, cur.z);
-        }
-    }
-    fe inv;
-    fe_inv(inv, acc);
-    const fe beta = fe_beta();
-    // (a software-pipelined pass 2 -- fetch entry q-1 while converting entry q -- measured 25 % SLOWER: 36 more live registers)
-    PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
-        size_t job = j0 + (size_t)jj;
-        PLUME_NOUNROLL for (int k = ENTRIES - 1; k >= 0; k--) {
-            const size_t q = (size_t)jj * ENTRIES + (size_t)k;
-            uint32_t* e = tab + job * (size_t)(ENTRIES * PLUME_TAB_ENTRY_WORDS) + k * PLUME_TAB_ENTRY_WORDS;
-            fe X, Y, Zk, cprev, zi, zi2;
-            scr_ld(X, scr, sstride, slane, q, 0); scr_ld(Y, scr, sstride, slane, q, 1); scr_ld(Zk, scr, sstride, slane, q, 2); scr_ld(cprev, scr, sstride, slane, q, 3);
-            fe_mul(zi, inv, cprev);      // 1/Z_k
-            fe_mul(inv, inv, Zk);        // inverse of the product before Z_k
-            fe_sqr(zi2, zi);
-            fe_mul(X, X, zi2);
-            fe_mul(zi2, zi2, zi); fe_mul(Y, Y, zi2);
-            fe bx; fe_mul_k(bx, beta, X);
-            sink(e, X, Y, bx);           // tight, not canonical: only ever multiplied / negated
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------ window tables by affine chains (round 2)
 // The window tables of the per-item bases (1P..8P, affine, + beta*x) built WITHOUT Jacobian intermediates: every entry comes from an affine
@@ -457,11 +362,7 @@ PLUME_HD void pre_st(uint32_t* scr, size_t sstride, size_t slane, size_t q, cons
 PLUME_HD void pre_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, size_t q) {
     PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = scr[((q * PLUME_FE_W + (size_t)i) * sstride) + slane];
 }
-#if PLUME_TAB_ENTRIES == 16
-#define PLUME_TAB_AFF_SCR_WORDS (3 * PLUME_FE_WORDS)       // ... and two for level 4 (its eight denominators go in two halves)
-#else
 #define PLUME_TAB_AFF_SCR_WORDS (2 * PLUME_FE_WORDS)       // prefix products per job: ONE per level (below), two alternating regions (consecutive levels overlap)
-#endif
 // 2P from affine P = (x, y) (tight) and l = 1 / (2y)
 PLUME_HD void aff_dbl(fe& x3, fe& y3, const fe& x, const fe& y, const fe& l) {
     fe lam, t;
@@ -484,7 +385,7 @@ PLUME_HD void aff_add(fe& x3, fe& y3, const fe& x1, const fe& y1, const fe& x2, 
 struct DirectRowSinkSync {                                       // host / single-lane builds: rows are stored by the lane that reads them back
     PLUME_HD void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const { st_tab_entry(e, x, y, bx); }
     PLUME_HD void sync() const {}
-    // the inversion of one level's product (never zero, see the guard); the table kernel's sink shares one inversion between the wavefronts of a workgroup
+    // the inversion of one level's product (never zero, see the guard)
     PLUME_HD void inv(fe& r, const fe& a, int) const { fe_inv(r, a); }
 };
 // Montgomery's trick in two tiers, so that a level costs ONE scratch slot per job instead of one per denominator (the table kernel is bandwidth-bound: 36 bytes
@@ -531,25 +432,14 @@ PLUME_HD void tab_den_l3(fe d[4], fe& p01, fe& p23, fe& D, const fe& x1, const f
     PLUME_UNROLL for (int k = 0; k < 4; k++) guard_one(d[k], guard);
     fe_mul(p01, d[0], d[1]); fe_mul(p23, d[2], d[3]); fe_mul(D, p01, p23);
 }
-// level 4 (16-row tables only), in two halves of four denominators each, same shape as level 3:
-//   half A  9P = 8P + P, 10P = 2 * 5P, 11P = 8P + 3P, 12P = 2 * 6P:   x8 - x1, 2 y5, x8 - x3, 2 y6
-//   half B 13P = 8P + 5P, 14P = 2 * 7P, 15P = 8P + 7P, 16P = 2 * 8P:  x8 - x5, 2 y7, x8 - x7, 2 y8
-PLUME_HD void tab_den_l4(fe d[4], fe& p01, fe& p23, fe& D, const fe& xa, const fe& ya, const fe& xb, const fe& yb, const fe& x8, bool guard) {
-    fe_sub_lazy<2>(d[0], x8, xa); fe_dbl_lazy(d[1], ya); fe_sub_lazy<2>(d[2], x8, xb); fe_dbl_lazy(d[3], yb);
-    PLUME_UNROLL for (int k = 0; k < 4; k++) guard_one(d[k], guard);
-    fe_mul(p01, d[0], d[1]); fe_mul(p23, d[2], d[3]); fe_mul(D, p01, p23);
-}
-PLUME_HD void ld_tab_x(fe& x, const uint32_t* e) { PLUME_UNROLL for (int i = 0; i < 8; i++) x.v[i] = e[i]; x.v[8] = e[24]; }
-PLUME_HD void ld_tab_y(fe& y, const uint32_t* e) { PLUME_UNROLL for (int i = 0; i < 8; i++) y.v[i] = e[8 + i]; y.v[8] = e[25]; }
 // Level k+1's denominators are formed -- and their product joins the lane's chain -- inside level k's finishing pass, while the entries they come from are
 // still in registers: four passes over a lane's jobs instead of six, and no pass that only re-reads rows.  Consecutive levels therefore run through the
 // jobs in opposite directions (a level is finished in the reverse of the order its products were parked in) and use alternating scratch regions.
 // The chain as PASSES (round 3).  Each pass walks the lane's jobs once; between two passes stands ONE field inversion of the lane's running product.  The passes share
 // no registers: what a lane carries from one to the next is that product / its inverse (`carry`, 9 words) and the guard flag, so the same code serves
-//   * table_build_affine below: all passes in one function, the inversion through the sink (host builds, single-lane builds, the one-kernel form of k_tables), and
-//   * the multi-kernel form of k_tables: one launch per pass with a small batched-inversion kernel (k_tab_invert) in between, `carry` parked in HBM.  No pass then
-//     contains an inversion or a workgroup barrier: in the one-kernel form a workgroup's waves idle through three serial 20 k-instruction inversions (VALUBusy 0.50,
-//     DESIGN.md §5); here every pass is a plain streaming kernel and the inversions of the whole batch run as one dense launch.
+//   * the table stage of the library: one launch per pass (k_tab_pass_a..d) with a small batched-inversion kernel (k_tab_invert) in between, `carry` parked in HBM: every
+//     pass is a plain streaming kernel, no inversion and no workgroup barrier inside, and the inversions of the whole batch run as one dense launch;
+//   * table_build_affine below: all passes in one function with the inversions in place (single-lane builds; the host harness holds the pass sequence to it).
 // Pass A (jobs ascending): denominators of level 1 -> carry = their product.
 template <class RowSink>
 PLUME_HD void tab_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane, fe& carry, bool& guard) {
@@ -655,10 +545,6 @@ PLUME_HD void tab_pass_d(uint32_t* tab, size_t j0, int cnt, uint32_t* scr, size_
     const fe beta = fe_beta();
     constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
     fe inv = carry;
-#if PLUME_TAB_ENTRIES == 16
-    const size_t RB = (size_t)cnt;
-    fe acc = fe_small(1);
-#endif
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
         uint32_t* t = tab + (j0 + (size_t)jj) * TW;
         fe x1, y1, x3, y3, x4, y4, d[4], p01, p23, D, Dinv, i01, i23, l, xr, yr, bx;
@@ -670,110 +556,18 @@ PLUME_HD void tab_pass_d(uint32_t* tab, size_t j0, int cnt, uint32_t* scr, size_
         fe_mul(l, i23, d[2]);                                                       // 1 / (2 y4)
         aff_dbl(xr, yr, x4, y4, l);                                                 // 8P
         fe_mul_k(bx, beta, xr); sink(t + 7 * EW, xr, yr, bx);
-#if PLUME_TAB_ENTRIES == 16
-        // level 4's two products grow as the entries appear (the entries themselves are not kept): PA = (x8-x1)(2y5)(x8-x3)(2y6), PB = (x8-x5)(2y7)(x8-x7)(2y8)
-        fe x8 = xr, PA, PB, dd;
-        fe_dbl_lazy(PB, yr);                                                        // 2 y8
-#endif
         fe_mul(l, i23, d[3]);                                                       // 1 / (x4 - x3)
         aff_add(xr, yr, x3, y3, x4, y4, l);                                         // 7P
         fe_mul_k(bx, beta, xr); sink(t + 6 * EW, xr, yr, bx);
-#if PLUME_TAB_ENTRIES == 16
-        fe_dbl_lazy(dd, yr); fe_mul(PB, PB, dd);                                    // 2 y7
-        fe_sub_lazy<2>(dd, x8, xr); fe_mul(PB, PB, dd);                             // x8 - x7
-#endif
         fe_mul(l, i01, d[0]);                                                       // 1 / (2 y3)
         aff_dbl(xr, yr, x3, y3, l);                                                 // 6P
         fe_mul_k(bx, beta, xr); sink(t + 5 * EW, xr, yr, bx);
-#if PLUME_TAB_ENTRIES == 16
-        fe_dbl_lazy(PA, yr);                                                        // 2 y6
-#endif
         fe_mul(l, i01, d[1]);                                                       // 1 / (x4 - x1)
         aff_add(xr, yr, x1, y1, x4, y4, l);                                         // 5P
         fe_mul_k(bx, beta, xr); sink(t + 4 * EW, xr, yr, bx);
-#if PLUME_TAB_ENTRIES == 16
-        fe_dbl_lazy(dd, yr); fe_mul(PA, PA, dd);                                    // 2 y5
-        fe_sub_lazy<2>(dd, x8, xr); fe_mul(PB, PB, dd);                             // x8 - x5
-        fe_sub_lazy<2>(dd, x8, x1); fe_mul(PA, PA, dd);                             // x8 - x1
-        fe_sub_lazy<2>(dd, x8, x3); fe_mul(PA, PA, dd);                             // x8 - x3
-        tab_park(acc, scr, sstride, slane, RB + 2 * (size_t)jj, PA);
-        tab_park(acc, scr, sstride, slane, RB + 2 * (size_t)jj + 1, PB);
-#endif
     }
-#if PLUME_TAB_ENTRIES == 16
-    sink.sync();
-    if (guard || fe_is_zero(acc)) {                                                 // cold: the same products, from the rows, with the zero check
-        guard = true; acc = fe_small(1);
-        PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
-            const uint32_t* t = tab + (j0 + (size_t)jj) * TW;
-            fe xa, ya, xb, yb, x8, d[4], p01, p23, D;
-            ld_tab_x(x8, t + 7 * EW);
-            ld_tab_x(xa, t); ld_tab_y(ya, t + 4 * EW); ld_tab_x(xb, t + 2 * EW); ld_tab_y(yb, t + 5 * EW);
-            tab_den_l4(d, p01, p23, D, xa, ya, xb, yb, x8, true);
-            tab_park(acc, scr, sstride, slane, RB + 2 * (size_t)jj, D);
-            ld_tab_x(xa, t + 4 * EW); ld_tab_y(ya, t + 6 * EW); ld_tab_x(xb, t + 6 * EW); ld_tab_y(yb, t + 7 * EW);
-            tab_den_l4(d, p01, p23, D, xa, ya, xb, yb, x8, true);
-            tab_park(acc, scr, sstride, slane, RB + 2 * (size_t)jj + 1, D);
-        }
-    }
-    carry = acc;
-#else
     (void)scr; (void)sstride; (void)slane; (void)guard;
-#endif
 }
-#if PLUME_TAB_ENTRIES == 16
-// Pass E (16-row tables; jobs ascending; per job half B, then half A: the reverse of the parking order): carry = 1 / (level 4's product) in; 9P..16P.
-template <class RowSink>
-PLUME_HD void tab_pass_e(uint32_t* tab, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane, fe& carry, bool& guard, const RowSink& sink) {
-    const fe beta = fe_beta();
-    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
-    const size_t RB = (size_t)cnt;
-    fe inv = carry;
-    PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
-        uint32_t* t = tab + (j0 + (size_t)jj) * TW;
-        fe x8, y8, xa, ya, xb, yb, d[4], p01, p23, D, Dinv, i01, i23, l, xr, yr, bx;
-        ld_tab_xy(x8, y8, t + 7 * EW, false);
-        // half B: 13P = 8P + 5P, 14P = 2 * 7P, 15P = 8P + 7P, 16P = 2 * 8P
-        ld_tab_xy(xa, ya, t + 4 * EW, false); ld_tab_xy(xb, yb, t + 6 * EW, false);          // 5P, 7P
-        tab_den_l4(d, p01, p23, D, xa, yb, xb, y8, x8, guard);                        // x8 - x5, 2 y7, x8 - x7, 2 y8
-        tab_unpark(Dinv, inv, scr, sstride, slane, RB + 2 * (size_t)jj + 1, D);
-        fe_mul(i01, Dinv, p23); fe_mul(i23, Dinv, p01);
-        fe_mul(l, i01, d[1]);                                                       // 1 / (x8 - x5)
-        aff_add(xr, yr, xa, ya, x8, y8, l);                                         // 13P
-        fe_mul_k(bx, beta, xr); sink(t + 12 * EW, xr, yr, bx);
-        fe_mul(l, i01, d[0]);                                                       // 1 / (2 y7)
-        aff_dbl(xr, yr, xb, yb, l);                                                 // 14P
-        fe_mul_k(bx, beta, xr); sink(t + 13 * EW, xr, yr, bx);
-        fe_mul(l, i23, d[3]);                                                       // 1 / (x8 - x7)
-        aff_add(xr, yr, xb, yb, x8, y8, l);                                         // 15P
-        fe_mul_k(bx, beta, xr); sink(t + 14 * EW, xr, yr, bx);
-        fe_mul(l, i23, d[2]);                                                       // 1 / (2 y8)
-        aff_dbl(xr, yr, x8, y8, l);                                                 // 16P
-        fe_mul_k(bx, beta, xr); sink(t + 15 * EW, xr, yr, bx);
-        // half A: 9P = 8P + P, 10P = 2 * 5P, 11P = 8P + 3P, 12P = 2 * 6P
-        fe y5, y6;
-        ld_tab_xy(xa, ya, t, false); ld_tab_xy(xb, yb, t + 2 * EW, false);                   // P, 3P
-        ld_tab_y(y5, t + 4 * EW); ld_tab_y(y6, t + 5 * EW);
-        tab_den_l4(d, p01, p23, D, xa, y5, xb, y6, x8, guard);                        // x8 - x1, 2 y5, x8 - x3, 2 y6
-        tab_unpark(Dinv, inv, scr, sstride, slane, RB + 2 * (size_t)jj, D);
-        fe_mul(i01, Dinv, p23); fe_mul(i23, Dinv, p01);
-        fe_mul(l, i01, d[1]);                                                       // 1 / (x8 - x1)
-        aff_add(xr, yr, xa, ya, x8, y8, l);                                         // 9P
-        fe_mul_k(bx, beta, xr); sink(t + 8 * EW, xr, yr, bx);
-        fe_mul(l, i23, d[3]);                                                       // 1 / (x8 - x3)
-        aff_add(xr, yr, xb, yb, x8, y8, l);                                         // 11P
-        fe_mul_k(bx, beta, xr); sink(t + 10 * EW, xr, yr, bx);
-        fe_mul(i01, i01, d[0]);                                                     // 1 / (2 y5)
-        fe_mul(i23, i23, d[2]);                                                     // 1 / (2 y6)
-        ld_tab_xy(xa, ya, t + 4 * EW, false);                                       // 5P
-        aff_dbl(xr, yr, xa, ya, i01);                                               // 10P
-        fe_mul_k(bx, beta, xr); sink(t + 9 * EW, xr, yr, bx);
-        ld_tab_xy(xa, ya, t + 5 * EW, false);                                       // 6P
-        aff_dbl(xr, yr, xa, ya, i23);                                               // 12P
-        fe_mul_k(bx, beta, xr); sink(t + 11 * EW, xr, yr, bx);
-    }
-}
-#endif
 // The inversion between two passes of the multi-kernel form: thread t of T takes the lane products t, t + T, ..., t + (K-1) T of the nl lanes (word-major array: coalesced)
 // and spends ONE inversion on their product (Montgomery's trick); in place.  The products are never zero (the passes' guard).
 template <int K>
@@ -794,8 +588,8 @@ PLUME_HD void tab_invert_group(uint32_t* carry, size_t nl, size_t T, size_t t) {
         if (l < nl) st_fe_soa(carry, nl, l, o);
     }
 }
-// All passes in one function: host builds, single-lane builds and the one-kernel form of k_tables (the sink supplies the inversion: DirectRowSinkSync inverts in place,
-// the table kernel's CoopRowSink shares one inversion between the wavefronts of a workgroup).
+// All passes in one function with the inversions in place: single-lane builds (the host harness checks the pass sequence against it; rounds 2-3 shipped a one-kernel
+// table stage of this shape, LABNOTES.md).
 template <class RowSink = DirectRowSinkSync>
 PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
                                  const RowSink& sink = RowSink()) {
@@ -808,10 +602,6 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
     tab_pass_c(tab, j0, cnt, scr, sstride, slane, carry, guard, sink);
     sink.inv(inv, carry, 3); carry = inv;
     tab_pass_d(tab, j0, cnt, scr, sstride, slane, carry, guard, sink);
-#if PLUME_TAB_ENTRIES == 16
-    sink.inv(inv, carry, 4); carry = inv;
-    tab_pass_e(tab, j0, cnt, scr, sstride, slane, carry, guard, sink);
-#endif
 }
 
 // ------------------------------------------------------------------------------ the generator's fixed tables, one entry per lane (round 3)
@@ -935,18 +725,12 @@ PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
 // halves (beta*x).  dig: digits of slot s, window i at dig[(s*PLUME_NDIG + i)*stride].  A NULL table (or a
 // job flagged INF) contributes nothing.
 // wide0: slots 0,1 use the generator's wide table with W-bit digits (stored by booth_store_wide).
-#ifndef PLUME_MSM_PREFETCH
-#define PLUME_MSM_PREFETCH 0   // 1: the row of the NEXT table addition is gathered while the current addition (or the window's doublings) runs; 0: gather, wait, add.
-                               // Round 3 built and measured the pipelined form (125 VGPRs, no spills, bit-exact): multi-scalar kernel 17.61 vs 17.48 ms on one box, the signer's
-                               // 13.20 vs 13.29 -- nothing: the SIMD's other three wavefronts already cover a gather's latency (VALUBusy 1.0).  Kept as the experiment's record.
-#endif
 // digit of slot s at window i (wide generator digits decoded); 0 = nothing to add
 PLUME_HD int msm_digit(const int8_t* dig, uint32_t stride, int i, int s, bool wide0) {
     int d = dig[(uint32_t)(s * PLUME_NDIG + i) * stride];
     if (wide0 && s < 2) {
         int mag = d & 0xFF;
         bool dn;
-#if PLUME_GW > 15
         if (i + PLUME_GW_BYTES < PLUME_NDIG) {
             PLUME_UNROLL for (int b = 1; b < PLUME_GW_BYTES; b++) mag |= (dig[(uint32_t)(s * PLUME_NDIG + i + b) * stride] & 0xFF) << (8 * b);
             dn = dig[(uint32_t)(s * PLUME_NDIG + i + PLUME_GW_BYTES) * stride] != 0;
@@ -954,12 +738,6 @@ PLUME_HD int msm_digit(const int8_t* dig, uint32_t stride, int i, int s, bool wi
             const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
             mag |= (hi & 0x7F) << 8; dn = (hi & 0x80) != 0;
         } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
-#else
-        if (i + 1 < PLUME_NDIG) {
-            const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
-            mag |= (hi & 0x7F) << 8; dn = (hi & 0x80) != 0;
-        } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
-#endif
         d = dn ? -mag : mag;
     }
     return d;
@@ -981,34 +759,6 @@ PLUME_HD int msm_fetch(fe& qx, fe& qy, const uint32_t* tab0, const uint32_t* tab
 template <bool CHECKED>
 PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
-#if PLUME_MSM_PREFETCH
-    // software pipeline over the steps (window i descending, slot s ascending, unused wide slots skipped): the operand of the step after the current one is in flight
-    // while the current addition -- or the four doublings between two windows -- runs.  (Rounds 1-2 gathered, waited and added: every addition exposed an HBM / L2 round
-    // trip to its wavefront, hidden only as far as the SIMD's other wavefronts were not waiting themselves.)
-    fe nx = fe_small(0), ny = fe_small(0);
-    int ni = PLUME_NDIG - 1, ns = 0;
-    while (ns < nslots && !msm_slot_used(ni, ns, wide0)) ns++;                       // first step (window NDIG-1 always holds slot 0 .. for wide digits NDIG-1 is a multiple of GWS)
-    int nd = ns < nslots ? msm_fetch(nx, ny, tab0, tab1, dig, stride, ni, ns, wide0) : 0;
-    PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
-        if (i != PLUME_NDIG - 1) {
-            PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl(acc);
-        }
-        PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
-            if (!msm_slot_used(i, s, wide0)) continue;                              // wave-uniform
-            fe qx = nx, qy = ny;
-            const int d = nd;
-            // successor step
-            ni = i; ns = s + 1;
-            while (ns < nslots && !msm_slot_used(ni, ns, wide0)) ns++;
-            if (ns >= nslots) { ni = i - 1; ns = 0; while (ni >= 0 && ns < nslots && !msm_slot_used(ni, ns, wide0)) ns++; }
-            nd = (ni >= 0 && ns < nslots) ? msm_fetch(nx, ny, tab0, tab1, dig, stride, ni, ns, wide0) : 0;
-            if (d != 0) {
-                if (d < 0) fe_neg_lazy(qy, qy);
-                jac_madd<CHECKED>(acc, qx, qy);
-            }
-        }
-    }
-#else
     PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
         if (i != PLUME_NDIG - 1) {
             PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl(acc);
@@ -1023,7 +773,6 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
             }
         }
     }
-#endif
 }
 // the same chain with the checked additions only (the redo kernel of the verifier: tasks whose unchecked chain met p == +-q)
 PLUME_HD void msm_run_checked(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {

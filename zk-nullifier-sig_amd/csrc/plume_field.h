@@ -84,18 +84,15 @@ PLUME_HD uint32_t opaque_u32(uint32_t x) {
 // Selects.  hipcc compiles `flag ? a : b` on 32-bit values to v_cndmask_b32 with the condition in VCC, and a RUN of those -- a multi-limb select, a select chain -- is the
 // slowest thing the SIMD does: tests/gpu_debug/instr_rates_r03.txt, one compare + 7 v_cndmask on its VCC = 6.7 ns per instruction at ANY occupancy (a multiply-add: 1.8).
 // A select through an opaque all-ones / all-zeros mask compiles to one v_bfi_b32 (1.8 ns) instead; the mask costs two instructions per condition.
-#ifndef PLUME_SELECT_BY_MASK
-#define PLUME_SELECT_BY_MASK 1
-#endif
 PLUME_HD uint32_t sel_mask(bool flag) {
     uint32_t m = 0u - (uint32_t)flag;
-#if defined(__HIP_DEVICE_COMPILE__) && PLUME_SELECT_BY_MASK
+#if defined(__HIP_DEVICE_COMPILE__)
     asm("" : "+v"(m));              // or the compiler turns the mask arithmetic back into a select
 #endif
     return m;
 }
 PLUME_HD uint32_t sel32(uint32_t mask, uint32_t a, uint32_t b) {      // mask all ones: a, all zeros: b
-#if defined(__HIP_DEVICE_COMPILE__) && PLUME_SELECT_BY_MASK
+#if defined(__HIP_DEVICE_COMPILE__)
     return (a & mask) | (b & ~mask);
 #else
     return mask ? a : b;
@@ -265,10 +262,7 @@ PLUME_HD void fe_dbl_lazy(fe& r, const fe& a) {
     PLUME_UNROLL for (int i = 0; i < 9; i++) { PLUME_FE_ASSERT((uint64_t)a.v[i] * 2 < (1ull << 32)); r.v[i] = u32_dbl(a.v[i]); }
 }
 
-#ifndef PLUME_FE_MUL_INC
-#define PLUME_FE_MUL_INC "plume_fe_mul.inc"
-#endif
-#include PLUME_FE_MUL_INC
+#include "plume_fe_mul.inc"
 
 // r = a * k for a small k (< 2^20), any a with limbs < 2^32; tight result
 PLUME_HD void fe_mul_small(fe& r, const fe& a, uint32_t k) {
@@ -446,11 +440,7 @@ PLUME_HD void fe_inv_gcd(fe& r, const fe& a) {
     }
     fe_from_words(r, w);
 }
-#ifndef PLUME_INV_FERMAT
 PLUME_HD void fe_inv(fe& r, const fe& a) { fe_inv_gcd(r, a); }
-#else
-PLUME_HD void fe_inv(fe& r, const fe& a) { fe_inv_fermat(r, a); }
-#endif
 
 // a^((p-3)/4)  (RFC 9380 F.2.1.2 constant c1): 253 squarings + 14 multiplications
 PLUME_HD void fe_pow_c1(fe& r, const fe& a) {

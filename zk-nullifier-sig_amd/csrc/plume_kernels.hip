@@ -16,29 +16,15 @@
 // Minimum waves per SIMD the register allocator must leave room for (HIP's second __launch_bounds__ argument).  The
 // instruction-rate probe (tests/gpu_debug/instr_rates_r01.txt) shows the VALU saturates at 4 waves per SIMD and loses
 // 2-3x at one; without a floor hipcc takes up to 300 VGPRs for the hash-to-curve kernels (one wave per SIMD).
-#ifndef PLUME_MIN_WAVES
 #define PLUME_MIN_WAVES 4
-#endif
-#ifndef PLUME_MSM_WAVES
 #define PLUME_MSM_WAVES PLUME_MIN_WAVES
-#endif
-#ifndef PLUME_TABLES_WAVES
-#define PLUME_TABLES_WAVES 3   // the table kernel streams ~3.6 KB per job through HBM; 3 waves with fewer spills measured 9 % faster than 4
-#endif
-#ifndef PLUME_H2C_WAVES
 #define PLUME_H2C_WAVES 3      // round 3, after the one-isogeny hash_to_curve: 3 waves (168 VGPRs, fewer spills) 2.54 ms, 4 waves 2.58, 2 waves 2.65 per 2^20 items (one box)
-#endif
-#ifndef PLUME_FINAL_WAVES
 #define PLUME_FINAL_WAVES 2    // the finalize kernels hold six encodings + SHA state: at 4 waves they spill ~200 VGPRs (measured 0.48 -> 0.33 ms at 2)
-#endif
-#ifndef PLUME_NORM_WAVES
 #define PLUME_NORM_WAVES 2     // 8 points per lane with their prefix products live in registers
-#endif
 #define PLUME_BOUNDS __launch_bounds__(kBlock, PLUME_MIN_WAVES)
 #define PLUME_FINAL_BOUNDS __launch_bounds__(kBlock, PLUME_FINAL_WAVES)
 #define PLUME_NORM_BOUNDS __launch_bounds__(kBlock, PLUME_NORM_WAVES)
 #define PLUME_MSM_BOUNDS __launch_bounds__(kBlock, PLUME_MSM_WAVES)
-#define PLUME_TABLES_BOUNDS __launch_bounds__(kBlock, PLUME_TABLES_WAVES)
 #define PLUME_H2C_BOUNDS __launch_bounds__(kBlock, PLUME_H2C_WAVES)
 
 namespace plume {
@@ -62,57 +48,14 @@ __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
     if (i < a.n) verify_ingest_h2c(a, i);
 }
 
-// Row sink of the table kernel.  A lane finishes one 128-byte row at a time, and the 64 rows a wavefront finishes together lie
+// Row sink of the table passes.  A lane finishes one 128-byte row at a time, and the 64 rows a wavefront finishes together lie
 // kilobytes apart, so storing them directly makes every store instruction touch 64 different cache lines with 16 bytes each.  When
 // all 64 lanes of the wavefront are in lock step (every wave except the batch's last one) the rows are transposed through LDS
 // instead: lane i then stores quad (i mod 8) of row (i div 8 + 8q), q = 0..7, i.e. every store instruction writes 8 complete lines.
-#ifndef PLUME_TABLES_COOP_STORE
-#define PLUME_TABLES_COOP_STORE 1
-#endif
-#ifndef PLUME_TABLES_AFFINE
-#define PLUME_TABLES_AFFINE 1    // 1: affine chains with level-batched inversions (table_build_affine); 0: the round-1 Jacobian builder (A/B runs)
-#endif
-#ifndef PLUME_TABLES_SHARED_INV
-#define PLUME_TABLES_SHARED_INV 1   // 1: one wavefront of the workgroup inverts for all four (below); 0: every lane inverts its own product (A/B runs)
-#endif
-struct CoopRowSink {
+struct WaveRowSink {
     uint4* rows;             // this wavefront's 64 x 8 quads (quad index xor-swizzled by row against bank conflicts)
     uint32_t** ptrs;         // this wavefront's 64 row addresses
     bool full;               // wave-uniform: all 64 lanes build the same number of rows
-    uint32_t* xch;           // the workgroup's row area, reused between levels as the exchange area of the shared inversion
-    // One level's inversion, shared by the wavefronts of the workgroup.  In SIMT an inversion costs a wavefront the same ~20 k instructions whether one lane
-    // or all 64 need it, so Montgomery's trick across LANES saves nothing -- across WAVEFRONTS it does: every lane parks its product in LDS, lane l of ONE
-    // wavefront multiplies the kWaves products of column l, inverts once, and peels the kWaves inverses off again (3 (kWaves - 1) multiplications), the other
-    // wavefronts wait at the barrier while the SIMDs run other workgroups.  The inverting wavefront rotates with the level and the workgroup so that the
-    // inversions spread over the four SIMDs of a CU.  A lane's slot lies inside its own wavefront's row area: rows are only staged there between the
-    // wave-level barriers of operator(), never across a workgroup barrier.  Every thread of the workgroup must get here (k_tables calls the builder with cnt = 0
-    // for lanes past the end); the products are never zero (table_build_affine's guard).
-    __device__ void inv(fe& r, const fe& a, int level) const {
-#if PLUME_TABLES_SHARED_INV
-        constexpr uint32_t kWaves = kBlock / 64, kWaveWords = 64 * 8 * 4;
-        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-        uint32_t* mine = xch + wave * kWaveWords + lane;
-        PLUME_UNROLL for (int i = 0; i < PLUME_FE_WORDS; i++) mine[i * 64] = a.v[i];
-        __syncthreads();
-        if (wave == (((uint32_t)level + blockIdx.x) % kWaves)) {
-            fe v[kWaves], pre[kWaves], t;
-            PLUME_UNROLL for (uint32_t k = 0; k < kWaves; k++) {
-                PLUME_UNROLL for (int i = 0; i < PLUME_FE_WORDS; i++) v[k].v[i] = xch[k * kWaveWords + lane + i * 64];
-                if (k == 0) pre[0] = v[0]; else fe_mul(pre[k], pre[k - 1], v[k]);
-            }
-            fe_inv(t, pre[kWaves - 1]);
-            PLUME_UNROLL for (int k = (int)kWaves - 1; k >= 0; k--) {
-                fe o;
-                if (k > 0) { fe_mul(o, t, pre[k - 1]); fe_mul(t, t, v[k]); } else o = t;
-                PLUME_UNROLL for (int i = 0; i < PLUME_FE_WORDS; i++) xch[(uint32_t)k * kWaveWords + lane + i * 64] = o.v[i];
-            }
-        }
-        __syncthreads();
-        PLUME_UNROLL for (int i = 0; i < PLUME_FE_WORDS; i++) r.v[i] = mine[i * 64];
-#else
-        (void)level; fe_inv(r, a);
-#endif
-    }
     // rows stored by OTHER lanes of the wavefront are read back by their owner in the next level of table_build_affine: order the wave's stores before its loads
     __device__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     __device__ void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const {
@@ -142,58 +85,13 @@ struct CoopRowSink {
     }
 };
 
-__global__ PLUME_TABLES_BOUNDS void k_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr) {
-#if PLUME_TABLES_COOP_STORE
-    static_assert(PLUME_TAB_ENTRY_WORDS == 32, "the cooperative row store assumes 128-byte rows");
-    __shared__ uint4 s_rows[kBlock * 8];
-    __shared__ uint32_t* s_ptrs[kBlock];
-#endif
-    size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    size_t j0 = lane * (size_t)L;
-    const int cnt = j0 < njobs ? (int)((njobs - j0) < (size_t)L ? (njobs - j0) : (size_t)L) : 0;
-#if PLUME_TABLES_COOP_STORE
-    CoopRowSink sink;
-    sink.rows = s_rows + (threadIdx.x & ~63u) * 8;
-    sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
-    sink.full = __ballot(cnt == L) == ~0ull;
-    sink.xch = reinterpret_cast<uint32_t*>(s_rows);
-#if PLUME_TABLES_AFFINE
-    // scratch interleaved across the lanes of THIS workgroup only (stride kBlock words): the words of one prefix product lie 1 KiB apart inside the workgroup's own
-    // region instead of (lanes x 4) bytes apart across the whole buffer -- same coalescing, but a wave's accesses stay within a few pages
-    // (every lane calls it, also with cnt = 0: the shared inversion has workgroup barriers)
-    table_build_affine<CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kBlock), (size_t)kBlock, threadIdx.x, sink);
-#else
-    if (cnt > 0) table_build<PLUME_TAB_ENTRIES, CoopRowSink>(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane, sink);
-#endif
-#else
-#if PLUME_TABLES_AFFINE
-    if (cnt > 0) table_build_affine(tab, bases, jobflags, njobs, j0, cnt, scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kBlock), (size_t)kBlock, threadIdx.x);
-#else
-    if (cnt > 0) table_build(tab, bases, jobflags, njobs, j0, cnt, scr, (size_t)gridDim.x * kBlock, lane);
-#endif
-#endif
-}
-
-// ---- the table kernel as one launch per PASS (round 3; plume_ec.h tab_pass_a..e) -------------------------------------------------------------------------------
-// k_tables above keeps a workgroup's four wavefronts waiting through three serial inversions (one wavefront inverts for all four: VALUBusy 0.50, and the kernel's time
-// is the critical path of a workgroup times the workgroups a CU can hold).  Here the chain's passes are separate launches over the same grid, a lane's running product
-// travels through HBM (9 words per lane, word-major: coalesced), and ALL the inversions of a level run as one dense launch of k_tab_invert in between (Montgomery's
-// trick over 8 lanes' products: one inversion per 48 jobs at 6 jobs per lane).  No pass holds an inversion or a workgroup barrier.
-#ifndef PLUME_TABLES_MULTIKERNEL
-#define PLUME_TABLES_MULTIKERNEL 1
-#endif
-#ifndef PLUME_TABPASS_WAVES_AB
+// ---- the window tables: one launch per PASS of the affine chain (plume_ec.h tab_pass_a..d) ---------------------------------------------------------------------------
+// A lane's running product travels through HBM between two passes (9 words per lane, word-major: coalesced), and ALL the inversions of a level run as one dense launch of
+// k_tab_invert in between (Montgomery's trick over 8 lanes' products: one inversion per 48 jobs at 6 jobs per lane).  No pass holds an inversion or a workgroup barrier.
+// (Rounds 2-3 also carried a one-kernel form, a workgroup's four wavefronts sharing three serial inversions: same time, the stage is HBM-bound; LABNOTES.md.)
 #define PLUME_TABPASS_WAVES_AB 3   // (r03 A/B on one box, table stage of a 2^20 verify: 4/3 waves 1.93 ms, 3/3 1.86, 3/2 1.83, 4/4 2.32; the one-kernel form 1.89)
-#endif
-#ifndef PLUME_TABPASS_WAVES_CD
 #define PLUME_TABPASS_WAVES_CD 2
-#endif
-#ifndef PLUME_TABINV_K
 #define PLUME_TABINV_K 8          // lane products per inversion
-#endif
-struct WaveRowSink : CoopRowSink {
-    __device__ void inv(fe&, const fe&, int) const {}      // never called: the inversions are k_tab_invert's
-};
 template <int PASS>
 __device__ __forceinline__ void tab_pass_body(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, uint8_t* guardf, uint4* s_rows, uint32_t** s_ptrs) {
     const size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x, nl = (size_t)gridDim.x * kBlock;
@@ -203,7 +101,6 @@ __device__ __forceinline__ void tab_pass_body(uint32_t* tab, const uint32_t* bas
     sink.rows = s_rows + (threadIdx.x & ~63u) * 8;
     sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
     sink.full = __ballot(cnt == L) == ~0ull;
-    sink.xch = nullptr;
     uint32_t* myscr = scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kBlock);
     fe c;
     bool g = false;
@@ -212,10 +109,7 @@ __device__ __forceinline__ void tab_pass_body(uint32_t* tab, const uint32_t* bas
     else if (PASS == 1) tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
     else if (PASS == 2) tab_pass_c(tab, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
     else if (PASS == 3) tab_pass_d(tab, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
-#if PLUME_TAB_ENTRIES == 16
-    else tab_pass_e(tab, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
-#endif
-    if (PASS < (PLUME_TAB_ENTRIES == 16 ? 4 : 3)) { st_fe_soa(carry, nl, lane, c); guardf[lane] = g ? 1 : 0; }
+    if (PASS < 3) { st_fe_soa(carry, nl, lane, c); guardf[lane] = g ? 1 : 0; }
 }
 __global__ __launch_bounds__(kBlock, PLUME_TABPASS_WAVES_AB) void k_tab_pass_a(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, uint8_t* guardf) {
     tab_pass_body<0>(tab, bases, jobflags, njobs, L, scr, carry, guardf, nullptr, nullptr);
@@ -230,9 +124,6 @@ __global__ __launch_bounds__(kBlock, PLUME_TABPASS_WAVES_AB) void k_tab_pass_a(u
 PLUME_TAB_PASS_KERNEL(k_tab_pass_b, 1, PLUME_TABPASS_WAVES_AB)
 PLUME_TAB_PASS_KERNEL(k_tab_pass_c, 2, PLUME_TABPASS_WAVES_CD)
 PLUME_TAB_PASS_KERNEL(k_tab_pass_d, 3, PLUME_TABPASS_WAVES_CD)
-#if PLUME_TAB_ENTRIES == 16
-PLUME_TAB_PASS_KERNEL(k_tab_pass_e, 4, PLUME_TABPASS_WAVES_CD)
-#endif
 // carry[.] <- 1 / carry[.] for the nl lane products of a level: thread t takes lanes t, t + T, ..., t + (K-1) T (coalesced) and spends ONE inversion on their product.
 // The products are never zero (the passes' guard).
 __global__ PLUME_NORM_BOUNDS void k_tab_invert(uint32_t* carry, size_t nl, size_t T) {
@@ -254,19 +145,8 @@ __device__ __forceinline__ void wipe_digits(int8_t* s_dig) {
 __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
     __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
-#ifndef PLUME_MSM_ORDER
-#define PLUME_MSM_ORDER 0   // 0: equation 1 blocks first; 1: the longer equation 2 first (measured: no difference); 2: interleaved (measured: 8 % slower, both loop bodies compete for the instruction cache)
-#endif
-#if PLUME_MSM_ORDER == 0
     const uint32_t eq = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t blk = eq ? blockIdx.x - nb : blockIdx.x;
-#elif PLUME_MSM_ORDER == 1
-    const uint32_t eq = blockIdx.x >= nb ? 0u : 1u;
-    const uint32_t blk = blockIdx.x >= nb ? blockIdx.x - nb : blockIdx.x;
-#else
-    const uint32_t eq = blockIdx.x & 1u;
-    const uint32_t blk = blockIdx.x >> 1;
-#endif
     const uint32_t* gt = a.gtab;   // read through L1/L2 (a 128-entry table staged in LDS was 10 % slower: bank conflicts on per-lane random rows)
     const uint32_t i = blk * kBlock + threadIdx.x;
     if (i < a.n) verify_msm<false>(a, i, eq, gt, s_dig + threadIdx.x, kBlock);
@@ -480,15 +360,10 @@ static size_t tables_park_bytes(size_t njobs, int L) {
 }
 size_t tables_scratch_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
-#if PLUME_TABLES_AFFINE
     return tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16;   // ... + the multi-kernel form's lane state: carry (9 words) and guard flag per lane
-#else
-    return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_ENTRIES * PLUME_TAB_SCR_WORDS * 4;
-#endif
 }
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st) {
     size_t lanes = (njobs + L - 1) / L;
-#if PLUME_TABLES_MULTIKERNEL && PLUME_TABLES_AFFINE && PLUME_TABLES_COOP_STORE
     const dim3 grid(nblocks(lanes)), block(kBlock);
     const size_t nl = (size_t)grid.x * kBlock, T = (nl + PLUME_TABINV_K - 1) / PLUME_TABINV_K;
     uint32_t* carry = scr + tables_park_bytes(njobs, L) / 4;
@@ -501,13 +376,6 @@ void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags
     hipLaunchKernelGGL(k_tab_pass_c, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
     hipLaunchKernelGGL(k_tab_invert, igrid, block, 0, st, carry, nl, T);
     hipLaunchKernelGGL(k_tab_pass_d, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
-#if PLUME_TAB_ENTRIES == 16
-    hipLaunchKernelGGL(k_tab_invert, igrid, block, 0, st, carry, nl, T);
-    hipLaunchKernelGGL(k_tab_pass_e, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
-#endif
-#else
-    hipLaunchKernelGGL(k_tables, dim3(nblocks(lanes)), dim3(kBlock), 0, st, tab, bases, jobflags, njobs, L, scr);
-#endif
 }
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {
     (void)hipMemsetAsync(a.redo, 0, 4, st);
