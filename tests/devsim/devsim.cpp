@@ -227,11 +227,13 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     std::vector<uint32_t> gtab; build_gtab(gtab);
     std::vector<uint32_t> bases(PLUME_BASE_WORDS * 3 * (size_t)n), tab((size_t)3 * n * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2 * (size_t)n);
     std::vector<uint8_t> jobflags(3 * (size_t)n), itemflags(n), resinf(2 * (size_t)n);
-    VerifyArgs a;
+    VerifyArgs a; memset(&a, 0, sizeof a);
     a.mode = mode; a.msgs_bytes = msgs_bytes == ~0ull ? msg_off[n] : msgs_bytes;
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags; a.rpt33 = rpt33; a.hr33 = hr33;
     a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data(); a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data();
     a.gtab = gtab.data();
+    std::vector<int8_t> digs((size_t)PLUME_VDIG_ROWS * n + 1, 0);
+    a.digs = digs.data();
     for (uint32_t i = 0; i < n; i++) verify_ingest_h2c(a, i);
     const size_t nj = 3 * (size_t)n;
     run_tables(a.tab, a.bases, a.jobflags, nj, L);
@@ -414,7 +416,9 @@ int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[6
     jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
     for (int j = 0; j < 3; j++) { st_base(a.bases, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
     run_tables(a.tab, a.bases, a.jobflags, 3, 3);
-    std::vector<int8_t> dig(4 * PLUME_NDIG);
+    std::vector<int8_t> dig(4 * PLUME_NDIG), digs(PLUME_VDIG_ROWS);
+    { sc sv, cv; sc_from_be_aligned(sv, sb); sc_from_be_aligned(cv, cb); verify_item_digits(digs.data(), 1, sv, cv); }     // what the ingest kernel leaves for the item
+    a.digs = digs.data();
     uint32_t redo[3] = {0, 0, 0};
     a.redo = redo;
     verify_msm<false>(a, 0, 0, a.gtab, dig.data(), 1);

@@ -149,7 +149,7 @@ struct plume_ctx {
     std::vector<plume_ctx*> lanes;
     size_t lane_next = 0;
     plume_ctx* lane_last = nullptr;                               // the lane the last device-resident call went to (plume_last_stage_times, plume_last_redo_tasks)
-    DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo;
+    DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo, digs;
     DevBuf dec[4], preflags;
     DevBuf agg[15];      // aggregate check (plume_aggregate.h): haff, scal, flags, gs, hash_ok, counters, count, sort tiles, sorted, bsum, bsuminf, red, redinf, ssum, perm + its histogram
     DevBuf agg_record;   // the running record of a host-pointer aggregate call (pieces of one batch)
@@ -219,7 +219,7 @@ static void destroy_single(plume_ctx* ctx) {
     (void)hipDeviceSynchronize();   // the context's workspace, events and lanes may still be in use by kernels queued on CALLER streams (device-resident calls run on whatever
                                     // stream they were given): wait for the whole device, not only for the context's own streams (plume_destroy, plume_set_in_flight shrinking)
     for (DevBuf* b : {&ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
-                      &ctx->sink, &ctx->redo, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
+                      &ctx->sink, &ctx->redo, &ctx->digs, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
     for (DevBuf& b : ctx->agg) b.release();
     if (ctx->fixed) {
@@ -612,7 +612,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, tables_scratch_bytes(3 * (cut[k + 1] - cut[k]), pick_jobs_per_lane(ctx, 3 * (cut[k + 1] - cut[k]), true)));
     if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
         ctx->tabscr.ensure(scr_bytes) ||
-        ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->redo.ensure((2 * n + nsub) * 4))
+        ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->redo.ensure((2 * n + nsub) * 4) || ctx->digs.ensure((size_t)PLUME_VDIG_ROWS * n))
         return PLUME_ERR_HIP;
     if (overlapped) { if (int rc = pre_events(ctx, nsub)) return rc; }
     StageTimer& t = ctx->timer;
@@ -632,6 +632,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * 3 * lo; a.res = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.resinf = ctx->resinf.as<uint8_t>() + 2 * lo;
         a.gtab = ctx->fixed->gtab.as<uint32_t>();
         a.redo = ctx->redo.as<uint32_t>() + 2 * lo + k;                      // the slice's redo list: counter + up to 2 * cnt tasks
+        a.digs = ctx->digs.as<int8_t>() + (size_t)PLUME_VDIG_ROWS * lo;        // the slice's digit rows (row-major over the slice's cnt items)
         if (k == 0) ctx->redo_counters.clear();
         ctx->redo_counters.push_back(2 * lo + k);
         launch_verify_ingest(a, pre); if (!overlapped) t.stage("verify_ingest_h2c", st);

@@ -161,7 +161,13 @@ struct VerifyArgs {
     uint8_t* resinf;      // 2n
     const uint32_t* gtab; // wide table of G (PLUME_GTAB_WORDS): (1..2^(W-1))*G
     uint32_t* redo;       // redo[0] = number of tasks whose unchecked chain met p == +-q, redo[1 + k] = the k-th such task (2i + eq); capacity 2n; zeroed before the multi-scalar kernel
+    int8_t* digs;         // PLUME_VDIG_ROWS x n signed window digits, row-major (row r of item i at digs[r * n + i]: a wavefront reads / writes 64 consecutive bytes per row).
+                          // Written once per item by the ingest kernel, read by the item's two multi-scalar lanes (round 4; rounds 1-3: each lane split s and c again)
 };
+// the digit rows of an item: three sets of 2 x PLUME_NDIG rows (the two halves of a GLV split): s in 4-bit windows (equation 2), s with the generator's wide digits
+// (equation 1), -c in 4-bit windows (both equations)
+#define PLUME_VDIG_SET (2 * PLUME_NDIG)
+#define PLUME_VDIG_ROWS (3 * PLUME_VDIG_SET)
 // One crafted item (pk = +-k G with small k, s = +-c, ...) steers its accumulator into p == +-q inside an UNCHECKED addition.  Rounds 1-2 redid such a lane on the spot with
 // the checked additions -- and its 63 neighbours waited: one crafted item per wavefront doubled the kernel.  Now the lane only files its task; a second,
 // dense launch (k_verify_msm_redo: one filed task per lane, grid-stride) redoes the filed tasks.  Honest batches file nothing and the second launch costs its launch; a batch
@@ -177,6 +183,17 @@ PLUME_HD uint32_t redo_file(uint32_t* redo, uint32_t task) {
     return k;
 }
 
+// the digit rows of one item (d = the item's column of the row-major digit array, n = its row pitch): s = k1 + k2 lambda in 4-bit Booth windows and in the generator's
+// wide windows, -c likewise in 4-bit windows
+PLUME_HD void verify_item_digits(int8_t* d, uint32_t n, const sc& s, const sc& c) {
+    glv_half h1, h2;
+    glv_split(h1, h2, s);
+    booth_store(d, n, h1, false); booth_store(d + (size_t)PLUME_NDIG * n, n, h2, false);
+    booth_store_wide(d + (size_t)PLUME_VDIG_SET * n, n, h1, false); booth_store_wide(d + (size_t)(PLUME_VDIG_SET + PLUME_NDIG) * n, n, h2, false);
+    glv_split(h1, h2, c);
+    booth_store(d + (size_t)2 * PLUME_VDIG_SET * n, n, h1, true); booth_store(d + (size_t)(2 * PLUME_VDIG_SET + PLUME_NDIG) * n, n, h2, true);
+}
+
 PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     fe pkx, pky, nx, ny;
     uint32_t fpk = load_affine_be(pkx, pky, a.pk + 64 * (size_t)i);
@@ -190,6 +207,9 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     const bool err = a.mode == PLUME_MODE_NON_ZK && !bad && fpk == PLUME_JOB_INF;      // hash_to_curve(message, pk)? -> Err
     a.itemflags[i] = (uint8_t)(bad ? PLUME_ITEM_REJECT : err ? PLUME_ITEM_ERR : 0u);
     bad = bad || err;
+    // The window digits of s and -c, once per item (round 4): the GLV splits and the Booth recoding used to open BOTH multi-scalar lanes of the item (4.5 k instructions
+    // per lane, 1.7 % of that kernel); here the scalars are in registers anyway and die before hash_to_curve starts.
+    if (!bad && a.digs) verify_item_digits(a.digs + i, a.n, s, c);     // (the aggregate check runs this stage without a multi-scalar kernel behind it: no digit rows)
     // the records of pk and the nullifier go out BEFORE hash_to_curve: nothing below needs y(nullifier) or more of pk than its x and parity, and 27 registers less are
     // live through the two exponentiations (the kernel spills at its 128-register budget)
     {
@@ -209,22 +229,6 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     st_base(a.bases, 3 * (size_t)i + 1, h); a.jobflags[3 * (size_t)i + 1] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
 }
 
-// digits of one double-base task a*A + b*B into dig (4 slots x 33): slots 0,1 = a's halves, 2,3 = b's halves
-PLUME_HD void task_digits(int8_t* dig, uint32_t stride, const sc& ka, bool flip_a, const sc& kb, bool flip_b, bool wide_a) {
-    glv_half h1, h2;
-    glv_split(h1, h2, ka);
-    if (wide_a) {
-        booth_store_wide(dig + 0 * PLUME_NDIG * stride, stride, h1, flip_a);
-        booth_store_wide(dig + 1 * PLUME_NDIG * stride, stride, h2, flip_a);
-    } else {
-        booth_store(dig + 0 * PLUME_NDIG * stride, stride, h1, flip_a);
-        booth_store(dig + 1 * PLUME_NDIG * stride, stride, h2, flip_a);
-    }
-    glv_split(h1, h2, kb);
-    booth_store(dig + 2 * PLUME_NDIG * stride, stride, h1, flip_b);
-    booth_store(dig + 3 * PLUME_NDIG * stride, stride, h2, flip_b);
-}
-
 // task t = 2*item + eq;  eq 0: s*G - c*pk, eq 1: s*H - c*nul.   dig: this lane's digit area (LDS), element stride.
 // CHECKED = false: the hot form; a task whose chain met p == +-q is filed in a.redo and stores nothing.  CHECKED = true: the redo launch's form.
 template <bool CHECKED>
@@ -234,10 +238,13 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
     if (a.itemflags[item]) {
         acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
     } else {
-        sc c, s;
-        sc_from_be_aligned(c, a.c + 32 * (size_t)item);
-        sc_from_be_aligned(s, a.s + 32 * (size_t)item);
-        task_digits(dig, stride, s, false, c, true, eq == 0);
+        // slots 0, 1: s (wide digits for equation 1's generator slots), slots 2, 3: -c -- the rows the ingest kernel left for this item, into the lane's digit area
+        const int8_t* ds = a.digs + (size_t)(eq == 0 ? PLUME_VDIG_SET : 0) * a.n + item;
+        const int8_t* dc = a.digs + (size_t)2 * PLUME_VDIG_SET * a.n + item;
+        PLUME_UNROLL for (int r = 0; r < PLUME_VDIG_SET; r++) {
+            dig[(uint32_t)r * stride] = ds[(size_t)r * a.n];
+            dig[(uint32_t)(PLUME_VDIG_SET + r) * stride] = dc[(size_t)r * a.n];
+        }
         const size_t ja = 3 * (size_t)item + 1, jb = 3 * (size_t)item + (eq ? 2 : 0);
         const uint32_t* tab0 = eq ? (job_state(a.jobflags[ja]) == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr) : gtab;
         const uint32_t* tab1 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
