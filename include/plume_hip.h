@@ -88,6 +88,12 @@ int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
  * whichever lane serves the call (so a sign followed by a verify of its outputs, both with stream = NULL, stay ordered).  Costs a second per-batch workspace.  Single-device contexts only (a multi-device context
  * already runs its shards side by side).  plume_last_stage_times / plume_last_redo_tasks then report the lane of the last device-resident call. */
 int plume_set_in_flight(plume_ctx* ctx, int batches);
+/* The signer's uniform schedule (default off; env PLUME_SIGN_UNIFORM=1 sets the default of new contexts).  k256's scalar multiplication is constant-time;
+ * the default signer here skips zero digits and branches on digit signs: its instruction trace depends on sk and r.  With on != 0 the two kernels that walk those digits
+ * (sk*G, r*G by the comb; sk*H, r*H by windows) run the same instructions for every digit value: every slot adds (a zero digit adds row 1 to a copy that a masked select
+ * drops), signs are masked selects, the accumulator starts at a fixed offset point that is subtracted at the end.  Outputs are bit-identical to the default's.  Still
+ * secret-dependent: the ADDRESS of the table row each slot gathers (memory access pattern), so this is "no secret-dependent control flow", not a constant-time claim. */
+int plume_set_sign_uniform(plume_ctx* ctx, int on);
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (an upload, a download and the compute streams,
  * four staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each following piece up to three times
  * the one before, up to the largest piece (default 1<<19, capped by the chunk size); calls with large outputs (the signer) end on a small piece (default 1<<16).

@@ -143,8 +143,9 @@ def verify_batch_sec1(version, msgs_buf, msg_off, pk33, nul33, c, s, r33=None, h
     return ok
 
 
-def sign_batch(version, msgs_buf, msg_off, sk, r, pk_in=None, L=3):
+def sign_batch(version, msgs_buf, msg_off, sk, r, pk_in=None, L=3, uniform=False):
     n = len(msg_off) - 1
+    lib().ds_set_sign_uniform(C.c_int(1 if uniform else 0))
     o = {k: np.zeros((n, w), dtype=np.uint8) for k, w in
          [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64), ("h", 64)]}
     status = np.zeros(n, dtype=np.uint8)
@@ -152,6 +153,7 @@ def sign_batch(version, msgs_buf, msg_off, sk, r, pk_in=None, L=3):
     rc = lib().ds_sign_batch(C.c_int(version), C.c_uint32(n), _p(msgs_buf), _p(msg_off, u64p), _p(sk), _p(r), _p(pk_in),
                              _p(o["pk"]), _p(o["nullifier"]), _p(o["c"]), _p(o["s"]), _p(o["r_point"]), _p(o["hashed_to_curve_r"]), _p(o["h"]),
                              _p(status), C.c_int(L))
+    lib().ds_set_sign_uniform(C.c_int(0))
     assert rc == 0
     o["status"] = status
     return o

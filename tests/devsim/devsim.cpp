@@ -369,6 +369,8 @@ int ds_aggregate_check(int version, int mode, uint32_t n, const uint8_t* msgs, c
 }
 void ds_aggregate_combine(const uint8_t* records, uint32_t m, uint8_t* result) { agg_combine(records, m, result); }
 
+static int g_sign_uniform = 0;
+void ds_set_sign_uniform(int on) { g_sign_uniform = on; }      // the signer's uniform-schedule bodies (plume_set_sign_uniform) instead of the default ones
 int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,
                   uint8_t* pk, uint8_t* nul, uint8_t* c, uint8_t* s, uint8_t* rpt, uint8_t* hr, uint8_t* h_out, uint8_t* status, int L) {
     if (version != 1 && version != 2) return -1;
@@ -383,7 +385,7 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     a.pkaff = pkaff.data(); a.tab = tab.data(); a.hres = hres.data(); a.hresinf = hresinf.data(); a.gcomb = gcomb.data();
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);
     for (uint32_t w = 0; w < 2; w++)
-        for (uint32_t i = 0; i < n; i++) sign_gmul(a, i, w);
+        for (uint32_t i = 0; i < n; i++) { if (g_sign_uniform) sign_gmul<true>(a, i, w); else sign_gmul(a, i, w); }
     {
         const size_t npts = 2 * (size_t)n, nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;
         for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.gres, a.gresinf, npts, lane, nlanes);
@@ -391,7 +393,7 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     for (uint32_t i = 0; i < n; i++) sign_h2c(a, i);
     run_tables(a.tab, a.bases, a.jobflags, n, L);
     for (uint32_t w = 0; w < 2; w++)
-        for (uint32_t i = 0; i < n; i++) sign_hmul(a, i, w, dig.data() + (i % B), B);
+        for (uint32_t i = 0; i < n; i++) { if (g_sign_uniform) sign_hmul<true>(a, i, w, dig.data() + (i % B), B); else sign_hmul(a, i, w, dig.data() + (i % B), B); }
     {
         const size_t npts = 2 * (size_t)n, nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;
         for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.hres, a.hresinf, npts, lane, nlanes);

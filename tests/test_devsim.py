@@ -223,6 +223,34 @@ def test_golden_sign(ver, kats):
     assert o["nullifier"][0].tobytes().hex() == v["nullifier_x"] + v["nullifier_y"]
 
 
+@pytest.mark.parametrize("ver", [1, 2])
+def test_uniform_schedule_signer_gives_the_same_bytes(ver):
+    """plume_set_sign_uniform (round 4): the signer's chains with no branch on a digit -- every slot adds, zero digits are dropped by a masked select, the accumulator starts
+    at an offset point -- produce exactly the default signer's outputs: the golden batch, scalars full of zero digits (0x...0001, 2^k, n - 1: long runs of dummy additions),
+    tiny keys (the crafted collisions of the default path), out-of-range scalars (status bits) and a supplied pk"""
+    items = GOLD[f"sign_v{ver}"]
+    mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+    sk, r = OC.arr(items, "sk", 32), OC.arr(items, "r", 32)
+    specials = [1, 2, 3, 7, 8, 9, 15, 16, 17, 2**16, 2**32 - 1, 2**64, 2**127, 2**128 - 1, 2**128, 2**128 + 1, 2**192, 2**255, N - 1, N - 2, N // 2, N // 3, (N + 1) // 2,
+                0x1111111111111111111111111111111111111111111111111111111111111111 % N, 0x8888888888888888888888888888888888888888888888888888888888888888 % N, 0, N, N + 1, 2**256 - 1]
+    sk, r = sk.copy(), r.copy()
+    for k in range(len(items)):
+        if k % 3 == 0:
+            sk[k] = np.frombuffer(specials[::-1][(k // 3) % len(specials)].to_bytes(32, "big"), dtype=np.uint8)
+        if k % 5 == 0:
+            r[k] = np.frombuffer(specials[(k // 5 + 11) % len(specials)].to_bytes(32, "big"), dtype=np.uint8)
+        if k % 7 == 0:
+            r[k] = sk[k]
+    want = D.sign_batch(ver, mb, off, sk, r)
+    got = D.sign_batch(ver, mb, off, sk, r, uniform=True)
+    for key in want:
+        assert np.array_equal(got[key], want[key]), key
+    assert int((want["status"] != 0).sum()) > 0
+    got2 = D.sign_batch(ver, mb, off, sk, r, pk_in=want["pk"], uniform=True)
+    for key in want:
+        assert np.array_equal(got2[key], want[key]), key
+
+
 def test_sign_edge_status():
     """out-of-range scalars and ragged messages: device sign path == C oracle, including status bits"""
     rng = random.Random(9)

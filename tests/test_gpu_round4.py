@@ -59,6 +59,43 @@ def test_null_stream_calls_stay_ordered_with_batches_in_flight(eng):
         eng.set_in_flight(1)
 
 
+def test_uniform_schedule_signer_every_item_of_2p18(eng):
+    """plume_set_sign_uniform: the signer with no branch on a digit of sk or r gives the default signer's bytes -- every item of 2^18 with edge scalars salted in (zero-digit
+    runs, tiny keys, out-of-range values: status bits), V1 and V2, pk computed and pk supplied -- and a sample of it the C oracle's"""
+    import random
+    n = 1 << 18
+    N = synth.N
+    b = synth.sign_inputs(n, start=31_000_000)
+    vals = [0, 1, 2, 3, 7, 8, 9, 16, 17, 255, 256, 2**16, 2**64, 2**127, 2**128 - 1, 2**128, 2**128 + 1, 2**192, 2**255, N - 1, N - 2, N // 2, N, N + 1, 2**256 - 1,
+            0x1111111111111111111111111111111111111111111111111111111111111111 % N, 0x8888888888888888888888888888888888888888888888888888888888888888 % N]
+    rng = random.Random(18)
+    idx = rng.sample(range(n), 4096)
+    for k, i in enumerate(idx):
+        b["sk" if k % 3 else "r"][i] = np.frombuffer(vals[k % len(vals)].to_bytes(32, "big"), dtype=np.uint8)
+    for i in rng.sample(range(n), 256):
+        b["r"][i] = b["sk"][i]
+    try:
+        for ver in (1, 2):
+            eng.set_sign_uniform(False)
+            want = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+            eng.set_sign_uniform(True)
+            got = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+            for k in want:
+                assert np.array_equal(got[k], want[k]), (ver, k)
+            assert int((want["status"] != 0).sum()) > 100
+            got2 = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"], pk_in=want["pk"])
+            for k in want:
+                assert np.array_equal(got2[k], want[k]), (ver, k, "pk supplied")
+        sub = np.sort(np.array(idx[:512] + rng.sample(range(n), 512)))
+        sub_msgs = np.concatenate([b["msgs"][32 * i:32 * i + 32] for i in sub] + [np.zeros(16, np.uint8)])
+        sub_off = np.arange(len(sub) + 1, dtype=np.uint64) * 32
+        ref = OC.sign_batch(2, sub_msgs, sub_off, b["sk"][sub], b["r"][sub], nthreads=8)
+        for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r", "status"):
+            assert np.array_equal(got[k][sub], ref[k]), k
+    finally:
+        eng.set_sign_uniform(False)
+
+
 _LAZY = r"""
 import json, sys
 import numpy as np

@@ -74,6 +74,7 @@ def _load():
     lib.plume_set_chunk.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_set_sub_batches.argtypes = [C.c_void_p, C.c_int]
     lib.plume_set_in_flight.argtypes = [C.c_void_p, C.c_int]
+    lib.plume_set_sign_uniform.argtypes = [C.c_void_p, C.c_int]
     lib.plume_set_host_piece.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_last_redo_tasks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.plume_last_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
@@ -110,7 +111,7 @@ def _load():
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_set_in_flight", "plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
+    return ["plume_set_in_flight", "plume_set_sign_uniform", "plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
             "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars", "plume_sec1_der_to_scalars_checked",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
@@ -264,6 +265,10 @@ class Engine:
         """batches in flight (plume_set_in_flight): with k = 2 the device-resident calls go in turn to two lanes of the context, so that calls issued on different streams run
         side by side (2^20 verifies: 20.1 instead of 20.8 ms per batch); default 1; results do not depend on it"""
         self._chk(self._lib.plume_set_in_flight(self._ctx, int(k)), "plume_set_in_flight")
+
+    def set_sign_uniform(self, on):
+        """the signer's uniform schedule (plume_set_sign_uniform): no branch on a digit of sk or r; outputs unchanged"""
+        self._chk(self._lib.plume_set_sign_uniform(self._ctx, 1 if on else 0), "plume_set_sign_uniform")
 
     def set_host_piece(self, n):
         """host-pointer calls: items per pipelined piece (upload / compute / download overlap across pieces)"""

@@ -140,6 +140,7 @@ struct plume_ctx {
     std::vector<Worker*> workers;
     HostSlot slot[4];                                              // host-pointer calls: staging slots (two for the one-lane pipeline, four when two lanes take the pieces in turn)
     plume_ctx* host_lane = nullptr;                                // ... the second lane of the host-pointer pipeline: a complete single-device context (workspace, streams), created on first use
+    bool sign_uniform = false;                                     // plume_set_sign_uniform: the signer's uniform-schedule kernels
     int host_lanes = 2;                                            // ... 1 = every piece on the context itself (rounds 1-3), 2 = pieces alternate between the context and host_lane
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
@@ -257,6 +258,7 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_HOST_FIRST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_first_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_TAIL_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_tail_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::atoi(e) != 0;   // default of new contexts (plume_set_sign_uniform)
     if (const char* e = std::getenv("PLUME_HOST_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_lanes = v; }   // 1 = the one-lane host-pointer pipeline of rounds 1-3 (A/B)
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
@@ -509,6 +511,20 @@ extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
     return 0;
 }
 
+// The signer's uniform schedule (opt-in): the two kernels that walk the digits of sk and r (comb multiplication by G, windowed multiplication by H) then execute the same
+// instruction sequence whatever the digits are -- no zero-digit skip, no sign branch, no "accumulator is still the identity" case: every slot adds (a zero digit adds row 1 to
+// a copy that a masked select drops), the sign is a masked select, and the accumulator starts at an offset point that comes off at the end.  Outputs are bit-identical.
+// What remains secret-dependent: the ADDRESS of the table row a slot gathers (k256 scans its 16-entry table with conditional moves; here a scan would cost 8 / 131072 rows
+// per slot).  Cost on the MI355X: DESIGN.md §9.
+extern "C" int plume_set_sign_uniform(plume_ctx* ctx, int on) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "plume_set_sign_uniform: null context");
+    ctx->sign_uniform = on != 0;
+    for (plume_ctx* sh : ctx->shards) sh->sign_uniform = on != 0;
+    for (plume_ctx* l : ctx->lanes) l->sign_uniform = on != 0;
+    if (ctx->host_lane) ctx->host_lane->sign_uniform = on != 0;
+    return 0;
+}
+
 // device-resident verify / sign: how many sub-batches a call is cut into (verify_device); 1 = strictly serial launch order
 extern "C" int plume_set_sub_batches(plume_ctx* ctx, int sub_batches) {
     if (!ctx || sub_batches < 1 || sub_batches > kMaxSubBatches) return fail(PLUME_ERR_ARG, "plume_set_sub_batches: bad argument");
@@ -531,7 +547,7 @@ extern "C" int plume_set_in_flight(plume_ctx* ctx, int batches) {
         plume_ctx* l = new plume_ctx();
         l->device = ctx->device;
         if (int rc = init_single(l)) { const std::string keep = g_err; destroy_single(l); g_err = keep; return rc; }
-        l->chunk = ctx->chunk; l->sub_batches = ctx->sub_batches; l->overlap_min = ctx->overlap_min;
+        l->chunk = ctx->chunk; l->sub_batches = ctx->sub_batches; l->overlap_min = ctx->overlap_min; l->sign_uniform = ctx->sign_uniform;
         l->jobs_per_lane = ctx->jobs_per_lane; l->jobs_per_lane_forced = ctx->jobs_per_lane_forced;
         ctx->lanes.push_back(l);
     }
@@ -685,7 +701,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
         a.gres = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.gresinf = ctx->resinf.as<uint8_t>() + 2 * lo; a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * lo;
         a.jobflags = ctx->jobflags.as<uint8_t>() + lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo; a.pkaff = ctx->pkaff.as<uint32_t>() + (size_t)2 * PLUME_FE_WORDS * lo;
         a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * lo; a.hres = ctx->res2.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.hresinf = ctx->res2inf.as<uint8_t>() + 2 * lo;
-        a.gcomb = ctx->fixed->gcomb.as<uint32_t>();
+        a.gcomb = ctx->fixed->gcomb.as<uint32_t>(); a.uniform = ctx->sign_uniform ? 1 : 0;
         launch_sign_gmul(a, pre); if (!overlapped) t.stage("sign_gmul", st);
         launch_normalize(a.gres, a.gresinf, 2 * cnt, pre); if (!overlapped) t.stage("to_affine_g", st);
         launch_sign_h2c(a, pre); if (!overlapped) t.stage("sign_h2c", st);

@@ -31,6 +31,16 @@ PLUME_HD fe fe_beta() { return fe_set(0x7AE96A2Bu, 0x657C0710u, 0x6E64479Eu, 0xA
 PLUME_HD fe fe_gx() { return fe_set(0x79BE667Eu, 0xF9DCBBACu, 0x55A06295u, 0xCE870B07u, 0x029BFCDBu, 0x2DCE28D9u, 0x59F2815Bu, 0x16F81798u); }  // curves/mod.rs:52
 PLUME_HD fe fe_gy() { return fe_set(0x483ADA77u, 0x26A3C465u, 0x5DA4FBFCu, 0x0E1108A8u, 0xFD17B448u, 0xA6855419u, 0x9C47D08Fu, 0xFB10D4B8u); }  // curves/mod.rs:57
 
+// The uniform-schedule signer's accumulator offset (round 4): B = hash_to_curve("plume_hip uniform-schedule signer: accumulator offset", the RFC suite of the PLUME DST) --
+// a point whose discrete logarithm to G and to any H nobody knows -- with -(2^128 B) and -B (computed once with the oracle, checked by the signer's parity tests: a wrong
+// constant changes every output).  A chain that STARTS at B never holds the identity, so its additions need no "accumulator is the identity" case (which depends on
+// the secret's leading digits); the offset comes off at the end with one checked addition.
+PLUME_HD fe fe_off_x() { return fe_set(0xBE71E685u, 0x6986BD54u, 0xA5797708u, 0x9EF9F753u, 0x1397E48Bu, 0x08AA9EB1u, 0x128983CAu, 0x1D5B099Bu); }
+PLUME_HD fe fe_off_y() { return fe_set(0x15AE5773u, 0x1FAF9233u, 0xF016B8C3u, 0x84D627FDu, 0x8CF7C500u, 0x22EAB6A1u, 0x27C3954Bu, 0x8A01ED04u); }
+PLUME_HD fe fe_off_c128_x() { return fe_set(0x8141C548u, 0xF0861E56u, 0xAE562CECu, 0x00E54F8Bu, 0x7535C0B1u, 0x943A12D3u, 0x469080E1u, 0xA23EEBF9u); }   // -(2^128 B)
+PLUME_HD fe fe_off_c128_y() { return fe_set(0xE429892Au, 0x9AB04F55u, 0xF3E86FE7u, 0xE225348Fu, 0xEF934040u, 0xDC585E87u, 0x1A3CC5BEu, 0x78194203u); }
+PLUME_HD fe fe_off_neg_y() { return fe_set(0xEA51A88Cu, 0xE0506DCCu, 0x0FE9473Cu, 0x7B29D802u, 0x73083AFFu, 0xDD15495Eu, 0xD83C6AB3u, 0x75FE0F2Bu); }    // -B = (x(B), this)
+
 // y^2 == x^3 + 7 (curves/mod.rs:36-39)
 PLUME_HD bool affine_on_curve(const fe& x, const fe& y) {
     fe l, r;
@@ -102,6 +112,21 @@ PLUME_HD void jac_madd(jac& p, const fe& qx, const fe& qy) {
     fe_sub_lazy<2>(t, v, p.x);                             // V - X'
     fe_neg_lazy(v, p.y);                                   // -Y1, unreduced
     fe_muladd(p.y, r, t, v, hhh);                          // Y' = r(V - X') - Y1*H^3: both products share one fold
+}
+
+// One table addition of the UNIFORM schedule (opt-in signer, round 4): the same instructions whatever the digit d is.  (qx, qy) is the row of |d| -- of 1 when d = 0 --,
+// the sign is applied by a masked select, the addition always runs on a copy and a masked select keeps or drops it.  No branch depends on d; the row's ADDRESS still does.
+// The accumulator is never the identity here (the chain starts at the offset point), so jac_madd's identity case is never taken.
+template <bool CHECKED>
+PLUME_HD void jac_madd_uniform(jac& p, const fe& qx, const fe& qy, int d) {
+    fe y = qy, ny;
+    fe_neg_lazy(ny, qy);
+    fe_cmov(y, ny, d < 0);
+    jac t = p;
+    jac_madd<CHECKED>(t, qx, y);
+    const bool take = d != 0;
+    fe_cmov(p.x, t.x, take); fe_cmov(p.y, t.y, take); fe_cmov(p.z, t.z, take);
+    if (CHECKED) p.inf = take ? t.inf : p.inf;      // (the checked form only runs in the redo of a chain that met p == +-q)
 }
 
 // p += q, both Jacobian.  12M + 4S; all exceptional cases handled.
@@ -711,6 +736,27 @@ PLUME_HD void comb_mul_g_impl(jac& acc, const sc& k, const uint32_t* comb) {
         }
     }
 }
+// the comb with the uniform schedule: every window adds (a zero digit adds row 1 to a copy that is dropped), the accumulator starts at the offset point B and loses it at the end
+template <bool CHECKED>
+PLUME_HD void comb_mul_g_uniform_impl(jac& acc, const sc& k, const uint32_t* comb) {
+    acc.x = fe_off_x(); acc.y = fe_off_y(); acc.z = fe_small(1); acc.inf = 0;
+    PLUME_NOUNROLL for (int i = 0; i < PLUME_COMB_WINDOWS; i++) {
+        const int d = booth_digit_comb(k.v, i);
+        const int ad = (d < 0 ? -d : d) + (d == 0 ? 1 : 0);
+        const uint32_t* e = comb + ((size_t)i * PLUME_COMB_ENTRIES + (size_t)(ad - 1)) * PLUME_TAB_ENTRY_WORDS;
+        fe qx, qy;
+        ld_tab_xy(qx, qy, e, false);
+        jac_madd_uniform<CHECKED>(acc, qx, qy, d);
+    }
+}
+PLUME_HD void comb_mul_g_uniform(jac& acc, const sc& k, const uint32_t* comb) {
+    comb_mul_g_uniform_impl<false>(acc, k, comb);
+    if (fe_is_zero(acc.z)) {                                    // met p == +-q (probability ~2^-250 for honest keys; crafted tiny keys cannot reach the offset point either)
+        PLUME_COUNT_FALLBACK();
+        comb_mul_g_uniform_impl<true>(acc, k, comb);
+    }
+    jac_madd<true>(acc, fe_off_x(), fe_off_neg_y());            // - B
+}
 // unchecked additions first; a lane that met p == +-q (Z = 0 mod p, see jac_madd) is recomputed with the checked form
 PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
     comb_mul_g_impl<false>(acc, k, comb);
@@ -773,6 +819,35 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
             }
         }
     }
+}
+// The chain with the UNIFORM schedule (opt-in signer): no slot is skipped and no branch depends on a digit.  `live` false (the table's base was the identity / invalid: a
+// public fact) turns every digit into 0.  Starts at the offset point B; the caller takes 2^(4 (NDIG-1)) B = 2^128 B off again.
+template <bool CHECKED>
+PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab, bool live, int nslots, const int8_t* dig, uint32_t stride) {
+    acc.x = fe_off_x(); acc.y = fe_off_y(); acc.z = fe_small(1); acc.inf = 0;
+    PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
+        if (i != PLUME_NDIG - 1) {
+            PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl(acc);
+        }
+        PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
+            int d = dig[(uint32_t)(s * PLUME_NDIG + i) * stride];
+            d = live ? d : 0;
+            const int ad = (d < 0 ? -d : d) + (d == 0 ? 1 : 0);
+            fe qx, qy;
+            ld_tab_xy(qx, qy, tab + (ad - 1) * PLUME_TAB_ENTRY_WORDS, (s & 1) != 0);
+            jac_madd_uniform<CHECKED>(acc, qx, qy, d);
+        }
+    }
+}
+static_assert(PLUME_WBITS * (PLUME_NDIG - 1) == 128, "the uniform chain's offset constant is -(2^128 B)");
+PLUME_HD void msm_run_uniform(jac& acc, const uint32_t* tab, bool live, int nslots, const int8_t* dig, uint32_t stride) {
+    msm_run_uniform_impl<false>(acc, tab, live, nslots, dig, stride);
+    if (fe_is_zero(acc.z)) {
+        PLUME_COUNT_FALLBACK();
+        msm_run_uniform_impl<true>(acc, tab, live, nslots, dig, stride);
+    }
+    if (!acc.inf) jac_madd<true>(acc, fe_off_c128_x(), fe_off_c128_y());     // - 2^128 B  (acc.inf: only after a checked redo that hit the identity)
+    else { acc.x = fe_off_c128_x(); acc.y = fe_off_c128_y(); acc.z = fe_small(1); acc.inf = 0; }
 }
 // the same chain with the checked additions only (the redo kernel of the verifier: tasks whose unchecked chain met p == +-q)
 PLUME_HD void msm_run_checked(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {

@@ -190,6 +190,22 @@ __global__ PLUME_MSM_BOUNDS void k_sign_hmul(SignArgs a) {
     wipe_digits<2 * PLUME_NDIG>(s_dig);   // the rows are digits of sk and r: nothing derived from a secret stays in LDS when the workgroup retires
 }
 
+// the uniform-schedule forms of the two kernels that walk secret digits (plume_set_sign_uniform): same grids, same outputs
+__global__ PLUME_MSM_BOUNDS void k_sign_hmul_uniform(SignArgs a) {
+    __shared__ int8_t s_dig[2 * PLUME_NDIG * kBlock];
+    const uint32_t nb = (a.n + kBlock - 1) / kBlock;
+    const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
+    const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
+    if (i < a.n) sign_hmul<true>(a, i, which, s_dig + threadIdx.x, kBlock);
+    wipe_digits<2 * PLUME_NDIG>(s_dig);
+}
+__global__ PLUME_MSM_BOUNDS void k_sign_gmul_uniform(SignArgs a) {
+    const uint32_t nb = (a.n + kBlock - 1) / kBlock;
+    const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
+    const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
+    if (i < a.n) sign_gmul<true>(a, i, which);
+}
+
 __global__ PLUME_FINAL_BOUNDS void k_sign_final(SignArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) sign_final(a, i);
@@ -384,9 +400,15 @@ void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_verify_msm_redo, dim3(redo_blocks), dim3(kBlock), 0, st, a);
 }
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_finalize, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
-void launch_sign_gmul(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_gmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_sign_gmul(const SignArgs& a, hipStream_t st) {
+    if (a.uniform) hipLaunchKernelGGL(k_sign_gmul_uniform, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL(k_sign_gmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+}
 void launch_sign_h2c(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_h2c, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
-void launch_sign_hmul(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_hmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_sign_hmul(const SignArgs& a, hipStream_t st) {
+    if (a.uniform) hipLaunchKernelGGL(k_sign_hmul_uniform, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL(k_sign_hmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+}
 void launch_sign_final(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_final, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, hipStream_t st) {
     size_t nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;

@@ -386,6 +386,7 @@ struct SignArgs {
     uint32_t* tab;                       // n tables
     uint32_t* hres;  uint8_t* hresinf;   // 2n tasks: sk*H, r*H
     const uint32_t* gcomb;               // fixed-base comb of G (PLUME_COMB_WORDS)
+    int uniform;                         // 1: the uniform-schedule kernels (plume_set_sign_uniform): no branch on a secret digit
 };
 
 // scalars reduced mod n for the arithmetic, status bit if out of range (the Rust types cannot hold such values)
@@ -396,6 +397,7 @@ PLUME_HD uint32_t load_scalar_reduced(sc& k, const uint8_t* p) {
     return ok ? 0u : PLUME_ST_BAD_SCALAR;
 }
 // task t = 2*item + which: which 0 -> sk, 1 -> r;  result = k * (table tab0)
+template <bool UNIFORM = false>
 PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, const uint32_t* tab0, uint32_t* res, uint8_t* resinf, int8_t* dig, uint32_t stride) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
     sc k;
@@ -404,18 +406,20 @@ PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, const u
     glv_split(h1, h2, k);
     booth_store(dig, stride, h1, false); booth_store(dig + PLUME_NDIG * stride, stride, h2, false);
     jac acc;
-    msm_run(acc, tab0, nullptr, 2, dig, stride, false);
+    if (UNIFORM) msm_run_uniform(acc, a.tab + (size_t)item * PLUME_TAB_WORDS, tab0 != nullptr, 2, dig, stride);     // (every job has a table: a dummy one when its base was no usable point)
+    else msm_run(acc, tab0, nullptr, 2, dig, stride, false);
     st_jac_soa(res, nt, t, acc);
     resinf[t] = (uint8_t)acc.inf;
 }
 // task t = 2*item + which: sk*G (which 0) or r*G (which 1) by the doubling-free comb
+template <bool UNIFORM = false>
 PLUME_HD void sign_gmul(const SignArgs& a, uint32_t item, uint32_t which) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
     if (which == 0 && a.pk_in) { a.gresinf[t] = 1; return; }   // pk supplied: sk*G not needed (flagged so the affine conversion skips it)
     sc k;
     (void)load_scalar_reduced(k, (which ? a.r : a.sk) + 32 * (size_t)item);
     jac acc;
-    comb_mul_g(acc, k, a.gcomb);
+    if (UNIFORM) comb_mul_g_uniform(acc, k, a.gcomb); else comb_mul_g(acc, k, a.gcomb);
     st_jac_soa(a.gres, nt, t, acc);
     a.gresinf[t] = (uint8_t)acc.inf;
 }
@@ -449,9 +453,10 @@ PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
     a.jobflags[i] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
     a.itemflags[i] = (uint8_t)(st | (pinf ? 0x80u : 0u));
 }
+template <bool UNIFORM = false>
 PLUME_HD void sign_hmul(const SignArgs& a, uint32_t item, uint32_t which, int8_t* dig, uint32_t stride) {
     const uint32_t* tab0 = job_state(a.jobflags[item]) == PLUME_JOB_OK ? a.tab + (size_t)item * PLUME_TAB_WORDS : nullptr;
-    sign_mul(a, item, which, tab0, a.hres, a.hresinf, dig, stride);
+    sign_mul<UNIFORM>(a, item, which, tab0, a.hres, a.hresinf, dig, stride);
 }
 PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
     const size_t nt = 2 * (size_t)a.n;
