@@ -286,7 +286,8 @@ def e2e_host_pinned(eng, n, b, signed_v1):
     # the same call with pageable caller arrays (the runtime stages them), for comparison
     tb, tm = best(lambda: eng.verify_batch(1, v["msgs"], b["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"]), reps=2)
     out["verify_v1_pageable"] = {"items_per_s": round(n / tm, 1), "ms_per_call": round(tm * 1e3, 3)}
-    out["note"] = "median of 3 calls after one warm-up; page-locked arrays from plume_host_alloc; pieces of up to 2^19 items (first 2^16, then x3 per piece; the signer's last piece 2^17), three streams"
+    out["note"] = ("median of 3 calls after one warm-up; page-locked arrays from plume_host_alloc; pieces of up to 2^19 items (first 2^16, then x3 per piece; the signer's last piece 2^16); "
+                   "verify: pieces alternate between two lanes of the context, four staging slots (round 4); sign and pageable arrays: one lane")
     return out
 
 
@@ -679,7 +680,12 @@ def main():
                         "executed_macs": round(lane_ops * share / dom_s / mad_rate, 4) if share else None,
                         "executed_macs_per_accounted_mac": round(lane_ops * share / (dom_fpmul * MACS_PER_FPMUL * n), 3) if share else None,
                         "valu_wave_insts_per_launch": iss["valu_wave_insts"], "valu_insts_per_lane": round(iss["valu_wave_insts"] / iss["waves"], 1) if iss.get("waves") else None,
-                        "mad_share_of_valu": share, "clock_ghz_in_kernel": iss.get("clock_ghz"), "source": iss["file"], "same_build": iss["same_build"],
+                        "mad_share_of_valu": share, "clock_ghz_in_kernel": iss.get("clock_ghz"),
+                        "peak_at_kernel_clock": round(256 * 4 * 16 * iss["clock_ghz"] * 1e9, 1) if iss.get("clock_ghz") else None,
+                        "frac_at_kernel_clock": round(msm / (256 * 4 * 16 * iss["clock_ghz"] * 1e9), 4) if iss.get("clock_ghz") else None,
+                        "source": iss["file"], "same_build": iss["same_build"],
+                        "clock_note": "clock_ghz_in_kernel = GRBM_GUI_ACTIVE / 8 XCDs / launch duration of the committed counter pass: the multi-scalar kernel runs at ~2.07 GHz (power), the "
+                                      "multiply-add probe that sets `peak` at ~2.2 GHz; peak_at_kernel_clock = 1024 SIMDs x 16 lanes x that clock",
                         "note": "valu_slots: every VALU instruction priced as one multiply-add slot (plain VOP1/VOP2 ops issue in about 0.57 of one: tests/gpu_debug/instr_rates_r03.txt), "
                                 "so a kernel that saturates the SIMDs with a mix reads a little above the measured busy fraction"}
             if dom_fpmul and in_flight_info and in_flight_info["stage_ms_in_flight"].get(dom):
@@ -717,6 +723,11 @@ def main():
             if ver == 1:
                 try:
                     line["e2e_host_pinned"] = e2e_host_pinned(eng, n, b, signed)
+                    # the host-pointer call against the same run's device-resident serial rate (VERDICT r3 #2 asks for >= 0.95; the floor analysis is in DESIGN.md §6)
+                    line["e2e_host_pinned"]["verify_v1"]["frac_of_value_serial"] = round(line["e2e_host_pinned"]["verify_v1"]["items_per_s"] / line["value_serial"], 4)
+                    sv = (line.get("other_workloads") or {}).get("sign_v1", {}).get("items_per_s")
+                    if sv:
+                        line["e2e_host_pinned"]["sign_v1"]["frac_of_device_resident_sign"] = round(line["e2e_host_pinned"]["sign_v1"]["items_per_s"] / sv, 4)
                 except Exception as e:
                     line["e2e_host_pinned"] = {"error": str(e)}
         if world == 1 and not a.no_cpu_baseline:

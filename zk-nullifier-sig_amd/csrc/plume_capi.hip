@@ -1143,6 +1143,14 @@ static plume_ctx* host_lane_of(plume_ctx* ctx) {
     return l;
 }
 
+// page-locked (hipHostMalloc / hipHostRegister) or device-accessible memory?  Pageable caller arrays make the runtime stage every copy and move it with blit KERNELS, which
+// queue behind the compute kernels: with two lanes keeping the machine saturated such a call got slower (26.7 vs 23.5 ms per 2^20 verifies), so it stays on one lane.
+static bool is_page_locked(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
 template <class Up, class Run, class Down>
 static int host_pipeline(plume_ctx* ctx, size_t n, bool out_heavy, Up up, Run run, Down down, bool may_use_two_lanes = false) {
     const std::vector<size_t> sched = piece_schedule(ctx, n, out_heavy);
@@ -1219,7 +1227,7 @@ static int verify_host(plume_ctx* ctx, int version, int mode, bool sec1, size_t 
             return verify_device(on, version, mode, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
                                  sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), rp, hp, sl.out[0].as<uint8_t>(), on->stream);
         },
-        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); }, true);
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); }, n > 0 && is_page_locked(pk) && is_page_locked(nullifier));
 }
 
 static int verify_host_any(plume_ctx* ctx, int version, int mode, bool sec1, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nullifier,
