@@ -13,7 +13,7 @@ over ranks and the gather of the per-rank times (backend nccl = RCCL).
   --config 4       BASELINE.json configs[3]: 2^22 V2 verifies in total, even split over the ranks (= --scaling strong --log2-batch 22 --version 2)
   --config 3       BASELINE.json configs[2]: the step is one 2^20 V1 SIGN pass (metric signs/s); --config 2: 2^16 V1 verify
   --multi-ctx      ONE process drives all --gpus N devices through one plume_init_multi context and the HOST-POINTER entry point (page-locked caller arrays,
-                   the library shards the batch): the other way to use a node.  PCIe-inclusive, so the number is reported as `e2e_multi_ctx`
+                   the library shards the batch): the other way to use a node (LABNOTES.md §7).  PCIe-inclusive, so the number is reported as `e2e_multi_ctx`
                    beside a `value` that says so in `config.form`; the driver's --gpus N launch (one process per GPU, inputs resident) is the headline form
 
 Objects on the line besides the contract's keys:
@@ -489,7 +489,7 @@ def main():
     eng.set_chunk(max(n, 1 << 20))
     # F batches in flight: F lanes of the context (each with its own workspace) on F streams, steps dealt out in turn.  Every kernel of a 2^20 batch fills the chip, yet the
     # memory-bound table passes and the ramps / tails of one batch's kernels do fit beside the issue-bound multi-scalar kernel of another: 20.1 vs 20.8 ms per batch on one box
-    # (tests/gpu_debug/two_inflight.py) -- with NO slicing cost, which is what sank the in-library sub-batch pipeline.
+    # (tests/gpu_debug/two_inflight.py) -- with NO slicing cost, which is what sank the in-library sub-batch pipeline (LABNOTES.md §6).
     F = max(1, a.in_flight)
     eng.set_in_flight(F)                   # plume_set_in_flight: the context's device-resident calls go in turn to F lanes (workspace, streams, events each; fixed tables shared)
     engines = [eng] * F

@@ -76,7 +76,7 @@ int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
 /* Device-resident verify / sign calls of >= 2^17 items can be cut into `sub_batches` slices: validation + hash_to_curve and the window tables of
  * slice k+1 then run on a second stream of the context beside the multi-scalar kernel of slice k.  Results do not depend on it.  Default 1 =
  * strictly serial launch order on the caller's stream, which is also the mode in which plume_last_stage_times reports one time per kernel:
- * on the MI355X the overlapped order measured 1-3 % SLOWER than the serial one (round 3, DESIGN.md §6: kernels of two streams sharing the
+ * on the MI355X the overlapped order measured 1-3 % SLOWER than the serial one (round 3, LABNOTES.md §6: kernels of two streams sharing the
  * compute units cost more than the table kernel's idle issue slots give back), so the knob is an experiment's record, not a recommendation.
  * Env PLUME_SUB_BATCHES=k sets the default of new contexts, PLUME_SERIAL=1 forces 1 (and wins when both are set). */
 int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);

@@ -1,4 +1,4 @@
-"""Round 3: what does a cross-stream dependency cost on this stack?  (why the sub-batch overlap lost.)
+"""Round 3: what does a cross-stream dependency cost on this stack?  (LABNOTES.md §6: why the sub-batch overlap lost.)
 N dependent kernels in ONE stream against the same N kernels alternating between TWO streams with an event hand-off in between (record on one, wait on the other),
 for tiny kernels (latency) and for kernels that write a large buffer (write-back between queues).  Prints microseconds per kernel / per hand-off."""
 import json

@@ -151,7 +151,7 @@ def test_every_item_verify_non_zk_2p20_vs_the_cpu(eng, ver):
     assert np.array_equal(got[idx], slow)
 
 
-# ------------------------------------------------------------------------------------------- sub-batch overlap
+# ------------------------------------------------------------------------------------------- sub-batch overlap (LABNOTES.md §6)
 def test_sub_batches_do_not_change_results(eng):
     """device-resident verify (V1, V2, SEC1, non-zk) and sign cut into 1 / 2 / 3 / 4 / 7 / 16 overlapped sub-batches: byte-identical outputs, for sizes that do and do not
     divide, ragged messages across the cuts, rejected items and identities on both sides of a cut"""
@@ -237,7 +237,7 @@ def test_stage_times_serial_and_overlapped(eng):
         eng.verify_batch_device(*a); torch.cuda.synchronize()
         over = dict(eng.last_stage_times())
         assert list(over) == ["verify_overlapped"] and bool(ok.all())
-        assert over["verify_overlapped"] < 1.25 * sum(serial.values())       # (measured: the overlapped order is 1-6 % slower than the serial one)
+        assert over["verify_overlapped"] < 1.25 * sum(serial.values())       # (measured: the overlapped order is 1-6 % slower than the serial one, LABNOTES.md §6)
     finally:
         eng.set_sub_batches(capi.DEFAULT_SUB_BATCHES)
 

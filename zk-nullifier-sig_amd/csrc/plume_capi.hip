@@ -125,7 +125,7 @@ struct plume_ctx {
     std::vector<hipEvent_t> pre_ready;                            // ... sub-batch k's window tables are built
     std::vector<size_t> redo_counters;                            // word offsets (in `redo`) of the last verify call's redo counters, one per sub-batch (plume_last_redo_tasks)
     int sub_batches = 1;                                          // device-resident verify / sign: number of sub-batches; 1 = strictly serial launch order (the default: measured on the MI355X, r03, kernels of two
-                                                                  // streams sharing the CUs cost MORE than the table kernel's idle issue slots give back -- 21.85 ms serial vs 22.1-22.4 ms for 2..16 sub-batches)
+                                                                  // streams sharing the CUs cost MORE than the table kernel's idle issue slots give back -- 21.85 ms serial vs 22.1-22.4 ms for 2..16 sub-batches, LABNOTES.md §6)
     size_t overlap_min = (size_t)1 << 17;                         // ... batches below this many items always run serial (a sub-batch must still fill the chip)
     hipEvent_t agg_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // terms ready / upper bucket sums ready / generator term ready / upper windows reduced
     hipEvent_t ws_free = nullptr;     // recorded behind the last kernel of every device-resident call: the next call's stream waits on it before it
@@ -593,7 +593,7 @@ static int pick_jobs_per_lane(const plume_ctx* ctx, size_t njobs, bool kinds_of_
 // ------------------------------------------------------------------------------------------ device pipelines
 // How a device-resident call of n items is cut into sub-batches: the stages in front of the multi-scalar kernel (validation + hash_to_curve, window tables) of sub-batch
 // k+1 run on ctx->pre beside the multi-scalar kernel of sub-batch k on the caller's stream.  The multi-scalar kernel saturates the vector ALUs but leaves HBM idle, the
-// table kernel is bound by the critical path of its workgroups and leaves half of the issue slots idle: side by side they fill each other's gaps, one
+// table kernel is bound by the critical path of its workgroups and leaves half of the issue slots idle (LABNOTES.md §5): side by side they fill each other's gaps, one
 // after the other they cannot.  Slices are multiples of 1024 items (whole workgroups, aligned records).  One sub-batch = the strictly serial order.
 static std::vector<size_t> sub_batch_bounds(const plume_ctx* ctx, size_t n) {
     size_t k = (ctx->sub_batches > 1 && n >= ctx->overlap_min) ? (size_t)ctx->sub_batches : 1;
