@@ -102,6 +102,11 @@ def _aligned(a):
     return a
 
 
+def set_ingest_two_roles(on):
+    """the verify harness then runs the ingest stage in its two-role form (the small-batch kernel k_verify_ingest_split: verify_ingest_a1..a3 / b1..b2)"""
+    lib().ds_set_ingest_two_roles(C.c_int(1 if on else 0))
+
+
 def verify_batch(version, msgs_buf, msg_off, pk, nul, c, s, r_point=None, hr=None, L=3):
     n = len(msg_off) - 1
     ok = np.full(n, 0xEE, dtype=np.uint8)

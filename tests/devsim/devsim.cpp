@@ -191,6 +191,8 @@ uint32_t ds_tab_entries() { return PLUME_TAB_ENTRIES; }     // rows per window t
 // simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)
 static const uint32_t B = 8;
 
+static int g_ingest_two_roles = 0;
+void ds_set_ingest_two_roles(int on) { g_ingest_two_roles = on; }      // the verify harness then runs the ingest stage in its two-role form
 static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
                        const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, int L, const uint8_t* preflags, const uint8_t* rpt33 = nullptr,
                        const uint8_t* hr33 = nullptr, int mode = PLUME_MODE_VERIFY, uint64_t msgs_bytes = ~0ull);
@@ -234,7 +236,17 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     a.gtab = gtab.data();
     std::vector<int8_t> digs((size_t)PLUME_VDIG_ROWS * n + 1, 0);
     a.digs = digs.data();
-    for (uint32_t i = 0; i < n; i++) verify_ingest_h2c(a, i);
+    if (g_ingest_two_roles) {            // the small-batch form of the stage (k_verify_ingest_split): role B and role A of every item, meeting twice
+        std::vector<ingest_xch> x(n);
+        std::vector<ingest_a_state> stt(n);
+        for (uint32_t i = 0; i < n; i++) verify_ingest_b1(a, i, x[i]);
+        for (uint32_t i = 0; i < n; i++) verify_ingest_a1(a, i, x[i], stt[i]);
+        for (uint32_t i = 0; i < n; i++) verify_ingest_b2(x[i]);
+        for (uint32_t i = 0; i < n; i++) verify_ingest_a2(a, i, x[i], stt[i]);
+        for (uint32_t i = 0; i < n; i++) verify_ingest_a3(a, i, x[i], stt[i]);
+    } else {
+        for (uint32_t i = 0; i < n; i++) verify_ingest_h2c(a, i);
+    }
     const size_t nj = 3 * (size_t)n;
     run_tables(a.tab, a.bases, a.jobflags, nj, L);
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);

@@ -251,6 +251,34 @@ def test_uniform_schedule_signer_gives_the_same_bytes(ver):
         assert np.array_equal(got2[key], want[key]), key
 
 
+def test_two_role_ingest_gives_the_same_verdicts():
+    """round 4: below 2^17 items the ingest stage runs with two lanes per item (role A: pk, message, XMD, map(u0), the sum and the isogeny; role B: nullifier, scalars, window
+    digits, map(u1)).  The host harness runs that form of the stage over the goldens, the edge cases (identity / off-curve / out-of-range inputs, ragged messages), the
+    verify_non_zk goldens and fuzzed batches: every verdict as the oracle's."""
+    from tests import _fuzz
+    from tests.test_oracle_c import non_zk_args
+    D.set_ingest_two_roles(True)
+    try:
+        for ver in (1, 2):
+            for items in (GOLD[f"verify_v{ver}"], [e for e in GOLD["edge"] if e["version"] == ver]):
+                mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+                rp = OC.arr(items, "r_point", 64) if ver == 1 else None
+                hr = OC.arr(items, "hashed_to_curve_r", 64) if ver == 1 else None
+                got = D.verify_batch(ver, mb, off, OC.arr(items, "pk", 64), OC.arr(items, "nullifier", 64), OC.arr(items, "c", 32), OC.arr(items, "s", 32), rp, hr)
+                assert [int(o) for o in got] == [it["ok"] for it in items]
+            n = 384
+            b = synth.sign_inputs(n, start=555 + ver)
+            signed = OC.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"], nthreads=8)
+            v = _fuzz.fuzz_verify_batch(ver, signed, b, seed=91 + ver)
+            args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
+            assert np.array_equal(D.verify_batch(*args), OC.verify_batch(*args, nthreads=8))
+            nz = [it for it in NONZK if it["version"] == ver]
+            got = D.verify_non_zk_batch(ver, *non_zk_args(nz))
+            assert [int(o) for o in got] == [it["ok"] for it in nz]
+    finally:
+        D.set_ingest_two_roles(False)
+
+
 def test_sign_edge_status():
     """out-of-range scalars and ragged messages: device sign path == C oracle, including status bits"""
     rng = random.Random(9)

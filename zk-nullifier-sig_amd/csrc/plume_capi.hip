@@ -140,6 +140,7 @@ struct plume_ctx {
     std::vector<Worker*> workers;
     HostSlot slot[4];                                              // host-pointer calls: staging slots (two for the one-lane pipeline, four when two lanes take the pieces in turn)
     plume_ctx* host_lane = nullptr;                                // ... the second lane of the host-pointer pipeline: a complete single-device context (workspace, streams), created on first use
+    size_t ingest_split_max = (size_t)1 << 16;                     // verify calls (slices) of at most this many items run the ingest stage with two lanes per item (latency-bound there)
     bool sign_uniform = false;                                     // plume_set_sign_uniform: the signer's uniform-schedule kernels
     int host_lanes = 2;                                            // ... 1 = every piece on the context itself (rounds 1-3), 2 = pieces alternate between the context and host_lane
     int jobs_per_lane = kTableJobsPerLane;
@@ -258,6 +259,7 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_HOST_FIRST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_first_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_TAIL_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_tail_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_INGEST_SPLIT_MAX")) { long v = std::atol(e); if (v >= 0) ctx->ingest_split_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::atoi(e) != 0;   // default of new contexts (plume_set_sign_uniform)
     if (const char* e = std::getenv("PLUME_HOST_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_lanes = v; }   // 1 = the one-lane host-pointer pipeline of rounds 1-3 (A/B)
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -547,7 +549,7 @@ extern "C" int plume_set_in_flight(plume_ctx* ctx, int batches) {
         plume_ctx* l = new plume_ctx();
         l->device = ctx->device;
         if (int rc = init_single(l)) { const std::string keep = g_err; destroy_single(l); g_err = keep; return rc; }
-        l->chunk = ctx->chunk; l->sub_batches = ctx->sub_batches; l->overlap_min = ctx->overlap_min; l->sign_uniform = ctx->sign_uniform;
+        l->chunk = ctx->chunk; l->sub_batches = ctx->sub_batches; l->overlap_min = ctx->overlap_min; l->sign_uniform = ctx->sign_uniform; l->ingest_split_max = ctx->ingest_split_max;
         l->jobs_per_lane = ctx->jobs_per_lane; l->jobs_per_lane_forced = ctx->jobs_per_lane_forced;
         ctx->lanes.push_back(l);
     }
@@ -651,7 +653,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         a.digs = ctx->digs.as<int8_t>() + (size_t)PLUME_VDIG_ROWS * lo;        // the slice's digit rows (row-major over the slice's cnt items)
         if (k == 0) ctx->redo_counters.clear();
         ctx->redo_counters.push_back(2 * lo + k);
-        launch_verify_ingest(a, pre); if (!overlapped) t.stage("verify_ingest_h2c", st);
+        launch_verify_ingest(a, pre, cnt <= ctx->ingest_split_max); if (!overlapped) t.stage("verify_ingest_h2c", st);
         launch_tables(a.tab, a.bases, a.jobflags, 3 * cnt, pick_jobs_per_lane(ctx, 3 * cnt, true), ctx->tabscr.as<uint32_t>(), pre); if (!overlapped) t.stage("tables", st);   // the table kernels of all sub-batches follow one another on one stream: one scratch
         if (overlapped) {
             HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));

@@ -223,6 +223,16 @@ PLUME_HD void map2_to_curve_jac(jac& h, const fe& u0, const fe& u1) {
         h.x = fe_small(1); h.y = fe_small(1); h.z = fe_small(0); h.inf = 1;
     }
 }
+// the same sum from the two maps' results, for callers that ran the maps elsewhere (the two-role ingest kernel of small batches: one map per wavefront role).
+// (a, b, y0) = map(u1), (c, d, y1) = map(u0): the operand order of map2_to_curve_jac, so that the Jacobian H is the same representative.
+PLUME_HD void maps_to_curve_jac(jac& h, const fe& a, const fe& b, const fe& y0, const fe& c, const fe& d, const fe& y1) {
+    fe xn, xd, yn, yd;
+    if (eprime_add_frac(xn, xd, yn, yd, a, b, y0, c, d, y1)) {
+        iso3_frac_to_jac(h, xn, xd, yn, &yd);
+    } else {
+        h.x = fe_small(1); h.y = fe_small(1); h.z = fe_small(0); h.inf = 1;
+    }
+}
 PLUME_HD void hash_to_curve_jac(jac& h, const uint8_t* msg, uint32_t mlen, const fe& pkx, uint32_t tag, uint32_t enc) {
     fe u0, u1;
     hash_to_field2(u0, u1, msg, mlen, pkx, tag, enc);

@@ -48,6 +48,41 @@ __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
     if (i < a.n) verify_ingest_h2c(a, i);
 }
 
+// The ingest stage of small batches: two wavefront ROLES per item (plume_stages.h verify_ingest_a1..a3 / b1..b2).  A workgroup serves kBlock / 2 items: threads [0, 128) are
+// role A, [128, 256) role B of the same 128 items; what they hand each other goes through LDS word-major (conflict-free), with a workgroup barrier at each meeting.
+__global__ PLUME_H2C_BOUNDS void k_verify_ingest_split(VerifyArgs a) {
+    constexpr uint32_t H = kBlock / 2;
+    __shared__ uint32_t s_u1[PLUME_FE_WORDS * H];
+    __shared__ uint32_t s_q[3 * PLUME_FE_WORDS * H];
+    __shared__ uint32_t s_fb[H];
+    const uint32_t l = threadIdx.x & (H - 1);
+    const bool roleB = threadIdx.x >= H;                          // wave-uniform
+    const uint32_t i = blockIdx.x * H + l;
+    const bool live = i < a.n;
+    ingest_xch x;
+    ingest_a_state st;
+    if (live) {
+        if (roleB) { verify_ingest_b1(a, i, x); s_fb[l] = x.fb; }
+        else { verify_ingest_a1(a, i, x, st); PLUME_UNROLL for (int k = 0; k < PLUME_FE_WORDS; k++) s_u1[k * H + l] = x.u1.v[k]; }
+    }
+    __syncthreads();
+    if (live) {
+        if (roleB) {
+            PLUME_UNROLL for (int k = 0; k < PLUME_FE_WORDS; k++) x.u1.v[k] = s_u1[k * H + l];
+            verify_ingest_b2(x);
+            PLUME_UNROLL for (int k = 0; k < PLUME_FE_WORDS; k++) { s_q[k * H + l] = x.xn.v[k]; s_q[(PLUME_FE_WORDS + k) * H + l] = x.xd.v[k]; s_q[(2 * PLUME_FE_WORDS + k) * H + l] = x.y.v[k]; }
+        } else {
+            x.fb = s_fb[l];
+            verify_ingest_a2(a, i, x, st);
+        }
+    }
+    __syncthreads();
+    if (live && !roleB) {
+        PLUME_UNROLL for (int k = 0; k < PLUME_FE_WORDS; k++) { x.xn.v[k] = s_q[k * H + l]; x.xd.v[k] = s_q[(PLUME_FE_WORDS + k) * H + l]; x.y.v[k] = s_q[(2 * PLUME_FE_WORDS + k) * H + l]; }
+        verify_ingest_a3(a, i, x, st);
+    }
+}
+
 // Row sink of the table passes.  A lane finishes one 128-byte row at a time, and the 64 rows a wavefront finishes together lie
 // kilobytes apart, so storing them directly makes every store instruction touch 64 different cache lines with 16 bytes each.  When
 // all 64 lanes of the wavefront are in lock step (every wave except the batch's last one) the rows are transposed through LDS
@@ -369,7 +404,10 @@ void launch_gather_probe(const uint32_t* tab, uint32_t nrows, int iters, uint32_
 // ------------------------------------------------------------------------------------------------ launchers
 static inline unsigned nblocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-void launch_verify_ingest(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_ingest, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_verify_ingest(const VerifyArgs& a, hipStream_t st, bool two_roles) {
+    if (two_roles) hipLaunchKernelGGL(k_verify_ingest_split, dim3((a.n + kBlock / 2 - 1) / (kBlock / 2)), dim3(kBlock), 0, st, a);   // two lanes per item: small batches
+    else hipLaunchKernelGGL(k_verify_ingest, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a);
+}
 static size_t tables_park_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
     return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_AFF_SCR_WORDS * 4;          // one parked product per job and level, two regions

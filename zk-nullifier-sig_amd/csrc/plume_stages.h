@@ -229,6 +229,69 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     st_base(a.bases, 3 * (size_t)i + 1, h); a.jobflags[3 * (size_t)i + 1] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
 }
 
+// ---- the ingest stage in TWO ROLES per item (round 4, small batches) ----------------------------------------------------------------------------------------------
+// Up to 2^16 items the ingest kernel is latency-bound (measured: 2^14 items 0.239 -> 0.150 ms, 2^16 0.273 -> 0.235, 2^17 no change): one wavefront per SIMD walks 96 k dependent instructions, 61 k of them the two square-root exponentiations of the
+// two simplified-SWU maps, which do not depend on each other.  Here an item is served by two lanes in DIFFERENT wavefronts of a workgroup (roles are wave-uniform: no
+// divergence): role A takes pk, the message and expand_message_xmd and maps u0; role B takes the nullifier, c, s, the window digits and maps u1; A adds the two results on
+// E', runs the isogeny and stores H.  They meet twice (ingest_xch, through LDS on the device, with a workgroup barrier each time).  Same outputs, byte for byte.
+struct ingest_xch {
+    fe u1;            // A -> B at the first meeting
+    uint32_t fb;      // B -> A at the first meeting: nullifier flag | bad scalar << 8
+    fe xn, xd, y;     // B -> A at the second meeting: map(u1) on E', x as a fraction
+};
+struct ingest_a_state { fe u0; fe c, d, y1; uint32_t fpk; bool bad_a, bad; };
+// role B, before the first meeting: nullifier record, scalars, window digits
+PLUME_HD void verify_ingest_b1(const VerifyArgs& a, uint32_t i, ingest_xch& x) {
+    fe nx, ny;
+    const uint32_t fnul = load_affine_be(nx, ny, a.nul + 64 * (size_t)i);
+    sc c, s;
+    bool okc = load_scalar_be(c, a.c + 32 * (size_t)i), oks = load_scalar_be(s, a.s + 32 * (size_t)i);
+    if (a.mode == PLUME_MODE_NON_ZK) { okc = sc_lt_n(c); oks = sc_lt_n(s); }
+    if (okc && oks && a.digs) verify_item_digits(a.digs + i, a.n, s, c);      // (an item rejected for another reason never reads them)
+    jac p; p.inf = 0; p.z = fe_small(1); p.x = nx; p.y = ny;
+    st_base(a.bases, 3 * (size_t)i + 2, p); a.jobflags[3 * (size_t)i + 2] = (uint8_t)(fnul | PLUME_JOB_AFFINE);
+    x.fb = fnul | ((okc && oks) ? 0u : 0x100u);
+}
+// role A, before the first meeting: pk record, message span, hash_to_field
+PLUME_HD void verify_ingest_a1(const VerifyArgs& a, uint32_t i, ingest_xch& x, ingest_a_state& st) {
+    fe pkx, pky;
+    st.fpk = load_affine_be(pkx, pky, a.pk + 64 * (size_t)i);
+    uint64_t o0; uint32_t mlen;
+    const bool okm = msg_span(o0, mlen, a.msg_off, i, a.msgs_bytes);
+    st.bad_a = !okm || st.fpk == PLUME_JOB_INVALID || (a.preflags && a.preflags[i]);
+    jac p; p.inf = 0; p.z = fe_small(1); p.x = pkx; p.y = pky;
+    st_base(a.bases, 3 * (size_t)i + 0, p); a.jobflags[3 * (size_t)i + 0] = (uint8_t)(st.fpk | PLUME_JOB_AFFINE);
+    const uint32_t pktag = 2u + (fe_is_odd(pky) ? 1u : 0u);
+    if (!st.bad_a) {
+        hash_to_field2(st.u0, x.u1, a.msgs + o0, mlen, pkx, pktag, st.fpk == PLUME_JOB_INF ? PLUME_ENC_IDENTITY : PLUME_ENC_POINT);
+    } else {                                                                   // (a malformed span is never read)
+        st.u0 = fe_small(1); x.u1 = fe_small(1);
+    }
+}
+// role A after the first meeting: the verdict of the checks, then map(u0)
+PLUME_HD void verify_ingest_a2(const VerifyArgs& a, uint32_t i, const ingest_xch& x, ingest_a_state& st) {
+    bool bad = st.bad_a || (x.fb & 0x100u) != 0 || (x.fb & 0xFFu) == PLUME_JOB_INVALID;
+    const bool err = a.mode == PLUME_MODE_NON_ZK && !bad && st.fpk == PLUME_JOB_INF;
+    a.itemflags[i] = (uint8_t)(bad ? PLUME_ITEM_REJECT : err ? PLUME_ITEM_ERR : 0u);
+    st.bad = bad || err;
+    sswu_frac(st.c, st.d, st.y1, st.u0);
+}
+// role B after the first meeting: map(u1)
+PLUME_HD void verify_ingest_b2(ingest_xch& x) {
+    const fe u = x.u1;
+    sswu_frac(x.xn, x.xd, x.y, u);
+}
+// role A after the second meeting: Q0' + Q1' on E', the isogeny, H
+PLUME_HD void verify_ingest_a3(const VerifyArgs& a, uint32_t i, const ingest_xch& x, const ingest_a_state& st) {
+    jac h;
+    if (!st.bad) {
+        maps_to_curve_jac(h, x.xn, x.xd, x.y, st.c, st.d, st.y1);
+    } else {
+        h.x = fe_gx(); h.y = fe_gy(); h.z = fe_small(1); h.inf = 0;
+    }
+    st_base(a.bases, 3 * (size_t)i + 1, h); a.jobflags[3 * (size_t)i + 1] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
+}
+
 // task t = 2*item + eq;  eq 0: s*G - c*pk, eq 1: s*H - c*nul.   dig: this lane's digit area (LDS), element stride.
 // CHECKED = false: the hot form; a task whose chain met p == +-q is filed in a.redo and stores nothing.  CHECKED = true: the redo launch's form.
 template <bool CHECKED>
