@@ -102,6 +102,11 @@ def _aligned(a):
     return a
 
 
+def set_tables_small(on):
+    """the table stage of the harness then takes the small-batch path (tabj_pass_a / tabj_pass_b: Jacobian chain per job, one inversion)"""
+    lib().ds_set_tables_small(C.c_int(1 if on else 0))
+
+
 def set_ingest_two_roles(on):
     """the verify harness then runs the ingest stage in its two-role form (the small-batch kernel k_verify_ingest_split: verify_ingest_a1..a3 / b1..b2)"""
     lib().ds_set_ingest_two_roles(C.c_int(1 if on else 0))

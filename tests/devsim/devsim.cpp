@@ -138,7 +138,23 @@ static const std::vector<uint32_t>& shared_gcomb() {
 // host stand-in for launch_tables: the same lane -> jobs mapping, the same lane-interleaved scratch indexing and the same PASS sequence as the multi-kernel form of
 // the table stage (one loop over the lanes per pass, the lanes' running products in a word-major array, tab_invert_group between two passes); a batch of one lane also runs
 // the one-function form (table_build_affine) and the two must agree
+static int g_tables_small = 0;
+void ds_set_tables_small(int on) { g_tables_small = on; }      // the table stage then takes the small-batch path (Jacobian chain, one inversion: tabj_pass_a / b)
+static void run_tables_small(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs) {
+    const size_t stride = ((njobs + 7) / 8) * 8;
+    std::vector<uint32_t> scr(stride * (size_t)PLUME_TAB_ENTRIES * PLUME_TABJ_ENTRY_WORDS), carry(stride * PLUME_FE_WORDS);
+    constexpr int K = 8;
+    const size_t T = (stride + K - 1) / K;
+    for (size_t lane = 0; lane < stride; lane++) {
+        fe c = fe_small(1);
+        if (lane < njobs) tabj_pass_a_guarded(bases, jobflags, njobs, lane, scr.data(), stride, lane, c);
+        st_fe_soa(carry.data(), stride, lane, c);
+    }
+    for (size_t t = 0; t < T; t++) tab_invert_group<K>(carry.data(), stride, T, t);
+    for (size_t lane = 0; lane < njobs; lane++) { fe c; ld_fe_soa(c, carry.data(), stride, lane); tabj_pass_b(tab, lane, scr.data(), stride, lane, c); }
+}
 static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
+    if (g_tables_small) { run_tables_small(tab, bases, jobflags, njobs); return; }
     const size_t lanes = (njobs + L - 1) / L, stride = ((lanes + 7) / 8) * 8;     // "grid" rounded up like the kernel's
     std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_AFF_SCR_WORDS), carry(stride * PLUME_FE_WORDS);
     std::vector<uint8_t> guardf(stride, 0);

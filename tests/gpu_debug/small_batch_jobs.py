@@ -27,8 +27,8 @@ if len(sys.argv) > 1:
     assert bool((ok.cpu().numpy() == synth.expected_ok(n)).all())
     print(json.dumps({"call_ms": round(sorted(ts)[len(ts) // 2] * 1e3, 4), **{k: round(x, 4) for k, x in acc.items()}}))
 else:
-    for lg in (14, 16, 17, 18):
-        for split in (0, 1 << 20):
-            env = dict(os.environ, PLUME_INGEST_SPLIT_MAX=str(split))
+    for lg in (12, 14, 16, 17, 18, 19):
+        for small in (0, 3 << 20):
+            env = dict(os.environ, PLUME_TABLES_SMALL_MAX=str(small))
             out = subprocess.run([sys.executable, __file__, str(lg)], env=env, capture_output=True, text=True)
-            print(f"2^{lg} two-role ingest {'on' if split else 'off'}: {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]}", flush=True)
+            print(f"2^{lg} small-batch tables {'on' if small else 'off'}: {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]}", flush=True)

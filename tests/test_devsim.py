@@ -251,6 +251,48 @@ def test_uniform_schedule_signer_gives_the_same_bytes(ver):
         assert np.array_equal(got2[key], want[key]), key
 
 
+def test_small_batch_table_path_gives_the_same_tables_and_results():
+    """round 4: table stages of up to 3 * 2^16 jobs build 1P..8P by a Jacobian chain with ONE inversion (tabj_pass_a / tabj_pass_b) instead of the affine chain's three.
+    The rows must be the same POINTS (k P affine, beta x), hence the same signatures and verdicts: tables of honest / identity / invalid bases, the golden signs (affine pk
+    bases and the Jacobian H), goldens + edge cases + a fuzzed batch through verify."""
+    from tests import _fuzz
+    rng = random.Random(5)
+    pts = [O.pt_mul(rng.randrange(1, N), O.G) for _ in range(11)]
+    bases = np.zeros((len(pts) + 1, 64), dtype=np.uint8)
+    for j, pt in enumerate(pts):
+        bases[j] = np.frombuffer(pt[0].to_bytes(32, "big") + pt[1].to_bytes(32, "big"), dtype=np.uint8)
+    bases[len(pts), 31] = 5                                               # (5, 0): no curve point, and y = 0 makes its doubling's Z vanish: the guard must keep the neighbours' rows intact
+    want = D.tables_raw(bases)
+    D.set_tables_small(True)
+    try:
+        got = D.tables_raw(bases)
+        assert np.array_equal(got[:len(pts)], want[:len(pts)])
+        for j, pt in enumerate(pts):
+            for k in range(8):
+                kp = O.pt_mul(k + 1, pt)
+                assert got[j, k].tobytes() == kp[0].to_bytes(32, "big") + kp[1].to_bytes(32, "big")
+        for ver in (1, 2):
+            items = GOLD[f"sign_v{ver}"]
+            mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+            o = D.sign_batch(ver, mb, off, OC.arr(items, "sk", 32), OC.arr(items, "r", 32))
+            for key, w in [("pk", 64), ("h", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]:
+                assert np.array_equal(o[key], OC.arr(items, key, w)), key
+            for items in (GOLD[f"verify_v{ver}"], [e for e in GOLD["edge"] if e["version"] == ver]):
+                mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+                rp = OC.arr(items, "r_point", 64) if ver == 1 else None
+                hr = OC.arr(items, "hashed_to_curve_r", 64) if ver == 1 else None
+                got = D.verify_batch(ver, mb, off, OC.arr(items, "pk", 64), OC.arr(items, "nullifier", 64), OC.arr(items, "c", 32), OC.arr(items, "s", 32), rp, hr)
+                assert [int(x) for x in got] == [it["ok"] for it in items]
+            n = 256
+            b = synth.sign_inputs(n, start=777 + ver)
+            signed = OC.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"], nthreads=8)
+            v = _fuzz.fuzz_verify_batch(ver, signed, b, seed=17 + ver)
+            args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
+            assert np.array_equal(D.verify_batch(*args), OC.verify_batch(*args, nthreads=8))
+    finally:
+        D.set_tables_small(False)
+
+
 def test_two_role_ingest_gives_the_same_verdicts():
     """round 4: below 2^17 items the ingest stage runs with two lanes per item (role A: pk, message, XMD, map(u0), the sum and the isogeny; role B: nullifier, scalars, window
     digits, map(u1)).  The host harness runs that form of the stage over the goldens, the edge cases (identity / off-curve / out-of-range inputs, ragged messages), the

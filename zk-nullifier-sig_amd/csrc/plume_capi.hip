@@ -140,6 +140,7 @@ struct plume_ctx {
     std::vector<Worker*> workers;
     HostSlot slot[4];                                              // host-pointer calls: staging slots (two for the one-lane pipeline, four when two lanes take the pieces in turn)
     plume_ctx* host_lane = nullptr;                                // ... the second lane of the host-pointer pipeline: a complete single-device context (workspace, streams), created on first use
+    size_t tables_small_max = (size_t)3 << 15;                     // table stages of at most this many jobs take the small-batch path (Jacobian chain, one inversion: launch_tables_small)
     size_t ingest_split_max = (size_t)1 << 16;                     // verify calls (slices) of at most this many items run the ingest stage with two lanes per item (latency-bound there)
     bool sign_uniform = false;                                     // plume_set_sign_uniform: the signer's uniform-schedule kernels
     int host_lanes = 2;                                            // ... 1 = every piece on the context itself (rounds 1-3), 2 = pieces alternate between the context and host_lane
@@ -259,6 +260,7 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_HOST_FIRST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_first_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_TAIL_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_tail_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_TABLES_SMALL_MAX")) { long v = std::atol(e); if (v >= 0) ctx->tables_small_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_INGEST_SPLIT_MAX")) { long v = std::atol(e); if (v >= 0) ctx->ingest_split_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::atoi(e) != 0;   // default of new contexts (plume_set_sign_uniform)
     if (const char* e = std::getenv("PLUME_HOST_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_lanes = v; }   // 1 = the one-lane host-pointer pipeline of rounds 1-3 (A/B)
@@ -549,7 +551,7 @@ extern "C" int plume_set_in_flight(plume_ctx* ctx, int batches) {
         plume_ctx* l = new plume_ctx();
         l->device = ctx->device;
         if (int rc = init_single(l)) { const std::string keep = g_err; destroy_single(l); g_err = keep; return rc; }
-        l->chunk = ctx->chunk; l->sub_batches = ctx->sub_batches; l->overlap_min = ctx->overlap_min; l->sign_uniform = ctx->sign_uniform; l->ingest_split_max = ctx->ingest_split_max;
+        l->chunk = ctx->chunk; l->sub_batches = ctx->sub_batches; l->overlap_min = ctx->overlap_min; l->sign_uniform = ctx->sign_uniform; l->ingest_split_max = ctx->ingest_split_max; l->tables_small_max = ctx->tables_small_max;
         l->jobs_per_lane = ctx->jobs_per_lane; l->jobs_per_lane_forced = ctx->jobs_per_lane_forced;
         ctx->lanes.push_back(l);
     }
@@ -592,6 +594,16 @@ static int pick_jobs_per_lane(const plume_ctx* ctx, size_t njobs, bool kinds_of_
     return (int)l;
 }
 
+// the window-table stage of njobs jobs: the small-batch path (one inversion on the critical path) or the affine chain's passes
+static size_t table_stage_scratch(const plume_ctx* ctx, size_t njobs, bool kinds_of_three) {
+    if (njobs <= ctx->tables_small_max) return tables_small_scratch_bytes(njobs);
+    return tables_scratch_bytes(njobs, pick_jobs_per_lane(ctx, njobs, kinds_of_three));
+}
+static void table_stage(plume_ctx* ctx, uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, bool kinds_of_three, hipStream_t st) {
+    if (njobs <= ctx->tables_small_max) launch_tables_small(tab, bases, jobflags, njobs, kinds_of_three, ctx->tabscr.as<uint32_t>(), st);
+    else launch_tables(tab, bases, jobflags, njobs, pick_jobs_per_lane(ctx, njobs, kinds_of_three), ctx->tabscr.as<uint32_t>(), st);
+}
+
 // ------------------------------------------------------------------------------------------ device pipelines
 // How a device-resident call of n items is cut into sub-batches: the stages in front of the multi-scalar kernel (validation + hash_to_curve, window tables) of sub-batch
 // k+1 run on ctx->pre beside the multi-scalar kernel of sub-batch k on the caller's stream.  The multi-scalar kernel saturates the vector ALUs but leaves HBM idle, the
@@ -627,7 +639,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     const size_t nsub = cut.size() - 1;
     const bool overlapped = nsub > 1;
     size_t scr_bytes = 0;
-    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, tables_scratch_bytes(3 * (cut[k + 1] - cut[k]), pick_jobs_per_lane(ctx, 3 * (cut[k + 1] - cut[k]), true)));
+    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, 3 * (cut[k + 1] - cut[k]), true));
     if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
         ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->redo.ensure((2 * n + nsub) * 4) || ctx->digs.ensure((size_t)PLUME_VDIG_ROWS * n))
@@ -654,7 +666,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         if (k == 0) ctx->redo_counters.clear();
         ctx->redo_counters.push_back(2 * lo + k);
         launch_verify_ingest(a, pre, cnt <= ctx->ingest_split_max); if (!overlapped) t.stage("verify_ingest_h2c", st);
-        launch_tables(a.tab, a.bases, a.jobflags, 3 * cnt, pick_jobs_per_lane(ctx, 3 * cnt, true), ctx->tabscr.as<uint32_t>(), pre); if (!overlapped) t.stage("tables", st);   // the table kernels of all sub-batches follow one another on one stream: one scratch
+        table_stage(ctx, a.tab, a.bases, a.jobflags, 3 * cnt, true, pre); if (!overlapped) t.stage("tables", st);   // the table kernels of all sub-batches follow one another on one stream: one scratch
         if (overlapped) {
             HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));
             HIPCHK(hipStreamWaitEvent(st, ctx->pre_ready[k], 0));
@@ -680,7 +692,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     const size_t nsub = cut.size() - 1;
     const bool overlapped = nsub > 1;
     size_t scr_bytes = 0;
-    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, tables_scratch_bytes(cut[k + 1] - cut[k], pick_jobs_per_lane(ctx, cut[k + 1] - cut[k], false)));
+    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, cut[k + 1] - cut[k], false));
     if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * n) || ctx->jobflags.ensure(n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * n) ||
         ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->res2.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->res2inf.ensure(2 * n) || ctx->pkaff.ensure((size_t)2 * PLUME_FE_WORDS * 4 * n))
@@ -707,7 +719,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
         launch_sign_gmul(a, pre); if (!overlapped) t.stage("sign_gmul", st);
         launch_normalize(a.gres, a.gresinf, 2 * cnt, pre); if (!overlapped) t.stage("to_affine_g", st);
         launch_sign_h2c(a, pre); if (!overlapped) t.stage("sign_h2c", st);
-        launch_tables(a.tab, a.bases, a.jobflags, cnt, pick_jobs_per_lane(ctx, cnt, false), ctx->tabscr.as<uint32_t>(), pre); if (!overlapped) t.stage("tables", st);
+        table_stage(ctx, a.tab, a.bases, a.jobflags, cnt, false, pre); if (!overlapped) t.stage("tables", st);
         if (overlapped) {
             HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));
             HIPCHK(hipStreamWaitEvent(st, ctx->pre_ready[k], 0));

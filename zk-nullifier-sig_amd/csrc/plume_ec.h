@@ -629,6 +629,91 @@ PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uin
     tab_pass_d(tab, j0, cnt, scr, sstride, slane, carry, guard, sink);
 }
 
+// ------------------------------------------------------------------------------ window tables of SMALL batches: Jacobian chain, ONE inversion (round 4)
+// Up to ~2^15 items the table stage above is pure latency: three inversion launches in a row, each a 20 k-instruction serial chain on a machine that is nearly empty
+// (0.22-0.28 ms whatever the batch size).  Measured on the MI355X (table stage of a verify call, one box): 2^12 items 0.217 -> 0.113 ms, 2^14 0.228 -> 0.120, 2^16 0.277 -> 0.272
+// (break-even), 2^17 0.371 -> 0.484: taken for stages of up to 3 * 2^15 jobs.  Here a lane takes ONE job: 2P..8P as Jacobian points (four doublings, three additions with P), the eight Z's multiplied up
+// with their prefix products parked next to X, Y, Z in scratch (lane-interleaved, 36 words per entry), ONE inversion of the lane's product (k_tab_invert, Montgomery's
+// trick over 8 lanes as before), and a second pass that peels the eight inverses off and writes the affine rows.  2.2 times the multiplications of the affine chain --
+// which is why large batches, where the vector ALUs are the scarce resource, keep the affine chain -- but one inversion on the critical path instead of three.
+#define PLUME_TABJ_ENTRY_WORDS (4 * PLUME_FE_WORDS)      // X | Y | Z | product of the Z's before this entry
+PLUME_HD void tabj_st(uint32_t* scr, size_t sstride, size_t slane, int q, int f, const fe& a) {
+    PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) scr[((size_t)(q * PLUME_TABJ_ENTRY_WORDS + f * PLUME_FE_W + i)) * sstride + slane] = a.v[i];
+}
+PLUME_HD void tabj_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, int q, int f) {
+    PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = scr[((size_t)(q * PLUME_TABJ_ENTRY_WORDS + f * PLUME_FE_W + i)) * sstride + slane];
+}
+// p += q, both Jacobian, WITHOUT the tests for p == +-q / identities (12M + 4S): the table chain of a point of prime order never meets them (k P + P, 2 <= k <= 6)
+PLUME_HD void jac_add_unchecked(jac& p, const jac& q) {
+    fe z1z1, z2z2, u1, s1, s2, h, r, hh, hhh, v, t;
+    fe_sqr(z1z1, p.z); fe_sqr(z2z2, q.z);
+    fe_mul(u1, p.x, z2z2);
+    fe_mul(s1, q.z, z2z2); fe_mul(s1, s1, p.y);
+    fe_mul_sub<2>(h, q.x, z1z1, u1);
+    fe_mul(s2, p.z, z1z1);
+    fe_mul_sub<2>(r, s2, q.y, s1);
+    fe_sqr(hh, h); fe_mul(hhh, hh, h); fe_mul(v, u1, hh);
+    fe_mul(p.z, p.z, q.z); fe_mul(p.z, p.z, h);
+    fe_dbl_lazy(hh, v); fe_add_lazy(hh, hh, hhh);
+    fe_sqr_sub<4>(p.x, r, hh);
+    fe_sub_lazy<2>(t, v, p.x);
+    fe_neg_lazy(v, s1);
+    fe_muladd(p.y, r, t, v, hhh);
+}
+// one entry of the chain goes to scratch: X, Y, Z and the product of the Z's before it; acc *= Z
+PLUME_HD void tabj_put(uint32_t* scr, size_t sstride, size_t slane, int q, const jac& pt, fe& acc) {
+    tabj_st(scr, sstride, slane, q, 0, pt.x); tabj_st(scr, sstride, slane, q, 1, pt.y); tabj_st(scr, sstride, slane, q, 2, pt.z); tabj_st(scr, sstride, slane, q, 3, acc);
+    fe_mul(acc, acc, pt.z);
+}
+// pass A of job `job` (lane slane of sstride): the chain and the product of its Z's -> carry.  ONE doubling body and one addition body in a rolled loop (an entry that is
+// doubled later is read back from the scratch the lane has just written): straight-line code with every point live ran out of registers (1.4-2.5 KB of scratch per lane,
+// three times slower).  Unchecked additions: a point of prime order never meets k P = +-P for 2 <= k <= 6, whatever is not such a point has been replaced by G (tab_base),
+// and the zero-product guard below catches the rest.
+PLUME_HD void tabj_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t job, uint32_t* scr, size_t sstride, size_t slane, fe& carry) {
+    jac b;
+    const bool zone = tab_base(b, bases, jobflags, njobs, job);      // affine (Z = 1) or Jacobian base; anything that is no usable point has become G
+    fe acc = fe_small(1);
+    jac cur = b;
+    PLUME_NOUNROLL for (int k = 0; k < PLUME_TAB_ENTRIES; k++) {      // entry k = (k + 1) P:  P, 2P = 2 * P, 3P = 2P + P, 4P = 2 * 2P, 5P = 4P + P, 6P = 2 * 3P, 7P = 6P + P, 8P = 2 * 4P
+        if (k & 1) {
+            if (k > 1) { const int h = (k + 1) / 2 - 1; tabj_ld(cur.x, scr, sstride, slane, h, 0); tabj_ld(cur.y, scr, sstride, slane, h, 1); tabj_ld(cur.z, scr, sstride, slane, h, 2); }
+            jac_dbl(cur);
+        } else if (k > 0) {
+            if (zone) jac_madd<false>(cur, b.x, b.y); else jac_add_unchecked(cur, b);
+        }
+        tabj_put(scr, sstride, slane, k, cur, acc);
+    }
+    carry = acc;
+}
+// (cold) the same with the base replaced by G: for a job whose product came out zero -- impossible for a point of the group (prime order, no point with y = 0), but
+// the inversion is shared by eight lanes and one poisoned product must not take seven honest jobs with it
+PLUME_HD void tabj_pass_a_guarded(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t job, uint32_t* scr, size_t sstride, size_t slane, fe& carry) {
+    tabj_pass_a(bases, jobflags, njobs, job, scr, sstride, slane, carry);
+    if (fe_is_zero(carry)) {
+        uint32_t g[PLUME_BASE_WORDS];
+        jac pg; pg.x = fe_gx(); pg.y = fe_gy(); pg.z = fe_small(1); pg.inf = 0;
+        st_base(g, 0, pg);
+        const uint8_t gf = (uint8_t)(PLUME_JOB_OK | PLUME_JOB_AFFINE);
+        tabj_pass_a(g, &gf, 1, 0, scr, sstride, slane, carry);
+    }
+}
+// pass B: carry = 1 / (product of the job's eight Z's); rows 8P .. 1P
+PLUME_HD void tabj_pass_b(uint32_t* tab, size_t job, const uint32_t* scr, size_t sstride, size_t slane, const fe& carry) {
+    const fe beta = fe_beta();
+    fe inv = carry;
+    PLUME_NOUNROLL for (int q = PLUME_TAB_ENTRIES - 1; q >= 0; q--) {
+        fe X, Y, Z, pre, zi, zi2, bx;
+        tabj_ld(X, scr, sstride, slane, q, 0); tabj_ld(Y, scr, sstride, slane, q, 1); tabj_ld(Z, scr, sstride, slane, q, 2); tabj_ld(pre, scr, sstride, slane, q, 3);
+        fe_mul(zi, inv, pre);                             // 1 / Z_q
+        fe_mul(inv, inv, Z);                              // inverse of the product before Z_q
+        fe_sqr(zi2, zi);
+        fe_mul(X, X, zi2);
+        fe_mul(zi2, zi2, zi); fe_mul(Y, Y, zi2);
+        fe_mul_k(bx, beta, X);
+        st_tab_entry(tab + job * (size_t)PLUME_TAB_WORDS + (size_t)q * PLUME_TAB_ENTRY_WORDS, X, Y, bx);      // tight, not canonical: only ever multiplied / negated
+    }
+}
+
 // ------------------------------------------------------------------------------ the generator's fixed tables, one entry per lane (round 3)
 // Rounds 1-2 built the verifier's window table of G and the signer's comb with the chained builder above, ONE lane per table: 175.6 + 56.7 ms per context once the
 // tables had grown to 32768 and 19 x 8192 entries.  Every entry is independent: lane (w, e) computes (e + 1) * B_w by MSB-first double-and-add

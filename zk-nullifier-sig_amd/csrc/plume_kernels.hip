@@ -159,6 +159,27 @@ __global__ __launch_bounds__(kBlock, PLUME_TABPASS_WAVES_AB) void k_tab_pass_a(u
 PLUME_TAB_PASS_KERNEL(k_tab_pass_b, 1, PLUME_TABPASS_WAVES_AB)
 PLUME_TAB_PASS_KERNEL(k_tab_pass_c, 2, PLUME_TABPASS_WAVES_CD)
 PLUME_TAB_PASS_KERNEL(k_tab_pass_d, 3, PLUME_TABPASS_WAVES_CD)
+// the table stage of small batches (plume_ec.h tabj_pass_a / tabj_pass_b): one job per lane, Jacobian chain, one k_tab_invert in between
+// lane -> job.  The verifier's jobs come in threes (pk, H, nullifier of an item: two affine bases and a Jacobian one); lanes are dealt out kind by kind, so that a wavefront
+// builds tables of ONE kind and runs one addition form (kinds = 3), not both.  The signer's jobs are all of one kind (kinds = 1).
+__device__ __forceinline__ size_t tabj_job_of_lane(size_t lane, size_t njobs, uint32_t kinds) {
+    if (kinds <= 1) return lane;
+    const size_t per = njobs / kinds;
+    return (lane % per) * kinds + lane / per;
+}
+__global__ PLUME_MSM_BOUNDS void k_tabj_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, uint32_t kinds, uint32_t* scr, uint32_t* carry) {
+    const size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x, nl = (size_t)gridDim.x * kBlock;
+    fe c = fe_small(1);
+    if (lane < njobs) tabj_pass_a_guarded(bases, jobflags, njobs, tabj_job_of_lane(lane, njobs, kinds), scr, nl, lane, c);
+    st_fe_soa(carry, nl, lane, c);
+}
+__global__ PLUME_MSM_BOUNDS void k_tabj_pass_b(uint32_t* tab, size_t njobs, uint32_t kinds, const uint32_t* scr, const uint32_t* carry) {
+    const size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x, nl = (size_t)gridDim.x * kBlock;
+    if (lane >= njobs) return;
+    fe c;
+    ld_fe_soa(c, carry, nl, lane);
+    tabj_pass_b(tab, tabj_job_of_lane(lane, njobs, kinds), scr, nl, lane, c);
+}
 // carry[.] <- 1 / carry[.] for the nl lane products of a level: thread t takes lanes t, t + T, ..., t + (K-1) T (coalesced) and spends ONE inversion on their product.
 // The products are never zero (the passes' guard).
 __global__ PLUME_NORM_BOUNDS void k_tab_invert(uint32_t* carry, size_t nl, size_t T) {
@@ -415,6 +436,16 @@ static size_t tables_park_bytes(size_t njobs, int L) {
 size_t tables_scratch_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
     return tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16;   // ... + the multi-kernel form's lane state: carry (9 words) and guard flag per lane
+}
+size_t tables_small_scratch_bytes(size_t njobs) { return (size_t)nblocks(njobs) * kBlock * ((size_t)PLUME_TAB_ENTRIES * PLUME_TABJ_ENTRY_WORDS + PLUME_FE_WORDS) * 4 + 16; }
+void launch_tables_small(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, bool kinds_of_three, uint32_t* scr, hipStream_t st) {
+    const uint32_t kinds = (kinds_of_three && njobs % 3 == 0) ? 3u : 1u;
+    const dim3 grid(nblocks(njobs)), block(kBlock);
+    const size_t nl = (size_t)grid.x * kBlock, T = (nl + PLUME_TABINV_K - 1) / PLUME_TABINV_K;
+    uint32_t* carry = scr + nl * (size_t)PLUME_TAB_ENTRIES * PLUME_TABJ_ENTRY_WORDS;
+    hipLaunchKernelGGL(k_tabj_pass_a, grid, block, 0, st, bases, jobflags, njobs, kinds, scr, carry);
+    hipLaunchKernelGGL(k_tab_invert, dim3(nblocks(T)), block, 0, st, carry, nl, T);
+    hipLaunchKernelGGL(k_tabj_pass_b, grid, block, 0, st, tab, njobs, kinds, scr, carry);
 }
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st) {
     size_t lanes = (njobs + L - 1) / L;
