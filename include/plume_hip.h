@@ -94,6 +94,15 @@ int plume_set_in_flight(plume_ctx* ctx, int batches);
  * drops), signs are masked selects, the accumulator starts at a fixed offset point that is subtracted at the end.  Outputs are bit-identical to the default's.  Still
  * secret-dependent: the ADDRESS of the table row each slot gathers (memory access pattern), so this is "no secret-dependent control flow", not a constant-time claim. */
 int plume_set_sign_uniform(plume_ctx* ctx, int on);
+/* Environment knobs read when a context is created (tuning and A/B runs; results never depend on them):
+ *   PLUME_SUB_BATCHES, PLUME_SERIAL, PLUME_OVERLAP_MIN   sub-batch overlap of the device-resident calls (plume_set_sub_batches)
+ *   PLUME_HOST_PIECE, PLUME_HOST_FIRST_PIECE, PLUME_HOST_TAIL_PIECE, PLUME_HOST_REGISTER_MIN, PLUME_HOST_LANES (1 | 2), PLUME_HOST_SCHEDULE (explicit piece list, read per call)
+ *                                                        the host-pointer pipeline (plume_set_host_*)
+ *   PLUME_INGEST_SPLIT_MAX   verify calls of at most this many items run the ingest stage with two lanes per item (default 65536; 0: never)
+ *   PLUME_TABLES_SMALL_MAX   window-table stages of at most this many jobs (3 per verify, 1 per sign) take the one-inversion Jacobian chain (default 98304; 0: never)
+ *   PLUME_JOBS_PER_LANE      jobs per lane of the affine table passes (default: 3..6 by batch size)
+ *   PLUME_SIGN_UNIFORM       default of plume_set_sign_uniform
+ *   PLUME_NO_AFFINITY        multi-device contexts: leave the shard threads' CPU affinity alone */
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (an upload, a download and the compute streams,
  * four staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each following piece up to three times
  * the one before, up to the largest piece (default 1<<19, capped by the chunk size); calls with large outputs (the signer) end on a small piece (default 1<<16).
