@@ -90,7 +90,7 @@ int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
 int plume_set_in_flight(plume_ctx* ctx, int batches);
 /* The signer's uniform schedule (default off; env PLUME_SIGN_UNIFORM=1 sets the default of new contexts).  k256's scalar multiplication is constant-time;
  * the default signer here skips zero digits and branches on digit signs: its instruction trace depends on sk and r.  With on != 0 the two kernels that walk those digits
- * (sk*G, r*G by the comb; sk*H, r*H by windows) run the same instructions for every digit value: every slot adds (a zero digit adds row 1 to a copy that a masked select
+ * (sk*G, r*G by the comb; sk*H, r*H by windows; also the comb of the SEC1-DER export, whose scalars are secret keys) run the same instructions for every digit value: every slot adds (a zero digit adds row 1 to a copy that a masked select
  * drops), signs are masked selects, the accumulator starts at a fixed offset point that is subtracted at the end.  Outputs are bit-identical to the default's.  Still
  * secret-dependent: the ADDRESS of the table row each slot gathers (memory access pattern), so this is "no secret-dependent control flow", not a constant-time claim. */
 int plume_set_sign_uniform(plume_ctx* ctx, int on);

@@ -16,8 +16,10 @@
 using namespace plume;
 
 static void fe_from_le_words(fe& r, const uint32_t* w) { fe_from_words(r, w); }   // any 256-bit integer, also >= p
+static int g_sign_uniform = 0;        // the signer's (and the DER export's) uniform-schedule bodies (plume_set_sign_uniform) instead of the default ones
 
 extern "C" {
+void ds_set_sign_uniform(int on) { g_sign_uniform = on; }
 
 // how many multi-scalar chains were redone with checked additions since the library was loaded (p == +-q inside a chain)
 unsigned long ds_fallback_count(void) { return fallback_counter(); }
@@ -397,8 +399,6 @@ int ds_aggregate_check(int version, int mode, uint32_t n, const uint8_t* msgs, c
 }
 void ds_aggregate_combine(const uint8_t* records, uint32_t m, uint8_t* result) { agg_combine(records, m, result); }
 
-static int g_sign_uniform = 0;
-void ds_set_sign_uniform(int on) { g_sign_uniform = on; }      // the signer's uniform-schedule bodies (plume_set_sign_uniform) instead of the default ones
 int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in,
                   uint8_t* pk, uint8_t* nul, uint8_t* c, uint8_t* s, uint8_t* rpt, uint8_t* hr, uint8_t* h_out, uint8_t* status, int L) {
     if (version != 1 && version != 2) return -1;
@@ -487,7 +487,7 @@ void ds_map2_to_curve(const uint8_t* u0b, const uint8_t* u1b, uint8_t* out) {
 }
 int ds_scalars_to_der(uint32_t n, const uint8_t* scalars, uint8_t* der, uint8_t* status) {
     const std::vector<uint32_t>& gcomb = shared_gcomb();
-    DerArgs a; a.n = n; a.scalars = scalars; a.der = der; a.status = status; a.gcomb = gcomb.data();
+    DerArgs a; a.n = n; a.scalars = scalars; a.der = der; a.status = status; a.gcomb = gcomb.data(); a.uniform = g_sign_uniform;
     for (uint32_t i = 0; i < n; i++) scalar_to_sec1_der(a, i);
     return 0;
 }

@@ -19,7 +19,7 @@ so["status"] = capi.pinned_empty(n)
 okp = capi.pinned_empty(n)
 
 
-def best(fn, reps=5):
+def best(fn, reps=7):
     fn()
     ts = []
     for _ in range(reps):
@@ -28,8 +28,8 @@ def best(fn, reps=5):
 
 
 K = 1024
-for sched in [[64, 192, 512, 256], [64, 64, 128, 256, 512], [64, 64, 128, 256, 256, 256], [128, 128, 256, 512], [64, 192, 256, 512], [32, 32, 64, 128, 256, 512], [64, 128, 320, 512], [64, 64, 128, 256, 384, 128],
-              [64, 64, 128, 256, 448, 64], [32, 96, 128, 256, 512], [64, 64, 128, 768], [64, 192, 768]]:
+for sched in [[64, 192, 512, 256], [64, 128, 192, 320, 320], [64, 96, 160, 256, 448], [64, 128, 256, 288, 288], [32, 64, 128, 192, 288, 320], [64, 128, 192, 256, 384], [48, 96, 176, 320, 384],
+              [64, 128, 192, 256, 256, 128], [64, 128, 224, 304, 304], [96, 160, 256, 256, 256], [64, 112, 176, 288, 384], [64, 192, 512, 256]]:
     os.environ["PLUME_HOST_SCHEDULE"] = ",".join(str(x * K) for x in sched)
     tv = best(lambda: e.verify_batch(1, vp["msgs"], pin["off"], vp["pk"], vp["nullifier"], vp["c"], vp["s"], vp["r_point"], vp["hashed_to_curve_r"], out=okp))
     assert np.array_equal(okp, want)

@@ -626,6 +626,11 @@ def _check_sec1_der(to_der, from_der, kats):
 
 def test_sec1_der_scalar_marshalling(kats):
     _check_sec1_der(D.scalars_to_der, None, kats)
+    D.lib().ds_set_sign_uniform(1)                 # ... and with the comb's uniform schedule (plume_set_sign_uniform covers the export: its scalars are secret keys)
+    try:
+        _check_sec1_der(D.scalars_to_der, None, kats)
+    finally:
+        D.lib().ds_set_sign_uniform(0)
 
 
 def test_affine_table_chain_and_its_zero_denominator_guard():

@@ -872,7 +872,7 @@ static int der_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t*
     if (n > 0xFFFFFFF0u) return fail(PLUME_ERR_ARG, "n too large");
     if (n == 0) return 0;
     if (int rc = need_gcomb(ctx)) return rc;
-    DerArgs a; a.n = (uint32_t)n; a.scalars = scalars; a.der = der109; a.status = status; a.gcomb = ctx->fixed->gcomb.as<uint32_t>();
+    DerArgs a; a.n = (uint32_t)n; a.scalars = scalars; a.der = der109; a.status = status; a.gcomb = ctx->fixed->gcomb.as<uint32_t>(); a.uniform = ctx->sign_uniform ? 1 : 0;
     ctx->timer.begin(st);
     launch_scalars_der(a, st); ctx->timer.stage("scalars_to_sec1_der", st);
     HIPCHK(hipGetLastError());

@@ -76,6 +76,20 @@ PLUME_HD void jac_dbl(jac& p) {
     fe_neg_lazy(nB, B);                                    // -2Y^2, unreduced (limbs <= 2p)
     fe_muladd(p.y, E, t, nB, dB);                          // Y' = E (D - X') - 8Y^4; bound: 9 (2^29 * 3 * 2^29 + 2^30 * 2^30) (1 + 2^-9) < 2^64 - 2^57
 }
+// -2P: the same doubling with the sign of Y' flipped -- Y'' = E (X' - D) + B * 2B = -Y' -- which needs no negated operand (jac_dbl spends nine subtractions on -B).
+// (X', -Y', Z') is the point -2P, so an EVEN number of these in a row doubles that many times: the four doublings between two windows of the multi-scalar loops are
+// two such pairs (round 4; 0.3 % of that kernel).
+PLUME_HD void jac_dbl_neg(jac& p) {
+    fe B, dB, E, D, t, dY;
+    fe_sqr3(E, p.x);
+    fe_sqr2_d(B, dY, p.y);
+    fe_mul(p.z, dY, p.z);
+    fe_dbl_lazy(dB, B);
+    fe_mul(D, p.x, dB);
+    fe_sqr_sub2<2>(p.x, E, D);                             // X' = 9X^4 - 8XY^2
+    fe_sub_lazy<2>(t, p.x, D);                             // X' - 4XY^2, limbs <= 3 * 2^29 + 2^19
+    fe_muladd(p.y, E, t, B, dB);                           // -Y' = E (X' - D) + 8Y^4
+}
 // cold path of the additions (P == Q).  Takes and returns BY VALUE through a local copy at the call site: passing the
 // accumulator by reference would make its address escape and pin it in scratch memory for the whole hot loop
 // (measured: ~900 scratch stores per lane and 21 GB of write traffic per 2^20 batch before this change).
@@ -892,7 +906,7 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
     PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
         if (i != PLUME_NDIG - 1) {
-            PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl(acc);
+            PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl_neg(acc);      // an even number of sign-flipping doublings
         }
         PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
             if (!msm_slot_used(i, s, wide0)) continue;              // wave-uniform: a wide digit sits at every (W/4)-th window only
@@ -912,7 +926,7 @@ PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab, bool live, int
     acc.x = fe_off_x(); acc.y = fe_off_y(); acc.z = fe_small(1); acc.inf = 0;
     PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
         if (i != PLUME_NDIG - 1) {
-            PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl(acc);
+            PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl_neg(acc);      // an even number of sign-flipping doublings
         }
         PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
             int d = dig[(uint32_t)(s * PLUME_NDIG + i) * stride];
@@ -925,6 +939,7 @@ PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab, bool live, int
     }
 }
 static_assert(PLUME_WBITS * (PLUME_NDIG - 1) == 128, "the uniform chain's offset constant is -(2^128 B)");
+static_assert(PLUME_WBITS % 2 == 0, "the window loops double with jac_dbl_neg: an even count per window");
 PLUME_HD void msm_run_uniform(jac& acc, const uint32_t* tab, bool live, int nslots, const int8_t* dig, uint32_t stride) {
     msm_run_uniform_impl<false>(acc, tab, live, nslots, dig, stride);
     if (fe_is_zero(acc.z)) {

@@ -205,8 +205,7 @@ __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
     const uint32_t blk = eq ? blockIdx.x - nb : blockIdx.x;
     const uint32_t* gt = a.gtab;   // read through L1/L2 (a 128-entry table staged in LDS was 10 % slower: bank conflicts on per-lane random rows)
     const uint32_t i = blk * kBlock + threadIdx.x;
-    if (i < a.n) verify_msm<false>(a, i, eq, gt, s_dig + threadIdx.x, kBlock);
-    wipe_digits<4 * PLUME_NDIG>(s_dig);
+    if (i < a.n) verify_msm<false>(a, i, eq, gt, s_dig + threadIdx.x, kBlock);      // (the rows hold digits of s and c: public parts of a signature, nothing to wipe)
 }
 // the tasks k_verify_msm filed (their unchecked chain met p == +-q), one per lane, with the checked additions; grid-stride over the filed count, so an honest batch's
 // launch finds nothing and returns
@@ -217,7 +216,6 @@ __global__ PLUME_MSM_BOUNDS void k_verify_msm_redo(VerifyArgs a) {
         const uint32_t t = a.redo[1 + k];
         verify_msm<true>(a, t >> 1, t & 1u, a.gtab, s_dig + threadIdx.x, kBlock);
     }
-    wipe_digits<4 * PLUME_NDIG>(s_dig);
 }
 
 __global__ PLUME_FINAL_BOUNDS void k_verify_finalize(VerifyArgs a) {

@@ -745,6 +745,7 @@ struct DerArgs {
     uint8_t* der;             // n x 109
     uint8_t* status;          // n
     const uint32_t* gcomb;
+    int uniform;              // 1: the comb's uniform schedule (plume_set_sign_uniform): the scalars are secret keys
 };
 PLUME_HD void scalar_to_sec1_der(const DerArgs& a, uint32_t i) {
     sc k;
@@ -755,7 +756,7 @@ PLUME_HD void scalar_to_sec1_der(const DerArgs& a, uint32_t i) {
         return;
     }
     jac p;
-    comb_mul_g(p, k, a.gcomb);                 // never the identity for k in [1, n-1]
+    if (a.uniform) comb_mul_g_uniform(p, k, a.gcomb); else comb_mul_g(p, k, a.gcomb);     // never the identity for k in [1, n-1]
     fe zi, zi2, x, y;
     fe_inv(zi, p.z); fe_sqr(zi2, zi); fe_mul(x, p.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y, p.y, zi2);
     fe_normalize(x); fe_normalize(y);
