@@ -74,7 +74,11 @@ def _load():
     lib.plume_set_chunk.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_set_sub_batches.argtypes = [C.c_void_p, C.c_int]
     lib.plume_set_in_flight.argtypes = [C.c_void_p, C.c_int]
-    lib.plume_set_sign_uniform.argtypes = [C.c_void_p, C.c_int]
+    try:
+        lib.plume_set_sign_uniform.argtypes = [C.c_void_p, C.c_int]
+    except AttributeError:      # an older build of the library selected through PLUME_HIP_LIB (A/B runs against an earlier round): it has no such entry point
+        if not os.environ.get("PLUME_HIP_LIB"):
+            raise
     lib.plume_set_host_piece.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_last_redo_tasks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.plume_last_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
