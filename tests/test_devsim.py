@@ -130,11 +130,18 @@ def test_glv_and_booth():
     rng = random.Random(4)
     lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
     ks = [0, 1, 2, N - 1, N - 2, lam, lam + 1, N - lam, (N - 1) // 2, (N + 1) // 2, 2**128, 2**128 - 1, 2**255 % N] + [rng.randrange(N) for _ in range(2000)]
+    # round 4: the split is exact integer arithmetic on 29-bit limbs (plume_ec.h glv_split): k1 = k - c1 a1 - c2 a2, k2 = c1 (-b1) - c2 b2 with c_i = round(k g_i / 2^384)
+    g1 = 0x3086D221A7D46BCDE86C90E49284EB153DAA8A1471E8CA7FE893209A45DBB031
+    g2 = 0xE4437ED6010E88286F547FA90ABFE4C4221208AC9DF506C61571B4AE8AC47F71
+    a1, mb1, a2 = 0x3086D221A7D46BCDE86C90E49284EB15, 0xE4437ED6010E88286F547FA90ABFE4C3, 0x114CA50F7A8E2F3F657C1108D9D44CFD8
+    ks += [N - lam, 2**255, 2**256 % N, (1 << 174) - 1, 1 << 174, (1 << 174) + 1, (1 << 145) - 1, g1 % N, g2 % N] + [rng.randrange(N) for _ in range(6000)]
     for k, (m1, n1, m2, n2, d1, d2) in zip(ks, D.glv(ks)):
         assert m1 < 2**128 and m2 < 2**128
         k1 = -m1 if n1 else m1
         k2 = -m2 if n2 else m2
         assert (k1 + k2 * lam) % N == k
+        c1, c2 = (k * g1 + (1 << 383)) >> 384, (k * g2 + (1 << 383)) >> 384
+        assert (k1, k2) == (k - c1 * a1 - c2 * a2, c1 * mb1 - c2 * a1), hex(k)
         w = D.wbits()
         for m, neg, d in ((m1, n1, d1), (m2, n2, d2)):
             assert len(d) == (128 + w) // w and all(-(1 << (w - 1)) <= x <= 1 << (w - 1) for x in d)

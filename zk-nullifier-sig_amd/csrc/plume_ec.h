@@ -186,40 +186,68 @@ struct glv_half {
     uint32_t m[4];
     uint32_t neg;
 };
+// Round 4: exact integer arithmetic on 29-bit limbs, no reduction mod n anywhere.  With the lattice basis (a1, b1), (a2, b2) (a_i + b_i lambda = 0 mod n):
+//     c1 = round(k g1 / 2^384), c2 = round(k g2 / 2^384)     (g1 = round(2^384 b2 / n), g2 = round(2^384 (-b1) / n))
+//     k1 = k - c1 a1 - c2 a2,   k2 = c1 (-b1) - c2 b2        as INTEGERS: both are below 2^128 in magnitude, so 174 bits of two's complement hold them
+// -- the same k1, k2 the earlier form reached through a 256 x 256-bit product mod n and k1 = k - k2 lambda mod n (1700 instructions per split, a third of them register
+// moves of the generic 32-bit schoolbook products; this form: product columns accumulate in 64 bits without carries, like the field arithmetic).
+PLUME_HD void glv_cmul(uint32_t c[5], const uint32_t kl[9], const uint32_t g[9]) {      // c = round(k g / 2^384) as five 29-bit limbs (c < 2^129)
+    uint64_t acc = 0;
+    uint32_t top[5];
+    PLUME_UNROLL for (int m = 0; m < 17; m++) {
+        PLUME_UNROLL for (int i = 0; i < 9; i++) { const int j = m - i; if (j >= 0 && j < 9) acc += (uint64_t)kl[i] * g[j]; }
+        if (m >= 13) top[m - 13] = (uint32_t)acc & PLUME_FE_MASK;
+        acc >>= 29;
+    }
+    top[4] = (uint32_t)acc;                                 // limb 17: what is left (k g < 2^512 = 2^(29 * 17 + 19))
+    // bit 383 of the product is bit 6 of limb 13: add the rounding half, then drop 7 bits
+    uint32_t cy = 64u;
+    PLUME_UNROLL for (int i = 0; i < 5; i++) { const uint32_t t = top[i] + cy; cy = i < 4 ? t >> 29 : 0u; top[i] = i < 4 ? (t & PLUME_FE_MASK) : t; }
+    PLUME_UNROLL for (int i = 0; i < 5; i++) c[i] = ((top[i] >> 7) | (i < 4 ? top[i + 1] << 22 : 0u)) & PLUME_FE_MASK;
+}
+// low six limbs (174 bits) of x * y for five-limb x, y
+PLUME_HD void glv_mul_lo(uint32_t r[6], const uint32_t x[5], const uint32_t y[5]) {
+    uint64_t acc = 0;
+    PLUME_UNROLL for (int m = 0; m < 6; m++) {
+        PLUME_UNROLL for (int i = 0; i < 5; i++) { const int j = m - i; if (j >= 0 && j < 5) acc += (uint64_t)x[i] * y[j]; }
+        r[m] = (uint32_t)acc & PLUME_FE_MASK;
+        acc >>= 29;
+    }
+}
+// d = six signed limb differences (|d_i| < 2^31) that sum, MODULO 2^174, to a value below 2^128 in magnitude (the operands were truncated to 174 bits, so what falls off
+// the top of the carry chain means nothing) -> magnitude (four 32-bit words) and sign
+PLUME_HD void glv_finish(glv_half& h, const int32_t d[6]) {
+    int32_t cy = 0;
+    uint32_t l[6];
+    PLUME_UNROLL for (int i = 0; i < 6; i++) { const int32_t t = d[i] + cy; l[i] = (uint32_t)t & PLUME_FE_MASK; cy = t >> 29; }      // arithmetic shift: the borrow travels up
+    const bool neg = (l[5] >> 28) != 0;                     // |value| < 2^128: modulo 2^174 it is either below 2^128 or within 2^128 of the top -- bit 173 tells which
+    const uint32_t m = sel_mask(neg);
+    uint32_t bw = neg ? 1u : 0u;                            // two's complement of the six limbs when negative: ~l + 1
+    PLUME_UNROLL for (int i = 0; i < 6; i++) { const uint32_t t = ((l[i] ^ m) & PLUME_FE_MASK) + bw; l[i] = t & PLUME_FE_MASK; bw = t >> 29; }
+    h.m[0] = l[0] | (l[1] << 29);
+    h.m[1] = (l[1] >> 3) | (l[2] << 26);
+    h.m[2] = (l[2] >> 6) | (l[3] << 23);
+    h.m[3] = (l[3] >> 9) | (l[4] << 20);
+    h.neg = neg ? 1u : 0u;
+}
 PLUME_HD void glv_split(glv_half& h1, glv_half& h2, const sc& k) {
-    const uint32_t g1[8] = {0x45DBB031u, 0xE893209Au, 0x71E8CA7Fu, 0x3DAA8A14u, 0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u};
-    const uint32_t g2[8] = {0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu, 0x0ABFE4C4u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u};
-    const uint32_t mb1[4] = {0x0ABFE4C3u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u};
-    const uint32_t mb2[8] = {0x3DB1562Cu, 0xD765CDA8u, 0x0774346Du, 0x8A280AC5u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    sc lam; { const uint32_t l[8] = {0x1B23BD72u, 0xDF02967Cu, 0x20816678u, 0x122E22EAu, 0x8812645Au, 0xA5261C02u, 0xC05C30E0u, 0x5363AD4Cu};
-              PLUME_UNROLL for (int i = 0; i < 8; i++) lam.v[i] = l[i]; }
-    uint32_t t[16], c1[4], c2[4];
-    uint32_t c;
-    mul_limbs<8, 8>(t, k.v, g1);            // c1 = round(k*g1 / 2^384)
-    c = t[11] >> 31;
-    PLUME_UNROLL for (int i = 0; i < 4; i++) c1[i] = addc0(t[12 + i], c);
-    mul_limbs<8, 8>(t, k.v, g2);            // c2 = round(k*g2 / 2^384)
-    c = t[11] >> 31;
-    PLUME_UNROLL for (int i = 0; i < 4; i++) c2[i] = addc0(t[12 + i], c);
-    // k2 = c1*(-b1) + c2*(-b2)  (mod n)
-    uint32_t p1[8], p2[12], w[16];
-    mul_limbs<4, 4>(p1, c1, mb1);
-    mul_limbs<4, 8>(p2, c2, mb2);
-    c = 0;
-    PLUME_UNROLL for (int i = 0; i < 12; i++) w[i] = addc(p2[i], i < 8 ? p1[i] : opaque_zero(), c);
-    w[12] = c; w[13] = 0; w[14] = 0; w[15] = 0;
-    sc k2, k1, tmp;
-    sc_reduce_wide(k2, w);
-    sc_mul(tmp, k2, lam);
-    sc_neg(tmp, tmp);
-    sc_add(k1, k, tmp);                     // k1 = k - k2*lambda
-    // |k_i| < 2^128: a "negative" residue is >= n - 2^128, i.e. has non-zero high limbs
-    sc n1, n2;
-    sc_neg(n1, k1); sc_neg(n2, k2);
-    h1.neg = (k1.v[4] | k1.v[5] | k1.v[6] | k1.v[7]) != 0;
-    h2.neg = (k2.v[4] | k2.v[5] | k2.v[6] | k2.v[7]) != 0;
-    const uint32_t m1 = sel_mask(h1.neg != 0), m2 = sel_mask(h2.neg != 0);
-    PLUME_UNROLL for (int i = 0; i < 4; i++) { h1.m[i] = sel32(m1, n1.v[i], k1.v[i]); h2.m[i] = sel32(m2, n2.v[i], k2.v[i]); }
+    const uint32_t G1[9] = {0x05DBB031u, 0x049904D2u, 0x1A329FFAu, 0x151428E3u, 0x0EB153DAu, 0x08724942u, 0x0F37A1B2u, 0x0434FA8Du, 0x003086D2u};
+    const uint32_t G2[9] = {0x0AC47F71u, 0x0B8DA574u, 0x1D41B185u, 0x0411593Bu, 0x1E4C4221u, 0x1FD4855Fu, 0x00A1BD51u, 0x1AC021D1u, 0x00E4437Eu};
+    const uint32_t A1[5] = {0x1284EB15u, 0x03648724u, 0x151AF37Au, 0x0DA4434Fu, 0x00000308u};      // a1 = b2
+    const uint32_t MB1[5] = {0x0ABFE4C3u, 0x1AA3FD48u, 0x03A20A1Bu, 0x06FDAC02u, 0x00000E44u};     // -b1
+    const uint32_t A2[5] = {0x1D44CFD8u, 0x1E08846Cu, 0x18BCFD95u, 0x14A1EF51u, 0x0000114Cu};
+    fe kf;
+    fe_from_words(kf, k.v);                                 // k as nine 29-bit limbs
+    uint32_t c1[5], c2[5], p[6], q[6];
+    glv_cmul(c1, kf.v, G1);
+    glv_cmul(c2, kf.v, G2);
+    int32_t d[6];
+    glv_mul_lo(p, c1, MB1); glv_mul_lo(q, c2, A1);          // k2 = c1 (-b1) - c2 b2
+    PLUME_UNROLL for (int i = 0; i < 6; i++) d[i] = (int32_t)p[i] - (int32_t)q[i];
+    glv_finish(h2, d);
+    glv_mul_lo(p, c1, A1); glv_mul_lo(q, c2, A2);           // k1 = k - c1 a1 - c2 a2
+    PLUME_UNROLL for (int i = 0; i < 6; i++) d[i] = (int32_t)kf.v[i] - (int32_t)p[i] - (int32_t)q[i];
+    glv_finish(h1, d);
 }
 
 // Booth recoding, window w = PLUME_WBITS = 4: m = sum d_i 2^(w i), d_i in [-2^(w-1), 2^(w-1)], i = 0..NDIG-1 covering 129 bits:
