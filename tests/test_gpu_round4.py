@@ -96,6 +96,60 @@ def test_uniform_schedule_signer_every_item_of_2p18(eng):
         eng.set_sign_uniform(False)
 
 
+_LANES = r"""
+import json, os, sys
+import numpy as np
+import zk_nullifier_sig_amd as plume
+from zk_nullifier_sig_amd import capi
+from tests import synth, _fuzz
+n = 300_000
+b = synth.sign_inputs(n, start=41_000_000)
+eng = plume.Engine(0)
+eng.set_host_first_piece(1 << 13); eng.set_host_piece(1 << 16)          # 8192, 24576, 65536, 65536, ...: seven pieces, both lanes busy
+signed = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+v = _fuzz.fuzz_verify_batch(1, signed, b, seed=404)
+pin = {k: capi.pinned_copy(v[k]) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+off = capi.pinned_copy(v["off"])
+ok_pinned = eng.verify_batch(1, pin["msgs"], off, pin["pk"], pin["nullifier"], pin["c"], pin["s"], pin["r_point"], pin["hashed_to_curve_r"])
+ok_pageable = eng.verify_batch(1, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"])
+names = [x for x, _ in eng.last_stage_times()]
+np.save(sys.argv[1], np.stack([ok_pinned, ok_pageable]))
+print(json.dumps({"lanes": os.environ.get("PLUME_HOST_LANES"), "stages": names, "valid": int(ok_pinned.sum())}))
+"""
+
+
+def test_host_pointer_verify_on_two_lanes_equals_one_lane(tmp_path):
+    """Round 4: the pieces of a host-pointer verify alternate between the context and a second lane (four staging slots); pageable caller arrays stay on one lane.  300 000
+    fuzzed V1 signatures in seven pieces: the verdicts with PLUME_HOST_LANES=2 (default), =1 and from pageable arrays are the same bytes, and they are the device-resident
+    call's (checked against the CPU on a sample)."""
+    outs = []
+    for lanes in ("2", "1"):
+        f = tmp_path / f"ok{lanes}.npy"
+        env = dict(os.environ, PYTHONPATH=str(ROOT), PLUME_HOST_LANES=lanes)
+        r = subprocess.run([sys.executable, "-c", _LANES, str(f)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["lanes"] == lanes and 0.2 * 300_000 < d["valid"] < 0.9 * 300_000, d
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0][0], outs[0][1]) and np.array_equal(outs[0], outs[1])
+    # a sample against the CPU oracle (the same fuzzed batch, regenerated here)
+    import zk_nullifier_sig_amd as plume
+    from tests import _fuzz
+    n = 300_000
+    b = synth.sign_inputs(n, start=41_000_000)
+    e = plume.Engine(0)
+    try:
+        signed = e.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    finally:
+        e.close()
+    v = _fuzz.fuzz_verify_batch(1, signed, b, seed=404)
+    idx = np.sort(np.random.default_rng(4).choice(n, size=1024, replace=False))
+    sub_msgs = np.concatenate([v["msgs"][int(v["off"][i]):int(v["off"][i + 1])] for i in idx] + [np.zeros(16, np.uint8)])
+    sub_off = np.concatenate([[0], np.cumsum([int(v["off"][i + 1] - v["off"][i]) for i in idx])]).astype(np.uint64)
+    want = OC.verify_batch(1, sub_msgs, sub_off, v["pk"][idx], v["nullifier"][idx], v["c"][idx], v["s"][idx], v["r_point"][idx], v["hashed_to_curve_r"][idx], nthreads=8)
+    assert np.array_equal(outs[0][0][idx], want)
+
+
 _LAZY = r"""
 import json, sys
 import numpy as np

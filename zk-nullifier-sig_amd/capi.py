@@ -19,7 +19,7 @@ _u64p = C.POINTER(C.c_uint64)
 DEFAULT_CHUNK = 1 << 20
 DEFAULT_HOST_PIECE = 1 << 19
 DEFAULT_HOST_FIRST_PIECE = 1 << 16
-DEFAULT_HOST_TAIL_PIECE = 1 << 17
+DEFAULT_HOST_TAIL_PIECE = 1 << 16
 DEFAULT_SUB_BATCHES = 1
 
 
