@@ -404,8 +404,8 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     if (version != 1 && version != 2) return -1;
     // (the signer reads the comb only)
     const std::vector<uint32_t>& gcomb = shared_gcomb();
-    std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_BASE_WORDS * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab((size_t)n * PLUME_TAB_WORDS);
-    std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(n), itemflags(n);
+    std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_BASE_WORDS * 2 * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab(2 * (size_t)n * PLUME_TAB_WORDS);
+    std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(2 * (size_t)n), itemflags(n);
     SignArgs a; memset(&a, 0, sizeof a);
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msg_off[n]; a.sk = sk; a.r = r; a.pk_in = pk_in;
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
@@ -419,7 +419,8 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
         for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.gres, a.gresinf, npts, lane, nlanes);
     }
     for (uint32_t i = 0; i < n; i++) sign_h2c(a, i);
-    run_tables(a.tab, a.bases, a.jobflags, n, L);
+    for (uint32_t i = 0; i < n; i++) sign_hdbl(a, i);
+    run_tables(a.tab, a.bases, a.jobflags, 2 * (size_t)n, L);
     for (uint32_t w = 0; w < 2; w++)
         for (uint32_t i = 0; i < n; i++) { if (g_sign_uniform) sign_hmul<true>(a, i, w, dig.data() + (i % B), B); else sign_hmul(a, i, w, dig.data() + (i % B), B); }
     {

@@ -39,6 +39,8 @@ PLUME_HD fe fe_off_x() { return fe_set(0xBE71E685u, 0x6986BD54u, 0xA5797708u, 0x
 PLUME_HD fe fe_off_y() { return fe_set(0x15AE5773u, 0x1FAF9233u, 0xF016B8C3u, 0x84D627FDu, 0x8CF7C500u, 0x22EAB6A1u, 0x27C3954Bu, 0x8A01ED04u); }
 PLUME_HD fe fe_off_c128_x() { return fe_set(0x8141C548u, 0xF0861E56u, 0xAE562CECu, 0x00E54F8Bu, 0x7535C0B1u, 0x943A12D3u, 0x469080E1u, 0xA23EEBF9u); }   // -(2^128 B)
 PLUME_HD fe fe_off_c128_y() { return fe_set(0xE429892Au, 0x9AB04F55u, 0xF3E86FE7u, 0xE225348Fu, 0xEF934040u, 0xDC585E87u, 0x1A3CC5BEu, 0x78194203u); }
+PLUME_HD fe fe_off_c64_x() { return fe_set(0x8C789E12u, 0x56849B1Eu, 0x66BB27D0u, 0x5BE6CDC5u, 0x043289AFu, 0xB56465A3u, 0xAF7D81E9u, 0xD0746A2Fu); }   // -(2^64 B): the signer's half-length chains
+PLUME_HD fe fe_off_c64_y() { return fe_set(0x951FAD83u, 0x6890A4BDu, 0x269416A6u, 0x5C972C30u, 0x9B5A23BDu, 0x5CBF67BDu, 0xB62C3867u, 0x3DBFF40Bu); }
 PLUME_HD fe fe_off_neg_y() { return fe_set(0xEA51A88Cu, 0xE0506DCCu, 0x0FE9473Cu, 0x7B29D802u, 0x73083AFFu, 0xDD15495Eu, 0xD83C6AB3u, 0x75FE0F2Bu); }    // -B = (x(B), this)
 
 // y^2 == x^3 + 7 (curves/mod.rs:36-39)
@@ -326,6 +328,17 @@ PLUME_HD void booth_store(int8_t* dig, uint32_t stride, const glv_half& h, bool 
     bool neg = (h.neg != 0) != flip;
     PLUME_UNROLL for (int i = 0; i < PLUME_NDIG; i++) {
         int d = booth_digit(h.m, i);
+        dig[(uint32_t)i * stride] = (int8_t)(neg ? -d : d);
+    }
+}
+
+// The signer's quarter scalars (round 4): a 128-bit half of the GLV split is cut once more at bit 64, m = lo + hi 2^64, so that k1 P = lo P + hi (2^64 P) runs along a
+// chain of 64 doublings instead of 128 when the table of 2^64 P exists.  17 Booth digits per 64-bit quarter (the top one is the recoding's carry: 0 or 1).
+#define PLUME_NDIG64 ((64 + PLUME_WBITS) / PLUME_WBITS)
+PLUME_HD void booth_store64(int8_t* dig, uint32_t stride, uint32_t lo, uint32_t hi, bool neg) {
+    const uint32_t m[4] = {lo, hi, 0u, 0u};
+    PLUME_UNROLL for (int i = 0; i < PLUME_NDIG64; i++) {
+        int d = booth_digit(m, i);
         dig[(uint32_t)i * stride] = (int8_t)(neg ? -d : d);
     }
 }
@@ -899,8 +912,9 @@ PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
 // job flagged INF) contributes nothing.
 // wide0: slots 0,1 use the generator's wide table with W-bit digits (stored by booth_store_wide).
 // digit of slot s at window i (wide generator digits decoded); 0 = nothing to add
+template <int ND = PLUME_NDIG>
 PLUME_HD int msm_digit(const int8_t* dig, uint32_t stride, int i, int s, bool wide0) {
-    int d = dig[(uint32_t)(s * PLUME_NDIG + i) * stride];
+    int d = dig[(uint32_t)(s * ND + i) * stride];
     if (wide0 && s < 2) {
         int mag = d & 0xFF;
         bool dn;
@@ -919,9 +933,10 @@ PLUME_HD int msm_digit(const int8_t* dig, uint32_t stride, int i, int s, bool wi
 PLUME_HD bool msm_slot_used(int i, int s, bool wide0) { return !(wide0 && s < 2 && (i % PLUME_GWS) != 0); }
 // gather the operand of step (i, s): digit and, for a non-zero digit of a live table, the row's x (or beta x) and y -- the loads are only ISSUED here, whoever
 // reads qx / qy first waits for them
+template <int ND = PLUME_NDIG>
 PLUME_HD int msm_fetch(fe& qx, fe& qy, const uint32_t* tab0, const uint32_t* tab1, const int8_t* dig, uint32_t stride, int i, int s, bool wide0) {
     const uint32_t* tab = (s & 2) ? tab1 : tab0;
-    int d = msm_digit(dig, stride, i, s, wide0);
+    int d = msm_digit<ND>(dig, stride, i, s, wide0);
     if (tab == nullptr) d = 0;
     if (d != 0) {
         const int ad = d < 0 ? -d : d;
@@ -929,17 +944,18 @@ PLUME_HD int msm_fetch(fe& qx, fe& qy, const uint32_t* tab0, const uint32_t* tab
     }
     return d;
 }
-template <bool CHECKED>
+// ND windows per slot: PLUME_NDIG (129-bit halves: the verifier) or PLUME_NDIG64 (the signer's 64-bit quarters; no wide digits there)
+template <bool CHECKED, int ND = PLUME_NDIG>
 PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
-    PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
-        if (i != PLUME_NDIG - 1) {
+    PLUME_NOUNROLL for (int i = ND - 1; i >= 0; i--) {
+        if (i != ND - 1) {
             PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl_neg(acc);      // an even number of sign-flipping doublings
         }
         PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
             if (!msm_slot_used(i, s, wide0)) continue;              // wave-uniform: a wide digit sits at every (W/4)-th window only
             fe qx, qy;
-            const int d = msm_fetch(qx, qy, tab0, tab1, dig, stride, i, s, wide0);
+            const int d = msm_fetch<ND>(qx, qy, tab0, tab1, dig, stride, i, s, wide0);
             if (d != 0) {
                 if (d < 0) fe_neg_lazy(qy, qy);
                 jac_madd<CHECKED>(acc, qx, qy);
@@ -949,15 +965,16 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
 }
 // The chain with the UNIFORM schedule (opt-in signer): no slot is skipped and no branch depends on a digit.  `live` false (the table's base was the identity / invalid: a
 // public fact) turns every digit into 0.  Starts at the offset point B; the caller takes 2^(4 (NDIG-1)) B = 2^128 B off again.
-template <bool CHECKED>
-PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab, bool live, int nslots, const int8_t* dig, uint32_t stride) {
+template <bool CHECKED, int ND>
+PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, bool live, int nslots, const int8_t* dig, uint32_t stride) {
     acc.x = fe_off_x(); acc.y = fe_off_y(); acc.z = fe_small(1); acc.inf = 0;
-    PLUME_NOUNROLL for (int i = PLUME_NDIG - 1; i >= 0; i--) {
-        if (i != PLUME_NDIG - 1) {
+    PLUME_NOUNROLL for (int i = ND - 1; i >= 0; i--) {
+        if (i != ND - 1) {
             PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl_neg(acc);      // an even number of sign-flipping doublings
         }
         PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
-            int d = dig[(uint32_t)(s * PLUME_NDIG + i) * stride];
+            const uint32_t* tab = (s & 2) ? tab1 : tab0;
+            int d = dig[(uint32_t)(s * ND + i) * stride];
             d = live ? d : 0;
             const int ad = (d < 0 ? -d : d) + (d == 0 ? 1 : 0);
             fe qx, qy;
@@ -966,16 +983,18 @@ PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab, bool live, int
         }
     }
 }
-static_assert(PLUME_WBITS * (PLUME_NDIG - 1) == 128, "the uniform chain's offset constant is -(2^128 B)");
+static_assert(PLUME_WBITS * (PLUME_NDIG - 1) == 128 && PLUME_WBITS * (PLUME_NDIG64 - 1) == 64, "the uniform chains' offset constants are -(2^128 B) and -(2^64 B)");
 static_assert(PLUME_WBITS % 2 == 0, "the window loops double with jac_dbl_neg: an even count per window");
-PLUME_HD void msm_run_uniform(jac& acc, const uint32_t* tab, bool live, int nslots, const int8_t* dig, uint32_t stride) {
-    msm_run_uniform_impl<false>(acc, tab, live, nslots, dig, stride);
+template <int ND>
+PLUME_HD void msm_run_uniform(jac& acc, const uint32_t* tab0, const uint32_t* tab1, bool live, int nslots, const int8_t* dig, uint32_t stride) {
+    msm_run_uniform_impl<false, ND>(acc, tab0, tab1, live, nslots, dig, stride);
     if (fe_is_zero(acc.z)) {
         PLUME_COUNT_FALLBACK();
-        msm_run_uniform_impl<true>(acc, tab, live, nslots, dig, stride);
+        msm_run_uniform_impl<true, ND>(acc, tab0, tab1, live, nslots, dig, stride);
     }
-    if (!acc.inf) jac_madd<true>(acc, fe_off_c128_x(), fe_off_c128_y());     // - 2^128 B  (acc.inf: only after a checked redo that hit the identity)
-    else { acc.x = fe_off_c128_x(); acc.y = fe_off_c128_y(); acc.z = fe_small(1); acc.inf = 0; }
+    const fe cx = ND == PLUME_NDIG64 ? fe_off_c64_x() : fe_off_c128_x(), cy = ND == PLUME_NDIG64 ? fe_off_c64_y() : fe_off_c128_y();     // - 2^(4 (ND - 1)) B
+    if (!acc.inf) jac_madd<true>(acc, cx, cy);
+    else { acc.x = cx; acc.y = cy; acc.z = fe_small(1); acc.inf = 0; }              // (acc.inf: only after a checked redo that hit the identity)
 }
 // the same chain with the checked additions only (the redo kernel of the verifier: tasks whose unchecked chain met p == +-q)
 PLUME_HD void msm_run_checked(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
@@ -987,12 +1006,13 @@ PLUME_HD bool msm_run_unchecked(jac& acc, const uint32_t* tab0, const uint32_t* 
     msm_run_impl<false>(acc, tab0, tab1, nslots, dig, stride, wide0);
     return acc.inf || !fe_is_zero(acc.z);
 }
+template <int ND = PLUME_NDIG>
 PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
-    msm_run_impl<false>(acc, tab0, tab1, nslots, dig, stride, wide0);
+    msm_run_impl<false, ND>(acc, tab0, tab1, nslots, dig, stride, wide0);
     // an accumulator that met p == +-q inside an unchecked addition has Z = 0 (mod p) forever after (see jac_madd): redo that lane
     if (!acc.inf && fe_is_zero(acc.z)) {
         PLUME_COUNT_FALLBACK();
-        msm_run_impl<true>(acc, tab0, tab1, nslots, dig, stride, wide0);
+        msm_run_impl<true, ND>(acc, tab0, tab1, nslots, dig, stride, wide0);
     }
 }
 

@@ -235,23 +235,29 @@ __global__ PLUME_H2C_BOUNDS void k_sign_h2c(SignArgs a) {
     if (i < a.n) sign_h2c(a, i);
 }
 
+// 2^64 H of every item (plume_stages.h sign_hdbl): 64 doublings, once per item, so that the item's two multiplications by H run along chains of half the length
+__global__ PLUME_MSM_BOUNDS void k_sign_hdbl(SignArgs a) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < a.n) sign_hdbl(a, i);
+}
+
 __global__ PLUME_MSM_BOUNDS void k_sign_hmul(SignArgs a) {
-    __shared__ int8_t s_dig[2 * PLUME_NDIG * kBlock];
+    __shared__ int8_t s_dig[4 * PLUME_NDIG64 * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
     if (i < a.n) sign_hmul(a, i, which, s_dig + threadIdx.x, kBlock);
-    wipe_digits<2 * PLUME_NDIG>(s_dig);   // the rows are digits of sk and r: nothing derived from a secret stays in LDS when the workgroup retires
+    wipe_digits<4 * PLUME_NDIG64>(s_dig);   // the rows are digits of sk and r: nothing derived from a secret stays in LDS when the workgroup retires
 }
 
 // the uniform-schedule forms of the two kernels that walk secret digits (plume_set_sign_uniform): same grids, same outputs
 __global__ PLUME_MSM_BOUNDS void k_sign_hmul_uniform(SignArgs a) {
-    __shared__ int8_t s_dig[2 * PLUME_NDIG * kBlock];
+    __shared__ int8_t s_dig[4 * PLUME_NDIG64 * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
     if (i < a.n) sign_hmul<true>(a, i, which, s_dig + threadIdx.x, kBlock);
-    wipe_digits<2 * PLUME_NDIG>(s_dig);
+    wipe_digits<4 * PLUME_NDIG64>(s_dig);
 }
 __global__ PLUME_MSM_BOUNDS void k_sign_gmul_uniform(SignArgs a) {
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
@@ -472,6 +478,7 @@ void launch_sign_gmul(const SignArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL(k_sign_gmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
 }
 void launch_sign_h2c(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_h2c, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
+void launch_sign_hdbl(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_hdbl, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_hmul(const SignArgs& a, hipStream_t st) {
     if (a.uniform) hipLaunchKernelGGL(k_sign_hmul_uniform, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
     else hipLaunchKernelGGL(k_sign_hmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);

@@ -21,6 +21,7 @@ void launch_verify_msm(const VerifyArgs& a, hipStream_t st);
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st);
 void launch_sign_gmul(const SignArgs& a, hipStream_t st);
 void launch_sign_h2c(const SignArgs& a, hipStream_t st);
+void launch_sign_hdbl(const SignArgs& a, hipStream_t st);     // 2^64 H per item (after launch_sign_h2c, before the table stage over 2n jobs)
 void launch_sign_hmul(const SignArgs& a, hipStream_t st);
 void launch_sign_final(const SignArgs& a, hipStream_t st);
 void launch_normalize(uint32_t* pts, const uint8_t* inf, size_t npts, hipStream_t st);

@@ -443,10 +443,10 @@ struct SignArgs {
     int out33;              // 0: pk, nul, rpt, hr are 64-byte affine records; 1: 33-byte SEC1-compressed records (stride 33)
     // scratch
     uint32_t* gres;  uint8_t* gresinf;   // 2n tasks: sk*G, r*G (Jacobian SoA)
-    uint32_t* bases; uint8_t* jobflags;  // n jobs: H
+    uint32_t* bases; uint8_t* jobflags;  // 2n jobs: H of item i at i, 2^64 H at n + i (round 4: the signer's chains are 64 doublings long, sign_hdbl)
     uint8_t* itemflags;                  // n: status bits accumulated across stages
     uint32_t* pkaff;                     // 2 * PLUME_FE_WORDS x n words SoA: affine pk (x, y), canonical, for the final stage
-    uint32_t* tab;                       // n tables
+    uint32_t* tab;                       // 2n tables, same order
     uint32_t* hres;  uint8_t* hresinf;   // 2n tasks: sk*H, r*H
     const uint32_t* gcomb;               // fixed-base comb of G (PLUME_COMB_WORDS)
     int uniform;                         // 1: the uniform-schedule kernels (plume_set_sign_uniform): no branch on a secret digit
@@ -460,19 +460,41 @@ PLUME_HD uint32_t load_scalar_reduced(sc& k, const uint8_t* p) {
     return ok ? 0u : PLUME_ST_BAD_SCALAR;
 }
 // task t = 2*item + which: which 0 -> sk, 1 -> r;  result = k * (table tab0)
+// k * H with the tables of H (tab0) and 2^64 H (tab1): k = k1 + k2 lambda (GLV), each 128-bit half = lo + hi 2^64 -- four 64-bit quarters on H, lambda H, 2^64 H,
+// lambda 2^64 H, one chain of 64 doublings (round 4; rounds 1-3: two halves, 128 doublings.  The 64 doublings that make 2^64 H are spent ONCE per item and serve both of
+// its multiplications, sk * H and r * H: sign_hdbl).
 template <bool UNIFORM = false>
-PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, const uint32_t* tab0, uint32_t* res, uint8_t* resinf, int8_t* dig, uint32_t stride) {
+PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, bool live, uint32_t* res, uint8_t* resinf, int8_t* dig, uint32_t stride) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
     sc k;
     (void)load_scalar_reduced(k, (which ? a.r : a.sk) + 32 * (size_t)item);
     glv_half h1, h2;
     glv_split(h1, h2, k);
-    booth_store(dig, stride, h1, false); booth_store(dig + PLUME_NDIG * stride, stride, h2, false);
+    booth_store64(dig + 0 * PLUME_NDIG64 * stride, stride, h1.m[0], h1.m[1], h1.neg != 0);
+    booth_store64(dig + 1 * PLUME_NDIG64 * stride, stride, h2.m[0], h2.m[1], h2.neg != 0);
+    booth_store64(dig + 2 * PLUME_NDIG64 * stride, stride, h1.m[2], h1.m[3], h1.neg != 0);
+    booth_store64(dig + 3 * PLUME_NDIG64 * stride, stride, h2.m[2], h2.m[3], h2.neg != 0);
+    const uint32_t* t0 = a.tab + (size_t)item * PLUME_TAB_WORDS;                      // (every job has a table: a dummy one when its base was no usable point)
+    const uint32_t* t1 = a.tab + ((size_t)a.n + item) * PLUME_TAB_WORDS;
     jac acc;
-    if (UNIFORM) msm_run_uniform(acc, a.tab + (size_t)item * PLUME_TAB_WORDS, tab0 != nullptr, 2, dig, stride);     // (every job has a table: a dummy one when its base was no usable point)
-    else msm_run(acc, tab0, nullptr, 2, dig, stride, false);
+    if (UNIFORM) msm_run_uniform<PLUME_NDIG64>(acc, t0, t1, live, 4, dig, stride);
+    else msm_run<PLUME_NDIG64>(acc, live ? t0 : nullptr, live ? t1 : nullptr, 4, dig, stride, false);
     st_jac_soa(res, nt, t, acc);
     resinf[t] = (uint8_t)acc.inf;
+}
+// 2^64 H of item i next to H (job n + i): 64 doublings of the Jacobian H, once per item.  A job whose H is no usable point (identity: a status bit, randomizedsigner.rs:61)
+// gets G under the same flag, like every other placeholder base.
+PLUME_HD void sign_hdbl(const SignArgs& a, uint32_t i) {
+    const uint8_t f = a.jobflags[i];
+    jac h;
+    if (job_state(f) == PLUME_JOB_OK) {
+        ld_base(h, a.bases, i, true); h.inf = 0;
+        PLUME_NOUNROLL for (int d = 0; d < 64; d++) jac_dbl_neg(h);               // an even number of sign-flipping doublings
+    } else {
+        h.x = fe_gx(); h.y = fe_gy(); h.z = fe_small(1); h.inf = 0;
+    }
+    st_base(a.bases, (size_t)a.n + i, h);
+    a.jobflags[(size_t)a.n + i] = f;
 }
 // task t = 2*item + which: sk*G (which 0) or r*G (which 1) by the doubling-free comb
 template <bool UNIFORM = false>
@@ -518,8 +540,7 @@ PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
 }
 template <bool UNIFORM = false>
 PLUME_HD void sign_hmul(const SignArgs& a, uint32_t item, uint32_t which, int8_t* dig, uint32_t stride) {
-    const uint32_t* tab0 = job_state(a.jobflags[item]) == PLUME_JOB_OK ? a.tab + (size_t)item * PLUME_TAB_WORDS : nullptr;
-    sign_mul<UNIFORM>(a, item, which, tab0, a.hres, a.hresinf, dig, stride);
+    sign_mul<UNIFORM>(a, item, which, job_state(a.jobflags[item]) == PLUME_JOB_OK, a.hres, a.hresinf, dig, stride);
 }
 PLUME_HD void sign_final(const SignArgs& a, uint32_t i) {
     const size_t nt = 2 * (size_t)a.n;
