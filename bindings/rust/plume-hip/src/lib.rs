@@ -282,8 +282,9 @@ impl HipEngine {
     /// Batches in flight (`plume_set_in_flight`): with 2, device-resident calls issued on different streams run side by side (two lanes of the context); default 1
     pub fn set_in_flight(&self, k: i32) -> Result<(), HipError> { if unsafe { plume_set_in_flight(self.0, k) } == 0 { Ok(()) } else { Err(last_error()) } }
     /// The signer's uniform schedule (`plume_set_sign_uniform`): no branch on a digit of `sk` or `r` in the two kernels that walk them (k256's multiplication is constant-time;
-    /// the default GPU signer skips zero digits).  Outputs are unchanged; a 2^20 sign costs 3 % more.  Table rows are still gathered at digit-dependent addresses.
-    pub fn set_sign_uniform(&self, on: bool) -> Result<(), HipError> { if unsafe { plume_set_sign_uniform(self.0, on as c_int) } == 0 { Ok(()) } else { Err(last_error()) } }
+    /// the default GPU signer skips zero digits).  `level` 0 = default, 1 = no secret-dependent branch (table rows still gathered at digit-dependent addresses),
+    /// 2 = no secret-dependent address either (every row of a window's table is read and one kept by masked selects, as k256 does).  Outputs are unchanged.
+    pub fn set_sign_uniform(&self, level: i32) -> Result<(), HipError> { if unsafe { plume_set_sign_uniform(self.0, level as c_int) } == 0 { Ok(()) } else { Err(last_error()) } }
     /// The NUMA node shard `d`'s worker thread bound itself to (`None`: not bound) — allocate / pin the caller arrays of that shard's slice there
     pub fn shard_numa_node(&self, d: usize) -> Option<i32> { let v = unsafe { plume_shard_numa_node(self.0, d as c_int) }; if v >= 0 { Some(v) } else { None } }
 

@@ -88,11 +88,14 @@ int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
  * whichever lane serves the call (so a sign followed by a verify of its outputs, both with stream = NULL, stay ordered).  Costs a second per-batch workspace.  Single-device contexts only (a multi-device context
  * already runs its shards side by side).  plume_last_stage_times / plume_last_redo_tasks then report the lane of the last device-resident call. */
 int plume_set_in_flight(plume_ctx* ctx, int batches);
-/* The signer's uniform schedule (default off; env PLUME_SIGN_UNIFORM=1 sets the default of new contexts).  k256's scalar multiplication is constant-time;
- * the default signer here skips zero digits and branches on digit signs: its instruction trace depends on sk and r.  With on != 0 the two kernels that walk those digits
- * (sk*G, r*G by the comb; sk*H, r*H by windows; also the comb of the SEC1-DER export, whose scalars are secret keys) run the same instructions for every digit value: every slot adds (a zero digit adds row 1 to a copy that a masked select
- * drops), signs are masked selects, the accumulator starts at a fixed offset point that is subtracted at the end.  Outputs are bit-identical to the default's.  Still
- * secret-dependent: the ADDRESS of the table row each slot gathers (memory access pattern), so this is "no secret-dependent control flow", not a constant-time claim. */
+/* The signer's uniform schedule (default 0 = off; env PLUME_SIGN_UNIFORM=<level> sets the default of new contexts).  k256's scalar multiplication is constant-time
+ * (SURVEY.md §5); the default signer here skips zero digits and branches on digit signs: its instruction trace depends on sk and r.
+ *   level 1: the two kernels that walk those digits (sk*G, r*G by the comb; sk*H, r*H by windows; also the comb of the SEC1-DER export, whose scalars are secret keys) run the
+ *            same instructions for every digit value: every slot adds (a zero digit adds row 1 to a copy that a masked select drops), signs are masked selects, the
+ *            accumulator starts at a fixed offset point that is subtracted at the end.  Still secret-dependent: the ADDRESS of the table row each slot gathers.
+ *   level 2: level 1, and no address is derived from a digit: every slot reads all 8 rows of its window's table and keeps one by masked selects (what k256 does with its
+ *            16-entry tables); the multiplications by G then use a 52-window x 16-row table instead of the 18-bit comb (52 additions instead of 15).
+ * Outputs are bit-identical at every level.  Returns PLUME_ERR_ARG for a level outside 0..2.  Costs: DESIGN.md §9. */
 int plume_set_sign_uniform(plume_ctx* ctx, int on);
 /* Environment knobs read when a context is created (tuning and A/B runs; results never depend on them):
  *   PLUME_SUB_BATCHES, PLUME_SERIAL, PLUME_OVERLAP_MIN   sub-batch overlap of the device-resident calls (plume_set_sub_batches)
@@ -101,7 +104,7 @@ int plume_set_sign_uniform(plume_ctx* ctx, int on);
  *   PLUME_INGEST_SPLIT_MAX   verify calls of at most this many items run the ingest stage with two lanes per item (default 65536; 0: never)
  *   PLUME_TABLES_SMALL_MAX   window-table stages of at most this many jobs (3 per verify, 1 per sign) take the one-inversion Jacobian chain (default 98304; 0: never)
  *   PLUME_JOBS_PER_LANE      jobs per lane of the affine table passes (default: 3..6 by batch size)
- *   PLUME_SIGN_UNIFORM       default of plume_set_sign_uniform
+ *   PLUME_SIGN_UNIFORM       default level of plume_set_sign_uniform (0, 1, 2)
  *   PLUME_NO_AFFINITY        multi-device contexts: leave the shard threads' CPU affinity alone */
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (an upload, a download and the compute streams,
  * four staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each following piece up to three times

@@ -155,7 +155,7 @@ def verify_batch_sec1(version, msgs_buf, msg_off, pk33, nul33, c, s, r33=None, h
 
 def sign_batch(version, msgs_buf, msg_off, sk, r, pk_in=None, L=3, uniform=False):
     n = len(msg_off) - 1
-    lib().ds_set_sign_uniform(C.c_int(1 if uniform else 0))
+    lib().ds_set_sign_uniform(C.c_int(int(uniform)))
     o = {k: np.zeros((n, w), dtype=np.uint8) for k, w in
          [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64), ("h", 64)]}
     status = np.zeros(n, dtype=np.uint8)

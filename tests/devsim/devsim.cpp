@@ -131,6 +131,17 @@ static void build_gcomb(std::vector<uint32_t>& comb) {
     for (uint32_t w = 0; w < PLUME_COMB_WINDOWS; w++) fixed_window_base(base18.data() + (size_t)w * 2 * PLUME_FE_WORDS, PLUME_COMB_W * w);      // mirrors k_fixed_bases
     for (size_t lane = 0; lane < (size_t)PLUME_COMB_ENTRIES * PLUME_COMB_WINDOWS; lane++) fixed_table_lane(comb.data(), base18.data(), PLUME_COMB_ENTRIES, lane);
 }
+// the scanned table of G of the uniform schedule's level 2 (mirrors launch_fixed_tables' gscan leg)
+static const std::vector<uint32_t>& shared_gscan() {
+    static std::vector<uint32_t> t;
+    if (t.empty()) {
+        t.assign(PLUME_GSCAN_WORDS, 0);
+        std::vector<uint32_t> base18((size_t)PLUME_GSCAN_WINDOWS * 2 * PLUME_FE_WORDS);
+        for (uint32_t w = 0; w < PLUME_GSCAN_WINDOWS; w++) fixed_window_base(base18.data() + (size_t)w * 2 * PLUME_FE_WORDS, PLUME_GSCAN_W * w);
+        for (size_t lane = 0; lane < (size_t)PLUME_GSCAN_ENTRIES * PLUME_GSCAN_WINDOWS; lane++) fixed_table_lane(t.data(), base18.data(), PLUME_GSCAN_ENTRIES, lane);
+    }
+    return t;
+}
 static const std::vector<uint32_t>& shared_gcomb() {
     static std::vector<uint32_t> gcomb;
     if (gcomb.empty()) build_gcomb(gcomb);
@@ -410,10 +421,10 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msg_off[n]; a.sk = sk; a.r = r; a.pk_in = pk_in;
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
     a.gres = gres.data(); a.gresinf = gresinf.data(); a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
-    a.pkaff = pkaff.data(); a.tab = tab.data(); a.hres = hres.data(); a.hresinf = hresinf.data(); a.gcomb = gcomb.data();
+    a.pkaff = pkaff.data(); a.tab = tab.data(); a.hres = hres.data(); a.hresinf = hresinf.data(); a.gcomb = gcomb.data(); a.gscan = shared_gscan().data(); a.uniform = g_sign_uniform;
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);
     for (uint32_t w = 0; w < 2; w++)
-        for (uint32_t i = 0; i < n; i++) { if (g_sign_uniform) sign_gmul<true>(a, i, w); else sign_gmul(a, i, w); }
+        for (uint32_t i = 0; i < n; i++) { if (g_sign_uniform == 2) sign_gmul<2>(a, i, w); else if (g_sign_uniform) sign_gmul<1>(a, i, w); else sign_gmul(a, i, w); }
     {
         const size_t npts = 2 * (size_t)n, nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;
         for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.gres, a.gresinf, npts, lane, nlanes);
@@ -422,7 +433,10 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     for (uint32_t i = 0; i < n; i++) sign_hdbl(a, i);
     run_tables(a.tab, a.bases, a.jobflags, 2 * (size_t)n, L);
     for (uint32_t w = 0; w < 2; w++)
-        for (uint32_t i = 0; i < n; i++) { if (g_sign_uniform) sign_hmul<true>(a, i, w, dig.data() + (i % B), B); else sign_hmul(a, i, w, dig.data() + (i % B), B); }
+        for (uint32_t i = 0; i < n; i++) {
+            int8_t* dg = dig.data() + (i % B);
+            if (g_sign_uniform == 2) sign_hmul<2>(a, i, w, dg, B); else if (g_sign_uniform) sign_hmul<1>(a, i, w, dg, B); else sign_hmul(a, i, w, dg, B);
+        }
     {
         const size_t npts = 2 * (size_t)n, nlanes = (npts + PLUME_NORM_K - 1) / PLUME_NORM_K;
         for (size_t lane = 0; lane < nlanes; lane++) normalize_points(a.hres, a.hresinf, npts, lane, nlanes);
@@ -488,7 +502,7 @@ void ds_map2_to_curve(const uint8_t* u0b, const uint8_t* u1b, uint8_t* out) {
 }
 int ds_scalars_to_der(uint32_t n, const uint8_t* scalars, uint8_t* der, uint8_t* status) {
     const std::vector<uint32_t>& gcomb = shared_gcomb();
-    DerArgs a; a.n = n; a.scalars = scalars; a.der = der; a.status = status; a.gcomb = gcomb.data(); a.uniform = g_sign_uniform;
+    DerArgs a; a.n = n; a.scalars = scalars; a.der = der; a.status = status; a.gcomb = gcomb.data(); a.gscan = shared_gscan().data(); a.uniform = g_sign_uniform;
     for (uint32_t i = 0; i < n; i++) scalar_to_sec1_der(a, i);
     return 0;
 }

@@ -230,10 +230,12 @@ def test_golden_sign(ver, kats):
     assert o["nullifier"][0].tobytes().hex() == v["nullifier_x"] + v["nullifier_y"]
 
 
+@pytest.mark.parametrize("level", [1, 2])
 @pytest.mark.parametrize("ver", [1, 2])
-def test_uniform_schedule_signer_gives_the_same_bytes(ver):
+def test_uniform_schedule_signer_gives_the_same_bytes(ver, level):
     """plume_set_sign_uniform (round 4): the signer's chains with no branch on a digit -- every slot adds, zero digits are dropped by a masked select, the accumulator starts
-    at an offset point -- produce exactly the default signer's outputs: the golden batch, scalars full of zero digits (0x...0001, 2^k, n - 1: long runs of dummy additions),
+    at an offset point -- and, at level 2, with no table address derived from a digit (all eight rows of a window read, one kept by masked selects; the multiplications by G
+    on the small scanned table instead of the comb) produce exactly the default signer's outputs: the golden batch, scalars full of zero digits (0x...0001, 2^k, n - 1: long runs of dummy additions),
     tiny keys (the crafted collisions of the default path), out-of-range scalars (status bits) and a supplied pk"""
     items = GOLD[f"sign_v{ver}"]
     mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
@@ -249,11 +251,11 @@ def test_uniform_schedule_signer_gives_the_same_bytes(ver):
         if k % 7 == 0:
             r[k] = sk[k]
     want = D.sign_batch(ver, mb, off, sk, r)
-    got = D.sign_batch(ver, mb, off, sk, r, uniform=True)
+    got = D.sign_batch(ver, mb, off, sk, r, uniform=level)
     for key in want:
         assert np.array_equal(got[key], want[key]), key
     assert int((want["status"] != 0).sum()) > 0
-    got2 = D.sign_batch(ver, mb, off, sk, r, pk_in=want["pk"], uniform=True)
+    got2 = D.sign_batch(ver, mb, off, sk, r, pk_in=want["pk"], uniform=level)
     for key in want:
         assert np.array_equal(got2[key], want[key]), key
 
@@ -633,11 +635,12 @@ def _check_sec1_der(to_der, from_der, kats):
 
 def test_sec1_der_scalar_marshalling(kats):
     _check_sec1_der(D.scalars_to_der, None, kats)
-    D.lib().ds_set_sign_uniform(1)                 # ... and with the comb's uniform schedule (plume_set_sign_uniform covers the export: its scalars are secret keys)
-    try:
-        _check_sec1_der(D.scalars_to_der, None, kats)
-    finally:
-        D.lib().ds_set_sign_uniform(0)
+    for level in (1, 2):                           # ... and with the comb's uniform schedules (plume_set_sign_uniform covers the export: its scalars are secret keys)
+        D.lib().ds_set_sign_uniform(level)
+        try:
+            _check_sec1_der(D.scalars_to_der, None, kats)
+        finally:
+            D.lib().ds_set_sign_uniform(0)
 
 
 def test_affine_table_chain_and_its_zero_denominator_guard():

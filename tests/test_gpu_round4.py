@@ -59,8 +59,9 @@ def test_null_stream_calls_stay_ordered_with_batches_in_flight(eng):
         eng.set_in_flight(1)
 
 
-def test_uniform_schedule_signer_every_item_of_2p18(eng):
-    """plume_set_sign_uniform: the signer with no branch on a digit of sk or r gives the default signer's bytes -- every item of 2^18 with edge scalars salted in (zero-digit
+@pytest.mark.parametrize("level", [1, 2])
+def test_uniform_schedule_signer_every_item_of_2p18(eng, level):
+    """plume_set_sign_uniform: the signer with no branch on a digit of sk or r (level 1) and with no table address from one either (level 2) gives the default signer's bytes -- every item of 2^18 with edge scalars salted in (zero-digit
     runs, tiny keys, out-of-range values: status bits), V1 and V2, pk computed and pk supplied -- and a sample of it the C oracle's"""
     import random
     n = 1 << 18
@@ -78,7 +79,7 @@ def test_uniform_schedule_signer_every_item_of_2p18(eng):
         for ver in (1, 2):
             eng.set_sign_uniform(False)
             want = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
-            eng.set_sign_uniform(True)
+            eng.set_sign_uniform(level)
             got = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
             for k in want:
                 assert np.array_equal(got[k], want[k]), (ver, k)

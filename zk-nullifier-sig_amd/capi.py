@@ -271,8 +271,9 @@ class Engine:
         self._chk(self._lib.plume_set_in_flight(self._ctx, int(k)), "plume_set_in_flight")
 
     def set_sign_uniform(self, on):
-        """the signer's uniform schedule (plume_set_sign_uniform): no branch on a digit of sk or r; outputs unchanged"""
-        self._chk(self._lib.plume_set_sign_uniform(self._ctx, 1 if on else 0), "plume_set_sign_uniform")
+        """the signer's uniform schedule (plume_set_sign_uniform): level 1 (or True) = no branch on a digit of sk or r, level 2 = and no table address derived from
+        one (every row of a window's table is read); outputs unchanged"""
+        self._chk(self._lib.plume_set_sign_uniform(self._ctx, int(on)), "plume_set_sign_uniform")
 
     def set_host_piece(self, n):
         """host-pointer calls: items per pipelined piece (upload / compute / download overlap across pieces)"""

@@ -109,9 +109,9 @@ struct Worker {
 // Round 4: each table is built by the first call that needs it (need_gtab: verify, verify_non_zk; need_gcomb: sign, SEC1-DER export, the aggregate check), so a
 // verify-only process never holds the comb, a sign-only one never the 1 GiB window table, and plume_init itself allocates neither.
 struct FixedTables {
-    DevBuf gtab, gcomb;
+    DevBuf gtab, gcomb, gscan;
     int refs = 0;
-    bool gtab_built = false, gcomb_built = false;
+    bool gtab_built = false, gcomb_built = false, gscan_built = false;
 };
 static std::mutex g_fixed_mutex;
 static std::map<int, FixedTables> g_fixed;
@@ -142,7 +142,7 @@ struct plume_ctx {
     plume_ctx* host_lane = nullptr;                                // ... the second lane of the host-pointer pipeline: a complete single-device context (workspace, streams), created on first use
     size_t tables_small_max = (size_t)3 << 15;                     // table stages of at most this many jobs take the small-batch path (Jacobian chain, one inversion: launch_tables_small)
     size_t ingest_split_max = (size_t)1 << 16;                     // verify calls (slices) of at most this many items run the ingest stage with two lanes per item (latency-bound there)
-    bool sign_uniform = false;                                     // plume_set_sign_uniform: the signer's uniform-schedule kernels
+    int sign_uniform = 0;                                          // plume_set_sign_uniform: the signer's uniform-schedule kernels (level 0, 1, 2)
     int host_lanes = 2;                                            // ... 1 = every piece on the context itself (rounds 1-3), 2 = pieces alternate between the context and host_lane
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
@@ -229,7 +229,7 @@ static void destroy_single(plume_ctx* ctx) {
         std::lock_guard<std::mutex> lk(g_fixed_mutex);
         if (--ctx->fixed->refs == 0) {
             (void)hipDeviceSynchronize();          // the tables are read by kernels on CALLER streams too: nothing may still be running when they go
-            ctx->fixed->gtab.release(); ctx->fixed->gcomb.release(); ctx->fixed->gtab_built = ctx->fixed->gcomb_built = false;
+            ctx->fixed->gtab.release(); ctx->fixed->gcomb.release(); ctx->fixed->gscan.release(); ctx->fixed->gtab_built = ctx->fixed->gcomb_built = ctx->fixed->gscan_built = false;
         }
         ctx->fixed = nullptr;
     }
@@ -262,7 +262,7 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_TABLES_SMALL_MAX")) { long v = std::atol(e); if (v >= 0) ctx->tables_small_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_INGEST_SPLIT_MAX")) { long v = std::atol(e); if (v >= 0) ctx->ingest_split_max = (size_t)v; }   // tuning knob (0: never)
-    if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::atoi(e) != 0;   // default of new contexts (plume_set_sign_uniform)
+    if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::min(2, std::max(0, std::atoi(e)));   // default of new contexts (plume_set_sign_uniform)
     if (const char* e = std::getenv("PLUME_HOST_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_lanes = v; }   // 1 = the one-lane host-pointer pipeline of rounds 1-3 (A/B)
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
@@ -280,7 +280,7 @@ static int init_single(plume_ctx* ctx) {
         HIPCHK(hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
     }
-    if (ctx->sink.ensure((size_t)(1 + PLUME_COMB_WINDOWS) * 2 * PLUME_FE_WORDS * 4 + 512)) return PLUME_ERR_HIP;
+    if (ctx->sink.ensure((size_t)PLUME_FIXED_BASES * 2 * PLUME_FE_WORDS * 4 + 512)) return PLUME_ERR_HIP;
     {
         std::lock_guard<std::mutex> lk(g_fixed_mutex);
         FixedTables& ft = g_fixed[ctx->device];
@@ -291,30 +291,35 @@ static int init_single(plume_ctx* ctx) {
 }
 // The generator's tables, built once per device and process on the first call that needs them, one entry per lane (k_fixed_bases + k_fixed_table), under the lock: contexts
 // that meet here side by side (plume_init_multi's shards, a second batch in flight) wait for the first one's build.  The build is synchronous (18 ms for both, once).
-static int need_fixed(plume_ctx* ctx, bool gtab, bool gcomb) {
+static int need_fixed(plume_ctx* ctx, bool gtab, bool gcomb, bool gscan = false) {
     std::lock_guard<std::mutex> lk(g_fixed_mutex);
     FixedTables& ft = *ctx->fixed;
-    const bool bt = gtab && !ft.gtab_built, bc = gcomb && !ft.gcomb_built;
-    if (!bt && !bc) return 0;
-    if ((bt && ft.gtab.ensure((size_t)PLUME_GTAB_WORDS * 4)) || (bc && ft.gcomb.ensure((size_t)PLUME_COMB_WORDS * 4))) {
+    const bool bt = gtab && !ft.gtab_built, bc = gcomb && !ft.gcomb_built, bs = gscan && !ft.gscan_built;
+    if (!bt && !bc && !bs) return 0;
+    if ((bt && ft.gtab.ensure((size_t)PLUME_GTAB_WORDS * 4)) || (bc && ft.gcomb.ensure((size_t)PLUME_COMB_WORDS * 4)) || (bs && ft.gscan.ensure((size_t)PLUME_GSCAN_WORDS * 4))) {
         if (bt) ft.gtab.release();
         if (bc) ft.gcomb.release();
+        if (bs) ft.gscan.release();
         return PLUME_ERR_HIP;
     }
-    launch_fixed_tables(bt ? ft.gtab.as<uint32_t>() : nullptr, bc ? ft.gcomb.as<uint32_t>() : nullptr, ctx->sink.as<uint32_t>(), ctx->stream);
+    launch_fixed_tables(bt ? ft.gtab.as<uint32_t>() : nullptr, bc ? ft.gcomb.as<uint32_t>() : nullptr, bs ? ft.gscan.as<uint32_t>() : nullptr, ctx->sink.as<uint32_t>(), ctx->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         if (bt) ft.gtab.release();
         if (bc) ft.gcomb.release();
+        if (bs) ft.gscan.release();
         return fail(PLUME_ERR_HIP, std::string("fixed tables: ") + hipGetErrorString(e));
     }
     if (bt) ft.gtab_built = true;
     if (bc) ft.gcomb_built = true;
+    if (bs) ft.gscan_built = true;
     return 0;
 }
 static int need_gtab(plume_ctx* ctx) { return need_fixed(ctx, true, false); }
 static int need_gcomb(plume_ctx* ctx) { return need_fixed(ctx, false, true); }
+// the signer's (and the SEC1-DER export's) table of G: the comb, or at level 2 of the uniform schedule the small scanned table
+static int need_sign_tables(plume_ctx* ctx) { return ctx->sign_uniform == 2 ? need_fixed(ctx, false, false, true) : need_gcomb(ctx); }
 
 static int check_device(int device_id) {
     if (device_id < 0) return fail(PLUME_ERR_ARG, "negative device id");
@@ -518,14 +523,16 @@ extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
 // The signer's uniform schedule (opt-in): the two kernels that walk the digits of sk and r (comb multiplication by G, windowed multiplication by H) then execute the same
 // instruction sequence whatever the digits are -- no zero-digit skip, no sign branch, no "accumulator is still the identity" case: every slot adds (a zero digit adds row 1 to
 // a copy that a masked select drops), the sign is a masked select, and the accumulator starts at an offset point that comes off at the end.  Outputs are bit-identical.
-// What remains secret-dependent: the ADDRESS of the table row a slot gathers (k256 scans its 16-entry table with conditional moves; here a scan would cost 8 / 131072 rows
-// per slot).  Cost on the MI355X: DESIGN.md §9.
+// Level 1 leaves one thing secret-dependent: the ADDRESS of the table row a slot gathers.  Level 2 removes that too, the way k256 does (it scans its 16-entry table with
+// conditional moves): every slot reads all 8 rows of its window's table and keeps one by masked selects (ld_tab_xy_scan), and because the 18-bit comb of G cannot be scanned
+// (131072 rows per window) the multiplications by G use a 52-window x 16-row table of their own (PLUME_GSCAN_*, 52 additions instead of 15).  Cost on the MI355X: DESIGN.md §9.
 extern "C" int plume_set_sign_uniform(plume_ctx* ctx, int on) {
     if (!ctx) return fail(PLUME_ERR_ARG, "plume_set_sign_uniform: null context");
-    ctx->sign_uniform = on != 0;
-    for (plume_ctx* sh : ctx->shards) sh->sign_uniform = on != 0;
-    for (plume_ctx* l : ctx->lanes) l->sign_uniform = on != 0;
-    if (ctx->host_lane) ctx->host_lane->sign_uniform = on != 0;
+    if (on < 0 || on > 2) return fail(PLUME_ERR_ARG, "plume_set_sign_uniform: the level is 0, 1 or 2");
+    ctx->sign_uniform = on;
+    for (plume_ctx* sh : ctx->shards) sh->sign_uniform = on;
+    for (plume_ctx* l : ctx->lanes) l->sign_uniform = on;
+    if (ctx->host_lane) ctx->host_lane->sign_uniform = on;
     return 0;
 }
 
@@ -685,7 +692,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
                        hipStream_t st, bool out33 = false) {
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
-    if (int rc = need_gcomb(ctx)) return rc;
+    if (int rc = need_sign_tables(ctx)) return rc;
     if (int rc = ws_acquire(ctx, st)) return rc;
     WsHold hold(ctx, st);
     const std::vector<size_t> cut = sub_batch_bounds(ctx, n);
@@ -716,7 +723,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
         a.gres = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.gresinf = ctx->resinf.as<uint8_t>() + 2 * lo; a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * 2 * lo;
         a.jobflags = ctx->jobflags.as<uint8_t>() + 2 * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo; a.pkaff = ctx->pkaff.as<uint32_t>() + (size_t)2 * PLUME_FE_WORDS * lo;
         a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * 2 * lo; a.hres = ctx->res2.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.hresinf = ctx->res2inf.as<uint8_t>() + 2 * lo;
-        a.gcomb = ctx->fixed->gcomb.as<uint32_t>(); a.uniform = ctx->sign_uniform ? 1 : 0;
+        a.gcomb = ctx->fixed->gcomb.as<uint32_t>(); a.gscan = ctx->fixed->gscan.as<uint32_t>(); a.uniform = ctx->sign_uniform;
         launch_sign_gmul(a, pre); if (!overlapped) t.stage("sign_gmul", st);
         launch_normalize(a.gres, a.gresinf, 2 * cnt, pre); if (!overlapped) t.stage("to_affine_g", st);
         launch_sign_h2c(a, pre); if (!overlapped) t.stage("sign_h2c", st);
@@ -873,8 +880,8 @@ static int der_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t*
     if (n && (!scalars || !der109 || !status)) return fail(PLUME_ERR_ARG, "null array");
     if (n > 0xFFFFFFF0u) return fail(PLUME_ERR_ARG, "n too large");
     if (n == 0) return 0;
-    if (int rc = need_gcomb(ctx)) return rc;
-    DerArgs a; a.n = (uint32_t)n; a.scalars = scalars; a.der = der109; a.status = status; a.gcomb = ctx->fixed->gcomb.as<uint32_t>(); a.uniform = ctx->sign_uniform ? 1 : 0;
+    if (int rc = need_sign_tables(ctx)) return rc;
+    DerArgs a; a.n = (uint32_t)n; a.scalars = scalars; a.der = der109; a.status = status; a.gcomb = ctx->fixed->gcomb.as<uint32_t>(); a.gscan = ctx->fixed->gscan.as<uint32_t>(); a.uniform = ctx->sign_uniform;
     ctx->timer.begin(st);
     launch_scalars_der(a, st); ctx->timer.stage("scalars_to_sec1_der", st);
     HIPCHK(hipGetLastError());

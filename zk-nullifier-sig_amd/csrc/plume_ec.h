@@ -361,6 +361,33 @@ PLUME_HD void ld_tab_xy(fe& x, fe& y, const uint32_t* e, bool lambda_half) {
     x.v[8] = lambda_half ? e[26] : e[24];
     y.v[8] = e[25];
 }
+// The same row WITHOUT a digit-dependent address (the signer's uniform schedule, level 2): all eight rows of the window's table are read, row `ad` (1..8) is kept by
+// masked selects: 18 selects and 128 B of reads per row beside an addition of ~1400 instructions.
+template <int ROWS = PLUME_TAB_ENTRIES>
+PLUME_HD void ld_tab_xy_scan(fe& x, fe& y, const uint32_t* tab, int ad, bool lambda_half) {
+    ld_tab_xy(x, y, tab, lambda_half);
+    PLUME_NOUNROLL for (int e = 1; e < ROWS; e++) {
+        fe rx, ry;
+        ld_tab_xy(rx, ry, tab + (size_t)e * PLUME_TAB_ENTRY_WORDS, lambda_half);
+        const bool take = ad == e + 1;
+        fe_cmov(x, rx, take); fe_cmov(y, ry, take);
+    }
+}
+// ... and for the two slots that share a table (P with digit ad_a, lambda P with digit ad_b) in ONE pass over its rows: a per-item table is 1 KiB that no cache holds
+// between two visits, so the scan is what the level-2 chain pays in HBM traffic
+PLUME_HD void ld_tab_xy_scan2(fe& xa, fe& ya, fe& xb, fe& yb, const uint32_t* tab, int ad_a, int ad_b) {
+    ld_tab_xy(xa, ya, tab, false);
+    ld_tab_xy(xb, yb, tab, true);
+    PLUME_NOUNROLL for (int e = 1; e < PLUME_TAB_ENTRIES; e++) {
+        const uint32_t* row = tab + (size_t)e * PLUME_TAB_ENTRY_WORDS;
+        fe rx, ry, rb;
+        ld_tab_xy(rx, ry, row, false);
+        ld_tab_xy(rb, ry, row, true);
+        const bool ta = ad_a == e + 1, tb = ad_b == e + 1;
+        fe_cmov(xa, rx, ta); fe_cmov(ya, ry, ta);
+        fe_cmov(xb, rb, tb); fe_cmov(yb, ry, tb);
+    }
+}
 PLUME_HD void st_tab_entry(uint32_t* e, const fe& x, const fe& y, const fe& bx) {   // (non-temporal stores here: 3.6x slower, they defeat write combining)
     PLUME_UNROLL for (int i = 0; i < 8; i++) { e[i] = x.v[i]; e[8 + i] = y.v[i]; e[16 + i] = bx.v[i]; }
     e[24] = x.v[8]; e[25] = y.v[8]; e[26] = bx.v[8]; e[27] = 0;
@@ -847,8 +874,9 @@ PLUME_HD void normalize_points(uint32_t* pts, const uint8_t* inf, size_t npts, s
 // (rust-k256/src/randomizedsigner.rs:51,53).
 #define PLUME_COMB_WINDOWS ((256 + PLUME_COMB_W) / PLUME_COMB_W)     // windows covering 257 bits
 #define PLUME_COMB_WORDS (PLUME_COMB_WINDOWS * PLUME_COMB_WINDOW_WORDS)
-PLUME_HD int booth_digit_comb(const uint32_t m[8], int k) {   // k is a runtime loop index here (no unrolling)
-    const int W = PLUME_COMB_W, lo = W * k - 1;
+template <int W>
+PLUME_HD int booth_digit_sc(const uint32_t m[8], int k) {   // k is a runtime loop index here (no unrolling)
+    const int lo = W * k - 1;
     const uint32_t mask = (1u << (W + 1)) - 1u;
     uint32_t u;
     if (lo < 0) {
@@ -861,6 +889,7 @@ PLUME_HD int booth_digit_comb(const uint32_t m[8], int k) {   // k is a runtime 
     }
     return (int)(u & 1) + (int)((u >> 1) & ((1u << (W - 1)) - 1u)) - (int)((u >> W) << (W - 1));
 }
+PLUME_HD int booth_digit_comb(const uint32_t m[8], int k) { return booth_digit_sc<PLUME_COMB_W>(m, k); }
 template <bool CHECKED>
 PLUME_HD void comb_mul_g_impl(jac& acc, const sc& k, const uint32_t* comb) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
@@ -894,6 +923,35 @@ PLUME_HD void comb_mul_g_uniform(jac& acc, const sc& k, const uint32_t* comb) {
     if (fe_is_zero(acc.z)) {                                    // met p == +-q (probability ~2^-250 for honest keys; crafted tiny keys cannot reach the offset point either)
         PLUME_COUNT_FALLBACK();
         comb_mul_g_uniform_impl<true>(acc, k, comb);
+    }
+    jac_madd<true>(acc, fe_off_x(), fe_off_neg_y());            // - B
+}
+// Level 2 of the uniform schedule: no digit-dependent ADDRESS either.  The big comb cannot be scanned (2^17 rows per window), so this form has its own small table:
+// gscan[i][e] = (e + 1) * 2^(W i) * G, W = 5: 52 windows x 16 rows (104 KiB; every lane reads the same addresses, so the rows come through the scalar cache), 52 uniform
+// additions, each after a scan of its window's 16 rows.  2^20 signatures, both multiplications: W = 4 (65 x 8) 7.34 ms, W = 5 6.98 ms, W = 6 (43 x 32) 7.42 ms
+// (tests/gpu_debug/gscan_width.py; the comb's 15 additions at level 1: 1.49 ms).
+#ifndef PLUME_GSCAN_W
+#define PLUME_GSCAN_W 5
+#endif
+#define PLUME_GSCAN_ENTRIES (1 << (PLUME_GSCAN_W - 1))
+#define PLUME_GSCAN_WINDOWS ((256 + PLUME_GSCAN_W) / PLUME_GSCAN_W)
+#define PLUME_GSCAN_WORDS (PLUME_GSCAN_WINDOWS * PLUME_GSCAN_ENTRIES * PLUME_TAB_ENTRY_WORDS)
+template <bool CHECKED>
+PLUME_HD void comb_mul_g_scan_impl(jac& acc, const sc& k, const uint32_t* gscan) {
+    acc.x = fe_off_x(); acc.y = fe_off_y(); acc.z = fe_small(1); acc.inf = 0;
+    PLUME_NOUNROLL for (int i = 0; i < PLUME_GSCAN_WINDOWS; i++) {
+        const int d = booth_digit_sc<PLUME_GSCAN_W>(k.v, i);
+        const int ad = (d < 0 ? -d : d) + (d == 0 ? 1 : 0);
+        fe qx, qy;
+        ld_tab_xy_scan<PLUME_GSCAN_ENTRIES>(qx, qy, gscan + (size_t)i * PLUME_GSCAN_ENTRIES * PLUME_TAB_ENTRY_WORDS, ad, false);
+        jac_madd_uniform<CHECKED>(acc, qx, qy, d);
+    }
+}
+PLUME_HD void comb_mul_g_scan(jac& acc, const sc& k, const uint32_t* gscan) {
+    comb_mul_g_scan_impl<false>(acc, k, gscan);
+    if (fe_is_zero(acc.z)) {
+        PLUME_COUNT_FALLBACK();
+        comb_mul_g_scan_impl<true>(acc, k, gscan);
     }
     jac_madd<true>(acc, fe_off_x(), fe_off_neg_y());            // - B
 }
@@ -965,12 +1023,23 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
 }
 // The chain with the UNIFORM schedule (opt-in signer): no slot is skipped and no branch depends on a digit.  `live` false (the table's base was the identity / invalid: a
 // public fact) turns every digit into 0.  Starts at the offset point B; the caller takes 2^(4 (NDIG-1)) B = 2^128 B off again.
-template <bool CHECKED, int ND>
+template <bool CHECKED, int ND, bool SCAN>
 PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, bool live, int nslots, const int8_t* dig, uint32_t stride) {
     acc.x = fe_off_x(); acc.y = fe_off_y(); acc.z = fe_small(1); acc.inf = 0;
     PLUME_NOUNROLL for (int i = ND - 1; i >= 0; i--) {
         if (i != ND - 1) {
             PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl_neg(acc);      // an even number of sign-flipping doublings
+        }
+        if (SCAN) {                                                         // level 2: slots 2t, 2t + 1 (P and lambda P of table t) fetched by one scan of the table's rows
+            PLUME_NOUNROLL for (int t = 0; 2 * t < nslots; t++) {
+                int da = dig[(uint32_t)((2 * t) * ND + i) * stride], db = dig[(uint32_t)((2 * t + 1) * ND + i) * stride];
+                da = live ? da : 0; db = live ? db : 0;
+                fe xa, ya, xb, yb;
+                ld_tab_xy_scan2(xa, ya, xb, yb, t ? tab1 : tab0, (da < 0 ? -da : da) + (da == 0 ? 1 : 0), (db < 0 ? -db : db) + (db == 0 ? 1 : 0));
+                jac_madd_uniform<CHECKED>(acc, xa, ya, da);
+                jac_madd_uniform<CHECKED>(acc, xb, yb, db);
+            }
+            continue;
         }
         PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
             const uint32_t* tab = (s & 2) ? tab1 : tab0;
@@ -985,12 +1054,12 @@ PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab0, const uint32_
 }
 static_assert(PLUME_WBITS * (PLUME_NDIG - 1) == 128 && PLUME_WBITS * (PLUME_NDIG64 - 1) == 64, "the uniform chains' offset constants are -(2^128 B) and -(2^64 B)");
 static_assert(PLUME_WBITS % 2 == 0, "the window loops double with jac_dbl_neg: an even count per window");
-template <int ND>
+template <int ND, bool SCAN = false>
 PLUME_HD void msm_run_uniform(jac& acc, const uint32_t* tab0, const uint32_t* tab1, bool live, int nslots, const int8_t* dig, uint32_t stride) {
-    msm_run_uniform_impl<false, ND>(acc, tab0, tab1, live, nslots, dig, stride);
+    msm_run_uniform_impl<false, ND, SCAN>(acc, tab0, tab1, live, nslots, dig, stride);
     if (fe_is_zero(acc.z)) {
         PLUME_COUNT_FALLBACK();
-        msm_run_uniform_impl<true, ND>(acc, tab0, tab1, live, nslots, dig, stride);
+        msm_run_uniform_impl<true, ND, SCAN>(acc, tab0, tab1, live, nslots, dig, stride);
     }
     const fe cx = ND == PLUME_NDIG64 ? fe_off_c64_x() : fe_off_c128_x(), cy = ND == PLUME_NDIG64 ? fe_off_c64_y() : fe_off_c128_y();     // - 2^(4 (ND - 1)) B
     if (!acc.inf) jac_madd<true>(acc, cx, cy);

@@ -250,20 +250,24 @@ __global__ PLUME_MSM_BOUNDS void k_sign_hmul(SignArgs a) {
     wipe_digits<4 * PLUME_NDIG64>(s_dig);   // the rows are digits of sk and r: nothing derived from a secret stays in LDS when the workgroup retires
 }
 
-// the uniform-schedule forms of the two kernels that walk secret digits (plume_set_sign_uniform): same grids, same outputs
+// the uniform-schedule forms of the two kernels that walk secret digits (plume_set_sign_uniform; LEVEL 1: no branch on a digit, LEVEL 2: no address from a digit
+// either): same grids, same outputs
+template <int LEVEL>
 __global__ PLUME_MSM_BOUNDS void k_sign_hmul_uniform(SignArgs a) {
     __shared__ int8_t s_dig[4 * PLUME_NDIG64 * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
-    const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
-    const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
-    if (i < a.n) sign_hmul<true>(a, i, which, s_dig + threadIdx.x, kBlock);
+    // level 2: the two tasks of an item (sk * H, r * H: the same two tables, every row of them read at every window) sit in ADJACENT lanes, so one fetch serves both
+    const uint32_t which = LEVEL == 2 ? (threadIdx.x & 1u) : blockIdx.x >= nb ? 1u : 0u;
+    const uint32_t i = LEVEL == 2 ? (blockIdx.x * kBlock + threadIdx.x) >> 1 : (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
+    if (i < a.n) sign_hmul<LEVEL>(a, i, which, s_dig + threadIdx.x, kBlock);
     wipe_digits<4 * PLUME_NDIG64>(s_dig);
 }
+template <int LEVEL>
 __global__ PLUME_MSM_BOUNDS void k_sign_gmul_uniform(SignArgs a) {
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
-    if (i < a.n) sign_gmul<true>(a, i, which);
+    if (i < a.n) sign_gmul<LEVEL>(a, i, which);
 }
 
 __global__ PLUME_FINAL_BOUNDS void k_sign_final(SignArgs a) {
@@ -474,13 +478,15 @@ void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {
 }
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_finalize, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_gmul(const SignArgs& a, hipStream_t st) {
-    if (a.uniform) hipLaunchKernelGGL(k_sign_gmul_uniform, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    if (a.uniform == 2) hipLaunchKernelGGL(k_sign_gmul_uniform<2>, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    else if (a.uniform) hipLaunchKernelGGL(k_sign_gmul_uniform<1>, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
     else hipLaunchKernelGGL(k_sign_gmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
 }
 void launch_sign_h2c(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_h2c, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_hdbl(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_hdbl, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_hmul(const SignArgs& a, hipStream_t st) {
-    if (a.uniform) hipLaunchKernelGGL(k_sign_hmul_uniform, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    if (a.uniform == 2) hipLaunchKernelGGL(k_sign_hmul_uniform<2>, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    else if (a.uniform) hipLaunchKernelGGL(k_sign_hmul_uniform<1>, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
     else hipLaunchKernelGGL(k_sign_hmul, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
 }
 void launch_sign_final(const SignArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_sign_final, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
@@ -495,9 +501,14 @@ void launch_scalars_der(const DerArgs& a, hipStream_t st) { hipLaunchKernelGGL(k
 void launch_registers_from_be(uint8_t* out, const uint8_t* in, size_t nvalues, hipStream_t st) {
     hipLaunchKernelGGL(k_registers_from_be, dim3(nblocks(nvalues)), dim3(kBlock), 0, st, out, in, nvalues);
 }
-// gtab / gcomb may be null: only the table asked for is built (plume_capi.hip builds each on its first use)
-void launch_fixed_tables(uint32_t* gtab, uint32_t* gcomb, uint32_t* base18 /* (1 + PLUME_COMB_WINDOWS) x 18 words */, hipStream_t st) {
+// gtab / gcomb / gscan may be null: only the table asked for is built (plume_capi.hip builds each on its first use)
+void launch_fixed_tables(uint32_t* gtab, uint32_t* gcomb, uint32_t* gscan, uint32_t* base18 /* PLUME_FIXED_BASES x 18 words */, hipStream_t st) {
     uint32_t* cb = base18 + 2 * PLUME_FE_WORDS;
+    uint32_t* sb = cb + (size_t)PLUME_COMB_WINDOWS * 2 * PLUME_FE_WORDS;
+    if (gscan) {
+        hipLaunchKernelGGL(k_fixed_bases, dim3(1), dim3(kBlock), 0, st, sb, (uint32_t)PLUME_GSCAN_WINDOWS, (uint32_t)PLUME_GSCAN_W);
+        hipLaunchKernelGGL(k_fixed_table, dim3(nblocks((size_t)PLUME_GSCAN_ENTRIES * PLUME_GSCAN_WINDOWS)), dim3(kBlock), 0, st, gscan, sb, (uint32_t)PLUME_GSCAN_ENTRIES, (uint32_t)PLUME_GSCAN_WINDOWS);
+    }
     if (gtab) {
         hipLaunchKernelGGL(k_fixed_bases, dim3(1), dim3(kBlock), 0, st, base18, 1u, 0u);
         hipLaunchKernelGGL(k_fixed_table, dim3(nblocks((size_t)PLUME_GTAB_ENTRIES)), dim3(kBlock), 0, st, gtab, base18, (uint32_t)PLUME_GTAB_ENTRIES, 1u);

@@ -31,7 +31,8 @@ void launch_h2c_intermediates(const H2cInterArgs& a, hipStream_t st);
 void launch_scalars_der(const DerArgs& a, hipStream_t st);
 void launch_registers_from_be(uint8_t* out, const uint8_t* in, size_t nvalues, hipStream_t st);
 // the generator's fixed tables (once per context): gtab = (1..2^(GW-1)) * G, gcomb = the signer's doubling-free comb; base18: scratch for the window bases
-void launch_fixed_tables(uint32_t* gtab, uint32_t* gcomb, uint32_t* base18 /* (1 + PLUME_COMB_WINDOWS) x 18 words */, hipStream_t st);
+#define PLUME_FIXED_BASES (1 + PLUME_COMB_WINDOWS + PLUME_GSCAN_WINDOWS)
+void launch_fixed_tables(uint32_t* gtab, uint32_t* gcomb, uint32_t* gscan, uint32_t* base18 /* PLUME_FIXED_BASES x 18 words */, hipStream_t st);
 size_t dedup_blockcnt_bytes(size_t n);                    // size of DedupArgs::blockcnt
 void launch_dedup(const DedupArgs& a, hipStream_t st);   // clear, insert, mark, sum (plume_dedup.h)
 void launch_microbench(int kind, int iters, uint32_t* sink, int blocks, hipStream_t st);

@@ -449,7 +449,8 @@ struct SignArgs {
     uint32_t* tab;                       // 2n tables, same order
     uint32_t* hres;  uint8_t* hresinf;   // 2n tasks: sk*H, r*H
     const uint32_t* gcomb;               // fixed-base comb of G (PLUME_COMB_WORDS)
-    int uniform;                         // 1: the uniform-schedule kernels (plume_set_sign_uniform): no branch on a secret digit
+    const uint32_t* gscan;               // level 2 only: the small scanned table of G (PLUME_GSCAN_WORDS)
+    int uniform;                         // plume_set_sign_uniform: 1 = the uniform-schedule kernels (no branch on a secret digit), 2 = and no table address from a secret digit
 };
 
 // scalars reduced mod n for the arithmetic, status bit if out of range (the Rust types cannot hold such values)
@@ -463,7 +464,7 @@ PLUME_HD uint32_t load_scalar_reduced(sc& k, const uint8_t* p) {
 // k * H with the tables of H (tab0) and 2^64 H (tab1): k = k1 + k2 lambda (GLV), each 128-bit half = lo + hi 2^64 -- four 64-bit quarters on H, lambda H, 2^64 H,
 // lambda 2^64 H, one chain of 64 doublings (round 4; rounds 1-3: two halves, 128 doublings.  The 64 doublings that make 2^64 H are spent ONCE per item and serve both of
 // its multiplications, sk * H and r * H: sign_hdbl).
-template <bool UNIFORM = false>
+template <int UNIFORM = 0>
 PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, bool live, uint32_t* res, uint8_t* resinf, int8_t* dig, uint32_t stride) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
     sc k;
@@ -477,7 +478,8 @@ PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, bool li
     const uint32_t* t0 = a.tab + (size_t)item * PLUME_TAB_WORDS;                      // (every job has a table: a dummy one when its base was no usable point)
     const uint32_t* t1 = a.tab + ((size_t)a.n + item) * PLUME_TAB_WORDS;
     jac acc;
-    if (UNIFORM) msm_run_uniform<PLUME_NDIG64>(acc, t0, t1, live, 4, dig, stride);
+    if (UNIFORM == 2) msm_run_uniform<PLUME_NDIG64, true>(acc, t0, t1, live, 4, dig, stride);
+    else if (UNIFORM == 1) msm_run_uniform<PLUME_NDIG64>(acc, t0, t1, live, 4, dig, stride);
     else msm_run<PLUME_NDIG64>(acc, live ? t0 : nullptr, live ? t1 : nullptr, 4, dig, stride, false);
     st_jac_soa(res, nt, t, acc);
     resinf[t] = (uint8_t)acc.inf;
@@ -497,14 +499,16 @@ PLUME_HD void sign_hdbl(const SignArgs& a, uint32_t i) {
     a.jobflags[(size_t)a.n + i] = f;
 }
 // task t = 2*item + which: sk*G (which 0) or r*G (which 1) by the doubling-free comb
-template <bool UNIFORM = false>
+template <int UNIFORM = 0>
 PLUME_HD void sign_gmul(const SignArgs& a, uint32_t item, uint32_t which) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
     if (which == 0 && a.pk_in) { a.gresinf[t] = 1; return; }   // pk supplied: sk*G not needed (flagged so the affine conversion skips it)
     sc k;
     (void)load_scalar_reduced(k, (which ? a.r : a.sk) + 32 * (size_t)item);
     jac acc;
-    if (UNIFORM) comb_mul_g_uniform(acc, k, a.gcomb); else comb_mul_g(acc, k, a.gcomb);
+    if (UNIFORM == 2) comb_mul_g_scan(acc, k, a.gscan);
+    else if (UNIFORM == 1) comb_mul_g_uniform(acc, k, a.gcomb);
+    else comb_mul_g(acc, k, a.gcomb);
     st_jac_soa(a.gres, nt, t, acc);
     a.gresinf[t] = (uint8_t)acc.inf;
 }
@@ -538,7 +542,7 @@ PLUME_HD void sign_h2c(const SignArgs& a, uint32_t i) {
     a.jobflags[i] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
     a.itemflags[i] = (uint8_t)(st | (pinf ? 0x80u : 0u));
 }
-template <bool UNIFORM = false>
+template <int UNIFORM = 0>
 PLUME_HD void sign_hmul(const SignArgs& a, uint32_t item, uint32_t which, int8_t* dig, uint32_t stride) {
     sign_mul<UNIFORM>(a, item, which, job_state(a.jobflags[item]) == PLUME_JOB_OK, a.hres, a.hresinf, dig, stride);
 }
@@ -766,7 +770,8 @@ struct DerArgs {
     uint8_t* der;             // n x 109
     uint8_t* status;          // n
     const uint32_t* gcomb;
-    int uniform;              // 1: the comb's uniform schedule (plume_set_sign_uniform): the scalars are secret keys
+    const uint32_t* gscan;    // level 2 only (PLUME_GSCAN_WORDS)
+    int uniform;              // the comb's schedule (plume_set_sign_uniform: 0, 1, 2): the scalars are secret keys
 };
 PLUME_HD void scalar_to_sec1_der(const DerArgs& a, uint32_t i) {
     sc k;
@@ -777,7 +782,9 @@ PLUME_HD void scalar_to_sec1_der(const DerArgs& a, uint32_t i) {
         return;
     }
     jac p;
-    if (a.uniform) comb_mul_g_uniform(p, k, a.gcomb); else comb_mul_g(p, k, a.gcomb);     // never the identity for k in [1, n-1]
+    if (a.uniform == 2) comb_mul_g_scan(p, k, a.gscan);
+    else if (a.uniform) comb_mul_g_uniform(p, k, a.gcomb);
+    else comb_mul_g(p, k, a.gcomb);     // never the identity for k in [1, n-1]
     fe zi, zi2, x, y;
     fe_inv(zi, p.z); fe_sqr(zi2, zi); fe_mul(x, p.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y, p.y, zi2);
     fe_normalize(x); fe_normalize(y);
