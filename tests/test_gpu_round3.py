@@ -299,7 +299,9 @@ def test_bench_multi_ctx_form_and_config3():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
     d = json.loads(lines[0])
-    assert d["unit"] == "signs/s" and "configs[2]" in d["config"]["workload"] and d["roofline"]["kernel"] == "k_sign_hmul" and list(d["stage_ms"])[0] == "sign_gmul"
+    assert d["unit"] == "signs/s" and "configs[2]" in d["config"]["workload"] and d["roofline"]["kernel"] == "k_sign_hmul + k_sign_hdbl" and list(d["stage_ms"])[0] == "sign_gmul"
+    parts = d["roofline"]["kernel_ms_parts"]                       # the signer's roofline is priced on both launches of the accounted sk*H, r*H (64 of the 128 doublings moved into k_sign_hdbl)
+    assert abs(parts["sign_hmul"] + parts["sign_hdbl"] - d["roofline"]["kernel_ms"]) < 1e-3
 
 
 # ------------------------------------------------------------------------------------------- circuit hints, the unpinned rest
