@@ -96,7 +96,7 @@ int plume_set_in_flight(plume_ctx* ctx, int batches);
  *   level 2: level 1, and no address is derived from a digit: every slot reads all 8 rows of its window's table and keeps one by masked selects (what k256 does with its
  *            16-entry tables); the multiplications by G then use a 52-window x 16-row table instead of the 18-bit comb (52 additions instead of 15).
  * Outputs are bit-identical at every level.  Returns PLUME_ERR_ARG for a level outside 0..2.  Costs: DESIGN.md §9. */
-int plume_set_sign_uniform(plume_ctx* ctx, int on);
+int plume_set_sign_uniform(plume_ctx* ctx, int level);
 /* Environment knobs read when a context is created (tuning and A/B runs; results never depend on them):
  *   PLUME_SUB_BATCHES, PLUME_SERIAL, PLUME_OVERLAP_MIN   sub-batch overlap of the device-resident calls (plume_set_sub_batches)
  *   PLUME_HOST_PIECE, PLUME_HOST_FIRST_PIECE, PLUME_HOST_TAIL_PIECE, PLUME_HOST_REGISTER_MIN, PLUME_HOST_LANES (1 | 2), PLUME_HOST_SCHEDULE (explicit piece list, read per call)

@@ -97,6 +97,28 @@ def test_uniform_schedule_signer_every_item_of_2p18(eng, level):
         eng.set_sign_uniform(False)
 
 
+def test_sec1_der_export_follows_the_uniform_levels(eng):
+    """the SEC1-DER export multiplies SECRET keys by G: plume_set_sign_uniform covers it (level 1: the comb's uniform schedule, level 2: the scanned table); records identical,
+    the level is rejected outside 0..2 and the default is restored"""
+    b = synth.sign_inputs(1 << 14, start=77_000)
+    sk = b["sk"].copy()
+    N = synth.N
+    for k, v in enumerate([1, 2, 3, 15, 16, 17, 2**31, 2**32, 2**64 - 1, 2**128, 2**255, N - 1, N - 2, N // 2, (N + 1) // 2]):
+        sk[k * 7] = np.frombuffer(v.to_bytes(32, "big"), dtype=np.uint8)
+    try:
+        eng.set_sign_uniform(0)
+        want, st0 = eng.scalars_to_sec1_der_batch(sk)
+        assert not st0.any()
+        for level in (1, 2):
+            eng.set_sign_uniform(level)
+            got, st = eng.scalars_to_sec1_der_batch(sk)
+            assert np.array_equal(got, want) and np.array_equal(st, st0), level
+        with pytest.raises(Exception):
+            eng.set_sign_uniform(3)
+    finally:
+        eng.set_sign_uniform(0)
+
+
 _LANES = r"""
 import json, os, sys
 import numpy as np

@@ -526,13 +526,13 @@ extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
 // Level 1 leaves one thing secret-dependent: the ADDRESS of the table row a slot gathers.  Level 2 removes that too, the way k256 does (it scans its 16-entry table with
 // conditional moves): every slot reads all 8 rows of its window's table and keeps one by masked selects (ld_tab_xy_scan), and because the 18-bit comb of G cannot be scanned
 // (131072 rows per window) the multiplications by G use a 52-window x 16-row table of their own (PLUME_GSCAN_*, 52 additions instead of 15).  Cost on the MI355X: DESIGN.md §9.
-extern "C" int plume_set_sign_uniform(plume_ctx* ctx, int on) {
+extern "C" int plume_set_sign_uniform(plume_ctx* ctx, int level) {
     if (!ctx) return fail(PLUME_ERR_ARG, "plume_set_sign_uniform: null context");
-    if (on < 0 || on > 2) return fail(PLUME_ERR_ARG, "plume_set_sign_uniform: the level is 0, 1 or 2");
-    ctx->sign_uniform = on;
-    for (plume_ctx* sh : ctx->shards) sh->sign_uniform = on;
-    for (plume_ctx* l : ctx->lanes) l->sign_uniform = on;
-    if (ctx->host_lane) ctx->host_lane->sign_uniform = on;
+    if (level < 0 || level > 2) return fail(PLUME_ERR_ARG, "plume_set_sign_uniform: the level is 0, 1 or 2");
+    ctx->sign_uniform = level;
+    for (plume_ctx* sh : ctx->shards) sh->sign_uniform = level;
+    for (plume_ctx* l : ctx->lanes) l->sign_uniform = level;
+    if (ctx->host_lane) ctx->host_lane->sign_uniform = level;
     return 0;
 }
 

@@ -930,9 +930,7 @@ PLUME_HD void comb_mul_g_uniform(jac& acc, const sc& k, const uint32_t* comb) {
 // gscan[i][e] = (e + 1) * 2^(W i) * G, W = 5: 52 windows x 16 rows (104 KiB; every lane reads the same addresses, so the rows come through the scalar cache), 52 uniform
 // additions, each after a scan of its window's 16 rows.  2^20 signatures, both multiplications: W = 4 (65 x 8) 7.34 ms, W = 5 6.98 ms, W = 6 (43 x 32) 7.42 ms
 // (tests/gpu_debug/gscan_width.py; the comb's 15 additions at level 1: 1.49 ms).
-#ifndef PLUME_GSCAN_W
 #define PLUME_GSCAN_W 5
-#endif
 #define PLUME_GSCAN_ENTRIES (1 << (PLUME_GSCAN_W - 1))
 #define PLUME_GSCAN_WINDOWS ((256 + PLUME_GSCAN_W) / PLUME_GSCAN_W)
 #define PLUME_GSCAN_WORDS (PLUME_GSCAN_WINDOWS * PLUME_GSCAN_ENTRIES * PLUME_TAB_ENTRY_WORDS)
