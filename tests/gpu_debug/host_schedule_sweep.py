@@ -28,8 +28,8 @@ def best(fn, reps=7):
 
 
 K = 1024
-for sched in [[64, 192, 512, 256], [64, 128, 192, 320, 320], [64, 96, 160, 256, 448], [64, 128, 256, 288, 288], [32, 64, 128, 192, 288, 320], [64, 128, 192, 256, 384], [48, 96, 176, 320, 384],
-              [64, 128, 192, 256, 256, 128], [64, 128, 224, 304, 304], [96, 160, 256, 256, 256], [64, 112, 176, 288, 384], [64, 192, 512, 256]]:
+for sched in [[64, 192, 512, 256], [16, 48, 128, 320, 512], [16, 64, 192, 448, 304], [32, 96, 256, 384, 256], [32, 96, 288, 608], [64, 192, 768], [128, 384, 512], [32, 64, 128, 288, 512],
+              [64, 192, 384, 256, 128], [64, 192, 448, 256, 64], [16, 32, 64, 192, 464, 256], [64, 192, 512, 256]]:
     os.environ["PLUME_HOST_SCHEDULE"] = ",".join(str(x * K) for x in sched)
     tv = best(lambda: e.verify_batch(1, vp["msgs"], pin["off"], vp["pk"], vp["nullifier"], vp["c"], vp["s"], vp["r_point"], vp["hashed_to_curve_r"], out=okp))
     assert np.array_equal(okp, want)

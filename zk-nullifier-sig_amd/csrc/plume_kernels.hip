@@ -127,33 +127,37 @@ struct WaveRowSink {
 #define PLUME_TABPASS_WAVES_AB 3   // (r03 A/B on one box, table stage of a 2^20 verify: 4/3 waves 1.93 ms, 3/3 1.86, 3/2 1.83, 4/4 2.32; the one-kernel form 1.89)
 #define PLUME_TABPASS_WAVES_CD 2
 #define PLUME_TABINV_K 8          // lane products per inversion
+// Workgroups of 128 lanes (round 4; 256 before): a pass that stages rows needs 17 KiB of LDS, which fits BESIDE a compute unit's four resident workgroups of the multi-scalar
+// kernel (4 x 33 KiB of digit rows leave 28 KiB of the 160).  With 34 KiB per workgroup the table passes of a second batch (another lane of the context, another piece of a
+// host-pointer call) could not start before the first batch's multi-scalar kernel had drained: rocprofv3 showed a 0.3 ms pass stretched over the other batch's whole 8 ms kernel.
+constexpr int kTabBlock = 128;
 template <int PASS>
 __device__ __forceinline__ void tab_pass_body(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, uint8_t* guardf, uint4* s_rows, uint32_t** s_ptrs) {
-    const size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x, nl = (size_t)gridDim.x * kBlock;
+    const size_t lane = (size_t)blockIdx.x * kTabBlock + threadIdx.x, nl = (size_t)gridDim.x * kTabBlock;
     const size_t j0 = lane * (size_t)L;
     const int cnt = j0 < njobs ? (int)((njobs - j0) < (size_t)L ? (njobs - j0) : (size_t)L) : 0;
     WaveRowSink sink;
     sink.rows = s_rows + (threadIdx.x & ~63u) * 8;
     sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
     sink.full = __ballot(cnt == L) == ~0ull;
-    uint32_t* myscr = scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kBlock);
+    uint32_t* myscr = scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kTabBlock);
     fe c;
     bool g = false;
     if (PASS > 0) { ld_fe_soa(c, carry, nl, lane); g = guardf[lane] != 0; }
-    if (PASS == 0) tab_pass_a<WaveRowSink>(bases, jobflags, njobs, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g);
-    else if (PASS == 1) tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
-    else if (PASS == 2) tab_pass_c(tab, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
-    else if (PASS == 3) tab_pass_d(tab, j0, cnt, myscr, (size_t)kBlock, threadIdx.x, c, g, sink);
+    if (PASS == 0) tab_pass_a<WaveRowSink>(bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, g);
+    else if (PASS == 1) tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, g, sink);
+    else if (PASS == 2) tab_pass_c(tab, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, g, sink);
+    else if (PASS == 3) tab_pass_d(tab, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, g, sink);
     if (PASS < 3) { st_fe_soa(carry, nl, lane, c); guardf[lane] = g ? 1 : 0; }
 }
-__global__ __launch_bounds__(kBlock, PLUME_TABPASS_WAVES_AB) void k_tab_pass_a(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, uint8_t* guardf) {
+__global__ __launch_bounds__(kTabBlock, PLUME_TABPASS_WAVES_AB) void k_tab_pass_a(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, uint8_t* guardf) {
     tab_pass_body<0>(tab, bases, jobflags, njobs, L, scr, carry, guardf, nullptr, nullptr);
 }
 #define PLUME_TAB_PASS_KERNEL(NAME, PASS, WAVES)                                                                                                                              \
-    __global__ __launch_bounds__(kBlock, WAVES) void NAME(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, \
+    __global__ __launch_bounds__(kTabBlock, WAVES) void NAME(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, \
                                                           uint8_t* guardf) {                                                                                                  \
-        __shared__ uint4 s_rows[kBlock * 8];                                                                                                                                  \
-        __shared__ uint32_t* s_ptrs[kBlock];                                                                                                                                  \
+        __shared__ uint4 s_rows[kTabBlock * 8];                                                                                                                                  \
+        __shared__ uint32_t* s_ptrs[kTabBlock];                                                                                                                                  \
         tab_pass_body<PASS>(tab, bases, jobflags, njobs, L, scr, carry, guardf, s_rows, s_ptrs);                                                                              \
     }
 PLUME_TAB_PASS_KERNEL(k_tab_pass_b, 1, PLUME_TABPASS_WAVES_AB)
@@ -209,12 +213,14 @@ __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
 }
 // the tasks k_verify_msm filed (their unchecked chain met p == +-q), one per lane, with the checked additions; grid-stride over the filed count, so an honest batch's
 // launch finds nothing and returns
-__global__ PLUME_MSM_BOUNDS void k_verify_msm_redo(VerifyArgs a) {
-    __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
+// Workgroups of one wavefront: 8 KiB of digit rows, so that the launch (which normally finds nothing) never waits for LDS behind another batch's multi-scalar kernel.
+constexpr int kRedoBlock = 64;
+__global__ __launch_bounds__(kRedoBlock, PLUME_MSM_WAVES) void k_verify_msm_redo(VerifyArgs a) {
+    __shared__ int8_t s_dig[4 * PLUME_NDIG * kRedoBlock];
     const uint32_t count = a.redo[0];
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
+    for (uint32_t k = blockIdx.x * kRedoBlock + threadIdx.x; k < count; k += gridDim.x * kRedoBlock) {
         const uint32_t t = a.redo[1 + k];
-        verify_msm<true>(a, t >> 1, t & 1u, a.gtab, s_dig + threadIdx.x, kBlock);
+        verify_msm<true>(a, t >> 1, t & 1u, a.gtab, s_dig + threadIdx.x, kRedoBlock);
     }
 }
 
@@ -457,24 +463,26 @@ void launch_tables_small(uint32_t* tab, const uint32_t* bases, const uint8_t* jo
 }
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st) {
     size_t lanes = (njobs + L - 1) / L;
-    const dim3 grid(nblocks(lanes)), block(kBlock);
-    const size_t nl = (size_t)grid.x * kBlock, T = (nl + PLUME_TABINV_K - 1) / PLUME_TABINV_K;
+    static_assert(kBlock % kTabBlock == 0, "the scratch regions are sized in units of kBlock lanes");
+    const dim3 grid(nblocks(lanes) * (kBlock / kTabBlock)), block(kTabBlock);
+    const size_t nl = (size_t)grid.x * kTabBlock, T = (nl + PLUME_TABINV_K - 1) / PLUME_TABINV_K;
     uint32_t* carry = scr + tables_park_bytes(njobs, L) / 4;
     uint8_t* guardf = reinterpret_cast<uint8_t*>(carry + nl * PLUME_FE_WORDS);
     const dim3 igrid(nblocks(T));
+    const dim3 iblock(kBlock);
     hipLaunchKernelGGL(k_tab_pass_a, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
-    hipLaunchKernelGGL(k_tab_invert, igrid, block, 0, st, carry, nl, T);
+    hipLaunchKernelGGL(k_tab_invert, igrid, iblock, 0, st, carry, nl, T);
     hipLaunchKernelGGL(k_tab_pass_b, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
-    hipLaunchKernelGGL(k_tab_invert, igrid, block, 0, st, carry, nl, T);
+    hipLaunchKernelGGL(k_tab_invert, igrid, iblock, 0, st, carry, nl, T);
     hipLaunchKernelGGL(k_tab_pass_c, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
-    hipLaunchKernelGGL(k_tab_invert, igrid, block, 0, st, carry, nl, T);
+    hipLaunchKernelGGL(k_tab_invert, igrid, iblock, 0, st, carry, nl, T);
     hipLaunchKernelGGL(k_tab_pass_d, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
 }
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {
     (void)hipMemsetAsync(a.redo, 0, 4, st);
     hipLaunchKernelGGL(k_verify_msm, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
-    const unsigned redo_blocks = std::min(2 * nblocks(a.n), 1024u);                      // grid-stride: enough lanes for a wholly crafted batch to fill the chip
-    hipLaunchKernelGGL(k_verify_msm_redo, dim3(redo_blocks), dim3(kBlock), 0, st, a);
+    const unsigned redo_blocks = std::min(2 * nblocks(a.n) * (kBlock / kRedoBlock), 4096u);   // grid-stride: enough lanes for a wholly crafted batch to fill the chip
+    hipLaunchKernelGGL(k_verify_msm_redo, dim3(redo_blocks), dim3(kRedoBlock), 0, st, a);
 }
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_finalize, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_sign_gmul(const SignArgs& a, hipStream_t st) {
