@@ -679,6 +679,12 @@ def main():
                 # what the SIMDs actually issued (committed counter pass of the same build): all VALU slots and the multiply-adds among them, against the same peak.  `frac` counts
                 # the ACCOUNTING's multiply-adds; these two say how full the issue ports are and how many multiply-adds the code spends per accounted one.
                 iss = pmc_issue("plume::k_" + dom, eng.version())
+                if iss and iss.get("valu_wave_insts") and dom_parts:
+                    iss2 = pmc_issue("plume::k_sign_hdbl", eng.version())        # the signer's roofline spans both launches: so do its instruction counts
+                    if iss2 and iss2.get("valu_wave_insts"):
+                        iss["valu_wave_insts"] += iss2["valu_wave_insts"]
+                    else:
+                        iss = None
                 if iss and iss.get("valu_wave_insts"):
                     lane_ops = iss["valu_wave_insts"] * 64.0 * (n / float(1 << 20))
                     share = iss.get("mad_share")
@@ -696,7 +702,7 @@ def main():
                         "note": "valu_slots: every VALU instruction priced as one multiply-add slot (plain VOP1/VOP2 ops issue in about 0.57 of one: tests/gpu_debug/instr_rates_r03.txt), "
                                 "so a kernel that saturates the SIMDs with a mix reads a little above the measured busy fraction"}
             if dom_fpmul and in_flight_info and in_flight_info["stage_ms_in_flight"].get(dom):
-                kin = in_flight_info["stage_ms_in_flight"][dom]
+                kin = in_flight_info["stage_ms_in_flight"][dom] + (in_flight_info["stage_ms_in_flight"].get("sign_hdbl", 0.0) if dom_parts else 0.0)
                 line["roofline"]["kernel_ms_in_timed_region"] = kin
                 line["roofline"]["frac_in_timed_region"] = round(dom_fpmul * MACS_PER_FPMUL * n / (kin * 1e-3) / mad_rate, 4)
                 line["roofline"]["note"] = (f"kernel_ms / frac: the serial pass (one call after the other).  In the timed region {F} batches are in flight and the kernels of the streams share the "

@@ -30,6 +30,23 @@ for tag in ("sq", "sq2"):
                 d.setdefault("_dur_ns_max", max(x))
             else:
                 d[c] = max(x) if k.startswith("plume::k_tab") else sum(x) / len(x)      # the table kernels also run for the setup signer's smaller launches: the verify launch is the largest
+# the signer's own counter pass (bench.py --config 3; collect.sh's pmc_sqs): its kernels only -- the table kernels keep the verify run's figures.  The run's launches differ in
+# size (the setup, the piece pipeline of the extras): the 2^20-item launch is the one with the most wavefronts.
+try:
+    for k, v in load("gpurun_out/pmc_sqs/sqs_counter_collection.csv").items():
+        if not k.startswith("plume::k_sign"):
+            continue
+        d = out.setdefault(k, {})
+        big = max(range(len(v["SQ_WAVES"])), key=lambda i: v["SQ_WAVES"][i]) if v.get("SQ_WAVES") else 0
+        for c, x in v.items():
+            if c == "_dur_ns":
+                d["_dur_ns_max"] = max(x)
+            elif c.startswith("_"):
+                d[c] = x[0]
+            else:
+                d[c] = x[big] if big < len(x) else max(x)
+except OSError:
+    pass
 fe, wr = load("gpurun_out/pmc_fetch/fetch_counter_collection.csv"), load("gpurun_out/pmc_write/write_counter_collection.csv")
 for k in out:
     if k in fe:
@@ -48,7 +65,7 @@ for k, d in out.items():
 def isa_mad_share(path):
     """share of v_mad_u64_u32 among the VALU instructions the multi-scalar kernels execute, from the ISA mix of their loop bodies (profiles/isa_mix.py output): the two largest
     blocks of a kernel's section are the mixed-addition body and the doubling body; a verify lane runs 128 doublings and ~98 additions (78 / 132 slots per equation, 15/16 non-zero),
-    a signer lane 128 doublings and ~124 additions"""
+    a signer lane (round 4: chains of 64 doublings) 64 doublings and ~64 additions"""
     share, cur, blocks = {}, None, {}
     try:
         lines = open(path).read().splitlines()
@@ -58,9 +75,9 @@ def isa_mad_share(path):
         if ln.startswith("# ") and "basic blocks" in ln:
             if cur and len(blocks) >= 2:
                 top = sorted(blocks.values(), key=lambda t: -t[0])[:2]          # (mad64, VALU): addition body first, doubling body second
-                w_add = 124.0 if "sign" in cur else 98.5
-                mad = w_add * top[0][0] + 128.0 * top[1][0]
-                valu = w_add * top[0][1] + 128.0 * top[1][1]
+                w_add, w_dbl = (64.0, 64.0) if "sign" in cur else (98.5, 128.0)
+                mad = w_add * top[0][0] + w_dbl * top[1][0]
+                valu = w_add * top[0][1] + w_dbl * top[1][1]
                 share["plume::" + cur] = round(mad / valu, 4)
             cur, blocks = ln[2:].split(":")[0].strip(), {}
         elif cur and ln[:1] in "._e" and len(ln.split()) >= 12 and ln.split()[1].isdigit():
