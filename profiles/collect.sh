@@ -23,7 +23,7 @@ for spec in "sq:SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUS
   tg=${spec%%:*}; cn=${spec#*:}
   rocprofv3 --pmc $cn --kernel-trace --output-format csv -d gpurun_out/pmc_$tg -o $tg -- python3 bench.py --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-probe > gpurun_out/pmc_$tg.log 2>&1
 done
-# the signer's counters (its own summary: profiles/<round>s_pmc_summary.json)
+# the signer's counters (summarize_pmc.py folds its k_sign_* kernels into the same profiles/<round>_pmc_summary.json)
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_sqs -o sqs -- python3 bench.py --config 3 --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-probe > gpurun_out/pmc_sqs.log 2>&1
 tail -1 gpurun_out/bench_$R.log | cut -c1-400
 head -8 gpurun_out/prof_$R/${R}_kernel_stats.csv | cut -c1-130
