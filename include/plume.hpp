@@ -62,6 +62,9 @@ class Engine {
     Engine(Engine&& o) noexcept : ctx_(o.ctx_) { o.ctx_ = nullptr; }
     plume_ctx* ctx() const { return ctx_; }
     int num_shards() const { return plume_num_shards(ctx_); }
+    // The signer's schedule (plume_hip.h, plume_set_sign_uniform): 0 = fastest (its instruction trace and table addresses depend on sk and r), 1 = no branch on a digit of
+    // them, 2 = and no table address derived from one -- the property k256's constant-time multiplication has (rust-k256/src/randomizedsigner.rs:51-70 multiplies by secrets).
+    void set_sign_uniform(int level) { check(plume_set_sign_uniform(ctx_, level), "plume_set_sign_uniform"); }
     // the engine single-item calls use when none is passed: PLUME_DEVICES="0,1,.." (one multi-device context) or device 0
     static Engine& shared() {
         static std::unique_ptr<Engine> e;
