@@ -286,6 +286,25 @@ def e2e_host_pinned(eng, n, b, signed_v1):
     # the same call with pageable caller arrays (the runtime stages them), for comparison
     tb, tm = best(lambda: eng.verify_batch(1, v["msgs"], b["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"]), reps=2)
     out["verify_v1_pageable"] = {"items_per_s": round(n / tm, 1), "ms_per_call": round(tm * 1e3, 3)}
+    # the same call through a plume_init_multi context of EIGHT shards that all sit on this one GPU (config 4's split in the library's own form), against the
+    # one-context call above.  The GPU's work is the same; anything well under 1.0 is host-side serialisation (locks, staging allocation, thread wake-ups, eight pipelines'
+    # launches) that eight real GPUs would meet too.  Each shard gets n/8 items = one piece, so nothing is pipelined INSIDE a shard: the eight shards overlap each other instead.
+    try:
+        import zk_nullifier_sig_amd as plume
+        dev_id = eng.device_id if hasattr(eng, "device_id") else 0
+        m = plume.Engine([dev_id] * 8)
+        try:
+            ok8 = capi.pinned_empty(n)
+            tb8, tm8 = best(lambda: m.verify_batch(1, vp["msgs"], pin["off"], vp["pk"], vp["nullifier"], vp["c"], vp["s"], vp["r_point"], vp["hashed_to_curve_r"], out=ok8))
+            assert np.array_equal(ok8, synth.expected_ok(n))
+            out["verify_v1_eight_shards_on_this_gpu"] = {"items_per_s": round(n / tm8, 1), "ms_per_call": round(tm8 * 1e3, 3), "best_ms": round(tb8 * 1e3, 3), "shards": m.num_shards(),
+                                                         "frac_of_one_context": round(tm / tm8, 4), "numa_nodes": m.shard_numa_nodes(),
+                                                         "note": "plume_init_multi([d] * 8): eight worker threads, eight workspaces, 8 x 4 staging slots sharing ONE GPU; "
+                                                                 "frac_of_one_context = this rate / verify_v1's (same arrays, same run)"}
+        finally:
+            m.close()
+    except Exception as e:
+        out["verify_v1_eight_shards_on_this_gpu"] = {"error": str(e)[:300]}
     out["note"] = ("median of 3 calls after one warm-up; page-locked arrays from plume_host_alloc; pieces of up to 2^19 items (first 2^16, then x3 per piece; the signer's last piece 2^16); "
                    "verify: pieces alternate between two lanes of the context, four staging slots (round 4); sign and pageable arrays: one lane")
     return out

@@ -82,7 +82,9 @@ extern "C" {
     fn plume_h2c_hints_batch(ctx: *mut plume_ctx, n: usize, msgs: *const u8, msg_off: *const u64, pk: *const u8, registers: c_int, hints: *mut u8) -> c_int;
     fn plume_set_sub_batches(ctx: *mut plume_ctx, sub_batches: c_int) -> c_int;
     fn plume_set_in_flight(ctx: *mut plume_ctx, batches: c_int) -> c_int;
-    fn plume_set_sign_uniform(ctx: *mut plume_ctx, on: c_int) -> c_int;
+    fn plume_set_sign_uniform(ctx: *mut plume_ctx, level: c_int) -> c_int;
+    fn plume_get_sign_uniform(ctx: *const plume_ctx) -> c_int;
+    fn plume_set_host_lanes(ctx: *mut plume_ctx, lanes: c_int) -> c_int;
     fn plume_shard_numa_node(ctx: *const plume_ctx, shard: c_int) -> c_int;
     fn plume_aggregate_check(ctx: *mut plume_ctx, version: c_int, mode: c_int, n: usize, msgs: *const u8, msg_off: *const u64, pk: *const u8, nullifier: *const u8, c: *const u8,
                              s: *const u8, r_point: *const u8, hashed_to_curve_r: *const u8, seed: *const u8, hash_ok: *mut u8, result: *mut u8) -> c_int;
@@ -281,9 +283,13 @@ impl HipEngine {
     pub fn set_sub_batches(&self, k: i32) -> Result<(), HipError> { if unsafe { plume_set_sub_batches(self.0, k) } == 0 { Ok(()) } else { Err(last_error()) } }
     /// Batches in flight (`plume_set_in_flight`): with 2, device-resident calls issued on different streams run side by side (two lanes of the context); default 1
     pub fn set_in_flight(&self, k: i32) -> Result<(), HipError> { if unsafe { plume_set_in_flight(self.0, k) } == 0 { Ok(()) } else { Err(last_error()) } }
-    /// The signer's uniform schedule (`plume_set_sign_uniform`): no branch on a digit of `sk` or `r` in the two kernels that walk them (k256's multiplication is constant-time;
-    /// the default GPU signer skips zero digits).  `level` 0 = default, 1 = no secret-dependent branch (table rows still gathered at digit-dependent addresses),
-    /// 2 = no secret-dependent address either (every row of a window's table is read and one kept by masked selects, as k256 does).  Outputs are unchanged.
+    /// The level this context signs at (`plume_get_sign_uniform`).
+    pub fn sign_uniform(&self) -> Result<i32, HipError> { let l = unsafe { plume_get_sign_uniform(self.0) }; if l >= 0 { Ok(l as i32) } else { Err(last_error()) } }
+    /// Host-pointer calls: 1 = every piece on the context itself, 2 (default) = pieces alternate between the context and a second lane.
+    pub fn set_host_lanes(&self, lanes: i32) -> Result<(), HipError> { if unsafe { plume_set_host_lanes(self.0, lanes as c_int) } == 0 { Ok(()) } else { Err(last_error()) } }
+    /// The signer's schedule (`plume_set_sign_uniform`).  k256's multiplication is constant-time, so the library's default is level 1 (no branch on a digit of `sk` or `r` in
+    /// the kernels that walk them; table rows still gathered at digit-dependent addresses).  0 = fastest, not uniform; 2 = no secret-dependent address either (every row of a
+    /// window's table is read and one kept by masked selects, as k256 does).  Outputs are unchanged at every level.
     pub fn set_sign_uniform(&self, level: i32) -> Result<(), HipError> { if unsafe { plume_set_sign_uniform(self.0, level as c_int) } == 0 { Ok(()) } else { Err(last_error()) } }
     /// The NUMA node shard `d`'s worker thread bound itself to (`None`: not bound) — allocate / pin the caller arrays of that shard's slice there
     pub fn shard_numa_node(&self, d: usize) -> Option<i32> { let v = unsafe { plume_shard_numa_node(self.0, d as c_int) }; if v >= 0 { Some(v) } else { None } }

@@ -65,6 +65,8 @@ class Engine {
     // The signer's schedule (plume_hip.h, plume_set_sign_uniform): 0 = fastest (its instruction trace and table addresses depend on sk and r), 1 = no branch on a digit of
     // them, 2 = and no table address derived from one -- the property k256's constant-time multiplication has (rust-k256/src/randomizedsigner.rs:51-70 multiplies by secrets).
     void set_sign_uniform(int level) { check(plume_set_sign_uniform(ctx_, level), "plume_set_sign_uniform"); }
+    int sign_uniform() const { const int l = plume_get_sign_uniform(ctx_); check(l < 0 ? l : 0, "plume_get_sign_uniform"); return l; }   // 1 by default (library 0.4)
+    void set_host_lanes(int lanes) { check(plume_set_host_lanes(ctx_, lanes), "plume_set_host_lanes"); }
     // the engine single-item calls use when none is passed: PLUME_DEVICES="0,1,.." (one multi-device context) or device 0
     static Engine& shared() {
         static std::unique_ptr<Engine> e;

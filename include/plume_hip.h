@@ -69,7 +69,9 @@ int plume_shard_numa_node(const plume_ctx* ctx, int shard);
 void plume_destroy(plume_ctx* ctx);
 /* Last error text of this thread (valid until the next failing call on the thread). */
 const char* plume_last_error(void);
-/* Library / build information, e.g. "plume_hip 0.1 gfx950". */
+/* Library / build information: "plume_hip <major.minor> gfx950 build=<hash of the device sources>".  0.4 (round 5): plume_get_sign_uniform, plume_set_host_lanes;
+ * the signer defaults to uniform level 1; the generator tables are built by the first call that needs them; stream = NULL means the stream of the context the caller
+ * holds; plume_destroy waits for the context's own work only (its last call on any stream and its private streams), not for the whole device. */
 const char* plume_version(void);
 /* Upper bound on items processed per internal pass (workspace is ~3.9 KB per in-flight item). Default 1<<20. */
 int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
@@ -88,23 +90,32 @@ int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
  * whichever lane serves the call (so a sign followed by a verify of its outputs, both with stream = NULL, stay ordered).  Costs a second per-batch workspace.  Single-device contexts only (a multi-device context
  * already runs its shards side by side).  plume_last_stage_times / plume_last_redo_tasks then report the lane of the last device-resident call. */
 int plume_set_in_flight(plume_ctx* ctx, int batches);
-/* The signer's uniform schedule (default 0 = off; env PLUME_SIGN_UNIFORM=<level> sets the default of new contexts).  k256's scalar multiplication is constant-time
- * (SURVEY.md §5); the default signer here skips zero digits and branches on digit signs: its instruction trace depends on sk and r.
- *   level 1: the two kernels that walk those digits (sk*G, r*G by the comb; sk*H, r*H by windows; also the comb of the SEC1-DER export, whose scalars are secret keys) run the
- *            same instructions for every digit value: every slot adds (a zero digit adds row 1 to a copy that a masked select drops), signs are masked selects, the
- *            accumulator starts at a fixed offset point that is subtracted at the end.  Still secret-dependent: the ADDRESS of the table row each slot gathers.
+/* The signer's schedule.  k256's scalar multiplication is constant-time (call sites rust-k256/src/randomizedsigner.rs:51-70), so the DEFAULT here is level 1
+ * since round 5 (library 0.4; rounds 1-4 defaulted to level 0).  Env PLUME_SIGN_UNIFORM=<level> sets the default of new contexts; plume_set_sign_uniform(ctx, 0) opts out.
+ *   level 0: fastest.  NOT uniform: zero digits of sk and r are skipped, digit signs are branches, table rows are gathered at digit-dependent addresses -- the instruction
+ *            trace and the memory addresses of k_sign_gmul / k_sign_hmul depend on the secrets.
+ *   level 1: (default) the two kernels that walk those digits (sk*G, r*G by the comb; sk*H, r*H by windows; also the comb of the SEC1-DER export, whose scalars are secret
+ *            keys) run the same instructions for every digit value: every slot adds (a zero digit adds row 1 to a copy that a masked select drops), signs are masked selects,
+ *            the accumulator starts at a fixed offset point that is subtracted at the end.  UNIFORM: control flow, instruction count.  NOT uniform: the ADDRESS of the
+ *            table row each slot gathers (cache / HBM-channel timing).  Price on the MI355X: +2.5 % per signature.
  *   level 2: level 1, and no address is derived from a digit: every slot reads all 8 rows of its window's table and keeps one by masked selects (what k256 does with its
- *            16-entry tables); the multiplications by G then use a 52-window x 16-row table instead of the 18-bit comb (52 additions instead of 15).
- * Outputs are bit-identical at every level.  Returns PLUME_ERR_ARG for a level outside 0..2.  Costs: DESIGN.md §9. */
+ *            16-entry tables); the multiplications by G then use a 52-window x 16-row table instead of the 18-bit comb (52 additions instead of 15).  UNIFORM: control flow,
+ *            instruction count, every memory address.  Price: +47 %.
+ * At every level: the scalar side (reduction mod n, GLV split, Booth recoding, s = r + sk*c) is select-based; the range checks of sk and r are not (an out-of-range scalar
+ * is a status bit, not a secret worth protecting); nothing is claimed about power / EM channels.  Outputs are bit-identical at every level.  Returns PLUME_ERR_ARG for a
+ * level outside 0..2.  Measurements: DESIGN.md §9. */
 int plume_set_sign_uniform(plume_ctx* ctx, int level);
+/* the level this context signs at (0, 1, 2), or a negative error code */
+int plume_get_sign_uniform(const plume_ctx* ctx);
 /* Environment knobs read when a context is created (tuning and A/B runs; results never depend on them):
  *   PLUME_SUB_BATCHES, PLUME_SERIAL, PLUME_OVERLAP_MIN   sub-batch overlap of the device-resident calls (plume_set_sub_batches)
  *   PLUME_HOST_PIECE, PLUME_HOST_FIRST_PIECE, PLUME_HOST_TAIL_PIECE, PLUME_HOST_REGISTER_MIN, PLUME_HOST_LANES (1 | 2), PLUME_HOST_SCHEDULE (explicit piece list, read per call)
  *                                                        the host-pointer pipeline (plume_set_host_*)
  *   PLUME_INGEST_SPLIT_MAX   verify calls of at most this many items run the ingest stage with two lanes per item (default 65536; 0: never)
- *   PLUME_TABLES_SMALL_MAX   window-table stages of at most this many jobs (3 per verify, 1 per sign) take the one-inversion Jacobian chain (default 98304; 0: never)
+ *   PLUME_TABLES_SMALL_MAX   window-table stages of at most this many jobs (3 per verify, 2 per sign: H and 2^64 H) take the one-inversion Jacobian chain (default 98304,
+ *                            i.e. verify calls of up to 32768 items and sign calls of up to 49152; 0: never)
  *   PLUME_JOBS_PER_LANE      jobs per lane of the affine table passes (default: 3..6 by batch size)
- *   PLUME_SIGN_UNIFORM       default level of plume_set_sign_uniform (0, 1, 2)
+ *   PLUME_SIGN_UNIFORM       default level of plume_set_sign_uniform (0, 1, 2; default 1)
  *   PLUME_NO_AFFINITY        multi-device contexts: leave the shard threads' CPU affinity alone */
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (an upload, a download and the compute streams,
  * four staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each following piece up to three times
@@ -117,6 +128,8 @@ int plume_set_sign_uniform(plume_ctx* ctx, int level);
 int plume_set_host_piece(plume_ctx* ctx, size_t largest_piece_items);
 int plume_set_host_first_piece(plume_ctx* ctx, size_t items);
 int plume_set_host_tail_piece(plume_ctx* ctx, size_t items);
+/* 1 = every piece of a host-pointer call runs on the context itself, 2 (default) = pieces alternate between the context and a second lane (env PLUME_HOST_LANES) */
+int plume_set_host_lanes(plume_ctx* ctx, int lanes);
 /* Host-pointer calls: caller arrays of at least `bytes` bytes that are not page-locked yet are registered (hipHostRegister) for the
  * duration of the call; 0 (default) = never.  Registration costs more than one batch's copies save: callers that reuse their buffers
  * should page-lock them ONCE with the helpers below instead. */

@@ -47,10 +47,11 @@ def _load():
     # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  Whichever copy is loaded first serves the
     # whole process; loading ours first leaves torch without a usable device ("No HIP GPUs are available").  So if
     # torch is installed, let it load its runtime first; the library itself has no torch dependency.
-    try:
-        import torch  # noqa: F401
-    except Exception:
-        pass
+    if not os.environ.get("PLUME_NO_TORCH_PRELOAD"):     # experiments only: run on /opt/rocm's runtime instead of the one torch bundles (tests/gpu_debug/d2h_in_library.py)
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(str(p))
     lib.plume_last_error.restype = C.c_char_p
     lib.plume_version.restype = C.c_char_p
@@ -74,11 +75,11 @@ def _load():
     lib.plume_set_chunk.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_set_sub_batches.argtypes = [C.c_void_p, C.c_int]
     lib.plume_set_in_flight.argtypes = [C.c_void_p, C.c_int]
-    try:
-        lib.plume_set_sign_uniform.argtypes = [C.c_void_p, C.c_int]
-    except AttributeError:      # an older build of the library selected through PLUME_HIP_LIB (A/B runs against an earlier round): it has no such entry point
-        if not os.environ.get("PLUME_HIP_LIB"):
-            raise
+    # later entry points: an older build selected through PLUME_HIP_LIB (A/B runs against an earlier round) may lack them; the in-tree library must have them all (checked below)
+    for name, args in (("plume_set_sign_uniform", [C.c_void_p, C.c_int]), ("plume_get_sign_uniform", [C.c_void_p]), ("plume_set_host_lanes", [C.c_void_p, C.c_int])):
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes = args
     lib.plume_set_host_piece.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_last_redo_tasks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.plume_last_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
@@ -110,12 +111,16 @@ def _load():
     lib.plume_aggregate_check.argtypes = [vp, i, i, sz] + [vp] * 11
     lib.plume_aggregate_check_device.argtypes = [vp, i, i, sz, vp, vp, sz] + [vp] * 7 + [C.c_uint64, vp, vp, vp]
     _lib = lib
+    ver = tuple(int(x) for x in lib.plume_version().decode().split()[1].split(".")[:2])
+    if ver < (0, 4) and not os.environ.get("PLUME_HIP_LIB"):
+        _lib = None
+        raise PlumeHipError(f"{p} is {lib.plume_version().decode()}: this module needs plume_hip >= 0.4 (rebuild: make -C zk-nullifier-sig_amd/csrc)")
     return lib
 
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_set_in_flight", "plume_set_sign_uniform", "plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
+    return ["plume_set_in_flight", "plume_set_sign_uniform", "plume_get_sign_uniform", "plume_set_host_lanes", "plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
             "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars", "plume_sec1_der_to_scalars_checked",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
@@ -274,6 +279,17 @@ class Engine:
         """the signer's uniform schedule (plume_set_sign_uniform): level 1 (or True) = no branch on a digit of sk or r, level 2 = and no table address derived from
         one (every row of a window's table is read); outputs unchanged"""
         self._chk(self._lib.plume_set_sign_uniform(self._ctx, int(on)), "plume_set_sign_uniform")
+
+    def sign_uniform(self):
+        """the level this context signs at (plume_get_sign_uniform): 1 by default since library 0.4"""
+        rc = self._lib.plume_get_sign_uniform(self._ctx)
+        if rc < 0:
+            self._chk(rc, "plume_get_sign_uniform")
+        return rc
+
+    def set_host_lanes(self, lanes):
+        """host-pointer calls: 1 = every piece on the context itself, 2 (default) = pieces alternate between the context and a second lane"""
+        self._chk(self._lib.plume_set_host_lanes(self._ctx, int(lanes)), "plume_set_host_lanes")
 
     def set_host_piece(self, n):
         """host-pointer calls: items per pipelined piece (upload / compute / download overlap across pieces)"""

@@ -23,6 +23,7 @@
 
 #include "../../include/plume_hip.h"
 #include "plume_agg_launch.h"
+#include "plume_host_logic.h"
 #include "plume_launch.h"
 
 using namespace plume;
@@ -142,8 +143,12 @@ struct plume_ctx {
     plume_ctx* host_lane = nullptr;                                // ... the second lane of the host-pointer pipeline: a complete single-device context (workspace, streams), created on first use
     size_t tables_small_max = (size_t)3 << 15;                     // table stages of at most this many jobs take the small-batch path (Jacobian chain, one inversion: launch_tables_small)
     size_t ingest_split_max = (size_t)1 << 16;                     // verify calls (slices) of at most this many items run the ingest stage with two lanes per item (latency-bound there)
-    int sign_uniform = 0;                                          // plume_set_sign_uniform: the signer's uniform-schedule kernels (level 0, 1, 2)
+    int sign_uniform = 1;                                          // plume_set_sign_uniform: the signer's schedule (level 0, 1, 2).  Default 1 since round 5: no branch on a digit of sk or r
+                                                                   // (k256's multiplication is constant-time, rust-k256/src/randomizedsigner.rs:51-70; measured price +2.5 % per signature)
     int host_lanes = 2;                                            // ... 1 = every piece on the context itself (rounds 1-3), 2 = pieces alternate between the context and host_lane
+    int host_sign_lanes = 1;                                       // ... the signer's host-pointer call: lanes it may use (env PLUME_HOST_SIGN_LANES; round-5 experiment)
+    bool host_lane_failed = false;                                 // ... the second lane could not be created once (out of memory): do not retry on every call
+    size_t msm_split_max = (size_t)1 << 16;                        // verify calls (slices) of at most this many items run the multi-scalar kernel with two lanes per (item, equation)
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
     FixedTables* fixed = nullptr;                                 // this device's shared generator tables (g_fixed)
@@ -159,6 +164,22 @@ struct plume_ctx {
     DevBuf dslots, dminid, dmyslot, dcount, dblockcnt;   // nullifier-set post-processing (plume_dedup.h)   // SEC1 ingest: decompressed 64-byte records + per-item reject flags
     StageTimer timer;
 };
+
+// Every per-context tunable a derived context (an in-flight lane, the host pipeline's second lane, a shard) has to share with the context it serves: ONE place, so that a new
+// knob cannot reach some derived contexts and miss others (round 4's host lane did not inherit sign_uniform: VERDICT r4).
+static void inherit_tunables(plume_ctx* to, const plume_ctx* from) {
+    to->chunk = from->chunk; to->sub_batches = from->sub_batches; to->overlap_min = from->overlap_min; to->sign_uniform = from->sign_uniform;
+    to->ingest_split_max = from->ingest_split_max; to->tables_small_max = from->tables_small_max; to->msm_split_max = from->msm_split_max;
+    to->jobs_per_lane = from->jobs_per_lane; to->jobs_per_lane_forced = from->jobs_per_lane_forced;
+    to->host_piece = from->host_piece; to->host_first_piece = from->host_first_piece; to->host_tail_piece = from->host_tail_piece; to->host_register_min = from->host_register_min;
+    to->host_lanes = from->host_lanes; to->host_sign_lanes = from->host_sign_lanes;
+}
+// after a setter changed `ctx`: hand the change to every context derived from it (shards and their derived contexts, in-flight lanes, the host pipeline's second lane)
+static void propagate_tunables(plume_ctx* ctx) {
+    for (plume_ctx* sh : ctx->shards) { inherit_tunables(sh, ctx); propagate_tunables(sh); }
+    for (plume_ctx* l : ctx->lanes) inherit_tunables(l, ctx);
+    if (ctx->host_lane) { inherit_tunables(ctx->host_lane, ctx); ctx->host_lane->sub_batches = 1; }   // the pieces of a host-pointer call are never cut again
+}
 
 static int bind(plume_ctx* ctx) {
     if (!ctx) return fail(PLUME_ERR_ARG, "null context");
@@ -212,23 +233,25 @@ extern "C" const char* plume_last_error(void) { return g_err.c_str(); }
 #ifndef PLUME_BUILD_ID
 #define PLUME_BUILD_ID "unknown"
 #endif
-extern "C" const char* plume_version(void) { return "plume_hip 0.3 gfx950 build=" PLUME_BUILD_ID; }
+extern "C" const char* plume_version(void) { return "plume_hip 0.4 gfx950 build=" PLUME_BUILD_ID; }
 
 static void destroy_single(plume_ctx* ctx) {
     for (plume_ctx* l : ctx->lanes) destroy_single(l);
     ctx->lanes.clear();
     if (ctx->host_lane) { destroy_single(ctx->host_lane); ctx->host_lane = nullptr; }
     (void)hipSetDevice(ctx->device);
-    (void)hipDeviceSynchronize();   // the context's workspace, events and lanes may still be in use by kernels queued on CALLER streams (device-resident calls run on whatever
-                                    // stream they were given): wait for the whole device, not only for the context's own streams (plume_destroy, plume_set_in_flight shrinking)
+    // The context's workspace, events and the shared tables may still be in use by kernels queued on CALLER streams (device-resident calls run on whatever stream they were
+    // given).  Every such call leaves ws_free behind its last kernel and waits for its predecessor's first (ws_acquire / ws_release), so the LAST ws_free covers them all: wait
+    // for that event and for the context's own streams -- not for the whole device, which would also wait for every other framework's work in the process.
+    if (ctx->ws_used && ctx->ws_free) (void)hipEventSynchronize(ctx->ws_free);
+    for (hipStream_t q : {ctx->stream, ctx->up, ctx->down, ctx->side, ctx->pre}) if (q) (void)hipStreamSynchronize(q);
     for (DevBuf* b : {&ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
                       &ctx->sink, &ctx->redo, &ctx->digs, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
     for (DevBuf& b : ctx->agg) b.release();
     if (ctx->fixed) {
         std::lock_guard<std::mutex> lk(g_fixed_mutex);
-        if (--ctx->fixed->refs == 0) {
-            (void)hipDeviceSynchronize();          // the tables are read by kernels on CALLER streams too: nothing may still be running when they go
+        if (--ctx->fixed->refs == 0) {           // every context that could read the tables has waited for its own last call on its way here: nothing is still running
             ctx->fixed->gtab.release(); ctx->fixed->gcomb.release(); ctx->fixed->gscan.release(); ctx->fixed->gtab_built = ctx->fixed->gcomb_built = ctx->fixed->gscan_built = false;
         }
         ctx->fixed = nullptr;
@@ -262,13 +285,19 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_TABLES_SMALL_MAX")) { long v = std::atol(e); if (v >= 0) ctx->tables_small_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_INGEST_SPLIT_MAX")) { long v = std::atol(e); if (v >= 0) ctx->ingest_split_max = (size_t)v; }   // tuning knob (0: never)
-    if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::min(2, std::max(0, std::atoi(e)));   // default of new contexts (plume_set_sign_uniform)
+    if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::min(2, std::max(0, std::atoi(e)));   // default of new contexts (plume_set_sign_uniform); 0 opts out of the uniform schedule
+    if (const char* e = std::getenv("PLUME_HOST_SIGN_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_sign_lanes = v; }
     if (const char* e = std::getenv("PLUME_HOST_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_lanes = v; }   // 1 = the one-lane host-pointer pipeline of rounds 1-3 (A/B)
+    // The runtime multiplexes a process's streams onto a few hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES, 4 by default), and two streams that share a queue wait for
+    // each other's packets -- event records and waits included.  Seen in the round-5 pipeline timelines (PLUME_HOST_TRACE): with two lanes, a finished piece's download waited
+    // for the OTHER lane's kernels (6 ms) because `down` shared a queue with that lane's stream.  So the copy streams live at high priority -- their own pool of queues, away
+    // from every compute stream of the process (the priority itself is irrelevant to them: copies run on the copy engines) -- and the side / pre streams that most contexts
+    // never use are created on first use (side_stream / pre_stream) instead of taking queue slots from the streams that matter.
+    int prio_least = 0, prio_greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&ctx->up, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&ctx->down, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&ctx->pre, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithPriority(&ctx->up, hipStreamNonBlocking, prio_greatest));
+    HIPCHK(hipStreamCreateWithPriority(&ctx->down, hipStreamNonBlocking, prio_greatest));
     HIPCHK(hipEventCreateWithFlags(&ctx->pre_begin, hipEventDisableTiming));
     if (const char* e = std::getenv("PLUME_SUB_BATCHES")) { int v = std::atoi(e); if (v >= 1 && v <= kMaxSubBatches) ctx->sub_batches = v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_SERIAL")) { if (std::atoi(e) != 0) ctx->sub_batches = 1; }                                  // ... and PLUME_SERIAL=1 wins over it: strictly serial launch order (per-kernel measurements)
@@ -436,7 +465,8 @@ template <class F>
 static int for_shards(plume_ctx* ctx, size_t n, F f) {
     const size_t g = ctx->shards.size();
     for (size_t d = 0; d < g; d++) {
-        const size_t lo = n * d / g, hi = n * (d + 1) / g;
+        size_t lo, hi;
+        plume_host::shard_bounds(n, d, g, lo, hi);
         plume_ctx* sh = ctx->shards[d];
         worker_post(ctx->workers[d], [=]() -> int { return lo < hi ? f(sh, lo, hi) : 0; });
     }
@@ -469,6 +499,7 @@ extern "C" int plume_init_multi(plume_ctx** out, const int* device_ids, int n_de
     for (std::thread& b : builders) b.join();
     for (int d = 0; d < n_devices; d++)
         if (rcs[(size_t)d]) { const std::string keep = "shard " + std::to_string(d) + " (device " + std::to_string(device_ids[d]) + "): " + errs[(size_t)d]; const int rc = rcs[(size_t)d]; destroy_multi(ctx); g_err = keep; return rc; }
+    inherit_tunables(ctx, ctx->shards[0]);   // the parent owns no GPU state but is what the setters are called on: it starts from what its shards read from the environment
     for (int d = 0; d < n_devices; d++) {
         Worker* w = new Worker();
         ctx->workers.push_back(w);
@@ -514,9 +545,7 @@ extern "C" int plume_host_unregister(void* p) {
 extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
     if (!ctx || max_items == 0 || max_items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_chunk: bad argument");
     ctx->chunk = max_items;
-    for (plume_ctx* sh : ctx->shards) sh->chunk = max_items;
-    for (plume_ctx* l : ctx->lanes) l->chunk = max_items;
-    if (ctx->host_lane) ctx->host_lane->chunk = max_items;
+    propagate_tunables(ctx);
     return 0;
 }
 
@@ -530,18 +559,20 @@ extern "C" int plume_set_sign_uniform(plume_ctx* ctx, int level) {
     if (!ctx) return fail(PLUME_ERR_ARG, "plume_set_sign_uniform: null context");
     if (level < 0 || level > 2) return fail(PLUME_ERR_ARG, "plume_set_sign_uniform: the level is 0, 1 or 2");
     ctx->sign_uniform = level;
-    for (plume_ctx* sh : ctx->shards) sh->sign_uniform = level;
-    for (plume_ctx* l : ctx->lanes) l->sign_uniform = level;
-    if (ctx->host_lane) ctx->host_lane->sign_uniform = level;
+    propagate_tunables(ctx);
     return 0;
+}
+
+extern "C" int plume_get_sign_uniform(const plume_ctx* ctx) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "plume_get_sign_uniform: null context");
+    return ctx->sign_uniform;
 }
 
 // device-resident verify / sign: how many sub-batches a call is cut into (verify_device); 1 = strictly serial launch order
 extern "C" int plume_set_sub_batches(plume_ctx* ctx, int sub_batches) {
     if (!ctx || sub_batches < 1 || sub_batches > kMaxSubBatches) return fail(PLUME_ERR_ARG, "plume_set_sub_batches: bad argument");
     ctx->sub_batches = sub_batches;
-    for (plume_ctx* sh : ctx->shards) sh->sub_batches = sub_batches;
-    for (plume_ctx* l : ctx->lanes) l->sub_batches = sub_batches;
+    propagate_tunables(ctx);
     return 0;
 }
 
@@ -558,8 +589,7 @@ extern "C" int plume_set_in_flight(plume_ctx* ctx, int batches) {
         plume_ctx* l = new plume_ctx();
         l->device = ctx->device;
         if (int rc = init_single(l)) { const std::string keep = g_err; destroy_single(l); g_err = keep; return rc; }
-        l->chunk = ctx->chunk; l->sub_batches = ctx->sub_batches; l->overlap_min = ctx->overlap_min; l->sign_uniform = ctx->sign_uniform; l->ingest_split_max = ctx->ingest_split_max; l->tables_small_max = ctx->tables_small_max;
-        l->jobs_per_lane = ctx->jobs_per_lane; l->jobs_per_lane_forced = ctx->jobs_per_lane_forced;
+        inherit_tunables(l, ctx);
         ctx->lanes.push_back(l);
     }
     ctx->lane_next = 0; ctx->lane_last = nullptr;
@@ -569,25 +599,31 @@ extern "C" int plume_set_in_flight(plume_ctx* ctx, int batches) {
 extern "C" int plume_set_host_piece(plume_ctx* ctx, size_t items) {
     if (!ctx || items == 0 || items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_host_piece: bad argument");
     ctx->host_piece = items;
-    for (plume_ctx* sh : ctx->shards) sh->host_piece = items;
+    propagate_tunables(ctx);
     return 0;
 }
 extern "C" int plume_set_host_first_piece(plume_ctx* ctx, size_t items) {
     if (!ctx || items == 0 || items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_host_first_piece: bad argument");
     ctx->host_first_piece = items;
-    for (plume_ctx* sh : ctx->shards) sh->host_first_piece = items;
+    propagate_tunables(ctx);
     return 0;
 }
 extern "C" int plume_set_host_tail_piece(plume_ctx* ctx, size_t items) {
     if (!ctx || items == 0 || items > ((size_t)1 << 26)) return fail(PLUME_ERR_ARG, "plume_set_host_tail_piece: bad argument");
     ctx->host_tail_piece = items;
-    for (plume_ctx* sh : ctx->shards) sh->host_tail_piece = items;
+    propagate_tunables(ctx);
+    return 0;
+}
+extern "C" int plume_set_host_lanes(plume_ctx* ctx, int lanes) {
+    if (!ctx || (lanes != 1 && lanes != 2)) return fail(PLUME_ERR_ARG, "plume_set_host_lanes: 1 or 2");
+    ctx->host_lanes = lanes;
+    propagate_tunables(ctx);
     return 0;
 }
 extern "C" int plume_set_host_register_min(plume_ctx* ctx, size_t bytes) {
     if (!ctx) return fail(PLUME_ERR_ARG, "plume_set_host_register_min: bad argument");
     ctx->host_register_min = bytes;
-    for (plume_ctx* sh : ctx->shards) sh->host_register_min = bytes;
+    propagate_tunables(ctx);
     return 0;
 }
 
@@ -616,15 +652,7 @@ static void table_stage(plume_ctx* ctx, uint32_t* tab, const uint32_t* bases, co
 // k+1 run on ctx->pre beside the multi-scalar kernel of sub-batch k on the caller's stream.  The multi-scalar kernel saturates the vector ALUs but leaves HBM idle, the
 // table kernel is bound by the critical path of its workgroups and leaves half of the issue slots idle (LABNOTES.md §5): side by side they fill each other's gaps, one
 // after the other they cannot.  Slices are multiples of 1024 items (whole workgroups, aligned records).  One sub-batch = the strictly serial order.
-static std::vector<size_t> sub_batch_bounds(const plume_ctx* ctx, size_t n) {
-    size_t k = (ctx->sub_batches > 1 && n >= ctx->overlap_min) ? (size_t)ctx->sub_batches : 1;
-    while (k > 1 && n / k < 8192) k--;
-    size_t per = (n + k - 1) / k;
-    per = (per + 1023) & ~(size_t)1023;
-    std::vector<size_t> b{0};
-    while (b.back() < n) b.push_back(b.back() + per < n ? b.back() + per : n);
-    return b;
-}
+static std::vector<size_t> sub_batch_bounds(const plume_ctx* ctx, size_t n) { return plume_host::sub_batch_bounds(n, ctx->sub_batches, ctx->overlap_min); }
 static int pre_events(plume_ctx* ctx, size_t k) {
     while (ctx->pre_ready.size() < k) {
         hipEvent_t e;
@@ -633,6 +661,9 @@ static int pre_events(plume_ctx* ctx, size_t k) {
     }
     return 0;
 }
+
+static int side_stream(plume_ctx* ctx) { if (!ctx->side) HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking)); return 0; }
+static int pre_stream(plume_ctx* ctx) { if (!ctx->pre) HIPCHK(hipStreamCreateWithFlags(&ctx->pre, hipStreamNonBlocking)); return 0; }
 
 static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk, const uint8_t* nul,
                          const uint8_t* c, const uint8_t* s, const uint8_t* rpt, const uint8_t* hr, uint8_t* ok, hipStream_t st,
@@ -651,7 +682,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->redo.ensure((2 * n + nsub) * 4) || ctx->digs.ensure((size_t)PLUME_VDIG_ROWS * n))
         return PLUME_ERR_HIP;
-    if (overlapped) { if (int rc = pre_events(ctx, nsub)) return rc; }
+    if (overlapped) { if (int rc = pre_events(ctx, nsub)) return rc; if (int rc = pre_stream(ctx)) return rc; }
     StageTimer& t = ctx->timer;
     if (!continue_timer) t.begin(st);
     hipStream_t pre = overlapped ? ctx->pre : st;
@@ -705,7 +736,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
         ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->res2.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->res2inf.ensure(2 * n) || ctx->pkaff.ensure((size_t)2 * PLUME_FE_WORDS * 4 * n))
         return PLUME_ERR_HIP;
-    if (overlapped) { if (int rc = pre_events(ctx, nsub)) return rc; }
+    if (overlapped) { if (int rc = pre_events(ctx, nsub)) return rc; if (int rc = pre_stream(ctx)) return rc; }
     StageTimer& t = ctx->timer;
     t.begin(st);
     hipStream_t pre = overlapped ? ctx->pre : st;                               // the stages in front of the H multiplications of sub-batch k+1 run beside those of sub-batch k (verify_device)
@@ -881,11 +912,13 @@ static int der_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t*
     if (n > 0xFFFFFFF0u) return fail(PLUME_ERR_ARG, "n too large");
     if (n == 0) return 0;
     if (int rc = need_sign_tables(ctx)) return rc;
+    if (int rc = ws_acquire(ctx, st)) return rc;          // no workspace is touched, but the kernel reads the shared table of G: the call joins the ws_free chain that plume_destroy waits on
+    WsHold hold(ctx, st);
     DerArgs a; a.n = (uint32_t)n; a.scalars = scalars; a.der = der109; a.status = status; a.gcomb = ctx->fixed->gcomb.as<uint32_t>(); a.gscan = ctx->fixed->gscan.as<uint32_t>(); a.uniform = ctx->sign_uniform;
     ctx->timer.begin(st);
     launch_scalars_der(a, st); ctx->timer.stage("scalars_to_sec1_der", st);
     HIPCHK(hipGetLastError());
-    return 0;
+    return hold.release();
 }
 extern "C" int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status, void* stream) {
     hipStream_t st_; ctx = route(ctx, stream, st_);
@@ -947,6 +980,7 @@ static int aggregate_device(plume_ctx* ctx, int version, int mode, size_t n, con
     for (int k = 0; k < 4; k++) { red[k] = B[11].as<uint32_t>() + (size_t)k * PLUME_JAC_WORDS * nred; rinf[k] = B[12].as<uint8_t>() + (size_t)k * nred; }
     uint32_t* gpt = B[13].as<uint32_t>() + 2 * sw; uint8_t* gptinf = (uint8_t*)(gpt + PLUME_JAC_WORDS);
     uint32_t* perm = B[14].as<uint32_t>(); uint32_t* hist = perm + a.nkeys;
+    if (int rc = side_stream(ctx)) return rc;
     hipStream_t side = ctx->side;
     StageTimer& t = ctx->timer;
     t.begin(st);
@@ -1082,11 +1116,11 @@ static int stage_msgs(plume_ctx* ctx, HostSlot& sl, const uint8_t* msgs, const u
     if (sl.relbuf.ensure((cnt + 1) * 8)) return PLUME_ERR_HIP;
     uint64_t* rel = sl.rel = (uint64_t*)sl.relbuf.p;
     const uint64_t base = off[i0];
-    for (size_t k = 0; k <= cnt; k++) {
-        if (off[i0 + k] < base || (k && off[i0 + k] < off[i0 + k - 1])) return fail(PLUME_ERR_ARG, "msg_off is not non-decreasing");
-        rel[k] = off[i0 + k] - base;
+    switch (plume_host::rebase_offsets(off, i0, cnt, rel)) {
+        case 0: break;
+        case 1: return fail(PLUME_ERR_ARG, "msg_off is not non-decreasing");
+        default: return fail(PLUME_ERR_ARG, "message bytes per pass exceed 4 GiB");
     }
-    if (rel[cnt] > 0xFFFFFF00ull) return fail(PLUME_ERR_ARG, "message bytes per pass exceed 4 GiB");
     if (sl.msgs.ensure((size_t)rel[cnt] + 16) || sl.off.ensure((cnt + 1) * 8)) return PLUME_ERR_HIP;
     if (rel[cnt]) HIPCHK(hipMemcpyAsync(sl.msgs.p, msgs + base, (size_t)rel[cnt], hipMemcpyHostToDevice, ctx->up));
     HIPCHK(hipMemcpyAsync(sl.off.p, rel, (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->up));
@@ -1131,25 +1165,8 @@ struct ScopedPins {
 // upload runs at ~7 ns per item, the kernels at ~23 ns per item, so piece k+1's upload still hides behind piece k's kernels) up to the
 // largest piece; calls with large outputs (the signer: 320 bytes out per item) also end on a small piece, whose download nothing hides.
 static std::vector<size_t> piece_schedule(const plume_ctx* ctx, size_t n, bool out_heavy) {
-    const size_t piece = ctx->host_piece < ctx->chunk ? ctx->host_piece : ctx->chunk;
-    std::vector<size_t> sched;
-    if (const char* e = std::getenv("PLUME_HOST_SCHEDULE")) {     // experiment knob: an explicit comma-separated piece list (used only when it adds up to n and fits the chunk)
-        size_t sum = 0; bool ok = true;
-        for (const char* q = e; *q;) { char* end; const unsigned long long v = std::strtoull(q, &end, 10); if (end == q || v == 0 || v > ctx->chunk) { ok = false; break; } sched.push_back((size_t)v); sum += (size_t)v; q = *end ? end + 1 : end; }
-        if (ok && sum == n) return sched;
-        sched.clear();
-    }
-    size_t rem = n, cur = ctx->host_first_piece < piece ? ctx->host_first_piece : piece;
-    if (n <= piece && n <= 2 * cur) { sched.push_back(n); return sched; }   // small calls: one piece
-    while (rem) {
-        const size_t c = cur < rem ? cur : rem;
-        sched.push_back(c);
-        rem -= c;
-        cur = cur * 3 < piece ? cur * 3 : piece;
-    }
-    const size_t tail = ctx->host_tail_piece;
-    if (out_heavy && sched.size() > 1 && sched.back() > 2 * tail) { const size_t last = sched.back(); sched.back() = last - tail; sched.push_back(tail); }
-    return sched;
+    const plume_host::PieceKnobs kn{ctx->chunk, ctx->host_piece, ctx->host_first_piece, ctx->host_tail_piece};
+    return plume_host::piece_schedule(kn, n, out_heavy, std::getenv("PLUME_HOST_SCHEDULE"));     // the rules and the experiment knob: plume_host_logic.h
 }
 
 // The second lane of the host-pointer pipeline (round 4).  Rounds 1-3 ran every piece of a call on the context's one workspace and stream: the kernels of piece k+1 queued
@@ -1159,10 +1176,18 @@ static std::vector<size_t> piece_schedule(const plume_ctx* ctx, size_t n, bool o
 // downloading from its slot when k+2 wants to upload).
 static plume_ctx* host_lane_of(plume_ctx* ctx) {
     if (ctx->host_lane) return ctx->host_lane;
+    if (ctx->host_lane_failed) return nullptr;
     plume_ctx* l = new plume_ctx();
     l->device = ctx->device;
-    if (init_single(l)) { destroy_single(l); return nullptr; }
+    if (init_single(l)) {
+        // the call goes on with one lane and succeeds: it must not leave this failure's text behind as "the last error", nor try the allocation again on every later call
+        destroy_single(l);
+        g_err.clear();
+        ctx->host_lane_failed = true;
+        return nullptr;
+    }
     ctx->host_lane = l;
+    propagate_tunables(ctx);
     return l;
 }
 
@@ -1174,18 +1199,32 @@ static bool is_page_locked(const void* p) {
     return at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
 }
 
+// PLUME_HOST_TRACE=1: every host-pointer call prints, per piece, when its uploads, kernels and downloads started and ended on the GPU's clock (timing events on the three
+// streams, read after the call) -- the pipeline's timeline WITHOUT a profiler attached (rocprofv3's memory-copy trace turns the downloads into blit kernels and stretches the
+// call: round 4 chased that artefact, tests/gpu_debug/d2h_probe.hip + d2h_in_library.py show the copies of an unprofiled run on the copy engines).
+struct PieceTrace { size_t cnt; int lane; hipEvent_t ev[6]; };    // up begin / end, run begin / end, down begin / end
+static bool host_trace_on() { static const bool on = [] { const char* e = std::getenv("PLUME_HOST_TRACE"); return e && std::atoi(e) != 0; }(); return on; }
+
 template <class Up, class Run, class Down>
 static int host_pipeline(plume_ctx* ctx, size_t n, bool out_heavy, Up up, Run run, Down down, bool may_use_two_lanes = false) {
     const std::vector<size_t> sched = piece_schedule(ctx, n, out_heavy);
     plume_ctx* lane2 = (may_use_two_lanes && ctx->host_lanes > 1 && sched.size() > 1) ? host_lane_of(ctx) : nullptr;
-    if (lane2) { lane2->chunk = ctx->chunk; lane2->sub_batches = 1; lane2->jobs_per_lane = ctx->jobs_per_lane; lane2->jobs_per_lane_forced = ctx->jobs_per_lane_forced; }
     const size_t nslots = lane2 ? 4 : 2;
     ctx->lane_last = nullptr;            // host-pointer calls report the stage timer of the lane their last piece ran on (set below)
-    struct { HostSlot* sl = nullptr; size_t i0 = 0, cnt = 0; } prev;
+    const bool trace = host_trace_on();
+    std::vector<PieceTrace> tr;
+    auto mark = [&](size_t k, int which, hipStream_t st) { if (trace) (void)hipEventRecord(tr[k].ev[which], st); };
+    if (trace) {
+        tr.resize(sched.size());
+        for (size_t k = 0; k < sched.size(); k++) { tr[k].cnt = sched[k]; tr[k].lane = (lane2 && (k & 1)) ? 1 : 0; for (hipEvent_t& e : tr[k].ev) (void)hipEventCreate(&e); }
+    }
+    struct { HostSlot* sl = nullptr; size_t i0 = 0, cnt = 0, k = 0; } prev;
     auto drain = [&]() -> int {
         HIPCHK(hipStreamWaitEvent(ctx->down, prev.sl->computed, 0));
+        mark(prev.k, 4, ctx->down);
         if (int rc = down(*prev.sl, prev.i0, prev.cnt)) return rc;
         HIPCHK(hipEventRecord(prev.sl->drained, ctx->down));
+        mark(prev.k, 5, ctx->down);
         return 0;
     };
     auto body = [&]() -> int {
@@ -1195,15 +1234,19 @@ static int host_pipeline(plume_ctx* ctx, size_t n, bool out_heavy, Up up, Run ru
             HostSlot& sl = ctx->slot[k % nslots];
             plume_ctx* on = (lane2 && (k & 1)) ? lane2 : ctx;
             if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.drained)); sl.in_flight = false; }   // the piece that used this slot last has left it
+            mark(k, 0, ctx->up);
             if (int rc = up(sl, i0, cnt)) return rc;
             HIPCHK(hipEventRecord(sl.ready, ctx->up));
+            mark(k, 1, ctx->up);
             HIPCHK(hipStreamWaitEvent(on->stream, sl.ready, 0));
+            mark(k, 2, on->stream);
             if (int rc = run(sl, cnt, on)) return rc;
             HIPCHK(hipEventRecord(sl.computed, on->stream));
+            mark(k, 3, on->stream);
             sl.in_flight = true;
             ctx->lane_last = on == ctx ? nullptr : on;
             if (prev.sl) { if (int rc = drain()) return rc; }
-            prev.sl = &sl; prev.i0 = i0; prev.cnt = cnt;
+            prev.sl = &sl; prev.i0 = i0; prev.cnt = cnt; prev.k = k;
             i0 += cnt;
         }
         if (prev.sl) { if (int rc = drain()) return rc; }
@@ -1211,6 +1254,22 @@ static int host_pipeline(plume_ctx* ctx, size_t n, bool out_heavy, Up up, Run ru
     };
     const int rc = body();
     quiesce(ctx);
+    if (trace) {
+        if (rc == 0) {
+            std::string out = "plume_host_trace: " + std::to_string(n) + " items in " + std::to_string(sched.size()) + " pieces" + (lane2 ? ", two lanes" : ", one lane") + "  (ms since the first upload began)\n";
+            for (size_t k = 0; k < tr.size(); k++) {
+                float t[6] = {0, 0, 0, 0, 0, 0};
+                for (int j = 0; j < 6; j++) (void)hipEventElapsedTime(&t[j], tr[0].ev[0], tr[k].ev[j]);
+                char line[256];
+                std::snprintf(line, sizeof line, "  piece %2zu lane %d %8zu items | up %7.3f -%7.3f | run %7.3f -%7.3f (%6.3f) | down %7.3f -%7.3f (%6.3f)\n", k, tr[k].lane, tr[k].cnt, t[0], t[1], t[2], t[3],
+                              t[3] - t[2], t[4], t[5], t[5] - t[4]);
+                out += line;
+            }
+            std::fputs(out.c_str(), stderr);
+        }
+        (void)hipGetLastError();
+        for (PieceTrace& p : tr) for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+    }
     if (rc == 0) HIPCHK(hipGetLastError());
     return rc;
 }
@@ -1228,6 +1287,12 @@ static int verify_host(plume_ctx* ctx, int version, int mode, bool sec1, size_t 
         pins.add(ctx, pk, P * n); pins.add(ctx, nullifier, P * n); pins.add(ctx, c, 32 * n); pins.add(ctx, s, 32 * n);
         if (pts) { pins.add(ctx, r_point, P * n); pins.add(ctx, hashed_to_curve_r, P * n); }
     }
+    // two lanes only when EVERY array of the call is page-locked: one pageable array is enough to send its copies through blit kernels, which queue behind the saturating
+    // kernels of two lanes and make the call slower than one lane would be (round 4 looked at pk and nullifier only)
+    bool all_locked = n > 0;
+    for (const void* a : {(const void*)pk, (const void*)nullifier, (const void*)c, (const void*)s, (const void*)ok, pts ? (const void*)r_point : (const void*)pk,
+                          pts ? (const void*)hashed_to_curve_r : (const void*)pk, (n && msg_off[n] > msg_off[0]) ? (const void*)(msgs + msg_off[0]) : (const void*)pk})
+        all_locked = all_locked && is_page_locked(a);
     return host_pipeline(
         ctx, n, false,
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
@@ -1250,7 +1315,7 @@ static int verify_host(plume_ctx* ctx, int version, int mode, bool sec1, size_t 
             return verify_device(on, version, mode, cnt, sl.msgs.as<uint8_t>(), sl.off.as<uint64_t>(), (size_t)sl.rel[cnt], sl.in[0].as<uint8_t>(), sl.in[1].as<uint8_t>(),
                                  sl.in[2].as<uint8_t>(), sl.in[3].as<uint8_t>(), rp, hp, sl.out[0].as<uint8_t>(), on->stream);
         },
-        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); }, n > 0 && is_page_locked(pk) && is_page_locked(nullifier));
+        [&](HostSlot& sl, size_t i0, size_t cnt) -> int { return d2h(ctx, ok + i0, sl.out[0], cnt); }, all_locked);
 }
 
 static int verify_host_any(plume_ctx* ctx, int version, int mode, bool sec1, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nullifier,
@@ -1366,6 +1431,11 @@ static int sign_host(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs,
         pins.add(ctx, sk, 32 * n); pins.add(ctx, r, 32 * n); pins.add(ctx, pk_in, 64 * n);
         pins.add(ctx, pk, P * n); pins.add(ctx, nullifier, P * n); pins.add(ctx, c, 32 * n); pins.add(ctx, s, 32 * n); pins.add(ctx, r_point, P * n); pins.add(ctx, hashed_to_curve_r, P * n);
     }
+    // two lanes (round 5) under the same condition as the verifier: every array of the call page-locked
+    bool sign_two_lanes = n > 0 && ctx->host_sign_lanes > 1;
+    for (const void* a : {(const void*)sk, (const void*)r, (const void*)nullifier, (const void*)c, (const void*)s, (const void*)r_point, (const void*)hashed_to_curve_r, (const void*)status,
+                          pk ? (const void*)pk : (const void*)sk, pk_in ? (const void*)pk_in : (const void*)sk, (n && msg_off[n] > msg_off[0]) ? (const void*)(msgs + msg_off[0]) : (const void*)sk})
+        sign_two_lanes = sign_two_lanes && is_page_locked(a);
     return host_pipeline(
         ctx, n, true,
         [&](HostSlot& sl, size_t i0, size_t cnt) -> int {
@@ -1396,7 +1466,7 @@ static int sign_host(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs,
             if (int rc = d2h(ctx, r_point + P * i0, sl.out[4], P * cnt)) return rc;
             if (int rc = d2h(ctx, hashed_to_curve_r + P * i0, sl.out[5], P * cnt)) return rc;
             return d2h(ctx, status + i0, sl.out[6], cnt);
-        });      // one lane: measured on the MI355X (round 4, tests/gpu_debug/host_sign_sweep.py) two lanes gain the signer nothing (19.98 vs 19.82 ms per 2^20) -- its call is bound by the 336 MB of outputs going down
+        }, sign_two_lanes);
 }
 static int sign_host_any(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r,
                          const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point, uint8_t* hashed_to_curve_r,
@@ -1519,19 +1589,8 @@ extern "C" int plume_scalars_to_sec1_der_batch(plume_ctx* ctx, size_t n, const u
 // plume_sec1_der_to_scalars_checked below is the function with the reference's semantics.  Host memory; no context needed.
 extern "C" int plume_sec1_der_to_scalars(size_t n, const uint8_t* der109, uint8_t* scalars, uint8_t* ok) {
     if (n && (!der109 || !scalars || !ok)) return fail(PLUME_ERR_ARG, "null array");
-    static const uint8_t head[7] = {0x30, 0x6b, 0x02, 0x01, 0x01, 0x04, 0x20}, mid[6] = {0xa1, 0x44, 0x03, 0x42, 0x00, 0x04};
-    static const uint8_t order[32] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFE,
-                                      0xBA, 0xAE, 0xDC, 0xE6, 0xAF, 0x48, 0xA0, 0x3B, 0xBF, 0xD2, 0x5E, 0x8C, 0xD0, 0x36, 0x41, 0x41};
-    for (size_t i = 0; i < n; i++) {
-        const uint8_t* d = der109 + PLUME_DER_LEN * i;
-        bool good = std::memcmp(d, head, 7) == 0 && std::memcmp(d + 39, mid, 6) == 0;
-        bool nz = false;
-        for (int j = 0; j < 32; j++) nz = nz || d[7 + j] != 0;
-        good = good && nz && std::memcmp(d + 7, order, 32) < 0;
-        std::memcpy(scalars + 32 * i, d + 7, 32);
-        if (!good) std::memset(scalars + 32 * i, 0, 32);
-        ok[i] = good ? 1 : 0;
-    }
+    static_assert(plume_host::kDerLen == PLUME_DER_LEN, "record length");
+    plume_host::sec1_der_to_scalars(n, der109, scalars, ok);
     return 0;
 }
 // SecretKey::from_sec1_der as the reference performs it (elliptic-curve's TryFrom<EcPrivateKey>: the embedded public key must be scalar * G, or the result is Err):
@@ -1553,12 +1612,7 @@ extern "C" int plume_sec1_der_to_scalars_checked(plume_ctx* ctx, size_t n, const
 // host form of the register packing: a byte reversal, done on the host (no reason to cross PCIe for it)
 extern "C" int plume_registers_from_be(size_t nvalues, const uint8_t* be32, uint64_t* registers) {
     if (nvalues && (!be32 || !registers)) return fail(PLUME_ERR_ARG, "null array");
-    for (size_t k = 0; k < nvalues; k++)
-        for (int j = 0; j < 4; j++) {
-            uint64_t v = 0;
-            for (int b = 0; b < 8; b++) v = (v << 8) | be32[32 * k + 8 * (3 - j) + b];
-            registers[4 * k + j] = v;
-        }
+    plume_host::registers_from_be(nvalues, be32, registers);
     return 0;
 }
 
