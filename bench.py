@@ -110,6 +110,58 @@ def pmc_issue(kernel: str, build: str):
         return None
 
 
+# frozen accounting per stage: Fp-multiplications per V1 / V2 verify, and the kernels each stage launches (tables: three inversion launches)
+STAGE_FPMUL = {"verify_ingest_h2c": 634, "verify_scalars": 0, "tables": 381, "verify_msm": FPMUL_MSM_PER_ITEM, "to_affine": 0, "verify_finalize": 282}
+STAGE_KERNELS = {"verify_ingest_h2c": [("plume::k_verify_ingest", 1)], "verify_scalars": [("plume::k_verify_scalars", 1)],
+                 "tables": [("plume::k_tab_pass_a", 1), ("plume::k_tab_pass_b", 1), ("plume::k_tab_pass_c", 1), ("plume::k_tab_pass_d", 1), ("plume::k_tab_invert", 3)],
+                 "verify_msm": [("plume::k_verify_msm", 1)], "verify_finalize": [("plume::k_verify_finalize", 1)]}
+
+
+def stage_roofline(stages: dict, n: int, mad_rate: float, build: str):
+    """Every stage of the step against both roofs: the integer-VALU roof in the frozen accounting's multiply-adds (Fp-mult x 72 x items / stage time / this
+    run's probe) and in ISSUED VALU instructions (the committed counter pass: SQ_INSTS_VALU x 64 lanes / time / probe -- every instruction priced as a multiply-add slot), and
+    the HBM roof (counter bytes: 2 x FETCH_SIZE + WRITE_SIZE of the stage's kernels / time / 8 TB/s).  The counters are per 2^20-item launch of the committed summary
+    (profiles/rNN_pmc_summary.json; `same_build` says whether they were collected from these kernels), scaled to this batch; the times are this run's."""
+    try:
+        f = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))[-1]
+        j = json.loads(f.read_text())
+    except Exception:
+        j, f = {}, None
+    out = {"_source": f"profiles/{f.name}" if f else None, "_same_build": bool(j) and j.get("_build") == build,
+           "_note": "valu_mac_frac: accounted multiply-adds / time / probe; valu_issue_frac: issued VALU wave-instructions x 64 / time / probe (1.0 = every issue slot taken by something "
+                    "priced as a multiply-add; plain ops issue faster, so a saturated mixed kernel reads ~0.95-1.0); hbm_frac: (2 x FETCH_SIZE + WRITE_SIZE) / time / 8 TB/s"}
+    scale = n / float(1 << 20)
+    for name, ms in stages.items():
+        if not ms or name not in STAGE_KERNELS:
+            continue
+        sec = ms * 1e-3
+        e = {"ms": ms, "accounted_fp_mult_per_item": STAGE_FPMUL.get(name, 0)}
+        if mad_rate and STAGE_FPMUL.get(name):
+            e["valu_mac_frac"] = round(STAGE_FPMUL[name] * MACS_PER_FPMUL * n / sec / mad_rate, 4)
+        insts = byts = 0.0
+        have = True
+        res = {}
+        for k, times in STAGE_KERNELS[name]:
+            d = j.get(k)
+            if not d or "SQ_INSTS_VALU" not in d:
+                have = False
+                break
+            insts += times * d["SQ_INSTS_VALU"]
+            byts += times * (FETCH_SIZE_FACTOR * d.get("FETCH_SIZE_KB_raw", 0.0) + d.get("WRITE_SIZE_KB_raw", 0.0)) * 1024
+            res[k.split("::")[1]] = {"vgpr": d.get("_vgpr"), "scratch_B_per_lane": d.get("_scratch"), "lds_B": d.get("_lds"), "VALUBusy": d.get("VALUBusy")}
+        if have:
+            if mad_rate:
+                e["valu_issue_frac"] = round(insts * 64 * scale / sec / mad_rate, 4)
+            e["valu_insts_per_item"] = round(insts * 64 / float(1 << 20), 1)
+            e["hbm_bytes_per_item"] = round(byts / float(1 << 20), 1)
+            e["hbm_GBps"] = round(byts * scale / sec / 1e9, 1)
+            e["hbm_frac"] = round(byts * scale / sec / 1e9 / HBM_PEAK_GBS, 4)
+            e["bound"] = "hbm" if e["hbm_frac"] > e.get("valu_issue_frac", 0) else "int-valu issue"
+            e["kernels"] = res
+        out[name] = e
+    return out
+
+
 def shard_bounds(total: int, rank: int, world: int):
     """contiguous even split [floor(r*T/W), floor((r+1)*T/W)) — SURVEY.md §8e"""
     return (total * rank) // world, (total * (rank + 1)) // world
@@ -726,6 +778,11 @@ def main():
                 line["roofline"]["frac_in_timed_region"] = round(dom_fpmul * MACS_PER_FPMUL * n / (kin * 1e-3) / mad_rate, 4)
                 line["roofline"]["note"] = (f"kernel_ms / frac: the serial pass (one call after the other).  In the timed region {F} batches are in flight and the kernels of the streams share the "
                                             "SIMDs: launches are stretched while the step gets shorter (kernel_ms_in_timed_region: the LAST call's launch, the one figure the library's stage events of a lane keep)")
+            if not sign:
+                try:
+                    line["stage_roofline"] = stage_roofline(stages, n, mad_rate if mad_measured else None, eng.version())
+                except Exception as e:
+                    line["stage_roofline"] = {"error": str(e)[:200]}
             line["hbm_view"] = {"bound": "hbm", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(hbm_achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": bytes_item * n,
                                 "traffic": round(traffic_bytes / dom_s / 1e9, 1) if traffic_bytes else None, "traffic_bytes_per_launch": traffic_bytes,

@@ -85,6 +85,7 @@ extern "C" {
     fn plume_set_sign_uniform(ctx: *mut plume_ctx, level: c_int) -> c_int;
     fn plume_get_sign_uniform(ctx: *const plume_ctx) -> c_int;
     fn plume_set_host_lanes(ctx: *mut plume_ctx, lanes: c_int) -> c_int;
+    fn plume_set_eq1_short(ctx: *mut plume_ctx, mode: c_int) -> c_int;
     fn plume_shard_numa_node(ctx: *const plume_ctx, shard: c_int) -> c_int;
     fn plume_aggregate_check(ctx: *mut plume_ctx, version: c_int, mode: c_int, n: usize, msgs: *const u8, msg_off: *const u64, pk: *const u8, nullifier: *const u8, c: *const u8,
                              s: *const u8, r_point: *const u8, hashed_to_curve_r: *const u8, seed: *const u8, hash_ok: *mut u8, result: *mut u8) -> c_int;
@@ -283,6 +284,8 @@ impl HipEngine {
     pub fn set_sub_batches(&self, k: i32) -> Result<(), HipError> { if unsafe { plume_set_sub_batches(self.0, k) } == 0 { Ok(()) } else { Err(last_error()) } }
     /// Batches in flight (`plume_set_in_flight`): with 2, device-resident calls issued on different streams run side by side (two lanes of the context); default 1
     pub fn set_in_flight(&self, k: i32) -> Result<(), HipError> { if unsafe { plume_set_in_flight(self.0, k) } == 0 { Ok(()) } else { Err(last_error()) } }
+    /// The verifier's first equation where `r_point` is given (`plume_set_eq1_short`): 1 = the short form (default), 0 = the long form always, 2 = test mode.  Verdicts do not depend on it.
+    pub fn set_eq1_short(&self, mode: i32) -> Result<(), HipError> { if unsafe { plume_set_eq1_short(self.0, mode as c_int) } == 0 { Ok(()) } else { Err(last_error()) } }
     /// The level this context signs at (`plume_get_sign_uniform`).
     pub fn sign_uniform(&self) -> Result<i32, HipError> { let l = unsafe { plume_get_sign_uniform(self.0) }; if l >= 0 { Ok(l as i32) } else { Err(last_error()) } }
     /// Host-pointer calls: 1 = every piece on the context itself, 2 (default) = pieces alternate between the context and a second lane.

@@ -67,6 +67,7 @@ class Engine {
     void set_sign_uniform(int level) { check(plume_set_sign_uniform(ctx_, level), "plume_set_sign_uniform"); }
     int sign_uniform() const { const int l = plume_get_sign_uniform(ctx_); check(l < 0 ? l : 0, "plume_get_sign_uniform"); return l; }   // 1 by default (library 0.4)
     void set_host_lanes(int lanes) { check(plume_set_host_lanes(ctx_, lanes), "plume_set_host_lanes"); }
+    void set_eq1_short(int mode) { check(plume_set_eq1_short(ctx_, mode), "plume_set_eq1_short"); }   // the verifier's first equation where R is given (plume_hip.h): 1 short (default), 0 long, 2 test
     // the engine single-item calls use when none is passed: PLUME_DEVICES="0,1,.." (one multi-device context) or device 0
     static Engine& shared() {
         static std::unique_ptr<Engine> e;

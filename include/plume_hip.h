@@ -69,7 +69,7 @@ int plume_shard_numa_node(const plume_ctx* ctx, int shard);
 void plume_destroy(plume_ctx* ctx);
 /* Last error text of this thread (valid until the next failing call on the thread). */
 const char* plume_last_error(void);
-/* Library / build information: "plume_hip <major.minor> gfx950 build=<hash of the device sources>".  0.4 (round 5): plume_get_sign_uniform, plume_set_host_lanes;
+/* Library / build information: "plume_hip <major.minor> gfx950 build=<hash of the device sources>".  0.4 (round 5): plume_get_sign_uniform, plume_set_host_lanes, plume_set_eq1_short;
  * the signer defaults to uniform level 1; the generator tables are built by the first call that needs them; stream = NULL means the stream of the context the caller
  * holds; plume_destroy waits for the context's own work only (its last call on any stream and its private streams), not for the whole device. */
 const char* plume_version(void);
@@ -107,6 +107,14 @@ int plume_set_in_flight(plume_ctx* ctx, int batches);
 int plume_set_sign_uniform(plume_ctx* ctx, int level);
 /* the level this context signs at (0, 1, 2), or a negative error code */
 int plume_get_sign_uniform(const plume_ctx* ctx);
+/* The verifier's first equation, R' = s G - c pk compared with the given r_point (rust-k256/src/lib.rs:101,115-121), for calls that GIVE r_point as a 64-byte record (V1
+ * verify, verify_non_zk).  It is an identity check, so it may be multiplied by any tau != 0: with (tau, upsilon) from a half-GCD of c in the Eisenstein integers
+ * (tau c = upsilon mod n through lambda; all four coefficients of about 64 bits -- csrc/plume_eis.h) the GPU checks  k G - upsilon pk - (tau - 1) R == R,  k = tau s mod n:
+ * 64 doublings instead of 128 on that equation, the generator's term from the signer's comb, one more window table per item (R).  Verdicts are identical by construction
+ * (the equivalence is exact, not probabilistic); mode 1 (default) = short form for calls of at least 2^17 items, 3 = for calls of any size, 0 = long form always,
+ * 2 = test mode (every item takes the scalar stage's fallback: the long form in the checked chain of the redo launch).  Env PLUME_EQ1_SHORT, PLUME_EQ1_SHORT_MIN.  Measured on the MI355X, 2^20 V1 verifies:
+ * k_verify_msm -7.2 %, the step -1 % serial / -1.6 % with two batches in flight (the fourth table and the half-GCD take most of it back: DESIGN.md). */
+int plume_set_eq1_short(plume_ctx* ctx, int mode);
 /* Environment knobs read when a context is created (tuning and A/B runs; results never depend on them):
  *   PLUME_SUB_BATCHES, PLUME_SERIAL, PLUME_OVERLAP_MIN   sub-batch overlap of the device-resident calls (plume_set_sub_batches)
  *   PLUME_HOST_PIECE, PLUME_HOST_FIRST_PIECE, PLUME_HOST_TAIL_PIECE, PLUME_HOST_REGISTER_MIN, PLUME_HOST_LANES (1 | 2), PLUME_HOST_SCHEDULE (explicit piece list, read per call)
@@ -116,6 +124,7 @@ int plume_get_sign_uniform(const plume_ctx* ctx);
  *                            i.e. verify calls of up to 32768 items and sign calls of up to 49152; 0: never)
  *   PLUME_JOBS_PER_LANE      jobs per lane of the affine table passes (default: 3..6 by batch size)
  *   PLUME_SIGN_UNIFORM       default level of plume_set_sign_uniform (0, 1, 2; default 1)
+ *   PLUME_EQ1_SHORT, PLUME_EQ1_SHORT_MIN   plume_set_eq1_short's mode and the smallest call that takes the short form (default 1, 131072)
  *   PLUME_NO_AFFINITY        multi-device contexts: leave the shard threads' CPU affinity alone */
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (an upload, a download and the compute streams,
  * four staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each following piece up to three times

@@ -226,6 +226,34 @@ def eq1(s: bytes, c: bytes, pk: bytes):
     return bytes(out) if ok else None
 
 
+def set_eq1_short(v):
+    """the verifier's first equation where R is given: 1 = short form (plume_eis.h, the default), 0 = long form always, 2 = every item takes the scalar stage's fallback
+    (filed as long form, run by the checked chain of the redo launch)"""
+    lib().ds_set_eq1_short(C.c_int(int(v)))
+
+
+def eis_half_gcd(cs):
+    """the half-GCD in Z[w] for a list of challenges (ints mod n): [(t0 - 1, t1, u0, u1, tau mod n, ok)]"""
+    m = len(cs)
+    cb = np.frombuffer(b"".join(int(c).to_bytes(32, "big") for c in cs), dtype=np.uint8).copy()
+    out, tau, ok = np.zeros(64 * m, np.uint8), np.zeros(32 * m, np.uint8), np.zeros(m, np.uint8)
+    lib().ds_eis_half_gcd(C.c_uint32(m), _p(cb), _p(out), _p(tau), _p(ok))
+    res = []
+    for i in range(m):
+        v = [int.from_bytes(out[64 * i + 16 * k:64 * i + 16 * k + 16].tobytes(), "little", signed=True) for k in range(4)]
+        res.append((v[0], v[1], v[2], v[3], int.from_bytes(tau[32 * i:32 * i + 32].tobytes(), "big"), bool(ok[i])))
+    return res
+
+
+def eq1_short(s: bytes, c: bytes, pk: bytes, r: bytes):
+    """k G - upsilon pk - (tau - 1) R through the scalar stage, the table stage and the multi-scalar body; (64 bytes | None, the scalar stage fell back to the long form)"""
+    out = (C.c_uint8 * 64)()
+    lng = C.c_int(0)
+    ok = lib().ds_eq1_short((C.c_uint8 * 32).from_buffer_copy(s), (C.c_uint8 * 32).from_buffer_copy(c), (C.c_uint8 * 64).from_buffer_copy(pk), (C.c_uint8 * 64).from_buffer_copy(r), out,
+                            C.byref(lng))
+    return (bytes(out) if ok else None), bool(lng.value)
+
+
 def fallback_count():
     """multi-scalar chains redone with checked additions so far (p == +-q met inside an unchecked chain)"""
     lib().ds_fallback_count.restype = C.c_ulong

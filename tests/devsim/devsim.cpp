@@ -220,6 +220,8 @@ uint32_t ds_tab_entries() { return PLUME_TAB_ENTRIES; }     // rows per window t
 // simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)
 static const uint32_t B = 8;
 
+static int g_eq1_short = 1;      // mirrors ctx->eq1_short (plume_capi.hip): 0 = long form always, 1 = short form where R is given, 2 = every item takes the fallback (long form through the checked chain)
+void ds_set_eq1_short(int v) { g_eq1_short = v; }
 static int g_ingest_two_roles = 0;
 void ds_set_ingest_two_roles(int on) { g_ingest_two_roles = on; }      // the verify harness then runs the ingest stage in its two-role form
 static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
@@ -256,9 +258,12 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
                        uint64_t msgs_bytes) {
     if (version != 1 && version != 2) return -1;
     std::vector<uint32_t> gtab; build_gtab(gtab);
-    std::vector<uint32_t> bases(PLUME_BASE_WORDS * 3 * (size_t)n), tab((size_t)3 * n * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2 * (size_t)n);
-    std::vector<uint8_t> jobflags(3 * (size_t)n), itemflags(n), resinf(2 * (size_t)n);
+    const bool eq1short = g_eq1_short != 0 && rpt != nullptr && rpt33 == nullptr && (version == 1 || mode == PLUME_MODE_NON_ZK);          // mirrors verify_device
+    const size_t J = eq1short ? 4 : 3;
+    std::vector<uint32_t> bases(PLUME_BASE_WORDS * J * (size_t)n), tab((size_t)J * n * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2 * (size_t)n), eq1k(8 * (size_t)n + 1);
+    std::vector<uint8_t> jobflags(J * (size_t)n), itemflags(n), resinf(2 * (size_t)n), eq1long(n + 1);
     VerifyArgs a; memset(&a, 0, sizeof a);
+    if (eq1short) { a.eq1long = eq1long.data(); a.eq1k = eq1k.data(); a.gcomb = shared_gcomb().data(); a.eq1force = g_eq1_short == 2 ? 1 : 0; }
     a.mode = mode; a.msgs_bytes = msgs_bytes == ~0ull ? msg_off[n] : msgs_bytes;
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags; a.rpt33 = rpt33; a.hr33 = hr33;
     a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data(); a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data();
@@ -276,7 +281,8 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     } else {
         for (uint32_t i = 0; i < n; i++) verify_ingest_h2c(a, i);
     }
-    const size_t nj = 3 * (size_t)n;
+    for (uint32_t i = 0; i < n; i++) verify_scalars(a, i);
+    const size_t nj = J * (size_t)n;
     run_tables(a.tab, a.bases, a.jobflags, nj, L);
     std::vector<int8_t> dig(4 * PLUME_NDIG * B);
     std::vector<uint32_t> redo(2 * (size_t)n + 1, 0);
@@ -462,8 +468,67 @@ int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[6
     for (int j = 0; j < 3; j++) { st_base(a.bases, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
     run_tables(a.tab, a.bases, a.jobflags, 3, 3);
     std::vector<int8_t> dig(4 * PLUME_NDIG), digs(PLUME_VDIG_ROWS);
-    { sc sv, cv; sc_from_be_aligned(sv, sb); sc_from_be_aligned(cv, cb); verify_item_digits(digs.data(), 1, sv, cv); }     // what the ingest kernel leaves for the item
+    { sc sv, cv; sc_from_be_aligned(sv, sb); sc_from_be_aligned(cv, cb); verify_item_digits(digs.data(), 1, sv, cv, true); }     // what the scalar stage leaves for the item (long form)
     a.digs = digs.data();
+    uint32_t redo[3] = {0, 0, 0};
+    a.redo = redo;
+    verify_msm<false>(a, 0, 0, a.gtab, dig.data(), 1);
+    if (redo[0]) verify_msm<true>(a, 0, 0, a.gtab, dig.data(), 1);
+    jac r; ld_jac_soa(r, a.res, 2, 0); r.inf = a.resinf[0];
+    fe ox = fe_zero(), oy = fe_zero();
+    if (!r.inf) { fe zi, zi2; fe_inv(zi, r.z); fe_sqr(zi2, zi); fe_mul(ox, r.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(oy, r.y, zi2); }
+    store_affine_be(ob, ox, oy, r.inf != 0);
+    memcpy(out, ob, 64);
+    return 1;
+}
+
+// the half-GCD in Z[w] (plume_eis.h) for n challenges c (32-byte big-endian, canonical): out[i] = t0 - 1, t1, u0, u1 as signed 128-bit little-endian integers (4 x 16 bytes),
+// tau[i] = t0 + t1 lambda mod n (32 bytes BE), okf[i] = the bound flag
+int ds_eis_half_gcd(uint32_t n, const uint8_t* c_be, uint8_t* out, uint8_t* tau_be, uint8_t* okf) {
+    for (uint32_t i = 0; i < n; i++) {
+        alignas(16) uint8_t cb[32], tb[32];
+        memcpy(cb, c_be + 32 * (size_t)i, 32);
+        sc c; sc_from_be_aligned(c, cb);
+        eis_short e;
+        eis_half_gcd(e, c);
+        const uint32_t (*mags[4])[3] = {&e.t[0], &e.t[1], &e.u[0], &e.u[1]};
+        const uint32_t negs[4] = {e.tneg[0], e.tneg[1], e.uneg[0], e.uneg[1]};
+        for (int k = 0; k < 4; k++) {
+            __int128 v = 0;
+            for (int w = 2; w >= 0; w--) v = (v << 32) | (*mags[k])[w];
+            if (negs[k]) v = -v;
+            memcpy(out + 64 * (size_t)i + 16 * k, &v, 16);
+        }
+        sc_to_be_aligned(tb, e.tau);
+        memcpy(tau_be + 32 * (size_t)i, tb, 32);
+        okf[i] = e.ok ? 1 : 0;
+    }
+    return 0;
+}
+// equation 1 in its SHORT form for one item: returns k G - upsilon pk - (tau - 1) R (which a valid signature makes equal to R) through verify_scalars, the table stage
+// and the multi-scalar body; *used_long = the scalar stage fell back to the long form
+int ds_eq1_short(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[64], const uint8_t r_be[64], uint8_t out[64], int* used_long) {
+    std::vector<uint32_t> gtab; build_gtab(gtab);
+    alignas(16) uint8_t sb[32], cb[32], pb[64], rb[64], ob[64];
+    memcpy(sb, s_be, 32); memcpy(cb, c_be, 32); memcpy(pb, pk_be, 64); memcpy(rb, r_be, 64);
+    fe x, y, rx, ry;
+    const uint32_t f = load_affine_be(x, y, pb), fr = load_affine_be(rx, ry, rb);
+    if (f == PLUME_JOB_INVALID || fr == PLUME_JOB_INVALID) return 0;
+    std::vector<uint32_t> bases(PLUME_BASE_WORDS * 4), tab(4 * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2), eq1k(8);
+    std::vector<uint8_t> jobflags(4), itemflags(1, 0), resinf(2), eq1long(1);
+    VerifyArgs a; memset(&a, 0, sizeof a);
+    a.version = 1; a.mode = PLUME_MODE_VERIFY; a.n = 1; a.c = cb; a.s = sb; a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
+    a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data(); a.gtab = gtab.data(); a.gcomb = shared_gcomb().data(); a.eq1long = eq1long.data(); a.eq1k = eq1k.data();
+    a.eq1force = g_eq1_short == 2 ? 1 : 0;
+    jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
+    for (int j = 0; j < 3; j++) { st_base(a.bases, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
+    p.x = rx; p.y = ry;
+    st_base(a.bases, 3, p); a.jobflags[3] = (uint8_t)(fr | PLUME_JOB_AFFINE);
+    run_tables(a.tab, a.bases, a.jobflags, 4, 4);
+    std::vector<int8_t> dig(4 * PLUME_NDIG), digs(PLUME_VDIG_ROWS);
+    a.digs = digs.data();
+    verify_scalars(a, 0);
+    if (used_long) *used_long = eq1long[0];
     uint32_t redo[3] = {0, 0, 0};
     a.redo = redo;
     verify_msm<false>(a, 0, 0, a.gtab, dig.data(), 1);

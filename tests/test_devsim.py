@@ -679,3 +679,103 @@ def test_twenty_bit_generator_window_build_of_the_device_headers(tmp_path):
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", str(Path(__file__)), "-k", "wide or golden_verify or equation1 or crafted"],
                        env=dict(os.environ, PLUME_DEVSIM_SO=str(so)), capture_output=True, text=True, cwd=str(ROOT))
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])
+
+
+# ------------------------------------------------------------------------------------------------ round 5: the short form of equation 1 (csrc/plume_eis.h)
+_LAM = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+
+
+def _eis_cases(rng, nrand):
+    n = O.N
+    a1, b1 = 0x3086D221A7D46BCDE86C90E49284EB15, 0xE4437ED6010E88286F547FA90ABFE4C3
+    cs = [0, 1, 2, 3, n - 1, n - 2, _LAM, _LAM + 1, _LAM * _LAM % n, 2**128, 2**64, 2**64 + 1, 2**65, 2**96, 2**127, 2**192, (n - 1) // 2, (n + 1) // 2, a1, b1, n - a1, n - b1]
+    cs += [(x + y * _LAM) % n for x in (1, 2**63, 2**64, 2**65, 2**66, -2**64, 3 * 2**62) for y in (0, 1, -1, 2**63, 2**64, -2**65)]      # short on the gamma side already
+    cs += [pow(rng.randrange(2, 2**70), -1, n) for _ in range(100)]                                                                       # tau short, upsilon = 1
+    cs += [rng.randrange(1, 2**66) * pow(rng.randrange(1, 2**66), -1, n) % n for _ in range(100)]                                      # both short: the answer is (nearly) unique
+    cs += [rng.getrandbits(k) % n for k in (8, 16, 32, 64, 96, 127, 129, 160, 200) for _ in range(10)]
+    cs += [rng.randrange(1, n) for _ in range(nrand)]
+    return [c % n for c in cs]
+
+
+def test_eis_half_gcd_relation_and_bounds():
+    """tau gamma = upsilon (mod pi) for every c -- i.e. (t0 + t1 lambda) c = u0 + u1 lambda (mod n) --, tau != 0, every coefficient below 2^67 (in fact <= 65 bits: the chain
+    has seventeen 4-bit windows), no fallback; random and crafted challenges, c = 0 included (verify_non_zk admits it).  The quotients are double-precision estimates: the
+    RELATION holds whatever they are, the BOUND is what this test measures."""
+    rng = random.Random(20261002)
+    cs = _eis_cases(rng, 20000)
+    worst = 0
+    for c, (tm1, t1, u0, u1, tau, ok) in zip(cs, D.eis_half_gcd(cs)):
+        t0 = tm1 + 1
+        assert tau == (t0 + t1 * _LAM) % O.N and tau != 0
+        assert (tau * c - (u0 + u1 * _LAM)) % O.N == 0, hex(c)
+        assert ok, hex(c)
+        worst = max(worst, abs(tm1), abs(t1), abs(u0), abs(u1))
+    assert worst.bit_length() <= 66, worst.bit_length()
+
+
+def test_equation1_short_form_value_and_fallback():
+    """the chain of the short form -- scalar stage, four tables, 64 doublings, the comb -- returns k G - upsilon pk - (tau - 1) R: checked through its meaning (for ANY s, c,
+    pk, R it equals R + tau (s G - c pk - R)), which a valid signature turns into R itself.  Crafted scalars; the forced fallback (long form in the checked chain) gives the
+    long form's value s G - c pk."""
+    rng = random.Random(7)
+    n = O.N
+    G = O.G
+    be = lambda p: p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")  # noqa: E731
+    cases = []
+    for c in _eis_cases(rng, 24)[1:]:
+        if c == 0:
+            continue
+        sk, r = rng.randrange(1, n), rng.randrange(1, n)
+        cases.append((sk, r, c, True))
+        cases.append((sk, r, c, False))
+    try:
+        for sk, r, c, valid in cases[:160]:
+            pk = O.pt_mul(sk, G)
+            s = (r + sk * c) % n if valid else rng.randrange(1, n)
+            R = O.pt_mul(r, G)
+            if s == 0:
+                continue
+            got, lng = D.eq1_short(s.to_bytes(32, "big"), c.to_bytes(32, "big"), be(pk), be(R))
+            assert not lng
+            tau = D.eis_half_gcd([c])[0][4]
+            # R + tau (s G - c pk - R)
+            e = O.pt_add(O.pt_add(O.pt_mul(s, G), O.pt_neg(O.pt_mul(c, pk))), O.pt_neg(R))
+            want = O.pt_add(R, O.pt_mul(tau, e)) if e is not None else R
+            assert got == (be(want) if want is not None else bytes(64)), (hex(c), valid)
+            if valid:
+                assert got == be(R)
+        D.set_eq1_short(2)
+        for sk, r, c, valid in cases[:24]:
+            pk = O.pt_mul(sk, G)
+            s = (r + sk * c) % n
+            R = O.pt_mul(r, G)
+            got, lng = D.eq1_short(s.to_bytes(32, "big"), c.to_bytes(32, "big"), be(pk), be(R))
+            assert lng and got == be(R)                       # the long form's value: s G - c pk
+    finally:
+        D.set_eq1_short(1)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_verdicts_do_not_depend_on_the_form_of_equation1(mode):
+    """the golden batches, the edge cases and a fuzzed batch (V1 verify, verify_non_zk V1 and V2) with the short form off (0) and with every item forced through the fallback
+    (2) -- the default (1) is what every other test of this file runs"""
+    from tests import _fuzz
+    try:
+        D.set_eq1_short(mode)
+        for items in (GOLD["verify_v1"][:48], [e for e in GOLD["edge"] if e["version"] == 1]):
+            mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+            got = D.verify_batch(1, mb, off, OC.arr(items, "pk", 64), OC.arr(items, "nullifier", 64), OC.arr(items, "c", 32), OC.arr(items, "s", 32), OC.arr(items, "r_point", 64),
+                                 OC.arr(items, "hashed_to_curve_r", 64))
+            assert [int(x) for x in got] == [it["ok"] for it in items]
+        n = 96
+        b = synth.sign_inputs(n, start=4242)
+        for ver in (1, 2):
+            signed = OC.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"], nthreads=8)
+            v = _fuzz.fuzz_verify_batch(ver, signed, b, seed=31 + ver)
+            if ver == 1:
+                args = (1, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"])
+                assert np.array_equal(D.verify_batch(*args), OC.verify_batch(*args, nthreads=8))
+            nz = (ver, b["msgs"], b["off"], signed["pk"], signed["nullifier"], signed["s"], signed["r_point"], signed["hashed_to_curve_r"], signed["c"])
+            assert np.array_equal(D.verify_non_zk_batch(*nz), OC.verify_non_zk_batch(*nz, nthreads=8))
+    finally:
+        D.set_eq1_short(1)

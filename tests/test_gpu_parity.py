@@ -244,7 +244,7 @@ def test_device_resident_api_matches_host_api(eng):
     torch.cuda.synchronize()
     assert bool(ok.all())
     st = eng.last_stage_times()
-    assert [s for s, _ in st] == ["verify_ingest_h2c", "tables", "verify_msm", "verify_finalize"] and all(ms > 0 for _, ms in st)
+    assert [s for s, _ in st] == ["verify_ingest_h2c", "verify_scalars", "tables", "verify_msm", "verify_finalize"] and all(ms > 0 for _, ms in st)
 
 
 def test_empty_batch(eng):

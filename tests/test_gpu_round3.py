@@ -231,7 +231,7 @@ def test_stage_times_serial_and_overlapped(eng):
         eng.set_sub_batches(1)
         eng.verify_batch_device(*a); torch.cuda.synchronize()
         serial = dict(eng.last_stage_times())
-        assert list(serial) == ["verify_ingest_h2c", "tables", "verify_msm", "verify_finalize"] and bool(ok.all())
+        assert list(serial) == ["verify_ingest_h2c", "verify_scalars", "tables", "verify_msm", "verify_finalize"] and bool(ok.all())
         eng.set_sub_batches(4)
         ok.zero_()
         eng.verify_batch_device(*a); torch.cuda.synchronize()
@@ -344,10 +344,24 @@ def test_crafted_items_are_redone_by_the_second_launch_and_cost_only_themselves(
     v["s"][idx] = 0; v["s"][idx, 31] = d
     minus = idx[::2]                                          # s = -c: the p == q case (the result is 2d*G), the others p == -q (identity)
     v["s"][minus] = np.frombuffer(b"".join((N - int(x)).to_bytes(32, "big") for x in d[::2]), dtype=np.uint8).reshape(-1, 32)
-    got, redone = run(v)
-    assert redone >= len(idx), (redone, len(idx))
     want = CF.verify_batch(1, b["msgs"], b["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"], nthreads=THREADS)
-    assert np.array_equal(got, want) and int(got.sum()) == n - len(idx)
+    try:
+        eng.set_eq1_short(0)                                  # the items are crafted against the LONG form of equation 1 (s G - c pk along one chain of 128 doublings)
+        got, redone = run(v)
+        assert redone >= len(idx), (redone, len(idx))
+        assert np.array_equal(got, want) and int(got.sum()) == n - len(idx)
+    finally:
+        eng.set_eq1_short(1)
+    got, redone = run(v)                                      # round 5: the short form (other coefficients: whatever collides there is filed the same way)
+    assert np.array_equal(got, want)
+    # ... and crafted against the SHORT form: pk = R, so that the chain adds rows of two equal tables -- equal digits at the top window meet p == q in the first addition
+    v2 = {k: sg[k].copy() for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+    v2["pk"][idx] = v2["r_point"][idx]
+    neg = idx[1::2]                                           # ... or pk = -R: p == -q
+    v2["pk"][neg, 32:] = np.frombuffer(b"".join((O.P - int.from_bytes(v2["r_point"][i, 32:].tobytes(), "big")).to_bytes(32, "big") for i in neg), dtype=np.uint8).reshape(-1, 32)
+    got, redone = run(v2)
+    want = CF.verify_batch(1, b["msgs"], b["off"], v2["pk"], v2["nullifier"], v2["c"], v2["s"], v2["r_point"], v2["hashed_to_curve_r"], nthreads=THREADS)
+    assert np.array_equal(got, want) and redone > len(idx) // 64, redone
 
 
 def test_contexts_of_one_device_share_the_fixed_tables_and_outlive_each_other(eng):

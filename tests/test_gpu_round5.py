@@ -212,3 +212,40 @@ def test_one_pageable_array_among_page_locked_ones(eng):
         assert np.array_equal(call(mixed, capi.pinned_empty(n)), want), odd
     assert np.array_equal(call(vp, np.empty(n, np.uint8)), want)         # pageable verdict array
     assert np.array_equal(call(v, np.empty(n, np.uint8)), want)
+
+
+@pytest.mark.parametrize("mode", [3, 2, 0])
+def test_equation1_short_form_gives_the_long_forms_verdicts(eng, mode):
+    """csrc/plume_eis.h: calls that give R check  k G - upsilon pk - (tau - 1) R == R  instead of  s G - c pk == R.  The golden batch, the 102 edge cases and a fuzzed
+    2^17-item batch (V1 verify; verify_non_zk V1 and V2) with the short form forced for every size (3), with every item sent through the scalar stage's fallback (2) and
+    with the long form (0): the verdicts of the C oracle each time."""
+    import json as _json
+    from tests import _fuzz
+    gold = _json.loads((ROOT / "tests" / "golden" / "golden_batches.json").read_text())
+    try:
+        eng.set_eq1_short(mode)
+        for items in (gold["verify_v1"], [e for e in gold["edge"] if e["version"] == 1]):
+            mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+            got = eng.verify_batch(1, mb, off, OC.arr(items, "pk", 64), OC.arr(items, "nullifier", 64), OC.arr(items, "c", 32), OC.arr(items, "s", 32), OC.arr(items, "r_point", 64),
+                                   OC.arr(items, "hashed_to_curve_r", 64))
+            assert [int(x) for x in got] == [it["ok"] for it in items]
+        n = (1 << 17) + 5 if mode != 2 else 20_011
+        b = synth.sign_inputs(n, start=26_000_000)
+        for ver in (1, 2):
+            sg = eng.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+            idx = _sample(n, 3000, 91 + ver)
+            sub, sub_off = _sub_msgs(b["msgs"], idx)
+            if ver == 1:
+                v = _fuzz.fuzz_verify_batch(1, sg, b, seed=51)
+                got = eng.verify_batch(1, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"])
+                vs, vso = _sub_msgs(v["msgs"], idx)
+                want = OC.verify_batch(1, vs, vso, v["pk"][idx], v["nullifier"][idx], v["c"][idx], v["s"][idx], v["r_point"][idx], v["hashed_to_curve_r"][idx], nthreads=16)
+                assert np.array_equal(got[idx], want) and 0 < int(got.sum()) < n
+            nz = eng.verify_non_zk_batch(ver, b["msgs"], b["off"], sg["pk"], sg["nullifier"], sg["s"], sg["r_point"], sg["hashed_to_curve_r"], sg["c"])
+            assert bool((nz == 1).all())
+            bad = sg["s"].copy()
+            bad[idx, 31] ^= 1
+            nz = eng.verify_non_zk_batch(ver, b["msgs"], b["off"], sg["pk"], sg["nullifier"], bad, sg["r_point"], sg["hashed_to_curve_r"], sg["c"])
+            assert not nz[idx].any() and int(nz.sum()) == n - len(idx)
+    finally:
+        eng.set_eq1_short(1)

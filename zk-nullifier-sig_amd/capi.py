@@ -76,7 +76,8 @@ def _load():
     lib.plume_set_sub_batches.argtypes = [C.c_void_p, C.c_int]
     lib.plume_set_in_flight.argtypes = [C.c_void_p, C.c_int]
     # later entry points: an older build selected through PLUME_HIP_LIB (A/B runs against an earlier round) may lack them; the in-tree library must have them all (checked below)
-    for name, args in (("plume_set_sign_uniform", [C.c_void_p, C.c_int]), ("plume_get_sign_uniform", [C.c_void_p]), ("plume_set_host_lanes", [C.c_void_p, C.c_int])):
+    for name, args in (("plume_set_sign_uniform", [C.c_void_p, C.c_int]), ("plume_get_sign_uniform", [C.c_void_p]), ("plume_set_host_lanes", [C.c_void_p, C.c_int]),
+                       ("plume_set_eq1_short", [C.c_void_p, C.c_int])):
         fn = getattr(lib, name, None)
         if fn is not None:
             fn.argtypes = args
@@ -120,7 +121,7 @@ def _load():
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_set_in_flight", "plume_set_sign_uniform", "plume_get_sign_uniform", "plume_set_host_lanes", "plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
+    return ["plume_set_in_flight", "plume_set_sign_uniform", "plume_get_sign_uniform", "plume_set_host_lanes", "plume_set_eq1_short", "plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
             "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars", "plume_sec1_der_to_scalars_checked",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
@@ -286,6 +287,11 @@ class Engine:
         if rc < 0:
             self._chk(rc, "plume_get_sign_uniform")
         return rc
+
+    def set_eq1_short(self, mode):
+        """the verifier's first equation where R is given: 1 = short form (csrc/plume_eis.h; default, calls of >= 2^17 items), 0 = long form always, 2 = test mode (every item
+        through the scalar stage's fallback)"""
+        self._chk(self._lib.plume_set_eq1_short(self._ctx, int(mode)), "plume_set_eq1_short")
 
     def set_host_lanes(self, lanes):
         """host-pointer calls: 1 = every piece on the context itself, 2 (default) = pieces alternate between the context and a second lane"""

@@ -157,7 +157,10 @@ struct plume_ctx {
     std::vector<plume_ctx*> lanes;
     size_t lane_next = 0;
     plume_ctx* lane_last = nullptr;                               // the lane the last device-resident call went to (plume_last_stage_times, plume_last_redo_tasks)
-    DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo, digs;
+    DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo, digs, eq1long, eq1k;
+    int eq1_short = 1;                                             // verify calls that give R: equation 1 in its short form (plume_eis.h).  0 = long form always (A/B), 2 = test: every item takes the fallback
+    size_t eq1_short_min = (size_t)1 << 17;                        // ... for calls (slices) of at least this many items: below, the half-GCD's ~45 dependent steps are latency nothing hides
+                                                                   // (2^16 items: scalar stage +0.12 ms, multi-scalar kernel -0.09 ms; 2^20: +0.28 / -1.1 ms)
     DevBuf dec[4], preflags;
     DevBuf agg[15];      // aggregate check (plume_aggregate.h): haff, scal, flags, gs, hash_ok, counters, count, sort tiles, sorted, bsum, bsuminf, red, redinf, ssum, perm + its histogram
     DevBuf agg_record;   // the running record of a host-pointer aggregate call (pieces of one batch)
@@ -172,7 +175,7 @@ static void inherit_tunables(plume_ctx* to, const plume_ctx* from) {
     to->ingest_split_max = from->ingest_split_max; to->tables_small_max = from->tables_small_max; to->msm_split_max = from->msm_split_max;
     to->jobs_per_lane = from->jobs_per_lane; to->jobs_per_lane_forced = from->jobs_per_lane_forced;
     to->host_piece = from->host_piece; to->host_first_piece = from->host_first_piece; to->host_tail_piece = from->host_tail_piece; to->host_register_min = from->host_register_min;
-    to->host_lanes = from->host_lanes; to->host_sign_lanes = from->host_sign_lanes;
+    to->host_lanes = from->host_lanes; to->host_sign_lanes = from->host_sign_lanes; to->eq1_short = from->eq1_short; to->eq1_short_min = from->eq1_short_min;
 }
 // after a setter changed `ctx`: hand the change to every context derived from it (shards and their derived contexts, in-flight lanes, the host pipeline's second lane)
 static void propagate_tunables(plume_ctx* ctx) {
@@ -246,7 +249,7 @@ static void destroy_single(plume_ctx* ctx) {
     if (ctx->ws_used && ctx->ws_free) (void)hipEventSynchronize(ctx->ws_free);
     for (hipStream_t q : {ctx->stream, ctx->up, ctx->down, ctx->side, ctx->pre}) if (q) (void)hipStreamSynchronize(q);
     for (DevBuf* b : {&ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
-                      &ctx->sink, &ctx->redo, &ctx->digs, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
+                      &ctx->sink, &ctx->redo, &ctx->digs, &ctx->eq1long, &ctx->eq1k, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
     for (DevBuf& b : ctx->agg) b.release();
     if (ctx->fixed) {
@@ -286,6 +289,8 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_TABLES_SMALL_MAX")) { long v = std::atol(e); if (v >= 0) ctx->tables_small_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_INGEST_SPLIT_MAX")) { long v = std::atol(e); if (v >= 0) ctx->ingest_split_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::min(2, std::max(0, std::atoi(e)));   // default of new contexts (plume_set_sign_uniform); 0 opts out of the uniform schedule
+    if (const char* e = std::getenv("PLUME_EQ1_SHORT")) { int v = std::atoi(e); if (v >= 0 && v <= 3) ctx->eq1_short = v; }   // A/B and test knob (plume_eis.h)
+    if (const char* e = std::getenv("PLUME_EQ1_SHORT_MIN")) { long v = std::atol(e); if (v >= 0) ctx->eq1_short_min = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_SIGN_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_sign_lanes = v; }
     if (const char* e = std::getenv("PLUME_HOST_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_lanes = v; }   // 1 = the one-lane host-pointer pipeline of rounds 1-3 (A/B)
     // The runtime multiplexes a process's streams onto a few hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES, 4 by default), and two streams that share a queue wait for
@@ -563,6 +568,15 @@ extern "C" int plume_set_sign_uniform(plume_ctx* ctx, int level) {
     return 0;
 }
 
+// The verifier's first equation where the call gives R (V1 verify, verify_non_zk): 1 = short form for calls of at least eq1_short_min items (csrc/plume_eis.h; the
+// default), 0 = long form always, 3 = short form whatever the size, 2 = test mode: the scalar stage files every item as "long form" and the checked chain of the redo
+// launch runs them all.
+extern "C" int plume_set_eq1_short(plume_ctx* ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 3) return fail(PLUME_ERR_ARG, "plume_set_eq1_short: 0, 1, 2 or 3");
+    ctx->eq1_short = mode;
+    propagate_tunables(ctx);
+    return 0;
+}
 extern "C" int plume_get_sign_uniform(const plume_ctx* ctx) {
     if (!ctx) return fail(PLUME_ERR_ARG, "plume_get_sign_uniform: null context");
     return ctx->sign_uniform;
@@ -638,13 +652,16 @@ static int pick_jobs_per_lane(const plume_ctx* ctx, size_t njobs, bool kinds_of_
 }
 
 // the window-table stage of njobs jobs: the small-batch path (one inversion on the critical path) or the affine chain's passes
-static size_t table_stage_scratch(const plume_ctx* ctx, size_t njobs, bool kinds_of_three) {
-    if (njobs <= ctx->tables_small_max) return tables_small_scratch_bytes(njobs);
-    return tables_scratch_bytes(njobs, pick_jobs_per_lane(ctx, njobs, kinds_of_three));
+// nthrees: how many of the jobs, from the front, come as (pk, H, nullifier) triples (the verifier: 3 per item; its short first equation appends one more job per item behind
+// them; the signer: 0).  The small-batch threshold counts the triples when there are any, so that it means the same number of ITEMS in either form of the verifier.
+static bool table_stage_small(const plume_ctx* ctx, size_t njobs, size_t nthrees) { return (nthrees ? nthrees : njobs) <= ctx->tables_small_max; }
+static size_t table_stage_scratch(const plume_ctx* ctx, size_t njobs, size_t nthrees) {
+    if (table_stage_small(ctx, njobs, nthrees)) return tables_small_scratch_bytes(njobs);
+    return tables_scratch_bytes(njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0));
 }
-static void table_stage(plume_ctx* ctx, uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, bool kinds_of_three, hipStream_t st) {
-    if (njobs <= ctx->tables_small_max) launch_tables_small(tab, bases, jobflags, njobs, kinds_of_three, ctx->tabscr.as<uint32_t>(), st);
-    else launch_tables(tab, bases, jobflags, njobs, pick_jobs_per_lane(ctx, njobs, kinds_of_three), ctx->tabscr.as<uint32_t>(), st);
+static void table_stage(plume_ctx* ctx, uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t nthrees, hipStream_t st) {
+    if (table_stage_small(ctx, njobs, nthrees)) launch_tables_small(tab, bases, jobflags, njobs, nthrees, ctx->tabscr.as<uint32_t>(), st);
+    else launch_tables(tab, bases, jobflags, njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0), ctx->tabscr.as<uint32_t>(), st);
 }
 
 // ------------------------------------------------------------------------------------------ device pipelines
@@ -671,16 +688,22 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     if (n == 0) return 0;
     if (n > ctx->chunk) return fail(PLUME_ERR_ARG, "n exceeds the chunk size (plume_set_chunk)");
     if (int rc = need_gtab(ctx)) return rc;
+    // Equation 1 in its short form (plume_eis.h) whenever the call GIVES r_point as a 64-byte record -- V1 verify and verify_non_zk; the SEC1 ingest keeps R compressed
+    // (a square root per item would cost more than the form saves) and V2 verify has no R: the long form.  One more table job per item (R), the comb of G.
+    const bool eq1short = ctx->eq1_short != 0 && (n >= ctx->eq1_short_min || ctx->eq1_short >= 2) && rpt != nullptr && rpt33 == nullptr && (version == 1 || mode == PLUME_MODE_NON_ZK);
+    if (eq1short) { if (int rc = need_gcomb(ctx)) return rc; }
+    const size_t J = eq1short ? 4 : 3;
     if (!continue_timer) { if (int rc = ws_acquire(ctx, st)) return rc; }     // continue_timer: the caller (SEC1 ingest) holds the workspace already
     std::unique_ptr<WsHold> hold(continue_timer ? nullptr : new WsHold(ctx, st));
     const std::vector<size_t> cut = sub_batch_bounds(ctx, n);
     const size_t nsub = cut.size() - 1;
     const bool overlapped = nsub > 1;
     size_t scr_bytes = 0;
-    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, 3 * (cut[k + 1] - cut[k]), true));
-    if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * 3 * n) || ctx->jobflags.ensure(3 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 3 * n) ||
+    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, J * (cut[k + 1] - cut[k]), 3 * (cut[k + 1] - cut[k])));
+    if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * J * n) || ctx->jobflags.ensure(J * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * J * n) ||
         ctx->tabscr.ensure(scr_bytes) ||
-        ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->redo.ensure((2 * n + nsub) * 4) || ctx->digs.ensure((size_t)PLUME_VDIG_ROWS * n))
+        ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->redo.ensure((2 * n + nsub) * 4) || ctx->digs.ensure((size_t)PLUME_VDIG_ROWS * n) ||
+        (eq1short && (ctx->eq1long.ensure(n) || ctx->eq1k.ensure(32 * n))))
         return PLUME_ERR_HIP;
     if (overlapped) { if (int rc = pre_events(ctx, nsub)) return rc; if (int rc = pre_stream(ctx)) return rc; }
     StageTimer& t = ctx->timer;
@@ -693,18 +716,24 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     for (size_t k = 0; k < nsub; k++) {
         const size_t lo = cut[k], cnt = cut[k + 1] - cut[k];
         VerifyArgs a;                                                         // the slice [lo, lo + cnt) as a batch of its own: every array and every scratch region starts at the slice
+        memset(&a, 0, sizeof a);
         a.version = version; a.mode = mode; a.n = (uint32_t)cnt; a.msgs = msgs; a.msg_off = msg_off + lo; a.msgs_bytes = msgs_bytes;
         a.pk = pk + 64 * lo; a.nul = nul + 64 * lo; a.c = c + 32 * lo; a.s = s + 32 * lo; a.rpt = rpt ? rpt + 64 * lo : nullptr; a.hr = hr ? hr + 64 * lo : nullptr; a.ok = ok + lo;
         a.preflags = preflags ? preflags + lo : nullptr; a.rpt33 = rpt33 ? rpt33 + 33 * lo : nullptr; a.hr33 = hr33 ? hr33 + 33 * lo : nullptr;
-        a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * 3 * lo; a.jobflags = ctx->jobflags.as<uint8_t>() + 3 * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo;
-        a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * 3 * lo; a.res = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.resinf = ctx->resinf.as<uint8_t>() + 2 * lo;
+        a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * J * lo; a.jobflags = ctx->jobflags.as<uint8_t>() + J * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo;
+        a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * J * lo; a.res = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.resinf = ctx->resinf.as<uint8_t>() + 2 * lo;
         a.gtab = ctx->fixed->gtab.as<uint32_t>();
         a.redo = ctx->redo.as<uint32_t>() + 2 * lo + k;                      // the slice's redo list: counter + up to 2 * cnt tasks
         a.digs = ctx->digs.as<int8_t>() + (size_t)PLUME_VDIG_ROWS * lo;        // the slice's digit rows (row-major over the slice's cnt items)
+        if (eq1short) {
+            a.eq1long = ctx->eq1long.as<uint8_t>() + lo; a.eq1k = ctx->eq1k.as<uint32_t>() + 8 * lo; a.gcomb = ctx->fixed->gcomb.as<uint32_t>();
+            a.eq1force = ctx->eq1_short == 2 ? 1 : 0;
+        }
         if (k == 0) ctx->redo_counters.clear();
         ctx->redo_counters.push_back(2 * lo + k);
         launch_verify_ingest(a, pre, cnt <= ctx->ingest_split_max); if (!overlapped) t.stage("verify_ingest_h2c", st);
-        table_stage(ctx, a.tab, a.bases, a.jobflags, 3 * cnt, true, pre); if (!overlapped) t.stage("tables", st);   // the table kernels of all sub-batches follow one another on one stream: one scratch
+        launch_verify_scalars(a, pre); if (!overlapped) t.stage("verify_scalars", st);
+        table_stage(ctx, a.tab, a.bases, a.jobflags, J * cnt, 3 * cnt, pre); if (!overlapped) t.stage("tables", st);   // the table kernels of all sub-batches follow one another on one stream: one scratch
         if (overlapped) {
             HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));
             HIPCHK(hipStreamWaitEvent(st, ctx->pre_ready[k], 0));
@@ -730,7 +759,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     const size_t nsub = cut.size() - 1;
     const bool overlapped = nsub > 1;
     size_t scr_bytes = 0;
-    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, 2 * (cut[k + 1] - cut[k]), false));
+    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, 2 * (cut[k + 1] - cut[k]), 0));
     // two table jobs per item: H and 2^64 H (the signer's chains are 64 doublings long)
     if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * 2 * n) || ctx->jobflags.ensure(2 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 2 * n) ||
         ctx->tabscr.ensure(scr_bytes) ||
@@ -759,7 +788,7 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
         launch_normalize(a.gres, a.gresinf, 2 * cnt, pre); if (!overlapped) t.stage("to_affine_g", st);
         launch_sign_h2c(a, pre); if (!overlapped) t.stage("sign_h2c", st);
         launch_sign_hdbl(a, pre); if (!overlapped) t.stage("sign_hdbl", st);
-        table_stage(ctx, a.tab, a.bases, a.jobflags, 2 * cnt, false, pre); if (!overlapped) t.stage("tables", st);
+        table_stage(ctx, a.tab, a.bases, a.jobflags, 2 * cnt, 0, pre); if (!overlapped) t.stage("tables", st);
         if (overlapped) {
             HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));
             HIPCHK(hipStreamWaitEvent(st, ctx->pre_ready[k], 0));

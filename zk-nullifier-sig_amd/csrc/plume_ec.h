@@ -905,6 +905,21 @@ PLUME_HD void comb_mul_g_impl(jac& acc, const sc& k, const uint32_t* comb) {
         }
     }
 }
+// acc += k G by the comb (the verifier's short first equation: the generator's term joins an accumulator that already holds the chain over pk and R)
+template <bool CHECKED>
+PLUME_HD void comb_add_g(jac& acc, const sc& k, const uint32_t* comb) {
+    PLUME_NOUNROLL for (int i = 0; i < PLUME_COMB_WINDOWS; i++) {
+        const int d = booth_digit_comb(k.v, i);
+        if (d != 0) {
+            const int ad = d < 0 ? -d : d;
+            const uint32_t* e = comb + ((size_t)i * PLUME_COMB_ENTRIES + (size_t)(ad - 1)) * PLUME_TAB_ENTRY_WORDS;
+            fe qx, qy;
+            ld_tab_xy(qx, qy, e, false);
+            if (d < 0) fe_neg_lazy(qy, qy);
+            jac_madd<CHECKED>(acc, qx, qy);
+        }
+    }
+}
 // the comb with the uniform schedule: every window adds (a zero digit adds row 1 to a copy that is dropped), the accumulator starts at the offset point B and loses it at the end
 template <bool CHECKED>
 PLUME_HD void comb_mul_g_uniform_impl(jac& acc, const sc& k, const uint32_t* comb) {

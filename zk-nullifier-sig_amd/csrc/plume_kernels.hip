@@ -43,6 +43,13 @@ __global__ PLUME_BOUNDS void k_fixed_table(uint32_t* rows, const uint32_t* base1
     if (lane < (size_t)entries * nwin) fixed_table_lane(rows, base18, entries, lane);
 }
 
+// The scalar stage (round 5): every window digit the multi-scalar kernel reads, once per item -- and for calls that give R, the half-GCD in Z[w] that shortens equation 1
+// (plume_eis.h).  Light on registers and latency-bound (about forty dependent quotient steps in double precision), so it runs at full occupancy beside nothing else.
+__global__ __launch_bounds__(kBlock, 4) void k_verify_scalars(VerifyArgs a) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < a.n) verify_scalars(a, i);
+}
+
 __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) verify_ingest_h2c(a, i);
@@ -166,23 +173,24 @@ PLUME_TAB_PASS_KERNEL(k_tab_pass_d, 3, PLUME_TABPASS_WAVES_CD)
 // the table stage of small batches (plume_ec.h tabj_pass_a / tabj_pass_b): one job per lane, Jacobian chain, one k_tab_invert in between
 // lane -> job.  The verifier's jobs come in threes (pk, H, nullifier of an item: two affine bases and a Jacobian one); lanes are dealt out kind by kind, so that a wavefront
 // builds tables of ONE kind and runs one addition form (kinds = 3), not both.  The signer's jobs are all of one kind (kinds = 1).
-__device__ __forceinline__ size_t tabj_job_of_lane(size_t lane, size_t njobs, uint32_t kinds) {
-    if (kinds <= 1) return lane;
-    const size_t per = njobs / kinds;
+// (nk = how many of the jobs, from the front, come in such groups: the verifier's short first equation appends one more job per item -- R, affine -- behind them)
+__device__ __forceinline__ size_t tabj_job_of_lane(size_t lane, size_t nk, uint32_t kinds) {
+    if (kinds <= 1 || lane >= nk) return lane;
+    const size_t per = nk / kinds;
     return (lane % per) * kinds + lane / per;
 }
-__global__ PLUME_MSM_BOUNDS void k_tabj_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, uint32_t kinds, uint32_t* scr, uint32_t* carry) {
+__global__ PLUME_MSM_BOUNDS void k_tabj_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t nk, uint32_t kinds, uint32_t* scr, uint32_t* carry) {
     const size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x, nl = (size_t)gridDim.x * kBlock;
     fe c = fe_small(1);
-    if (lane < njobs) tabj_pass_a_guarded(bases, jobflags, njobs, tabj_job_of_lane(lane, njobs, kinds), scr, nl, lane, c);
+    if (lane < njobs) tabj_pass_a_guarded(bases, jobflags, njobs, tabj_job_of_lane(lane, nk, kinds), scr, nl, lane, c);
     st_fe_soa(carry, nl, lane, c);
 }
-__global__ PLUME_MSM_BOUNDS void k_tabj_pass_b(uint32_t* tab, size_t njobs, uint32_t kinds, const uint32_t* scr, const uint32_t* carry) {
+__global__ PLUME_MSM_BOUNDS void k_tabj_pass_b(uint32_t* tab, size_t njobs, size_t nk, uint32_t kinds, const uint32_t* scr, const uint32_t* carry) {
     const size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x, nl = (size_t)gridDim.x * kBlock;
     if (lane >= njobs) return;
     fe c;
     ld_fe_soa(c, carry, nl, lane);
-    tabj_pass_b(tab, tabj_job_of_lane(lane, njobs, kinds), scr, nl, lane, c);
+    tabj_pass_b(tab, tabj_job_of_lane(lane, nk, kinds), scr, nl, lane, c);
 }
 // carry[.] <- 1 / carry[.] for the nl lane products of a level: thread t takes lanes t, t + T, ..., t + (K-1) T (coalesced) and spends ONE inversion on their product.
 // The products are never zero (the passes' guard).
@@ -202,14 +210,24 @@ __device__ __forceinline__ void wipe_digits(int8_t* s_dig) {
 
 // blocks [0, nb): equation 1 (s*G - c*pk); blocks [nb, 2nb): equation 2 (s*H - c*nullifier) — the role is uniform
 // per workgroup so the generator-table-in-LDS path never diverges inside a wavefront
-__global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
-    __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
+template <int FORM>
+__device__ __forceinline__ void verify_msm_body(const VerifyArgs& a, int8_t* s_dig) {
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t eq = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t blk = eq ? blockIdx.x - nb : blockIdx.x;
     const uint32_t* gt = a.gtab;   // read through L1/L2 (a 128-entry table staged in LDS was 10 % slower: bank conflicts on per-lane random rows)
     const uint32_t i = blk * kBlock + threadIdx.x;
-    if (i < a.n) verify_msm<false>(a, i, eq, gt, s_dig + threadIdx.x, kBlock);      // (the rows hold digits of s and c: public parts of a signature, nothing to wipe)
+    if (i < a.n) verify_msm<false, FORM>(a, i, eq, gt, s_dig + threadIdx.x, kBlock);      // (the rows hold digits of s and c: public parts of a signature, nothing to wipe)
+}
+__global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
+    __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
+    verify_msm_body<0>(a, s_dig);
+}
+// the same launch for calls whose equation 1 runs in the short form (round 5, plume_eis.h): blocks [0, nb) walk 64 doublings and add the generator's term from the comb,
+// blocks [nb, 2 nb) are equation 2 as before.  A kernel of its own so that neither form pays for the other's registers and code.
+__global__ PLUME_MSM_BOUNDS void k_verify_msm_s(VerifyArgs a) {
+    __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
+    verify_msm_body<1>(a, s_dig);
 }
 // the tasks k_verify_msm filed (their unchecked chain met p == +-q), one per lane, with the checked additions; grid-stride over the filed count, so an honest batch's
 // launch finds nothing and returns
@@ -439,6 +457,7 @@ void launch_gather_probe(const uint32_t* tab, uint32_t nrows, int iters, uint32_
 // ------------------------------------------------------------------------------------------------ launchers
 static inline unsigned nblocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
+void launch_verify_scalars(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_scalars, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
 void launch_verify_ingest(const VerifyArgs& a, hipStream_t st, bool two_roles) {
     if (two_roles) hipLaunchKernelGGL(k_verify_ingest_split, dim3((a.n + kBlock / 2 - 1) / (kBlock / 2)), dim3(kBlock), 0, st, a);   // two lanes per item: small batches
     else hipLaunchKernelGGL(k_verify_ingest, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a);
@@ -452,14 +471,14 @@ size_t tables_scratch_bytes(size_t njobs, int L) {
     return tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16;   // ... + the multi-kernel form's lane state: carry (9 words) and guard flag per lane
 }
 size_t tables_small_scratch_bytes(size_t njobs) { return (size_t)nblocks(njobs) * kBlock * ((size_t)PLUME_TAB_ENTRIES * PLUME_TABJ_ENTRY_WORDS + PLUME_FE_WORDS) * 4 + 16; }
-void launch_tables_small(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, bool kinds_of_three, uint32_t* scr, hipStream_t st) {
-    const uint32_t kinds = (kinds_of_three && njobs % 3 == 0) ? 3u : 1u;
+void launch_tables_small(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t nthrees, uint32_t* scr, hipStream_t st) {
+    const uint32_t kinds = (nthrees && nthrees % 3 == 0 && nthrees <= njobs) ? 3u : 1u;     // the first nthrees jobs come as (pk, H, nullifier) triples
     const dim3 grid(nblocks(njobs)), block(kBlock);
     const size_t nl = (size_t)grid.x * kBlock, T = (nl + PLUME_TABINV_K - 1) / PLUME_TABINV_K;
     uint32_t* carry = scr + nl * (size_t)PLUME_TAB_ENTRIES * PLUME_TABJ_ENTRY_WORDS;
-    hipLaunchKernelGGL(k_tabj_pass_a, grid, block, 0, st, bases, jobflags, njobs, kinds, scr, carry);
+    hipLaunchKernelGGL(k_tabj_pass_a, grid, block, 0, st, bases, jobflags, njobs, nthrees, kinds, scr, carry);
     hipLaunchKernelGGL(k_tab_invert, dim3(nblocks(T)), block, 0, st, carry, nl, T);
-    hipLaunchKernelGGL(k_tabj_pass_b, grid, block, 0, st, tab, njobs, kinds, scr, carry);
+    hipLaunchKernelGGL(k_tabj_pass_b, grid, block, 0, st, tab, njobs, nthrees, kinds, scr, carry);
 }
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st) {
     size_t lanes = (njobs + L - 1) / L;
@@ -480,7 +499,8 @@ void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags
 }
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {
     (void)hipMemsetAsync(a.redo, 0, 4, st);
-    hipLaunchKernelGGL(k_verify_msm, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    if (a.eq1long) hipLaunchKernelGGL(k_verify_msm_s, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    else hipLaunchKernelGGL(k_verify_msm, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
     const unsigned redo_blocks = std::min(2 * nblocks(a.n) * (kBlock / kRedoBlock), 4096u);   // grid-stride: enough lanes for a wholly crafted batch to fill the chip
     hipLaunchKernelGGL(k_verify_msm_redo, dim3(redo_blocks), dim3(kRedoBlock), 0, st, a);
 }

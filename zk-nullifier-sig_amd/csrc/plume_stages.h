@@ -17,6 +17,7 @@
 //   G4 sign_final   lane = item     affine outputs, c = SHA256(..) mod n, s = r + sk*c, status bits
 #pragma once
 #include "plume_h2c.h"
+#include "plume_eis.h"
 
 namespace plume {
 
@@ -162,12 +163,23 @@ struct VerifyArgs {
     const uint32_t* gtab; // wide table of G (PLUME_GTAB_WORDS): (1..2^(W-1))*G
     uint32_t* redo;       // redo[0] = number of tasks whose unchecked chain met p == +-q, redo[1 + k] = the k-th such task (2i + eq); capacity 2n; zeroed before the multi-scalar kernel
     int8_t* digs;         // PLUME_VDIG_ROWS x n signed window digits, row-major (row r of item i at digs[r * n + i]: a wavefront reads / writes 64 consecutive bytes per row).
-                          // Written once per item by the ingest kernel, read by the item's two multi-scalar lanes (round 4; rounds 1-3: each lane split s and c again)
+                          // Written once per item by the scalar stage (verify_scalars; rounds 4: by the ingest kernel; rounds 1-3: each multi-scalar lane split s and c again)
+    // Round 5, calls that GIVE r_point as a 64-byte record (V1 verify, verify_non_zk): equation 1 in its short form (plume_eis.h) -- NULL = the long form for every item
+    uint8_t* eq1long;     // n : 0 = the item's equation 1 runs in the short form (digit set B holds the 64-bit coefficients, eq1k the generator's scalar), 1 = long form (set B holds
+                          //     s in the generator's wide digits): the half-GCD's coefficients did not fit (no such input is known) or the caller forces it (tests)
+    uint32_t* eq1k;       // 8 x n words, word-major: k = tau s mod n, multiplied by G through the comb
+    const uint32_t* gcomb;  // the doubling-free comb of G (PLUME_COMB_WORDS), shared with the signer
+    int eq1force;         // test knob: 1 = file every item's equation 1 as "long form" (everything then runs through the redo launch's checked chain)
 };
+// jobs: 3 per item (pk, H, nullifier) at 3i, 3i+1, 3i+2; in the short form a fourth, R, at 3n + i -- behind the others so that the job kinds of the first 3n stay aligned
+// across the lanes of the table passes and the last n are all of one kind (affine)
+PLUME_HD size_t verify_njobs(const VerifyArgs& a) { return (a.eq1long ? 4 : 3) * (size_t)a.n; }
 // the digit rows of an item: three sets of 2 x PLUME_NDIG rows (the two halves of a GLV split): s in 4-bit windows (equation 2), s with the generator's wide digits
 // (equation 1), -c in 4-bit windows (both equations)
 #define PLUME_VDIG_SET (2 * PLUME_NDIG)
-#define PLUME_VDIG_ROWS (3 * PLUME_VDIG_SET)
+#define PLUME_VDIG_SETB (4 * PLUME_NDIG64)          // set B: s in the generator's wide digits (2 x 33 rows: long form) OR the four 64-bit coefficients of the short form (4 x 17)
+#define PLUME_VDIG_ROWS (2 * PLUME_VDIG_SET + PLUME_VDIG_SETB)
+static_assert(PLUME_VDIG_SETB >= PLUME_VDIG_SET, "set B holds either form");
 // One crafted item (pk = +-k G with small k, s = +-c, ...) steers its accumulator into p == +-q inside an UNCHECKED addition.  Rounds 1-2 redid such a lane on the spot with
 // the checked additions -- and its 63 neighbours waited: one crafted item per wavefront doubled the kernel.  Now the lane only files its task; a second,
 // dense launch (k_verify_msm_redo: one filed task per lane, grid-stride) redoes the filed tasks.  Honest batches file nothing and the second launch costs its launch; a batch
@@ -183,15 +195,42 @@ PLUME_HD uint32_t redo_file(uint32_t* redo, uint32_t task) {
     return k;
 }
 
-// the digit rows of one item (d = the item's column of the row-major digit array, n = its row pitch): s = k1 + k2 lambda in 4-bit Booth windows and in the generator's
-// wide windows, -c likewise in 4-bit windows
-PLUME_HD void verify_item_digits(int8_t* d, uint32_t n, const sc& s, const sc& c) {
+// the digit rows of one item (d = the item's column of the row-major digit array, n = its row pitch): set A = s = k1 + k2 lambda in 4-bit Booth windows (equation 2),
+// set B = equation 1's own rows (below), set C = -c in 4-bit windows (equation 2, and equation 1 in its long form)
+PLUME_HD void verify_item_digits(int8_t* d, uint32_t n, const sc& s, const sc& c, bool long_b) {
     glv_half h1, h2;
     glv_split(h1, h2, s);
     booth_store(d, n, h1, false); booth_store(d + (size_t)PLUME_NDIG * n, n, h2, false);
-    booth_store_wide(d + (size_t)PLUME_VDIG_SET * n, n, h1, false); booth_store_wide(d + (size_t)(PLUME_VDIG_SET + PLUME_NDIG) * n, n, h2, false);
+    if (long_b) { booth_store_wide(d + (size_t)PLUME_VDIG_SET * n, n, h1, false); booth_store_wide(d + (size_t)(PLUME_VDIG_SET + PLUME_NDIG) * n, n, h2, false); }
     glv_split(h1, h2, c);
-    booth_store(d + (size_t)2 * PLUME_VDIG_SET * n, n, h1, true); booth_store(d + (size_t)(2 * PLUME_VDIG_SET + PLUME_NDIG) * n, n, h2, true);
+    int8_t* dc = d + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * n;
+    booth_store(dc, n, h1, true); booth_store(dc + (size_t)PLUME_NDIG * n, n, h2, true);
+}
+// The scalar stage: every digit row the multi-scalar kernel reads, once per item.  Short form of equation 1 (a.eq1long != NULL; plume_eis.h): (tau, upsilon) from the
+// half-GCD of c, k = tau s mod n for the comb, and set B = the digits of -upsilon (slots 0, 1: pk, lambda pk) and of -(tau - 1) (slots 2, 3: R, lambda R).
+PLUME_HD void verify_scalars(const VerifyArgs& a, uint32_t i) {
+    sc c, s;
+    bool okc = load_scalar_be(c, a.c + 32 * (size_t)i), oks = load_scalar_be(s, a.s + 32 * (size_t)i);
+    if (a.mode == PLUME_MODE_NON_ZK) { okc = sc_lt_n(c); oks = sc_lt_n(s); }
+    if (!okc || !oks) { if (a.eq1long) a.eq1long[i] = 1; return; }            // (the ingest stage rejects the item; its digit rows are never read)
+    bool lng = true;
+    if (a.eq1long) {
+        eis_short e;
+        eis_half_gcd(e, c);
+        lng = !e.ok || a.eq1force != 0;
+        if (!lng) {
+            sc k;
+            sc_mul(k, e.tau, s);
+            PLUME_UNROLL for (int w = 0; w < 8; w++) a.eq1k[(size_t)w * a.n + i] = k.v[w];
+            int8_t* b = a.digs + (size_t)PLUME_VDIG_SET * a.n + i;
+            booth_store67(b, a.n, e.u[0], !e.uneg[0]);
+            booth_store67(b + (size_t)PLUME_NDIG64 * a.n, a.n, e.u[1], !e.uneg[1]);
+            booth_store67(b + (size_t)2 * PLUME_NDIG64 * a.n, a.n, e.t[0], !e.tneg[0]);
+            booth_store67(b + (size_t)3 * PLUME_NDIG64 * a.n, a.n, e.t[1], !e.tneg[1]);
+        }
+        a.eq1long[i] = lng ? 1 : 0;
+    }
+    verify_item_digits(a.digs + i, a.n, s, c, lng);
 }
 
 PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
@@ -207,9 +246,16 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     const bool err = a.mode == PLUME_MODE_NON_ZK && !bad && fpk == PLUME_JOB_INF;      // hash_to_curve(message, pk)? -> Err
     a.itemflags[i] = (uint8_t)(bad ? PLUME_ITEM_REJECT : err ? PLUME_ITEM_ERR : 0u);
     bad = bad || err;
-    // The window digits of s and -c, once per item (round 4): the GLV splits and the Booth recoding used to open BOTH multi-scalar lanes of the item (4.5 k instructions
-    // per lane, 1.7 % of that kernel); here the scalars are in registers anyway and die before hash_to_curve starts.
-    if (!bad && a.digs) verify_item_digits(a.digs + i, a.n, s, c);     // (the aggregate check runs this stage without a multi-scalar kernel behind it: no digit rows)
+    // (The window digits of s and c are the scalar stage's work since round 5: verify_scalars.)
+    // Short form of equation 1: R is a base of the multi-scalar chain, so it is validated HERE (an r_point that is no curve point rejects the item, as it does in the
+    // finalize stage of the long form) and becomes job 3n + i of the table stage.
+    if (a.eq1long) {
+        fe rx, ry;
+        const uint32_t fr = load_affine_be(rx, ry, a.rpt + 64 * (size_t)i);
+        if (fr == PLUME_JOB_INVALID && !err) { bad = true; a.itemflags[i] = (uint8_t)PLUME_ITEM_REJECT; }
+        jac p; p.inf = 0; p.z = fe_small(1); p.x = rx; p.y = ry;
+        st_base(a.bases, 3 * (size_t)a.n + i, p); a.jobflags[3 * (size_t)a.n + i] = (uint8_t)(fr | PLUME_JOB_AFFINE);
+    }
     // the records of pk and the nullifier go out BEFORE hash_to_curve: nothing below needs y(nullifier) or more of pk than its x and parity, and 27 registers less are
     // live through the two exponentiations (the kernel spills at its 128-register budget)
     {
@@ -240,17 +286,24 @@ struct ingest_xch {
     fe xn, xd, y;     // B -> A at the second meeting: map(u1) on E', x as a fraction
 };
 struct ingest_a_state { fe u0; fe c, d, y1; uint32_t fpk; bool bad_a, bad; };
-// role B, before the first meeting: nullifier record, scalars, window digits
+// role B, before the first meeting: nullifier record, scalar range checks (the window digits are the scalar stage's: verify_scalars)
 PLUME_HD void verify_ingest_b1(const VerifyArgs& a, uint32_t i, ingest_xch& x) {
     fe nx, ny;
     const uint32_t fnul = load_affine_be(nx, ny, a.nul + 64 * (size_t)i);
     sc c, s;
     bool okc = load_scalar_be(c, a.c + 32 * (size_t)i), oks = load_scalar_be(s, a.s + 32 * (size_t)i);
     if (a.mode == PLUME_MODE_NON_ZK) { okc = sc_lt_n(c); oks = sc_lt_n(s); }
-    if (okc && oks && a.digs) verify_item_digits(a.digs + i, a.n, s, c);      // (an item rejected for another reason never reads them)
     jac p; p.inf = 0; p.z = fe_small(1); p.x = nx; p.y = ny;
     st_base(a.bases, 3 * (size_t)i + 2, p); a.jobflags[3 * (size_t)i + 2] = (uint8_t)(fnul | PLUME_JOB_AFFINE);
-    x.fb = fnul | ((okc && oks) ? 0u : 0x100u);
+    bool okr = true;
+    if (a.eq1long) {                                                          // short form of equation 1: R is validated here and becomes job 3n + i (verify_ingest_h2c)
+        fe rx, ry;
+        const uint32_t fr = load_affine_be(rx, ry, a.rpt + 64 * (size_t)i);
+        okr = fr != PLUME_JOB_INVALID;
+        p.x = rx; p.y = ry;
+        st_base(a.bases, 3 * (size_t)a.n + i, p); a.jobflags[3 * (size_t)a.n + i] = (uint8_t)(fr | PLUME_JOB_AFFINE);
+    }
+    x.fb = fnul | ((okc && oks && okr) ? 0u : 0x100u);
 }
 // role A, before the first meeting: pk record, message span, hash_to_field
 PLUME_HD void verify_ingest_a1(const VerifyArgs& a, uint32_t i, ingest_xch& x, ingest_a_state& st) {
@@ -294,16 +347,36 @@ PLUME_HD void verify_ingest_a3(const VerifyArgs& a, uint32_t i, const ingest_xch
 
 // task t = 2*item + eq;  eq 0: s*G - c*pk, eq 1: s*H - c*nul.   dig: this lane's digit area (LDS), element stride.
 // CHECKED = false: the hot form; a task whose chain met p == +-q is filed in a.redo and stores nothing.  CHECKED = true: the redo launch's form.
-template <bool CHECKED>
+// FORM: which forms of equation 1 the instantiation carries -- 0: the long form only (calls without a.eq1long), 1: the short form only (the hot kernel of a short-form call:
+// an item the scalar stage left in the long form is filed for the redo launch), 2: both (the redo launch, host harness)
+template <bool CHECKED, int FORM = 2>
 PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const uint32_t* gtab, int8_t* dig, uint32_t stride) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + eq;
     jac acc;
+    const bool short_call = FORM == 1 || (FORM == 2 && a.eq1long != nullptr);
     if (a.itemflags[item]) {
         acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
+    } else if (FORM != 0 && eq == 0 && short_call && !a.eq1long[item]) {
+        // Equation 1, short form (plume_eis.h): k G - upsilon pk - (tau - 1) R, to be compared with R by the finalize stage.  Slots 0, 1: pk and lambda pk, slots 2, 3: R and
+        // lambda R, seventeen windows (64 doublings); then the generator's term from the doubling-free comb, fifteen additions.
+        const int8_t* db = a.digs + (size_t)PLUME_VDIG_SET * a.n + item;
+        PLUME_UNROLL for (int r = 0; r < PLUME_VDIG_SETB; r++) dig[(uint32_t)r * stride] = db[(size_t)r * a.n];
+        const size_t jp = 3 * (size_t)item, jr = 3 * (size_t)a.n + item;
+        const uint32_t* tabp = job_state(a.jobflags[jp]) == PLUME_JOB_OK ? a.tab + jp * PLUME_TAB_WORDS : nullptr;
+        const uint32_t* tabr = job_state(a.jobflags[jr]) == PLUME_JOB_OK ? a.tab + jr * PLUME_TAB_WORDS : nullptr;
+        msm_run_impl<CHECKED, PLUME_NDIG64>(acc, tabp, tabr, 4, dig, stride, false);
+        sc k;                                                                 // (loaded after the chain: eight registers the chain does not have to carry)
+        PLUME_UNROLL for (int w = 0; w < 8; w++) k.v[w] = a.eq1k[(size_t)w * a.n + item];
+        comb_add_g<CHECKED>(acc, k, a.gcomb);
+        if (!CHECKED && !acc.inf && fe_is_zero(acc.z)) { redo_file(a.redo, (uint32_t)t); return; }
+    } else if (FORM == 1 && eq == 0) {
+        redo_file(a.redo, (uint32_t)t);                                       // a long-form item of a short-form call (never on known inputs): the redo launch takes it
+        return;
     } else {
-        // slots 0, 1: s (wide digits for equation 1's generator slots), slots 2, 3: -c -- the rows the ingest kernel left for this item, into the lane's digit area
+        if (FORM == 2 && !CHECKED && eq == 0 && short_call) { redo_file(a.redo, (uint32_t)t); return; }
+        // slots 0, 1: s (wide digits for equation 1's generator slots), slots 2, 3: -c -- the rows the scalar stage left for this item, into the lane's digit area
         const int8_t* ds = a.digs + (size_t)(eq == 0 ? PLUME_VDIG_SET : 0) * a.n + item;
-        const int8_t* dc = a.digs + (size_t)2 * PLUME_VDIG_SET * a.n + item;
+        const int8_t* dc = a.digs + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * a.n + item;
         PLUME_UNROLL for (int r = 0; r < PLUME_VDIG_SET; r++) {
             dig[(uint32_t)r * stride] = ds[(size_t)r * a.n];
             dig[(uint32_t)(PLUME_VDIG_SET + r) * stride] = dc[(size_t)r * a.n];
