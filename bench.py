@@ -117,7 +117,7 @@ STAGE_KERNELS = {"verify_ingest_h2c": [("plume::k_verify_ingest", 1)], "verify_s
                  "verify_msm": [("plume::k_verify_msm", 1)], "verify_finalize": [("plume::k_verify_finalize", 1)]}
 
 
-def stage_roofline(stages: dict, n: int, mad_rate: float, build: str):
+def stage_roofline(stages: dict, n: int, mad_rate: float, build: str, short1: bool = False):
     """Every stage of the step against both roofs: the integer-VALU roof in the frozen accounting's multiply-adds (Fp-mult x 72 x items / stage time / this
     run's probe) and in ISSUED VALU instructions (the committed counter pass: SQ_INSTS_VALU x 64 lanes / time / probe -- every instruction priced as a multiply-add slot), and
     the HBM roof (counter bytes: 2 x FETCH_SIZE + WRITE_SIZE of the stage's kernels / time / 8 TB/s).  The counters are per 2^20-item launch of the committed summary
@@ -142,6 +142,8 @@ def stage_roofline(stages: dict, n: int, mad_rate: float, build: str):
         have = True
         res = {}
         for k, times in STAGE_KERNELS[name]:
+            if short1 and k == "plume::k_verify_msm":
+                k = "plume::k_verify_msm_s"
             d = j.get(k)
             if not d or "SQ_INSTS_VALU" not in d:
                 have = False
@@ -714,7 +716,10 @@ def main():
             bytes_item = BYTES_PER_SIGN if sign else BYTES_PER_ITEM[ver]
             hbm_achieved = bytes_item * n / dom_s / 1e9
             # HBM bytes per launch from the committed PMC passes (2^20-item launch, scaled to this batch)
-            tb, tsrc = pmc_traffic("plume::k_" + dom, eng.version())
+            from zk_nullifier_sig_amd import capi as _capi
+            short1 = (not sign) and _capi.eq1_short_applies(ver, n)            # equation 1 in its short form (csrc/plume_eis.h): the launch is k_verify_msm_s
+            dom_kernel = "k_" + dom + ("_s" if (short1 and dom == "verify_msm") else "")
+            tb, tsrc = pmc_traffic("plume::" + dom_kernel, eng.version())
             traffic_bytes = int(tb * (n / float(1 << 20))) if tb else None
             try:
                 if a.no_probe:
@@ -735,7 +740,7 @@ def main():
             dom_fpmul = {"verify_msm": FPMUL_MSM_PER_ITEM, "sign_hmul": FPMUL_SIGN_HMUL_PER_ITEM}.get(dom)
             if dom_fpmul:
                 msm = dom_fpmul * MACS_PER_FPMUL * n / dom_s
-                line["roofline"] = {"bound": "int-valu", "kernel": "k_" + dom + (" + k_sign_hdbl" if dom_parts else ""), "kernel_ms": round(dom_s * 1e3, 4),
+                line["roofline"] = {"bound": "int-valu", "kernel": dom_kernel + (" + k_sign_hdbl" if dom_parts else ""), "kernel_ms": round(dom_s * 1e3, 4),
                                     **({"kernel_ms_parts": dom_parts} if dom_parts else {}), "achieved": round(msm, 1), "peak": round(mad_rate, 1),
                                     "unit": "32-bit MAC/s", "frac": round(msm / mad_rate, 4),
                                     "peak_rule": "this run's v_mad_u64_u32 probe (median)" if mad_measured else "no probe in this run (--no-probe or a failed probe): the pool's reference rate",
@@ -744,12 +749,15 @@ def main():
                                     "traffic": traffic_bytes, "traffic_source": tsrc,
                                     "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE; the factor 2 of gfx950's FETCH_SIZE calibrated on this kernel's access pattern, "
                                                     "profiles/r02_fetch_calibration.json); read from the committed counter passes, not measured in this run: see traffic_source.same_build",
+                                    "equation1_form": ("short (csrc/plume_eis.h): k G - upsilon pk - (tau - 1) R along 64 doublings + 15 comb additions; the accounting below stays the frozen "
+                                                       "long-form count, so `achieved` prices the work the REFERENCE's equation asks for, not the instructions executed") if short1 else
+                                                      ("long" if not sign else None),
                                     "accounting": (f"{dom_fpmul} Fp-mult per {op} in this kernel " + ("(r*H, sk*H: 2 x 1584)" if sign else "(s*G - c*pk: 1900, s*H - c*nul: 2260)") +
                                                    f" x {MACS_PER_FPMUL} MACs x {n} items per launch (SURVEY.md §8d, frozen in BASELINE.md §4); the 9x29-limb code issues 111 multiply-adds per "
                                                    f"Fp-mult (81 products + 22 fold + 8 column hand-offs), 75 per squaring; the accounting stays on the frozen 72")}
                 # what the SIMDs actually issued (committed counter pass of the same build): all VALU slots and the multiply-adds among them, against the same peak.  `frac` counts
                 # the ACCOUNTING's multiply-adds; these two say how full the issue ports are and how many multiply-adds the code spends per accounted one.
-                iss = pmc_issue("plume::k_" + dom, eng.version())
+                iss = pmc_issue("plume::" + dom_kernel, eng.version())
                 if iss and iss.get("valu_wave_insts") and dom_parts:
                     iss2 = pmc_issue("plume::k_sign_hdbl", eng.version())        # the signer's roofline spans both launches: so do its instruction counts
                     if iss2 and iss2.get("valu_wave_insts"):
@@ -780,10 +788,10 @@ def main():
                                             "SIMDs: launches are stretched while the step gets shorter (kernel_ms_in_timed_region: the LAST call's launch, the one figure the library's stage events of a lane keep)")
             if not sign:
                 try:
-                    line["stage_roofline"] = stage_roofline(stages, n, mad_rate if mad_measured else None, eng.version())
+                    line["stage_roofline"] = stage_roofline(stages, n, mad_rate if mad_measured else None, eng.version(), short1)
                 except Exception as e:
                     line["stage_roofline"] = {"error": str(e)[:200]}
-            line["hbm_view"] = {"bound": "hbm", "kernel": "k_" + dom, "kernel_ms": stages[dom], "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            line["hbm_view"] = {"bound": "hbm", "kernel": dom_kernel, "kernel_ms": stages[dom], "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(hbm_achieved / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": bytes_item * n,
                                 "traffic": round(traffic_bytes / dom_s / 1e9, 1) if traffic_bytes else None, "traffic_bytes_per_launch": traffic_bytes,
                                 "traffic_over_algorithmic": round(traffic_bytes / (bytes_item * n), 1) if traffic_bytes else None,

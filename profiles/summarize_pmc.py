@@ -75,7 +75,8 @@ def isa_mad_share(path):
         if ln.startswith("# ") and "basic blocks" in ln:
             if cur and len(blocks) >= 2:
                 top = sorted(blocks.values(), key=lambda t: -t[0])[:2]          # (mad64, VALU): addition body first, doubling body second
-                w_add, w_dbl = (64.0, 64.0) if "sign" in cur else (98.5, 128.0)
+                # k_verify_msm_s (round 5): equation 1's lanes walk 64 doublings and ~79 additions (4 x 17 slots, 15/16 non-zero, + 15 from the comb), equation 2's 128 and ~124
+                w_add, w_dbl = (64.0, 64.0) if "sign" in cur else ((101.5, 96.0) if cur.endswith("_msm_s") else (98.5, 128.0))
                 mad = w_add * top[0][0] + w_dbl * top[1][0]
                 valu = w_add * top[0][1] + w_dbl * top[1][1]
                 share["plume::" + cur] = round(mad / valu, 4)

@@ -58,6 +58,15 @@ def fe_raw(op, a, b=None, c=None, e=None):
     return [[int(w) for w in row] for row in out]
 
 
+def group_raw(op, px, py, pz, qx, qy):
+    """jac_dbl / jac_dbl_neg / jac_madd / jac_add on raw limb vectors (lists of 9 ints): the host build's limb-bound assertions abort the process on a violation"""
+    n = len(px)
+    arrs = [np.ascontiguousarray(np.array(v, dtype=np.uint32).reshape(n, 9)) for v in (px, py, pz, qx, qy)]
+    out = np.zeros((n, 27), dtype=np.uint32)
+    lib().ds_group_raw(C.c_int(op), C.c_size_t(n), *[_p(x, u32p) for x in arrs], _p(out, u32p))
+    return [[int(w) for w in row] for row in out]
+
+
 def sc_op(op, a, b=None):
     A = to_limbs(a)
     Bm = to_limbs(b if b is not None else [0] * len(a))

@@ -82,6 +82,26 @@ void ds_fe_raw(int op, size_t count, const uint32_t* a, const uint32_t* b, const
         for (int k = 0; k < 9; k++) out[9 * i + k] = r.v[k];
     }
 }
+// The group law on RAW limbs: every lazy sum / difference that feeds a product inside jac_dbl / jac_dbl_neg / jac_madd / jac_add, driven by operands whose limbs
+// sit at the ends of the "tight" range -- the host build's PLUME_FE_CHECK assertions (fe_mul_inputs_ok: limbs 0..7 by the column bound, limb 8 <= 2^26) abort on a violation.
+// op: 0 jac_dbl, 1 jac_dbl_neg, 2 jac_madd<false>, 3 jac_madd<true>, 4 the same with the row's y negated lazily (what a negative digit does), 5 jac_add (q = (qx, qy, p.z)).
+// p = (x, y, z) and the affine (qx, qy): 9 words each; out: the resulting x, y, z (27 words).
+void ds_group_raw(int op, size_t count, const uint32_t* px, const uint32_t* py, const uint32_t* pz, const uint32_t* qx, const uint32_t* qy, uint32_t* out) {
+    for (size_t i = 0; i < count; i++) {
+        jac p; p.inf = 0;
+        fe ax, ay;
+        for (int k = 0; k < 9; k++) { p.x.v[k] = px[9 * i + k]; p.y.v[k] = py[9 * i + k]; p.z.v[k] = pz[9 * i + k]; ax.v[k] = qx[9 * i + k]; ay.v[k] = qy[9 * i + k]; }
+        switch (op) {
+            case 0: jac_dbl(p); break;
+            case 1: jac_dbl_neg(p); break;
+            case 2: jac_madd<false>(p, ax, ay); break;
+            case 3: jac_madd<true>(p, ax, ay); break;
+            case 4: { fe ny; fe_neg_lazy(ny, ay); jac_madd<false>(p, ax, ny); break; }
+            case 5: { jac q; q.inf = 0; q.x = ax; q.y = ay; q.z = p.z; jac_add(p, q); break; }
+        }
+        for (int k = 0; k < 9; k++) { out[27 * i + k] = p.x.v[k]; out[27 * i + 9 + k] = p.y.v[k]; out[27 * i + 18 + k] = p.z.v[k]; }
+    }
+}
 // op: 0 mul, 1 add, 2 neg, 3 reduce of 512-bit a|b (a low)
 void ds_sc_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     for (size_t i = 0; i < count; i++) {

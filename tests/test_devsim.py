@@ -104,6 +104,43 @@ def test_products_at_their_operand_bounds_come_back_tight():
         assert tight(got) and val(got) % P == (val(x) * val(y) + val(z) * val(w)) % P
 
 
+def test_group_law_compositions_keep_every_product_operand_in_bounds():
+    """the product's limb-8 precondition (<= 2^26, since round 4's top-columns-first fold) is asserted in host builds only -- on whatever values a test happens to
+    carry.  Here the group law's lazy sums and differences meet operands at the ENDS of the tight range (every limb 0 or its maximum, 2^29 + 2^19 and 2^24 + 2^10 on top, in
+    every combination that matters plus random ones): each fe_mul / fe_sqr / fe_muladd inside jac_dbl, jac_dbl_neg, jac_madd (row y negated or not) and jac_add is checked by
+    fe_mul_inputs_ok (the process aborts on a violation), and what comes back must be tight again, so that the operations compose."""
+    T, T8 = 2**29 + 2**19, 2**24 + 2**10
+    rng = random.Random(99)
+    tight = lambda L: all(x <= T for x in L[:8]) and L[8] <= T8
+    hi, lo = [T] * 8 + [T8], [0] * 9
+
+    def pick():
+        r = rng.random()
+        if r < 0.3:
+            return list(hi)
+        if r < 0.45:
+            return list(lo)
+        if r < 0.8:
+            return [rng.choice([0, T]) for _ in range(8)] + [rng.choice([0, T8])]
+        return [rng.randrange(T + 1) for _ in range(8)] + [rng.randrange(T8 + 1)]
+    n = 600
+    ops = [[pick() for _ in range(n)] for _ in range(5)]
+    for k in range(5):                                   # the all-maximum and the all-but-one-maximum combinations first
+        for j in range(5):
+            ops[j][k] = list(hi if j != k else lo)
+    ops[0][5], ops[1][5], ops[2][5], ops[3][5], ops[4][5] = list(hi), list(hi), list(hi), list(hi), list(hi)
+    for op in range(6):
+        for row in D.group_raw(op, *ops):
+            assert tight(row[0:9]) and tight(row[9:18]) and tight(row[18:27]), op
+    # ... and composed: the outputs of one operation are the inputs of the next, twelve deep, every order
+    cur = [ops[0], ops[1], ops[2]]
+    for step in range(12):
+        op = rng.choice([0, 1, 2, 4, 5])
+        out = D.group_raw(op, cur[0], cur[1], cur[2], ops[3], ops[4])
+        cur = [[r[0:9] for r in out], [r[9:18] for r in out], [r[18:27] for r in out]]
+        assert all(tight(a) and tight(b) and tight(c) for a, b, c in zip(*cur)), (step, op)
+
+
 def test_fe_inv_pow():
     rng = random.Random(2)
     a = [1, 2, P - 1, P + 1, 2**256 - 1, PC] + [rng.randrange(1, 2**256) for _ in range(40)]

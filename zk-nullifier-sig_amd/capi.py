@@ -183,6 +183,15 @@ def sec1_der_to_scalars(der109):
     return sc, ok
 
 
+def eq1_short_applies(version, n, mode=0, sec1=False):
+    """mirror of verify_device's rule (csrc/plume_capi.hip) for callers that want to NAME the multi-scalar kernel a call ran (bench.py looks its counters up): calls that give R
+    as a 64-byte record -- V1 verify, verify_non_zk -- of at least PLUME_EQ1_SHORT_MIN items (default 2^17) run equation 1 in the short form (k_verify_msm_s), unless
+    PLUME_EQ1_SHORT=0.  Contexts reconfigured with Engine.set_eq1_short are not covered: this reads the environment's defaults only."""
+    m = int(os.environ.get("PLUME_EQ1_SHORT", "1"))
+    lo = int(os.environ.get("PLUME_EQ1_SHORT_MIN", str(1 << 17)))
+    return m != 0 and (n >= lo or m >= 2) and not sec1 and (version == 1 or mode == 1)
+
+
 def pinned_empty(shape, dtype=np.uint8):
     """numpy array in page-locked host memory (plume_host_alloc): the copy engines read / write it directly, so the host-pointer calls
     overlap every transfer with the neighbouring pieces' kernels.  Freed when the array (and every view of it) is gone."""

@@ -12,14 +12,17 @@ v_mad_u64_u32, and the carry into the next column is simply that chain's initial
                 stands; the high register (weight 2^32 = 8 * 2^29 relative to the column) opens the next column's chain as `v_mad_u64_u32 acc, hi, 8, 0`
                 (a fresh accumulator pair, nothing copied).  32-bit h[] are harmless: the fold multiplies them by 31264 and 256 only.
     top first   column 7 WITHOUT its carry-in (E7), handed on the same way (x7 = its low 32 bits stay behind), then column 8 (E8).  Bits >= 24 of E8 are
-                multiples of 2^256 = 2^32 + 977 (mod p): t = E8 >> 24 (40 bits: tlo = 32 bits by one v_alignbit, thi = the rest) goes into columns 0..2 as four
-                more multiply-adds BEFORE those columns run -- limb 0 += tlo*977, limb 1 += tlo*8 + thi*7816, limb 2 += thi*64 -- next to h[8]'s 2^8 part
-                (2^261 again: limb 0 += h[8]*(31264 << 11), limb 1 += h[8] << 19).
+                multiples of 2^256 = 2^32 + 977 (mod p).  E8's high word takes h[8] << 8 by a plain add first (h[8] * 8 * (2^37 + 31264) * 2^232: the 2^40 part lands
+                exactly there -- which is why limb 8 of a multiplication input must stay <= 2^26), then the excess is cut in two: tlo = bits 24..31 of the low word
+                (weight 2^256), thi = the whole high word (weight 2^264).  Both go into columns 0 and 1 as four more multiply-adds BEFORE those columns run, with the
+                constants the emitted code names: limb 0 += tlo * K4 + thi * K4H (K4 = 977, K4H = 977 << 8), limb 1 += tlo * 8 + thi * K11 (K11 = 2048 = 2^(32 + 8 - 29));
+                h[8] itself joins column 8 as h[8] * K0H (31264 << 3).
     low half    column k = sum a_i b_(k-i) + h[k]*31264 + h[k-1]*2^8 (+ the terms above), k = 0..6: one v_and (limb) and one v_lshrrev_b64 (carry) each
     fix-up      column 6's carry + x7 (one multiply-add by the literal 1) -> limb 7 and a remainder < 2^8 that joins limb 8: tight, no second pass.
 
 Rounds 1-3 ran the low half 0..8 in order and folded column 8's excess at the end, which touched limbs 0..2 a second time (two more masks, two shifts, a 64-bit
-add, moves): 140 VALU instructions per multiplication against 133 now (squaring 112 -> 105) with the same 81 + 18 fold + 7 hand-off products.
+add, moves): 140 VALU instructions per multiplication against 132 now (111 multiply-adds + 21 others; squaring 112 -> 104, 75 + 29) -- the counts of
+profiles/r04_isa_mix.txt (tests/test_abi_cpu.py holds the committed plume_fe_mul.inc to this script's output).
 
 fe_sqr3 (3a^2), fe_sqr2 (2a^2), fe_sqr_d / fe_sqr2_d (also return 2a) ride factors in the squaring's operands for the group law's doubling;
 fe_mul_sub / fe_sqr_sub / fe_sqr_sub2 take the group law's "product minus something" into the product's own fold: the unreduced difference M*p - s joins the low

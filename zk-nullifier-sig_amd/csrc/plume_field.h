@@ -110,8 +110,12 @@ PLUME_HD uint32_t subb0(uint32_t a, uint32_t& bw) { return subb(a, opaque_zero()
 //
 // Limb bounds ("magnitudes") are the caller's contract, checked by assertions in host builds with PLUME_FE_CHECK:
 //   tight      limbs 0..7 <= 2^29 + 2^19, limb 8 <= 2^24 + 2^10        what fe_mul / fe_sqr / fe_carry / fe_add / fe_sub return
-//   fe_mul, fe_sqr inputs: 9 * max(a[0..7]) * max(b[0..7]) < 2^64 - 2^50 and limb 8 <= 2^26 on both sides, i.e. both
-//              operands up to ~1.3 * 2^30 (sums of two tight values), or one up to 2^31 and the other tight
+//   fe_mul, fe_sqr inputs: 9 * max(a[0..7]) * max(b[0..7]) < 2^64 - 2^50 AND limb 8 <= 2^26 on both sides.  In terms of lazy sums: both operands sums of two tight
+//              values (limbs 0..7 up to ~1.3 * 2^30), or one a sum of THREE tight values (limbs 0..7 < 2^31, limb 8 <= 3 * (2^24 + 2^10) < 2^26) and the other tight.
+//              A sum of FOUR tight values breaks the limb-8 bound (4 * (2^24 + 2^10) > 2^26) although its lower limbs would still pass: carry it first.  (Limb 8 is
+//              tighter than the others since round 4: the product's top column adds h[8] << 8 on a 32-bit high word, gen_fe_mul.py.)  Host builds assert both bounds on
+//              every product (PLUME_FE_CHECK); tests/test_devsim.py::test_group_law_compositions_keep_every_product_operand_in_bounds drives the group law's
+//              compositions to the ends of the tight range.
 //   fe_add_lazy / fe_sub_lazy<M> return unreduced sums: limb bounds add (a + M*p - b), no carry pass
 //   fe_normalize gives the canonical representative (limbs < 2^29, value < p) where one is needed (comparisons, parity,
 //              serialisation).
