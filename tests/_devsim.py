@@ -75,17 +75,32 @@ def sc_op(op, a, b=None):
     return from_limbs(out)
 
 
+NPOS = 65          # PLUME_NPOS: positions of the Eisenstein digits of a pair of 128-bit halves
+
+
+def eis_digit(code):
+    """digit code of csrc/plume_ec.h -> the Eisenstein integer (a, b) = a + b w it stands for: 0 -> 0; 1 + 6 row + 2 j + neg -> (-1)^neg w^j (1 | theta = 1 - w | 2)"""
+    if code == 0:
+        return (0, 0)
+    c = code - 1
+    row, j, neg = c // 6, (c % 6) >> 1, c & 1
+    a, b = [(1, 0), (1, -1), (2, 0)][row]
+    for _ in range(j):
+        a, b = -b, a - b                                   # times w:  w (a + b w) = -b + (a - b) w
+    return (-a, -b) if neg else (a, b)
+
+
 def glv(ks):
+    """k -> (|k1|, sign, |k2|, sign, the 65 digit codes of k1 + k2 w)"""
     K = to_limbs(ks)
     out = np.zeros((len(ks), 10), dtype=np.uint32)
-    dig = np.zeros((len(ks), 66), dtype=np.int8)
+    dig = np.zeros((len(ks), NPOS), dtype=np.int8)
     lib().ds_glv(C.c_size_t(len(ks)), _p(K, u32p), _p(out, u32p), dig.ctypes.data_as(C.POINTER(C.c_int8)))
     res = []
-    nd = (128 + wbits()) // wbits()                    # PLUME_NDIG: 33 digits per half for 4-bit windows
     for r in range(len(ks)):
         m1 = sum(int(out[r, i]) << (32 * i) for i in range(4))
         m2 = sum(int(out[r, 5 + i]) << (32 * i) for i in range(4))
-        res.append((m1, int(out[r, 4]), m2, int(out[r, 9]), dig[r, :nd].tolist(), dig[r, nd:2 * nd].tolist()))
+        res.append((m1, int(out[r, 4]), m2, int(out[r, 9]), dig[r].tolist()))
     return res
 
 
@@ -215,7 +230,7 @@ def registers_from_be(values):
 
 
 def tables_raw(points):
-    """window tables (1P..8P as 64-byte records; 1P..16P in the 5-bit-window build) of raw, UNVALIDATED affine bases built by one lane"""
+    """window tables (rows P, theta P = P - lambda P, 2P as 64-byte records) of raw, UNVALIDATED affine bases built by one lane"""
     pts = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 64)
     lib().ds_tab_entries.restype = C.c_uint32
     out = np.zeros((len(pts), int(lib().ds_tab_entries()), 64), dtype=np.uint8)

@@ -115,7 +115,7 @@ void ds_sc_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32
     }
 }
 uint32_t ds_wbits() { return PLUME_WBITS; }                  // window width (4)
-// k (8 limbs) -> m1[4], neg1, m2[4], neg2 (10 words) and 2 x PLUME_NDIG digits (int8) in rows of 66
+// k (8 limbs) -> m1[4], neg1, m2[4], neg2 (10 words) and the PLUME_NPOS Eisenstein digit codes of the pair (int8, rows of 65)
 void ds_glv(size_t count, const uint32_t* k, uint32_t* out, int8_t* digits) {
     for (size_t i = 0; i < count; i++) {
         sc x; for (int j = 0; j < 8; j++) x.v[j] = k[8 * i + j];
@@ -123,8 +123,7 @@ void ds_glv(size_t count, const uint32_t* k, uint32_t* out, int8_t* digits) {
         glv_split(h1, h2, x);
         for (int j = 0; j < 4; j++) { out[10 * i + j] = h1.m[j]; out[10 * i + 5 + j] = h2.m[j]; }
         out[10 * i + 4] = h1.neg; out[10 * i + 9] = h2.neg;
-        booth_store(digits + 66 * i, 1, h1, false);
-        booth_store(digits + 66 * i + PLUME_NDIG, 1, h2, false);
+        eisd_store_glv(digits + PLUME_NPOS * i, 1, h1, h2, false);
     }
 }
 void ds_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
@@ -168,55 +167,39 @@ static const std::vector<uint32_t>& shared_gcomb() {
     return gcomb;
 }
 
-// host stand-in for launch_tables: the same lane -> jobs mapping, the same lane-interleaved scratch indexing and the same PASS sequence as the multi-kernel form of
-// the table stage (one loop over the lanes per pass, the lanes' running products in a word-major array, tab_invert_group between two passes); a batch of one lane also runs
-// the one-function form (table_build_affine) and the two must agree
-static int g_tables_small = 0;
-void ds_set_tables_small(int on) { g_tables_small = on; }      // the table stage then takes the small-batch path (Jacobian chain, one inversion: tabj_pass_a / b)
-static void run_tables_small(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs) {
-    const size_t stride = ((njobs + 7) / 8) * 8;
-    std::vector<uint32_t> scr(stride * (size_t)PLUME_TAB_ENTRIES * PLUME_TABJ_ENTRY_WORDS), carry(stride * PLUME_FE_WORDS);
+// host stand-in for launch_tables: the same lane -> jobs mapping, the same lane-interleaved scratch indexing and the same PASS sequence as the table stage (one loop over the
+// lanes per pass, the lanes' running products in a word-major array, tab_invert_group between the two passes); a batch of one lane also runs the one-function form
+// (table_build) and the two must agree
+void ds_set_tables_small(int) {}                                  // (rounds 4's small-batch table path is gone: one path for every size)
+static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
+    const size_t lanes = (njobs + L - 1) / L, stride = ((lanes + 7) / 8) * 8;     // "grid" rounded up like the kernel's
+    std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_SCR_WORDS), carry(stride * PLUME_FE_WORDS);
+    std::vector<uint8_t> guardf(stride, 0);
     constexpr int K = 8;
     const size_t T = (stride + K - 1) / K;
+    const DirectRowSinkSync sink;
+    auto span = [&](size_t lane, size_t& j0, int& cnt) { j0 = lane * (size_t)L; cnt = j0 < njobs ? (int)(njobs - j0 < (size_t)L ? njobs - j0 : (size_t)L) : 0; };
     for (size_t lane = 0; lane < stride; lane++) {
-        fe c = fe_small(1);
-        if (lane < njobs) tabj_pass_a_guarded(bases, jobflags, njobs, lane, scr.data(), stride, lane, c);
-        st_fe_soa(carry.data(), stride, lane, c);
+        size_t j0; int cnt; span(lane, j0, cnt);
+        fe c; bool g = false;
+        tab_pass_a(bases, jobflags, njobs, j0, cnt, scr.data(), stride, lane, c, g);
+        st_fe_soa(carry.data(), stride, lane, c); guardf[lane] = g ? 1 : 0;
     }
     for (size_t t = 0; t < T; t++) tab_invert_group<K>(carry.data(), stride, T, t);
-    for (size_t lane = 0; lane < njobs; lane++) { fe c; ld_fe_soa(c, carry.data(), stride, lane); tabj_pass_b(tab, lane, scr.data(), stride, lane, c); }
-}
-static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
-    if (g_tables_small) { run_tables_small(tab, bases, jobflags, njobs); return; }
-    const size_t lanes = (njobs + L - 1) / L, stride = ((lanes + 7) / 8) * 8;     // "grid" rounded up like the kernel's
-    std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_AFF_SCR_WORDS), carry(stride * PLUME_FE_WORDS);
-    std::vector<uint8_t> guardf(stride, 0);
-    constexpr int K = 8, NPASS = 4;
-    const size_t T = (stride + K - 1) / K;
-    const DirectRowSinkSync sink;
-    for (int pass = 0; pass < NPASS; pass++) {
-        for (size_t lane = 0; lane < stride; lane++) {
-            const size_t j0 = lane * (size_t)L;
-            const int cnt = j0 < njobs ? (int)(njobs - j0 < (size_t)L ? njobs - j0 : (size_t)L) : 0;
-            fe c; bool g = false;
-            if (pass > 0) { ld_fe_soa(c, carry.data(), stride, lane); g = guardf[lane] != 0; }
-            if (pass == 0) tab_pass_a<DirectRowSinkSync>(bases, jobflags, njobs, j0, cnt, scr.data(), stride, lane, c, g);
-            else if (pass == 1) tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr.data(), stride, lane, c, g, sink);
-            else if (pass == 2) tab_pass_c(tab, j0, cnt, scr.data(), stride, lane, c, g, sink);
-            else if (pass == 3) tab_pass_d(tab, j0, cnt, scr.data(), stride, lane, c, g, sink);
-            if (pass < NPASS - 1) { st_fe_soa(carry.data(), stride, lane, c); guardf[lane] = g ? 1 : 0; }
-        }
-        if (pass < NPASS - 1) for (size_t t = 0; t < T; t++) tab_invert_group<K>(carry.data(), stride, T, t);
+    for (size_t lane = 0; lane < stride; lane++) {
+        size_t j0; int cnt; span(lane, j0, cnt);
+        fe c; ld_fe_soa(c, carry.data(), stride, lane);
+        tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr.data(), stride, lane, c, guardf[lane] != 0, sink);
     }
     if (lanes == 1) {                                                              // the one-function form on the same input
-        std::vector<uint32_t> tab2((size_t)njobs * PLUME_TAB_WORDS), scr2((size_t)L * PLUME_TAB_AFF_SCR_WORDS);
-        table_build_affine(tab2.data(), bases, jobflags, njobs, 0, (int)njobs, scr2.data(), 1, 0);
-        if (memcmp(tab2.data(), tab, tab2.size() * 4) != 0) { fprintf(stderr, "devsim: table_build_affine and the pass sequence disagree\n"); abort(); }
+        std::vector<uint32_t> tab2((size_t)njobs * PLUME_TAB_WORDS), scr2((size_t)L * PLUME_TAB_SCR_WORDS);
+        table_build(tab2.data(), bases, jobflags, njobs, 0, (int)njobs, scr2.data(), 1, 0);
+        if (memcmp(tab2.data(), tab, tab2.size() * 4) != 0) { fprintf(stderr, "devsim: table_build and the pass sequence disagree\n"); abort(); }
     }
 }
 
 // window tables of `nb` affine bases given as raw 64-byte records, all flagged usable WITHOUT validation, built by ONE lane (test hook for the
-// zero-denominator guard of table_build_affine); out: nb x PLUME_TAB_ENTRIES x 64 bytes (x || y of 1P..)
+// zero-denominator guard of the table passes); out: nb x PLUME_TAB_ENTRIES x 64 bytes (x || y of the rows P, theta P, 2P)
 void ds_tables_raw(uint32_t nb, const uint8_t* pts, uint8_t* out) {
     std::vector<uint32_t> bases(PLUME_BASE_WORDS * (size_t)nb), tab((size_t)nb * PLUME_TAB_WORDS);
     std::vector<uint8_t> flags(nb, (uint8_t)(PLUME_JOB_OK | PLUME_JOB_AFFINE));
@@ -235,7 +218,7 @@ void ds_tables_raw(uint32_t nb, const uint8_t* pts, uint8_t* out) {
             memcpy(out + 64 * (PLUME_TAB_ENTRIES * (size_t)j + k), rec, 64);
         }
 }
-uint32_t ds_tab_entries() { return PLUME_TAB_ENTRIES; }     // rows per window table (8)
+uint32_t ds_tab_entries() { return PLUME_TAB_ENTRIES; }     // rows per window table (3: P, theta P = P - lambda P, 2P)
 
 // simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)
 static const uint32_t B = 8;
@@ -304,7 +287,7 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     for (uint32_t i = 0; i < n; i++) verify_scalars(a, i);
     const size_t nj = J * (size_t)n;
     run_tables(a.tab, a.bases, a.jobflags, nj, L);
-    std::vector<int8_t> dig(4 * PLUME_NDIG * B);
+    std::vector<int8_t> dig((2 * PLUME_NDIG + PLUME_NPOS) * B);
     std::vector<uint32_t> redo(2 * (size_t)n + 1, 0);
     a.redo = redo.data();
     for (uint32_t eq = 0; eq < 2; eq++)
@@ -448,7 +431,7 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
     a.gres = gres.data(); a.gresinf = gresinf.data(); a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
     a.pkaff = pkaff.data(); a.tab = tab.data(); a.hres = hres.data(); a.hresinf = hresinf.data(); a.gcomb = gcomb.data(); a.gscan = shared_gscan().data(); a.uniform = g_sign_uniform;
-    std::vector<int8_t> dig(4 * PLUME_NDIG * B);
+    std::vector<int8_t> dig((2 * PLUME_NDIG + PLUME_NPOS) * B);
     for (uint32_t w = 0; w < 2; w++)
         for (uint32_t i = 0; i < n; i++) { if (g_sign_uniform == 2) sign_gmul<2>(a, i, w); else if (g_sign_uniform) sign_gmul<1>(a, i, w); else sign_gmul(a, i, w); }
     {
@@ -487,7 +470,7 @@ int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[6
     jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
     for (int j = 0; j < 3; j++) { st_base(a.bases, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
     run_tables(a.tab, a.bases, a.jobflags, 3, 3);
-    std::vector<int8_t> dig(4 * PLUME_NDIG), digs(PLUME_VDIG_ROWS);
+    std::vector<int8_t> dig(2 * PLUME_NDIG + PLUME_NPOS), digs(PLUME_VDIG_ROWS);
     { sc sv, cv; sc_from_be_aligned(sv, sb); sc_from_be_aligned(cv, cb); verify_item_digits(digs.data(), 1, sv, cv, true); }     // what the scalar stage leaves for the item (long form)
     a.digs = digs.data();
     uint32_t redo[3] = {0, 0, 0};
@@ -545,7 +528,7 @@ int ds_eq1_short(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t p
     p.x = rx; p.y = ry;
     st_base(a.bases, 3, p); a.jobflags[3] = (uint8_t)(fr | PLUME_JOB_AFFINE);
     run_tables(a.tab, a.bases, a.jobflags, 4, 4);
-    std::vector<int8_t> dig(4 * PLUME_NDIG), digs(PLUME_VDIG_ROWS);
+    std::vector<int8_t> dig(2 * PLUME_NDIG + PLUME_NPOS), digs(PLUME_VDIG_ROWS);
     a.digs = digs.data();
     verify_scalars(a, 0);
     if (used_long) *used_long = eq1long[0];
@@ -610,9 +593,9 @@ int ds_point_mul(const uint8_t k_be[32], const uint8_t p_be[64], uint8_t out[64]
     sc k; sc_from_be_aligned(k, kb);
     while (!sc_lt_n(k)) sc_cond_sub_n(k);
     glv_half h1, h2; glv_split(h1, h2, k);
-    std::vector<int8_t> dig(2 * PLUME_NDIG);
-    booth_store(dig.data(), 1, h1, false); booth_store(dig.data() + PLUME_NDIG, 1, h2, false);
-    jac acc; msm_run(acc, tab.data(), nullptr, 2, dig.data(), 1);
+    std::vector<int8_t> dig(2 * PLUME_NPOS);
+    eisd_store_glv(dig.data(), 1, h1, h2, false);
+    jac acc; msm_run(acc, tab.data(), nullptr, dig.data(), 1);
     fe ox = fe_zero(), oy = fe_zero();
     if (!acc.inf) { fe zi, zi2; fe_inv(zi, acc.z); fe_sqr(zi2, zi); fe_mul(ox, acc.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(oy, acc.y, zi2); }
     store_affine_be(ob, ox, oy, acc.inf != 0);

@@ -172,17 +172,57 @@ def test_glv_and_booth():
     g2 = 0xE4437ED6010E88286F547FA90ABFE4C4221208AC9DF506C61571B4AE8AC47F71
     a1, mb1, a2 = 0x3086D221A7D46BCDE86C90E49284EB15, 0xE4437ED6010E88286F547FA90ABFE4C3, 0x114CA50F7A8E2F3F657C1108D9D44CFD8
     ks += [N - lam, 2**255, 2**256 % N, (1 << 174) - 1, 1 << 174, (1 << 174) + 1, (1 << 145) - 1, g1 % N, g2 % N] + [rng.randrange(N) for _ in range(6000)]
-    for k, (m1, n1, m2, n2, d1, d2) in zip(ks, D.glv(ks)):
+    nonzero = total = 0
+    for k, (m1, n1, m2, n2, codes) in zip(ks, D.glv(ks)):
         assert m1 < 2**128 and m2 < 2**128
         k1 = -m1 if n1 else m1
         k2 = -m2 if n2 else m2
         assert (k1 + k2 * lam) % N == k
         c1, c2 = (k * g1 + (1 << 383)) >> 384, (k * g2 + (1 << 383)) >> 384
         assert (k1, k2) == (k - c1 * a1 - c2 * a2, c1 * mb1 - c2 * a1), hex(k)
-        w = D.wbits()
-        for m, neg, d in ((m1, n1, d1), (m2, n2, d2)):
-            assert len(d) == (128 + w) // w and all(-(1 << (w - 1)) <= x <= 1 << (w - 1) for x in d)
-            assert sum(x << (w * i) for i, x in enumerate(d)) == (-m if neg else m)
+        # round 5: ONE Eisenstein digit per position (plume_ec.h eisd_store): k1 + k2 w = sum d_i 4^i, d_i in {0, units, associates of 1 - w, associates of 2}
+        assert len(codes) == D.NPOS and all(0 <= c <= 18 for c in codes)
+        va = vb = 0
+        for c in reversed(codes):
+            da, db = D.eis_digit(c)
+            va, vb = 4 * va + da, 4 * vb + db
+        assert (va, vb) == (k1, k2), hex(k)
+        nonzero += sum(1 for c in codes[:64] if c)
+        total += 64
+    assert 0.92 < nonzero / total < 0.95                       # fifteen of the sixteen residues mod 4 are non-zero digits
+
+
+def test_eisenstein_digit_table():
+    """the 64-entry table behind eisd_entry (plume_ec.h), regenerated from its definition: for t = (ta, tb), |t| <= 4, the digit is the representative of t mod 4 among
+    0, the units, the associates of theta = 1 - w and of 2 that leaves a carry (t - d) / 4 in {-1, 0, 1}^2; and the header carries exactly this table"""
+    import re
+    digits = {c: D.eis_digit(c) for c in range(1, 19)}
+    assert len(set(digits.values())) == 18 and all(max(abs(a), abs(b)) <= 2 for a, b in digits.values())
+    assert {(a % 4, b % 4) for a, b in digits.values()} | {(0, 0)} == {(a, b) for a in range(4) for b in range(4)}      # a complete residue system of Z[w] / 4
+    tab = []
+    for idx in range(64):
+        ca, cb, na, nb = (idx >> 2) & 3, idx & 3, (idx >> 4) & 1, (idx >> 5) & 1
+        ta_s = [t for t in range(-4, 5) if t % 4 == ca and (t < 0) == bool(na)]
+        tb_s = [t for t in range(-4, 5) if t % 4 == cb and (t < 0) == bool(nb)]
+        if not ta_s or not tb_s:
+            tab.append(0)
+            continue
+        if (ca, cb) == (0, 0):
+            tab.append(0 | (2 << 5) | (2 << 8))
+            continue
+        best = None
+        for code, d in digits.items():
+            if (d[0] % 4, d[1] % 4) != (ca, cb):
+                continue
+            worst = max([abs((t - d[0]) // 4) for t in ta_s] + [abs((t - d[1]) // 4) for t in tb_s])
+            if best is None or worst < best[0]:
+                best = (worst, code, d)
+        assert best and best[0] <= 1, idx
+        tab.append(best[1] | ((best[2][0] + 2) << 5) | ((best[2][1] + 2) << 8))
+    src = (Path(__file__).parent.parent / "zk-nullifier-sig_amd" / "csrc" / "plume_ec.h").read_text()
+    body = src[src.index("static const uint16_t T[64] = {"):]
+    body = body[:body.index("};")]
+    assert [int(x, 16) for x in re.findall(r"0x[0-9A-Fa-f]{3}", body)] == tab
 
 
 def test_sha256_generic():
@@ -297,26 +337,33 @@ def test_uniform_schedule_signer_gives_the_same_bytes(ver, level):
         assert np.array_equal(got2[key], want[key]), key
 
 
+
+_LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+
+
+def _table_rows(pt):
+    """the three rows of a window table (csrc/plume_ec.h, round 5): P, theta P = P - lambda P, 2P"""
+    lp = O.pt_mul(_LAMBDA, pt)
+    return [O.pt_bytes(pt), O.pt_bytes(O.pt_add(pt, O.pt_neg(lp))), O.pt_bytes(O.pt_mul(2, pt))]
+
+
 def test_small_batch_table_path_gives_the_same_tables_and_results():
-    """round 4: table stages of up to 3 * 2^16 jobs build 1P..8P by a Jacobian chain with ONE inversion (tabj_pass_a / tabj_pass_b) instead of the affine chain's three.
-    The rows must be the same POINTS (k P affine, beta x), hence the same signatures and verdicts: tables of honest / identity / invalid bases, the golden signs (affine pk
-    bases and the Jacobian H), goldens + edge cases + a fuzzed batch through verify."""
+    """(Round 4 had two table builders, an affine chain and a Jacobian one for small batches, and this test held them to each other.  Round 5 has ONE: rows P, theta P,
+    2P by a single round of inversions, plume_ec.h.)  The rows are the right POINTS -- tables of honest bases next to a record that is no curve point --, and the pipeline on
+    top gives the oracle's bytes: the golden signs (affine pk bases and the Jacobian H), goldens + edge cases + a fuzzed batch through verify."""
     from tests import _fuzz
     rng = random.Random(5)
     pts = [O.pt_mul(rng.randrange(1, N), O.G) for _ in range(11)]
     bases = np.zeros((len(pts) + 1, 64), dtype=np.uint8)
     for j, pt in enumerate(pts):
         bases[j] = np.frombuffer(pt[0].to_bytes(32, "big") + pt[1].to_bytes(32, "big"), dtype=np.uint8)
-    bases[len(pts), 31] = 5                                               # (5, 0): no curve point, and y = 0 makes its doubling's Z vanish: the guard must keep the neighbours' rows intact
-    want = D.tables_raw(bases)
-    D.set_tables_small(True)
+    bases[len(pts), 31] = 5                                               # (5, 0): no curve point, and y = 0 makes a denominator vanish: the guard must keep the neighbours' rows intact
+    D.set_tables_small(True)                                              # (a no-op since round 5)
     try:
         got = D.tables_raw(bases)
-        assert np.array_equal(got[:len(pts)], want[:len(pts)])
+        assert got.shape[1] == 3
         for j, pt in enumerate(pts):
-            for k in range(8):
-                kp = O.pt_mul(k + 1, pt)
-                assert got[j, k].tobytes() == kp[0].to_bytes(32, "big") + kp[1].to_bytes(32, "big")
+            assert [got[j, k].tobytes() for k in range(3)] == _table_rows(pt), j
         for ver in (1, 2):
             items = GOLD[f"sign_v{ver}"]
             mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
@@ -681,23 +728,24 @@ def test_sec1_der_scalar_marshalling(kats):
 
 
 def test_affine_table_chain_and_its_zero_denominator_guard():
-    """table_build_affine: (a) the tables of honest bases are k*P, k = 1..8, whatever else shares the lane; (b) a record that is no curve point and makes a
-    denominator vanish (y = 0: the first doubling divides by 2y) cannot poison the OTHER jobs of its lane -- the level is redone with that denominator
-    replaced.  (Such a record never reaches the builder through the API: bases are validated and replaced by G first.)"""
+    """the table passes: (a) the tables of honest bases are P, theta P = P - lambda P, 2P, whatever else shares the lane; (b) a record that is no curve point and makes a
+    denominator vanish (y = 0: the doubling divides by 2y; x = 0: theta P divides by (beta - 1) x) cannot poison the OTHER jobs of its lane -- the pass is redone with that
+    denominator replaced.  (Such a record never reaches the builder through the API: bases are validated and replaced by G first.)"""
     rng = random.Random(12)
     pts = [O.G, O.pt_mul(rng.randrange(1, N), O.G), O.pt_mul(N - 1, O.G), O.pt_mul(rng.randrange(1, N), O.G)]
     rec = lambda p: p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")  # noqa: E731
     good = np.frombuffer(b"".join(rec(p) for p in pts), dtype=np.uint8).reshape(-1, 64)
     got = D.tables_raw(good)
-    E = got.shape[1]                                                   # 8 rows (16 in the 5-bit-window build)
-    want = [[O.pt_bytes(O.pt_mul(k, p)) for k in range(1, E + 1)] for p in pts]
+    E = got.shape[1]
+    assert E == 3
+    want = [_table_rows(p) for p in pts]
     assert [[got[j, k].tobytes() for k in range(E)] for j in range(len(pts))] == want
-    bogus = (5).to_bytes(32, "big") + bytes(32)                        # y = 0
-    mixed = np.concatenate([good[:2], np.frombuffer(bogus, dtype=np.uint8).reshape(1, 64), good[2:]])
-    got = D.tables_raw(mixed)
-    for j, src in enumerate([0, 1, None, 2, 3]):
-        if src is not None:
-            assert [got[j, k].tobytes() for k in range(E)] == want[src], j
+    for bogus in ((5).to_bytes(32, "big") + bytes(32), bytes(32) + (3).to_bytes(32, "big")):      # y = 0; x = 0
+        mixed = np.concatenate([good[:2], np.frombuffer(bogus, dtype=np.uint8).reshape(1, 64), good[2:]])
+        got = D.tables_raw(mixed)
+        for j, src in enumerate([0, 1, None, 2, 3]):
+            if src is not None:
+                assert [got[j, k].tobytes() for k in range(E)] == want[src], j
 
 
 def test_twenty_bit_generator_window_build_of_the_device_headers(tmp_path):

@@ -348,7 +348,8 @@ def test_crafted_items_are_redone_by_the_second_launch_and_cost_only_themselves(
     try:
         eng.set_eq1_short(0)                                  # the items are crafted against the LONG form of equation 1 (s G - c pk along one chain of 128 doublings)
         got, redone = run(v)
-        assert redone >= len(idx), (redone, len(idx))
+        assert redone >= len(idx) // 4, (redone, len(idx))   # (rounds 3-4: every crafted item met p == +-q; with the Eisenstein digits of round 5 about half of these do -- the others'
+                                                             # digits of -c no longer mirror the generator's -- and whatever does is filed; the verdicts are the CPU's either way)
         assert np.array_equal(got, want) and int(got.sum()) == n - len(idx)
     finally:
         eng.set_eq1_short(1)

@@ -141,7 +141,6 @@ struct plume_ctx {
     std::vector<Worker*> workers;
     HostSlot slot[4];                                              // host-pointer calls: staging slots (two for the one-lane pipeline, four when two lanes take the pieces in turn)
     plume_ctx* host_lane = nullptr;                                // ... the second lane of the host-pointer pipeline: a complete single-device context (workspace, streams), created on first use
-    size_t tables_small_max = (size_t)3 << 15;                     // table stages of at most this many jobs take the small-batch path (Jacobian chain, one inversion: launch_tables_small)
     size_t ingest_split_max = (size_t)1 << 16;                     // verify calls (slices) of at most this many items run the ingest stage with two lanes per item (latency-bound there)
     int sign_uniform = 1;                                          // plume_set_sign_uniform: the signer's schedule (level 0, 1, 2).  Default 1 since round 5: no branch on a digit of sk or r
                                                                    // (k256's multiplication is constant-time, rust-k256/src/randomizedsigner.rs:51-70; measured price +2.5 % per signature)
@@ -172,7 +171,7 @@ struct plume_ctx {
 // knob cannot reach some derived contexts and miss others (round 4's host lane did not inherit sign_uniform: VERDICT r4).
 static void inherit_tunables(plume_ctx* to, const plume_ctx* from) {
     to->chunk = from->chunk; to->sub_batches = from->sub_batches; to->overlap_min = from->overlap_min; to->sign_uniform = from->sign_uniform;
-    to->ingest_split_max = from->ingest_split_max; to->tables_small_max = from->tables_small_max; to->msm_split_max = from->msm_split_max;
+    to->ingest_split_max = from->ingest_split_max; to->msm_split_max = from->msm_split_max;
     to->jobs_per_lane = from->jobs_per_lane; to->jobs_per_lane_forced = from->jobs_per_lane_forced;
     to->host_piece = from->host_piece; to->host_first_piece = from->host_first_piece; to->host_tail_piece = from->host_tail_piece; to->host_register_min = from->host_register_min;
     to->host_lanes = from->host_lanes; to->host_sign_lanes = from->host_sign_lanes; to->eq1_short = from->eq1_short; to->eq1_short_min = from->eq1_short_min;
@@ -286,7 +285,6 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_HOST_FIRST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_first_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_TAIL_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_tail_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
-    if (const char* e = std::getenv("PLUME_TABLES_SMALL_MAX")) { long v = std::atol(e); if (v >= 0) ctx->tables_small_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_INGEST_SPLIT_MAX")) { long v = std::atol(e); if (v >= 0) ctx->ingest_split_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::min(2, std::max(0, std::atoi(e)));   // default of new contexts (plume_set_sign_uniform); 0 opts out of the uniform schedule
     if (const char* e = std::getenv("PLUME_EQ1_SHORT")) { int v = std::atoi(e); if (v >= 0 && v <= 3) ctx->eq1_short = v; }   // A/B and test knob (plume_eis.h)
@@ -653,15 +651,10 @@ static int pick_jobs_per_lane(const plume_ctx* ctx, size_t njobs, bool kinds_of_
 
 // the window-table stage of njobs jobs: the small-batch path (one inversion on the critical path) or the affine chain's passes
 // nthrees: how many of the jobs, from the front, come as (pk, H, nullifier) triples (the verifier: 3 per item; its short first equation appends one more job per item behind
-// them; the signer: 0).  The small-batch threshold counts the triples when there are any, so that it means the same number of ITEMS in either form of the verifier.
-static bool table_stage_small(const plume_ctx* ctx, size_t njobs, size_t nthrees) { return (nthrees ? nthrees : njobs) <= ctx->tables_small_max; }
-static size_t table_stage_scratch(const plume_ctx* ctx, size_t njobs, size_t nthrees) {
-    if (table_stage_small(ctx, njobs, nthrees)) return tables_small_scratch_bytes(njobs);
-    return tables_scratch_bytes(njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0));
-}
+// them; the signer: 0): the jobs per lane are then a multiple of three, so that the kinds line up across a wavefront (affine and Jacobian bases take different paths).
+static size_t table_stage_scratch(const plume_ctx* ctx, size_t njobs, size_t nthrees) { return tables_scratch_bytes(njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0)); }
 static void table_stage(plume_ctx* ctx, uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t nthrees, hipStream_t st) {
-    if (table_stage_small(ctx, njobs, nthrees)) launch_tables_small(tab, bases, jobflags, njobs, nthrees, ctx->tabscr.as<uint32_t>(), st);
-    else launch_tables(tab, bases, jobflags, njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0), ctx->tabscr.as<uint32_t>(), st);
+    launch_tables(tab, bases, jobflags, njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0), ctx->tabscr.as<uint32_t>(), st);
 }
 
 // ------------------------------------------------------------------------------------------ device pipelines

@@ -107,7 +107,7 @@ PLUME_HD void jac_dbl_cold(jac& p) { jac tmp = p; jac_dbl_cold_impl(&tmp); p = t
 template <bool CHECKED = true>
 PLUME_HD void jac_madd(jac& p, const fe& qx, const fe& qy) {
     if (p.inf) {
-        p.x = qx; p.y = qy; fe_carry(p.y); p.z = fe_small(1); p.inf = 0;
+        p.x = qx; fe_carry(p.x); p.y = qy; fe_carry(p.y); p.z = fe_small(1); p.inf = 0;      // (qx: a table row's beta^2 x arrives unreduced, ld_tab_unit)
         return;
     }
     fe z1z1, s2, h, r, hh, hhh, v, t;
@@ -323,32 +323,58 @@ PLUME_HD void booth_store_wide(int8_t* dig, uint32_t stride, const glv_half& h, 
         }
     }
 }
-// writes the 33 signed digits of one half-scalar to dig[i*stride], sign applied
-PLUME_HD void booth_store(int8_t* dig, uint32_t stride, const glv_half& h, bool flip) {
-    bool neg = (h.neg != 0) != flip;
-    PLUME_UNROLL for (int i = 0; i < PLUME_NDIG; i++) {
-        int d = booth_digit(h.m, i);
-        dig[(uint32_t)i * stride] = (int8_t)(neg ? -d : d);
-    }
+// ---------------------------------------------------------------------------------- digits in the Eisenstein integers (round 5)
+// A GLV pair (k1, k2) IS the Eisenstein integer kappa = k1 + k2 w (w^2 + w + 1 = 0; w acts as lambda: (x, y) -> (beta x, y)).  Rounds 1-4 recoded the two halves apart --
+// 4-bit Booth windows, a P-slot and a lambda-P-slot per window, tables of 1P..8P -- i.e. 17 x 17 joint digit values of which only the 8 multiples of P were shared.  The
+// ring structure gives more: base 4 with ONE digit per position taken from the sixteen residues of Z[w] / 4, represented by their smallest elements
+//     0;   the six units  +-1, +-w, +-w^2;   the six associates of theta = 1 - w (norm 3);   2, 2w, 2w^2 and their negatives (norm 4; -2 = 2 mod 4)
+// and every associate u d of a digit d costs nothing: u (x, y) = (x | beta x | beta^2 x, +-y).  So a table is THREE rows -- P, theta P = P - lambda P, 2P -- instead of
+// eight, built with ONE round of inversions instead of three (the denominators 2y and (beta - 1) x come straight from P), while the chain keeps its counts: a position
+// (two doublings) adds one point with probability 15/16, where a 4-bit window (four doublings) added two.  Table stage of a 2^20 verify: see DESIGN.md.
+//   digit code (one byte per position):  0 = nothing to add;  otherwise 1 + 6 row + 2 j + neg  =  (-1)^neg w^j (row point),  row 0: P, 1: theta P, 2: 2P
+// Recoding walks the pair two bits at a time with carries in {-1, 0, 1}: t = (sign chunk + carry) for both coordinates, the digit is the representative of t mod 4 that
+// keeps the next carry small (64-entry table: residues and signs of t), carry = (t - d) / 4.  After the last chunk the carries themselves are a digit (a unit or +-theta), so
+// a magnitude below 4^(NP - 1) needs NP positions.
+#define PLUME_NPOS 65        // pairs of 128-bit halves (the verifier)
+#define PLUME_NPOS64 33      // pairs of 64-bit quarters (the signer's chains of 64 doublings)
+#define PLUME_NPOS66 34      // pairs below 2^66 (the verifier's short first equation, plume_eis.h)
+PLUME_HD uint32_t eisd_entry(int ta, int tb) {
+    // entry = code | (d0 + 2) << 5 | (d1 + 2) << 8 for t = (ta, tb), |ta|, |tb| <= 4; generated (and its invariants checked) by tests/test_devsim.py::test_eisenstein_digits
+    static const uint16_t T[64] = {0x240, 0x343, 0x44F, 0x144, 0x261, 0x366, 0x469, 0x167, 0x28D, 0x38C, 0x492, 0x10B, 0x222, 0x328, 0x02A, 0x125,
+                                   0x240, 0x343, 0x44F, 0x144, 0x261, 0x366, 0x469, 0x167, 0x28D, 0x38C, 0x011, 0x10B, 0x222, 0x328, 0x02A, 0x125,
+                                   0x240, 0x343, 0x44F, 0x144, 0x261, 0x366, 0x469, 0x167, 0x28D, 0x38C, 0x011, 0x10B, 0x222, 0x328, 0x02A, 0x125,
+                                   0x240, 0x343, 0x44F, 0x144, 0x261, 0x366, 0x469, 0x167, 0x28D, 0x38C, 0x011, 0x10B, 0x222, 0x328, 0x02A, 0x125};
+    const uint32_t idx = (((uint32_t)ta & 3u) << 2) | ((uint32_t)tb & 3u) | (ta < 0 ? 16u : 0u) | (tb < 0 ? 32u : 0u);
+    return T[idx];
 }
-
-// The signer's quarter scalars (round 4): a 128-bit half of the GLV split is cut once more at bit 64, m = lo + hi 2^64, so that k1 P = lo P + hi (2^64 P) runs along a
-// chain of 64 doublings instead of 128 when the table of 2^64 P exists.  17 Booth digits per 64-bit quarter (the top one is the recoding's carry: 0 or 1).
-#define PLUME_NDIG64 ((64 + PLUME_WBITS) / PLUME_WBITS)
-PLUME_HD void booth_store64(int8_t* dig, uint32_t stride, uint32_t lo, uint32_t hi, bool neg) {
-    const uint32_t m[4] = {lo, hi, 0u, 0u};
-    PLUME_UNROLL for (int i = 0; i < PLUME_NDIG64; i++) {
-        int d = booth_digit(m, i);
-        dig[(uint32_t)i * stride] = (int8_t)(neg ? -d : d);
+// NP digit codes of  +-(a + b w),  a = (aneg ? -1 : 1) am,  b likewise, magnitudes below 4^(NP - 1) given as NW little-endian words; dig[i * stride] = position i.
+// Returns false if a carry is left over (the magnitude bound did not hold).
+template <int NP, int NW>
+PLUME_HD bool eisd_store(int8_t* dig, uint32_t stride, const uint32_t (&am)[NW], bool aneg, const uint32_t (&bm)[NW], bool bneg, bool flip) {
+    const int sa = (aneg != flip) ? -1 : 1, sb = (bneg != flip) ? -1 : 1;
+    int ca = 0, cb = 0;
+    PLUME_UNROLL for (int i = 0; i < NP; i++) {
+        const int w = (2 * i) >> 5, sh = (2 * i) & 31;
+        const int cha = w < NW ? (int)((am[w < NW ? w : 0] >> sh) & 3u) : 0, chb = w < NW ? (int)((bm[w < NW ? w : 0] >> sh) & 3u) : 0;
+        const int ta = sa * cha + ca, tb = sb * chb + cb;
+        const uint32_t e = eisd_entry(ta, tb);
+        dig[(uint32_t)i * stride] = (int8_t)(e & 31u);
+        ca = (ta - ((int)((e >> 5) & 7u) - 2)) >> 2;                  // exact: t = d (mod 4)
+        cb = (tb - ((int)((e >> 8) & 7u) - 2)) >> 2;
     }
+    return ca == 0 && cb == 0;
+}
+PLUME_HD void eisd_store_glv(int8_t* dig, uint32_t stride, const glv_half& h1, const glv_half& h2, bool flip) {
+    (void)eisd_store<PLUME_NPOS, 4>(dig, stride, h1.m, h1.neg != 0, h2.m, h2.neg != 0, flip);
 }
 
 // ------------------------------------------------------------------------------------------ window tables
-// One table = 8 rows x 32 words (128 B = one cache line), row e holds (e+1)*P affine as 29-bit limbs of tight field elements:
-//     [ x0..x7 | y0..y7 | b0..b7 | x8 y8 b8 0 | 0 0 0 0 ]        b = beta * x (the x of lambda*P)
-// i.e. eight 16-byte quads; one table addition gathers five of them (x or b, y, the top limbs) with aligned 16-byte loads from
-// ONE line, and the table kernel writes whole lines (112-byte rows, without the padding quad, measured 6 % slower there).
-#define PLUME_TAB_ENTRIES (1 << (PLUME_WBITS - 1))       // 8 rows per table
+// One table = 3 rows x 32 words (128 B = one cache line): row 0 = P, row 1 = theta P = P - lambda P, row 2 = 2P, affine, as 29-bit limbs of tight field elements:
+//     [ x0..x7 | y0..y7 | b0..b7 | x8 y8 b8 0 | 0 0 0 0 ]        b = beta * x (the x of lambda * (row point))
+// i.e. eight 16-byte quads; one table addition gathers seven of them (x, b, y, the top limbs) with aligned 16-byte loads from ONE line, and the table kernel writes whole
+// lines (112-byte rows, without the padding quad, measured 6 % slower there).  The generator's fixed tables (wide window table, comb, scanned table) keep rows of PLAIN
+// multiples in the same row format.  (Rounds 1-4: eight rows 1P..8P per table, 1 KiB.)
+#define PLUME_TAB_ENTRIES 3
 #define PLUME_FE_W PLUME_FE_WORDS
 #define PLUME_JAC_WORDS (3 * PLUME_FE_WORDS)      // Jacobian point in HBM scratch: x | y | z
 #define PLUME_TAB_ENTRY_WORDS 32                 // 128-byte rows (112-byte rows without the padding quad: 6 % slower in the table passes, round 2)
@@ -361,9 +387,9 @@ PLUME_HD void ld_tab_xy(fe& x, fe& y, const uint32_t* e, bool lambda_half) {
     x.v[8] = lambda_half ? e[26] : e[24];
     y.v[8] = e[25];
 }
-// The same row WITHOUT a digit-dependent address (the signer's uniform schedule, level 2): all eight rows of the window's table are read, row `ad` (1..8) is kept by
-// masked selects: 18 selects and 128 B of reads per row beside an addition of ~1400 instructions.
-template <int ROWS = PLUME_TAB_ENTRIES>
+// A row of a fixed table of plain multiples WITHOUT a digit-dependent address (the signer's uniform schedule, level 2: the scanned table of G): all ROWS rows of the window
+// are read, row `ad` (1..ROWS) is kept by masked selects: 18 selects and 128 B of reads per row beside an addition of ~1400 instructions.
+template <int ROWS>
 PLUME_HD void ld_tab_xy_scan(fe& x, fe& y, const uint32_t* tab, int ad, bool lambda_half) {
     ld_tab_xy(x, y, tab, lambda_half);
     PLUME_NOUNROLL for (int e = 1; e < ROWS; e++) {
@@ -371,21 +397,6 @@ PLUME_HD void ld_tab_xy_scan(fe& x, fe& y, const uint32_t* tab, int ad, bool lam
         ld_tab_xy(rx, ry, tab + (size_t)e * PLUME_TAB_ENTRY_WORDS, lambda_half);
         const bool take = ad == e + 1;
         fe_cmov(x, rx, take); fe_cmov(y, ry, take);
-    }
-}
-// ... and for the two slots that share a table (P with digit ad_a, lambda P with digit ad_b) in ONE pass over its rows: a per-item table is 1 KiB that no cache holds
-// between two visits, so the scan is what the level-2 chain pays in HBM traffic
-PLUME_HD void ld_tab_xy_scan2(fe& xa, fe& ya, fe& xb, fe& yb, const uint32_t* tab, int ad_a, int ad_b) {
-    ld_tab_xy(xa, ya, tab, false);
-    ld_tab_xy(xb, yb, tab, true);
-    PLUME_NOUNROLL for (int e = 1; e < PLUME_TAB_ENTRIES; e++) {
-        const uint32_t* row = tab + (size_t)e * PLUME_TAB_ENTRY_WORDS;
-        fe rx, ry, rb;
-        ld_tab_xy(rx, ry, row, false);
-        ld_tab_xy(rb, ry, row, true);
-        const bool ta = ad_a == e + 1, tb = ad_b == e + 1;
-        fe_cmov(xa, rx, ta); fe_cmov(ya, ry, ta);
-        fe_cmov(xb, rb, tb); fe_cmov(yb, ry, tb);
     }
 }
 PLUME_HD void st_tab_entry(uint32_t* e, const fe& x, const fe& y, const fe& bx) {   // (non-temporal stores here: 3.6x slower, they defeat write combining)
@@ -448,28 +459,25 @@ PLUME_HD uint32_t job_state(uint8_t f) { return f & 3u; }
 #define PLUME_COMB_ENTRIES (1 << (PLUME_COMB_W - 1))
 #define PLUME_COMB_WINDOW_WORDS (PLUME_COMB_ENTRIES * PLUME_TAB_ENTRY_WORDS)
 
-// ------------------------------------------------------------------------------ window tables by affine chains (round 2)
-// The window tables of the per-item bases (1P..8P, affine, + beta*x) built WITHOUT Jacobian intermediates: every entry comes from an affine
-// doubling or an affine addition of earlier entries, and the field inversions those need are shared by all jobs of a lane, level by level
-// (Montgomery's trick):
-//     level 1:  P (made affine if the base is Jacobian), 2P = dbl(P)                           denominators 2y            (Jacobian base: Z and 2Y)
-//     level 2:  3P = 2P + P,  4P = dbl(2P)                                                    x2 - x1,  2 y2
-//     level 3:  5P = 4P + P,  6P = dbl(3P),  7P = 4P + 3P,  8P = dbl(4P)                      x4 - x1,  2 y3,  x4 - x3,  2 y4
-// An affine doubling is 2M + 2S and an addition 2M + 1S once the inverse is known (+3M for the inverse's share of the batch), against 3M + 4S /
-// 8M + 3S for the Jacobian forms PLUS the ~7M per entry the Jacobian table paid to become affine afterwards: 54 (affine base) / 64 (Jacobian base)
-// multiplications per table instead of ~125, three inversions per lane instead of one.  Entries are final when they are computed: they are written
-// once, as whole rows, and read back (by the same lane) as operands of the next level; the only scratch is the prefix products of a level
-// (4 x 36 bytes per job, lane-interleaved like the Jacobian builder's), an eighth of what that one streamed through HBM.
-// Denominators cannot vanish for a base of prime order n (kP = +-P needs (k-+1)P = O; the curve has no point with y = 0) and every base that is
-// not such a point (identity, failed validation) is replaced by G before it gets here; should a level's product be zero all the same, the level
-// is redone with zero denominators replaced by 1, so that one item can never poison the other jobs of its lane.
+// ------------------------------------------------------------------------------ window tables: P, theta P, 2P by ONE round of inversions (round 5)
+// Rounds 2-4 built 1P..8P by affine chains in three levels (three inversion rounds, every level reading the rows of the one before: 2 KB of HBM traffic per table, the
+// stage HBM-bound at 0.55 ms per job and 2^20 items) and, for small batches, by a Jacobian chain with one inversion.  The Eisenstein digits (above) need three rows, and
+// both computed rows come straight from P:
+//     2P:       slope 3 x^2 / (2 y)                          theta P = P - lambda P = (x, y) + (beta x, -y):   slope -2 y / ((beta - 1) x)
+// so a job has two denominators, 2y and (beta - 1) x -- and a Jacobian base (H from hash_to_curve, 2^64 H of the signer) a third, Z -- whose PRODUCT D joins the lane's
+// running product; one inversion per 8 lanes (k_tab_invert, Montgomery's trick twice over) returns 1/D, from which the job peels its own inverses with the denominators it
+// recomputes from the base.  Pass A reads the base and parks one prefix product per job; pass B reads the base again, writes three rows.  ~0.7 KB of traffic and ~20-30
+// multiplications per table instead of 2 KB and ~55.
+// Denominators cannot vanish for a point of the group: y = 0 would be a point of order 2, x = 0 a point fixed by lambda, i.e. of order 3, and the order n is prime; whatever
+// is not such a point (identity, failed validation) has been replaced by G before it gets here (tab_base).  Should a lane's product come out zero all the same (a test
+// feeding unvalidated garbage), the pass is redone with zero denominators replaced by 1: the rows of that job are garbage, the other jobs of the lane are not.
 PLUME_HD void pre_st(uint32_t* scr, size_t sstride, size_t slane, size_t q, const fe& a) {
     PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) scr[((q * PLUME_FE_W + (size_t)i) * sstride) + slane] = a.v[i];
 }
 PLUME_HD void pre_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, size_t q) {
     PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = scr[((q * PLUME_FE_W + (size_t)i) * sstride) + slane];
 }
-#define PLUME_TAB_AFF_SCR_WORDS (2 * PLUME_FE_WORDS)       // prefix products per job: ONE per level (below), two alternating regions (consecutive levels overlap)
+#define PLUME_TAB_SCR_WORDS PLUME_FE_WORDS                  // one parked prefix product per job
 // 2P from affine P = (x, y) (tight) and l = 1 / (2y)
 PLUME_HD void aff_dbl(fe& x3, fe& y3, const fe& x, const fe& y, const fe& l) {
     fe lam, t;
@@ -479,26 +487,22 @@ PLUME_HD void aff_dbl(fe& x3, fe& y3, const fe& x, const fe& y, const fe& l) {
     fe_sub_lazy<2>(t, x, x3);
     fe_mul_sub<2>(y3, lam, t, y);                               // lambda (x - x3) - y
 }
-// P1 + P2 from affine points (tight) and dinv = 1 / (x2 - x1)
-PLUME_HD void aff_add(fe& x3, fe& y3, const fe& x1, const fe& y1, const fe& x2, const fe& y2, const fe& dinv) {
-    fe lam, t, s;
-    fe_sub_lazy<2>(t, y2, y1);
-    fe_mul(lam, t, dinv);
-    fe_add_lazy(s, x1, x2);
-    fe_sqr_sub<3>(x3, lam, s);                                  // lambda^2 - x1 - x2
-    fe_sub_lazy<2>(t, x1, x3);
-    fe_mul_sub<2>(y3, lam, t, y1);                              // lambda (x1 - x3) - y1
+// theta P = (x, y) + (bx, -y) from affine P, bx = beta x and dinv = 1 / (bx - x)
+PLUME_HD void aff_theta(fe& x3, fe& y3, const fe& x, const fe& y, const fe& bx, const fe& dinv) {
+    fe lam, t, s, m2y;
+    const fe z = fe_zero();
+    fe_dbl_lazy(t, y); fe_sub_lazy<3>(m2y, z, t);               // (-y) - y = 3p - 2y, unreduced: a product operand next to a tight one
+    fe_mul(lam, m2y, dinv);
+    fe_add_lazy(s, x, bx);
+    fe_sqr_sub<3>(x3, lam, s);                                  // lambda^2 - x - beta x
+    fe_sub_lazy<2>(t, x, x3);
+    fe_mul_sub<2>(y3, lam, t, y);                               // lambda (x - x3) - y
 }
-struct DirectRowSinkSync {                                       // host / single-lane builds: rows are stored by the lane that reads them back
+struct DirectRowSinkSync {                                       // host / single-lane builds: rows are stored by the lane that built them
     PLUME_HD void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const { st_tab_entry(e, x, y, bx); }
     PLUME_HD void sync() const {}
-    // the inversion of one level's product (never zero, see the guard)
     PLUME_HD void inv(fe& r, const fe& a, int) const { fe_inv(r, a); }
 };
-// Montgomery's trick in two tiers, so that a level costs ONE scratch slot per job instead of one per denominator (the table kernel is bandwidth-bound: 36 bytes
-// written and read per job and level instead of up to 144).  A job's denominators of a level are multiplied together first (D = d1 d2 [d3 d4]); the lane's running
-// product is parked before D joins it.  The finishing pass gets 1/D from the chain and splits it with the denominators themselves, which it recomputes from the
-// entries it has to load anyway (x2 - x1, 2 y2, ...): 1 / d1 = (1/D) d2 for a pair, two such steps for four.
 PLUME_HD void guard_one(fe& d, bool guard) { if (guard) { if (fe_is_zero(d)) d = fe_small(1); } }
 // park the running product, then acc *= D
 PLUME_HD void tab_park(fe& acc, uint32_t* scr, size_t sstride, size_t slane, size_t q, const fe& D) {
@@ -512,7 +516,7 @@ PLUME_HD void tab_unpark(fe& Dinv, fe& inv, const uint32_t* scr, size_t sstride,
     fe_mul(Dinv, inv, pre);
     fe_mul(inv, inv, D);
 }
-// the base of a job as the chain sees it: affine (x, y) for Z = 1 bases, Jacobian otherwise; anything that is not a usable point becomes G.  The Z words of an
+// the base of a job as the builder sees it: affine (x, y) for Z = 1 bases, Jacobian otherwise; anything that is not a usable point becomes G.  The Z words of an
 // affine base are not even loaded.
 PLUME_HD bool tab_base(jac& b, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t job) {
     bool zone = (jobflags[job] & PLUME_JOB_AFFINE) != 0;
@@ -522,33 +526,15 @@ PLUME_HD bool tab_base(jac& b, const uint32_t* bases, const uint8_t* jobflags, s
     if (job_state(jobflags[job]) != PLUME_JOB_OK) { b.x = fe_gx(); b.y = fe_gy(); b.z = fe_small(1); zone = true; }
     return zone;
 }
-// level 1 of one job: denominators Z (Jacobian base only) and 2Y
-PLUME_HD void tab_den_l1(fe& dz, fe& dy, fe& D, const jac& b, bool zone, bool guard) {
+PLUME_HD fe fe_beta_m1() { return fe_set(0x7AE96A2Bu, 0x657C0710u, 0x6E64479Eu, 0xAC3434E9u, 0x9CF04975u, 0x12F58995u, 0xC1396C28u, 0x719501EDu); }   // beta - 1
+// the denominators of one job: dy = 2Y, dx = (beta - 1) X, dz = Z (Jacobian base) and their product D
+PLUME_HD void tab_dens(fe& dy, fe& dx, fe& dz, fe& pyx, fe& D, const jac& b, bool zone, bool guard) {
     fe_dbl_lazy(dy, b.y); guard_one(dy, guard);
-    if (zone) { D = dy; dz = fe_small(1); } else { dz = b.z; guard_one(dz, guard); fe_mul(D, dz, dy); }
+    fe_mul_k(dx, fe_beta_m1(), b.x); guard_one(dx, guard);
+    fe_mul(pyx, dy, dx);
+    if (zone) { dz = fe_small(1); D = pyx; } else { dz = b.z; guard_one(dz, guard); fe_mul(D, pyx, dz); }
 }
-// level 2: x2 - x1, 2 y2
-PLUME_HD void tab_den_l2(fe& da, fe& db, fe& D, const fe& x1, const fe& x2, const fe& y2, bool guard) {
-    fe_sub_lazy<2>(da, x2, x1); guard_one(da, guard);
-    fe_dbl_lazy(db, y2); guard_one(db, guard);
-    fe_mul(D, da, db);
-}
-// level 3: x4 - x1, 2 y3, x4 - x3, 2 y4;  p01 = d0 d1, p23 = d2 d3, D = p01 p23
-PLUME_HD void tab_den_l3(fe d[4], fe& p01, fe& p23, fe& D, const fe& x1, const fe& x3, const fe& y3, const fe& x4, const fe& y4, bool guard) {
-    fe_sub_lazy<2>(d[0], x4, x1); fe_dbl_lazy(d[1], y3); fe_sub_lazy<2>(d[2], x4, x3); fe_dbl_lazy(d[3], y4);
-    PLUME_UNROLL for (int k = 0; k < 4; k++) guard_one(d[k], guard);
-    fe_mul(p01, d[0], d[1]); fe_mul(p23, d[2], d[3]); fe_mul(D, p01, p23);
-}
-// Level k+1's denominators are formed -- and their product joins the lane's chain -- inside level k's finishing pass, while the entries they come from are
-// still in registers: four passes over a lane's jobs instead of six, and no pass that only re-reads rows.  Consecutive levels therefore run through the
-// jobs in opposite directions (a level is finished in the reverse of the order its products were parked in) and use alternating scratch regions.
-// The chain as PASSES (round 3).  Each pass walks the lane's jobs once; between two passes stands ONE field inversion of the lane's running product.  The passes share
-// no registers: what a lane carries from one to the next is that product / its inverse (`carry`, 9 words) and the guard flag, so the same code serves
-//   * the table stage of the library: one launch per pass (k_tab_pass_a..d) with a small batched-inversion kernel (k_tab_invert) in between, `carry` parked in HBM: every
-//     pass is a plain streaming kernel, no inversion and no workgroup barrier inside, and the inversions of the whole batch run as one dense launch;
-//   * table_build_affine below: all passes in one function with the inversions in place (single-lane builds; the host harness holds the pass sequence to it).
-// Pass A (jobs ascending): denominators of level 1 -> carry = their product.
-template <class RowSink>
+// Pass A (jobs ascending): every job's D joins the lane's product -> carry.
 PLUME_HD void tab_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane, fe& carry, bool& guard) {
     fe acc;
     guard = false;
@@ -557,8 +543,8 @@ PLUME_HD void tab_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t 
         PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
             jac b;
             const bool zone = tab_base(b, bases, jobflags, njobs, j0 + (size_t)jj);
-            fe dz, dy, D;
-            tab_den_l1(dz, dy, D, b, zone, guard);
+            fe dy, dx, dz, pyx, D;
+            tab_dens(dy, dx, dz, pyx, D, b, zone, guard);
             tab_park(acc, scr, sstride, slane, (size_t)jj, D);
         }
         if (guard || !fe_is_zero(acc)) break;
@@ -566,117 +552,50 @@ PLUME_HD void tab_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t 
     }
     carry = acc;
 }
-// Pass B (jobs descending): carry = 1 / (level 1's product) in; P -> affine, 2P; level 2's denominators -> carry = their product out.
+// Pass B (jobs descending): carry = 1 / (the lane's product) in; rows P, theta P, 2P of every job out.
 template <class RowSink>
-PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
-                         fe& carry, bool& guard, const RowSink& sink) {
-    const fe beta = fe_beta();
-    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
-    const size_t RB = (size_t)cnt;                               // second scratch region
-    fe inv = carry, acc = fe_small(1);
-    PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
-        const size_t job = j0 + (size_t)jj;
-        jac b;
-        const bool zone = tab_base(b, bases, jobflags, njobs, job);
-        fe dz, dy, D, l, x1 = b.x, y1 = b.y;
-        tab_den_l1(dz, dy, D, b, zone, guard);
-        tab_unpark(l, inv, scr, sstride, slane, (size_t)jj, D);                     // 1 / D:  1 / (2Y) for an affine base,  1 / (Z 2Y) otherwise
-        if (!zone) {
-            fe zi, z2, z3, zi2;
-            fe_mul(zi, l, dy);                                                      // 1 / Z
-            fe_mul(l, l, dz);                                                       // 1 / (2Y)
-            fe_sqr(z2, b.z); fe_mul(z3, z2, b.z); fe_mul(l, l, z3);                 // 1 / (2y) = Z^3 / (2Y)
-            fe_sqr(zi2, zi); fe_mul(x1, b.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(y1, b.y, zi2);
-        }
-        fe x2, y2, bx;
-        aff_dbl(x2, y2, x1, y1, l);
-        uint32_t* t = tab + job * TW;
-        fe_mul_k(bx, beta, x1); sink(t, x1, y1, bx);
-        fe_mul_k(bx, beta, x2); sink(t + EW, x2, y2, bx);
-        fe da, db;
-        tab_den_l2(da, db, D, x1, x2, y2, false);
-        tab_park(acc, scr, sstride, slane, RB + (size_t)jj, D);
-    }
-    sink.sync();
-    if (guard || fe_is_zero(acc)) {                                                 // cold: the same products, from the rows, with the zero check
-        guard = true; acc = fe_small(1);
-        PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
-            const uint32_t* t = tab + (j0 + (size_t)jj) * TW;
-            fe x1, y1, x2, y2, da, db, D;
-            ld_tab_xy(x1, y1, t, false); ld_tab_xy(x2, y2, t + EW, false);
-            tab_den_l2(da, db, D, x1, x2, y2, true);
-            tab_park(acc, scr, sstride, slane, RB + (size_t)jj, D);
-        }
-    }
-    carry = acc;
-}
-// Pass C (jobs ascending): carry = 1 / (level 2's product) in; 4P, 3P; level 3's denominators -> carry out.
-template <class RowSink>
-PLUME_HD void tab_pass_c(uint32_t* tab, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane, fe& carry, bool& guard, const RowSink& sink) {
-    const fe beta = fe_beta();
-    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
-    const size_t RB = (size_t)cnt;
-    fe inv = carry, acc = fe_small(1);
-    PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
-        uint32_t* t = tab + (j0 + (size_t)jj) * TW;
-        fe x1, y1, x2, y2, da, db, D, Dinv, l, x3, y3, x4, y4, bx;
-        ld_tab_xy(x1, y1, t, false); ld_tab_xy(x2, y2, t + EW, false);
-        tab_den_l2(da, db, D, x1, x2, y2, guard);
-        tab_unpark(Dinv, inv, scr, sstride, slane, RB + (size_t)jj, D);
-        fe_mul(l, Dinv, da);                                                        // 1 / (2 y2)
-        aff_dbl(x4, y4, x2, y2, l);                                                 // 4P
-        fe_mul_k(bx, beta, x4); sink(t + 3 * EW, x4, y4, bx);
-        fe_mul(l, Dinv, db);                                                        // 1 / (x2 - x1)
-        aff_add(x3, y3, x1, y1, x2, y2, l);                                         // 3P
-        fe_mul_k(bx, beta, x3); sink(t + 2 * EW, x3, y3, bx);
-        fe d[4], p01, p23;
-        tab_den_l3(d, p01, p23, D, x1, x3, y3, x4, y4, false);
-        tab_park(acc, scr, sstride, slane, (size_t)jj, D);
-    }
-    sink.sync();
-    if (guard || fe_is_zero(acc)) {
-        guard = true; acc = fe_small(1);
-        PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
-            const uint32_t* t = tab + (j0 + (size_t)jj) * TW;
-            fe x1, y1, x3, y3, x4, y4, d[4], p01, p23, D;
-            ld_tab_xy(x1, y1, t, false); ld_tab_xy(x3, y3, t + 2 * EW, false); ld_tab_xy(x4, y4, t + 3 * EW, false);
-            tab_den_l3(d, p01, p23, D, x1, x3, y3, x4, y4, true);
-            tab_park(acc, scr, sstride, slane, (size_t)jj, D);
-        }
-    }
-    carry = acc;
-}
-// Pass D (jobs descending): carry = 1 / (level 3's product) in; 8P, 7P, 6P, 5P  [16-row tables: + level 4's denominators -> carry out].
-template <class RowSink>
-PLUME_HD void tab_pass_d(uint32_t* tab, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane, fe& carry, bool& guard, const RowSink& sink) {
+PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, const uint32_t* scr, size_t sstride, size_t slane,
+                         const fe& carry, bool guard, const RowSink& sink) {
     const fe beta = fe_beta();
     constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
     fe inv = carry;
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
-        uint32_t* t = tab + (j0 + (size_t)jj) * TW;
-        fe x1, y1, x3, y3, x4, y4, d[4], p01, p23, D, Dinv, i01, i23, l, xr, yr, bx;
-        ld_tab_xy(x1, y1, t, false); ld_tab_xy(x3, y3, t + 2 * EW, false); ld_tab_xy(x4, y4, t + 3 * EW, false);
-        tab_den_l3(d, p01, p23, D, x1, x3, y3, x4, y4, guard);
+        const size_t job = j0 + (size_t)jj;
+        jac b;
+        const bool zone = tab_base(b, bases, jobflags, njobs, job);
+        fe dy, dx, dz, pyx, D, Dinv, x, y, iy, ix;
+        tab_dens(dy, dx, dz, pyx, D, b, zone, guard);
         tab_unpark(Dinv, inv, scr, sstride, slane, (size_t)jj, D);
-        fe_mul(i01, Dinv, p23);                                                     // 1 / (d0 d1)
-        fe_mul(i23, Dinv, p01);                                                     // 1 / (d2 d3)
-        fe_mul(l, i23, d[2]);                                                       // 1 / (2 y4)
-        aff_dbl(xr, yr, x4, y4, l);                                                 // 8P
-        fe_mul_k(bx, beta, xr); sink(t + 7 * EW, xr, yr, bx);
-        fe_mul(l, i23, d[3]);                                                       // 1 / (x4 - x3)
-        aff_add(xr, yr, x3, y3, x4, y4, l);                                         // 7P
-        fe_mul_k(bx, beta, xr); sink(t + 6 * EW, xr, yr, bx);
-        fe_mul(l, i01, d[0]);                                                       // 1 / (2 y3)
-        aff_dbl(xr, yr, x3, y3, l);                                                 // 6P
-        fe_mul_k(bx, beta, xr); sink(t + 5 * EW, xr, yr, bx);
-        fe_mul(l, i01, d[1]);                                                       // 1 / (x4 - x1)
-        aff_add(xr, yr, x1, y1, x4, y4, l);                                         // 5P
-        fe_mul_k(bx, beta, xr); sink(t + 4 * EW, xr, yr, bx);
+        if (zone) {
+            x = b.x; y = b.y;
+            fe_mul(iy, Dinv, dx);                               // 1 / (2y)
+            fe_mul(ix, Dinv, dy);                               // 1 / ((beta - 1) x)
+        } else {
+            // 1 / Z = Dinv (dy dx);  1 / (2Y) = Dinv dx Z;  1 / ((beta - 1) X) = Dinv dy Z;  affine x = X / Z^2, y = Y / Z^3, so
+            // 1 / (2y) = Z^3 / (2Y) and 1 / ((beta - 1) x) = Z^2 / ((beta - 1) X)
+            fe zi, zi2, z2, t;
+            fe_mul(zi, Dinv, pyx);
+            fe_sqr(zi2, zi);
+            fe_mul(x, b.x, zi2);
+            fe_mul(t, zi2, zi); fe_mul(y, b.y, t);
+            fe_sqr(z2, dz);
+            fe_mul(t, Dinv, dz);                                // 1 / (dy dx)
+            fe_mul(iy, t, dx); fe_mul(iy, iy, z2); fe_mul(iy, iy, dz);      // Z^3 / (2Y)
+            fe_mul(ix, t, dy); fe_mul(ix, ix, z2);                          // Z^2 / ((beta - 1) X)
+        }
+        uint32_t* rows = tab + job * TW;
+        fe bx, x2, y2, b2;
+        fe_mul_k(bx, beta, x);
+        sink(rows, x, y, bx);                                   // row 0: P
+        aff_theta(x2, y2, x, y, bx, ix);
+        fe_mul_k(b2, beta, x2);
+        sink(rows + EW, x2, y2, b2);                            // row 1: theta P = P - lambda P
+        aff_dbl(x2, y2, x, y, iy);
+        fe_mul_k(b2, beta, x2);
+        sink(rows + 2 * EW, x2, y2, b2);                        // row 2: 2P
     }
-    (void)scr; (void)sstride; (void)slane; (void)guard;
 }
-// The inversion between two passes of the multi-kernel form: thread t of T takes the lane products t, t + T, ..., t + (K-1) T of the nl lanes (word-major array: coalesced)
-// and spends ONE inversion on their product (Montgomery's trick); in place.  The products are never zero (the passes' guard).
+// carry[.] <- 1 / carry[.] for nl lane products: thread t of T takes lanes t, t + T, ..., t + (K-1) T and spends ONE inversion on their product
 template <int K>
 PLUME_HD void tab_invert_group(uint32_t* carry, size_t nl, size_t T, size_t t) {
     fe v[K], pre[K], acc = fe_small(1), inv;
@@ -695,105 +614,15 @@ PLUME_HD void tab_invert_group(uint32_t* carry, size_t nl, size_t T, size_t t) {
         if (l < nl) st_fe_soa(carry, nl, l, o);
     }
 }
-// All passes in one function with the inversions in place: single-lane builds (the host harness checks the pass sequence against it; rounds 2-3 shipped a one-kernel
-// table stage of this shape, LABNOTES.md).
+// Both passes in one function with the inversion in place: single-lane builds (the host harness holds the pass sequence to it).
 template <class RowSink = DirectRowSinkSync>
-PLUME_HD void table_build_affine(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
-                                 const RowSink& sink = RowSink()) {
+PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
+                          const RowSink& sink = RowSink()) {
     fe carry, inv;
     bool guard;
-    tab_pass_a<RowSink>(bases, jobflags, njobs, j0, cnt, scr, sstride, slane, carry, guard);
-    sink.inv(inv, carry, 1); carry = inv;
-    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr, sstride, slane, carry, guard, sink);
-    sink.inv(inv, carry, 2); carry = inv;
-    tab_pass_c(tab, j0, cnt, scr, sstride, slane, carry, guard, sink);
-    sink.inv(inv, carry, 3); carry = inv;
-    tab_pass_d(tab, j0, cnt, scr, sstride, slane, carry, guard, sink);
-}
-
-// ------------------------------------------------------------------------------ window tables of SMALL batches: Jacobian chain, ONE inversion (round 4)
-// Up to ~2^15 items the table stage above is pure latency: three inversion launches in a row, each a 20 k-instruction serial chain on a machine that is nearly empty
-// (0.22-0.28 ms whatever the batch size).  Measured on the MI355X (table stage of a verify call, one box): 2^12 items 0.217 -> 0.113 ms, 2^14 0.228 -> 0.120, 2^16 0.277 -> 0.272
-// (break-even), 2^17 0.371 -> 0.484: taken for stages of up to 3 * 2^15 jobs.  Here a lane takes ONE job: 2P..8P as Jacobian points (four doublings, three additions with P), the eight Z's multiplied up
-// with their prefix products parked next to X, Y, Z in scratch (lane-interleaved, 36 words per entry), ONE inversion of the lane's product (k_tab_invert, Montgomery's
-// trick over 8 lanes as before), and a second pass that peels the eight inverses off and writes the affine rows.  2.2 times the multiplications of the affine chain --
-// which is why large batches, where the vector ALUs are the scarce resource, keep the affine chain -- but one inversion on the critical path instead of three.
-#define PLUME_TABJ_ENTRY_WORDS (4 * PLUME_FE_WORDS)      // X | Y | Z | product of the Z's before this entry
-PLUME_HD void tabj_st(uint32_t* scr, size_t sstride, size_t slane, int q, int f, const fe& a) {
-    PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) scr[((size_t)(q * PLUME_TABJ_ENTRY_WORDS + f * PLUME_FE_W + i)) * sstride + slane] = a.v[i];
-}
-PLUME_HD void tabj_ld(fe& r, const uint32_t* scr, size_t sstride, size_t slane, int q, int f) {
-    PLUME_UNROLL for (int i = 0; i < PLUME_FE_W; i++) r.v[i] = scr[((size_t)(q * PLUME_TABJ_ENTRY_WORDS + f * PLUME_FE_W + i)) * sstride + slane];
-}
-// p += q, both Jacobian, WITHOUT the tests for p == +-q / identities (12M + 4S): the table chain of a point of prime order never meets them (k P + P, 2 <= k <= 6)
-PLUME_HD void jac_add_unchecked(jac& p, const jac& q) {
-    fe z1z1, z2z2, u1, s1, s2, h, r, hh, hhh, v, t;
-    fe_sqr(z1z1, p.z); fe_sqr(z2z2, q.z);
-    fe_mul(u1, p.x, z2z2);
-    fe_mul(s1, q.z, z2z2); fe_mul(s1, s1, p.y);
-    fe_mul_sub<2>(h, q.x, z1z1, u1);
-    fe_mul(s2, p.z, z1z1);
-    fe_mul_sub<2>(r, s2, q.y, s1);
-    fe_sqr(hh, h); fe_mul(hhh, hh, h); fe_mul(v, u1, hh);
-    fe_mul(p.z, p.z, q.z); fe_mul(p.z, p.z, h);
-    fe_dbl_lazy(hh, v); fe_add_lazy(hh, hh, hhh);
-    fe_sqr_sub<4>(p.x, r, hh);
-    fe_sub_lazy<2>(t, v, p.x);
-    fe_neg_lazy(v, s1);
-    fe_muladd(p.y, r, t, v, hhh);
-}
-// one entry of the chain goes to scratch: X, Y, Z and the product of the Z's before it; acc *= Z
-PLUME_HD void tabj_put(uint32_t* scr, size_t sstride, size_t slane, int q, const jac& pt, fe& acc) {
-    tabj_st(scr, sstride, slane, q, 0, pt.x); tabj_st(scr, sstride, slane, q, 1, pt.y); tabj_st(scr, sstride, slane, q, 2, pt.z); tabj_st(scr, sstride, slane, q, 3, acc);
-    fe_mul(acc, acc, pt.z);
-}
-// pass A of job `job` (lane slane of sstride): the chain and the product of its Z's -> carry.  ONE doubling body and one addition body in a rolled loop (an entry that is
-// doubled later is read back from the scratch the lane has just written): straight-line code with every point live ran out of registers (1.4-2.5 KB of scratch per lane,
-// three times slower).  Unchecked additions: a point of prime order never meets k P = +-P for 2 <= k <= 6, whatever is not such a point has been replaced by G (tab_base),
-// and the zero-product guard below catches the rest.
-PLUME_HD void tabj_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t job, uint32_t* scr, size_t sstride, size_t slane, fe& carry) {
-    jac b;
-    const bool zone = tab_base(b, bases, jobflags, njobs, job);      // affine (Z = 1) or Jacobian base; anything that is no usable point has become G
-    fe acc = fe_small(1);
-    jac cur = b;
-    PLUME_NOUNROLL for (int k = 0; k < PLUME_TAB_ENTRIES; k++) {      // entry k = (k + 1) P:  P, 2P = 2 * P, 3P = 2P + P, 4P = 2 * 2P, 5P = 4P + P, 6P = 2 * 3P, 7P = 6P + P, 8P = 2 * 4P
-        if (k & 1) {
-            if (k > 1) { const int h = (k + 1) / 2 - 1; tabj_ld(cur.x, scr, sstride, slane, h, 0); tabj_ld(cur.y, scr, sstride, slane, h, 1); tabj_ld(cur.z, scr, sstride, slane, h, 2); }
-            jac_dbl(cur);
-        } else if (k > 0) {
-            if (zone) jac_madd<false>(cur, b.x, b.y); else jac_add_unchecked(cur, b);
-        }
-        tabj_put(scr, sstride, slane, k, cur, acc);
-    }
-    carry = acc;
-}
-// (cold) the same with the base replaced by G: for a job whose product came out zero -- impossible for a point of the group (prime order, no point with y = 0), but
-// the inversion is shared by eight lanes and one poisoned product must not take seven honest jobs with it
-PLUME_HD void tabj_pass_a_guarded(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t job, uint32_t* scr, size_t sstride, size_t slane, fe& carry) {
-    tabj_pass_a(bases, jobflags, njobs, job, scr, sstride, slane, carry);
-    if (fe_is_zero(carry)) {
-        uint32_t g[PLUME_BASE_WORDS];
-        jac pg; pg.x = fe_gx(); pg.y = fe_gy(); pg.z = fe_small(1); pg.inf = 0;
-        st_base(g, 0, pg);
-        const uint8_t gf = (uint8_t)(PLUME_JOB_OK | PLUME_JOB_AFFINE);
-        tabj_pass_a(g, &gf, 1, 0, scr, sstride, slane, carry);
-    }
-}
-// pass B: carry = 1 / (product of the job's eight Z's); rows 8P .. 1P
-PLUME_HD void tabj_pass_b(uint32_t* tab, size_t job, const uint32_t* scr, size_t sstride, size_t slane, const fe& carry) {
-    const fe beta = fe_beta();
-    fe inv = carry;
-    PLUME_NOUNROLL for (int q = PLUME_TAB_ENTRIES - 1; q >= 0; q--) {
-        fe X, Y, Z, pre, zi, zi2, bx;
-        tabj_ld(X, scr, sstride, slane, q, 0); tabj_ld(Y, scr, sstride, slane, q, 1); tabj_ld(Z, scr, sstride, slane, q, 2); tabj_ld(pre, scr, sstride, slane, q, 3);
-        fe_mul(zi, inv, pre);                             // 1 / Z_q
-        fe_mul(inv, inv, Z);                              // inverse of the product before Z_q
-        fe_sqr(zi2, zi);
-        fe_mul(X, X, zi2);
-        fe_mul(zi2, zi2, zi); fe_mul(Y, Y, zi2);
-        fe_mul_k(bx, beta, X);
-        st_tab_entry(tab + job * (size_t)PLUME_TAB_WORDS + (size_t)q * PLUME_TAB_ENTRY_WORDS, X, Y, bx);      // tight, not canonical: only ever multiplied / negated
-    }
+    tab_pass_a(bases, jobflags, njobs, j0, cnt, scr, sstride, slane, carry, guard);
+    sink.inv(inv, carry, 1);
+    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr, sstride, slane, inv, guard, sink);
 }
 
 // ------------------------------------------------------------------------------ the generator's fixed tables, one entry per lane (round 3)
@@ -978,123 +807,148 @@ PLUME_HD void comb_mul_g(jac& acc, const sc& k, const uint32_t* comb) {
 }
 
 // --------------------------------------------------------------------------------------- multi-scalar loop
-// acc = sum over slots of digit * table point.  Slot s uses table tabs[s >> 1]; odd slots are the lambda
-// halves (beta*x).  dig: digits of slot s, window i at dig[(s*PLUME_NDIG + i)*stride].  A NULL table (or a
-// job flagged INF) contributes nothing.
-// wide0: slots 0,1 use the generator's wide table with W-bit digits (stored by booth_store_wide).
-// digit of slot s at window i (wide generator digits decoded); 0 = nothing to add
-template <int ND = PLUME_NDIG>
-PLUME_HD int msm_digit(const int8_t* dig, uint32_t stride, int i, int s, bool wide0) {
-    int d = dig[(uint32_t)(s * ND + i) * stride];
-    if (wide0 && s < 2) {
-        int mag = d & 0xFF;
-        bool dn;
-        if (i + PLUME_GW_BYTES < PLUME_NDIG) {
-            PLUME_UNROLL for (int b = 1; b < PLUME_GW_BYTES; b++) mag |= (dig[(uint32_t)(s * PLUME_NDIG + i + b) * stride] & 0xFF) << (8 * b);
-            dn = dig[(uint32_t)(s * PLUME_NDIG + i + PLUME_GW_BYTES) * stride] != 0;
-        } else if (i + 1 < PLUME_NDIG) {
-            const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
-            mag |= (hi & 0x7F) << 8; dn = (hi & 0x80) != 0;
-        } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
-        d = dn ? -mag : mag;
-    }
-    return d;
+// acc = sum over JOINT slots of (digit of the slot at position p) 4^p.  A joint slot is a window table (P, theta P, 2P) with the Eisenstein digits of one GLV pair
+// (eisd_store): one byte per position, at most one addition per position.  Two joint slots: tab0 with rows [0, NP) of the lane's digit area, tab1 with rows [NP, 2 NP).
+// wide0 (the verifier's first equation in its long form): tab0 is the generator's WIDE table and rows [0, 2 PLUME_NDIG) hold s in its 24-bit Booth digits, one for each
+// half, on the grid of 4-bit windows the rounds before used (booth_store_wide) -- digit k sits at window 6k, i.e. position 12k; tab1's rows follow at 2 PLUME_NDIG.
+// A NULL table (a job flagged INF) contributes nothing.
+// the wide digit of generator slot s (0: G, 1: lambda G) at 4-bit window w; 0 = nothing to add
+PLUME_HD int msm_wide_digit(const int8_t* dig, uint32_t stride, int w, int s) {
+    const int i = w;
+    int mag = dig[(uint32_t)(s * PLUME_NDIG + i) * stride] & 0xFF;
+    bool dn;
+    if (i + PLUME_GW_BYTES < PLUME_NDIG) {
+        PLUME_UNROLL for (int b = 1; b < PLUME_GW_BYTES; b++) mag |= (dig[(uint32_t)(s * PLUME_NDIG + i + b) * stride] & 0xFF) << (8 * b);
+        dn = dig[(uint32_t)(s * PLUME_NDIG + i + PLUME_GW_BYTES) * stride] != 0;
+    } else if (i + 1 < PLUME_NDIG) {
+        const int hi = dig[(uint32_t)(s * PLUME_NDIG + i + 1) * stride];
+        mag |= (hi & 0x7F) << 8; dn = (hi & 0x80) != 0;
+    } else { dn = (mag & 0x40) != 0; mag &= 0x3F; }
+    return dn ? -mag : mag;
 }
-// wave-uniform: slots 0, 1 of a wide-digit task hold a digit at every (W/4)-th window only
-PLUME_HD bool msm_slot_used(int i, int s, bool wide0) { return !(wide0 && s < 2 && (i % PLUME_GWS) != 0); }
-// gather the operand of step (i, s): digit and, for a non-zero digit of a live table, the row's x (or beta x) and y -- the loads are only ISSUED here, whoever
-// reads qx / qy first waits for them
-template <int ND = PLUME_NDIG>
-PLUME_HD int msm_fetch(fe& qx, fe& qy, const uint32_t* tab0, const uint32_t* tab1, const int8_t* dig, uint32_t stride, int i, int s, bool wide0) {
-    const uint32_t* tab = (s & 2) ? tab1 : tab0;
-    int d = msm_digit<ND>(dig, stride, i, s, wide0);
-    if (tab == nullptr) d = 0;
-    if (d != 0) {
-        const int ad = d < 0 ? -d : d;
-        ld_tab_xy(qx, qy, tab + (ad - 1) * PLUME_TAB_ENTRY_WORDS, (s & 1) != 0);
-    }
-    return d;
+// the row of a digit code (1..18): (-1)^neg w^j (row point) = (x | beta x | beta^2 x, +-y).  beta^2 x = -(x + beta x) is formed here, unreduced (3p - x - beta x: limbs
+// below 2^31, limb 8 below 2^26 -- a product operand next to a tight one, which is all jac_madd does with it); the three candidates are selected without a branch (every
+// wavefront holds all three kinds).  Seven of a row's eight 16-byte quads are read, from one cache line.
+PLUME_HD void ld_tab_unit(fe& qx, fe& qy, const uint32_t* tab, int code) {
+    const uint32_t c = (uint32_t)(code - 1), row = c / 6u, u = c - 6u * row, j = u >> 1;
+    const uint32_t* e = tab + row * PLUME_TAB_ENTRY_WORDS;
+    fe x, bx, s, t;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) { x.v[i] = e[i]; qy.v[i] = e[8 + i]; bx.v[i] = e[16 + i]; }
+    x.v[8] = e[24]; qy.v[8] = e[25]; bx.v[8] = e[26];
+    fe_add_lazy(s, x, bx);
+    const fe z = fe_zero();
+    fe_sub_lazy<3>(t, z, s);
+    qx = x;
+    fe_cmov(qx, bx, j == 1u);
+    fe_cmov(qx, t, j == 2u);
+    if (u & 1u) fe_neg_lazy(qy, qy);
 }
-// ND windows per slot: PLUME_NDIG (129-bit halves: the verifier) or PLUME_NDIG64 (the signer's 64-bit quarters; no wide digits there)
-template <bool CHECKED, int ND = PLUME_NDIG>
-PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0) {
+// wave-uniform "every accumulator is still the identity": the doublings of leading all-zero positions are skipped
+PLUME_HD bool msm_all_inf(const jac& acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(acc.inf != 0) != 0;
+#else
+    return acc.inf != 0;
+#endif
+}
+template <bool CHECKED, int NP = PLUME_NPOS>
+PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, const int8_t* dig, uint32_t stride, bool wide0) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
-    PLUME_NOUNROLL for (int i = ND - 1; i >= 0; i--) {
-        if (i != ND - 1) {
-            PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl_neg(acc);      // an even number of sign-flipping doublings
-        }
-        PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
-            if (!msm_slot_used(i, s, wide0)) continue;              // wave-uniform: a wide digit sits at every (W/4)-th window only
-            fe qx, qy;
-            const int d = msm_fetch<ND>(qx, qy, tab0, tab1, dig, stride, i, s, wide0);
-            if (d != 0) {
-                if (d < 0) fe_neg_lazy(qy, qy);
-                jac_madd<CHECKED>(acc, qx, qy);
+    const uint32_t r1 = wide0 ? 2u * PLUME_NDIG : (uint32_t)NP;        // first digit row of tab1's joint slot
+    PLUME_NOUNROLL for (int p = NP - 1; p >= 0; p--) {
+        if (p != NP - 1 && !msm_all_inf(acc)) { jac_dbl_neg(acc); jac_dbl_neg(acc); }      // (an even number of sign-flipping doublings)
+        if (wide0) {
+            if (p % (2 * PLUME_GWS) == 0 && p / 2 < PLUME_NDIG) {    // wave-uniform: a wide digit sits at every 6th 4-bit window only
+                PLUME_NOUNROLL for (int s = 0; s < 2; s++) {
+                    const int d = tab0 ? msm_wide_digit(dig, stride, p / 2, s) : 0;
+                    if (d != 0) {
+                        fe qx, qy;
+                        ld_tab_xy(qx, qy, tab0 + ((d < 0 ? -d : d) - 1) * PLUME_TAB_ENTRY_WORDS, s != 0);
+                        if (d < 0) fe_neg_lazy(qy, qy);
+                        jac_madd<CHECKED>(acc, qx, qy);
+                    }
+                }
             }
+        } else {
+            const int c = tab0 ? dig[(uint32_t)p * stride] : 0;
+            if (c != 0) { fe qx, qy; ld_tab_unit(qx, qy, tab0, c); jac_madd<CHECKED>(acc, qx, qy); }
         }
+        const int c = tab1 ? dig[(r1 + (uint32_t)p) * stride] : 0;
+        if (c != 0) { fe qx, qy; ld_tab_unit(qx, qy, tab1, c); jac_madd<CHECKED>(acc, qx, qy); }
     }
 }
-// The chain with the UNIFORM schedule (opt-in signer): no slot is skipped and no branch depends on a digit.  `live` false (the table's base was the identity / invalid: a
-// public fact) turns every digit into 0.  Starts at the offset point B; the caller takes 2^(4 (NDIG-1)) B = 2^128 B off again.
-template <bool CHECKED, int ND, bool SCAN>
-PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, bool live, int nslots, const int8_t* dig, uint32_t stride) {
+// One joint-slot addition of the UNIFORM schedule (the signer): the same instructions whatever the digit code is.  A zero code adds code 1's point to a copy that a masked
+// select drops; unit and sign are masked selects (ld_tab_unit's own, plus the sign here).  Level 1: the row's ADDRESS still depends on the code; SCAN (level 2): all three
+// rows are read and one is kept by masked selects.
+template <bool CHECKED, bool SCAN>
+PLUME_HD void msm_add_uniform(jac& acc, const uint32_t* tab, int code) {
+    const bool zero = code == 0;
+    const uint32_t c = zero ? 0u : (uint32_t)(code - 1), row = c / 6u, u = c - 6u * row, j = u >> 1;
+    fe x, y, bx;
+    if (SCAN) {
+        PLUME_UNROLL for (uint32_t r = 0; r < PLUME_TAB_ENTRIES; r++) {
+            const uint32_t* e = tab + r * PLUME_TAB_ENTRY_WORDS;
+            fe rx, ry, rb;
+            PLUME_UNROLL for (int i = 0; i < 8; i++) { rx.v[i] = e[i]; ry.v[i] = e[8 + i]; rb.v[i] = e[16 + i]; }
+            rx.v[8] = e[24]; ry.v[8] = e[25]; rb.v[8] = e[26];
+            if (r == 0) { x = rx; y = ry; bx = rb; }
+            else { fe_cmov(x, rx, row == r); fe_cmov(y, ry, row == r); fe_cmov(bx, rb, row == r); }
+        }
+    } else {
+        const uint32_t* e = tab + row * PLUME_TAB_ENTRY_WORDS;
+        PLUME_UNROLL for (int i = 0; i < 8; i++) { x.v[i] = e[i]; y.v[i] = e[8 + i]; bx.v[i] = e[16 + i]; }
+        x.v[8] = e[24]; y.v[8] = e[25]; bx.v[8] = e[26];
+    }
+    fe s, t, qx;
+    fe_add_lazy(s, x, bx);
+    const fe z = fe_zero();
+    fe_sub_lazy<3>(t, z, s);
+    qx = x;
+    fe_cmov(qx, bx, j == 1u);
+    fe_cmov(qx, t, j == 2u);
+    jac_madd_uniform<CHECKED>(acc, qx, y, zero ? 0 : ((u & 1u) ? -1 : 1));
+}
+// The chain with the UNIFORM schedule (the signer, levels 1 and 2): no position is skipped and no branch depends on a digit.  `live` false (the table's base was the
+// identity / invalid: a public fact) turns every digit into 0.  Starts at the offset point B; the caller takes 4^(NP - 1) B off again.
+template <bool CHECKED, int NP, bool SCAN>
+PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, bool live, const int8_t* dig, uint32_t stride) {
     acc.x = fe_off_x(); acc.y = fe_off_y(); acc.z = fe_small(1); acc.inf = 0;
-    PLUME_NOUNROLL for (int i = ND - 1; i >= 0; i--) {
-        if (i != ND - 1) {
-            PLUME_NOUNROLL for (int d = 0; d < PLUME_WBITS; d++) jac_dbl_neg(acc);      // an even number of sign-flipping doublings
-        }
-        if (SCAN) {                                                         // level 2: slots 2t, 2t + 1 (P and lambda P of table t) fetched by one scan of the table's rows
-            PLUME_NOUNROLL for (int t = 0; 2 * t < nslots; t++) {
-                int da = dig[(uint32_t)((2 * t) * ND + i) * stride], db = dig[(uint32_t)((2 * t + 1) * ND + i) * stride];
-                da = live ? da : 0; db = live ? db : 0;
-                fe xa, ya, xb, yb;
-                ld_tab_xy_scan2(xa, ya, xb, yb, t ? tab1 : tab0, (da < 0 ? -da : da) + (da == 0 ? 1 : 0), (db < 0 ? -db : db) + (db == 0 ? 1 : 0));
-                jac_madd_uniform<CHECKED>(acc, xa, ya, da);
-                jac_madd_uniform<CHECKED>(acc, xb, yb, db);
-            }
-            continue;
-        }
-        PLUME_NOUNROLL for (int s = 0; s < nslots; s++) {
-            const uint32_t* tab = (s & 2) ? tab1 : tab0;
-            int d = dig[(uint32_t)(s * ND + i) * stride];
-            d = live ? d : 0;
-            const int ad = (d < 0 ? -d : d) + (d == 0 ? 1 : 0);
-            fe qx, qy;
-            ld_tab_xy(qx, qy, tab + (ad - 1) * PLUME_TAB_ENTRY_WORDS, (s & 1) != 0);
-            jac_madd_uniform<CHECKED>(acc, qx, qy, d);
-        }
+    PLUME_NOUNROLL for (int p = NP - 1; p >= 0; p--) {
+        if (p != NP - 1) { jac_dbl_neg(acc); jac_dbl_neg(acc); }
+        const int c0 = live ? dig[(uint32_t)p * stride] : 0, c1 = live ? dig[((uint32_t)NP + (uint32_t)p) * stride] : 0;
+        msm_add_uniform<CHECKED, SCAN>(acc, tab0, c0);
+        msm_add_uniform<CHECKED, SCAN>(acc, tab1, c1);
     }
 }
-static_assert(PLUME_WBITS * (PLUME_NDIG - 1) == 128 && PLUME_WBITS * (PLUME_NDIG64 - 1) == 64, "the uniform chains' offset constants are -(2^128 B) and -(2^64 B)");
-static_assert(PLUME_WBITS % 2 == 0, "the window loops double with jac_dbl_neg: an even count per window");
-template <int ND, bool SCAN = false>
-PLUME_HD void msm_run_uniform(jac& acc, const uint32_t* tab0, const uint32_t* tab1, bool live, int nslots, const int8_t* dig, uint32_t stride) {
-    msm_run_uniform_impl<false, ND, SCAN>(acc, tab0, tab1, live, nslots, dig, stride);
+static_assert(2 * (PLUME_NPOS - 1) == 128 && 2 * (PLUME_NPOS64 - 1) == 64, "the uniform chains' offset constants are -(2^128 B) and -(2^64 B)");
+template <int NP, bool SCAN = false>
+PLUME_HD void msm_run_uniform(jac& acc, const uint32_t* tab0, const uint32_t* tab1, bool live, const int8_t* dig, uint32_t stride) {
+    msm_run_uniform_impl<false, NP, SCAN>(acc, tab0, tab1, live, dig, stride);
     if (fe_is_zero(acc.z)) {
         PLUME_COUNT_FALLBACK();
-        msm_run_uniform_impl<true, ND, SCAN>(acc, tab0, tab1, live, nslots, dig, stride);
+        msm_run_uniform_impl<true, NP, SCAN>(acc, tab0, tab1, live, dig, stride);
     }
-    const fe cx = ND == PLUME_NDIG64 ? fe_off_c64_x() : fe_off_c128_x(), cy = ND == PLUME_NDIG64 ? fe_off_c64_y() : fe_off_c128_y();     // - 2^(4 (ND - 1)) B
+    const fe cx = NP == PLUME_NPOS64 ? fe_off_c64_x() : fe_off_c128_x(), cy = NP == PLUME_NPOS64 ? fe_off_c64_y() : fe_off_c128_y();     // - 4^(NP - 1) B
     if (!acc.inf) jac_madd<true>(acc, cx, cy);
     else { acc.x = cx; acc.y = cy; acc.z = fe_small(1); acc.inf = 0; }              // (acc.inf: only after a checked redo that hit the identity)
 }
 // the same chain with the checked additions only (the redo kernel of the verifier: tasks whose unchecked chain met p == +-q)
-PLUME_HD void msm_run_checked(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
+PLUME_HD void msm_run_checked(jac& acc, const uint32_t* tab0, const uint32_t* tab1, const int8_t* dig, uint32_t stride, bool wide0 = false) {
     PLUME_COUNT_FALLBACK();
-    msm_run_impl<true>(acc, tab0, tab1, nslots, dig, stride, wide0);
+    msm_run_impl<true>(acc, tab0, tab1, dig, stride, wide0);
 }
 // the unchecked chain; returns false when the accumulator met p == +-q on the way (Z = 0 mod p: the result is garbage and the task has to be redone with checked additions)
-PLUME_HD bool msm_run_unchecked(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
-    msm_run_impl<false>(acc, tab0, tab1, nslots, dig, stride, wide0);
+PLUME_HD bool msm_run_unchecked(jac& acc, const uint32_t* tab0, const uint32_t* tab1, const int8_t* dig, uint32_t stride, bool wide0 = false) {
+    msm_run_impl<false>(acc, tab0, tab1, dig, stride, wide0);
     return acc.inf || !fe_is_zero(acc.z);
 }
-template <int ND = PLUME_NDIG>
-PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, int nslots, const int8_t* dig, uint32_t stride, bool wide0 = false) {
-    msm_run_impl<false, ND>(acc, tab0, tab1, nslots, dig, stride, wide0);
+template <int NP = PLUME_NPOS>
+PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, const int8_t* dig, uint32_t stride, bool wide0 = false) {
+    msm_run_impl<false, NP>(acc, tab0, tab1, dig, stride, wide0);
     // an accumulator that met p == +-q inside an unchecked addition has Z = 0 (mod p) forever after (see jac_madd): redo that lane
     if (!acc.inf && fe_is_zero(acc.z)) {
         PLUME_COUNT_FALLBACK();
-        msm_run_impl<true, ND>(acc, tab0, tab1, nslots, dig, stride, wide0);
+        msm_run_impl<true, NP>(acc, tab0, tab1, dig, stride, wide0);
     }
 }
 

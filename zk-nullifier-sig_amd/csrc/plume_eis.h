@@ -13,7 +13,7 @@
 //
 // Quotients are ESTIMATED in double precision (any quotient gives a unimodular step, so the relation above holds whatever the estimates are; good estimates make the
 // coefficients short).  Measured over 10^5 random and 10^3 crafted c: coefficients <= 65 bits, 39 steps on average, 51 at most (tests/test_devsim.py).  The caller checks
-// the bound it needs (< 2^67: seventeen 4-bit Booth digits) and falls back to the long form of the equation when it fails -- no input is known that does.
+// the bound it needs (< 2^66: thirty-four positions of base-4 Eisenstein digits) and falls back to the long form of the equation when it fails -- no input is known that does.
 #pragma once
 #include "plume_ec.h"
 
@@ -95,10 +95,10 @@ PLUME_HD void eis_step(int32_t (&x0)[N], int32_t (&x1)[N], const int32_t (&y0)[N
 }
 
 struct eis_short {
-    uint32_t t[2][3], u[2][3];      // magnitudes of tau - 1 = (t0 - 1) + t1 w and of upsilon = u0 + u1 w (below 2^67 when ok)
+    uint32_t t[2][3], u[2][3];      // magnitudes of tau - 1 = (t0 - 1) + t1 w and of upsilon = u0 + u1 w (below 2^66 when ok)
     uint32_t tneg[2], uneg[2];      // their signs
     sc tau;                         // tau = t0 + t1 lambda mod n
-    bool ok;                        // every coefficient is below 2^67 in magnitude
+    bool ok;                        // every coefficient is below 2^66 in magnitude
 };
 // a GLV half (magnitude of at most 129 bits in four words... the splits stay below 2^128) as signed limbs
 template <int N>
@@ -116,9 +116,9 @@ PLUME_HD void eis_from_half(int32_t (&l)[N], const glv_half& h) {
         if (i < N - 1) { l[i] = t & kEisMask; cy = t >> 29; } else l[i] = t;
     }
 }
-// |value| as three 32-bit words + sign, and whether it is below 2^67; the limbs are normalised (lower limbs in [0, 2^29), sign in the top limb)
+// |value| as three 32-bit words + sign, and whether it is below 2^66 (thirty-four positions of Eisenstein digits, plume_ec.h); the limbs are normalised (lower limbs in [0, 2^29), sign in the top limb)
 template <int N>
-PLUME_HD bool eis_abs67(uint32_t (&mag)[3], uint32_t& neg, const int32_t (&l)[N]) {
+PLUME_HD bool eis_abs66(uint32_t (&mag)[3], uint32_t& neg, const int32_t (&l)[N]) {
     neg = l[N - 1] < 0 ? 1u : 0u;
     int32_t v[N];
     int32_t cy = 0;
@@ -131,7 +131,7 @@ PLUME_HD bool eis_abs67(uint32_t (&mag)[3], uint32_t& neg, const int32_t (&l)[N]
     mag[0] = a | (b << 29);
     mag[1] = (b >> 3) | (c << 26);
     mag[2] = (c >> 6) | (d << 23);
-    bool small = (mag[2] >> 3) == 0 && (N <= 3 || (d >> 9) == 0);       // below 2^67: nothing above bit 66
+    bool small = (mag[2] >> 2) == 0 && (N <= 3 || (d >> 9) == 0);       // below 2^66: nothing above bit 65
     PLUME_UNROLL for (int i = 4; i < N; i++) small = small && v[i] == 0;
     return small;
 }
@@ -170,8 +170,8 @@ PLUME_HD void eis_half_gcd(eis_short& out, const sc& c) {
     PLUME_UNROLL for (int i = 0; i < kEisT; i++) { t0[i] = sel ? ty0[i] : tx0[i]; t1[i] = sel ? ty1[i] : tx1[i]; }
     bool ok = which >= 0;
     uint32_t m0[3], m1[3], n0, n1;
-    ok = eis_abs67(m0, n0, t0) && ok;
-    ok = eis_abs67(m1, n1, t1) && ok;
+    ok = eis_abs66(m0, n0, t0) && ok;
+    ok = eis_abs66(m1, n1, t1) && ok;
     {   // tau = t0 + t1 lambda mod n
         sc a, b, lam, bl;
         PLUME_UNROLL for (int i = 0; i < 8; i++) { a.v[i] = i < 3 ? m0[i] : 0u; b.v[i] = i < 3 ? m1[i] : 0u; }
@@ -183,26 +183,17 @@ PLUME_HD void eis_half_gcd(eis_short& out, const sc& c) {
         sc_add(out.tau, a, bl);
         ok = ok && !sc_is_zero(out.tau);
     }
-    {   // tau - 1: one off t0's bottom limb (the normalisation inside eis_abs67 carries it)
+    {   // tau - 1: one off t0's bottom limb (the normalisation inside eis_abs66 carries it)
         t0[0] -= 1;
         int32_t cy = 0;
         PLUME_UNROLL for (int i = 0; i < kEisT; i++) { const int32_t t = t0[i] + cy; if (i < kEisT - 1) { t0[i] = t & kEisMask; cy = t >> 29; } else t0[i] = t; }
     }
-    ok = eis_abs67(out.t[0], out.tneg[0], t0) && ok;
+    ok = eis_abs66(out.t[0], out.tneg[0], t0) && ok;
     PLUME_UNROLL for (int i = 0; i < 3; i++) out.t[1][i] = m1[i];
     out.tneg[1] = n1;
-    ok = eis_abs67(out.u[0], out.uneg[0], r0) && ok;
-    ok = eis_abs67(out.u[1], out.uneg[1], r1) && ok;
+    ok = eis_abs66(out.u[0], out.uneg[0], r0) && ok;
+    ok = eis_abs66(out.u[1], out.uneg[1], r1) && ok;
     out.ok = ok;
-}
-
-// seventeen 4-bit Booth digits of a magnitude below 2^67 (three words), sign applied
-PLUME_HD void booth_store67(int8_t* dig, uint32_t stride, const uint32_t (&mag)[3], bool neg) {
-    const uint32_t m[4] = {mag[0], mag[1], mag[2], 0u};
-    PLUME_UNROLL for (int i = 0; i < PLUME_NDIG64; i++) {
-        const int d = booth_digit(m, i);
-        dig[(uint32_t)i * stride] = (int8_t)(neg ? -d : d);
-    }
 }
 
 }  // namespace plume

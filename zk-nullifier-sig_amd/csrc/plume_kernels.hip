@@ -127,19 +127,31 @@ struct WaveRowSink {
     }
 };
 
-// ---- the window tables: one launch per PASS of the affine chain (plume_ec.h tab_pass_a..d) ---------------------------------------------------------------------------
-// A lane's running product travels through HBM between two passes (9 words per lane, word-major: coalesced), and ALL the inversions of a level run as one dense launch of
-// k_tab_invert in between (Montgomery's trick over 8 lanes' products: one inversion per 48 jobs at 6 jobs per lane).  No pass holds an inversion or a workgroup barrier.
-// (Rounds 2-3 also carried a one-kernel form, a workgroup's four wavefronts sharing three serial inversions: same time, the stage is HBM-bound; LABNOTES.md.)
-#define PLUME_TABPASS_WAVES_AB 3   // (r03 A/B on one box, table stage of a 2^20 verify: 4/3 waves 1.93 ms, 3/3 1.86, 3/2 1.83, 4/4 2.32; the one-kernel form 1.89)
-#define PLUME_TABPASS_WAVES_CD 2
+// ---- the window tables (plume_ec.h: P, theta P, 2P per job by one round of inversions): pass A, the batched inversion, pass B -------------------------------------------
+// A lane's running product travels through HBM between the passes (9 words per lane, word-major: coalesced), and ALL the inversions run as one dense launch of k_tab_invert in
+// between (Montgomery's trick over 8 lanes' products: one inversion per 48 jobs at 6 jobs per lane).  No pass holds an inversion or a workgroup barrier.
+// (Rounds 2-4: four passes and three inversion launches for 1P..8P by affine chains, plus a Jacobian-chain form for small batches; LABNOTES.md.)
+#define PLUME_TABPASS_WAVES_A 4
+#define PLUME_TABPASS_WAVES_B 3
 #define PLUME_TABINV_K 8          // lane products per inversion
 // Workgroups of 128 lanes (round 4; 256 before): a pass that stages rows needs 17 KiB of LDS, which fits BESIDE a compute unit's four resident workgroups of the multi-scalar
 // kernel (4 x 33 KiB of digit rows leave 28 KiB of the 160).  With 34 KiB per workgroup the table passes of a second batch (another lane of the context, another piece of a
 // host-pointer call) could not start before the first batch's multi-scalar kernel had drained: rocprofv3 showed a 0.3 ms pass stretched over the other batch's whole 8 ms kernel.
 constexpr int kTabBlock = 128;
-template <int PASS>
-__device__ __forceinline__ void tab_pass_body(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, uint8_t* guardf, uint4* s_rows, uint32_t** s_ptrs) {
+__global__ __launch_bounds__(kTabBlock, PLUME_TABPASS_WAVES_A) void k_tab_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, uint8_t* guardf) {
+    const size_t lane = (size_t)blockIdx.x * kTabBlock + threadIdx.x, nl = (size_t)gridDim.x * kTabBlock;
+    const size_t j0 = lane * (size_t)L;
+    const int cnt = j0 < njobs ? (int)((njobs - j0) < (size_t)L ? (njobs - j0) : (size_t)L) : 0;
+    uint32_t* myscr = scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_SCR_WORDS * kTabBlock);
+    fe c;
+    bool g = false;
+    tab_pass_a(bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, g);
+    st_fe_soa(carry, nl, lane, c); guardf[lane] = g ? 1 : 0;
+}
+__global__ __launch_bounds__(kTabBlock, PLUME_TABPASS_WAVES_B) void k_tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, const uint32_t* scr, const uint32_t* carry,
+                                                                                  const uint8_t* guardf) {
+    __shared__ uint4 s_rows[kTabBlock * 8];
+    __shared__ uint32_t* s_ptrs[kTabBlock];
     const size_t lane = (size_t)blockIdx.x * kTabBlock + threadIdx.x, nl = (size_t)gridDim.x * kTabBlock;
     const size_t j0 = lane * (size_t)L;
     const int cnt = j0 < njobs ? (int)((njobs - j0) < (size_t)L ? (njobs - j0) : (size_t)L) : 0;
@@ -147,52 +159,12 @@ __device__ __forceinline__ void tab_pass_body(uint32_t* tab, const uint32_t* bas
     sink.rows = s_rows + (threadIdx.x & ~63u) * 8;
     sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
     sink.full = __ballot(cnt == L) == ~0ull;
-    uint32_t* myscr = scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_AFF_SCR_WORDS * kTabBlock);
-    fe c;
-    bool g = false;
-    if (PASS > 0) { ld_fe_soa(c, carry, nl, lane); g = guardf[lane] != 0; }
-    if (PASS == 0) tab_pass_a<WaveRowSink>(bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, g);
-    else if (PASS == 1) tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, g, sink);
-    else if (PASS == 2) tab_pass_c(tab, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, g, sink);
-    else if (PASS == 3) tab_pass_d(tab, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, g, sink);
-    if (PASS < 3) { st_fe_soa(carry, nl, lane, c); guardf[lane] = g ? 1 : 0; }
-}
-__global__ __launch_bounds__(kTabBlock, PLUME_TABPASS_WAVES_AB) void k_tab_pass_a(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, uint8_t* guardf) {
-    tab_pass_body<0>(tab, bases, jobflags, njobs, L, scr, carry, guardf, nullptr, nullptr);
-}
-#define PLUME_TAB_PASS_KERNEL(NAME, PASS, WAVES)                                                                                                                              \
-    __global__ __launch_bounds__(kTabBlock, WAVES) void NAME(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, uint32_t* carry, \
-                                                          uint8_t* guardf) {                                                                                                  \
-        __shared__ uint4 s_rows[kTabBlock * 8];                                                                                                                                  \
-        __shared__ uint32_t* s_ptrs[kTabBlock];                                                                                                                                  \
-        tab_pass_body<PASS>(tab, bases, jobflags, njobs, L, scr, carry, guardf, s_rows, s_ptrs);                                                                              \
-    }
-PLUME_TAB_PASS_KERNEL(k_tab_pass_b, 1, PLUME_TABPASS_WAVES_AB)
-PLUME_TAB_PASS_KERNEL(k_tab_pass_c, 2, PLUME_TABPASS_WAVES_CD)
-PLUME_TAB_PASS_KERNEL(k_tab_pass_d, 3, PLUME_TABPASS_WAVES_CD)
-// the table stage of small batches (plume_ec.h tabj_pass_a / tabj_pass_b): one job per lane, Jacobian chain, one k_tab_invert in between
-// lane -> job.  The verifier's jobs come in threes (pk, H, nullifier of an item: two affine bases and a Jacobian one); lanes are dealt out kind by kind, so that a wavefront
-// builds tables of ONE kind and runs one addition form (kinds = 3), not both.  The signer's jobs are all of one kind (kinds = 1).
-// (nk = how many of the jobs, from the front, come in such groups: the verifier's short first equation appends one more job per item -- R, affine -- behind them)
-__device__ __forceinline__ size_t tabj_job_of_lane(size_t lane, size_t nk, uint32_t kinds) {
-    if (kinds <= 1 || lane >= nk) return lane;
-    const size_t per = nk / kinds;
-    return (lane % per) * kinds + lane / per;
-}
-__global__ PLUME_MSM_BOUNDS void k_tabj_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t nk, uint32_t kinds, uint32_t* scr, uint32_t* carry) {
-    const size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x, nl = (size_t)gridDim.x * kBlock;
-    fe c = fe_small(1);
-    if (lane < njobs) tabj_pass_a_guarded(bases, jobflags, njobs, tabj_job_of_lane(lane, nk, kinds), scr, nl, lane, c);
-    st_fe_soa(carry, nl, lane, c);
-}
-__global__ PLUME_MSM_BOUNDS void k_tabj_pass_b(uint32_t* tab, size_t njobs, size_t nk, uint32_t kinds, const uint32_t* scr, const uint32_t* carry) {
-    const size_t lane = (size_t)blockIdx.x * kBlock + threadIdx.x, nl = (size_t)gridDim.x * kBlock;
-    if (lane >= njobs) return;
+    const uint32_t* myscr = scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_SCR_WORDS * kTabBlock);
     fe c;
     ld_fe_soa(c, carry, nl, lane);
-    tabj_pass_b(tab, tabj_job_of_lane(lane, nk, kinds), scr, nl, lane, c);
+    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, guardf[lane] != 0, sink);
 }
-// carry[.] <- 1 / carry[.] for the nl lane products of a level: thread t takes lanes t, t + T, ..., t + (K-1) T (coalesced) and spends ONE inversion on their product.
+// carry[.] <- 1 / carry[.] for the nl lane products: thread t takes lanes t, t + T, ..., t + (K-1) T (coalesced) and spends ONE inversion on their product.
 // The products are never zero (the passes' guard).
 __global__ PLUME_NORM_BOUNDS void k_tab_invert(uint32_t* carry, size_t nl, size_t T) {
     const size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -210,6 +182,8 @@ __device__ __forceinline__ void wipe_digits(int8_t* s_dig) {
 
 // blocks [0, nb): equation 1 (s*G - c*pk); blocks [nb, 2nb): equation 2 (s*H - c*nullifier) — the role is uniform
 // per workgroup so the generator-table-in-LDS path never diverges inside a wavefront
+// digit rows per lane of the verifier's multi-scalar kernels: equation 1 in its long form needs the most (s in wide digits, 2 x 33 rows, + the 65 positions of -c)
+#define PLUME_MSM_DIG_ROWS (2 * PLUME_NDIG + PLUME_NPOS)
 template <int FORM>
 __device__ __forceinline__ void verify_msm_body(const VerifyArgs& a, int8_t* s_dig) {
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
@@ -220,13 +194,13 @@ __device__ __forceinline__ void verify_msm_body(const VerifyArgs& a, int8_t* s_d
     if (i < a.n) verify_msm<false, FORM>(a, i, eq, gt, s_dig + threadIdx.x, kBlock);      // (the rows hold digits of s and c: public parts of a signature, nothing to wipe)
 }
 __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
-    __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
+    __shared__ int8_t s_dig[PLUME_MSM_DIG_ROWS * kBlock];
     verify_msm_body<0>(a, s_dig);
 }
 // the same launch for calls whose equation 1 runs in the short form (round 5, plume_eis.h): blocks [0, nb) walk 64 doublings and add the generator's term from the comb,
 // blocks [nb, 2 nb) are equation 2 as before.  A kernel of its own so that neither form pays for the other's registers and code.
 __global__ PLUME_MSM_BOUNDS void k_verify_msm_s(VerifyArgs a) {
-    __shared__ int8_t s_dig[4 * PLUME_NDIG * kBlock];
+    __shared__ int8_t s_dig[PLUME_MSM_DIG_ROWS * kBlock];
     verify_msm_body<1>(a, s_dig);
 }
 // the tasks k_verify_msm filed (their unchecked chain met p == +-q), one per lane, with the checked additions; grid-stride over the filed count, so an honest batch's
@@ -234,7 +208,7 @@ __global__ PLUME_MSM_BOUNDS void k_verify_msm_s(VerifyArgs a) {
 // Workgroups of one wavefront: 8 KiB of digit rows, so that the launch (which normally finds nothing) never waits for LDS behind another batch's multi-scalar kernel.
 constexpr int kRedoBlock = 64;
 __global__ __launch_bounds__(kRedoBlock, PLUME_MSM_WAVES) void k_verify_msm_redo(VerifyArgs a) {
-    __shared__ int8_t s_dig[4 * PLUME_NDIG * kRedoBlock];
+    __shared__ int8_t s_dig[PLUME_MSM_DIG_ROWS * kRedoBlock];
     const uint32_t count = a.redo[0];
     for (uint32_t k = blockIdx.x * kRedoBlock + threadIdx.x; k < count; k += gridDim.x * kRedoBlock) {
         const uint32_t t = a.redo[1 + k];
@@ -266,25 +240,25 @@ __global__ PLUME_MSM_BOUNDS void k_sign_hdbl(SignArgs a) {
 }
 
 __global__ PLUME_MSM_BOUNDS void k_sign_hmul(SignArgs a) {
-    __shared__ int8_t s_dig[4 * PLUME_NDIG64 * kBlock];
+    __shared__ int8_t s_dig[2 * PLUME_NPOS64 * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
     if (i < a.n) sign_hmul(a, i, which, s_dig + threadIdx.x, kBlock);
-    wipe_digits<4 * PLUME_NDIG64>(s_dig);   // the rows are digits of sk and r: nothing derived from a secret stays in LDS when the workgroup retires
+    wipe_digits<2 * PLUME_NPOS64>(s_dig);   // the rows are digits of sk and r: nothing derived from a secret stays in LDS when the workgroup retires
 }
 
 // the uniform-schedule forms of the two kernels that walk secret digits (plume_set_sign_uniform; LEVEL 1: no branch on a digit, LEVEL 2: no address from a digit
 // either): same grids, same outputs
 template <int LEVEL>
 __global__ PLUME_MSM_BOUNDS void k_sign_hmul_uniform(SignArgs a) {
-    __shared__ int8_t s_dig[4 * PLUME_NDIG64 * kBlock];
+    __shared__ int8_t s_dig[2 * PLUME_NPOS64 * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     // level 2: the two tasks of an item (sk * H, r * H: the same two tables, every row of them read at every window) sit in ADJACENT lanes, so one fetch serves both
     const uint32_t which = LEVEL == 2 ? (threadIdx.x & 1u) : blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = LEVEL == 2 ? (blockIdx.x * kBlock + threadIdx.x) >> 1 : (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
     if (i < a.n) sign_hmul<LEVEL>(a, i, which, s_dig + threadIdx.x, kBlock);
-    wipe_digits<4 * PLUME_NDIG64>(s_dig);
+    wipe_digits<2 * PLUME_NPOS64>(s_dig);
 }
 template <int LEVEL>
 __global__ PLUME_MSM_BOUNDS void k_sign_gmul_uniform(SignArgs a) {
@@ -464,21 +438,11 @@ void launch_verify_ingest(const VerifyArgs& a, hipStream_t st, bool two_roles) {
 }
 static size_t tables_park_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
-    return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_AFF_SCR_WORDS * 4;          // one parked product per job and level, two regions
+    return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_SCR_WORDS * 4;          // one parked prefix product per job
 }
 size_t tables_scratch_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
-    return tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16;   // ... + the multi-kernel form's lane state: carry (9 words) and guard flag per lane
-}
-size_t tables_small_scratch_bytes(size_t njobs) { return (size_t)nblocks(njobs) * kBlock * ((size_t)PLUME_TAB_ENTRIES * PLUME_TABJ_ENTRY_WORDS + PLUME_FE_WORDS) * 4 + 16; }
-void launch_tables_small(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t nthrees, uint32_t* scr, hipStream_t st) {
-    const uint32_t kinds = (nthrees && nthrees % 3 == 0 && nthrees <= njobs) ? 3u : 1u;     // the first nthrees jobs come as (pk, H, nullifier) triples
-    const dim3 grid(nblocks(njobs)), block(kBlock);
-    const size_t nl = (size_t)grid.x * kBlock, T = (nl + PLUME_TABINV_K - 1) / PLUME_TABINV_K;
-    uint32_t* carry = scr + nl * (size_t)PLUME_TAB_ENTRIES * PLUME_TABJ_ENTRY_WORDS;
-    hipLaunchKernelGGL(k_tabj_pass_a, grid, block, 0, st, bases, jobflags, njobs, nthrees, kinds, scr, carry);
-    hipLaunchKernelGGL(k_tab_invert, dim3(nblocks(T)), block, 0, st, carry, nl, T);
-    hipLaunchKernelGGL(k_tabj_pass_b, grid, block, 0, st, tab, njobs, nthrees, kinds, scr, carry);
+    return tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16;   // ... + the lanes' state between the passes: carry (9 words) and guard flag per lane
 }
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st) {
     size_t lanes = (njobs + L - 1) / L;
@@ -487,15 +451,9 @@ void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags
     const size_t nl = (size_t)grid.x * kTabBlock, T = (nl + PLUME_TABINV_K - 1) / PLUME_TABINV_K;
     uint32_t* carry = scr + tables_park_bytes(njobs, L) / 4;
     uint8_t* guardf = reinterpret_cast<uint8_t*>(carry + nl * PLUME_FE_WORDS);
-    const dim3 igrid(nblocks(T));
-    const dim3 iblock(kBlock);
-    hipLaunchKernelGGL(k_tab_pass_a, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
-    hipLaunchKernelGGL(k_tab_invert, igrid, iblock, 0, st, carry, nl, T);
+    hipLaunchKernelGGL(k_tab_pass_a, grid, block, 0, st, bases, jobflags, njobs, L, scr, carry, guardf);
+    hipLaunchKernelGGL(k_tab_invert, dim3(nblocks(T)), dim3(kBlock), 0, st, carry, nl, T);
     hipLaunchKernelGGL(k_tab_pass_b, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
-    hipLaunchKernelGGL(k_tab_invert, igrid, iblock, 0, st, carry, nl, T);
-    hipLaunchKernelGGL(k_tab_pass_c, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
-    hipLaunchKernelGGL(k_tab_invert, igrid, iblock, 0, st, carry, nl, T);
-    hipLaunchKernelGGL(k_tab_pass_d, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
 }
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {
     (void)hipMemsetAsync(a.redo, 0, 4, st);

@@ -12,11 +12,8 @@ constexpr int kTableJobsPerLane = 6;   // (measured r02, one box, final layout: 
 
 void launch_verify_scalars(const VerifyArgs& a, hipStream_t st);                           // window digits of s and c; the short first equation's coefficients (plume_eis.h)
 void launch_verify_ingest(const VerifyArgs& a, hipStream_t st, bool two_roles = false);   // two_roles: the small-batch form, two lanes per item (k_verify_ingest_split)
-// scr: lane-interleaved pass-1 scratch of tables_scratch_bytes(njobs, jobs_per_lane) bytes (plume_ec.h tab_pass_a..d)
+// the window tables of njobs bases (plume_ec.h: rows P, theta P, 2P): pass A, one batched inversion, pass B.  scr: tables_scratch_bytes(njobs, jobs_per_lane) bytes
 size_t tables_scratch_bytes(size_t njobs, int jobs_per_lane);
-// the table stage of small batches: Jacobian chain per job, one inversion (plume_ec.h tabj_pass_a / b); scr of tables_small_scratch_bytes(njobs) bytes
-size_t tables_small_scratch_bytes(size_t njobs);
-void launch_tables_small(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t nthrees /* jobs, from the front, that come as (pk, H, nullifier) triples */, uint32_t* scr, hipStream_t st);
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int jobs_per_lane, uint32_t* scr, hipStream_t st);
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st);
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st);

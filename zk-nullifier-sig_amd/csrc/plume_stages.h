@@ -176,10 +176,10 @@ struct VerifyArgs {
 PLUME_HD size_t verify_njobs(const VerifyArgs& a) { return (a.eq1long ? 4 : 3) * (size_t)a.n; }
 // the digit rows of an item: three sets of 2 x PLUME_NDIG rows (the two halves of a GLV split): s in 4-bit windows (equation 2), s with the generator's wide digits
 // (equation 1), -c in 4-bit windows (both equations)
-#define PLUME_VDIG_SET (2 * PLUME_NDIG)
-#define PLUME_VDIG_SETB (4 * PLUME_NDIG64)          // set B: s in the generator's wide digits (2 x 33 rows: long form) OR the four 64-bit coefficients of the short form (4 x 17)
+#define PLUME_VDIG_SET PLUME_NPOS                    // sets A and C: the Eisenstein digits of one GLV pair, one row per position
+#define PLUME_VDIG_SETB (2 * PLUME_NPOS66)          // set B: s in the generator's wide digits (2 x 33 rows: long form) OR the two coefficient pairs of the short form (2 x 34)
 #define PLUME_VDIG_ROWS (2 * PLUME_VDIG_SET + PLUME_VDIG_SETB)
-static_assert(PLUME_VDIG_SETB >= PLUME_VDIG_SET, "set B holds either form");
+static_assert(PLUME_VDIG_SETB >= 2 * PLUME_NDIG, "set B holds either form");
 // One crafted item (pk = +-k G with small k, s = +-c, ...) steers its accumulator into p == +-q inside an UNCHECKED addition.  Rounds 1-2 redid such a lane on the spot with
 // the checked additions -- and its 63 neighbours waited: one crafted item per wavefront doubled the kernel.  Now the lane only files its task; a second,
 // dense launch (k_verify_msm_redo: one filed task per lane, grid-stride) redoes the filed tasks.  Honest batches file nothing and the second launch costs its launch; a batch
@@ -195,19 +195,18 @@ PLUME_HD uint32_t redo_file(uint32_t* redo, uint32_t task) {
     return k;
 }
 
-// the digit rows of one item (d = the item's column of the row-major digit array, n = its row pitch): set A = s = k1 + k2 lambda in 4-bit Booth windows (equation 2),
-// set B = equation 1's own rows (below), set C = -c in 4-bit windows (equation 2, and equation 1 in its long form)
+// the digit rows of one item (d = the item's column of the row-major digit array, n = its row pitch): set A = the Eisenstein digits of s = k1 + k2 lambda (equation 2's H),
+// set B = equation 1's own rows (below), set C = the digits of -c (equation 2's nullifier, and pk in equation 1's long form)
 PLUME_HD void verify_item_digits(int8_t* d, uint32_t n, const sc& s, const sc& c, bool long_b) {
     glv_half h1, h2;
     glv_split(h1, h2, s);
-    booth_store(d, n, h1, false); booth_store(d + (size_t)PLUME_NDIG * n, n, h2, false);
+    eisd_store_glv(d, n, h1, h2, false);
     if (long_b) { booth_store_wide(d + (size_t)PLUME_VDIG_SET * n, n, h1, false); booth_store_wide(d + (size_t)(PLUME_VDIG_SET + PLUME_NDIG) * n, n, h2, false); }
     glv_split(h1, h2, c);
-    int8_t* dc = d + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * n;
-    booth_store(dc, n, h1, true); booth_store(dc + (size_t)PLUME_NDIG * n, n, h2, true);
+    eisd_store_glv(d + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * n, n, h1, h2, true);
 }
 // The scalar stage: every digit row the multi-scalar kernel reads, once per item.  Short form of equation 1 (a.eq1long != NULL; plume_eis.h): (tau, upsilon) from the
-// half-GCD of c, k = tau s mod n for the comb, and set B = the digits of -upsilon (slots 0, 1: pk, lambda pk) and of -(tau - 1) (slots 2, 3: R, lambda R).
+// half-GCD of c, k = tau s mod n for the comb, and set B = the Eisenstein digits of -upsilon (pk's joint slot) and of -(tau - 1) (R's).
 PLUME_HD void verify_scalars(const VerifyArgs& a, uint32_t i) {
     sc c, s;
     bool okc = load_scalar_be(c, a.c + 32 * (size_t)i), oks = load_scalar_be(s, a.s + 32 * (size_t)i);
@@ -223,10 +222,8 @@ PLUME_HD void verify_scalars(const VerifyArgs& a, uint32_t i) {
             sc_mul(k, e.tau, s);
             PLUME_UNROLL for (int w = 0; w < 8; w++) a.eq1k[(size_t)w * a.n + i] = k.v[w];
             int8_t* b = a.digs + (size_t)PLUME_VDIG_SET * a.n + i;
-            booth_store67(b, a.n, e.u[0], !e.uneg[0]);
-            booth_store67(b + (size_t)PLUME_NDIG64 * a.n, a.n, e.u[1], !e.uneg[1]);
-            booth_store67(b + (size_t)2 * PLUME_NDIG64 * a.n, a.n, e.t[0], !e.tneg[0]);
-            booth_store67(b + (size_t)3 * PLUME_NDIG64 * a.n, a.n, e.t[1], !e.tneg[1]);
+            (void)eisd_store<PLUME_NPOS66, 3>(b, a.n, e.u[0], e.uneg[0] != 0, e.u[1], e.uneg[1] != 0, true);                                   // - upsilon
+            (void)eisd_store<PLUME_NPOS66, 3>(b + (size_t)PLUME_NPOS66 * a.n, a.n, e.t[0], e.tneg[0] != 0, e.t[1], e.tneg[1] != 0, true);      // - (tau - 1)
         }
         a.eq1long[i] = lng ? 1 : 0;
     }
@@ -357,14 +354,14 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
     if (a.itemflags[item]) {
         acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
     } else if (FORM != 0 && eq == 0 && short_call && !a.eq1long[item]) {
-        // Equation 1, short form (plume_eis.h): k G - upsilon pk - (tau - 1) R, to be compared with R by the finalize stage.  Slots 0, 1: pk and lambda pk, slots 2, 3: R and
-        // lambda R, seventeen windows (64 doublings); then the generator's term from the doubling-free comb, fifteen additions.
+        // Equation 1, short form (plume_eis.h): k G - upsilon pk - (tau - 1) R, to be compared with R by the finalize stage.  Two joint slots, pk and R, thirty-four positions
+        // (66 doublings at most; leading all-zero positions are skipped); then the generator's term from the doubling-free comb, fifteen additions.
         const int8_t* db = a.digs + (size_t)PLUME_VDIG_SET * a.n + item;
         PLUME_UNROLL for (int r = 0; r < PLUME_VDIG_SETB; r++) dig[(uint32_t)r * stride] = db[(size_t)r * a.n];
         const size_t jp = 3 * (size_t)item, jr = 3 * (size_t)a.n + item;
         const uint32_t* tabp = job_state(a.jobflags[jp]) == PLUME_JOB_OK ? a.tab + jp * PLUME_TAB_WORDS : nullptr;
         const uint32_t* tabr = job_state(a.jobflags[jr]) == PLUME_JOB_OK ? a.tab + jr * PLUME_TAB_WORDS : nullptr;
-        msm_run_impl<CHECKED, PLUME_NDIG64>(acc, tabp, tabr, 4, dig, stride, false);
+        msm_run_impl<CHECKED, PLUME_NPOS66>(acc, tabp, tabr, dig, stride, false);
         sc k;                                                                 // (loaded after the chain: eight registers the chain does not have to carry)
         PLUME_UNROLL for (int w = 0; w < 8; w++) k.v[w] = a.eq1k[(size_t)w * a.n + item];
         comb_add_g<CHECKED>(acc, k, a.gcomb);
@@ -374,19 +371,23 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
         return;
     } else {
         if (FORM == 2 && !CHECKED && eq == 0 && short_call) { redo_file(a.redo, (uint32_t)t); return; }
-        // slots 0, 1: s (wide digits for equation 1's generator slots), slots 2, 3: -c -- the rows the scalar stage left for this item, into the lane's digit area
-        const int8_t* ds = a.digs + (size_t)(eq == 0 ? PLUME_VDIG_SET : 0) * a.n + item;
+        // the rows the scalar stage left for this item, into the lane's digit area: s first (equation 1: its wide digits for the generator's table, 2 x 33 rows; equation 2: its
+        // Eisenstein digits for H, 65 rows), then the Eisenstein digits of -c (pk / the nullifier)
         const int8_t* dc = a.digs + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * a.n + item;
-        PLUME_UNROLL for (int r = 0; r < PLUME_VDIG_SET; r++) {
-            dig[(uint32_t)r * stride] = ds[(size_t)r * a.n];
-            dig[(uint32_t)(PLUME_VDIG_SET + r) * stride] = dc[(size_t)r * a.n];
+        if (eq == 0) {
+            const int8_t* ds = a.digs + (size_t)PLUME_VDIG_SET * a.n + item;
+            PLUME_UNROLL for (int r = 0; r < 2 * PLUME_NDIG; r++) dig[(uint32_t)r * stride] = ds[(size_t)r * a.n];
+            PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) dig[(uint32_t)(2 * PLUME_NDIG + r) * stride] = dc[(size_t)r * a.n];
+        } else {
+            const int8_t* ds = a.digs + item;
+            PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) { dig[(uint32_t)r * stride] = ds[(size_t)r * a.n]; dig[(uint32_t)(PLUME_NPOS + r) * stride] = dc[(size_t)r * a.n]; }
         }
         const size_t ja = 3 * (size_t)item + 1, jb = 3 * (size_t)item + (eq ? 2 : 0);
         const uint32_t* tab0 = eq ? (job_state(a.jobflags[ja]) == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr) : gtab;
         const uint32_t* tab1 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
         if (CHECKED) {
-            msm_run_checked(acc, tab0, tab1, 4, dig, stride, eq == 0);
-        } else if (!msm_run_unchecked(acc, tab0, tab1, 4, dig, stride, eq == 0)) {
+            msm_run_checked(acc, tab0, tab1, dig, stride, eq == 0);
+        } else if (!msm_run_unchecked(acc, tab0, tab1, dig, stride, eq == 0)) {
             redo_file(a.redo, (uint32_t)t);
             return;
         }
@@ -544,16 +545,17 @@ PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, bool li
     (void)load_scalar_reduced(k, (which ? a.r : a.sk) + 32 * (size_t)item);
     glv_half h1, h2;
     glv_split(h1, h2, k);
-    booth_store64(dig + 0 * PLUME_NDIG64 * stride, stride, h1.m[0], h1.m[1], h1.neg != 0);
-    booth_store64(dig + 1 * PLUME_NDIG64 * stride, stride, h2.m[0], h2.m[1], h2.neg != 0);
-    booth_store64(dig + 2 * PLUME_NDIG64 * stride, stride, h1.m[2], h1.m[3], h1.neg != 0);
-    booth_store64(dig + 3 * PLUME_NDIG64 * stride, stride, h2.m[2], h2.m[3], h2.neg != 0);
+    {   // k = (k1lo + k2lo lambda) + 2^64 (k1hi + k2hi lambda): the Eisenstein digits of the low pair for H's table, of the high pair for 2^64 H's
+        const uint32_t lo1[2] = {h1.m[0], h1.m[1]}, lo2[2] = {h2.m[0], h2.m[1]}, hi1[2] = {h1.m[2], h1.m[3]}, hi2[2] = {h2.m[2], h2.m[3]};
+        (void)eisd_store<PLUME_NPOS64, 2>(dig, stride, lo1, h1.neg != 0, lo2, h2.neg != 0, false);
+        (void)eisd_store<PLUME_NPOS64, 2>(dig + PLUME_NPOS64 * stride, stride, hi1, h1.neg != 0, hi2, h2.neg != 0, false);
+    }
     const uint32_t* t0 = a.tab + (size_t)item * PLUME_TAB_WORDS;                      // (every job has a table: a dummy one when its base was no usable point)
     const uint32_t* t1 = a.tab + ((size_t)a.n + item) * PLUME_TAB_WORDS;
     jac acc;
-    if (UNIFORM == 2) msm_run_uniform<PLUME_NDIG64, true>(acc, t0, t1, live, 4, dig, stride);
-    else if (UNIFORM == 1) msm_run_uniform<PLUME_NDIG64>(acc, t0, t1, live, 4, dig, stride);
-    else msm_run<PLUME_NDIG64>(acc, live ? t0 : nullptr, live ? t1 : nullptr, 4, dig, stride, false);
+    if (UNIFORM == 2) msm_run_uniform<PLUME_NPOS64, true>(acc, t0, t1, live, dig, stride);
+    else if (UNIFORM == 1) msm_run_uniform<PLUME_NPOS64>(acc, t0, t1, live, dig, stride);
+    else msm_run<PLUME_NPOS64>(acc, live ? t0 : nullptr, live ? t1 : nullptr, dig, stride, false);
     st_jac_soa(res, nt, t, acc);
     resinf[t] = (uint8_t)acc.inf;
 }
