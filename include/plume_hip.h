@@ -98,10 +98,10 @@ int plume_set_in_flight(plume_ctx* ctx, int batches);
  *            keys) run the same instructions for every digit value: every slot adds (a zero digit adds row 1 to a copy that a masked select drops), signs are masked selects,
  *            the accumulator starts at a fixed offset point that is subtracted at the end.  UNIFORM: control flow, instruction count.  NOT uniform: the ADDRESS of the
  *            table row each slot gathers (cache / HBM-channel timing).  Price on the MI355X: +2.5 % per signature.
- *   level 2: level 1, and no address is derived from a digit: every slot reads all 8 rows of its window's table and keeps one by masked selects (what k256 does with its
+ *   level 2: level 1, and no address is derived from a digit: every slot reads all 3 rows of its table (P, theta P, 2P: csrc/plume_ec.h) and keeps one by masked selects (what k256 does with its
  *            16-entry tables); the multiplications by G then use a 52-window x 16-row table instead of the 18-bit comb (52 additions instead of 15).  UNIFORM: control flow,
  *            instruction count, every memory address.  Price: +47 %.
- * At every level: the scalar side (reduction mod n, GLV split, Booth recoding, s = r + sk*c) is select-based; the range checks of sk and r are not (an out-of-range scalar
+ * At every level: the scalar side (reduction mod n, GLV split, digit recoding, s = r + sk*c) is select-based; the range checks of sk and r are not (an out-of-range scalar
  * is a status bit, not a secret worth protecting); nothing is claimed about power / EM channels.  Outputs are bit-identical at every level.  Returns PLUME_ERR_ARG for a
  * level outside 0..2.  Measurements: DESIGN.md §9. */
 int plume_set_sign_uniform(plume_ctx* ctx, int level);
@@ -120,9 +120,7 @@ int plume_set_eq1_short(plume_ctx* ctx, int mode);
  *   PLUME_HOST_PIECE, PLUME_HOST_FIRST_PIECE, PLUME_HOST_TAIL_PIECE, PLUME_HOST_REGISTER_MIN, PLUME_HOST_LANES (1 | 2), PLUME_HOST_SCHEDULE (explicit piece list, read per call)
  *                                                        the host-pointer pipeline (plume_set_host_*)
  *   PLUME_INGEST_SPLIT_MAX   verify calls of at most this many items run the ingest stage with two lanes per item (default 65536; 0: never)
- *   PLUME_TABLES_SMALL_MAX   window-table stages of at most this many jobs (3 per verify, 2 per sign: H and 2^64 H) take the one-inversion Jacobian chain (default 98304,
- *                            i.e. verify calls of up to 32768 items and sign calls of up to 49152; 0: never)
- *   PLUME_JOBS_PER_LANE      jobs per lane of the affine table passes (default: 3..6 by batch size)
+ *   PLUME_JOBS_PER_LANE      jobs per lane of the table passes (default: 3..6 by batch size)
  *   PLUME_SIGN_UNIFORM       default level of plume_set_sign_uniform (0, 1, 2; default 1)
  *   PLUME_EQ1_SHORT, PLUME_EQ1_SHORT_MIN   plume_set_eq1_short's mode and the smallest call that takes the short form (default 1, 131072)
  *   PLUME_NO_AFFINITY        multi-device contexts: leave the shard threads' CPU affinity alone */

@@ -218,6 +218,11 @@ void ds_tables_raw(uint32_t nb, const uint8_t* pts, uint8_t* out) {
             memcpy(out + 64 * (PLUME_TAB_ENTRIES * (size_t)j + k), rec, 64);
         }
 }
+// the digit table of eisd_store in its two forms (the 64-entry table, the register-resident packing the kernels run) for every t = (ta, tb) in [-4, 4]^2: 81 x 2 words
+void ds_eisd_entries(uint32_t* out) {
+    int k = 0;
+    for (int ta = -4; ta <= 4; ta++) for (int tb = -4; tb <= 4; tb++) { out[k++] = eisd_entry_table(ta, tb); out[k++] = eisd_entry(ta, tb); }
+}
 uint32_t ds_tab_entries() { return PLUME_TAB_ENTRIES; }     // rows per window table (3: P, theta P = P - lambda P, 2P)
 
 // simulated launch geometry: blocks of B lanes sharing a digit buffer with element stride B (as LDS does on the GPU)
@@ -471,7 +476,7 @@ int ds_eq1(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[6
     for (int j = 0; j < 3; j++) { st_base(a.bases, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
     run_tables(a.tab, a.bases, a.jobflags, 3, 3);
     std::vector<int8_t> dig(2 * PLUME_NDIG + PLUME_NPOS), digs(PLUME_VDIG_ROWS);
-    { sc sv, cv; sc_from_be_aligned(sv, sb); sc_from_be_aligned(cv, cb); verify_item_digits(digs.data(), 1, sv, cv, true); }     // what the scalar stage leaves for the item (long form)
+    { sc sv, cv; sc_from_be_aligned(sv, sb); sc_from_be_aligned(cv, cb); glv_half c1, c2; glv_split(c1, c2, cv); verify_item_digits(digs.data(), 1, sv, c1, c2, true); }     // what the scalar stage leaves for the item (long form)
     a.digs = digs.data();
     uint32_t redo[3] = {0, 0, 0};
     a.redo = redo;
@@ -493,7 +498,9 @@ int ds_eis_half_gcd(uint32_t n, const uint8_t* c_be, uint8_t* out, uint8_t* tau_
         memcpy(cb, c_be + 32 * (size_t)i, 32);
         sc c; sc_from_be_aligned(c, cb);
         eis_short e;
-        eis_half_gcd(e, c);
+        glv_half g0, g1;
+        glv_split(g0, g1, c);
+        eis_half_gcd(e, g0, g1);
         const uint32_t (*mags[4])[3] = {&e.t[0], &e.t[1], &e.u[0], &e.u[1]};
         const uint32_t negs[4] = {e.tneg[0], e.tneg[1], e.uneg[0], e.uneg[1]};
         for (int k = 0; k < 4; k++) {

@@ -223,6 +223,16 @@ def test_eisenstein_digit_table():
     body = src[src.index("static const uint16_t T[64] = {"):]
     body = body[:body.index("};")]
     assert [int(x, 16) for x in re.findall(r"0x[0-9A-Fa-f]{3}", body)] == tab
+    # ... and the register-resident packing the kernels run (eisd_entry) is this table for every t the recoding can meet
+    import ctypes as C
+    out = np.zeros(162, dtype=np.uint32)
+    D.lib().ds_eisd_entries(out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    k = 0
+    for ta in range(-4, 5):
+        for tb in range(-4, 5):
+            idx = ((ta & 3) << 2) | (tb & 3) | (16 if ta < 0 else 0) | (32 if tb < 0 else 0)
+            assert int(out[k]) == tab[idx] and int(out[k + 1]) == tab[idx], (ta, tb)
+            k += 2
 
 
 def test_sha256_generic():

@@ -338,14 +338,24 @@ PLUME_HD void booth_store_wide(int8_t* dig, uint32_t stride, const glv_half& h, 
 #define PLUME_NPOS 65        // pairs of 128-bit halves (the verifier)
 #define PLUME_NPOS64 33      // pairs of 64-bit quarters (the signer's chains of 64 doublings)
 #define PLUME_NPOS66 34      // pairs below 2^66 (the verifier's short first equation, plume_eis.h)
-PLUME_HD uint32_t eisd_entry(int ta, int tb) {
-    // entry = code | (d0 + 2) << 5 | (d1 + 2) << 8 for t = (ta, tb), |ta|, |tb| <= 4; generated (and its invariants checked) by tests/test_devsim.py::test_eisenstein_digits
+PLUME_HD uint32_t eisd_entry_table(int ta, int tb) {
+    // entry = code | (d0 + 2) << 5 | (d1 + 2) << 8 for t = (ta, tb), |ta|, |tb| <= 4; generated (and its invariants checked) by tests/test_devsim.py::test_eisenstein_digit_table
     static const uint16_t T[64] = {0x240, 0x343, 0x44F, 0x144, 0x261, 0x366, 0x469, 0x167, 0x28D, 0x38C, 0x492, 0x10B, 0x222, 0x328, 0x02A, 0x125,
                                    0x240, 0x343, 0x44F, 0x144, 0x261, 0x366, 0x469, 0x167, 0x28D, 0x38C, 0x011, 0x10B, 0x222, 0x328, 0x02A, 0x125,
                                    0x240, 0x343, 0x44F, 0x144, 0x261, 0x366, 0x469, 0x167, 0x28D, 0x38C, 0x011, 0x10B, 0x222, 0x328, 0x02A, 0x125,
                                    0x240, 0x343, 0x44F, 0x144, 0x261, 0x366, 0x469, 0x167, 0x28D, 0x38C, 0x011, 0x10B, 0x222, 0x328, 0x02A, 0x125};
     const uint32_t idx = (((uint32_t)ta & 3u) << 2) | ((uint32_t)tb & 3u) | (ta < 0 ? 16u : 0u) | (tb < 0 ? 32u : 0u);
     return T[idx];
+}
+// The same table held in registers (what the kernels run: no load per position).  The four sign quadrants differ in ONE entry -- the residue (2, 2): 2w^2 or its negative
+// -- so sixteen entries packed into three constants (5-bit codes, 3-bit d0 + 2, d1 + 2) and one special case; tests hold it to the table above for every t.
+PLUME_HD uint32_t eisd_entry(int ta, int tb) {
+    const uint32_t i = (((uint32_t)ta & 3u) << 2) | ((uint32_t)tb & 3u);
+    const uint64_t CLO = 0x5C98D3A4C123C60ull, CHI = 0x2A902ull, D0 = 0x2491246DB492ull, D1 = 0x21A31A31A31Aull;     // codes 0..11 | codes 12..15 | d0 + 2 | d1 + 2
+    uint32_t code = (uint32_t)((i < 12u ? CLO >> (5u * i) : CHI >> (5u * (i - 12u))) & 31u);
+    uint32_t d0 = (uint32_t)(D0 >> (3u * i)) & 7u, d1 = (uint32_t)(D1 >> (3u * i)) & 7u;
+    if (i == 10u && (ta < 0 || tb < 0)) { code = 17u; d0 = 0u; d1 = 0u; }
+    return code | (d0 << 5) | (d1 << 8);
 }
 // NP digit codes of  +-(a + b w),  a = (aneg ? -1 : 1) am,  b likewise, magnitudes below 4^(NP - 1) given as NW little-endian words; dig[i * stride] = position i.
 // Returns false if a carry is left over (the magnitude bound did not hold).

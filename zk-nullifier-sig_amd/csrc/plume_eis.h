@@ -136,12 +136,10 @@ PLUME_HD bool eis_abs66(uint32_t (&mag)[3], uint32_t& neg, const int32_t (&l)[N]
     return small;
 }
 
-// (tau, upsilon) for the challenge c (canonical, any value including 0): the GLV split of c, then the half-GCD.  At most kEisMaxSteps reductions; every honest input
+// (tau, upsilon) for the challenge c (canonical, any value including 0) given by its GLV split: the half-GCD of (pi, gamma).  At most kEisMaxSteps reductions; every honest input
 // finishes in about forty.
 constexpr int kEisMaxSteps = 400;
-PLUME_HD void eis_half_gcd(eis_short& out, const sc& c) {
-    glv_half g0, g1;
-    glv_split(g0, g1, c);
+PLUME_HD void eis_half_gcd(eis_short& out, const glv_half& g0, const glv_half& g1) {      // gamma = g0 + g1 w: the GLV split of c (glv_split)
     // pi = a1 + b1 w:  a1 = 0x3086d221a7d46bcde86c90e49284eb15, b1 = -0xe4437ed6010e88286f547fa90abfe4c3 (the lattice vector glv_split calls (a1, b1))
     const glv_half pa = {{0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u}, 0u}, pb = {{0x0ABFE4C3u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u}, 1u};
     int32_t x0[kEisR], x1[kEisR], y0[kEisR], y1[kEisR];

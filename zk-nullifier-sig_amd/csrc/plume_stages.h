@@ -197,13 +197,12 @@ PLUME_HD uint32_t redo_file(uint32_t* redo, uint32_t task) {
 
 // the digit rows of one item (d = the item's column of the row-major digit array, n = its row pitch): set A = the Eisenstein digits of s = k1 + k2 lambda (equation 2's H),
 // set B = equation 1's own rows (below), set C = the digits of -c (equation 2's nullifier, and pk in equation 1's long form)
-PLUME_HD void verify_item_digits(int8_t* d, uint32_t n, const sc& s, const sc& c, bool long_b) {
+PLUME_HD void verify_item_digits(int8_t* d, uint32_t n, const sc& s, const glv_half& c1, const glv_half& c2, bool long_b) {
     glv_half h1, h2;
     glv_split(h1, h2, s);
     eisd_store_glv(d, n, h1, h2, false);
     if (long_b) { booth_store_wide(d + (size_t)PLUME_VDIG_SET * n, n, h1, false); booth_store_wide(d + (size_t)(PLUME_VDIG_SET + PLUME_NDIG) * n, n, h2, false); }
-    glv_split(h1, h2, c);
-    eisd_store_glv(d + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * n, n, h1, h2, true);
+    eisd_store_glv(d + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * n, n, c1, c2, true);
 }
 // The scalar stage: every digit row the multi-scalar kernel reads, once per item.  Short form of equation 1 (a.eq1long != NULL; plume_eis.h): (tau, upsilon) from the
 // half-GCD of c, k = tau s mod n for the comb, and set B = the Eisenstein digits of -upsilon (pk's joint slot) and of -(tau - 1) (R's).
@@ -213,9 +212,11 @@ PLUME_HD void verify_scalars(const VerifyArgs& a, uint32_t i) {
     if (a.mode == PLUME_MODE_NON_ZK) { okc = sc_lt_n(c); oks = sc_lt_n(s); }
     if (!okc || !oks) { if (a.eq1long) a.eq1long[i] = 1; return; }            // (the ingest stage rejects the item; its digit rows are never read)
     bool lng = true;
+    glv_half c1, c2;
+    glv_split(c1, c2, c);                                                     // once: the half-GCD starts from it, the digits of -c are its
     if (a.eq1long) {
         eis_short e;
-        eis_half_gcd(e, c);
+        eis_half_gcd(e, c1, c2);
         lng = !e.ok || a.eq1force != 0;
         if (!lng) {
             sc k;
@@ -227,7 +228,7 @@ PLUME_HD void verify_scalars(const VerifyArgs& a, uint32_t i) {
         }
         a.eq1long[i] = lng ? 1 : 0;
     }
-    verify_item_digits(a.digs + i, a.n, s, c, lng);
+    verify_item_digits(a.digs + i, a.n, s, c1, c2, lng);
 }
 
 PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
