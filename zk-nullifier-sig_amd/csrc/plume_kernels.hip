@@ -47,6 +47,7 @@ __global__ PLUME_BOUNDS void k_fixed_table(uint32_t* rows, const uint32_t* base1
 // (plume_eis.h).  Light on registers and latency-bound (about forty dependent quotient steps in double precision), so it runs at full occupancy beside nothing else.
 __global__ __launch_bounds__(kBlock, 4) void k_verify_scalars(VerifyArgs a) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) a.redo[0] = 0;                 // the redo list of the multi-scalar launch behind this one starts empty (rounds 3-4: a memset launch of its own in front of that kernel)
     if (i < a.n) verify_scalars(a, i);
 }
 
@@ -455,8 +456,7 @@ void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags
     hipLaunchKernelGGL(k_tab_invert, dim3(nblocks(T)), dim3(kBlock), 0, st, carry, nl, T);
     hipLaunchKernelGGL(k_tab_pass_b, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
 }
-void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {
-    (void)hipMemsetAsync(a.redo, 0, 4, st);
+void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {      // (a.redo[0] was zeroed by k_verify_scalars, which every verify pipeline runs first)
     if (a.eq1long) hipLaunchKernelGGL(k_verify_msm_s, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
     else hipLaunchKernelGGL(k_verify_msm, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
     const unsigned redo_blocks = std::min(2 * nblocks(a.n) * (kBlock / kRedoBlock), 4096u);   // grid-stride: enough lanes for a wholly crafted batch to fill the chip
