@@ -896,13 +896,14 @@ PLUME_HD void msm_add_uniform(jac& acc, const uint32_t* tab, int code) {
     const uint32_t c = zero ? 0u : (uint32_t)(code - 1), row = c / 6u, u = c - 6u * row, j = u >> 1;
     fe x, y, bx;
     if (SCAN) {
-        PLUME_UNROLL for (uint32_t r = 0; r < PLUME_TAB_ENTRIES; r++) {
+        PLUME_UNROLL for (int i = 0; i < 8; i++) { x.v[i] = tab[i]; y.v[i] = tab[8 + i]; bx.v[i] = tab[16 + i]; }
+        x.v[8] = tab[24]; y.v[8] = tab[25]; bx.v[8] = tab[26];
+        PLUME_NOUNROLL for (uint32_t r = 1; r < PLUME_TAB_ENTRIES; r++) {       // (rolled: one row's 27 words in flight at a time -- unrolled, the three rows' loads were hoisted together and spilled)
             const uint32_t* e = tab + r * PLUME_TAB_ENTRY_WORDS;
             fe rx, ry, rb;
             PLUME_UNROLL for (int i = 0; i < 8; i++) { rx.v[i] = e[i]; ry.v[i] = e[8 + i]; rb.v[i] = e[16 + i]; }
             rx.v[8] = e[24]; ry.v[8] = e[25]; rb.v[8] = e[26];
-            if (r == 0) { x = rx; y = ry; bx = rb; }
-            else { fe_cmov(x, rx, row == r); fe_cmov(y, ry, row == r); fe_cmov(bx, rb, row == r); }
+            fe_cmov(x, rx, row == r); fe_cmov(y, ry, row == r); fe_cmov(bx, rb, row == r);
         }
     } else {
         const uint32_t* e = tab + row * PLUME_TAB_ENTRY_WORDS;
