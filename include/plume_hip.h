@@ -126,12 +126,14 @@ int plume_set_eq1_short(plume_ctx* ctx, int mode);
  *   PLUME_NO_AFFINITY        multi-device contexts: leave the shard threads' CPU affinity alone */
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (an upload, a download and the compute streams,
  * four staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each following piece up to three times
- * the one before, up to the largest piece (default 1<<19, capped by the chunk size); calls with large outputs (the signer) end on a small piece (default 1<<16).
- * Round 4: the pieces of a VERIFY call alternate between the context and a second lane of its own (workspace + stream, created on the first such call), so that the ingest and
- * table stages of piece k+1 run beside the multi-scalar kernel of piece k, and the message offsets the library prepares go up from page-locked memory: 2^20 V1 verifies from
- * page-locked arrays 21.4-21.9 ms against 22.3-23.2 ms on the same boxes (0.90-0.92 of the device-resident serial rate, 0.85-0.88 before).  The GPU is busy from the first
- * piece's arrival to the end (kernel + copy trace, tests/gpu_debug/e2e_trace.py); what remains is the first upload (0.57 ms) and the pieces' smaller launches.  Env
- * PLUME_HOST_LANES=1 restores the one-lane pipeline.  Results do not depend on any of this. */
+ * the one before, up to the largest piece (default 1<<19, capped by the chunk size); calls with large outputs (the signer: 320 bytes down per item) taper instead -- a first
+ * piece of twice the tail piece (default 1<<16), a body of pieces of at most half the largest, then 3, 2 and 1 tail pieces -- so that the last, unhidden download is short.
+ * The pieces of a VERIFY call alternate between the context and a second lane of its own (workspace + stream, created on the first such call) when EVERY array of the call
+ * is page-locked; the signer stays on one lane (measured: no gain from two).  The copy streams are created at high priority: the runtime multiplexes a process's streams onto
+ * a few hardware queues per priority level, and a copy stream that shares a queue with a compute stream waits for its kernels (round 5: a finished piece's download started
+ * 6 ms late).  Env PLUME_HOST_TRACE=1 prints every call's timeline to stderr (per piece: upload, kernels, download on the GPU's clock; no profiler needed -- and none should be
+ * attached: rocprofv3's memory-copy trace turns the downloads into blit kernels).  2^20 items from page-locked arrays on the MI355X: verify 20.7-21.0 ms, sign 18.7-19.1 ms,
+ * 0.89-0.91 of the device-resident rates.  Results do not depend on any of this. */
 int plume_set_host_piece(plume_ctx* ctx, size_t largest_piece_items);
 int plume_set_host_first_piece(plume_ctx* ctx, size_t items);
 int plume_set_host_tail_piece(plume_ctx* ctx, size_t items);
