@@ -114,7 +114,7 @@ void ds_sc_op(int op, size_t count, const uint32_t* a, const uint32_t* b, uint32
         for (int k = 0; k < 8; k++) out[8 * i + k] = r.v[k];
     }
 }
-uint32_t ds_wbits() { return PLUME_WBITS; }                  // window width (4)
+uint32_t ds_wbits() { return PLUME_WBITS; }                  // width of the grid the generator's wide digits sit on (4)
 // k (8 limbs) -> m1[4], neg1, m2[4], neg2 (10 words) and the PLUME_NPOS Eisenstein digit codes of the pair (int8, rows of 65)
 void ds_glv(size_t count, const uint32_t* k, uint32_t* out, int8_t* digits) {
     for (size_t i = 0; i < count; i++) {

@@ -556,7 +556,7 @@ extern "C" int plume_set_chunk(plume_ctx* ctx, size_t max_items) {
 // instruction sequence whatever the digits are -- no zero-digit skip, no sign branch, no "accumulator is still the identity" case: every slot adds (a zero digit adds row 1 to
 // a copy that a masked select drops), the sign is a masked select, and the accumulator starts at an offset point that comes off at the end.  Outputs are bit-identical.
 // Level 1 leaves one thing secret-dependent: the ADDRESS of the table row a slot gathers.  Level 2 removes that too, the way k256 does (it scans its 16-entry table with
-// conditional moves): every slot reads all 8 rows of its window's table and keeps one by masked selects (ld_tab_xy_scan), and because the 18-bit comb of G cannot be scanned
+// conditional moves): every slot reads all 3 rows of its table and keeps one by masked selects (msm_add_uniform), and because the 18-bit comb of G cannot be scanned
 // (131072 rows per window) the multiplications by G use a 52-window x 16-row table of their own (PLUME_GSCAN_*, 52 additions instead of 15).  Cost on the MI355X: DESIGN.md §9.
 extern "C" int plume_set_sign_uniform(plume_ctx* ctx, int level) {
     if (!ctx) return fail(PLUME_ERR_ARG, "plume_set_sign_uniform: null context");
@@ -649,7 +649,6 @@ static int pick_jobs_per_lane(const plume_ctx* ctx, size_t njobs, bool kinds_of_
     return (int)l;
 }
 
-// the window-table stage of njobs jobs: the small-batch path (one inversion on the critical path) or the affine chain's passes
 // nthrees: how many of the jobs, from the front, come as (pk, H, nullifier) triples (the verifier: 3 per item; its short first equation appends one more job per item behind
 // them; the signer: 0): the jobs per lane are then a multiple of three, so that the kinds line up across a wavefront (affine and Jacobian bases take different paths).
 static size_t table_stage_scratch(const plume_ctx* ctx, size_t njobs, size_t nthrees) { return tables_scratch_bytes(njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0)); }

@@ -1,14 +1,15 @@
-// secp256k1 group law, GLV split, signed fixed-window recoding, per-lane window tables and the multi-scalar
+// secp256k1 group law, GLV split, fixed-position digit recoding, per-lane window tables and the multi-scalar
 // loop for the PLUME hot path (the reference's `ProjectivePoint * Scalar` and point subtraction:
 // rust-k256/src/lib.rs:101,109; randomizedsigner.rs:51,53,67,70 — there done by the k256 crate).
 //
 // Design (SIMT-first, not a port of k256/libsecp): one scalar multiplication "task" per lane; because every
-// lane of a wavefront must execute the same instruction stream, recoding is a FIXED signed window (Booth,
-// w = 4, digits in [-8, 8]) rather than wNAF — all lanes add at the same positions, a zero digit just idles
-// its lane for one slot.  The endomorphism split (k = k1 + k2*lambda, |k_i| < 2^128) halves the doubling chain
-// to 128 for all four half-scalars of a double-base task.  Tables hold the eight AFFINE multiples 1P..8P plus
-// beta*x for the lambda half; they are produced by `table_build` with one field inversion per lane shared by
-// all tables the lane builds (Montgomery's trick through HBM scratch).
+// lane of a wavefront must execute the same instruction stream, recoding is by FIXED positions rather than wNAF
+// or any other sparse form -- all lanes add at the same positions, a zero digit just idles its lane for one slot.
+// The endomorphism split (k = k1 + k2*lambda, |k_i| < 2^128) halves the doubling chain to 128; since round 5 the
+// pair (k1, k2) is recoded as ONE Eisenstein integer in base 4 (a digit per two doublings, from the residues of
+// Z[w] / 4) and a table holds three AFFINE rows -- P, theta P = P - lambda P, 2P, each with beta*x -- whose unit
+// multiples are free.  Tables are produced by the table passes with one field inversion per 8 lanes shared by
+// all tables those lanes build (Montgomery's trick through HBM scratch).
 #pragma once
 #include "plume_field.h"
 
@@ -252,25 +253,11 @@ PLUME_HD void glv_split(glv_half& h1, glv_half& h2, const sc& k) {
     glv_finish(h1, d);
 }
 
-// Booth recoding, window w = PLUME_WBITS = 4: m = sum d_i 2^(w i), d_i in [-2^(w-1), 2^(w-1)], i = 0..NDIG-1 covering 129 bits:
-// d_i = k_{4i-1} + k_{4i} + 2k_{4i+1} + 4k_{4i+2} - 8k_{4i+3}.  (5-bit windows -- 26 digits, 16-row tables with a fourth chain level -- were built and measured in
-// rounds 2 and 3: the multi-scalar kernel gains 9 %, the HBM-bound table stage loses more; LABNOTES.md.  The build option is gone with round 4.)
+// The grid the generator's WIDE digits sit on: windows of PLUME_WBITS = 4 bits, PLUME_NDIG = 33 of them covering a 129-bit half (rounds 1-4 walked this grid for every
+// base -- 4-bit Booth digits, tables 1P..8P; 5-bit windows were built and measured in rounds 2 and 3 and lost to their table stage, LABNOTES.md.  Since round 5 the per-item
+// bases use the Eisenstein digits further down, whose positions are half a window apart: window w = position 2w.)
 #define PLUME_WBITS 4
 #define PLUME_NDIG ((128 + PLUME_WBITS) / PLUME_WBITS)       // 33
-PLUME_HD int booth_digit(const uint32_t m[4], int i) {
-    // u = bits [w i - 1, w i + w - 1] of m (bit -1 = 0); i is a compile-time constant after unrolling
-    const int W = PLUME_WBITS, lo = W * i - 1;
-    const uint32_t mask = (1u << (W + 1)) - 1u;
-    uint32_t u;
-    if (lo < 0) {
-        u = (m[0] << 1) & mask;
-    } else {
-        int wi = lo >> 5, sh = lo & 31;
-        uint32_t a = wi < 4 ? m[wi] : 0u, b = (wi + 1) < 4 ? m[wi + 1] : 0u;
-        u = (sh == 0 ? a : ((a >> sh) | (sh > 31 - W ? (b << (32 - sh)) : 0u))) & mask;
-    }
-    return (int)(u & 1) + (int)((u >> 1) & ((1u << (W - 1)) - 1u)) - (int)((u >> W) << (W - 1));
-}
 // Booth recoding with a WIDE window for the generator's slots of the verifier: m = sum d_k 2^(W k), d_k in [-2^(W-1), 2^(W-1)].
 // W = PLUME_GW must be a multiple of 4 so that digit k lines up with the 4-bit window i = k * W/4 of the shared doubling chain.
 // W = 12: 11 digits per 128-bit half (22 generator additions per verify instead of 34 with W = 8) from a 2048-entry table (256 KiB, L2-resident);

@@ -3,16 +3,17 @@
 // bodies from plain host loops so the exact device logic is checked on the CPU against the oracle.
 //
 // verify (rust-k256/src/lib.rs:93-145), n items:
-//   S1 ingest_h2c   lane = item     validate inputs; H = h2c(m || enc(pk)) (Jacobian); publish the three table
-//                                   jobs of the item: 3i = pk, 3i+1 = H, 3i+2 = nullifier
-//   S2 tables       lane = L jobs   affine window tables 1P..8P (+ beta*x), one inversion per lane
-//   S3 msm          lane = task     task 2i: R' = s*G - c*pk ;  task 2i+1: Hr' = s*H - c*nul   (Jacobian results)
+//   S1 ingest_h2c   lane = item     validate inputs; H = h2c(m || enc(pk)) (Jacobian); publish the table jobs of the item: 3i = pk, 3i+1 = H,
+//                                   3i+2 = nullifier (and 3n+i = R when equation 1 runs in its short form)
+//   S1' scalars     lane = item     every digit row the multi-scalar stage reads: Eisenstein digits of s and -c; equation 1's own rows (plume_eis.h)
+//   S2 tables       lane = L jobs   window tables P, theta P, 2P (+ beta*x), one inversion per 8 lanes
+//   S3 msm          lane = task     task 2i: R' = s*G - c*pk (or k*G - upsilon*pk - (tau-1)*R) ;  task 2i+1: Hr' = s*H - c*nul   (Jacobian results)
 //   S4 finalize     lane = item     V1: R' == r_point, Hr' == hashed_to_curve_r, c == SHA256(G,pk,H,nul,R,Hr) mod n
 //                                   V2: c == SHA256(nul, R', Hr') mod n
 // sign (rust-k256/src/randomizedsigner.rs:43-112; arkworks flavour rust-arkworks/src/lib.rs:229-278), n items:
 //   G1 sign_gmul    lane = task     task 2i: pk = sk*G ; task 2i+1: R = r*G
 //   G2 sign_h2c     lane = item     pk -> affine (or caller-supplied), H = h2c(m || enc(pk)); table job i = H
-//   S2 tables       (as above, 1 job per item)
+//   S2 tables       (as above, 2 jobs per item: H and 2^64 H)
 //   G3 sign_hmul    lane = task     task 2i: nullifier = sk*H ; task 2i+1: Hr = r*H
 //   G4 sign_final   lane = item     affine outputs, c = SHA256(..) mod n, s = r + sk*c, status bits
 #pragma once
