@@ -1,0 +1,451 @@
+// TEST INFRASTRUCTURE ONLY.  Drives the HOST side of libplume_hip.so -- csrc/plume_capi.hip compiled as plain C++ against the mock runtime (mockhip/hip/hip_runtime.h) with
+// the kernels as host loops (host_launch.cpp) -- through its C ABI, on several mock devices, and compares every output with the C oracle (oracle/plume_oracle.c).  Built and
+// run by tests/test_sanitizers.py under AddressSanitizer + UBSan and under ThreadSanitizer: the contexts, lanes, staging slots, piece pipeline, chunk loop, shard worker
+// threads and their teardown then run for real, with every caller array sized exactly on the heap and the mock's lazy / random stream scheduler running whatever the
+// library did not order in the worst order.
+//   pipeline_driver <group> [seed]        groups: verify sign multi device misc all
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/plume_hip.h"
+
+extern "C" {
+int oracle_verify_batch(int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s,
+                        const uint8_t* r_point, const uint8_t* hashed_to_curve_r, uint8_t* ok, int nthreads);
+int oracle_verify_non_zk_batch(int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nullifier, const uint8_t* s,
+                               const uint8_t* r_point, const uint8_t* hashed_to_curve_r, const uint8_t* digest_private, uint8_t* ok, int nthreads);
+int oracle_sign_batch(int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* sk, const uint8_t* r, const uint8_t* pk_in, uint8_t* pk,
+                      uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point, uint8_t* hashed_to_curve_r, uint8_t* h_out, uint8_t* status, int nthreads);
+int oracle_aggregate_check(int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk_b, const uint8_t* nul_b, const uint8_t* c_b,
+                           const uint8_t* s_b, const uint8_t* r_b, const uint8_t* hr_b, const uint8_t seed[32], uint64_t index_base, uint8_t* hash_ok, uint8_t result[72], int nthreads);
+int oracle_hash_to_curve_batch(size_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, uint8_t* h_out, int nthreads);
+int oracle_point_mul(const uint8_t k[32], const uint8_t p[64], uint8_t out[64]);
+size_t oracle_sec1_compress(const uint8_t p[64], uint8_t out[33]);
+}
+
+#define REQUIRE(c)                                                                                                                   \
+    do {                                                                                                                             \
+        if (!(c)) { std::fprintf(stderr, "pipeline_driver: %s:%d: %s   [%s] (text of the last library error on this thread, possibly an earlier, expected one: %s)\n", __FILE__, __LINE__, #c, g_what.c_str(), plume_last_error()); std::exit(2); } \
+    } while (0)
+static std::string g_what;
+static std::mt19937_64 rng;
+static uint64_t rnd(uint64_t lo, uint64_t hi) { return lo + rng() % (hi - lo + 1); }
+
+// A caller array: exactly `bytes` long.  kind 0 = pageable heap memory, 1 = page-locked by the library's allocator, 2 = heap memory page-locked with plume_host_register
+struct Arr {
+    uint8_t* p = nullptr;
+    size_t bytes = 0;
+    int kind = 0;
+    Arr() = default;
+    Arr(size_t b, int k) { alloc(b, k); }
+    Arr(const Arr&) = delete;
+    Arr& operator=(const Arr&) = delete;
+    void alloc(size_t b, int k) {
+        release();
+        bytes = b; kind = k;
+        if (k == 1) { p = (uint8_t*)plume_host_alloc(b ? b : 1); if (!p) { std::fprintf(stderr, "plume_host_alloc failed\n"); std::exit(2); } }
+        else { p = (uint8_t*)std::malloc(b ? b : 1); if (k == 2 && b && plume_host_register(p, b) != 0) { std::fprintf(stderr, "plume_host_register failed\n"); std::exit(2); } }
+        std::memset(p, 0xEE, b);
+    }
+    void release() {
+        if (!p) return;
+        if (kind == 1) plume_host_free(p);
+        else { if (kind == 2 && bytes) plume_host_unregister(p); std::free(p); }
+        p = nullptr;
+    }
+    ~Arr() { release(); }
+    void set(const std::vector<uint8_t>& v) { if (v.size() != bytes) { std::fprintf(stderr, "Arr::set size\n"); std::exit(2); } if (bytes) std::memcpy(p, v.data(), bytes); }
+};
+
+struct Batch {                     // a signed batch from the oracle, with some items spoiled; everything as plain vectors
+    int version = 1;
+    size_t n = 0;
+    std::vector<uint8_t> msgs, sk, r, pk, nul, c, s, rpt, hr, h, status;
+    std::vector<uint64_t> off;
+    std::vector<uint8_t> ok_expect, ok_nonzk_expect;
+};
+static std::vector<uint8_t> random_scalar_bytes(size_t n) {
+    std::vector<uint8_t> v(32 * n);
+    for (size_t i = 0; i < v.size(); i++) v[i] = (uint8_t)rng();
+    for (size_t i = 0; i < n; i++) { v[32 * i] &= 0x7F; v[32 * i + 31] |= 1; }          // in [1, n-1] for sure
+    return v;
+}
+static Batch make_batch(int version, size_t n, bool spoil) {
+    Batch b;
+    b.version = version; b.n = n;
+    b.off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; i++) { const size_t len = rnd(0, 9) == 0 ? 0 : rnd(0, 3) == 0 ? rnd(50, 150) : rnd(1, 40); b.off[i + 1] = b.off[i] + len; }
+    b.msgs.resize(b.off[n]);
+    for (auto& x : b.msgs) x = (uint8_t)rng();
+    b.sk = random_scalar_bytes(n); b.r = random_scalar_bytes(n);
+    b.pk.assign(64 * n, 0); b.nul.assign(64 * n, 0); b.c.assign(32 * n, 0); b.s.assign(32 * n, 0); b.rpt.assign(64 * n, 0); b.hr.assign(64 * n, 0); b.h.assign(64 * n, 0); b.status.assign(n, 0);
+    if (n) oracle_sign_batch(version, n, b.msgs.data(), b.off.data(), b.sk.data(), b.r.data(), nullptr, b.pk.data(), b.nul.data(), b.c.data(), b.s.data(), b.rpt.data(), b.hr.data(), b.h.data(), b.status.data(), 4);
+    if (spoil)
+        for (size_t i = 0; i < n; i++) {
+            switch (rnd(0, 11)) {
+                case 0: b.s[32 * i + 31] ^= 1; break;                                    // wrong s
+                case 1: b.c[32 * i + 7] ^= 0x10; break;                                  // wrong c
+                case 2: b.nul[64 * i + 63] ^= 1; break;                                  // nullifier off the curve
+                case 3: std::memset(&b.s[32 * i], 0, 32); break;                         // s = 0
+                case 4: std::memset(&b.pk[64 * i], 0xFF, 32); break;                     // pk.x >= p
+                case 5: if (version == 1) b.rpt[64 * i + 5] ^= 4; break;                 // r_point wrong
+                case 6: if (i > 0) std::memcpy(&b.nul[64 * i], &b.nul[64 * (i - 1)], 64); break;   // somebody else's nullifier (on the curve, wrong)
+                default: break;
+            }
+        }
+    b.ok_expect.assign(n, 0); b.ok_nonzk_expect.assign(n, 0);
+    if (n) {
+        oracle_verify_batch(version, n, b.msgs.data(), b.off.data(), b.pk.data(), b.nul.data(), b.c.data(), b.s.data(), b.rpt.data(), b.hr.data(), b.ok_expect.data(), 4);
+        oracle_verify_non_zk_batch(version, n, b.msgs.data(), b.off.data(), b.pk.data(), b.nul.data(), b.s.data(), b.rpt.data(), b.hr.data(), b.c.data(), b.ok_nonzk_expect.data(), 4);
+    }
+    return b;
+}
+static std::vector<uint8_t> compress_all(const std::vector<uint8_t>& pts, size_t n) {
+    std::vector<uint8_t> out(33 * n, 0);
+    for (size_t i = 0; i < n; i++) oracle_sec1_compress(&pts[64 * i], &out[33 * i]);
+    return out;
+}
+
+struct Knobs { size_t piece = 0, first = 0, tail = 0, chunk = 0, regmin = 0; int lanes = 0, eq1 = -1, uniform = -1, sub = 0; };
+static void apply(plume_ctx* ctx, const Knobs& k) {
+    if (k.chunk) REQUIRE(plume_set_chunk(ctx, k.chunk) == 0);
+    if (k.piece) REQUIRE(plume_set_host_piece(ctx, k.piece) == 0);
+    if (k.first) REQUIRE(plume_set_host_first_piece(ctx, k.first) == 0);
+    if (k.tail) REQUIRE(plume_set_host_tail_piece(ctx, k.tail) == 0);
+    if (k.lanes) REQUIRE(plume_set_host_lanes(ctx, k.lanes) == 0);
+    if (k.regmin) REQUIRE(plume_set_host_register_min(ctx, k.regmin) == 0);
+    if (k.eq1 >= 0) REQUIRE(plume_set_eq1_short(ctx, k.eq1) == 0);
+    if (k.uniform >= 0) REQUIRE(plume_set_sign_uniform(ctx, k.uniform) == 0);
+    if (k.sub) REQUIRE(plume_set_sub_batches(ctx, k.sub) == 0);
+}
+
+// every host-pointer verify form on one batch, arrays of memory kind `mk`
+static void check_verify(plume_ctx* ctx, const Batch& b, int mk) {
+    const size_t n = b.n;
+    Arr msgs(b.msgs.size(), mk), off(8 * (n + 1), mk), pk(64 * n, mk), nul(64 * n, mk), c(32 * n, mk), s(32 * n, mk), rpt(64 * n, mk), hr(64 * n, mk), ok(n, mk);
+    msgs.set(b.msgs); std::memcpy(off.p, b.off.data(), 8 * (n + 1)); pk.set(b.pk); nul.set(b.nul); c.set(b.c); s.set(b.s); rpt.set(b.rpt); hr.set(b.hr);
+    const bool v1 = b.version == 1;
+    REQUIRE(plume_verify_batch(ctx, b.version, n, msgs.p, (const uint64_t*)off.p, pk.p, nul.p, c.p, s.p, v1 ? rpt.p : nullptr, v1 ? hr.p : nullptr, ok.p) == 0);
+    REQUIRE(n == 0 || std::memcmp(ok.p, b.ok_expect.data(), n) == 0);
+    std::memset(ok.p, 0xEE, n);
+    REQUIRE(plume_verify_non_zk_batch(ctx, b.version, n, msgs.p, (const uint64_t*)off.p, pk.p, nul.p, s.p, rpt.p, hr.p, c.p, ok.p) == 0);
+    REQUIRE(n == 0 || std::memcmp(ok.p, b.ok_nonzk_expect.data(), n) == 0);
+    // SEC1 records of the same points (an item whose point is off the curve has no record: its oracle verdict is 0 either way, give it a bad tag)
+    Arr pk33(33 * n, mk), nul33(33 * n, mk), r33(33 * n, mk), hr33(33 * n, mk);
+    pk33.set(compress_all(b.pk, n)); nul33.set(compress_all(b.nul, n)); r33.set(compress_all(b.rpt, n)); hr33.set(compress_all(b.hr, n));
+    std::vector<uint8_t> expect(b.ok_expect);
+    for (size_t i = 0; i < n; i++)
+        if (!expect[i]) { pk33.p[33 * i] = 0x05; }            // whatever made the 64-byte form fail, the 33-byte form of this item fails on its tag
+    std::memset(ok.p, 0xEE, n);
+    REQUIRE(plume_verify_batch_sec1(ctx, b.version, n, msgs.p, (const uint64_t*)off.p, pk33.p, nul33.p, c.p, s.p, v1 ? r33.p : nullptr, v1 ? hr33.p : nullptr, ok.p) == 0);
+    REQUIRE(n == 0 || std::memcmp(ok.p, expect.data(), n) == 0);
+}
+
+static void check_sign(plume_ctx* ctx, const Batch& b, int mk, bool supply_pk) {
+    const size_t n = b.n;
+    Arr msgs(b.msgs.size(), mk), off(8 * (n + 1), mk), sk(32 * n, mk), r(32 * n, mk), pkin(64 * n, mk);
+    msgs.set(b.msgs); std::memcpy(off.p, b.off.data(), 8 * (n + 1)); sk.set(b.sk); r.set(b.r); pkin.set(b.pk);
+    // what the oracle signs from these inputs (the batch's own signature fields may have been spoiled)
+    std::vector<uint8_t> epk(64 * n), enul(64 * n), ec(32 * n), es(32 * n), erpt(64 * n), ehr(64 * n), eh(64 * n), est(n);
+    if (n) oracle_sign_batch(b.version, n, b.msgs.data(), b.off.data(), b.sk.data(), b.r.data(), supply_pk ? b.pk.data() : nullptr, epk.data(), enul.data(), ec.data(), es.data(), erpt.data(), ehr.data(), eh.data(), est.data(), 4);
+    {
+        Arr pk(64 * n, mk), nul(64 * n, mk), c(32 * n, mk), s(32 * n, mk), rpt(64 * n, mk), hr(64 * n, mk), status(n, mk);
+        REQUIRE(plume_sign_batch(ctx, b.version, n, msgs.p, (const uint64_t*)off.p, sk.p, r.p, supply_pk ? pkin.p : nullptr, pk.p, nul.p, c.p, s.p, rpt.p, hr.p, status.p) == 0);
+        if (n) {
+            REQUIRE(std::memcmp(status.p, est.data(), n) == 0);
+            REQUIRE(std::memcmp(nul.p, enul.data(), 64 * n) == 0 && std::memcmp(c.p, ec.data(), 32 * n) == 0 && std::memcmp(s.p, es.data(), 32 * n) == 0);
+            REQUIRE(std::memcmp(rpt.p, erpt.data(), 64 * n) == 0 && std::memcmp(hr.p, ehr.data(), 64 * n) == 0);
+            if (!supply_pk) REQUIRE(std::memcmp(pk.p, epk.data(), 64 * n) == 0);
+        }
+    }
+    {
+        Arr nul33(33 * n, mk), c(32 * n, mk), s(32 * n, mk), r33(33 * n, mk), hr33(33 * n, mk), status(n, mk);
+        REQUIRE(plume_sign_batch_sec1(ctx, b.version, n, msgs.p, (const uint64_t*)off.p, sk.p, r.p, supply_pk ? pkin.p : nullptr, nullptr, nul33.p, c.p, s.p, r33.p, hr33.p, status.p) == 0);
+        if (n) {
+            REQUIRE(std::memcmp(nul33.p, compress_all(enul, n).data(), 33 * n) == 0 && std::memcmp(r33.p, compress_all(erpt, n).data(), 33 * n) == 0);
+            REQUIRE(std::memcmp(hr33.p, compress_all(ehr, n).data(), 33 * n) == 0 && std::memcmp(s.p, es.data(), 32 * n) == 0);
+        }
+    }
+}
+
+static void check_aggregate(plume_ctx* ctx, const Batch& b, int mk, int mode) {
+    const size_t n = b.n;
+    Arr msgs(b.msgs.size(), mk), off(8 * (n + 1), mk), pk(64 * n, mk), nul(64 * n, mk), c(32 * n, mk), s(32 * n, mk), rpt(64 * n, mk), hr(64 * n, mk), hok(n, mk);
+    msgs.set(b.msgs); std::memcpy(off.p, b.off.data(), 8 * (n + 1)); pk.set(b.pk); nul.set(b.nul); c.set(b.c); s.set(b.s); rpt.set(b.rpt); hr.set(b.hr);
+    uint8_t seed[32], res[72], eres[72];
+    for (auto& x : seed) x = (uint8_t)rng();
+    std::vector<uint8_t> ehok(n);
+    REQUIRE(oracle_aggregate_check(b.version, mode, n, b.msgs.data(), b.off.data(), b.pk.data(), b.nul.data(), b.c.data(), b.s.data(), b.rpt.data(), b.hr.data(), seed, 0, ehok.data(), eres, 4) == 0);
+    REQUIRE(plume_aggregate_check(ctx, b.version, mode, n, msgs.p, (const uint64_t*)off.p, pk.p, nul.p, c.p, s.p, rpt.p, hr.p, seed, hok.p, res) == 0);
+    REQUIRE(std::memcmp(res, eres, 72) == 0);
+    REQUIRE(n == 0 || std::memcmp(hok.p, ehok.data(), n) == 0);
+    REQUIRE(plume_aggregate_check(ctx, b.version, mode, n, msgs.p, (const uint64_t*)off.p, pk.p, nul.p, c.p, s.p, rpt.p, hr.p, nullptr, nullptr, res) == 0);     // the library's own seed
+    REQUIRE(res[0] == eres[0] || eres[1] == 0);              // an all-true batch stays all-true under any seed
+}
+
+static void check_h2c_and_friends(plume_ctx* ctx, const Batch& b, int mk) {
+    const size_t n = b.n;
+    Arr msgs(b.msgs.size(), mk), off(8 * (n + 1), mk), pk(64 * n, mk), h(64 * n, mk);
+    msgs.set(b.msgs); std::memcpy(off.p, b.off.data(), 8 * (n + 1));
+    std::vector<uint8_t> good_pk(64 * n), eh(64 * n);
+    static const uint8_t G[64] = {0x79, 0xBE, 0x66, 0x7E, 0xF9, 0xDC, 0xBB, 0xAC, 0x55, 0xA0, 0x62, 0x95, 0xCE, 0x87, 0x0B, 0x07, 0x02, 0x9B, 0xFC, 0xDB, 0x2D, 0xCE, 0x28, 0xD9, 0x59, 0xF2, 0x81, 0x5B, 0x16, 0xF8, 0x17, 0x98,
+                                  0x48, 0x3A, 0xDA, 0x77, 0x26, 0xA3, 0xC4, 0x65, 0x5D, 0xA4, 0xFB, 0xFC, 0x0E, 0x11, 0x08, 0xA8, 0xFD, 0x17, 0xB4, 0x48, 0xA6, 0x85, 0x54, 0x19, 0x9C, 0x47, 0xD0, 0x8F, 0xFB, 0x10, 0xD4, 0xB8};
+    for (size_t i = 0; i < n; i++) oracle_point_mul(&b.sk[32 * i], G, &good_pk[64 * i]);
+    pk.set(good_pk);
+    if (n) oracle_hash_to_curve_batch(n, b.msgs.data(), b.off.data(), good_pk.data(), eh.data(), 4);
+    REQUIRE(plume_hash_to_curve_batch(ctx, n, msgs.p, (const uint64_t*)off.p, pk.p, h.p) == 0);
+    REQUIRE(n == 0 || std::memcmp(h.p, eh.data(), 64 * n) == 0);
+    {   // the intermediates: h must agree with the call above in both encodings; u, mapped, q are sized exactly
+        Arr u(64 * n, mk), mapped(128 * n, mk), q(128 * n, mk), h2(64 * n, mk), hints(192 * n, mk);
+        REQUIRE(plume_h2c_intermediates_batch(ctx, n, msgs.p, (const uint64_t*)off.p, pk.p, 0, u.p, mapped.p, q.p, h2.p) == 0);
+        REQUIRE(n == 0 || std::memcmp(h2.p, eh.data(), 64 * n) == 0);
+        REQUIRE(plume_h2c_intermediates_batch(ctx, n, msgs.p, (const uint64_t*)off.p, pk.p, 1, nullptr, nullptr, nullptr, h2.p) == 0);
+        std::vector<uint64_t> regs(8 * n);
+        REQUIRE(plume_registers_from_be(2 * n, eh.data(), regs.data()) == 0);
+        REQUIRE(n == 0 || std::memcmp(h2.p, regs.data(), 64 * n) == 0);
+        REQUIRE(plume_h2c_hints_batch(ctx, n, msgs.p, (const uint64_t*)off.p, pk.p, 0, hints.p) == 0);
+    }
+    {   // SEC1-DER export of the secret keys and the checked import of the records
+        Arr sk(32 * n, mk), der(109 * n, mk), st(n, mk), back(32 * n, mk), okf(n, mk);
+        sk.set(b.sk);
+        if (n > 2) std::memset(sk.p + 32, 0, 32);                                     // a scalar no SecretKey holds
+        REQUIRE(plume_scalars_to_sec1_der_batch(ctx, n, sk.p, der.p, st.p) == 0);
+        for (size_t i = 0; i < n; i++) {
+            const bool bad = n > 2 && i == 1;
+            REQUIRE(st.p[i] == (bad ? PLUME_STATUS_BAD_SCALAR : 0));
+            if (bad) continue;
+            REQUIRE(std::memcmp(der.p + 109 * i + 7, &b.sk[32 * i], 32) == 0 && std::memcmp(der.p + 109 * i + 45, &good_pk[64 * i], 64) == 0);
+        }
+        if (n > 3) der.p[109 * 3 + 100] ^= 1;                                         // a tampered public-key field
+        REQUIRE(plume_sec1_der_to_scalars_checked(ctx, n, der.p, back.p, okf.p) == 0);
+        for (size_t i = 0; i < n; i++) {
+            const bool bad = (n > 2 && i == 1) || (n > 3 && i == 3);
+            REQUIRE(okf.p[i] == (bad ? 0 : 1));
+            if (!bad) REQUIRE(std::memcmp(back.p + 32 * i, &b.sk[32 * i], 32) == 0);
+        }
+    }
+    {   // first occurrences among repeated nullifiers
+        Arr nul(64 * n, mk), live(n, mk), first(n, mk);
+        std::vector<uint8_t> v(b.nul);
+        for (size_t i = 0; i + 1 < n; i += 3) std::memcpy(&v[64 * (i + 1)], &v[64 * i], 64);
+        nul.set(v);
+        for (size_t i = 0; i < n; i++) live.p[i] = (i % 7) != 6;
+        uint64_t nu = ~0ull, expect_nu = 0;
+        REQUIRE(plume_nullifier_first_occurrence(ctx, n, nul.p, live.p, nullptr, first.p, &nu) == 0);
+        for (size_t i = 0; i < n; i++) {
+            bool f = live.p[i] != 0;
+            for (size_t j = 0; j < i && f; j++) if (live.p[j] && !std::memcmp(&v[64 * j], &v[64 * i], 64)) f = false;
+            REQUIRE(first.p[i] == (f ? 1 : 0));
+            expect_nu += f;
+        }
+        REQUIRE(nu == expect_nu);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ groups
+static void group_verify(uint64_t seed) {
+    plume_ctx* ctx = nullptr;
+    REQUIRE(plume_init(&ctx, 0) == 0);
+    const Batch v1 = make_batch(1, 150 + seed % 7, true), v2 = make_batch(2, 70, true), tiny = make_batch(1, 3, false), empty = make_batch(1, 0, false);
+    struct Case { const char* name; Knobs k; int mk; };
+    const Case cases[] = {
+        {"defaults, pageable arrays", {}, 0},
+        {"small pieces, pageable arrays (one lane, staged copies)", {40, 12, 12, 0, 0, 0, 3, -1, 0}, 0},
+        {"small pieces, page-locked arrays (two lanes, four slots), short first equation", {40, 12, 12, 0, 0, 2, 3, -1, 0}, 1},
+        {"small pieces, registered arrays, one lane, long first equation", {33, 7, 7, 0, 0, 1, 0, -1, 0}, 2},
+        {"pieces larger than the chunk, registration for the call, every item through the checked chain", {64, 16, 16, 24, 1, 2, 2, -1, 0}, 0},
+        {"sub-batches on the caller's stream", {0, 0, 0, 0, 0, 0, 1, -1, 2}, 1},
+    };
+    for (const Case& cs : cases) {
+        g_what = cs.name;
+        apply(ctx, cs.k);
+        check_verify(ctx, v1, cs.mk);
+        check_verify(ctx, v2, cs.mk);
+        check_verify(ctx, tiny, cs.mk);
+        check_verify(ctx, empty, cs.mk);
+    }
+    g_what = "argument errors";
+    uint8_t ok1[4] = {9, 9, 9, 9};
+    REQUIRE(plume_verify_batch(ctx, 3, 3, tiny.msgs.data(), tiny.off.data(), tiny.pk.data(), tiny.nul.data(), tiny.c.data(), tiny.s.data(), tiny.rpt.data(), tiny.hr.data(), ok1) != 0);
+    REQUIRE(plume_verify_batch(ctx, 1, 3, tiny.msgs.data(), tiny.off.data(), tiny.pk.data(), tiny.nul.data(), tiny.c.data(), tiny.s.data(), nullptr, nullptr, ok1) != 0);      // V1 needs R and Hr
+    REQUIRE(plume_verify_batch(nullptr, 1, 3, tiny.msgs.data(), tiny.off.data(), tiny.pk.data(), tiny.nul.data(), tiny.c.data(), tiny.s.data(), tiny.rpt.data(), tiny.hr.data(), ok1) != 0);
+    {   // message offsets that run backwards: the items are rejected, nothing outside msgs is read
+        std::vector<uint64_t> bad(tiny.off);
+        bad[1] = bad[3] + 1000;
+        REQUIRE(plume_verify_batch(ctx, 1, 3, tiny.msgs.data(), bad.data(), tiny.pk.data(), tiny.nul.data(), tiny.c.data(), tiny.s.data(), tiny.rpt.data(), tiny.hr.data(), ok1) != 0 || (ok1[0] == 0 && ok1[1] == 0));
+    }
+    plume_destroy(ctx);
+}
+
+static void group_sign(uint64_t seed) {
+    plume_ctx* ctx = nullptr;
+    REQUIRE(plume_init(&ctx, 1) == 0);
+    Batch v1 = make_batch(1, 90 + seed % 5, false), v2 = make_batch(2, 40, false), empty = make_batch(2, 0, false);
+    std::memset(&v1.sk[32 * 4], 0, 32);                       // sk = 0: BAD_SCALAR
+    std::memset(&v1.r[32 * 9], 0xFF, 32);                     // r >= n
+    struct Case { const char* name; Knobs k; int mk; bool supply_pk; };
+    const Case cases[] = {
+        {"defaults (uniform level 1), pageable arrays", {}, 0, false},
+        {"tapered small pieces, page-locked arrays, level 0", {24, 0, 6, 0, 0, 0, -1, 0, 0}, 1, false},
+        {"tapered small pieces, registered arrays, level 2 (scanned tables), pk supplied", {24, 0, 6, 0, 0, 0, -1, 2, 0}, 2, true},
+        {"chunk smaller than the pieces, registration for the call, level 1", {32, 0, 8, 20, 1, 0, -1, 1, 0}, 0, true},
+    };
+    for (const Case& cs : cases) {
+        g_what = cs.name;
+        apply(ctx, cs.k);
+        REQUIRE(cs.k.uniform < 0 || plume_get_sign_uniform(ctx) == cs.k.uniform);
+        check_sign(ctx, v1, cs.mk, cs.supply_pk);
+        check_sign(ctx, v2, cs.mk, cs.supply_pk);
+        check_sign(ctx, empty, cs.mk, cs.supply_pk);
+    }
+    plume_destroy(ctx);
+}
+
+static void group_multi(uint64_t seed) {
+    int ids[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    plume_ctx* ctx = nullptr;
+    g_what = "eight shards, eight devices";
+    REQUIRE(plume_init_multi(&ctx, ids, 8) == 0);
+    REQUIRE(plume_num_shards(ctx) == 8);
+    for (int d = 0; d < 8; d++) REQUIRE(plume_shard_numa_node(ctx, d) == -1);
+    Knobs k; k.piece = 16; k.first = 5; k.tail = 5; k.eq1 = 3; k.lanes = 2;
+    apply(ctx, k);
+    const Batch v1 = make_batch(1, 203 + seed % 11, true), v2 = make_batch(2, 61, true), few = make_batch(1, 5, false), empty = make_batch(1, 0, false);
+    for (int mk : {1, 0}) {
+        check_verify(ctx, v1, mk); check_verify(ctx, v2, mk); check_verify(ctx, few, mk); check_verify(ctx, empty, mk);
+        check_sign(ctx, v2, mk, false); check_sign(ctx, few, mk, true); check_sign(ctx, empty, mk, false);
+    }
+    const Batch clean = make_batch(1, 97, false), clean2 = make_batch(2, 41, false);
+    check_aggregate(ctx, clean, 1, 0); check_aggregate(ctx, clean, 0, 1); check_aggregate(ctx, clean2, 1, 1); check_aggregate(ctx, v1, 1, 0); check_aggregate(ctx, few, 0, 0); check_aggregate(ctx, empty, 0, 0);
+    check_h2c_and_friends(ctx, v2, 1);
+    check_h2c_and_friends(ctx, few, 0);
+    {   // device-resident calls need a single-device context
+        uint8_t ok1[8];
+        REQUIRE(plume_verify_batch_device(ctx, 1, 5, few.msgs.data(), few.off.data(), few.msgs.size(), few.pk.data(), few.nul.data(), few.c.data(), few.s.data(), few.rpt.data(), few.hr.data(), ok1, nullptr) == PLUME_ERR_ARG);
+    }
+    plume_destroy(ctx);
+    g_what = "three shards on two devices, used from two caller threads in turn";
+    int ids2[3] = {2, 2, 5};
+    REQUIRE(plume_init_multi(&ctx, ids2, 3) == 0);
+    apply(ctx, k);
+    std::thread t([&] { g_what = "second caller thread"; check_verify(ctx, v2, 1); });
+    t.join();
+    check_verify(ctx, v1, 0);
+    plume_destroy(ctx);
+    g_what = "bad device lists";
+    int bad[2] = {0, 99};
+    REQUIRE(plume_init_multi(&ctx, bad, 2) != 0 && ctx == nullptr);
+    REQUIRE(plume_init_multi(&ctx, ids, 0) != 0);
+    REQUIRE(plume_init(&ctx, -1) != 0);
+}
+
+// device-resident calls: the caller owns the device arrays and the streams
+struct DevArr {
+    uint8_t* p = nullptr; size_t bytes;
+    DevArr(const void* src, size_t b) : bytes(b) { if (hipMalloc((void**)&p, b ? b : 1) != hipSuccess) std::exit(2); if (src && b) (void)hipMemcpy(p, src, b, hipMemcpyHostToDevice); }
+    ~DevArr() { (void)hipFree(p); }
+};
+static void group_device(uint64_t seed) {
+    plume_ctx* ctx = nullptr;
+    REQUIRE(plume_init(&ctx, 3) == 0);
+    REQUIRE(hipSetDevice(3) == hipSuccess);
+    const Batch a = make_batch(1, 130 + seed % 3, true), b = make_batch(2, 77, true);
+    hipStream_t s1, s2;
+    REQUIRE(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess);
+    for (int in_flight : {1, 2}) {
+        for (int sub : {1, 2}) {
+            g_what = "device-resident verify: in_flight " + std::to_string(in_flight) + ", sub-batches " + std::to_string(sub);
+            REQUIRE(plume_set_in_flight(ctx, in_flight) == 0);
+            REQUIRE(plume_set_sub_batches(ctx, sub) == 0);
+            REQUIRE(plume_set_eq1_short(ctx, sub == 1 ? 3 : 0) == 0);
+            DevArr am(a.msgs.data(), a.msgs.size()), ao(a.off.data(), 8 * (a.n + 1)), apk(a.pk.data(), 64 * a.n), an(a.nul.data(), 64 * a.n), ac(a.c.data(), 32 * a.n), as(a.s.data(), 32 * a.n), ar(a.rpt.data(), 64 * a.n),
+                ah(a.hr.data(), 64 * a.n), aok(nullptr, a.n), aok2(nullptr, a.n);
+            DevArr bm(b.msgs.data(), b.msgs.size()), bo(b.off.data(), 8 * (b.n + 1)), bpk(b.pk.data(), 64 * b.n), bn(b.nul.data(), 64 * b.n), bc(b.c.data(), 32 * b.n), bs(b.s.data(), 32 * b.n), bok(nullptr, b.n);
+            // three calls on two streams and the context's own, nothing waited for in between: they share the context's workspace(s)
+            REQUIRE(plume_verify_batch_device(ctx, 1, a.n, am.p, (const uint64_t*)ao.p, a.msgs.size(), apk.p, an.p, ac.p, as.p, ar.p, ah.p, aok.p, s1) == 0);
+            REQUIRE(plume_verify_batch_device(ctx, 2, b.n, bm.p, (const uint64_t*)bo.p, b.msgs.size(), bpk.p, bn.p, bc.p, bs.p, nullptr, nullptr, bok.p, s2) == 0);
+            REQUIRE(plume_verify_non_zk_batch_device(ctx, 1, a.n, am.p, (const uint64_t*)ao.p, a.msgs.size(), apk.p, an.p, as.p, ar.p, ah.p, ac.p, aok2.p, nullptr) == 0);
+            REQUIRE(plume_verify_batch_device(ctx, 1, (size_t)1 << 30, am.p, (const uint64_t*)ao.p, a.msgs.size(), apk.p, an.p, ac.p, as.p, ar.p, ah.p, aok.p, s1) != 0);       // more than a chunk
+            std::vector<uint8_t> ra(a.n), rb(b.n), ra2(a.n);
+            REQUIRE(hipMemcpyAsync(rb.data(), bok.p, b.n, hipMemcpyDeviceToHost, s2) == hipSuccess);       // pageable destination: blocks until s2 got there
+            REQUIRE(hipMemcpyAsync(ra.data(), aok.p, a.n, hipMemcpyDeviceToHost, s1) == hipSuccess);
+            REQUIRE(hipMemcpyAsync(ra2.data(), aok2.p, a.n, hipMemcpyDeviceToHost, nullptr) == hipSuccess);   // NULL = the context's stream in the call; here the null stream ...
+            REQUIRE(ra == a.ok_expect && rb == b.ok_expect);
+            float ms[16]; const char* names[16]; int nst = plume_last_stage_times(ctx, names, ms, 16);                            // ... so wait for the context's last call through its own API
+            (void)nst;
+            REQUIRE(hipMemcpy(ra2.data(), aok2.p, a.n, hipMemcpyDeviceToHost) == hipSuccess);
+            REQUIRE(ra2 == a.ok_nonzk_expect);
+        }
+    }
+    {
+        g_what = "device-resident sign, then destroy with the call still queued";
+        REQUIRE(plume_set_in_flight(ctx, 1) == 0);
+        const Batch& q = b;
+        DevArr m(q.msgs.data(), q.msgs.size()), o(q.off.data(), 8 * (q.n + 1)), sk(q.sk.data(), 32 * q.n), r(q.r.data(), 32 * q.n), pk(nullptr, 64 * q.n), nul(nullptr, 64 * q.n), c(nullptr, 32 * q.n), s(nullptr, 32 * q.n),
+            rpt(nullptr, 64 * q.n), hr(nullptr, 64 * q.n), st(nullptr, q.n);
+        REQUIRE(plume_sign_batch_device(ctx, 2, q.n, m.p, (const uint64_t*)o.p, q.msgs.size(), sk.p, r.p, nullptr, pk.p, nul.p, c.p, s.p, rpt.p, hr.p, st.p, s1) == 0);
+        plume_destroy(ctx);                                   // has to wait for the call on s1: its workspace is what the queued kernels write
+        REQUIRE(hipStreamSynchronize(s1) == hipSuccess);
+        std::vector<uint8_t> got(64 * q.n), es(32 * q.n), enul(64 * q.n), d1(64 * q.n), d2(32 * q.n), d3(64 * q.n), d4(64 * q.n), d5(64 * q.n), d6(q.n);
+        oracle_sign_batch(2, q.n, q.msgs.data(), q.off.data(), q.sk.data(), q.r.data(), nullptr, d1.data(), enul.data(), d2.data(), es.data(), d3.data(), d4.data(), d5.data(), d6.data(), 4);
+        REQUIRE(hipMemcpy(got.data(), nul.p, 64 * q.n, hipMemcpyDeviceToHost) == hipSuccess && got == enul);
+        got.resize(32 * q.n);
+        REQUIRE(hipMemcpy(got.data(), s.p, 32 * q.n, hipMemcpyDeviceToHost) == hipSuccess && got == es);
+    }
+    REQUIRE(hipStreamDestroy(s1) == hipSuccess && hipStreamDestroy(s2) == hipSuccess);
+}
+
+static void group_misc(uint64_t seed) {
+    plume_ctx* ctx = nullptr;
+    REQUIRE(plume_init(&ctx, 7) == 0);
+    Knobs k; k.piece = 32; k.first = 8; k.tail = 8;
+    apply(ctx, k);
+    const Batch clean = make_batch(1, 75 + seed % 4, false), spoiled = make_batch(1, 50, true), v2 = make_batch(2, 33, false), empty = make_batch(1, 0, false);
+    g_what = "aggregate check, one device";
+    for (int mk : {0, 1}) { check_aggregate(ctx, clean, mk, 0); check_aggregate(ctx, clean, mk, 1); check_aggregate(ctx, spoiled, mk, 0); check_aggregate(ctx, v2, mk, 1); check_aggregate(ctx, empty, mk, 0); }
+    g_what = "hash_to_curve, DER, first occurrences, one device";
+    check_h2c_and_friends(ctx, clean, 0);
+    check_h2c_and_friends(ctx, v2, 1);
+    check_h2c_and_friends(ctx, empty, 0);
+    g_what = "two contexts on one device share the generator's tables; the first to go leaves them to the other";
+    plume_ctx* other = nullptr;
+    REQUIRE(plume_init(&other, 7) == 0);
+    check_verify(other, v2, 0);
+    plume_destroy(ctx);
+    check_verify(other, clean, 1);
+    check_sign(other, v2, 0, false);
+    plume_destroy(other);
+    plume_destroy(nullptr);
+}
+
+int main(int argc, char** argv) {
+    const std::string group = argc > 1 ? argv[1] : "all";
+    const uint64_t seed = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 1;
+    rng.seed(seed * 0x9E3779B97F4A7C15ull + 12345);
+    std::printf("%s\n", plume_version());
+    if (group == "verify" || group == "all") group_verify(seed);
+    if (group == "sign" || group == "all") group_sign(seed);
+    if (group == "multi" || group == "all") group_multi(seed);
+    if (group == "device" || group == "all") group_device(seed);
+    if (group == "misc" || group == "all") group_misc(seed);
+    // everything the library took from the runtime has gone back
+    g_what = "leak check";
+    REQUIRE(mockhip::outstanding(0) == 0);
+    REQUIRE(mockhip::outstanding(1) == 0);
+    REQUIRE(mockhip::outstanding(2) == 0);
+    REQUIRE(mockhip::outstanding(3) == 0);
+    long ops = 0, other = 0;
+    for (int d = 0; d < 8; d++) { ops += mockhip::ops_run(d, false); other += mockhip::ops_run(d, true); }
+    std::printf("pipeline_driver %s seed %llu: ok (%ld queued operations run, %ld of them pulled in through an event dependency)\n", group.c_str(), (unsigned long long)seed, ops, other);
+    return 0;
+}

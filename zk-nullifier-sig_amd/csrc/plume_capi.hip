@@ -75,7 +75,8 @@ struct StageTimer {
     std::vector<const char*> names;
     std::vector<hipEvent_t> ev;   // ev[0] start, ev[i+1] after stage i
     size_t used = 0;
-    void begin(hipStream_t st) { names.clear(); used = 0; mark(st); }
+    uint64_t runs = 0;            // calls that started a timeline here, i.e. put work on this context (Route)
+    void begin(hipStream_t st) { runs++; names.clear(); used = 0; mark(st); }
     void mark(hipStream_t st) {
         if (used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev.push_back(e); }
         (void)hipEventRecord(ev[used++], st);
@@ -110,11 +111,13 @@ struct Worker {
 // Round 4: each table is built by the first call that needs it (need_gtab: verify, verify_non_zk; need_gcomb: sign, SEC1-DER export, the aggregate check), so a
 // verify-only process never holds the comb, a sign-only one never the 1 GiB window table, and plume_init itself allocates neither.
 struct FixedTables {
+    std::mutex m;                 // the tables of ONE device: their build (18 ms, synchronous) holds this lock, not the process-wide one -- the shards of a multi-device context
+                                  // build theirs side by side (the CPU pipeline harness showed eight shards' first call queueing behind one lock: tests/hostsim)
     DevBuf gtab, gcomb, gscan;
-    int refs = 0;
+    int refs = 0;                 // under g_fixed_mutex
     bool gtab_built = false, gcomb_built = false, gscan_built = false;
 };
-static std::mutex g_fixed_mutex;
+static std::mutex g_fixed_mutex;                 // the map and the reference counts.  Lock order: g_fixed_mutex, then a device's FixedTables::m
 static std::map<int, FixedTables> g_fixed;
 
 struct plume_ctx {
@@ -193,14 +196,31 @@ static int bind(plume_ctx* ctx) {
 // context the CALLER holds before the call is dealt out: NULL means "that context's own stream" whichever lane serves the call, so successive NULL-stream calls stay
 // ordered against each other (a sign followed by a verify of its outputs) exactly as they are without lanes.  (Round 3 resolved NULL after routing, i.e. to the lane's
 // private stream, which changes from call to call: ADVICE r3.)  A lane's workspace is guarded by its ws_free event, so running it on a stream it does not own is safe.
-static plume_ctx* route(plume_ctx* ctx, void* stream, hipStream_t& st) {
-    st = stream ? (hipStream_t)stream : (ctx ? ctx->stream : nullptr);
-    if (!ctx || ctx->lanes.empty()) { if (ctx) ctx->lane_last = ctx; return ctx; }
-    const size_t k = ctx->lanes.size() + 1, i = ctx->lane_next++ % k;
-    plume_ctx* t = i == 0 ? ctx : ctx->lanes[i - 1];
-    ctx->lane_last = t;
-    return t;
-}
+struct Route {
+    plume_ctx* held;           // the context the caller holds
+    plume_ctx* lane;           // the lane that serves this call
+    hipStream_t st;
+    size_t next0 = 0;
+    plume_ctx* last0 = nullptr;
+    uint64_t epoch0 = 0;
+    Route(plume_ctx* ctx, void* stream) : held(ctx), lane(ctx) {
+        st = stream ? (hipStream_t)stream : (ctx ? ctx->stream : nullptr);
+        if (!ctx) return;
+        next0 = ctx->lane_next; last0 = ctx->lane_last;
+        if (!ctx->lanes.empty()) {
+            const size_t k = ctx->lanes.size() + 1, i = ctx->lane_next++ % k;
+            lane = i == 0 ? ctx : ctx->lanes[i - 1];
+        }
+        ctx->lane_last = lane;
+        epoch0 = lane->timer.runs;
+    }
+    Route(const Route&) = delete;
+    Route& operator=(const Route&) = delete;
+    // A call that is refused before it starts its lane's stage timeline (an argument check, n above the chunk size, an empty batch) never happened as far as the lanes are concerned:
+    // it neither takes a turn nor becomes "the last device-resident call" that plume_last_stage_times / plume_last_redo_tasks report.  (Found by the CPU pipeline harness,
+    // tests/hostsim: a refused call moved lane_last to a lane that had run nothing, and the stage times read afterwards -- and the wait they imply -- were another call's.)
+    ~Route() { if (held && lane->timer.runs == epoch0) { held->lane_next = next0; held->lane_last = last0; } }
+};
 // Workspace ordering for the device-resident entry points: every call leaves ws_free behind its last kernel, and the next call's stream
 // waits on it first.  Calls on one stream are ordered anyway; this makes calls on DIFFERENT streams of one context safe too.
 static int ws_acquire(plume_ctx* ctx, hipStream_t st) {
@@ -253,6 +273,7 @@ static void destroy_single(plume_ctx* ctx) {
     for (DevBuf& b : ctx->agg) b.release();
     if (ctx->fixed) {
         std::lock_guard<std::mutex> lk(g_fixed_mutex);
+        std::lock_guard<std::mutex> lk2(ctx->fixed->m);
         if (--ctx->fixed->refs == 0) {           // every context that could read the tables has waited for its own last call on its way here: nothing is still running
             ctx->fixed->gtab.release(); ctx->fixed->gcomb.release(); ctx->fixed->gscan.release(); ctx->fixed->gtab_built = ctx->fixed->gcomb_built = ctx->fixed->gscan_built = false;
         }
@@ -324,8 +345,8 @@ static int init_single(plume_ctx* ctx) {
 // The generator's tables, built once per device and process on the first call that needs them, one entry per lane (k_fixed_bases + k_fixed_table), under the lock: contexts
 // that meet here side by side (plume_init_multi's shards, a second batch in flight) wait for the first one's build.  The build is synchronous (18 ms for both, once).
 static int need_fixed(plume_ctx* ctx, bool gtab, bool gcomb, bool gscan = false) {
-    std::lock_guard<std::mutex> lk(g_fixed_mutex);
     FixedTables& ft = *ctx->fixed;
+    std::lock_guard<std::mutex> lk(ft.m);
     const bool bt = gtab && !ft.gtab_built, bc = gcomb && !ft.gcomb_built, bs = gscan && !ft.gscan_built;
     if (!bt && !bc && !bs) return 0;
     if ((bt && ft.gtab.ensure((size_t)PLUME_GTAB_WORDS * 4)) || (bc && ft.gcomb.ensure((size_t)PLUME_COMB_WORDS * 4)) || (bs && ft.gscan.ensure((size_t)PLUME_GSCAN_WORDS * 4))) {
@@ -806,7 +827,7 @@ static int args_ok(int version, size_t n, const void* msgs, const void* off) {
 extern "C" int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                          const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point,
                                          const uint8_t* hashed_to_curve_r, uint8_t* ok, void* stream) {
-    hipStream_t st_; ctx = route(ctx, stream, st_);
+    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk || !nullifier || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
@@ -819,7 +840,7 @@ extern "C" int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n, 
 extern "C" int plume_verify_non_zk_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                                 const uint8_t* pk, const uint8_t* nullifier, const uint8_t* s, const uint8_t* r_point,
                                                 const uint8_t* hashed_to_curve_r, const uint8_t* digest_private, uint8_t* ok, void* stream) {
-    hipStream_t st_; ctx = route(ctx, stream, st_);
+    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk || !nullifier || !s || !r_point || !hashed_to_curve_r || !digest_private || !ok)) return fail(PLUME_ERR_ARG, "null array");
@@ -854,7 +875,7 @@ static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8
 extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                               const uint8_t* pk33, const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s, const uint8_t* r_point33,
                                               const uint8_t* hashed_to_curve_r33, uint8_t* ok, void* stream) {
-    hipStream_t st_; ctx = route(ctx, stream, st_);
+    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk33 || !nullifier33 || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
@@ -865,7 +886,7 @@ extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_
 extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
                                        const uint8_t* r, const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point,
                                        uint8_t* hashed_to_curve_r, uint8_t* status, void* stream) {
-    hipStream_t st_; ctx = route(ctx, stream, st_);
+    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
@@ -876,7 +897,7 @@ extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, co
 extern "C" int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
                                             const uint8_t* r, const uint8_t* pk_in, uint8_t* pk33, uint8_t* nullifier33, uint8_t* c, uint8_t* s, uint8_t* r_point33,
                                             uint8_t* hashed_to_curve_r33, uint8_t* status, void* stream) {
-    hipStream_t st_; ctx = route(ctx, stream, st_);
+    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier33 || !c || !s || !r_point33 || !hashed_to_curve_r33 || !status)) return fail(PLUME_ERR_ARG, "null array");
@@ -898,7 +919,7 @@ static int h2c_only_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const 
 }
 extern "C" int plume_hash_to_curve_batch_device(plume_ctx* ctx, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
                                                 uint8_t* h_out, void* stream) {
-    hipStream_t st_; ctx = route(ctx, stream, st_);
+    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     return h2c_only_device(ctx, n, msgs, msg_off, msgs_bytes, pk, h_out, st_);
 }
 
@@ -942,11 +963,11 @@ static int der_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t*
     return hold.release();
 }
 extern "C" int plume_scalars_to_sec1_der_batch_device(plume_ctx* ctx, size_t n, const uint8_t* scalars, uint8_t* der109, uint8_t* status, void* stream) {
-    hipStream_t st_; ctx = route(ctx, stream, st_);
+    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     return der_device(ctx, n, scalars, der109, status, st_);
 }
 extern "C" int plume_registers_from_be_device(plume_ctx* ctx, size_t nvalues, const uint8_t* be32, uint64_t* registers, void* stream) {
-    hipStream_t st_; ctx = route(ctx, stream, st_);
+    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (nvalues && (!be32 || !registers)) return fail(PLUME_ERR_ARG, "null array");
     if (nvalues == 0) return 0;
@@ -1064,7 +1085,7 @@ static const uint8_t* agg_seed(const uint8_t* seed, uint8_t drawn[32]) {      //
 extern "C" int plume_aggregate_check_device(plume_ctx* ctx, int version, int mode, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* pk,
                                             const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point, const uint8_t* hashed_to_curve_r,
                                             const uint8_t seed[32], uint64_t index_base, uint8_t* hash_ok, uint8_t* result, void* stream) {
-    hipStream_t st_; ctx = route(ctx, stream, st_);
+    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = agg_args_ok(version, mode, n, msgs, msg_off, seed)) return rc;
     if (!result || (n && (!pk || !nullifier || !c || !s || !r_point || !hashed_to_curve_r))) return fail(PLUME_ERR_ARG, "null array");
@@ -1097,7 +1118,7 @@ static int dedup_device(plume_ctx* ctx, size_t n, const uint8_t* nul, const uint
 }
 extern "C" int plume_nullifier_first_occurrence_device(plume_ctx* ctx, size_t n, const uint8_t* nullifier, const uint8_t* live, const uint64_t* ids, uint8_t* first,
                                                        uint64_t* n_unique, void* stream) {
-    hipStream_t st_; ctx = route(ctx, stream, st_);
+    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (n && (!nullifier || !first)) return fail(PLUME_ERR_ARG, "null array");
     return dedup_device(ctx, n, nullifier, live, ids, first, n_unique, st_);
