@@ -85,6 +85,7 @@ extern "C" {
     fn plume_set_sign_uniform(ctx: *mut plume_ctx, level: c_int) -> c_int;
     fn plume_get_sign_uniform(ctx: *const plume_ctx) -> c_int;
     fn plume_set_host_lanes(ctx: *mut plume_ctx, lanes: c_int) -> c_int;
+    fn plume_set_stage_timing(ctx: *mut plume_ctx, on: c_int) -> c_int;
     fn plume_set_eq1_short(ctx: *mut plume_ctx, mode: c_int) -> c_int;
     fn plume_shard_numa_node(ctx: *const plume_ctx, shard: c_int) -> c_int;
     fn plume_aggregate_check(ctx: *mut plume_ctx, version: c_int, mode: c_int, n: usize, msgs: *const u8, msg_off: *const u64, pk: *const u8, nullifier: *const u8, c: *const u8,
@@ -289,6 +290,8 @@ impl HipEngine {
     /// The level this context signs at (`plume_get_sign_uniform`).
     pub fn sign_uniform(&self) -> Result<i32, HipError> { let l = unsafe { plume_get_sign_uniform(self.0) }; if l >= 0 { Ok(l as i32) } else { Err(last_error()) } }
     /// Host-pointer calls: 1 = every piece on the context itself, 2 (default) = pieces alternate between the context and a second lane.
+    /// per-stage timing events inside the device pipelines: off by default (library 0.5); turn on before a call whose `last_stage_times` are wanted
+    pub fn set_stage_timing(&self, on: bool) -> Result<(), HipError> { if unsafe { plume_set_stage_timing(self.0, on as c_int) } == 0 { Ok(()) } else { Err(last_error()) } }
     pub fn set_host_lanes(&self, lanes: i32) -> Result<(), HipError> { if unsafe { plume_set_host_lanes(self.0, lanes as c_int) } == 0 { Ok(()) } else { Err(last_error()) } }
     /// The signer's schedule (`plume_set_sign_uniform`).  k256's multiplication is constant-time, so the library's default is level 1 (no branch on a digit of `sk` or `r` in
     /// the kernels that walk them; table rows still gathered at digit-dependent addresses).  0 = fastest, not uniform; 2 = no secret-dependent address either (every row of a

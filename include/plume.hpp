@@ -66,6 +66,7 @@ class Engine {
     // them, 2 = and no table address derived from one -- the property k256's constant-time multiplication has (rust-k256/src/randomizedsigner.rs:51-70 multiplies by secrets).
     void set_sign_uniform(int level) { check(plume_set_sign_uniform(ctx_, level), "plume_set_sign_uniform"); }
     int sign_uniform() const { const int l = plume_get_sign_uniform(ctx_); check(l < 0 ? l : 0, "plume_get_sign_uniform"); return l; }   // 1 by default (library 0.4)
+    void set_stage_timing(bool on) { check(plume_set_stage_timing(ctx_, on ? 1 : 0), "plume_set_stage_timing"); }   // off by default (library 0.5): needed before last_stage_times
     void set_host_lanes(int lanes) { check(plume_set_host_lanes(ctx_, lanes), "plume_set_host_lanes"); }
     void set_eq1_short(int mode) { check(plume_set_eq1_short(ctx_, mode), "plume_set_eq1_short"); }   // the verifier's first equation where R is given (plume_hip.h): 1 short (default), 0 long, 2 test
     // the engine single-item calls use when none is passed: PLUME_DEVICES="0,1,.." (one multi-device context) or device 0

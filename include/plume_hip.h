@@ -69,7 +69,7 @@ int plume_shard_numa_node(const plume_ctx* ctx, int shard);
 void plume_destroy(plume_ctx* ctx);
 /* Last error text of this thread (valid until the next failing call on the thread). */
 const char* plume_last_error(void);
-/* Library / build information: "plume_hip <major.minor> gfx950 build=<hash of the device sources>".  0.4 (round 5): plume_get_sign_uniform, plume_set_host_lanes, plume_set_eq1_short;
+/* Library / build information: "plume_hip <major.minor> gfx950 build=<hash of the device sources>".  0.5 (round 5): plume_set_stage_timing, stage events off by default; 0.4 (round 5): plume_get_sign_uniform, plume_set_host_lanes, plume_set_eq1_short;
  * the signer defaults to uniform level 1; the generator tables are built by the first call that needs them; stream = NULL means the stream of the context the caller
  * holds; plume_destroy waits for the context's own work only (its last call on any stream and its private streams), not for the whole device. */
 const char* plume_version(void);
@@ -366,6 +366,11 @@ int plume_aggregate_check_device(plume_ctx* ctx, int version, int mode, size_t n
  * the stream the kernels were launched on.  Fills up to `cap` entries: names[i] (static strings) and ms[i];
  * returns the number of stages, or a negative error.  Synchronises the recorded events. */
 int plume_last_stage_times(plume_ctx* ctx, const char** names, float* ms, int cap);
+/* The events behind plume_last_stage_times are recorded only on request (library 0.5; always before): a timing event between two kernels of a stream leaves the GPU idle
+ * for about 6 us (rocprofv3 kernel trace of back-to-back 2^16-item verifies: 6.1 +- 0.2 us at each of the five stage boundaries, 0.0-0.2 us between kernels with no event
+ * in between) -- 2 % of a 2^16-item call, 0.2 % of a 2^20-item one.  on = 1 before the call to be timed; env PLUME_STAGE_TIMES=1 sets the default of new contexts.  With
+ * timing off plume_last_stage_times returns PLUME_ERR_ARG. */
+int plume_set_stage_timing(plume_ctx* ctx, int on);
 /* Measurement / test hook: the number of multi-scalar tasks (two per item) of the last verify call on this context whose unchecked addition chain met p == +-q and that
  * the second, dense launch redid with checked additions (k_verify_msm_redo).  Honest batches: 0.  Crafted items (pk = +-k G for small k with s = +-c, ...) file one or two
  * tasks each: that is all they cost -- their wavefront neighbours no longer wait for them.  Counts the last device-resident call (for a host-pointer call: its last piece;

@@ -77,7 +77,7 @@ def _load():
     lib.plume_set_in_flight.argtypes = [C.c_void_p, C.c_int]
     # later entry points: an older build selected through PLUME_HIP_LIB (A/B runs against an earlier round) may lack them; the in-tree library must have them all (checked below)
     for name, args in (("plume_set_sign_uniform", [C.c_void_p, C.c_int]), ("plume_get_sign_uniform", [C.c_void_p]), ("plume_set_host_lanes", [C.c_void_p, C.c_int]),
-                       ("plume_set_eq1_short", [C.c_void_p, C.c_int])):
+                       ("plume_set_eq1_short", [C.c_void_p, C.c_int]), ("plume_set_stage_timing", [C.c_void_p, C.c_int])):
         fn = getattr(lib, name, None)
         if fn is not None:
             fn.argtypes = args
@@ -113,15 +113,15 @@ def _load():
     lib.plume_aggregate_check_device.argtypes = [vp, i, i, sz, vp, vp, sz] + [vp] * 7 + [C.c_uint64, vp, vp, vp]
     _lib = lib
     ver = tuple(int(x) for x in lib.plume_version().decode().split()[1].split(".")[:2])
-    if ver < (0, 4) and not os.environ.get("PLUME_HIP_LIB"):
+    if ver < (0, 5) and not os.environ.get("PLUME_HIP_LIB"):
         _lib = None
-        raise PlumeHipError(f"{p} is {lib.plume_version().decode()}: this module needs plume_hip >= 0.4 (rebuild: make -C zk-nullifier-sig_amd/csrc)")
+        raise PlumeHipError(f"{p} is {lib.plume_version().decode()}: this module needs plume_hip >= 0.5 (rebuild: make -C zk-nullifier-sig_amd/csrc)")
     return lib
 
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_set_in_flight", "plume_set_sign_uniform", "plume_get_sign_uniform", "plume_set_host_lanes", "plume_set_eq1_short", "plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
+    return ["plume_set_stage_timing", "plume_set_in_flight", "plume_set_sign_uniform", "plume_get_sign_uniform", "plume_set_host_lanes", "plume_set_eq1_short", "plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
             "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars", "plume_sec1_der_to_scalars_checked",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
@@ -538,7 +538,16 @@ class Engine:
                   "plume_nullifier_first_occurrence_device")
 
     # ------------------------------------------------------------------ measurement
+    def set_stage_timing(self, on):
+        """per-stage timing events inside the device pipelines (plume_set_stage_timing): OFF by default since library 0.5 -- an event between two kernels costs ~6 us of idle
+        GPU, five or six per call.  Env PLUME_STAGE_TIMES=1 turns it on for new contexts."""
+        fn = getattr(self._lib, "plume_set_stage_timing", None)
+        if fn is None:
+            return                                   # an older library (PLUME_HIP_LIB): always on
+        self._chk(fn(self._ctx, 1 if on else 0), "plume_set_stage_timing")
+
     def last_stage_times(self):
+        """(stage, ms) of the last device-resident call; needs set_stage_timing(True) (or PLUME_STAGE_TIMES=1) BEFORE that call"""
         cap = 512
         names = (C.c_char_p * cap)()
         ms = (C.c_float * cap)()

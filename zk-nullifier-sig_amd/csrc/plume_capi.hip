@@ -76,12 +76,14 @@ struct StageTimer {
     std::vector<hipEvent_t> ev;   // ev[0] start, ev[i+1] after stage i
     size_t used = 0;
     uint64_t runs = 0;            // calls that started a timeline here, i.e. put work on this context (Route)
-    void begin(hipStream_t st) { runs++; names.clear(); used = 0; mark(st); }
+    bool on = false;              // plume_set_stage_timing: a timing event between two kernels of a stream costs ~6 us of idle GPU (rocprofv3 trace of 2^16-item calls, round 5:
+                                  // kernels without an event between them follow each other within 0.2 us), five or six per call -- 2 % of a 2^16-item verify, so only on request
+    void begin(hipStream_t st) { runs++; names.clear(); used = 0; if (on) mark(st); }
     void mark(hipStream_t st) {
         if (used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev.push_back(e); }
         (void)hipEventRecord(ev[used++], st);
     }
-    void stage(const char* name, hipStream_t st) { names.push_back(name); mark(st); }
+    void stage(const char* name, hipStream_t st) { if (!on) return; names.push_back(name); mark(st); }
     void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); }
 };
 
@@ -178,6 +180,7 @@ static void inherit_tunables(plume_ctx* to, const plume_ctx* from) {
     to->jobs_per_lane = from->jobs_per_lane; to->jobs_per_lane_forced = from->jobs_per_lane_forced;
     to->host_piece = from->host_piece; to->host_first_piece = from->host_first_piece; to->host_tail_piece = from->host_tail_piece; to->host_register_min = from->host_register_min;
     to->host_lanes = from->host_lanes; to->host_sign_lanes = from->host_sign_lanes; to->eq1_short = from->eq1_short; to->eq1_short_min = from->eq1_short_min;
+    to->timer.on = from->timer.on;
 }
 // after a setter changed `ctx`: hand the change to every context derived from it (shards and their derived contexts, in-flight lanes, the host pipeline's second lane)
 static void propagate_tunables(plume_ctx* ctx) {
@@ -255,7 +258,7 @@ extern "C" const char* plume_last_error(void) { return g_err.c_str(); }
 #ifndef PLUME_BUILD_ID
 #define PLUME_BUILD_ID "unknown"
 #endif
-extern "C" const char* plume_version(void) { return "plume_hip 0.4 gfx950 build=" PLUME_BUILD_ID; }
+extern "C" const char* plume_version(void) { return "plume_hip 0.5 gfx950 build=" PLUME_BUILD_ID; }
 
 static void destroy_single(plume_ctx* ctx) {
     for (plume_ctx* l : ctx->lanes) destroy_single(l);
@@ -311,6 +314,7 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_EQ1_SHORT")) { int v = std::atoi(e); if (v >= 0 && v <= 3) ctx->eq1_short = v; }   // A/B and test knob (plume_eis.h)
     if (const char* e = std::getenv("PLUME_EQ1_SHORT_MIN")) { long v = std::atol(e); if (v >= 0) ctx->eq1_short_min = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_SIGN_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_sign_lanes = v; }
+    if (const char* e = std::getenv("PLUME_STAGE_TIMES")) ctx->timer.on = std::atoi(e) != 0;   // default of new contexts (plume_set_stage_timing)
     if (const char* e = std::getenv("PLUME_HOST_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_lanes = v; }   // 1 = the one-lane host-pointer pipeline of rounds 1-3 (A/B)
     // The runtime multiplexes a process's streams onto a few hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES, 4 by default), and two streams that share a queue wait for
     // each other's packets -- event records and waits included.  Seen in the round-5 pipeline timelines (PLUME_HOST_TRACE): with two lanes, a finished piece's download waited
@@ -626,6 +630,14 @@ extern "C" int plume_set_in_flight(plume_ctx* ctx, int batches) {
         ctx->lanes.push_back(l);
     }
     ctx->lane_next = 0; ctx->lane_last = nullptr;
+    return 0;
+}
+
+// per-stage timing events inside the device pipelines (plume_last_stage_times); off by default
+extern "C" int plume_set_stage_timing(plume_ctx* ctx, int on) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "plume_set_stage_timing: null context");
+    ctx->timer.on = on != 0;
+    propagate_tunables(ctx);
     return 0;
 }
 
@@ -1664,6 +1676,7 @@ extern "C" int plume_last_stage_times(plume_ctx* ctx, const char** names, float*
     if (ctx && ctx->lane_last) ctx = ctx->lane_last;           // ... a context with batches in flight the lane of its last device-resident call
     if (int rc = bind(ctx)) return rc;
     StageTimer& t = ctx->timer;
+    if (!t.on) return fail(PLUME_ERR_ARG, "stage timing is off: plume_set_stage_timing(ctx, 1) (or env PLUME_STAGE_TIMES=1) before the call to be timed");
     const int ns = (int)t.names.size();
     if (t.used < (size_t)ns + 1) return fail(PLUME_ERR_ARG, "no timed call recorded");
     for (int i = 0; i < ns && i < cap; i++) {
