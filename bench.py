@@ -36,6 +36,10 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# Every context this script creates records the per-stage timing events (off by default in the library since 0.5: ~6 us of idle GPU each): roofline.kernel_ms is the
+# multi-scalar kernel's duration by HIP events over the timed region, as the contract asks -- so `value` carries their cost (0.2 % at 2^20); the 2^16 entry also
+# reports the default, event-free call (other_workloads.verify_v1_2p16.ms_per_batch).
+os.environ.setdefault("PLUME_STAGE_TIMES", "1")
 sys.path.insert(0, str(ROOT))
 
 BYTES_PER_ITEM = {1: 353, 2: 225}                 # SURVEY.md §8d / BASELINE.md §4 (in + out)
@@ -440,15 +444,25 @@ def small_batch_entry(eng, dev, log2n=16):
     off, ok = t(v["off"].view(np.int64)), torch.zeros(n, dtype=torch.uint8, device=dev)
     mb = int(v["off"][-1])
     fn = lambda: eng.verify_batch_device(1, n, d["msgs"], off, mb, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], ok)  # noqa: E731
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
     reps = 20
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+
+    def timed():
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    # the library's default first: no timing events between the kernels (plume_set_stage_timing; each costs ~6 us of idle GPU, 2 % of a call this size) ...
+    eng.set_stage_timing(False)
+    try:
+        dt = timed()
+    finally:
+        eng.set_stage_timing(True)
+    # ... then the same calls with the stage events this script reads everywhere else
+    dt_ev = timed()
     assert bool((ok.cpu() == torch.from_numpy(synth.expected_ok(n))).all())
     stages = {k: round(x, 4) for k, x in eng.last_stage_times()}
     # The same calls with TWO batches in flight: two lanes of the context (plume_set_in_flight) on two streams, calls alternating.  A 2^16 batch leaves most SIMDs one or two
@@ -471,7 +485,8 @@ def small_batch_entry(eng, dev, log2n=16):
     finally:
         eng.set_in_flight(1)
     assert bool((ok2.cpu() == torch.from_numpy(synth.expected_ok(n))).all()) and bool((ok.cpu() == torch.from_numpy(synth.expected_ok(n))).all())
-    return {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "stage_ms": stages,
+    return {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "ms_per_batch_with_stage_events": round(dt_ev * 1e3, 4), "stage_ms": stages,
+            "stage_events": "ms_per_batch: the library's default, no timing events inside the call; stage_ms and ms_per_batch_with_stage_events: plume_set_stage_timing(1), as everywhere else in this line",
             "workload": f"BASELINE.json configs[1]: 2^{log2n} V1 verifies per call, inputs resident in HBM, {reps} calls back to back",
             "two_batches_in_flight": {"items_per_s": round(n / dt2, 1), "ms_per_batch": round(dt2 * 1e3, 4),
                                       "note": "plume_set_in_flight(2), two streams, calls alternating: throughput with two small batches in flight, not one call's latency"}}

@@ -286,10 +286,12 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
         for (uint32_t i = 0; i < n; i++) verify_ingest_b2(x[i]);
         for (uint32_t i = 0; i < n; i++) verify_ingest_a2(a, i, x[i], stt[i]);
         for (uint32_t i = 0; i < n; i++) verify_ingest_a3(a, i, x[i], stt[i]);
+        a.scalars_in_ingest = 1;
+        for (uint32_t i = 0; i < n; i++) verify_scalars(a, i);            // role B's last duty in that kernel: no scalar launch of its own
     } else {
         for (uint32_t i = 0; i < n; i++) verify_ingest_h2c(a, i);
+        for (uint32_t i = 0; i < n; i++) verify_scalars(a, i);
     }
-    for (uint32_t i = 0; i < n; i++) verify_scalars(a, i);
     const size_t nj = J * (size_t)n;
     run_tables(a.tab, a.bases, a.jobflags, nj, L);
     std::vector<int8_t> dig((2 * PLUME_NDIG + PLUME_NPOS) * B);

@@ -32,6 +32,7 @@ void launch_verify_ingest(const VerifyArgs& a0, hipStream_t st, bool two_roles) 
     mockhip::launch(st, [a = a0] {                            // k_verify_ingest_split: roles A and B of 128 items per workgroup, meeting at two barriers
         constexpr uint32_t H = kBlock / 2;
         const unsigned nb = (a.n + H - 1) / H;
+        if (a.scalars_in_ingest) a.redo[0] = 0;
         std::vector<ingest_xch> x(H);
         std::vector<ingest_a_state> stt(H);
         for (unsigned blk = 0; blk < nb; blk++) {
@@ -41,6 +42,7 @@ void launch_verify_ingest(const VerifyArgs& a0, hipStream_t st, bool two_roles) 
             for (uint32_t l = 0; l < cnt; l++) verify_ingest_b2(x[l]);
             for (uint32_t l = 0; l < cnt; l++) verify_ingest_a2(a, blk * H + l, x[l], stt[l]);
             for (uint32_t l = 0; l < cnt; l++) verify_ingest_a3(a, blk * H + l, x[l], stt[l]);
+            if (a.scalars_in_ingest) for (uint32_t l = 0; l < cnt; l++) verify_scalars(a, blk * H + l);          // role B's last duty: the scalar stage
         }
     });
 }

@@ -359,6 +359,11 @@ static void group_device(uint64_t seed) {
     plume_ctx* ctx = nullptr;
     REQUIRE(plume_init(&ctx, 3) == 0);
     REQUIRE(hipSetDevice(3) == hipSuccess);
+    {   // stage timing is off by default: the hook says so instead of reporting stale times
+        float ms0[4]; const char* nm0[4];
+        REQUIRE(plume_last_stage_times(ctx, nm0, ms0, 4) == PLUME_ERR_ARG);
+        REQUIRE(plume_set_stage_timing(ctx, 1) == 0);
+    }
     const Batch a = make_batch(1, 130 + seed % 3, true), b = make_batch(2, 77, true);
     hipStream_t s1, s2;
     REQUIRE(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess);
@@ -381,8 +386,8 @@ static void group_device(uint64_t seed) {
             REQUIRE(hipMemcpyAsync(ra.data(), aok.p, a.n, hipMemcpyDeviceToHost, s1) == hipSuccess);
             REQUIRE(hipMemcpyAsync(ra2.data(), aok2.p, a.n, hipMemcpyDeviceToHost, nullptr) == hipSuccess);   // NULL = the context's stream in the call; here the null stream ...
             REQUIRE(ra == a.ok_expect && rb == b.ok_expect);
-            float ms[16]; const char* names[16]; int nst = plume_last_stage_times(ctx, names, ms, 16);                            // ... so wait for the context's last call through its own API
-            (void)nst;
+            float ms[16]; const char* names[16]; const int nst = plume_last_stage_times(ctx, names, ms, 16);                      // ... so wait for the context's last call through its own API
+            REQUIRE(nst >= 4);
             REQUIRE(hipMemcpy(ra2.data(), aok2.p, a.n, hipMemcpyDeviceToHost) == hipSuccess);
             REQUIRE(ra2 == a.ok_nonzk_expect);
         }

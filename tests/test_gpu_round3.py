@@ -229,6 +229,7 @@ def test_stage_times_serial_and_overlapped(eng):
     a = (1, n, t(b["msgs"]), t(b["off"].view(np.int64)), int(b["off"][-1]), t(sg["pk"]), t(sg["nullifier"]), t(sg["c"]), t(sg["s"]), t(sg["r_point"]), t(sg["hashed_to_curve_r"]), ok)
     try:
         eng.set_sub_batches(1)
+        eng.set_stage_timing(True)
         eng.verify_batch_device(*a); torch.cuda.synchronize()
         serial = dict(eng.last_stage_times())
         assert list(serial) == ["verify_ingest_h2c", "verify_scalars", "tables", "verify_msm", "verify_finalize"] and bool(ok.all())
@@ -240,6 +241,7 @@ def test_stage_times_serial_and_overlapped(eng):
         assert over["verify_overlapped"] < 1.25 * sum(serial.values())       # (measured: the overlapped order is 1-6 % slower than the serial one, LABNOTES.md §6)
     finally:
         eng.set_sub_batches(capi.DEFAULT_SUB_BATCHES)
+        eng.set_stage_timing(False)
 
 
 # ------------------------------------------------------------------------------------------- multi-GPU readiness
@@ -415,6 +417,7 @@ def test_batches_in_flight_do_not_change_results(eng):
     st = [torch.cuda.Stream(device=dev) for _ in range(3)]
     torch.cuda.synchronize()
     try:
+        eng.set_stage_timing(True)                               # (inherited by the lanes set_in_flight creates and by those that exist)
         for k in (2, 3):
             eng.set_in_flight(k)
             oks = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(k)]
@@ -436,6 +439,7 @@ def test_batches_in_flight_do_not_change_results(eng):
             eng.set_in_flight(0)
     finally:
         eng.set_in_flight(1)
+        eng.set_stage_timing(False)
     ok = torch.zeros(n, dtype=torch.uint8, device=dev)
     eng.verify_batch_device(1, n, t["msgs"], off, int(v["off"][-1]), t["pk"], t["nullifier"], t["c"], t["s"], t["r_point"], t["hashed_to_curve_r"], ok)
     torch.cuda.synchronize()

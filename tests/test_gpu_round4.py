@@ -128,6 +128,7 @@ from tests import synth, _fuzz
 n = 300_000
 b = synth.sign_inputs(n, start=41_000_000)
 eng = plume.Engine(0)
+eng.set_stage_timing(True)
 eng.set_host_first_piece(1 << 13); eng.set_host_piece(1 << 16)          # 8192, 24576, 65536, 65536, ...: seven pieces, both lanes busy
 signed = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
 v = _fuzz.fuzz_verify_batch(1, signed, b, seed=404)

@@ -250,3 +250,39 @@ def test_equation1_short_form_gives_the_long_forms_verdicts(eng, mode):
             assert not nz[idx].any() and int(nz.sum()) == n - len(idx)
     finally:
         eng.set_eq1_short(1)
+
+
+def test_stage_timing_is_opt_in_and_a_refused_call_takes_no_lane_turn(eng):
+    """Library 0.5: no timing events between the kernels unless asked for (plume_set_stage_timing) -- plume_last_stage_times then says so instead of returning stale times;
+    verdicts are the same either way.  And (found by the CPU pipeline harness, tests/hostsim): with two batches in flight a call REFUSED before it enqueued anything
+    (n above the chunk) must not become "the last call" whose stage times are reported."""
+    import torch
+    import zk_nullifier_sig_amd as plume
+    dev = torch.device("cuda:0")
+    n = 4096
+    b = synth.sign_inputs(n, start=77_000)
+    sg = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    v = synth.corrupt_for_verify(1, b, sg, start=77_000)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v[k])).to(dev) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+    off = torch.from_numpy(v["off"].view(np.int64)).to(dev)
+    exp = synth.expected_ok(n, 77_000)
+    call = lambda ok, cnt=n: eng.verify_batch_device(1, cnt, t["msgs"], off, int(v["off"][-1]), t["pk"], t["nullifier"], t["c"], t["s"], t["r_point"], t["hashed_to_curve_r"], ok)  # noqa: E731
+    ok0, ok1 = (torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(2))
+    call(ok0); torch.cuda.synchronize()
+    with pytest.raises(plume.PlumeHipError, match="stage timing is off"):
+        eng.last_stage_times()
+    try:
+        eng.set_stage_timing(True)
+        eng.set_in_flight(2)
+        call(ok1); torch.cuda.synchronize()
+        first = eng.last_stage_times()
+        assert [s for s, _ in first] == ["verify_ingest_h2c+scalars", "tables", "verify_msm", "verify_finalize"] and all(ms > 0 for _, ms in first)
+        eng.set_chunk(1024)
+        with pytest.raises(plume.PlumeHipError, match="chunk"):
+            call(ok1)                                                   # refused: 4096 items, chunk 1024
+        assert eng.last_stage_times() == first                        # still the call that ran, on the lane that ran it
+    finally:
+        eng.set_chunk(1 << 20)
+        eng.set_in_flight(1)
+        eng.set_stage_timing(False)
+    assert np.array_equal(ok0.cpu().numpy(), exp) and np.array_equal(ok1.cpu().numpy(), exp)

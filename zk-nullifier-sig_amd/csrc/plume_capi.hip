@@ -136,6 +136,7 @@ struct plume_ctx {
     hipEvent_t agg_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // terms ready / upper bucket sums ready / generator term ready / upper windows reduced
     hipEvent_t ws_free = nullptr;     // recorded behind the last kernel of every device-resident call: the next call's stream waits on it before it
     bool ws_used = false;             // touches the per-context workspace, so calls on DIFFERENT streams of one context cannot race on that scratch
+    hipStream_t ws_stream = nullptr;  // the stream ws_free was last recorded on
     size_t chunk = (size_t)1 << 20;
     size_t host_piece = (size_t)1 << 19;                            // host-pointer calls: largest pipelined piece
     size_t host_first_piece = (size_t)1 << 16;                      // ... the first piece (its upload is the only one no kernel hides); pieces then grow 3x per step
@@ -146,6 +147,7 @@ struct plume_ctx {
     std::vector<Worker*> workers;
     HostSlot slot[4];                                              // host-pointer calls: staging slots (two for the one-lane pipeline, four when two lanes take the pieces in turn)
     plume_ctx* host_lane = nullptr;                                // ... the second lane of the host-pointer pipeline: a complete single-device context (workspace, streams), created on first use
+    bool split_scalars = true;                                      // ... and the scalar stage in that kernel's idle role (env PLUME_SPLIT_SCALARS=0: a launch of its own, A/B)
     size_t ingest_split_max = (size_t)1 << 16;                     // verify calls (slices) of at most this many items run the ingest stage with two lanes per item (latency-bound there)
     int sign_uniform = 1;                                          // plume_set_sign_uniform: the signer's schedule (level 0, 1, 2).  Default 1 since round 5: no branch on a digit of sk or r
                                                                    // (k256's multiplication is constant-time, rust-k256/src/randomizedsigner.rs:51-70; measured price +2.5 % per signature)
@@ -176,7 +178,7 @@ struct plume_ctx {
 // knob cannot reach some derived contexts and miss others (round 4's host lane did not inherit sign_uniform: VERDICT r4).
 static void inherit_tunables(plume_ctx* to, const plume_ctx* from) {
     to->chunk = from->chunk; to->sub_batches = from->sub_batches; to->overlap_min = from->overlap_min; to->sign_uniform = from->sign_uniform;
-    to->ingest_split_max = from->ingest_split_max; to->msm_split_max = from->msm_split_max;
+    to->ingest_split_max = from->ingest_split_max; to->msm_split_max = from->msm_split_max; to->split_scalars = from->split_scalars;
     to->jobs_per_lane = from->jobs_per_lane; to->jobs_per_lane_forced = from->jobs_per_lane_forced;
     to->host_piece = from->host_piece; to->host_first_piece = from->host_first_piece; to->host_tail_piece = from->host_tail_piece; to->host_register_min = from->host_register_min;
     to->host_lanes = from->host_lanes; to->host_sign_lanes = from->host_sign_lanes; to->eq1_short = from->eq1_short; to->eq1_short_min = from->eq1_short_min;
@@ -227,12 +229,14 @@ struct Route {
 // Workspace ordering for the device-resident entry points: every call leaves ws_free behind its last kernel, and the next call's stream
 // waits on it first.  Calls on one stream are ordered anyway; this makes calls on DIFFERENT streams of one context safe too.
 static int ws_acquire(plume_ctx* ctx, hipStream_t st) {
-    if (ctx->ws_used) HIPCHK(hipStreamWaitEvent(st, ctx->ws_free, 0));
+    // (the previous call on the SAME stream is ordered by the stream itself: no wait packet between two calls of a stream of small calls -- each one is a few us of idle GPU)
+    if (ctx->ws_used && ctx->ws_stream != st) HIPCHK(hipStreamWaitEvent(st, ctx->ws_free, 0));
     return 0;
 }
 static int ws_release(plume_ctx* ctx, hipStream_t st) {
     HIPCHK(hipEventRecord(ctx->ws_free, st));
     ctx->ws_used = true;
+    ctx->ws_stream = st;
     return 0;
 }
 // Holds the workspace from a successful ws_acquire to the end of the call.  A call that fails half way (an allocation, a launch) must still leave ws_free behind
@@ -251,6 +255,7 @@ struct WsHold {
         if (ctx->pre) (void)hipStreamSynchronize(ctx->pre);
         (void)hipEventRecord(ctx->ws_free, st);
         ctx->ws_used = true;
+        ctx->ws_stream = st;
     }
 };
 
@@ -309,6 +314,7 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_HOST_FIRST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_first_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_TAIL_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_tail_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_SPLIT_SCALARS")) ctx->split_scalars = std::atoi(e) != 0;   // A/B knob
     if (const char* e = std::getenv("PLUME_INGEST_SPLIT_MAX")) { long v = std::atol(e); if (v >= 0) ctx->ingest_split_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::min(2, std::max(0, std::atoi(e)));   // default of new contexts (plume_set_sign_uniform); 0 opts out of the uniform schedule
     if (const char* e = std::getenv("PLUME_EQ1_SHORT")) { int v = std::atoi(e); if (v >= 0 && v <= 3) ctx->eq1_short = v; }   // A/B and test knob (plume_eis.h)
@@ -756,8 +762,10 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         }
         if (k == 0) ctx->redo_counters.clear();
         ctx->redo_counters.push_back(2 * lo + k);
-        launch_verify_ingest(a, pre, cnt <= ctx->ingest_split_max); if (!overlapped) t.stage("verify_ingest_h2c", st);
-        launch_verify_scalars(a, pre); if (!overlapped) t.stage("verify_scalars", st);
+        const bool two_roles = cnt <= ctx->ingest_split_max;
+        a.scalars_in_ingest = two_roles && ctx->split_scalars ? 1 : 0;             // the small-batch ingest kernel runs the scalar stage in its idle role: one launch less
+        launch_verify_ingest(a, pre, two_roles); if (!overlapped) t.stage(a.scalars_in_ingest ? "verify_ingest_h2c+scalars" : "verify_ingest_h2c", st);
+        if (!a.scalars_in_ingest) { launch_verify_scalars(a, pre); if (!overlapped) t.stage("verify_scalars", st); }
         table_stage(ctx, a.tab, a.bases, a.jobflags, J * cnt, 3 * cnt, pre); if (!overlapped) t.stage("tables", st);   // the table kernels of all sub-batches follow one another on one stream: one scratch
         if (overlapped) {
             HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));

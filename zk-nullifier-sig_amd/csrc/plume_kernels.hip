@@ -58,6 +58,9 @@ __global__ PLUME_H2C_BOUNDS void k_verify_ingest(VerifyArgs a) {
 
 // The ingest stage of small batches: two wavefront ROLES per item (plume_stages.h verify_ingest_a1..a3 / b1..b2).  A workgroup serves kBlock / 2 items: threads [0, 128) are
 // role A, [128, 256) role B of the same 128 items; what they hand each other goes through LDS word-major (conflict-free), with a workgroup barrier at each meeting.
+// Role B has nothing left to do after the second meeting while role A finishes the hash (a3): it runs the item's SCALAR stage there (verify_scalars: the window digits, the
+// short first equation's coefficients -- independent of everything the ingest stage computes), so that small calls have no k_verify_scalars launch: 20 us of kernel at one
+// wavefront per SIMD plus the launch's place in the queue, out of a 1.5 ms call of 2^16 items (round 5).
 __global__ PLUME_H2C_BOUNDS void k_verify_ingest_split(VerifyArgs a) {
     constexpr uint32_t H = kBlock / 2;
     __shared__ uint32_t s_u1[PLUME_FE_WORDS * H];
@@ -67,6 +70,7 @@ __global__ PLUME_H2C_BOUNDS void k_verify_ingest_split(VerifyArgs a) {
     const bool roleB = threadIdx.x >= H;                          // wave-uniform
     const uint32_t i = blockIdx.x * H + l;
     const bool live = i < a.n;
+    if (a.scalars_in_ingest && blockIdx.x == 0 && threadIdx.x == H) a.redo[0] = 0;          // (k_verify_scalars' other duty: the redo list of the multi-scalar launch behind this one starts empty)
     ingest_xch x;
     ingest_a_state st;
     if (live) {
@@ -88,6 +92,8 @@ __global__ PLUME_H2C_BOUNDS void k_verify_ingest_split(VerifyArgs a) {
     if (live && !roleB) {
         PLUME_UNROLL for (int k = 0; k < PLUME_FE_WORDS; k++) { x.xn.v[k] = s_q[k * H + l]; x.xd.v[k] = s_q[(PLUME_FE_WORDS + k) * H + l]; x.y.v[k] = s_q[(2 * PLUME_FE_WORDS + k) * H + l]; }
         verify_ingest_a3(a, i, x, st);
+    } else if (live && a.scalars_in_ingest) {
+        verify_scalars(a, i);
     }
 }
 
@@ -433,6 +439,7 @@ void launch_gather_probe(const uint32_t* tab, uint32_t nrows, int iters, uint32_
 static inline unsigned nblocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 void launch_verify_scalars(const VerifyArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_verify_scalars, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a); }
+// two_roles: the kernel also runs the scalar stage when a.scalars_in_ingest says so (no launch_verify_scalars for that call)
 void launch_verify_ingest(const VerifyArgs& a, hipStream_t st, bool two_roles) {
     if (two_roles) hipLaunchKernelGGL(k_verify_ingest_split, dim3((a.n + kBlock / 2 - 1) / (kBlock / 2)), dim3(kBlock), 0, st, a);   // two lanes per item: small batches
     else hipLaunchKernelGGL(k_verify_ingest, dim3(nblocks(a.n)), dim3(kBlock), 0, st, a);

@@ -11,7 +11,7 @@ constexpr int kBlock = 256;              // threads per workgroup: four wavefron
 constexpr int kTableJobsPerLane = 6;   // (measured r02, one box, final layout: 6 -> 2.11 ms, 9 -> 2.25, 12 -> 2.30, 18 -> 2.9, 24 -> 3.3 per 2^20 verifies; the Jacobian builder it replaced: 3.1 on boxes of that speed) multiple of 3: job kinds (pk, H, nullifier) then line up across the lanes of a wavefront
 
 void launch_verify_scalars(const VerifyArgs& a, hipStream_t st);                           // window digits of s and c; the short first equation's coefficients (plume_eis.h)
-void launch_verify_ingest(const VerifyArgs& a, hipStream_t st, bool two_roles = false);   // two_roles: the small-batch form, two lanes per item (k_verify_ingest_split)
+void launch_verify_ingest(const VerifyArgs& a, hipStream_t st, bool two_roles = false);   // two_roles: the small-batch form, two lanes per item (k_verify_ingest_split), which runs the scalar stage too when a.scalars_in_ingest is set: no launch_verify_scalars then
 // the window tables of njobs bases (plume_ec.h: rows P, theta P, 2P): pass A, one batched inversion, pass B.  scr: tables_scratch_bytes(njobs, jobs_per_lane) bytes
 size_t tables_scratch_bytes(size_t njobs, int jobs_per_lane);
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int jobs_per_lane, uint32_t* scr, hipStream_t st);

@@ -170,6 +170,7 @@ struct VerifyArgs {
                           //     s in the generator's wide digits): the half-GCD's coefficients did not fit (no such input is known) or the caller forces it (tests)
     uint32_t* eq1k;       // 8 x n words, word-major: k = tau s mod n, multiplied by G through the comb
     const uint32_t* gcomb;  // the doubling-free comb of G (PLUME_COMB_WORDS), shared with the signer
+    int scalars_in_ingest;   // the two-role ingest kernel (small calls) runs verify_scalars in its role B: no k_verify_scalars launch for this call (plume_kernels.hip)
     int eq1force;         // test knob: 1 = file every item's equation 1 as "long form" (everything then runs through the redo launch's checked chain)
 };
 // jobs: 3 per item (pk, H, nullifier) at 3i, 3i+1, 3i+2; in the short form a fourth, R, at 3n + i -- behind the others so that the job kinds of the first 3n stay aligned
