@@ -357,7 +357,9 @@ struct DevArr {
 };
 static void group_device(uint64_t seed) {
     plume_ctx* ctx = nullptr;
+    setenv("PLUME_SPLIT_SCALARS", "0", 1);                   // this context: the two-role ingest kernel WITHOUT the scalar stage in its idle role (the A/B form)
     REQUIRE(plume_init(&ctx, 3) == 0);
+    unsetenv("PLUME_SPLIT_SCALARS");
     REQUIRE(hipSetDevice(3) == hipSuccess);
     {   // stage timing is off by default: the hook says so instead of reporting stale times
         float ms0[4]; const char* nm0[4];
@@ -424,7 +426,9 @@ static void group_misc(uint64_t seed) {
     check_h2c_and_friends(ctx, empty, 0);
     g_what = "two contexts on one device share the generator's tables; the first to go leaves them to the other";
     plume_ctx* other = nullptr;
+    setenv("PLUME_INGEST_SPLIT_MAX", "20", 1);               // this context: calls of more than 20 items take the one-role ingest kernel and a scalar launch of its own
     REQUIRE(plume_init(&other, 7) == 0);
+    unsetenv("PLUME_INGEST_SPLIT_MAX");
     check_verify(other, v2, 0);
     plume_destroy(ctx);
     check_verify(other, clean, 1);
