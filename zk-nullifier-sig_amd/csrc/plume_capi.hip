@@ -154,7 +154,6 @@ struct plume_ctx {
     int host_lanes = 2;                                            // ... 1 = every piece on the context itself (rounds 1-3), 2 = pieces alternate between the context and host_lane
     int host_sign_lanes = 1;                                       // ... the signer's host-pointer call: lanes it may use (env PLUME_HOST_SIGN_LANES; round-5 experiment)
     bool host_lane_failed = false;                                 // ... the second lane could not be created once (out of memory): do not retry on every call
-    size_t msm_split_max = (size_t)1 << 16;                        // verify calls (slices) of at most this many items run the multi-scalar kernel with two lanes per (item, equation)
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
     FixedTables* fixed = nullptr;                                 // this device's shared generator tables (g_fixed)
@@ -178,7 +177,7 @@ struct plume_ctx {
 // knob cannot reach some derived contexts and miss others (round 4's host lane did not inherit sign_uniform: VERDICT r4).
 static void inherit_tunables(plume_ctx* to, const plume_ctx* from) {
     to->chunk = from->chunk; to->sub_batches = from->sub_batches; to->overlap_min = from->overlap_min; to->sign_uniform = from->sign_uniform;
-    to->ingest_split_max = from->ingest_split_max; to->msm_split_max = from->msm_split_max; to->split_scalars = from->split_scalars;
+    to->ingest_split_max = from->ingest_split_max; to->split_scalars = from->split_scalars;
     to->jobs_per_lane = from->jobs_per_lane; to->jobs_per_lane_forced = from->jobs_per_lane_forced;
     to->host_piece = from->host_piece; to->host_first_piece = from->host_first_piece; to->host_tail_piece = from->host_tail_piece; to->host_register_min = from->host_register_min;
     to->host_lanes = from->host_lanes; to->host_sign_lanes = from->host_sign_lanes; to->eq1_short = from->eq1_short; to->eq1_short_min = from->eq1_short_min;
