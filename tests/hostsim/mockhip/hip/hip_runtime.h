@@ -58,6 +58,7 @@ struct State {
     std::mutex m;                                        // the address map and the counters
     std::map<const void*, Range> ranges;                 // allocations and registrations by base address
     long device_allocs = 0, host_allocs = 0, streams = 0, events = 0;
+    long alloc_calls = 0, fail_alloc_at = -1;            // fault injection: the fail_alloc_at-th allocation (hipMalloc / hipHostMalloc, counted from 0) from now on fails once
     Device dev[16];
     int sched = 0;                                       // 0 lazy, 1 eager, 2 random
     State() {
@@ -86,6 +87,9 @@ inline bool lookup(const void* p, Range& out, size_t need = 1) {
     out = it->second;
     return true;
 }
+// the driver's fault injection: make the k-th allocation from now fail (k < 0: none); returns how many allocations were made since the last call
+inline long fail_allocation(long k) { State& s = st(); std::lock_guard<std::mutex> lk(s.m); const long made = s.alloc_calls; s.alloc_calls = 0; s.fail_alloc_at = k; return made; }
+inline bool alloc_fails() { State& s = st(); std::lock_guard<std::mutex> lk(s.m); const bool f = s.fail_alloc_at >= 0 && s.alloc_calls == s.fail_alloc_at; s.alloc_calls++; if (f) s.fail_alloc_at = -1; return f; }
 inline long outstanding(int what) { State& s = st(); std::lock_guard<std::mutex> lk(s.m); return what == 0 ? s.device_allocs : what == 1 ? s.host_allocs : what == 2 ? s.streams : s.events; }
 inline long ops_run(int device, bool by_other) { Device& d = st().dev[device]; std::lock_guard<std::recursive_mutex> lk(d.m); return by_other ? d.ops_run_by_other_stream : d.ops_run; }
 
@@ -202,6 +206,7 @@ inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *
 inline hipError_t hipDeviceSynchronize() { mockhip::drain_device(mockhip::current_device()); return hipSuccess; }
 
 inline hipError_t hipMalloc(void** p, size_t bytes) {
+    if (mockhip::alloc_fails()) return hipErrorOutOfMemory;
     void* q = std::malloc(bytes ? bytes : 1);
     if (!q) return hipErrorOutOfMemory;
     std::memset(q, 0xA5, bytes);                          // device memory comes back dirty
@@ -217,6 +222,7 @@ inline hipError_t hipFree(void* p) {                      // (the real call wait
     return hipSuccess;
 }
 inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+    if (mockhip::alloc_fails()) return hipErrorOutOfMemory;
     void* q = std::malloc(bytes ? bytes : 1);
     if (!q) return hipErrorOutOfMemory;
     std::memset(q, 0x5A, bytes);

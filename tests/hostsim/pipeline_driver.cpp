@@ -3,12 +3,13 @@
 // run by tests/test_sanitizers.py under AddressSanitizer + UBSan and under ThreadSanitizer: the contexts, lanes, staging slots, piece pipeline, chunk loop, shard worker
 // threads and their teardown then run for real, with every caller array sized exactly on the heap and the mock's lazy / random stream scheduler running whatever the
 // library did not order in the worst order.
-//   pipeline_driver <group> [seed]        groups: verify sign multi device misc all
+//   pipeline_driver <group> [seed]        groups: verify sign multi device misc devapi faults all
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <random>
 #include <string>
@@ -412,6 +413,146 @@ static void group_device(uint64_t seed) {
     REQUIRE(hipStreamDestroy(s1) == hipSuccess && hipStreamDestroy(s2) == hipSuccess);
 }
 
+// every device-resident entry point the other groups do not reach, against the host-pointer form of the same context (itself checked against the oracle by the other
+// groups); verify and sign in the OVERLAPPED sub-batch order (a second stream of the context runs the stages in front of the multi-scalar kernel: pre stream, pre_ready events)
+static void group_devapi(uint64_t seed) {
+    plume_ctx* ctx = nullptr;
+    setenv("PLUME_OVERLAP_MIN", "8", 1);                      // sub-batches overlap from 8 items on (default 2^17)
+    REQUIRE(plume_init(&ctx, 4) == 0);
+    unsetenv("PLUME_OVERLAP_MIN");
+    REQUIRE(hipSetDevice(4) == hipSuccess);
+    hipStream_t st;
+    REQUIRE(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+    const Batch a = make_batch(1, 120 + seed % 5, true), v2 = make_batch(2, 60, true);
+    auto dl = [&](const DevArr& d) { std::vector<uint8_t> h(d.bytes); REQUIRE(hipMemcpyAsync(h.data(), d.p, d.bytes, hipMemcpyDeviceToHost, st) == hipSuccess); return h; };   // pageable: blocks until st got there
+    for (const Batch* bp : {&a, &v2}) {
+        const Batch& b = *bp;
+        const size_t n = b.n;
+        const bool v1 = b.version == 1;
+        g_what = "device-resident entry points, V" + std::to_string(b.version);
+        DevArr m(b.msgs.data(), b.msgs.size()), o(b.off.data(), 8 * (n + 1)), pk(b.pk.data(), 64 * n), nul(b.nul.data(), 64 * n), c(b.c.data(), 32 * n), s(b.s.data(), 32 * n), rp(b.rpt.data(), 64 * n), hr(b.hr.data(), 64 * n);
+        const uint64_t* off = (const uint64_t*)o.p;
+        for (int sub : {3, 1}) {                               // overlapped order, then the serial one
+            REQUIRE(plume_set_sub_batches(ctx, sub) == 0);
+            {   // verify, SEC1 ingest
+                const std::vector<uint8_t> pk33 = compress_all(b.pk, n), nul33 = compress_all(b.nul, n), r33 = compress_all(b.rpt, n), hr33 = compress_all(b.hr, n);
+                std::vector<uint8_t> expect(n), okh(n);
+                REQUIRE(plume_verify_batch_sec1(ctx, b.version, n, b.msgs.data(), b.off.data(), pk33.data(), nul33.data(), b.c.data(), b.s.data(), v1 ? r33.data() : nullptr, v1 ? hr33.data() : nullptr, expect.data()) == 0);
+                DevArr dpk(pk33.data(), 33 * n), dnul(nul33.data(), 33 * n), dr(r33.data(), 33 * n), dhr(hr33.data(), 33 * n), ok(nullptr, n), ok64(nullptr, n);
+                REQUIRE(plume_verify_batch_sec1_device(ctx, b.version, n, m.p, off, b.msgs.size(), dpk.p, dnul.p, c.p, s.p, v1 ? dr.p : nullptr, v1 ? dhr.p : nullptr, ok.p, st) == 0);
+                REQUIRE(plume_verify_batch_device(ctx, b.version, n, m.p, off, b.msgs.size(), pk.p, nul.p, c.p, s.p, v1 ? rp.p : nullptr, v1 ? hr.p : nullptr, ok64.p, st) == 0);
+                REQUIRE(dl(ok) == expect && dl(ok64) == b.ok_expect);
+            }
+            {   // sign, both output forms
+                DevArr sk(b.sk.data(), 32 * n), r(b.r.data(), 32 * n), opk(nullptr, 64 * n), onul(nullptr, 64 * n), oc(nullptr, 32 * n), os(nullptr, 32 * n), orp(nullptr, 64 * n), ohr(nullptr, 64 * n), ost(nullptr, n);
+                DevArr pk33(nullptr, 33 * n), nul33(nullptr, 33 * n), oc2(nullptr, 32 * n), os2(nullptr, 32 * n), r33(nullptr, 33 * n), hr33(nullptr, 33 * n), ost2(nullptr, n);
+                REQUIRE(plume_sign_batch_device(ctx, b.version, n, m.p, off, b.msgs.size(), sk.p, r.p, nullptr, opk.p, onul.p, oc.p, os.p, orp.p, ohr.p, ost.p, st) == 0);
+                REQUIRE(plume_sign_batch_sec1_device(ctx, b.version, n, m.p, off, b.msgs.size(), sk.p, r.p, nullptr, pk33.p, nul33.p, oc2.p, os2.p, r33.p, hr33.p, ost2.p, st) == 0);
+                std::vector<uint8_t> epk(64 * n), enul(64 * n), ec(32 * n), es(32 * n), erp(64 * n), ehr(64 * n), eh(64 * n), est(n);
+                oracle_sign_batch(b.version, n, b.msgs.data(), b.off.data(), b.sk.data(), b.r.data(), nullptr, epk.data(), enul.data(), ec.data(), es.data(), erp.data(), ehr.data(), eh.data(), est.data(), 4);
+                REQUIRE(dl(opk) == epk && dl(onul) == enul && dl(oc) == ec && dl(os) == es && dl(orp) == erp && dl(ohr) == ehr && dl(ost) == est);
+                REQUIRE(dl(pk33) == compress_all(epk, n) && dl(nul33) == compress_all(enul, n) && dl(r33) == compress_all(erp, n) && dl(hr33) == compress_all(ehr, n) && dl(os2) == es && dl(oc2) == ec);
+            }
+        }
+        {   // hash_to_curve and its intermediates, hints, DER, registers, first occurrences
+            std::vector<uint8_t> eh(64 * n), eu(64 * n), emap(128 * n), eq(128 * n), eh2(64 * n), ehint(192 * n), eder(109 * n), edst(n), efirst(n);
+            uint64_t enu = 0;
+            REQUIRE(plume_hash_to_curve_batch(ctx, n, b.msgs.data(), b.off.data(), b.pk.data(), eh.data()) == 0);
+            REQUIRE(plume_h2c_intermediates_batch(ctx, n, b.msgs.data(), b.off.data(), b.pk.data(), 1, eu.data(), emap.data(), eq.data(), eh2.data()) == 0);
+            REQUIRE(plume_h2c_hints_batch(ctx, n, b.msgs.data(), b.off.data(), b.pk.data(), 0, ehint.data()) == 0);
+            REQUIRE(plume_scalars_to_sec1_der_batch(ctx, n, b.sk.data(), eder.data(), edst.data()) == 0);
+            REQUIRE(plume_nullifier_first_occurrence(ctx, n, b.nul.data(), nullptr, nullptr, efirst.data(), &enu) == 0);
+            DevArr h(nullptr, 64 * n), u(nullptr, 64 * n), mp(nullptr, 128 * n), q(nullptr, 128 * n), h2(nullptr, 64 * n), hint(nullptr, 192 * n), sk(b.sk.data(), 32 * n), der(nullptr, 109 * n), dst(nullptr, n),
+                first(nullptr, n), nu(nullptr, 8), regs(nullptr, 64 * n);
+            REQUIRE(plume_hash_to_curve_batch_device(ctx, n, m.p, off, b.msgs.size(), pk.p, h.p, st) == 0);
+            REQUIRE(plume_h2c_intermediates_batch_device(ctx, n, m.p, off, b.msgs.size(), pk.p, 1, u.p, mp.p, q.p, h2.p, st) == 0);
+            REQUIRE(plume_h2c_hints_batch_device(ctx, n, m.p, off, b.msgs.size(), pk.p, 0, hint.p, st) == 0);
+            REQUIRE(plume_scalars_to_sec1_der_batch_device(ctx, n, sk.p, der.p, dst.p, st) == 0);
+            REQUIRE(plume_nullifier_first_occurrence_device(ctx, n, nul.p, nullptr, nullptr, first.p, (uint64_t*)nu.p, st) == 0);
+            REQUIRE(plume_registers_from_be_device(ctx, 2 * n, h.p, (uint64_t*)regs.p, st) == 0);
+            REQUIRE(dl(h) == eh && dl(u) == eu && dl(mp) == emap && dl(q) == eq && dl(h2) == eh2 && dl(hint) == ehint && dl(der) == eder && dl(dst) == edst && dl(first) == efirst);
+            std::vector<uint8_t> nub = dl(nu);
+            REQUIRE(std::memcmp(nub.data(), &enu, 8) == 0);
+            std::vector<uint64_t> eregs(8 * n);
+            REQUIRE(plume_registers_from_be(2 * n, eh.data(), eregs.data()) == 0);
+            REQUIRE(std::memcmp(dl(regs).data(), eregs.data(), 64 * n) == 0);
+        }
+        {   // the aggregate check: one call, and the same batch as two pieces with a carried record
+            uint8_t seed32[32], eres[72];
+            for (auto& x : seed32) x = (uint8_t)rng();
+            const int mode = v1 ? 0 : 1;
+            std::vector<uint8_t> ehok(n);
+            REQUIRE(oracle_aggregate_check(b.version, mode, n, b.msgs.data(), b.off.data(), b.pk.data(), b.nul.data(), b.c.data(), b.s.data(), b.rpt.data(), b.hr.data(), seed32, 0, ehok.data(), eres, 4) == 0);
+            DevArr hok(nullptr, n), res(nullptr, 72);
+            REQUIRE(plume_aggregate_check_device(ctx, b.version, mode, n, m.p, off, b.msgs.size(), pk.p, nul.p, c.p, s.p, rp.p, hr.p, seed32, 0, hok.p, res.p, st) == 0);
+            REQUIRE(dl(hok) == ehok);
+            REQUIRE(std::memcmp(dl(res).data(), eres, 72) == 0);
+        }
+    }
+    g_what = "argument errors of the device forms";
+    REQUIRE(plume_hash_to_curve_batch_device(ctx, 3, nullptr, nullptr, 0, nullptr, nullptr, st) != 0);
+    REQUIRE(plume_registers_from_be_device(ctx, 3, nullptr, nullptr, st) != 0);
+    REQUIRE(std::string(plume_last_error()).size() > 0);
+    plume_destroy(ctx);
+    REQUIRE(hipStreamDestroy(st) == hipSuccess);
+}
+
+// allocation failures: the k-th hipMalloc / hipHostMalloc of a call fails, for every k the call makes.  The call must fail cleanly (an error code, no crash, nothing leaked or
+// double-freed: ASan and the leak accounting at exit watch) and the context must work afterwards
+static void group_faults(uint64_t seed) {
+    const Batch b = make_batch(1, 40 + seed % 3, true), sg = make_batch(2, 24, false);
+    struct Call { const char* name; std::function<int(plume_ctx*)> run; };
+    std::vector<uint8_t> ok(b.n), opk(64 * sg.n), onul(64 * sg.n), oc(32 * sg.n), os(32 * sg.n), orp(64 * sg.n), ohr(64 * sg.n), ost(sg.n), res(72), hok(b.n);
+    uint8_t seed32[32] = {1, 2, 3};
+    const Call calls[] = {
+        {"verify", [&](plume_ctx* c) { return plume_verify_batch(c, 1, b.n, b.msgs.data(), b.off.data(), b.pk.data(), b.nul.data(), b.c.data(), b.s.data(), b.rpt.data(), b.hr.data(), ok.data()); }},
+        {"sign", [&](plume_ctx* c) { return plume_sign_batch(c, 2, sg.n, sg.msgs.data(), sg.off.data(), sg.sk.data(), sg.r.data(), nullptr, opk.data(), onul.data(), oc.data(), os.data(), orp.data(), ohr.data(), ost.data()); }},
+        {"aggregate", [&](plume_ctx* c) { return plume_aggregate_check(c, 1, 0, b.n, b.msgs.data(), b.off.data(), b.pk.data(), b.nul.data(), b.c.data(), b.s.data(), b.rpt.data(), b.hr.data(), seed32, hok.data(), res.data()); }},
+    };
+    // pass 0: nothing else alive -- the generator's tables are allocated (and, on failure, given back) by the call under test; the first allocations of a verify call only,
+    // a table build costs a second here.  Passes 1, 2: a keeper context per device holds the tables, every allocation of every call fails in turn (one device, three shards).
+    plume_ctx* keeper[2] = {nullptr, nullptr};
+    for (int pass = 0; pass < 3; pass++) {
+        const int multi = pass == 2;
+        if (pass == 1) {
+            REQUIRE(plume_init(&keeper[0], 5) == 0 && plume_init(&keeper[1], 6) == 0);
+            for (plume_ctx* kc : keeper) { REQUIRE(plume_set_eq1_short(kc, 3) == 0); for (const Call& cl : calls) REQUIRE(cl.run(kc) == 0); }
+        }
+        for (const Call& cl : calls) {
+            if (pass == 0 && std::string(cl.name) != "verify") continue;
+            if (pass == 2 && std::string(cl.name) == "sign") continue;      // (the shards' fan-out and join are the same code for every call: verify and the aggregate's combine step cover them)
+            g_what = std::string("allocation failures in ") + cl.name + (multi ? " (three shards)" : pass == 0 ? " (tables not built yet)" : "");
+            long total = -1;
+            for (long k = 0; total < 0 || k < (pass == 0 ? std::min<long>(total, 14) : total); k++) {
+                // a fresh context every time: the allocations of a first call (workspace, slots, tables) are the interesting ones
+                plume_ctx* ctx = nullptr;
+                int ids[3] = {5, 6, 5};
+                REQUIRE((multi ? plume_init_multi(&ctx, ids, 3) : plume_init(&ctx, 6)) == 0);
+                REQUIRE(plume_set_host_piece(ctx, 32) == 0 && plume_set_host_first_piece(ctx, 8) == 0 && plume_set_host_tail_piece(ctx, 8) == 0 && plume_set_eq1_short(ctx, 3) == 0);
+                if (total < 0) {                               // how many allocations does the call make?
+                    mockhip::fail_allocation(-1);
+                    REQUIRE(cl.run(ctx) == 0);
+                    total = mockhip::fail_allocation(-1);
+                    REQUIRE(total > 3);
+                    plume_destroy(ctx);
+                    k = -1;
+                    continue;
+                }
+                mockhip::fail_allocation(k);
+                const int rc = cl.run(ctx);
+                mockhip::fail_allocation(-1);
+                // (a failed allocation may be survivable: the second host lane is optional, a registration is optional)
+                if (rc == 0) { if (std::string(cl.name) == "verify") REQUIRE(ok == b.ok_expect); }
+                else REQUIRE(rc == PLUME_ERR_HIP);
+                REQUIRE(cl.run(ctx) == 0);                     // and the context is usable afterwards
+                if (std::string(cl.name) == "verify") REQUIRE(ok == b.ok_expect);
+                plume_destroy(ctx);
+            }
+        }
+    }
+    for (plume_ctx* kc : keeper) plume_destroy(kc);
+}
+
 static void group_misc(uint64_t seed) {
     plume_ctx* ctx = nullptr;
     REQUIRE(plume_init(&ctx, 7) == 0);
@@ -447,6 +588,8 @@ int main(int argc, char** argv) {
     if (group == "multi" || group == "all") group_multi(seed);
     if (group == "device" || group == "all") group_device(seed);
     if (group == "misc" || group == "all") group_misc(seed);
+    if (group == "devapi" || group == "all") group_devapi(seed);
+    if (group == "faults" || group == "all") group_faults(seed);
     // everything the library took from the runtime has gone back
     g_what = "leak check";
     REQUIRE(mockhip::outstanding(0) == 0);

@@ -8,7 +8,9 @@ kernels as host loops over the same per-lane bodies and the same buffers (tests/
 page-locked and registered arrays, device-resident calls on caller streams with one and two batches in flight, plume_init_multi over eight devices and over a repeated device,
 teardown with work queued, leak accounting of every runtime object.
 
-* AddressSanitizer + UBSan (leak detection on) over every group, lazy and random schedules;
+* AddressSanitizer + UBSan (leak detection on) over every group, lazy and random schedules -- including every device-resident entry point with the overlapped sub-batch
+  order (`devapi`) and allocation-failure injection (`faults`: the k-th hipMalloc / hipHostMalloc of a call fails, for every k: an error code, nothing leaked, the context
+  usable afterwards);
 * ThreadSanitizer over the multi-device group (eight shard worker threads + the caller's) and the device group;
 * mutants: the harness has to FAIL when an event wait, the slot hand-back, the workspace guard or the final quiesce is taken out of the library -- otherwise it proves nothing.
 """
@@ -66,11 +68,15 @@ def _all_ok(results):
 
 def test_host_side_under_asan_ubsan_on_eight_devices(builds):
     exe = builds["asan"] / "pipeline_driver"
-    jobs = [("verify", None, 1), ("sign", None, 1), ("misc", None, 2), ("device", None, 1), ("device", "random:1", 1), ("device", "random:2", 2), ("verify", "random:3", 3), ("sign", "eager", 1),
-            ("multi", None, 1)]
+    jobs = [("faults", None, 1), ("multi", None, 1), ("verify", None, 1), ("sign", None, 1), ("misc", None, 2), ("device", None, 1), ("device", "random:1", 1), ("device", "random:2", 2),
+            ("verify", "random:3", 3), ("sign", "eager", 1), ("devapi", None, 1), ("devapi", "random:4", 2)]
     with ThreadPoolExecutor(4) as ex:
         res = list(ex.map(lambda j: (j, _run(exe, j[0], j[1], j[2])), jobs))
     _all_ok(res)
+    # the pipeline's own timeline (PLUME_HOST_TRACE=1: six timing events per piece, read after the call) through the same runs
+    r = _run(exe, "verify", None, 4, {"PLUME_HOST_TRACE": "1"})
+    _all_ok([("host trace", r)])
+    assert "plume_host_trace:" in r.stderr and "piece  1 lane" in r.stderr
 
 
 def test_shard_threads_under_tsan(builds):
