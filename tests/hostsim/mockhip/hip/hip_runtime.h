@@ -59,6 +59,7 @@ struct State {
     std::map<const void*, Range> ranges;                 // allocations and registrations by base address
     long device_allocs = 0, host_allocs = 0, streams = 0, events = 0;
     long alloc_calls = 0, fail_alloc_at = -1;            // fault injection: the fail_alloc_at-th allocation (hipMalloc / hipHostMalloc, counted from 0) from now on fails once
+    size_t fail_big_bytes = 0; long fail_big_skip = 0;   // ... or the (skip+1)-th allocation of at least fail_big_bytes bytes fails once (the generator's tables)
     Device dev[16];
     int sched = 0;                                       // 0 lazy, 1 eager, 2 random
     State() {
@@ -89,7 +90,15 @@ inline bool lookup(const void* p, Range& out, size_t need = 1) {
 }
 // the driver's fault injection: make the k-th allocation from now fail (k < 0: none); returns how many allocations were made since the last call
 inline long fail_allocation(long k) { State& s = st(); std::lock_guard<std::mutex> lk(s.m); const long made = s.alloc_calls; s.alloc_calls = 0; s.fail_alloc_at = k; return made; }
-inline bool alloc_fails() { State& s = st(); std::lock_guard<std::mutex> lk(s.m); const bool f = s.fail_alloc_at >= 0 && s.alloc_calls == s.fail_alloc_at; s.alloc_calls++; if (f) s.fail_alloc_at = -1; return f; }
+inline void fail_allocation_of_at_least(size_t bytes, long skip) { State& s = st(); std::lock_guard<std::mutex> lk(s.m); s.fail_big_bytes = bytes; s.fail_big_skip = skip; }
+inline bool alloc_fails(size_t bytes) {
+    State& s = st(); std::lock_guard<std::mutex> lk(s.m);
+    bool f = s.fail_alloc_at >= 0 && s.alloc_calls == s.fail_alloc_at;
+    s.alloc_calls++;
+    if (f) s.fail_alloc_at = -1;
+    if (!f && s.fail_big_bytes && bytes >= s.fail_big_bytes) { if (s.fail_big_skip-- == 0) { f = true; s.fail_big_bytes = 0; } }
+    return f;
+}
 inline long outstanding(int what) { State& s = st(); std::lock_guard<std::mutex> lk(s.m); return what == 0 ? s.device_allocs : what == 1 ? s.host_allocs : what == 2 ? s.streams : s.events; }
 inline long ops_run(int device, bool by_other) { Device& d = st().dev[device]; std::lock_guard<std::recursive_mutex> lk(d.m); return by_other ? d.ops_run_by_other_stream : d.ops_run; }
 
@@ -193,7 +202,8 @@ inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= mockhip::device_count(
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d) {
     if (d < 0 || d >= mockhip::device_count()) return hipErrorInvalidDevice;
     std::memset(p, 0, sizeof *p);
-    std::snprintf(p->gcnArchName, sizeof p->gcnArchName, "gfx950:sramecc+:xnack-");
+    const char* arch = std::getenv("PLUME_MOCK_ARCH");                      // (a machine with another GPU: the library must refuse it)
+    std::snprintf(p->gcnArchName, sizeof p->gcnArchName, "%s:sramecc+:xnack-", arch ? arch : "gfx950");
     p->multiProcessorCount = 256;
     return hipSuccess;
 }
@@ -206,7 +216,7 @@ inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *
 inline hipError_t hipDeviceSynchronize() { mockhip::drain_device(mockhip::current_device()); return hipSuccess; }
 
 inline hipError_t hipMalloc(void** p, size_t bytes) {
-    if (mockhip::alloc_fails()) return hipErrorOutOfMemory;
+    if (mockhip::alloc_fails(bytes)) return hipErrorOutOfMemory;
     void* q = std::malloc(bytes ? bytes : 1);
     if (!q) return hipErrorOutOfMemory;
     std::memset(q, 0xA5, bytes);                          // device memory comes back dirty
@@ -222,7 +232,7 @@ inline hipError_t hipFree(void* p) {                      // (the real call wait
     return hipSuccess;
 }
 inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
-    if (mockhip::alloc_fails()) return hipErrorOutOfMemory;
+    if (mockhip::alloc_fails(bytes)) return hipErrorOutOfMemory;
     void* q = std::malloc(bytes ? bytes : 1);
     if (!q) return hipErrorOutOfMemory;
     std::memset(q, 0x5A, bytes);

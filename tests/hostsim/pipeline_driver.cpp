@@ -5,6 +5,7 @@
 // library did not order in the worst order.
 //   pipeline_driver <group> [seed]        groups: verify sign multi device misc devapi faults all
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -489,6 +490,8 @@ static void group_devapi(uint64_t seed) {
             REQUIRE(std::memcmp(dl(res).data(), eres, 72) == 0);
         }
     }
+    // (The OVERLAPPED order itself needs slices of at least 8192 items -- csrc/plume_host_logic.h sub_batch_bounds -- which is minutes of CPU under a sanitizer: the GPU suite runs
+    // it, tests/test_gpu_round3.py::test_stage_times_serial_and_overlapped; here sub_batches = 3 exercises the knob's bookkeeping with one slice.)
     g_what = "argument errors of the device forms";
     REQUIRE(plume_hash_to_curve_batch_device(ctx, 3, nullptr, nullptr, 0, nullptr, nullptr, st) != 0);
     REQUIRE(plume_registers_from_be_device(ctx, 3, nullptr, nullptr, st) != 0);
@@ -522,8 +525,9 @@ static void group_faults(uint64_t seed) {
             if (pass == 0 && std::string(cl.name) != "verify") continue;
             if (pass == 2 && std::string(cl.name) == "sign") continue;      // (the shards' fan-out and join are the same code for every call: verify and the aggregate's combine step cover them)
             g_what = std::string("allocation failures in ") + cl.name + (multi ? " (three shards)" : pass == 0 ? " (tables not built yet)" : "");
-            long total = -1;
-            for (long k = 0; total < 0 || k < (pass == 0 ? std::min<long>(total, 14) : total); k++) {
+            long total = -1, runs = 0;
+            const auto t_begin = std::chrono::steady_clock::now();
+            for (long k = 0; total < 0 || k < (pass == 0 ? std::min<long>(total, 10) : total); k++, runs++) {
                 // a fresh context every time: the allocations of a first call (workspace, slots, tables) are the interesting ones
                 plume_ctx* ctx = nullptr;
                 int ids[3] = {5, 6, 5};
@@ -548,9 +552,54 @@ static void group_faults(uint64_t seed) {
                 if (std::string(cl.name) == "verify") REQUIRE(ok == b.ok_expect);
                 plume_destroy(ctx);
             }
+            std::printf("  %s: %ld allocations per call, %ld failure points tried, %.1f s\n", g_what.c_str(), total, runs, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
         }
     }
     for (plume_ctx* kc : keeper) plume_destroy(kc);
+    {   // the generator's tables themselves (the largest allocations by far): the window table of the verifier, then the comb of the short first equation
+        g_what = "the generator's tables cannot be allocated";
+        for (long skip = 0; skip < 2; skip++) {
+            plume_ctx* ctx = nullptr;
+            REQUIRE(plume_init(&ctx, 6) == 0 && plume_set_eq1_short(ctx, 3) == 0);
+            mockhip::fail_allocation_of_at_least((size_t)1 << 20, skip);
+            REQUIRE(calls[0].run(ctx) == PLUME_ERR_HIP);
+            REQUIRE(calls[0].run(ctx) == 0 && ok == b.ok_expect);
+            plume_destroy(ctx);
+        }
+    }
+    {   // page-locked arrays: the call asks for a second lane of the context; when that lane cannot be created the call goes on with one
+        g_what = "the second host lane cannot be created";
+        keeper[0] = nullptr;
+        REQUIRE(plume_init(&keeper[0], 6) == 0 && plume_set_eq1_short(keeper[0], 3) == 0 && calls[0].run(keeper[0]) == 0);
+        Arr msgs(b.msgs.size(), 1), off(8 * (b.n + 1), 1), pk(64 * b.n, 1), nul(64 * b.n, 1), c(32 * b.n, 1), s(32 * b.n, 1), rpt(64 * b.n, 1), hr(64 * b.n, 1), okp(b.n, 1);
+        msgs.set(b.msgs); std::memcpy(off.p, b.off.data(), 8 * (b.n + 1)); pk.set(b.pk); nul.set(b.nul); c.set(b.c); s.set(b.s); rpt.set(b.rpt); hr.set(b.hr);
+        long total = -1;
+        for (long k = 0; total < 0 || k < total; k++) {
+            plume_ctx* ctx = nullptr;
+            REQUIRE(plume_init(&ctx, 6) == 0);
+            REQUIRE(plume_set_host_piece(ctx, 16) == 0 && plume_set_host_first_piece(ctx, 8) == 0 && plume_set_eq1_short(ctx, 3) == 0 && plume_set_host_lanes(ctx, 2) == 0);
+            mockhip::fail_allocation(total < 0 ? -1 : k);
+            const int rc = plume_verify_batch(ctx, 1, b.n, msgs.p, (const uint64_t*)off.p, pk.p, nul.p, c.p, s.p, rpt.p, hr.p, okp.p);
+            const long made = mockhip::fail_allocation(-1);
+            if (total < 0) { REQUIRE(rc == 0); total = made; k = -1; plume_destroy(ctx); continue; }
+            REQUIRE(rc == 0 || rc == PLUME_ERR_HIP);
+            if (rc == 0) REQUIRE(std::memcmp(okp.p, b.ok_expect.data(), b.n) == 0);
+            REQUIRE(plume_verify_batch(ctx, 1, b.n, msgs.p, (const uint64_t*)off.p, pk.p, nul.p, c.p, s.p, rpt.p, hr.p, okp.p) == 0 && std::memcmp(okp.p, b.ok_expect.data(), b.n) == 0);
+            plume_destroy(ctx);
+        }
+        plume_destroy(keeper[0]);
+    }
+}
+
+// a machine whose GPU is not a gfx950 (PLUME_MOCK_ARCH): the library refuses it by name; and a machine without any device
+static void group_noarch() {
+    plume_ctx* ctx = nullptr;
+    g_what = "another architecture";
+    const int rc = plume_init(&ctx, 0);
+    REQUIRE(rc == PLUME_ERR_NODEV && ctx == nullptr);
+    REQUIRE(std::string(plume_last_error()).find(std::getenv("PLUME_MOCK_ARCH") ? "gfx950" : "no HIP device") != std::string::npos);
+    int ids[2] = {0, 0};
+    REQUIRE(plume_init_multi(&ctx, ids, 2) == PLUME_ERR_NODEV && ctx == nullptr);
 }
 
 static void group_misc(uint64_t seed) {
@@ -590,6 +639,7 @@ int main(int argc, char** argv) {
     if (group == "misc" || group == "all") group_misc(seed);
     if (group == "devapi" || group == "all") group_devapi(seed);
     if (group == "faults" || group == "all") group_faults(seed);
+    if (group == "noarch") group_noarch();
     // everything the library took from the runtime has gone back
     g_what = "leak check";
     REQUIRE(mockhip::outstanding(0) == 0);

@@ -77,6 +77,8 @@ def test_host_side_under_asan_ubsan_on_eight_devices(builds):
     r = _run(exe, "verify", None, 4, {"PLUME_HOST_TRACE": "1"})
     _all_ok([("host trace", r)])
     assert "plume_host_trace:" in r.stderr and "piece  1 lane" in r.stderr
+    # a machine with another GPU, a machine with none: refused by name, no context
+    _all_ok([("gfx942", _run(exe, "noarch", None, 1, {"PLUME_MOCK_ARCH": "gfx942"})), ("no device", _run(exe, "noarch", None, 1, {"PLUME_MOCK_DEVICES": "0"}))])
 
 
 def test_shard_threads_under_tsan(builds):
@@ -99,7 +101,7 @@ MUTANTS = {
 
 def test_the_harness_fails_when_a_dependency_is_taken_out(builds, tmp_path):
     plain = builds["plain"]
-    flags = ["-x", "c++", "-O1", "-std=c++17", "-ffp-contract=off", "-DPLUME_GW=16", "-DPLUME_COMB_W=14", f"-I{HOSTSIM / 'mockhip'}", '-DPLUME_BUILD_ID="mutant"']
+    flags = ["-x", "c++", "-O1", "-std=c++17", "-ffp-contract=off", "-DPLUME_GW=16", "-DPLUME_COMB_W=10", f"-I{HOSTSIM / 'mockhip'}", '-DPLUME_BUILD_ID="mutant"']
 
     def mutant(item):
         k, (name, (old, new, group, sched)) = item
