@@ -4,6 +4,7 @@ dense launch.  Prints ms per 2^20-item V1 verify for: honest, 1 crafted item per
 redone tasks and a verdict check against the CPU (oracle/plume_cpu_fast.c).
 
     python tests/gpu_debug/adversarial_timing.py [--log2 20]"""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import argparse
 import json
 import pathlib

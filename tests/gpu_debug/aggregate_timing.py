@@ -1,4 +1,5 @@
 """Stage times of the aggregate pre-filter at 2^20 (and smaller), device-resident, next to the per-item verify on the same batch."""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import sys
 import time
 from pathlib import Path

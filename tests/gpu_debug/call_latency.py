@@ -1,4 +1,5 @@
 """Wall time of device-resident verify calls: one isolated call vs. calls queued back to back (is there a per-call gap?)."""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import sys, pathlib, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np, torch

@@ -1,5 +1,6 @@
 """(round 5) A/B of the verifier's first equation: long form (PLUME_EQ1_SHORT=0) against the short form (plume_eis.h) on one box, one process per setting, alternating.
 Device-resident 2^20 V1 verifies (1/16 corrupted), serial stage times (median of the timed calls) and the rate with two batches in flight."""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import json
 import os
 import subprocess

@@ -1,4 +1,5 @@
 """Level 2 of the signer's uniform schedule: time of the multiplications by G (k_sign_gmul_uniform<2>) for the library named by PLUME_HIP_LIB (round 4: builds with PLUME_GSCAN_W edited to 4 / 5 / 6 in plume_ec.h; 5 was kept: 7.34 / 6.98 / 7.42 ms per 2^20 signs)."""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import sys, pathlib
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np

@@ -32,11 +32,13 @@ if what in ("both", "sign"):
     off = t(b["off"].view(np.int64))
     o = {k: torch.zeros((n, w), dtype=torch.uint8, device=dev) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
     st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    eng.set_stage_timing(True)                     # (off by default since library 0.5; the host-pointer calls above ran without stage events, as a caller's would)
     for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         eng.sign_batch_device(1, n, d["msgs"], off, int(b["off"][-1]), d["sk"], d["r"], None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], st)
         torch.cuda.synchronize()
         print(f"=== sign device-resident {1e3 * (time.perf_counter() - t0):.3f} ms  {dict((k, round(v, 3)) for k, v in eng.last_stage_times())}", file=sys.stderr, flush=True)
+    eng.set_stage_timing(False)
 else:
     eng.sign_batch(1, pin["msgs"], pin["off"], pin["sk"], pin["r"], out=so)
 if what in ("both", "verify"):
@@ -53,6 +55,7 @@ if what in ("both", "verify"):
     dv = {k: t(v[k]) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
     off = t(b["off"].view(np.int64))
     okd = torch.zeros(n, dtype=torch.uint8, device=dev)
+    eng.set_stage_timing(True)
     for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         eng.verify_batch_device(1, n, dv["msgs"], off, int(b["off"][-1]), dv["pk"], dv["nullifier"], dv["c"], dv["s"], dv["r_point"], dv["hashed_to_curve_r"], okd)

@@ -1,5 +1,6 @@
 """Device-resident timings at 2^20 of the entry points that are not on the headline metric's path: verify_non_zk (V1, V2), h2c intermediates,
 SEC1-DER scalar export, register packing."""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import sys, pathlib, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import ctypes as C

@@ -3,6 +3,7 @@ device-resident 2^20 V1 verify and V1 sign (same resident batch), check the verd
 
     python tests/gpu_debug/overlap_sweep.py [--log2 20] [--subs 1,2,4,8,16]
 Boxes of the pool differ by +-5 %, so only numbers from one invocation are comparable; the default build runs first and again last (drift)."""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import json
 import os
 import pathlib

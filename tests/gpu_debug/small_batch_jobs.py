@@ -1,4 +1,5 @@
 """2^16-item device-resident verify (BASELINE config 2), one call after the other: stage times for different table jobs per lane (env PLUME_JOBS_PER_LANE; unset = the library's pick)."""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import os, sys, pathlib, time, subprocess, json
 ROOT = pathlib.Path(__file__).resolve().parents[2]
 if len(sys.argv) > 1:

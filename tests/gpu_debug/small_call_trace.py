@@ -1,6 +1,7 @@
 """Twenty device-resident 2^16-item verify calls back to back, for a kernel trace of one call's launches and the gaps between them:
    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/small_call -o sc -- python3 tests/gpu_debug/small_call_trace.py
    python3 tests/gpu_debug/trace_timeline.py gpurun_out/small_call"""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import sys, pathlib, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np, torch

@@ -1,4 +1,5 @@
 """The signer's uniform schedules (plume_set_sign_uniform levels 1 and 2) against the default one: stage times of a device-resident 2^20 V1 sign."""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import sys, pathlib, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np

@@ -2,6 +2,7 @@
 
     python tests/gpu_debug/variants.py            (parent: makes the batch with the default build, then one child per library)
 Boxes of the pool differ by +-5 %, so only numbers from one invocation are comparable."""
+import os; os.environ.setdefault("PLUME_STAGE_TIMES", "1")   # the stage-timing events are off by default since library 0.5; this script reads them
 import os, sys, subprocess, pathlib, json, time
 ROOT = pathlib.Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
