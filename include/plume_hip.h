@@ -110,7 +110,7 @@ int plume_get_sign_uniform(const plume_ctx* ctx);
 /* The verifier's first equation, R' = s G - c pk compared with the given r_point (rust-k256/src/lib.rs:101,115-121), for calls that GIVE r_point as a 64-byte record (V1
  * verify, verify_non_zk).  It is an identity check, so it may be multiplied by any tau != 0: with (tau, upsilon) from a half-GCD of c in the Eisenstein integers
  * (tau c = upsilon mod n through lambda; all four coefficients of about 64 bits -- csrc/plume_eis.h) the GPU checks  k G - upsilon pk - (tau - 1) R == R,  k = tau s mod n:
- * 64 doublings instead of 128 on that equation, the generator's term from the signer's comb, one more window table per item (R).  Verdicts are identical by construction
+ * 64 doublings instead of 128 on that equation, the generator's term from the signer's comb, one more window table per item (R).  Verdicts are identical by construction (and the pair is re-checked per item -- tau c == upsilon mod n -- before it is used; a failure, which cannot happen, would send the item to the long form)
  * (the equivalence is exact, not probabilistic); mode 1 (default) = short form for calls of at least 2^17 items, 3 = for calls of any size, 0 = long form always,
  * 2 = test mode (every item takes the scalar stage's fallback: the long form in the checked chain of the redo launch).  Env PLUME_EQ1_SHORT, PLUME_EQ1_SHORT_MIN.  Measured on the MI355X, 2^20 V1 verifies:
  * k_verify_msm -7.2 %, the step -1 % serial / -1.6 % with two batches in flight (the fourth table and the half-GCD take most of it back: DESIGN.md). */

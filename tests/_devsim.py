@@ -269,6 +269,15 @@ def eis_half_gcd(cs):
     return res
 
 
+def eis_consistent(cs, which=0):
+    """eis_consistent on the half-GCD's pair of each challenge, after tamper `which` (0 = none; tests/devsim/devsim.cpp ds_eis_consistent)"""
+    m = len(cs)
+    cb = np.frombuffer(b"".join(int(c).to_bytes(32, "big") for c in cs), dtype=np.uint8).copy()
+    out = np.zeros(m, np.uint8)
+    lib().ds_eis_consistent(C.c_uint32(m), _p(cb), C.c_int(which), _p(out))
+    return out.astype(bool)
+
+
 def eq1_short(s: bytes, c: bytes, pk: bytes, r: bytes):
     """k G - upsilon pk - (tau - 1) R through the scalar stage, the table stage and the multi-scalar body; (64 bytes | None, the scalar stage fell back to the long form)"""
     out = (C.c_uint8 * 64)()

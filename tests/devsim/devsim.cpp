@@ -517,6 +517,26 @@ int ds_eis_half_gcd(uint32_t n, const uint8_t* c_be, uint8_t* out, uint8_t* tau_
     }
     return 0;
 }
+// eis_consistent(half-GCD of c, c) for n challenges, and the same after one tamper of the pair: which = 0 none, 1 upsilon's first coefficient + 1, 2 upsilon's second
+// coefficient's sign flipped, 3 tau + 1, 4 the pair of ANOTHER challenge (c + 1)
+int ds_eis_consistent(uint32_t n, const uint8_t* c_be, int which, uint8_t* out) {
+    for (uint32_t i = 0; i < n; i++) {
+        alignas(16) uint8_t cb[32];
+        memcpy(cb, c_be + 32 * (size_t)i, 32);
+        sc c; sc_from_be_aligned(c, cb);
+        sc c_for_pair = c;
+        if (which == 4) { sc one; for (int k = 0; k < 8; k++) one.v[k] = k == 0 ? 1u : 0u; sc_add(c_for_pair, c, one); }
+        eis_short e;
+        glv_half g0, g1;
+        glv_split(g0, g1, c_for_pair);
+        eis_half_gcd(e, g0, g1);
+        if (which == 1) e.u[0][0] ^= 1u;
+        if (which == 2) e.uneg[1] ^= 1u;
+        if (which == 3) { sc one; for (int k = 0; k < 8; k++) one.v[k] = k == 0 ? 1u : 0u; sc_add(e.tau, e.tau, one); }
+        out[i] = eis_consistent(e, c) ? 1 : 0;
+    }
+    return 0;
+}
 // equation 1 in its SHORT form for one item: returns k G - upsilon pk - (tau - 1) R (which a valid signature makes equal to R) through verify_scalars, the table stage
 // and the multi-scalar body; *used_long = the scalar stage fell back to the long form
 int ds_eq1_short(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t pk_be[64], const uint8_t r_be[64], uint8_t out[64], int* used_long) {

@@ -808,6 +808,21 @@ def test_eis_half_gcd_relation_and_bounds():
     assert worst.bit_length() <= 66, worst.bit_length()
 
 
+def test_eis_pair_is_checked_before_it_is_used():
+    """the scalar stage re-derives tau c == upsilon (mod n) from the pair it is about to use (eis_consistent) and falls back to the long form when it does not hold: true for
+    every honest pair, crafted challenges included; false after any single tamper -- a coefficient's bit, a sign, tau itself, the pair of a neighbouring challenge"""
+    rng = random.Random(99)
+    cs = _eis_cases(rng, 4000)
+    assert D.eis_consistent(cs).all()
+    pairs = D.eis_half_gcd(cs)
+    for which in (1, 2, 3, 4):
+        got = D.eis_consistent(cs, which)
+        for c, g, (_, _, _, u1, _, _) in zip(cs, got, pairs):
+            if g:       # a tamper that changes nothing: the sign of a ZERO coefficient (upsilon = u0 for small c and for c near n); tau + 1 for c = 0 (both sides stay 0)
+                assert (which == 2 and u1 == 0) or (which == 3 and c == 0), (which, hex(c))
+        assert got.sum() < len(cs) // 20, (which, int(got.sum()))
+
+
 def test_equation1_short_form_value_and_fallback():
     """the chain of the short form -- scalar stage, four tables, 64 doublings, the comb -- returns k G - upsilon pk - (tau - 1) R: checked through its meaning (for ANY s, c,
     pk, R it equals R + tau (s G - c pk - R)), which a valid signature turns into R itself.  Crafted scalars; the forced fallback (long form in the checked chain) gives the

@@ -194,4 +194,21 @@ PLUME_HD void eis_half_gcd(eis_short& out, const glv_half& g0, const glv_half& g
     out.ok = ok;
 }
 
+// tau c == upsilon (mod n)?  The relation holds by construction -- every step applies one exact integer transformation to (x, y) and (tx, ty), the double-precision estimates only
+// choose the quotient -- so this never fails; it is CHECKED all the same before the short form is used, because a pair that broke it would make equation 1 accept or reject
+// the wrong signatures without any other symptom.  Two scalar multiplications per item (3 % of the scalar stage); a failure sends the item to the long form (verify_scalars).
+PLUME_HD bool eis_consistent(const eis_short& e, const sc& c) {
+    const uint32_t L[8] = {0x1B23BD72u, 0xDF02967Cu, 0x20816678u, 0x122E22EAu, 0x8812645Au, 0xA5261C02u, 0xC05C30E0u, 0x5363AD4Cu};      // lambda, little-endian words
+    sc a, b, lam, bl, ups, lhs;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) { a.v[i] = i < 3 ? e.u[0][i] : 0u; b.v[i] = i < 3 ? e.u[1][i] : 0u; lam.v[i] = L[i]; }
+    sc_mul(bl, b, lam);
+    if (e.uneg[1]) sc_neg(bl, bl);
+    if (e.uneg[0]) sc_neg(a, a);
+    sc_add(ups, a, bl);                                               // upsilon = u0 + u1 lambda mod n
+    sc_mul(lhs, e.tau, c);
+    uint32_t d = 0;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) d |= lhs.v[i] ^ ups.v[i];
+    return d == 0;
+}
+
 }  // namespace plume

@@ -219,7 +219,7 @@ PLUME_HD void verify_scalars(const VerifyArgs& a, uint32_t i) {
     if (a.eq1long) {
         eis_short e;
         eis_half_gcd(e, c1, c2);
-        lng = !e.ok || a.eq1force != 0;
+        lng = !e.ok || a.eq1force != 0 || !eis_consistent(e, c);
         if (!lng) {
             sc k;
             sc_mul(k, e.tau, s);
