@@ -53,6 +53,11 @@ def test_device_headers_host_build_under_asan_ubsan(tmp_path):
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", *SAN, "-DPLUME_FE_CHECK", "-DPLUME_GW=16", "-DPLUME_COMB_W=14", f"-I{CSRC}", "-o", str(so),
                            str(ROOT / "tests" / "devsim" / "devsim.cpp")])
     env = dict(os.environ, PLUME_DEVSIM_SO=str(so), LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1", PYTHONPATH=str(ROOT))
-    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_devsim.py"), "-x", "-q", "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    try:                                            # four workers where pytest-xdist exists (the run is 80 s of single-threaded table arithmetic under ASan otherwise)
+        import xdist  # noqa: F401
+        par = ["-n", "4"]
+    except ImportError:
+        par = []
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_devsim.py"), "-x", "-q", "-p", "no:cacheprovider", *par], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     assert "passed" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
