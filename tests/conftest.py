@@ -35,6 +35,34 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+# which slow-to-compile native artefacts the selected tests need (tests/_prebuild.py compiles them in the background while the quick tests run)
+_PREBUILD_NEEDS = {
+    "test_device_headers_host_build_under_asan_ubsan": ["devsim_asan"],
+    "test_twenty_bit_generator_window_build_of_the_device_headers": ["devsim_gw20"],
+    "test_host_side_under_asan_ubsan_on_eight_devices": ["hostsim_asan"],
+    "test_shard_threads_under_tsan": ["hostsim_tsan"],
+    "test_the_harness_fails_when_a_dependency_is_taken_out": ["hostsim_plain"],
+}
+
+
+def pytest_collection_finish(session):
+    from tests import _prebuild
+    names = []
+    for item in session.items:
+        if any(m.name == "skip" for m in item.iter_markers()):
+            continue
+        for n in _PREBUILD_NEEDS.get(item.originalname if hasattr(item, "originalname") else item.name, []):
+            if n not in names:
+                names.append(n)
+    if len(session.items) >= 20:          # a whole-suite run: for one or two selected tests the test builds its artefact itself, nothing is gained by a second path
+        _prebuild.start(names)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    from tests import _prebuild
+    _prebuild.cleanup()
+
+
 @pytest.fixture(scope="session")
 def kats():
     import json

@@ -767,10 +767,11 @@ def test_twenty_bit_generator_window_build_of_the_device_headers(tmp_path):
     import sys
     if os.environ.get("PLUME_DEVSIM_SO"):
         pytest.skip("already inside the child run")
-    so = tmp_path / "libplume_devsim_gw20.so"
-    csrc = ROOT / "zk-nullifier-sig_amd" / "csrc"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DPLUME_FE_CHECK", "-DPLUME_GW=20", "-DPLUME_COMB_W=14", f"-I{csrc}", "-o", str(so), str(ROOT / "tests" / "devsim" / "devsim.cpp")],
-                   check=True, capture_output=True, text=True)
+    from tests import _prebuild
+    so = _prebuild.get("devsim_gw20")                  # compiled in the background since collection when the whole suite runs (tests/_prebuild.py); else here, the same command
+    if so is None:
+        so = tmp_path / "libplume_devsim_gw20.so"
+        subprocess.run(_prebuild.devsim_gw20_cmd(so), check=True, capture_output=True, text=True)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", str(Path(__file__)), "-k", "wide or golden_verify or equation1 or crafted"],
                        env=dict(os.environ, PLUME_DEVSIM_SO=str(so)), capture_output=True, text=True, cwd=str(ROOT))
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-1000:])

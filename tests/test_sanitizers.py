@@ -49,9 +49,11 @@ def test_the_capi_uses_the_fuzzed_bodies():
 def test_device_headers_host_build_under_asan_ubsan(tmp_path):
     """tests/devsim built with ASan + UBSan (every limb-bound assertion on), tests/test_devsim.py run against it."""
     asan = _libasan()
-    so = tmp_path / "libplume_devsim_asan.so"
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", *SAN, "-DPLUME_FE_CHECK", "-DPLUME_GW=16", "-DPLUME_COMB_W=14", f"-I{CSRC}", "-o", str(so),
-                           str(ROOT / "tests" / "devsim" / "devsim.cpp")])
+    from tests import _prebuild
+    so = _prebuild.get("devsim_asan")                  # compiled in the background since collection when the whole suite runs (tests/_prebuild.py); else here, the same command
+    if so is None:
+        so = tmp_path / "libplume_devsim_asan.so"
+        subprocess.check_call(_prebuild.devsim_asan_cmd(so))
     env = dict(os.environ, PLUME_DEVSIM_SO=str(so), LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1", PYTHONPATH=str(ROOT))
     try:                                            # four workers where pytest-xdist exists (the run is 80 s of single-threaded table arithmetic under ASan otherwise)
         import xdist  # noqa: F401
