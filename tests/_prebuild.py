@@ -40,8 +40,8 @@ def _run(cmd, result):
 def start(names):
     """called once, from conftest, with the artefacts the selected tests need"""
     global _pool, _dir
-    if _pool is not None or not names or not shutil.which("g++") or os.environ.get("PLUME_NO_PREBUILD") or os.environ.get("PLUME_DEVSIM_SO"):
-        return
+    if _pool is not None or not names or not shutil.which("g++") or os.environ.get("PLUME_NO_PREBUILD") or os.environ.get("PLUME_DEVSIM_SO") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return                                           # (child runs of the harness tests and xdist workers build nothing in the background: their tests build what they need)
     _dir = Path(tempfile.mkdtemp(prefix="plume_prebuild_"))
     _pool = ThreadPoolExecutor(4)
     for n in names:
