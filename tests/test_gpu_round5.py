@@ -286,3 +286,11 @@ def test_stage_timing_is_opt_in_and_a_refused_call_takes_no_lane_turn(eng):
         eng.set_in_flight(1)
         eng.set_stage_timing(False)
     assert np.array_equal(ok0.cpu().numpy(), exp) and np.array_equal(ok1.cpu().numpy(), exp)
+
+
+def test_ragged_calls_through_randomly_configured_contexts():
+    """tests/gpu_debug/soak_ragged.py, sixty iterations: calls of 1 .. 65 537 items through contexts with randomly chosen piece sizes, chunk, lanes, first-equation form,
+    signer level and one to five shards sharing the GPU; every signer output and every verdict of both verify semantics against the CPU (oracle/plume_cpu_fast.c).
+    (A child process: the script owns its engines.  Round 5 ran it for 2 900 iterations: profiles/r05_soak.txt.)"""
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "gpu_debug" / "soak_ragged.py"), "60", "5"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "ragged soak ok: 60 iterations" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
