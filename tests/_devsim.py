@@ -136,6 +136,11 @@ def set_ingest_two_roles(on):
     lib().ds_set_ingest_two_roles(C.c_int(1 if on else 0))
 
 
+def set_msm_pair(on):
+    """the verify harness then runs every long-form chain as two halves on two "lanes" joined by a checked addition (the small-call kernel k_verify_msm_pair)"""
+    lib().ds_set_msm_pair(C.c_int(1 if on else 0))
+
+
 def verify_batch(version, msgs_buf, msg_off, pk, nul, c, s, r_point=None, hr=None, L=3):
     n = len(msg_off) - 1
     ok = np.full(n, 0xEE, dtype=np.uint8)

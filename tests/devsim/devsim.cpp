@@ -230,6 +230,8 @@ static const uint32_t B = 8;
 
 static int g_eq1_short = 1;      // mirrors ctx->eq1_short (plume_capi.hip): 0 = long form always, 1 = short form where R is given, 2 = every item takes the fallback (long form through the checked chain)
 void ds_set_eq1_short(int v) { g_eq1_short = v; }
+static int g_msm_pair = 0;
+void ds_set_msm_pair(int on) { g_msm_pair = on; }                     // the verify harness then runs every long-form chain as two halves + a join (k_verify_msm_pair)
 static int g_ingest_two_roles = 0;
 void ds_set_ingest_two_roles(int on) { g_ingest_two_roles = on; }      // the verify harness then runs the ingest stage in its two-role form
 static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* pk, const uint8_t* nul, const uint8_t* c,
@@ -297,6 +299,16 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     std::vector<int8_t> dig((2 * PLUME_NDIG + PLUME_NPOS) * B);
     std::vector<uint32_t> redo(2 * (size_t)n + 1, 0);
     a.redo = redo.data();
+    if (g_msm_pair && !eq1short) {          // the small-call form (k_verify_msm_pair): the two halves of every chain, joined by a checked addition
+        a.msm_pair = 1;
+        for (uint32_t eq = 0; eq < 2; eq++)
+            for (uint32_t i = 0; i < n; i++) {
+                jac h0, h1;
+                const bool ok1 = verify_msm_half(a, i, eq, 1, a.gtab, dig.data() + (i % B), B, h1);
+                const bool ok0 = verify_msm_half(a, i, eq, 0, a.gtab, dig.data() + (i % B), B, h0);
+                verify_msm_join(a, i, eq, h0, ok0, h1, ok1);
+            }
+    } else
     for (uint32_t eq = 0; eq < 2; eq++)
         for (uint32_t i = 0; i < n; i++) verify_msm<false>(a, i, eq, a.gtab, dig.data() + (i % B), B);
     for (uint32_t k = 0; k < redo[0]; k++) verify_msm<true>(a, redo[1 + k] >> 1, redo[1 + k] & 1u, a.gtab, dig.data() + (k % B), B);      // mirrors k_verify_msm_redo

@@ -89,7 +89,23 @@ void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags
 
 #define PLUME_MSM_DIG_ROWS (2 * PLUME_NDIG + PLUME_NPOS)
 void launch_verify_msm(const VerifyArgs& a0, hipStream_t st) {
-    mockhip::launch(st, [a = a0] {
+    if (a0.msm_pair && !a0.eq1long) mockhip::launch(st, [a = a0] {       // k_verify_msm_pair: 128 tasks of one equation per workgroup, halves 1 first (they park their sums), then halves 0 and the join
+        constexpr uint32_t H = kBlock / 2;
+        std::vector<int8_t> s_dig((size_t)PLUME_MSM_DIG_ROWS * kBlock);
+        std::vector<jac> parked(H);
+        std::vector<uint8_t> okb(H);
+        const uint32_t nb = (a.n + H - 1) / H;
+        for (uint32_t b = 0; b < 2 * nb; b++) {
+            const uint32_t eq = b >= nb ? 1u : 0u, blk = eq ? b - nb : b;
+            for (uint32_t l = 0; l < H && blk * H + l < a.n; l++) okb[l] = verify_msm_half(a, blk * H + l, eq, 1, a.gtab, s_dig.data() + H + l, kBlock, parked[l]) ? 1 : 0;
+            for (uint32_t l = 0; l < H && blk * H + l < a.n; l++) {
+                jac acc;
+                const bool ok = verify_msm_half(a, blk * H + l, eq, 0, a.gtab, s_dig.data() + l, kBlock, acc);
+                verify_msm_join(a, blk * H + l, eq, acc, ok, parked[l], okb[l] != 0);
+            }
+        }
+    });
+    else mockhip::launch(st, [a = a0] {
         std::vector<int8_t> s_dig((size_t)PLUME_MSM_DIG_ROWS * kBlock);
         const uint32_t nb = nblocks(a.n);
         grid(2 * nb, kBlock, [&](unsigned b, unsigned t) {

@@ -338,7 +338,9 @@ static void group_multi(uint64_t seed) {
     plume_destroy(ctx);
     g_what = "three shards on two devices, used from two caller threads in turn";
     int ids2[3] = {2, 2, 5};
+    setenv("PLUME_MSM_PAIR_MAX", "0", 1);                    // (these shards: one lane per chain whatever the size)
     REQUIRE(plume_init_multi(&ctx, ids2, 3) == 0);
+    unsetenv("PLUME_MSM_PAIR_MAX");
     apply(ctx, k);
     std::thread t([&] { g_what = "second caller thread"; check_verify(ctx, v2, 1); });
     t.join();
@@ -616,9 +618,11 @@ static void group_misc(uint64_t seed) {
     check_h2c_and_friends(ctx, empty, 0);
     g_what = "two contexts on one device share the generator's tables; the first to go leaves them to the other";
     plume_ctx* other = nullptr;
-    setenv("PLUME_INGEST_SPLIT_MAX", "20", 1);               // this context: calls of more than 20 items take the one-role ingest kernel and a scalar launch of its own
+    setenv("PLUME_INGEST_SPLIT_MAX", "20", 1);               // this context: calls of more than 20 items take the one-role ingest kernel and a scalar launch of its own,
+    setenv("PLUME_MSM_PAIR_MAX", "30", 1);                   // calls of more than 30 the multi-scalar kernel of large batches (one lane per chain; the default here: two half chains)
     REQUIRE(plume_init(&other, 7) == 0);
     unsetenv("PLUME_INGEST_SPLIT_MAX");
+    unsetenv("PLUME_MSM_PAIR_MAX");
     check_verify(other, v2, 0);
     plume_destroy(ctx);
     check_verify(other, clean, 1);

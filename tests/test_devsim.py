@@ -424,6 +424,40 @@ def test_two_role_ingest_gives_the_same_verdicts():
         D.set_ingest_two_roles(False)
 
 
+def test_paired_half_chains_give_the_same_verdicts():
+    """round 5: calls of at most 2^14 items run every long-form chain of the verifier as two halves -- the first joint slot on one lane, the second on another -- joined by one
+    checked addition (k_verify_msm_pair).  The host harness runs that form over the goldens, the edge cases, the verify_non_zk goldens, fuzzed batches and the crafted items
+    whose unchecked chains meet p == +-q (they are filed by the join and redone whole): every verdict as the oracle's; the same with the two-role ingest beside it and with
+    equation 1's short form asked for (the pair form then stays out of the way)."""
+    from tests import _fuzz
+    from tests.test_oracle_c import non_zk_args
+    D.set_msm_pair(True)
+    try:
+        for two_roles, eq1 in ((False, 0), (True, 0), (False, 1)):
+            D.set_ingest_two_roles(two_roles)
+            D.set_eq1_short(eq1)
+            for ver in (1, 2):
+                for items in (GOLD[f"verify_v{ver}"], [e for e in GOLD["edge"] if e["version"] == ver]):
+                    mb, off = OC.pack_msgs([bytes.fromhex(it["msg"]) for it in items])
+                    rp = OC.arr(items, "r_point", 64) if ver == 1 else None
+                    hr = OC.arr(items, "hashed_to_curve_r", 64) if ver == 1 else None
+                    got = D.verify_batch(ver, mb, off, OC.arr(items, "pk", 64), OC.arr(items, "nullifier", 64), OC.arr(items, "c", 32), OC.arr(items, "s", 32), rp, hr)
+                    assert [int(o) for o in got] == [it["ok"] for it in items]
+                n = 256
+                b = synth.sign_inputs(n, start=7777 + ver)
+                signed = OC.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"], nthreads=8)
+                v = _fuzz.fuzz_verify_batch(ver, signed, b, seed=191 + ver)
+                args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v.get("r_point"), v.get("hashed_to_curve_r"))
+                assert np.array_equal(D.verify_batch(*args), OC.verify_batch(*args, nthreads=8))
+                nz = [it for it in NONZK if it["version"] == ver]
+                got = D.verify_non_zk_batch(ver, *non_zk_args(nz))
+                assert [int(o) for o in got] == [it["ok"] for it in nz]
+    finally:
+        D.set_msm_pair(False)
+        D.set_ingest_two_roles(False)
+        D.set_eq1_short(1)
+
+
 def test_sign_edge_status():
     """out-of-range scalars and ragged messages: device sign path == C oracle, including status bits"""
     rng = random.Random(9)

@@ -147,6 +147,7 @@ struct plume_ctx {
     std::vector<Worker*> workers;
     HostSlot slot[4];                                              // host-pointer calls: staging slots (two for the one-lane pipeline, four when two lanes take the pieces in turn)
     plume_ctx* host_lane = nullptr;                                // ... the second lane of the host-pointer pipeline: a complete single-device context (workspace, streams), created on first use
+    size_t msm_pair_max = (size_t)1 << 14;                          // verify calls (slices) of at most this many items run k_verify_msm_pair (env PLUME_MSM_PAIR_MAX; 0: never)
     bool split_scalars = true;                                      // ... and the scalar stage in that kernel's idle role (env PLUME_SPLIT_SCALARS=0: a launch of its own, A/B)
     size_t ingest_split_max = (size_t)1 << 16;                     // verify calls (slices) of at most this many items run the ingest stage with two lanes per item (latency-bound there)
     int sign_uniform = 1;                                          // plume_set_sign_uniform: the signer's schedule (level 0, 1, 2).  Default 1 since round 5: no branch on a digit of sk or r
@@ -177,7 +178,7 @@ struct plume_ctx {
 // knob cannot reach some derived contexts and miss others (round 4's host lane did not inherit sign_uniform: VERDICT r4).
 static void inherit_tunables(plume_ctx* to, const plume_ctx* from) {
     to->chunk = from->chunk; to->sub_batches = from->sub_batches; to->overlap_min = from->overlap_min; to->sign_uniform = from->sign_uniform;
-    to->ingest_split_max = from->ingest_split_max; to->split_scalars = from->split_scalars;
+    to->ingest_split_max = from->ingest_split_max; to->split_scalars = from->split_scalars; to->msm_pair_max = from->msm_pair_max;
     to->jobs_per_lane = from->jobs_per_lane; to->jobs_per_lane_forced = from->jobs_per_lane_forced;
     to->host_piece = from->host_piece; to->host_first_piece = from->host_first_piece; to->host_tail_piece = from->host_tail_piece; to->host_register_min = from->host_register_min;
     to->host_lanes = from->host_lanes; to->host_sign_lanes = from->host_sign_lanes; to->eq1_short = from->eq1_short; to->eq1_short_min = from->eq1_short_min;
@@ -313,6 +314,7 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_HOST_FIRST_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_first_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_TAIL_PIECE")) { long v = std::atol(e); if (v >= 1) ctx->host_tail_piece = (size_t)v; }   // tuning knob
     if (const char* e = std::getenv("PLUME_HOST_REGISTER_MIN")) { long v = std::atol(e); if (v >= 0) ctx->host_register_min = (size_t)v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_MSM_PAIR_MAX")) { long v = std::atol(e); if (v >= 0) ctx->msm_pair_max = (size_t)v; }   // tuning / A-B knob (0: never)
     if (const char* e = std::getenv("PLUME_SPLIT_SCALARS")) ctx->split_scalars = std::atoi(e) != 0;   // A/B knob
     if (const char* e = std::getenv("PLUME_INGEST_SPLIT_MAX")) { long v = std::atol(e); if (v >= 0) ctx->ingest_split_max = (size_t)v; }   // tuning knob (0: never)
     if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::min(2, std::max(0, std::atoi(e)));   // default of new contexts (plume_set_sign_uniform); 0 opts out of the uniform schedule
@@ -762,6 +764,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         if (k == 0) ctx->redo_counters.clear();
         ctx->redo_counters.push_back(2 * lo + k);
         const bool two_roles = cnt <= ctx->ingest_split_max;
+        a.msm_pair = (!eq1short && cnt <= ctx->msm_pair_max) ? 1 : 0;             // a few thousand items: a chain's latency is the kernel's time, so each long-form chain runs as two halves on two lanes
         a.scalars_in_ingest = two_roles && ctx->split_scalars ? 1 : 0;             // the small-batch ingest kernel runs the scalar stage in its idle role: one launch less
         launch_verify_ingest(a, pre, two_roles); if (!overlapped) t.stage(a.scalars_in_ingest ? "verify_ingest_h2c+scalars" : "verify_ingest_h2c", st);
         if (!a.scalars_in_ingest) { launch_verify_scalars(a, pre); if (!overlapped) t.stage("verify_scalars", st); }

@@ -210,6 +210,35 @@ __global__ PLUME_MSM_BOUNDS void k_verify_msm_s(VerifyArgs a) {
     __shared__ int8_t s_dig[PLUME_MSM_DIG_ROWS * kBlock];
     verify_msm_body<1>(a, s_dig);
 }
+// Calls of a few thousand items (VerifyArgs::msm_pair; plume_stages.h verify_msm_half): a workgroup serves kBlock / 2 tasks of one equation, threads [0, 128) walk the first
+// joint slot of their task's chain, threads [128, 256) the second -- wave-uniform roles, so neither half pays for the other's additions -- and the halves meet once, through
+// LDS: half 0's lane adds them (checked) and stores.  2^14 items: the kernel's time falls from one long chain's latency to one half chain's.
+__global__ __launch_bounds__(kBlock, 3) void k_verify_msm_pair(VerifyArgs a) {      // (47 KiB of LDS: three workgroups per CU at most, so the register budget of three)
+    constexpr uint32_t H = kBlock / 2;
+    __shared__ int8_t s_dig[PLUME_MSM_DIG_ROWS * kBlock];
+    __shared__ uint32_t s_acc[3 * PLUME_FE_WORDS * H];
+    __shared__ uint8_t s_fl[H];
+    const uint32_t nb = (a.n + H - 1) / H;
+    const uint32_t eq = blockIdx.x >= nb ? 1u : 0u, blk = eq ? blockIdx.x - nb : blockIdx.x;
+    const uint32_t l = threadIdx.x & (H - 1), half = threadIdx.x >= H ? 1u : 0u;       // wave-uniform
+    const uint32_t i = blk * H + l;
+    const bool live = i < a.n;
+    jac acc;
+    bool ok = true;
+    if (live) ok = verify_msm_half(a, i, eq, half, a.gtab, s_dig + threadIdx.x, kBlock, acc);
+    if (live && half) {
+        PLUME_UNROLL for (int k = 0; k < PLUME_FE_WORDS; k++) { s_acc[k * H + l] = acc.x.v[k]; s_acc[(PLUME_FE_WORDS + k) * H + l] = acc.y.v[k]; s_acc[(2 * PLUME_FE_WORDS + k) * H + l] = acc.z.v[k]; }
+        s_fl[l] = (uint8_t)((ok ? 1u : 0u) | (acc.inf ? 2u : 0u));
+    }
+    __syncthreads();
+    if (live && !half) {
+        jac b;
+        PLUME_UNROLL for (int k = 0; k < PLUME_FE_WORDS; k++) { b.x.v[k] = s_acc[k * H + l]; b.y.v[k] = s_acc[(PLUME_FE_WORDS + k) * H + l]; b.z.v[k] = s_acc[(2 * PLUME_FE_WORDS + k) * H + l]; }
+        const uint32_t f = s_fl[l];
+        b.inf = (f & 2u) ? 1 : 0;
+        verify_msm_join(a, i, eq, acc, ok, b, (f & 1u) != 0);
+    }
+}
 // the tasks k_verify_msm filed (their unchecked chain met p == +-q), one per lane, with the checked additions; grid-stride over the filed count, so an honest batch's
 // launch finds nothing and returns
 // Workgroups of one wavefront: 8 KiB of digit rows, so that the launch (which normally finds nothing) never waits for LDS behind another batch's multi-scalar kernel.
@@ -464,7 +493,8 @@ void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags
     hipLaunchKernelGGL(k_tab_pass_b, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
 }
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {      // (a.redo[0] was zeroed by k_verify_scalars, which every verify pipeline runs first)
-    if (a.eq1long) hipLaunchKernelGGL(k_verify_msm_s, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    if (a.msm_pair && !a.eq1long) hipLaunchKernelGGL(k_verify_msm_pair, dim3(2 * ((a.n + kBlock / 2 - 1) / (kBlock / 2))), dim3(kBlock), 0, st, a);
+    else if (a.eq1long) hipLaunchKernelGGL(k_verify_msm_s, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
     else hipLaunchKernelGGL(k_verify_msm, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
     const unsigned redo_blocks = std::min(2 * nblocks(a.n) * (kBlock / kRedoBlock), 4096u);   // grid-stride: enough lanes for a wholly crafted batch to fill the chip
     hipLaunchKernelGGL(k_verify_msm_redo, dim3(redo_blocks), dim3(kRedoBlock), 0, st, a);

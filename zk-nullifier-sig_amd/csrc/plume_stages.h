@@ -170,6 +170,7 @@ struct VerifyArgs {
                           //     s in the generator's wide digits): the half-GCD's coefficients did not fit (no such input is known) or the caller forces it (tests)
     uint32_t* eq1k;       // 8 x n words, word-major: k = tau s mod n, multiplied by G through the comb
     const uint32_t* gcomb;  // the doubling-free comb of G (PLUME_COMB_WORDS), shared with the signer
+    int msm_pair;            // calls of a few thousand items: the long-form chains run as two halves on two lanes (k_verify_msm_pair; verify_msm_half below)
     int scalars_in_ingest;   // the two-role ingest kernel (small calls) runs verify_scalars in its role B: no k_verify_scalars launch for this call (plume_kernels.hip)
     int eq1force;         // test knob: 1 = file every item's equation 1 as "long form" (everything then runs through the redo launch's checked chain)
 };
@@ -397,6 +398,39 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
     }
     st_jac_soa(a.res, nt, t, acc);
     a.resinf[t] = (uint8_t)acc.inf;
+}
+
+// ---- calls of a few thousand items (k_verify_msm_pair, round 5) ----------------------------------------------------------------------------------------------------
+// Such a call leaves most SIMDs one wavefront or none: the multi-scalar kernel's time is the LATENCY of one chain, 130 doublings + 122 additions for equation 2.  There the
+// long-form chain of a task is cut in two -- half 0 walks the first joint slot alone (equation 1: the generator's wide digits; equation 2: H), half 1 the second (pk / the
+// nullifier): 130 doublings + 61 additions each, on two lanes of different wavefronts -- and the halves are joined by one checked addition.  More work in total (the doublings
+// run twice), so only where the machine is empty: VerifyArgs::msm_pair, set by the host for calls of at most 2^14 items.
+// Returns false when the unchecked half met p == +-q (the join then files the task for the redo launch, which runs the whole chain with checked additions as ever).
+PLUME_HD bool verify_msm_half(const VerifyArgs& a, uint32_t item, uint32_t eq, uint32_t half, const uint32_t* gtab, int8_t* dig, uint32_t stride, jac& acc) {
+    acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
+    if (a.itemflags[item]) return true;
+    const int8_t* dc = a.digs + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * a.n + item;
+    if (eq == 0) {       // rows as verify_msm lays them out: s's wide digits first, then the digits of -c
+        const int8_t* ds = a.digs + (size_t)PLUME_VDIG_SET * a.n + item;
+        if (half == 0) { PLUME_UNROLL for (int r = 0; r < 2 * PLUME_NDIG; r++) dig[(uint32_t)r * stride] = ds[(size_t)r * a.n]; }
+        else { PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) dig[(uint32_t)(2 * PLUME_NDIG + r) * stride] = dc[(size_t)r * a.n]; }
+    } else {
+        const int8_t* ds = a.digs + item;
+        if (half == 0) { PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) dig[(uint32_t)r * stride] = ds[(size_t)r * a.n]; }
+        else { PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) dig[(uint32_t)(PLUME_NPOS + r) * stride] = dc[(size_t)r * a.n]; }
+    }
+    const size_t ja = 3 * (size_t)item + 1, jb = 3 * (size_t)item + (eq ? 2 : 0);
+    const uint32_t* tab0 = eq ? (job_state(a.jobflags[ja]) == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr) : gtab;
+    const uint32_t* tab1 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
+    return msm_run_unchecked(acc, half == 0 ? tab0 : nullptr, half == 1 ? tab1 : nullptr, dig, stride, eq == 0);
+}
+// the join, by half 0's lane: acc0 += acc1 with the checked Jacobian addition (the two halves may well meet in p == +-q: a valid equation 2 whose halves are H-multiples)
+PLUME_HD void verify_msm_join(const VerifyArgs& a, uint32_t item, uint32_t eq, jac& acc0, bool ok0, const jac& acc1, bool ok1) {
+    const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + eq;
+    if (!ok0 || !ok1) { redo_file(a.redo, (uint32_t)t); return; }
+    jac_add(acc0, acc1);
+    st_jac_soa(a.res, nt, t, acc0);
+    a.resinf[t] = (uint8_t)acc0.inf;
 }
 
 PLUME_HD void verify_finalize(const VerifyArgs& a, uint32_t i) {
