@@ -120,6 +120,8 @@ int plume_set_eq1_short(plume_ctx* ctx, int mode);
  *   PLUME_HOST_PIECE, PLUME_HOST_FIRST_PIECE, PLUME_HOST_TAIL_PIECE, PLUME_HOST_REGISTER_MIN, PLUME_HOST_LANES (1 | 2), PLUME_HOST_SCHEDULE (explicit piece list, read per call)
  *                                                        the host-pointer pipeline (plume_set_host_*)
  *   PLUME_INGEST_SPLIT_MAX   verify calls of at most this many items run the ingest stage with two lanes per item (default 65536; 0: never)
+ *   PLUME_MSM_PAIR_MAX       verify calls of at most this many items run every long-form chain of the multi-scalar stage as two half chains on two lanes, joined by one checked
+ *                            addition (default 16384; 0: never): on a machine a small call leaves empty, the kernel's time is one chain's latency
  *   PLUME_JOBS_PER_LANE      jobs per lane of the table passes (default: 3..6 by batch size)
  *   PLUME_SIGN_UNIFORM       default level of plume_set_sign_uniform (0, 1, 2; default 1)
  *   PLUME_EQ1_SHORT, PLUME_EQ1_SHORT_MIN   plume_set_eq1_short's mode and the smallest call that takes the short form (default 1, 131072)

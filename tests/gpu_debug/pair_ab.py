@@ -19,7 +19,7 @@ for ver in (1, 2):
         b = synth.sign_inputs(n)
         signed = engines[0].sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
         v = synth.corrupt_for_verify(ver, b, signed)
-        t = {k: torch.from_numpy(np.ascontiguousarray(v[k])).to(dev) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
+        t = {k: torch.from_numpy(np.ascontiguousarray(v[k])).to(dev) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r") if k in v}
         off = torch.from_numpy(v["off"].view(np.int64)).to(dev)
         mb = int(v["off"][-1])
         exp = synth.expected_ok(n)
