@@ -294,3 +294,43 @@ def test_ragged_calls_through_randomly_configured_contexts():
     (A child process: the script owns its engines.  Round 5 ran it for 2 900 iterations: profiles/r05_soak.txt.)"""
     r = subprocess.run([sys.executable, str(ROOT / "tests" / "gpu_debug" / "soak_ragged.py"), "60", "5"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "ragged soak ok: 60 iterations" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_half_chains_of_small_calls_give_the_one_lane_verdicts():
+    """calls of at most 2^14 items run every long-form chain of the multi-scalar stage as two half chains on two lanes (k_verify_msm_pair): the verdicts are those of a
+    context that never does (PLUME_MSM_PAIR_MAX=0) and the CPU's -- on a fuzzed batch salted with the crafted items whose slots meet in p == +-q (pk = G, s = +-c small:
+    with half chains the generator's slot and pk's meet in the JOIN, a checked addition, so nothing of theirs is filed any more) and with items whose two slots are the same
+    point (nullifier = H-multiple games: pk = nullifier), V1 and V2, several sizes around the threshold"""
+    import zk_nullifier_sig_amd as plume
+    from oracle import plume_oracle as O
+    from tests import _cpu_fast as CF
+    from tests import _fuzz
+    os.environ["PLUME_MSM_PAIR_MAX"] = "0"
+    try:
+        one = plume.Engine(0)
+    finally:
+        del os.environ["PLUME_MSM_PAIR_MAX"]
+    two = plume.Engine(0)
+    try:
+        for ver, n in ((1, 5000), (2, 3001), (1, 16384), (1, 16385), (2, 1), (1, 130)):
+            b = synth.sign_inputs(n, start=88_000_000 + n)
+            sg = two.sign_batch(ver, b["msgs"], b["off"], b["sk"], b["r"])
+            v = _fuzz.fuzz_verify_batch(ver, sg, b, seed=n)
+            idx = np.arange(3, n, 17)
+            d = (idx % 8 + 1).astype(np.uint8)
+            v["pk"][idx] = np.frombuffer(O.pt_bytes(O.G), dtype=np.uint8)
+            v["c"][idx] = 0; v["c"][idx, 31] = d
+            v["s"][idx] = 0; v["s"][idx, 31] = d
+            minus = idx[::2]
+            if len(minus):
+                v["s"][minus] = np.frombuffer(b"".join((O.N - int(x)).to_bytes(32, "big") for x in d[::2]), dtype=np.uint8).reshape(-1, 32)
+            same = np.arange(7, n, 29)
+            v["nullifier"][same] = v["pk"][same]
+            args = (ver, v["msgs"], v["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"] if ver == 1 else None, v["hashed_to_curve_r"] if ver == 1 else None)
+            want = CF.verify_batch(*args, nthreads=min(32, os.cpu_count() or 1))
+            for eq1 in (0, 1):
+                one.set_eq1_short(eq1); two.set_eq1_short(eq1)
+                assert np.array_equal(one.verify_batch(*args), want), (ver, n, eq1, "one lane per chain")
+                assert np.array_equal(two.verify_batch(*args), want), (ver, n, eq1, "half chains")
+    finally:
+        one.close(); two.close()
