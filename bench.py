@@ -37,8 +37,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # Every context this script creates records the per-stage timing events (off by default in the library since 0.5: ~6 us of idle GPU each): roofline.kernel_ms is the
-# multi-scalar kernel's duration by HIP events over the timed region, as the contract asks -- so `value` carries their cost (0.2 % at 2^20); the 2^16 entry also
-# reports the default, event-free call (other_workloads.verify_v1_2p16.ms_per_batch).
+# multi-scalar kernel's duration by HIP events over the timed region, as the contract asks -- so `value` carries their cost (0.2 % at 2^20: five events of ~6 us in a
+# step of 18 ms; the library's default, without them, is that much FASTER than `value`); the 2^16 entry also reports the default, event-free call
+# (other_workloads.verify_v1_2p16.ms_per_batch).
 os.environ.setdefault("PLUME_STAGE_TIMES", "1")
 sys.path.insert(0, str(ROOT))
 
@@ -637,12 +638,17 @@ def main():
     fence()
     t0 = time.perf_counter()
     stage_acc = {}
+    clk_acc = []                            # the multi-scalar kernel's shader clock, sampled inside the kernel (plume_last_msm_clock), one value per serial call
     for i in range(a.steps):
         step(i)
         if F == 1 and a.steps <= 64:  # per-stage HIP-event times (events are recorded on the launch stream inside the library; the library's default launch order is strictly serial)
             torch.cuda.current_stream().synchronize()
             for name, ms in eng.last_stage_times():
                 stage_acc[name] = stage_acc.get(name, 0.0) + ms
+            if not sign:
+                g = eng.last_msm_clock_ghz()
+                if g:
+                    clk_acc.append(g)
     fence()
     elapsed_rank = time.perf_counter() - t0
     stage_div = a.steps
@@ -662,6 +668,10 @@ def main():
             torch.cuda.current_stream().synchronize()
             for name, ms in eng.last_stage_times():
                 stage_acc[name] = stage_acc.get(name, 0.0) + ms
+            if not sign:
+                g = eng.last_msm_clock_ghz()
+                if g:
+                    clk_acc.append(g)
         serial_s = (time.perf_counter() - ts) / S
         stage_div = S
         in_flight_info = {"batches_in_flight": F, "stage_ms_in_flight": {k: round(x, 4) for k, x in infl.items()},
@@ -744,9 +754,9 @@ def main():
             bytes_item = BYTES_PER_SIGN if sign else BYTES_PER_ITEM[ver]
             hbm_achieved = bytes_item * n / dom_s / 1e9
             # HBM bytes per launch from the committed PMC passes (2^20-item launch, scaled to this batch)
-            from zk_nullifier_sig_amd import capi as _capi
-            short1 = (not sign) and _capi.eq1_short_applies(ver, n)            # equation 1 in its short form (csrc/plume_eis.h): the launch is k_verify_msm_s
-            dom_kernel = "k_" + dom + ("_s" if (short1 and dom == "verify_msm") else "")
+            ran = None if sign else eng.last_msm_kernel()                      # what the context's last verify call (the serial pass's) LAUNCHED: plume_last_msm_kernel
+            short1 = ran == "k_verify_msm_s"                                   # equation 1 in its short form (csrc/plume_eis.h)
+            dom_kernel = ran if (ran and dom == "verify_msm") else "k_" + dom
             tb, tsrc = pmc_traffic("plume::" + dom_kernel, eng.version())
             traffic_bytes = int(tb * (n / float(1 << 20))) if tb else None
             try:
@@ -785,6 +795,19 @@ def main():
                                                    f"Fp-mult (81 products + 22 fold + 8 column hand-offs), 75 per squaring; the accounting stays on the frozen 72")}
                 # what the SIMDs actually issued (committed counter pass of the same build): all VALU slots and the multiply-adds among them, against the same peak.  `frac` counts
                 # the ACCOUNTING's multiply-adds; these two say how full the issue ports are and how many multiply-adds the code spends per accounted one.
+                line["roofline"]["frac_is"] = ("reference-equivalent work: the frozen accounting's multiply-adds (what the reference's two equations ask for) over kernel time over the probe's "
+                                               "rate -- NOT the share of issue slots taken (issue_frac.valu_slots) nor the multiply-adds executed (issue_frac.executed_macs)")
+                if clk_acc:
+                    # box-independent: the kernel's duration in shader cycles.  The clock is sampled INSIDE the kernel in this run (one workgroup in 32 adds its lifetime in shader cycles
+                    # and in constant-rate wall-clock ticks to two counters: plume_last_msm_clock), so a box that runs the kernel at a lower clock shows the same cycle count
+                    ghz = sorted(clk_acc)[len(clk_acc) // 2]
+                    line["roofline"]["clock_ghz_in_kernel_this_run"] = round(ghz, 4)
+                    line["roofline"]["cycles_per_item"] = round(dom_s * ghz * 1e9 / n, 3)
+                    line["roofline"]["simd_cycles_per_item"] = round(dom_s * ghz * 1e9 * 1024 / n, 1)
+                    line["roofline"]["peak_at_this_runs_kernel_clock"] = round(256 * 4 * 16 * ghz * 1e9, 1)
+                    line["roofline"]["frac_at_this_runs_kernel_clock"] = round(msm / (256 * 4 * 16 * ghz * 1e9), 4)
+                    line["roofline"]["cycles_note"] = ("cycles_per_item = kernel_ms x the kernel's own shader clock / items (chip-wide cycles per verify); simd_cycles_per_item = x 1024 SIMDs: compare with "
+                                                       "issue_frac.valu_insts_per_item x 4 cycles per multiply-add-class wave instruction / 64 lanes")
                 iss = pmc_issue("plume::" + dom_kernel, eng.version())
                 if iss and iss.get("valu_wave_insts") and dom_parts:
                     iss2 = pmc_issue("plume::k_sign_hdbl", eng.version())        # the signer's roofline spans both launches: so do its instruction counts
@@ -800,6 +823,7 @@ def main():
                         "executed_macs": round(lane_ops * share / dom_s / mad_rate, 4) if share else None,
                         "executed_macs_per_accounted_mac": round(lane_ops * share / (dom_fpmul * MACS_PER_FPMUL * n), 3) if share else None,
                         "valu_wave_insts_per_launch": iss["valu_wave_insts"], "valu_insts_per_lane": round(iss["valu_wave_insts"] / iss["waves"], 1) if iss.get("waves") else None,
+                        "valu_insts_per_item": round(iss["valu_wave_insts"] * 64.0 / float(1 << 20), 1),
                         "mad_share_of_valu": share, "clock_ghz_in_kernel": iss.get("clock_ghz"),
                         "peak_at_kernel_clock": round(256 * 4 * 16 * iss["clock_ghz"] * 1e9, 1) if iss.get("clock_ghz") else None,
                         "frac_at_kernel_clock": round(msm / (256 * 4 * 16 * iss["clock_ghz"] * 1e9), 4) if iss.get("clock_ghz") else None,

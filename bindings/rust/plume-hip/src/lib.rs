@@ -87,6 +87,8 @@ extern "C" {
     fn plume_set_host_lanes(ctx: *mut plume_ctx, lanes: c_int) -> c_int;
     fn plume_set_stage_timing(ctx: *mut plume_ctx, on: c_int) -> c_int;
     fn plume_set_eq1_short(ctx: *mut plume_ctx, mode: c_int) -> c_int;
+    fn plume_get_eq1_short(ctx: *const plume_ctx, min_items: *mut usize) -> c_int;
+    fn plume_last_msm_kernel(ctx: *const plume_ctx) -> *const c_char;
     fn plume_shard_numa_node(ctx: *const plume_ctx, shard: c_int) -> c_int;
     fn plume_aggregate_check(ctx: *mut plume_ctx, version: c_int, mode: c_int, n: usize, msgs: *const u8, msg_off: *const u64, pk: *const u8, nullifier: *const u8, c: *const u8,
                              s: *const u8, r_point: *const u8, hashed_to_curve_r: *const u8, seed: *const u8, hash_ok: *mut u8, result: *mut u8) -> c_int;
@@ -285,13 +287,18 @@ impl HipEngine {
     pub fn set_sub_batches(&self, k: i32) -> Result<(), HipError> { if unsafe { plume_set_sub_batches(self.0, k) } == 0 { Ok(()) } else { Err(last_error()) } }
     /// Batches in flight (`plume_set_in_flight`): with 2, device-resident calls issued on different streams run side by side (two lanes of the context); default 1
     pub fn set_in_flight(&self, k: i32) -> Result<(), HipError> { if unsafe { plume_set_in_flight(self.0, k) } == 0 { Ok(()) } else { Err(last_error()) } }
-    /// The verifier's first equation where `r_point` is given (`plume_set_eq1_short`): 1 = the short form (default), 0 = the long form always, 2 = test mode.  Verdicts do not depend on it.
+    /// The verifier's first equation where `r_point` is given (`plume_set_eq1_short`): 1 = the short form for calls of at least `eq1_short()?.1` items (default), 3 = the short
+    /// form whatever the size, 0 = the long form always, 2 = test mode (every item through the fallback).  Verdicts do not depend on it.
     pub fn set_eq1_short(&self, mode: i32) -> Result<(), HipError> { if unsafe { plume_set_eq1_short(self.0, mode as c_int) } == 0 { Ok(()) } else { Err(last_error()) } }
+    /// `(mode, min_items)` in force (`plume_get_eq1_short`).
+    pub fn eq1_short(&self) -> Result<(i32, usize), HipError> { let mut m: usize = 0; let r = unsafe { plume_get_eq1_short(self.0, &mut m) }; if r >= 0 { Ok((r as i32, m)) } else { Err(last_error()) } }
+    /// Measurement hook (`plume_last_msm_kernel`): the multi-scalar kernel the last verify call on this context launched.
+    pub fn last_msm_kernel(&self) -> Option<String> { let p = unsafe { plume_last_msm_kernel(self.0) }; if p.is_null() { None } else { Some(unsafe { std::ffi::CStr::from_ptr(p) }.to_string_lossy().into_owned()) } }
     /// The level this context signs at (`plume_get_sign_uniform`).
     pub fn sign_uniform(&self) -> Result<i32, HipError> { let l = unsafe { plume_get_sign_uniform(self.0) }; if l >= 0 { Ok(l as i32) } else { Err(last_error()) } }
-    /// Host-pointer calls: 1 = every piece on the context itself, 2 (default) = pieces alternate between the context and a second lane.
     /// per-stage timing events inside the device pipelines: off by default (library 0.5); turn on before a call whose `last_stage_times` are wanted
     pub fn set_stage_timing(&self, on: bool) -> Result<(), HipError> { if unsafe { plume_set_stage_timing(self.0, on as c_int) } == 0 { Ok(()) } else { Err(last_error()) } }
+    /// Host-pointer calls: 1 = every piece on the context itself, 2 (default) = pieces alternate between the context and a second lane.
     pub fn set_host_lanes(&self, lanes: i32) -> Result<(), HipError> { if unsafe { plume_set_host_lanes(self.0, lanes as c_int) } == 0 { Ok(()) } else { Err(last_error()) } }
     /// The signer's schedule (`plume_set_sign_uniform`).  k256's multiplication is constant-time, so the library's default is level 1 (no branch on a digit of `sk` or `r` in
     /// the kernels that walk them; table rows still gathered at digit-dependent addresses).  0 = fastest, not uniform; 2 = no secret-dependent address either (every row of a

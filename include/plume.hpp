@@ -68,7 +68,9 @@ class Engine {
     int sign_uniform() const { const int l = plume_get_sign_uniform(ctx_); check(l < 0 ? l : 0, "plume_get_sign_uniform"); return l; }   // 1 by default (library 0.4)
     void set_stage_timing(bool on) { check(plume_set_stage_timing(ctx_, on ? 1 : 0), "plume_set_stage_timing"); }   // off by default (library 0.5): needed before last_stage_times
     void set_host_lanes(int lanes) { check(plume_set_host_lanes(ctx_, lanes), "plume_set_host_lanes"); }
-    void set_eq1_short(int mode) { check(plume_set_eq1_short(ctx_, mode), "plume_set_eq1_short"); }   // the verifier's first equation where R is given (plume_hip.h): 1 short (default), 0 long, 2 test
+    void set_eq1_short(int mode) { check(plume_set_eq1_short(ctx_, mode), "plume_set_eq1_short"); }   // the verifier's first equation where R is given (plume_hip.h): 1 short for large calls (default), 3 short always, 0 long, 2 test
+    int eq1_short(size_t* min_items = nullptr) const { const int m = plume_get_eq1_short(ctx_, min_items); check(m < 0 ? m : 0, "plume_get_eq1_short"); return m; }
+    const char* last_msm_kernel() const { return plume_last_msm_kernel(ctx_); }                       // measurement hook: the multi-scalar kernel the last verify call launched
     // the engine single-item calls use when none is passed: PLUME_DEVICES="0,1,.." (one multi-device context) or device 0
     static Engine& shared() {
         static std::unique_ptr<Engine> e;

@@ -49,8 +49,10 @@ typedef struct plume_ctx plume_ctx;
  * that needs them, ONCE per device and process -- (1..2^23)*G for the verifier's 24-bit windows (1 GiB, first verify / verify_non_zk call) and the signer's doubling-free
  * comb, 15 windows of 2^17 rows (252 MiB, first sign / SEC1-DER export / aggregate check) -- about 18 ms for both, synchronously inside that call.  They are read-only and
  * shared by every context of the process on that device; the last context to go frees them.  A verify-only process never holds the comb, a sign-only one never the 1 GiB table.
- * plume_destroy (and plume_set_in_flight when it takes lanes away) waits for the whole device (hipDeviceSynchronize) before releasing anything: device-resident calls may
- * have left work on caller streams. */
+ * plume_destroy (and plume_set_in_flight when it takes lanes away) waits for the context's OWN work before it releases anything -- the last device-resident call it was
+ * given, on whatever stream (every such call leaves an event behind its last kernel and waits for its predecessor's), and its private streams -- and does not call
+ * hipDeviceSynchronize.  It then frees its workspace with hipFree, which the HIP runtime may itself implement with a device-wide wait: a caller that must not stall
+ * other streams should destroy contexts at a quiet point.  A caller-provided stream must stay alive until the context's last call on it has finished. */
 int plume_init(plume_ctx** out, int device_id);
 /* Create a multi-device context: one shard (a complete single-device context with its own streams and workspace, driven by its own
  * worker thread) per entry of device_ids (SURVEY.md §8b sketch, §8e).  Every HOST-POINTER entry point below then splits its batch
@@ -85,7 +87,9 @@ int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
 /* Batches in flight (default 1).  A context runs its device-resident calls one at a time: they share its workspace, so calls issued on different streams queue.  With
  * batches = 2 the calls go in turn to two lanes of the context (each with a workspace, streams and events of its own; the generator's fixed tables are shared), and calls the
  * caller issues on DIFFERENT streams run side by side: the memory-bound table passes and the ramps / tails of one batch's kernels fit beside the issue-bound multi-scalar
- * kernel of the other -- 20.1 instead of 20.8 ms per 2^20 verifies, 1.37 instead of 1.77 ms per 2^16 on the MI355X; a third lane gains nothing more (1..4 accepted).
+ * kernel of the other -- about 1 % per 2^20-item batch on the MI355X (17.95 against 18.14 ms, round 5), a third lane gains nothing more (1..4 accepted).  It pays for
+ * LARGE calls only: since the small-call kernels of round 5 a 2^16-item call is latency-bound and two of them side by side measured 1.55 against 1.42 ms each, so device-resident
+ * calls of fewer than 2^17 items (env PLUME_IN_FLIGHT_MIN) all run on the context's first lane, whatever `batches` is.
  * Results do not depend on it; calls on one stream keep that stream's order -- including NULL, which always means the stream of the context the caller holds,
  * whichever lane serves the call (so a sign followed by a verify of its outputs, both with stream = NULL, stay ordered).  Costs a second per-batch workspace.  Single-device contexts only (a multi-device context
  * already runs its shards side by side).  plume_last_stage_times / plume_last_redo_tasks then report the lane of the last device-resident call. */
@@ -110,11 +114,18 @@ int plume_get_sign_uniform(const plume_ctx* ctx);
 /* The verifier's first equation, R' = s G - c pk compared with the given r_point (rust-k256/src/lib.rs:101,115-121), for calls that GIVE r_point as a 64-byte record (V1
  * verify, verify_non_zk).  It is an identity check, so it may be multiplied by any tau != 0: with (tau, upsilon) from a half-GCD of c in the Eisenstein integers
  * (tau c = upsilon mod n through lambda; all four coefficients of about 64 bits -- csrc/plume_eis.h) the GPU checks  k G - upsilon pk - (tau - 1) R == R,  k = tau s mod n:
- * 64 doublings instead of 128 on that equation, the generator's term from the signer's comb, one more window table per item (R).  Verdicts are identical by construction (and the pair is re-checked per item -- tau c == upsilon mod n -- before it is used; a failure, which cannot happen, would send the item to the long form)
- * (the equivalence is exact, not probabilistic); mode 1 (default) = short form for calls of at least 2^17 items, 3 = for calls of any size, 0 = long form always,
- * 2 = test mode (every item takes the scalar stage's fallback: the long form in the checked chain of the redo launch).  Env PLUME_EQ1_SHORT, PLUME_EQ1_SHORT_MIN.  Measured on the MI355X, 2^20 V1 verifies:
- * k_verify_msm -7.2 %, the step -1 % serial / -1.6 % with two batches in flight (the fourth table and the half-GCD take most of it back: DESIGN.md). */
+ * 66 doublings instead of 128 on that equation, the generator's term from the signer's comb, one more window table per item (R).  Verdicts are identical by construction:
+ * the equivalence is exact, not probabilistic, and the pair is re-checked per item (tau c == upsilon mod n) before it is used -- a failure, which cannot happen, would send
+ * the item to the long form.
+ *   mode 1 (default): short form for calls of at least PLUME_EQ1_SHORT_MIN items (plume_get_eq1_short reports the threshold)
+ *   mode 3: short form for calls of any size          mode 0: long form always
+ *   mode 2: test mode -- every item takes the scalar stage's fallback, i.e. the long form inside the checked chain of the redo launch
+ * Env PLUME_EQ1_SHORT, PLUME_EQ1_SHORT_MIN set the defaults of new contexts.  Measured on the MI355X, 2^20 V1 verifies (round 5, three-row tables): k_verify_msm -7 %,
+ * the step -2.5 % (the fourth table and the half-GCD take the rest back: DESIGN.md). */
 int plume_set_eq1_short(plume_ctx* ctx, int mode);
+/* the mode in force (0..3, or a negative error code); min_items, when not NULL, receives the smallest call (items) that takes the short form in mode 1.  The rule looks at
+ * the CALL's n, also when plume_set_sub_batches cuts the call into slices. */
+int plume_get_eq1_short(const plume_ctx* ctx, size_t* min_items);
 /* Environment knobs read when a context is created (tuning and A/B runs; results never depend on them):
  *   PLUME_SUB_BATCHES, PLUME_SERIAL, PLUME_OVERLAP_MIN   sub-batch overlap of the device-resident calls (plume_set_sub_batches)
  *   PLUME_HOST_PIECE, PLUME_HOST_FIRST_PIECE, PLUME_HOST_TAIL_PIECE, PLUME_HOST_REGISTER_MIN, PLUME_HOST_LANES (1 | 2), PLUME_HOST_SCHEDULE (explicit piece list, read per call)
@@ -378,6 +389,13 @@ int plume_set_stage_timing(plume_ctx* ctx, int on);
  * tasks each: that is all they cost -- their wavefront neighbours no longer wait for them.  Counts the last device-resident call (for a host-pointer call: its last piece;
  * for a multi-device context: the first shard).  Synchronises with the device. */
 int plume_last_redo_tasks(plume_ctx* ctx, uint64_t* count);
+/* Measurement hook: the multi-scalar kernel the last verify call served by this context launched -- "k_verify_msm" (both equations in the long form), "k_verify_msm_s"
+ * (equation 1 in the short form) or "k_verify_msm_pair" (half chains: small calls); NULL before the first verify.  Reports the same call as plume_last_stage_times.  A static string. */
+const char* plume_last_msm_kernel(const plume_ctx* ctx);
+/* Measurement hook: the shader clock (GHz) the multi-scalar kernel of the last verify call on this context ran at, sampled INSIDE that kernel -- one workgroup in 32 adds the
+ * shader-clock cycles and the constant-rate wall-clock ticks it lived for to two counters.  kernel time x this clock = the kernel's duration in cycles, a figure that does not
+ * move with the box's power / thermal state the way the time does.  Only with stage timing on (plume_set_stage_timing) before the call; PLUME_ERR_ARG otherwise. */
+int plume_last_msm_clock(plume_ctx* ctx, double* ghz);
 /* VALU issue-rate microbenchmark (32 waves per CU, 8 independent chains per lane, `iters` x 8 instructions per lane):
  * returns operations per second chip-wide (<= 0 on error).  kind: 0 v_mad_u64_u32, 1 v_addc_co_u32, 2 v_mul_lo_u32,
  * 3 v_mad_u32_u24, 4 v_add_u32, 5 one Fp multiplication, 6 one Fp squaring, 7 v_fma_f64, 8 v_lshl_add_u64.

@@ -58,7 +58,47 @@ def fuzz_verify_batch(ver, signed, b, seed):
             a, bb = rng.choice([("r_point", "hashed_to_curve_r"), ("pk", "nullifier")])
             t = v[a][i].copy(); v[a][i] = v[bb][i]; v[bb][i] = t
         # 13..15: honest
+    plant_nonce_zero(ver, v, b, seed)
     return v
+
+
+def plant_nonce_zero(ver, v, b, seed, every=48, tamper=True):
+    """Where the batch carries its secret keys (b["sk"]): about one item in `every` becomes the signature with nonce r = 0 -- R = Hr = identity, c = SHA256(.. || 00 || 00)
+    mod n, s = c sk -- which the reference's verify ACCEPTS (no nonce check anywhere in rust-k256/src/lib.rs:93-145; R' and Hr' come out as the identity), and half of the
+    planted items are then tampered in one field.  It is the one valid input on which both equations END at the identity: the short form's accumulator, the long form's last
+    addition and the half chains' join all meet their exceptional case on an expected-accept item.  The records come from the C oracle's signer (r = 0 is a status bit there,
+    the outputs are still the reference's arithmetic).  Returns the planted indices."""
+    if "sk" not in b:
+        return np.zeros(0, dtype=np.int64)
+    from tests import _oracle_c as OC
+    rng = random.Random(seed ^ 0x5A5A)
+    n = len(b["off"]) - 1
+    idx = np.array(sorted(rng.sample(range(n), max(1, n // every))), dtype=np.int64)
+    lo, hi = b["off"][idx].astype(np.int64), b["off"][idx + 1].astype(np.int64)
+    msgs = [b["msgs"][a:z].tobytes() for a, z in zip(lo, hi)]
+    mb, off = OC.pack_msgs(msgs)
+    sg = OC.sign_batch(ver, mb, off, np.ascontiguousarray(b["sk"][idx]), np.zeros((len(idx), 32), dtype=np.uint8), nthreads=4)
+    assert not sg["r_point"].any() and not sg["hashed_to_curve_r"].any() and (sg["status"] & 2).all()
+    for k, i in enumerate(idx):
+        v["msgs"][lo[k]:hi[k]] = b["msgs"][lo[k]:hi[k]]                 # (an earlier mutation may have flipped a message bit)
+        for f in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r"):
+            if f in v:
+                v[f][i] = sg[f][k]
+        t = rng.randrange(12) if tamper else 11
+        if t == 0:
+            v["s"][i, 31] ^= 1
+        elif t == 1:
+            v["c"][i, rng.randrange(32)] ^= 1 << rng.randrange(8)
+        elif t == 2:
+            v["nullifier"][i] = v["nullifier"][(i + 1) % n]
+        elif t == 3 and "r_point" in v:
+            v["r_point"][i] = v["pk"][i]
+        elif t == 4 and "hashed_to_curve_r" in v:
+            v["hashed_to_curve_r"][i] = v["nullifier"][i]
+        elif t == 5 and hi[k] > lo[k]:
+            v["msgs"][lo[k]] ^= 1
+        # 6..11: the planted signature stays as it is (expected: accepted)
+    return idx
 
 
 def fuzz_non_zk_batch(ver, signed, b, seed):

@@ -271,9 +271,9 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
     const bool eq1short = g_eq1_short != 0 && rpt != nullptr && rpt33 == nullptr && (version == 1 || mode == PLUME_MODE_NON_ZK);          // mirrors verify_device
     const size_t J = eq1short ? 4 : 3;
     std::vector<uint32_t> bases(PLUME_BASE_WORDS * J * (size_t)n), tab((size_t)J * n * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2 * (size_t)n), eq1k(8 * (size_t)n + 1);
-    std::vector<uint8_t> jobflags(J * (size_t)n), itemflags(n), resinf(2 * (size_t)n), eq1long(n + 1);
+    std::vector<uint8_t> jobflags(J * (size_t)n), itemflags(n), resinf(2 * (size_t)n), eq1fall(n + 1);
     VerifyArgs a; memset(&a, 0, sizeof a);
-    if (eq1short) { a.eq1long = eq1long.data(); a.eq1k = eq1k.data(); a.gcomb = shared_gcomb().data(); a.eq1force = g_eq1_short == 2 ? 1 : 0; }
+    if (eq1short) { a.eq1fall = eq1fall.data(); a.eq1k = eq1k.data(); a.gcomb = shared_gcomb().data(); a.eq1force = g_eq1_short == 2 ? 1 : 0; }
     a.mode = mode; a.msgs_bytes = msgs_bytes == ~0ull ? msg_off[n] : msgs_bytes;
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.ok = ok; a.preflags = preflags; a.rpt33 = rpt33; a.hr33 = hr33;
     a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data(); a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data();
@@ -559,10 +559,10 @@ int ds_eq1_short(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t p
     const uint32_t f = load_affine_be(x, y, pb), fr = load_affine_be(rx, ry, rb);
     if (f == PLUME_JOB_INVALID || fr == PLUME_JOB_INVALID) return 0;
     std::vector<uint32_t> bases(PLUME_BASE_WORDS * 4), tab(4 * PLUME_TAB_WORDS), res(PLUME_JAC_WORDS * 2), eq1k(8);
-    std::vector<uint8_t> jobflags(4), itemflags(1, 0), resinf(2), eq1long(1);
+    std::vector<uint8_t> jobflags(4), itemflags(1, 0), resinf(2), eq1fall(1);
     VerifyArgs a; memset(&a, 0, sizeof a);
     a.version = 1; a.mode = PLUME_MODE_VERIFY; a.n = 1; a.c = cb; a.s = sb; a.bases = bases.data(); a.jobflags = jobflags.data(); a.itemflags = itemflags.data();
-    a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data(); a.gtab = gtab.data(); a.gcomb = shared_gcomb().data(); a.eq1long = eq1long.data(); a.eq1k = eq1k.data();
+    a.tab = tab.data(); a.res = res.data(); a.resinf = resinf.data(); a.gtab = gtab.data(); a.gcomb = shared_gcomb().data(); a.eq1fall = eq1fall.data(); a.eq1k = eq1k.data();
     a.eq1force = g_eq1_short == 2 ? 1 : 0;
     jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
     for (int j = 0; j < 3; j++) { st_base(a.bases, j, p); a.jobflags[j] = (uint8_t)(f | PLUME_JOB_AFFINE); }
@@ -572,7 +572,7 @@ int ds_eq1_short(const uint8_t s_be[32], const uint8_t c_be[32], const uint8_t p
     std::vector<int8_t> dig(2 * PLUME_NDIG + PLUME_NPOS), digs(PLUME_VDIG_ROWS);
     a.digs = digs.data();
     verify_scalars(a, 0);
-    if (used_long) *used_long = eq1long[0];
+    if (used_long) *used_long = eq1fall[0];
     uint32_t redo[3] = {0, 0, 0};
     a.redo = redo;
     verify_msm<false>(a, 0, 0, a.gtab, dig.data(), 1);

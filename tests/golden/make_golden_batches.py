@@ -156,6 +156,27 @@ def edge_cases():
         out.append((ver, dict(msg=hx(msg), pk=hx(O.pt_bytes(sig["pk"])), nullifier=hx(O.pt_bytes(sig["nullifier"])),
                               c=hx(sig["c"].to_bytes(32, "big")), s=hx(sig["s"].to_bytes(32, "big")),
                               r_point=hx(O.pt_bytes(sig["r_point"])), hashed_to_curve_r=hx(O.pt_bytes(sig["hashed_to_curve_r"])), note="sk=2, r=3")))
+        # r = 0: R = Hr = identity, c = SHA256(.. || 00 || 00) mod n, s = c sk.  The reference's verify has no nonce check (rust-k256/src/lib.rs:101-143): it computes
+        # R' = s G - c pk = identity, Hr' = s H - c nul = identity and ACCEPTS.  This is the one valid input on which every form of the two equations ends AT the identity
+        # (the short form's accumulator k G - upsilon pk - (tau - 1) R, the long form's last addition, the half chains' join), and on which V2 hashes a 35-byte preimage.
+        for tag, skz, mz in (("", O.synth_sk(4242), b"nonce zero"), (", empty message", O.synth_sk(4243), b""), (", sk=1", 1, b"nonce zero"), (", sk=n-1", O.N - 1, b"nonce zero")):
+            sig = O.sign(ver, skz, 0, mz)
+            assert sig["r_point"] is None and sig["hashed_to_curve_r"] is None and sig["status"] == 2
+            z = dict(msg=hx(mz), pk=hx(O.pt_bytes(sig["pk"])), nullifier=hx(O.pt_bytes(sig["nullifier"])), c=hx(sig["c"].to_bytes(32, "big")), s=hx(sig["s"].to_bytes(32, "big")),
+                     r_point=zero64, hashed_to_curve_r=zero64, note="r=0: R=Hr=identity (reference accepts)" + tag)
+            out.append((ver, z))
+            if tag:
+                continue
+            flip = lambda h: h[:-2] + f"{int(h[-2:], 16) ^ 1:02x}"  # noqa: E731
+            negy = lambda q: q[:64] + (O.P - int(q[64:], 16)).to_bytes(32, "big").hex()  # noqa: E731
+            g_hex = hx(O.pt_bytes(O.G))
+            for note, kw in (("s ^ 1", dict(s=flip(z["s"]))), ("c ^ 1", dict(c=flip(z["c"]))), ("nullifier negated", dict(nullifier=negy(z["nullifier"]))),
+                             ("pk negated", dict(pk=negy(z["pk"]))), ("pk = G", dict(pk=g_hex)), ("nullifier = G", dict(nullifier=g_hex)),
+                             ("message extended", dict(msg=z["msg"] + "00")), ("s = c (as if sk = 1)", dict(s=z["c"]))) + \
+                    ((("r_point = G", dict(r_point=g_hex)), ("hashed_to_curve_r = G", dict(hashed_to_curve_r=g_hex)), ("r_point = pk", dict(r_point=z["pk"])),
+                      ("hashed_to_curve_r = nullifier", dict(hashed_to_curve_r=z["nullifier"]))) if ver == 1 else ()):
+                t = dict(z); t.update(kw); t["note"] = "r=0 signature, " + note
+                out.append((ver, t))
     return out
 
 

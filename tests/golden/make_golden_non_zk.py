@@ -84,8 +84,26 @@ def main():
         src, oth = gold[f"sign_v{ver}"], gold[f"sign_v{3 - ver}"]
         for i, it in enumerate(src):
             items.append(mutate(ver, i, it, src[i - 1], oth[i]))
+    # The signature with nonce r = 0 (R = Hr = identity, s = c sk): both equations hold with every term ending at the identity and the hash is taken over .. || 00 || 00
+    # -- verify_non_zk returns Ok(true) (rust-arkworks/src/tests.rs:28-78 has no nonce check either) -- followed by its single-field tamperings.
+    for ver in (1, 2):
+        for tag, skz, mz in (("", O.synth_sk(4242), b"nonce zero"), (", empty message", O.synth_sk(4243), b""), (", sk=1", 1, b"nonce zero")):
+            sig = O.sign(ver, skz, 0, mz)
+            assert sig["r_point"] is None and sig["hashed_to_curve_r"] is None
+            z = dict(msg=mz.hex(), pk=O.pt_bytes(sig["pk"]).hex(), nullifier=O.pt_bytes(sig["nullifier"]).hex(), s=sig["s"].to_bytes(32, "big").hex(),
+                     r_point="00" * 64, hashed_to_curve_r="00" * 64, digest_private=sig["c"].to_bytes(32, "big").hex(), note="r=0: R=Hr=identity (Ok(true))" + tag, version=ver)
+            items.append(z)
+            if tag:
+                continue
+            g_hex = O.pt_bytes(O.G).hex()
+            flip = lambda h: h[:-2] + f"{int(h[-2:], 16) ^ 1:02x}"  # noqa: E731
+            for note, kw in (("s ^ 1", dict(s=flip(z["s"]))), ("digest ^ 1", dict(digest_private=flip(z["digest_private"]))), ("r_point = G", dict(r_point=g_hex)),
+                             ("hashed_to_curve_r = G", dict(hashed_to_curve_r=g_hex)), ("nullifier = G", dict(nullifier=g_hex)), ("pk = G", dict(pk=g_hex)),
+                             ("r_point = pk", dict(r_point=z["pk"])), ("message extended", dict(msg=z["msg"] + "00"))):
+                items.append(dict(z, **kw, note="r=0 signature, " + note))
     with Pool(8) as pool:
         out = pool.map(expect, items)
+    assert all(it["ok"] == 1 for it in out if it["note"].startswith("r=0: ")) and all(it["ok"] == 0 for it in out if it["note"].startswith("r=0 signature, "))
     assert sum(1 for it in out if it["ok"] == 1) >= 20 and any(it["ok"] == 2 for it in out) and any(it["ok"] == 0 for it in out)
     (ROOT / "tests" / "golden" / "golden_non_zk.json").write_text(json.dumps(
         {"_generated_by": "tests/golden/make_golden_non_zk.py (python oracle, rust-arkworks/src/tests.rs:28-78)", "items": out}, indent=0))

@@ -88,8 +88,9 @@ void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags
 }
 
 #define PLUME_MSM_DIG_ROWS (2 * PLUME_NDIG + PLUME_NPOS)
+const char* verify_msm_kernel_name(const VerifyArgs& a) { return a.msm_pair && !verify_eq1_short(a) ? "k_verify_msm_pair" : verify_eq1_short(a) ? "k_verify_msm_s" : "k_verify_msm"; }
 void launch_verify_msm(const VerifyArgs& a0, hipStream_t st) {
-    if (a0.msm_pair && !a0.eq1long) mockhip::launch(st, [a = a0] {       // k_verify_msm_pair: 128 tasks of one equation per workgroup, halves 1 first (they park their sums), then halves 0 and the join
+    if (a0.msm_pair && !verify_eq1_short(a0)) mockhip::launch(st, [a = a0] {       // k_verify_msm_pair: 128 tasks of one equation per workgroup, halves 1 first (they park their sums), then halves 0 and the join
         constexpr uint32_t H = kBlock / 2;
         std::vector<int8_t> s_dig((size_t)PLUME_MSM_DIG_ROWS * kBlock);
         std::vector<jac> parked(H);
@@ -111,7 +112,7 @@ void launch_verify_msm(const VerifyArgs& a0, hipStream_t st) {
         grid(2 * nb, kBlock, [&](unsigned b, unsigned t) {
             const uint32_t eq = b >= nb ? 1u : 0u, i = (eq ? b - nb : b) * kBlock + t;
             if (i >= a.n) return;
-            if (a.eq1long) verify_msm<false, 1>(a, i, eq, a.gtab, s_dig.data() + t, kBlock);
+            if (verify_eq1_short(a)) verify_msm<false, 1>(a, i, eq, a.gtab, s_dig.data() + t, kBlock);
             else verify_msm<false, 0>(a, i, eq, a.gtab, s_dig.data() + t, kBlock);
         });
     });

@@ -212,6 +212,8 @@ inline hipError_t hipDeviceGetPCIBusId(char* out, int len, int d) {          // 
     std::snprintf(out, (size_t)len, "FFFF:%02X:00.0", 0xE0 + d);
     return hipSuccess;
 }
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 100000; return hipSuccess; }     // (kHz: the constant-rate wall clock)
 inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 1; *greatest = -1; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { mockhip::drain_device(mockhip::current_device()); return hipSuccess; }
 

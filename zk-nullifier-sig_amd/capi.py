@@ -81,6 +81,10 @@ def _load():
         fn = getattr(lib, name, None)
         if fn is not None:
             fn.argtypes = args
+    lib.plume_get_eq1_short.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.plume_last_msm_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.plume_last_msm_kernel.restype = C.c_char_p
+    lib.plume_last_msm_kernel.argtypes = [C.c_void_p]
     lib.plume_set_host_piece.argtypes = [C.c_void_p, C.c_size_t]
     lib.plume_last_redo_tasks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.plume_last_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
@@ -113,15 +117,15 @@ def _load():
     lib.plume_aggregate_check_device.argtypes = [vp, i, i, sz, vp, vp, sz] + [vp] * 7 + [C.c_uint64, vp, vp, vp]
     _lib = lib
     ver = tuple(int(x) for x in lib.plume_version().decode().split()[1].split(".")[:2])
-    if ver < (0, 5) and not os.environ.get("PLUME_HIP_LIB"):
+    if ver < (0, 6) and not os.environ.get("PLUME_HIP_LIB"):
         _lib = None
-        raise PlumeHipError(f"{p} is {lib.plume_version().decode()}: this module needs plume_hip >= 0.5 (rebuild: make -C zk-nullifier-sig_amd/csrc)")
+        raise PlumeHipError(f"{p} is {lib.plume_version().decode()}: this module needs plume_hip >= 0.6 (rebuild: make -C zk-nullifier-sig_amd/csrc)")
     return lib
 
 
 def exported_symbols():
     """every entry point include/plume_hip.h declares (used by the CPU-side ABI test)"""
-    return ["plume_set_stage_timing", "plume_set_in_flight", "plume_set_sign_uniform", "plume_get_sign_uniform", "plume_set_host_lanes", "plume_set_eq1_short", "plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
+    return ["plume_set_stage_timing", "plume_set_in_flight", "plume_set_sign_uniform", "plume_get_sign_uniform", "plume_set_host_lanes", "plume_set_eq1_short", "plume_get_eq1_short", "plume_last_msm_kernel", "plume_last_msm_clock", "plume_last_redo_tasks", "plume_h2c_hints_batch", "plume_h2c_hints_batch_device", "plume_shard_numa_node", "plume_set_sub_batches", "plume_aggregate_check", "plume_aggregate_check_device", "plume_init_multi", "plume_num_shards", "plume_set_host_first_piece", "plume_set_host_register_min", "plume_set_host_tail_piece", "plume_host_alloc", "plume_host_free", "plume_host_register",
             "plume_host_unregister", "plume_verify_non_zk_batch", "plume_verify_non_zk_batch_device", "plume_h2c_intermediates_batch", "plume_h2c_intermediates_batch_device",
             "plume_registers_from_be", "plume_registers_from_be_device", "plume_scalars_to_sec1_der_batch", "plume_scalars_to_sec1_der_batch_device", "plume_sec1_der_to_scalars", "plume_sec1_der_to_scalars_checked",
             "plume_init", "plume_destroy", "plume_last_error", "plume_version", "plume_set_chunk", "plume_set_host_piece", "plume_verify_batch", "plume_verify_batch_sec1", "plume_verify_batch_sec1_device", "plume_sign_batch", "plume_sign_batch_sec1", "plume_sign_batch_sec1_device",
@@ -181,15 +185,6 @@ def sec1_der_to_scalars(der109):
     if rc != 0:
         raise PlumeHipError(f"plume_sec1_der_to_scalars failed ({rc}): {lib.plume_last_error().decode()}")
     return sc, ok
-
-
-def eq1_short_applies(version, n, mode=0, sec1=False):
-    """mirror of verify_device's rule (csrc/plume_capi.hip) for callers that want to NAME the multi-scalar kernel a call ran (bench.py looks its counters up): calls that give R
-    as a 64-byte record -- V1 verify, verify_non_zk -- of at least PLUME_EQ1_SHORT_MIN items (default 2^17) run equation 1 in the short form (k_verify_msm_s), unless
-    PLUME_EQ1_SHORT=0.  Contexts reconfigured with Engine.set_eq1_short are not covered: this reads the environment's defaults only."""
-    m = int(os.environ.get("PLUME_EQ1_SHORT", "1"))
-    lo = int(os.environ.get("PLUME_EQ1_SHORT_MIN", str(1 << 17)))
-    return m != 0 and (n >= lo or m >= 2) and not sec1 and (version == 1 or mode == 1)
 
 
 def pinned_empty(shape, dtype=np.uint8):
@@ -282,7 +277,7 @@ class Engine:
 
     def set_in_flight(self, k):
         """batches in flight (plume_set_in_flight): with k = 2 the device-resident calls go in turn to two lanes of the context, so that calls issued on different streams run
-        side by side (2^20 verifies: 20.1 instead of 20.8 ms per batch); default 1; results do not depend on it"""
+        side by side (2^20 verifies: about 1 % per batch; calls of fewer than 2^17 items stay on the first lane); default 1; results do not depend on it"""
         self._chk(self._lib.plume_set_in_flight(self._ctx, int(k)), "plume_set_in_flight")
 
     def set_sign_uniform(self, on):
@@ -298,9 +293,28 @@ class Engine:
         return rc
 
     def set_eq1_short(self, mode):
-        """the verifier's first equation where R is given: 1 = short form (csrc/plume_eis.h; default, calls of >= 2^17 items), 0 = long form always, 2 = test mode (every item
-        through the scalar stage's fallback)"""
+        """the verifier's first equation where R is given: 1 = short form for calls of at least eq1_short()[1] items (csrc/plume_eis.h; the default), 3 = short form whatever the
+        size, 0 = long form always, 2 = test mode (every item through the scalar stage's fallback)"""
         self._chk(self._lib.plume_set_eq1_short(self._ctx, int(mode)), "plume_set_eq1_short")
+
+    def eq1_short(self):
+        """(mode, min_items) in force on this context (plume_get_eq1_short): mode as set_eq1_short takes it, min_items = the smallest call that takes the short form in mode 1"""
+        m = C.c_size_t(0)
+        rc = self._lib.plume_get_eq1_short(self._ctx, C.byref(m))
+        if rc < 0:
+            self._chk(rc, "plume_get_eq1_short")
+        return rc, int(m.value)
+
+    def last_msm_clock_ghz(self):
+        """the shader clock (GHz) the multi-scalar kernel of the last verify call ran at, sampled inside the kernel (plume_last_msm_clock; stage timing must be on), or None"""
+        g = C.c_double(0.0)
+        rc = self._lib.plume_last_msm_clock(self._ctx, C.byref(g))
+        return float(g.value) if rc == 0 else None
+
+    def last_msm_kernel(self):
+        """the multi-scalar kernel the last verify call on this context launched (plume_last_msm_kernel): 'k_verify_msm', 'k_verify_msm_s', 'k_verify_msm_pair', or None"""
+        r = self._lib.plume_last_msm_kernel(self._ctx)
+        return r.decode() if r else None
 
     def set_host_lanes(self, lanes):
         """host-pointer calls: 1 = every piece on the context itself, 2 (default) = pieces alternate between the context and a second lane"""

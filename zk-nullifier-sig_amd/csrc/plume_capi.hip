@@ -129,6 +129,7 @@ struct plume_ctx {
     hipStream_t pre = nullptr;                                    // overlapped verify / sign: the stages BEFORE the multi-scalar kernel of sub-batch k+1 run here, beside that kernel of sub-batch k
     hipEvent_t pre_begin = nullptr;                               // ... the caller's stream has reached the call (inputs are there, the workspace is free)
     std::vector<hipEvent_t> pre_ready;                            // ... sub-batch k's window tables are built
+    const char* last_msm_kernel = nullptr;                         // the multi-scalar kernel the last verify call on this context launched (plume_last_msm_kernel)
     std::vector<size_t> redo_counters;                            // word offsets (in `redo`) of the last verify call's redo counters, one per sub-batch (plume_last_redo_tasks)
     int sub_batches = 1;                                          // device-resident verify / sign: number of sub-batches; 1 = strictly serial launch order (the default: measured on the MI355X, r03, kernels of two
                                                                   // streams sharing the CUs cost MORE than the table kernel's idle issue slots give back -- 21.85 ms serial vs 22.1-22.4 ms for 2..16 sub-batches, LABNOTES.md §6)
@@ -162,8 +163,9 @@ struct plume_ctx {
     // (workspace, streams, events; the fixed tables are shared), so that calls the caller issues on DIFFERENT streams run side by side instead of queueing for one workspace
     std::vector<plume_ctx*> lanes;
     size_t lane_next = 0;
+    size_t in_flight_min = (size_t)1 << 17;                        // verify / sign calls of fewer items are not dealt out to the lanes (env PLUME_IN_FLIGHT_MIN): latency-bound calls side by side measured slower than one after the other
     plume_ctx* lane_last = nullptr;                               // the lane the last device-resident call went to (plume_last_stage_times, plume_last_redo_tasks)
-    DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo, digs, eq1long, eq1k;
+    DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo, digs, eq1fall, eq1k, clk;
     int eq1_short = 1;                                             // verify calls that give R: equation 1 in its short form (plume_eis.h).  0 = long form always (A/B), 2 = test: every item takes the fallback
     size_t eq1_short_min = (size_t)1 << 17;                        // ... for calls (slices) of at least this many items: below, the half-GCD's ~45 dependent steps are latency nothing hides
                                                                    // (2^16 items: scalar stage +0.12 ms, multi-scalar kernel -0.09 ms; 2^20: +0.28 / -1.1 ms)
@@ -208,11 +210,11 @@ struct Route {
     size_t next0 = 0;
     plume_ctx* last0 = nullptr;
     uint64_t epoch0 = 0;
-    Route(plume_ctx* ctx, void* stream) : held(ctx), lane(ctx) {
+    Route(plume_ctx* ctx, void* stream, size_t n = (size_t)-1) : held(ctx), lane(ctx) {
         st = stream ? (hipStream_t)stream : (ctx ? ctx->stream : nullptr);
         if (!ctx) return;
         next0 = ctx->lane_next; last0 = ctx->lane_last;
-        if (!ctx->lanes.empty()) {
+        if (!ctx->lanes.empty() && n >= ctx->in_flight_min) {                 // (a small call stays on the first lane: plume_set_in_flight)
             const size_t k = ctx->lanes.size() + 1, i = ctx->lane_next++ % k;
             lane = i == 0 ? ctx : ctx->lanes[i - 1];
         }
@@ -263,7 +265,7 @@ extern "C" const char* plume_last_error(void) { return g_err.c_str(); }
 #ifndef PLUME_BUILD_ID
 #define PLUME_BUILD_ID "unknown"
 #endif
-extern "C" const char* plume_version(void) { return "plume_hip 0.5 gfx950 build=" PLUME_BUILD_ID; }
+extern "C" const char* plume_version(void) { return "plume_hip 0.6 gfx950 build=" PLUME_BUILD_ID; }
 
 static void destroy_single(plume_ctx* ctx) {
     for (plume_ctx* l : ctx->lanes) destroy_single(l);
@@ -276,7 +278,7 @@ static void destroy_single(plume_ctx* ctx) {
     if (ctx->ws_used && ctx->ws_free) (void)hipEventSynchronize(ctx->ws_free);
     for (hipStream_t q : {ctx->stream, ctx->up, ctx->down, ctx->side, ctx->pre}) if (q) (void)hipStreamSynchronize(q);
     for (DevBuf* b : {&ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
-                      &ctx->sink, &ctx->redo, &ctx->digs, &ctx->eq1long, &ctx->eq1k, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
+                      &ctx->sink, &ctx->redo, &ctx->digs, &ctx->eq1fall, &ctx->eq1k, &ctx->clk, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
     for (DevBuf& b : ctx->agg) b.release();
     if (ctx->fixed) {
@@ -320,6 +322,7 @@ static int init_single(plume_ctx* ctx) {
     if (const char* e = std::getenv("PLUME_SIGN_UNIFORM")) ctx->sign_uniform = std::min(2, std::max(0, std::atoi(e)));   // default of new contexts (plume_set_sign_uniform); 0 opts out of the uniform schedule
     if (const char* e = std::getenv("PLUME_EQ1_SHORT")) { int v = std::atoi(e); if (v >= 0 && v <= 3) ctx->eq1_short = v; }   // A/B and test knob (plume_eis.h)
     if (const char* e = std::getenv("PLUME_EQ1_SHORT_MIN")) { long v = std::atol(e); if (v >= 0) ctx->eq1_short_min = (size_t)v; }   // tuning knob
+    if (const char* e = std::getenv("PLUME_IN_FLIGHT_MIN")) { long v = std::atol(e); if (v >= 0) ctx->in_flight_min = (size_t)v; }   // tuning knob (plume_set_in_flight)
     if (const char* e = std::getenv("PLUME_HOST_SIGN_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_sign_lanes = v; }
     if (const char* e = std::getenv("PLUME_STAGE_TIMES")) ctx->timer.on = std::atoi(e) != 0;   // default of new contexts (plume_set_stage_timing)
     if (const char* e = std::getenv("PLUME_HOST_LANES")) { int v = std::atoi(e); if (v == 1 || v == 2) ctx->host_lanes = v; }   // 1 = the one-lane host-pointer pipeline of rounds 1-3 (A/B)
@@ -611,6 +614,21 @@ extern "C" int plume_get_sign_uniform(const plume_ctx* ctx) {
     if (!ctx) return fail(PLUME_ERR_ARG, "plume_get_sign_uniform: null context");
     return ctx->sign_uniform;
 }
+// the mode plume_set_eq1_short left (or the environment's default) and, through min_items when given, the smallest CALL that takes the short form in mode 1.  The rule is
+// applied to the call's n, not to the slices plume_set_sub_batches may cut it into.
+extern "C" int plume_get_eq1_short(const plume_ctx* ctx, size_t* min_items) {
+    if (!ctx) return fail(PLUME_ERR_ARG, "plume_get_eq1_short: null context");
+    if (min_items) *min_items = ctx->eq1_short_min;
+    return ctx->eq1_short;
+}
+// Which multi-scalar kernel the last verify call served by this context launched: "k_verify_msm" (both equations in the long form), "k_verify_msm_s" (equation 1 in the
+// short form) or "k_verify_msm_pair" (half chains, small calls); NULL before the first verify.  With batches in flight: the lane of the last device-resident call; for a
+// multi-device context: the first shard.  So that a measurement NAMES the kernel it looks up counters for from what ran, not from the environment's defaults.
+extern "C" const char* plume_last_msm_kernel(const plume_ctx* ctx) {
+    if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
+    if (ctx && ctx->lane_last) ctx = ctx->lane_last;
+    return ctx ? ctx->last_msm_kernel : nullptr;
+}
 
 // device-resident verify / sign: how many sub-batches a call is cut into (verify_device); 1 = strictly serial launch order
 extern "C" int plume_set_sub_batches(plume_ctx* ctx, int sub_batches) {
@@ -623,8 +641,9 @@ extern "C" int plume_set_sub_batches(plume_ctx* ctx, int sub_batches) {
 // Batches in flight: with k > 1 the device-resident calls of this context go in turn to k lanes -- the context itself and k - 1 further single-device contexts of its own
 // (each with its workspace, streams and events; the generator's fixed tables are shared) -- so that calls the caller issues on DIFFERENT streams run side by side instead
 // of queueing for one workspace: the memory-bound table passes and the ramps / tails of one batch's kernels fit beside the issue-bound multi-scalar kernel of another
-// (2^20 verifies: 20.1 instead of 20.8 ms per batch with two in flight, 2^16: 1.37 instead of 1.77 ms; three gain nothing more).  Results do not depend on it.  Calls on ONE
-// stream stay in that stream's order whatever k is.  Default 1.
+// (2^20 verifies: about 1 % per batch with two in flight; three gain nothing more).  Calls of fewer than in_flight_min items (2^17; env PLUME_IN_FLIGHT_MIN) stay on the
+// first lane: since round 5 they are latency-bound and two side by side measured SLOWER than one after the other (2^16: 1.55 against 1.42 ms each).  Results do not depend
+// on any of it.  Calls on ONE stream stay in that stream's order whatever k is.  Default 1.
 extern "C" int plume_set_in_flight(plume_ctx* ctx, int batches) {
     if (!ctx || batches < 1 || batches > 4) return fail(PLUME_ERR_ARG, "plume_set_in_flight: bad argument");
     if (!ctx->shards.empty()) return fail(PLUME_ERR_ARG, "plume_set_in_flight: a multi-device context runs its shards side by side already");
@@ -735,7 +754,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * J * n) || ctx->jobflags.ensure(J * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * J * n) ||
         ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->redo.ensure((2 * n + nsub) * 4) || ctx->digs.ensure((size_t)PLUME_VDIG_ROWS * n) ||
-        (eq1short && (ctx->eq1long.ensure(n) || ctx->eq1k.ensure(32 * n))))
+        (eq1short && (ctx->eq1fall.ensure(n) || ctx->eq1k.ensure(32 * n))))
         return PLUME_ERR_HIP;
     if (overlapped) { if (int rc = pre_events(ctx, nsub)) return rc; if (int rc = pre_stream(ctx)) return rc; }
     StageTimer& t = ctx->timer;
@@ -758,7 +777,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         a.redo = ctx->redo.as<uint32_t>() + 2 * lo + k;                      // the slice's redo list: counter + up to 2 * cnt tasks
         a.digs = ctx->digs.as<int8_t>() + (size_t)PLUME_VDIG_ROWS * lo;        // the slice's digit rows (row-major over the slice's cnt items)
         if (eq1short) {
-            a.eq1long = ctx->eq1long.as<uint8_t>() + lo; a.eq1k = ctx->eq1k.as<uint32_t>() + 8 * lo; a.gcomb = ctx->fixed->gcomb.as<uint32_t>();
+            a.eq1fall = ctx->eq1fall.as<uint8_t>() + lo; a.eq1k = ctx->eq1k.as<uint32_t>() + 8 * lo; a.gcomb = ctx->fixed->gcomb.as<uint32_t>();
             a.eq1force = ctx->eq1_short == 2 ? 1 : 0;
         }
         if (k == 0) ctx->redo_counters.clear();
@@ -772,6 +791,12 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         if (overlapped) {
             HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));
             HIPCHK(hipStreamWaitEvent(st, ctx->pre_ready[k], 0));
+        }
+        ctx->last_msm_kernel = verify_msm_kernel_name(a);
+        if (t.on && !overlapped && k == 0) {                                   // stage timing: the multi-scalar kernel also samples its clocks (plume_last_msm_clock)
+            if (ctx->clk.ensure(16)) return PLUME_ERR_HIP;
+            HIPCHK(hipMemsetAsync(ctx->clk.p, 0, 16, st));
+            a.clk = ctx->clk.as<unsigned long long>();
         }
         launch_verify_msm(a, st); if (!overlapped) t.stage("verify_msm", st);
         if (version == 2 && mode == PLUME_MODE_VERIFY) { launch_normalize(a.res, a.resinf, 2 * cnt, st); if (!overlapped) t.stage("to_affine", st); }   // V2 hashes the computed R', Hr'
@@ -849,7 +874,7 @@ static int args_ok(int version, size_t n, const void* msgs, const void* off) {
 extern "C" int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                          const uint8_t* pk, const uint8_t* nullifier, const uint8_t* c, const uint8_t* s, const uint8_t* r_point,
                                          const uint8_t* hashed_to_curve_r, uint8_t* ok, void* stream) {
-    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
+    Route rt_(ctx, stream, n); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk || !nullifier || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
@@ -862,7 +887,7 @@ extern "C" int plume_verify_batch_device(plume_ctx* ctx, int version, size_t n, 
 extern "C" int plume_verify_non_zk_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                                 const uint8_t* pk, const uint8_t* nullifier, const uint8_t* s, const uint8_t* r_point,
                                                 const uint8_t* hashed_to_curve_r, const uint8_t* digest_private, uint8_t* ok, void* stream) {
-    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
+    Route rt_(ctx, stream, n); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk || !nullifier || !s || !r_point || !hashed_to_curve_r || !digest_private || !ok)) return fail(PLUME_ERR_ARG, "null array");
@@ -897,7 +922,7 @@ static int verify_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8
 extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes,
                                               const uint8_t* pk33, const uint8_t* nullifier33, const uint8_t* c, const uint8_t* s, const uint8_t* r_point33,
                                               const uint8_t* hashed_to_curve_r33, uint8_t* ok, void* stream) {
-    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
+    Route rt_(ctx, stream, n); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!pk33 || !nullifier33 || !c || !s || !ok)) return fail(PLUME_ERR_ARG, "null array");
@@ -908,7 +933,7 @@ extern "C" int plume_verify_batch_sec1_device(plume_ctx* ctx, int version, size_
 extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
                                        const uint8_t* r, const uint8_t* pk_in, uint8_t* pk, uint8_t* nullifier, uint8_t* c, uint8_t* s, uint8_t* r_point,
                                        uint8_t* hashed_to_curve_r, uint8_t* status, void* stream) {
-    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
+    Route rt_(ctx, stream, n); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier || !c || !s || !r_point || !hashed_to_curve_r || !status)) return fail(PLUME_ERR_ARG, "null array");
@@ -919,7 +944,7 @@ extern "C" int plume_sign_batch_device(plume_ctx* ctx, int version, size_t n, co
 extern "C" int plume_sign_batch_sec1_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msgs, const uint64_t* msg_off, size_t msgs_bytes, const uint8_t* sk,
                                             const uint8_t* r, const uint8_t* pk_in, uint8_t* pk33, uint8_t* nullifier33, uint8_t* c, uint8_t* s, uint8_t* r_point33,
                                             uint8_t* hashed_to_curve_r33, uint8_t* status, void* stream) {
-    Route rt_(ctx, stream); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
+    Route rt_(ctx, stream, n); ctx = rt_.lane; const hipStream_t st_ = rt_.st;
     if (int rc = bind(ctx)) return rc;
     if (int rc = args_ok(version, n, msgs, msg_off)) return rc;
     if (n && (!sk || !r || !nullifier33 || !c || !s || !r_point33 || !hashed_to_curve_r33 || !status)) return fail(PLUME_ERR_ARG, "null array");
@@ -1701,6 +1726,23 @@ extern "C" int plume_last_stage_times(plume_ctx* ctx, const char** names, float*
 
 // measurement / test hook: how many multi-scalar tasks of the last verify call on this context met p == +-q in an unchecked addition and were redone by the second launch
 // (0 for honest batches; crafted items -- pk = +-k G with small k and s = +-c -- file one or two tasks each).  Synchronises with the device.
+// The shader clock the multi-scalar kernel of the last verify call ran at, in GHz: one workgroup in 32 adds the cycles and the constant-rate wall-clock ticks it lived for to
+// two counters; their ratio times the wall clock's rate is the clock.  Needs stage timing on before the call (PLUME_ERR_ARG otherwise).  Synchronises with the device.
+extern "C" int plume_last_msm_clock(plume_ctx* ctx, double* ghz) {
+    if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
+    if (ctx && ctx->lane_last) ctx = ctx->lane_last;
+    if (int rc = bind(ctx)) return rc;
+    if (!ghz) return fail(PLUME_ERR_ARG, "null argument");
+    if (!ctx->timer.on || !ctx->clk.p || !ctx->last_msm_kernel) return fail(PLUME_ERR_ARG, "plume_last_msm_clock: no verify call with stage timing on (plume_set_stage_timing) has run on this context");
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long c[2] = {0, 0};
+    HIPCHK(hipMemcpy(c, ctx->clk.p, 16, hipMemcpyDeviceToHost));
+    int khz = 0;
+    HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    if (c[1] == 0 || khz <= 0) return fail(PLUME_ERR_ARG, "plume_last_msm_clock: the last call sampled nothing");
+    *ghz = (double)c[0] / (double)c[1] * (double)khz * 1e-6;
+    return 0;
+}
 extern "C" int plume_last_redo_tasks(plume_ctx* ctx, uint64_t* count) {
     if (ctx && !ctx->shards.empty()) ctx = ctx->shards[0];
     if (ctx && ctx->lane_last) ctx = ctx->lane_last;

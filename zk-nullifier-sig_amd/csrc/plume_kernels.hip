@@ -198,7 +198,15 @@ __device__ __forceinline__ void verify_msm_body(const VerifyArgs& a, int8_t* s_d
     const uint32_t blk = eq ? blockIdx.x - nb : blockIdx.x;
     const uint32_t* gt = a.gtab;   // read through L1/L2 (a 128-entry table staged in LDS was 10 % slower: bank conflicts on per-lane random rows)
     const uint32_t i = blk * kBlock + threadIdx.x;
+    // one workgroup in 32 reports how long it lived on the shader clock and on the constant-rate wall clock (scalar reads, two atomics per sampled workgroup, on request only)
+    const bool sample = a.clk != nullptr && (blockIdx.x & 31u) == 0;                      // wave-uniform
+    long long c0 = 0, w0 = 0;
+    if (sample) { c0 = clock64(); w0 = wall_clock64(); }
     if (i < a.n) verify_msm<false, FORM>(a, i, eq, gt, s_dig + threadIdx.x, kBlock);      // (the rows hold digits of s and c: public parts of a signature, nothing to wipe)
+    if (sample) {
+        const long long c1 = clock64(), w1 = wall_clock64();
+        if (threadIdx.x == 0) { atomicAdd(a.clk, (unsigned long long)(c1 - c0)); atomicAdd(a.clk + 1, (unsigned long long)(w1 - w0)); }
+    }
 }
 __global__ PLUME_MSM_BOUNDS void k_verify_msm(VerifyArgs a) {
     __shared__ int8_t s_dig[PLUME_MSM_DIG_ROWS * kBlock];
@@ -492,9 +500,10 @@ void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags
     hipLaunchKernelGGL(k_tab_invert, dim3(nblocks(T)), dim3(kBlock), 0, st, carry, nl, T);
     hipLaunchKernelGGL(k_tab_pass_b, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
 }
+const char* verify_msm_kernel_name(const VerifyArgs& a) { return a.msm_pair && !verify_eq1_short(a) ? "k_verify_msm_pair" : verify_eq1_short(a) ? "k_verify_msm_s" : "k_verify_msm"; }
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {      // (a.redo[0] was zeroed by k_verify_scalars, which every verify pipeline runs first)
-    if (a.msm_pair && !a.eq1long) hipLaunchKernelGGL(k_verify_msm_pair, dim3(2 * ((a.n + kBlock / 2 - 1) / (kBlock / 2))), dim3(kBlock), 0, st, a);
-    else if (a.eq1long) hipLaunchKernelGGL(k_verify_msm_s, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
+    if (a.msm_pair && !verify_eq1_short(a)) hipLaunchKernelGGL(k_verify_msm_pair, dim3(2 * ((a.n + kBlock / 2 - 1) / (kBlock / 2))), dim3(kBlock), 0, st, a);
+    else if (verify_eq1_short(a)) hipLaunchKernelGGL(k_verify_msm_s, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
     else hipLaunchKernelGGL(k_verify_msm, dim3(2 * nblocks(a.n)), dim3(kBlock), 0, st, a);
     const unsigned redo_blocks = std::min(2 * nblocks(a.n) * (kBlock / kRedoBlock), 4096u);   // grid-stride: enough lanes for a wholly crafted batch to fill the chip
     hipLaunchKernelGGL(k_verify_msm_redo, dim3(redo_blocks), dim3(kRedoBlock), 0, st, a);

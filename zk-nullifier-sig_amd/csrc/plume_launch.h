@@ -16,6 +16,7 @@ void launch_verify_ingest(const VerifyArgs& a, hipStream_t st, bool two_roles = 
 size_t tables_scratch_bytes(size_t njobs, int jobs_per_lane);
 void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int jobs_per_lane, uint32_t* scr, hipStream_t st);
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st);
+const char* verify_msm_kernel_name(const VerifyArgs& a);      // the kernel launch_verify_msm picks for this call
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st);
 void launch_sign_gmul(const SignArgs& a, hipStream_t st);
 void launch_sign_h2c(const SignArgs& a, hipStream_t st);

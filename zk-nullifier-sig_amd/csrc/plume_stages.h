@@ -165,18 +165,23 @@ struct VerifyArgs {
     uint32_t* redo;       // redo[0] = number of tasks whose unchecked chain met p == +-q, redo[1 + k] = the k-th such task (2i + eq); capacity 2n; zeroed before the multi-scalar kernel
     int8_t* digs;         // PLUME_VDIG_ROWS x n signed window digits, row-major (row r of item i at digs[r * n + i]: a wavefront reads / writes 64 consecutive bytes per row).
                           // Written once per item by the scalar stage (verify_scalars; rounds 4: by the ingest kernel; rounds 1-3: each multi-scalar lane split s and c again)
-    // Round 5, calls that GIVE r_point as a 64-byte record (V1 verify, verify_non_zk): equation 1 in its short form (plume_eis.h) -- NULL = the long form for every item
-    uint8_t* eq1long;     // n : 0 = the item's equation 1 runs in the short form (digit set B holds the 64-bit coefficients, eq1k the generator's scalar), 1 = long form (set B holds
-                          //     s in the generator's wide digits): the half-GCD's coefficients did not fit (no such input is known) or the caller forces it (tests)
+    // Calls that GIVE r_point as a 64-byte record (V1 verify, verify_non_zk) may run equation 1 in its SHORT form (plume_eis.h).  They do iff eq1fall is set
+    // (verify_eq1_short below); every item of such a call then has a flag here:
+    uint8_t* eq1fall;     // n : 0 = the item's equation 1 runs in the short form (digit set B holds the 64-bit coefficients, eq1k the generator's scalar), 1 = the item FALLS
+                          //     BACK to the long form (set B holds s in the generator's wide digits): the half-GCD's coefficients did not fit (no such input is known) or the
+                          //     caller forces it (tests).  NULL = the whole call runs the long form
     uint32_t* eq1k;       // 8 x n words, word-major: k = tau s mod n, multiplied by G through the comb
     const uint32_t* gcomb;  // the doubling-free comb of G (PLUME_COMB_WORDS), shared with the signer
     int msm_pair;            // calls of a few thousand items: the long-form chains run as two halves on two lanes (k_verify_msm_pair; verify_msm_half below)
     int scalars_in_ingest;   // the two-role ingest kernel (small calls) runs verify_scalars in its role B: no k_verify_scalars launch for this call (plume_kernels.hip)
+    unsigned long long* clk;   // optional (stage timing on): clk[0] += shader-clock cycles, clk[1] += constant-rate wall-clock ticks that sampled workgroups of the multi-scalar kernel lived
+                               // for -- their ratio is the clock the kernel ran at (plume_last_msm_clock): what turns a kernel time into a box-independent cycle count
     int eq1force;         // test knob: 1 = file every item's equation 1 as "long form" (everything then runs through the redo launch's checked chain)
 };
 // jobs: 3 per item (pk, H, nullifier) at 3i, 3i+1, 3i+2; in the short form a fourth, R, at 3n + i -- behind the others so that the job kinds of the first 3n stay aligned
 // across the lanes of the table passes and the last n are all of one kind (affine)
-PLUME_HD size_t verify_njobs(const VerifyArgs& a) { return (a.eq1long ? 4 : 3) * (size_t)a.n; }
+PLUME_HD bool verify_eq1_short(const VerifyArgs& a) { return a.eq1fall != nullptr; }      // does this call run equation 1 in the short form?
+PLUME_HD size_t verify_njobs(const VerifyArgs& a) { return (verify_eq1_short(a) ? 4 : 3) * (size_t)a.n; }
 // the digit rows of an item: three sets of 2 x PLUME_NDIG rows (the two halves of a GLV split): s in 4-bit windows (equation 2), s with the generator's wide digits
 // (equation 1), -c in 4-bit windows (both equations)
 #define PLUME_VDIG_SET PLUME_NPOS                    // sets A and C: the Eisenstein digits of one GLV pair, one row per position
@@ -207,17 +212,17 @@ PLUME_HD void verify_item_digits(int8_t* d, uint32_t n, const sc& s, const glv_h
     if (long_b) { booth_store_wide(d + (size_t)PLUME_VDIG_SET * n, n, h1, false); booth_store_wide(d + (size_t)(PLUME_VDIG_SET + PLUME_NDIG) * n, n, h2, false); }
     eisd_store_glv(d + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * n, n, c1, c2, true);
 }
-// The scalar stage: every digit row the multi-scalar kernel reads, once per item.  Short form of equation 1 (a.eq1long != NULL; plume_eis.h): (tau, upsilon) from the
+// The scalar stage: every digit row the multi-scalar kernel reads, once per item.  Short form of equation 1 (verify_eq1_short(a); plume_eis.h): (tau, upsilon) from the
 // half-GCD of c, k = tau s mod n for the comb, and set B = the Eisenstein digits of -upsilon (pk's joint slot) and of -(tau - 1) (R's).
 PLUME_HD void verify_scalars(const VerifyArgs& a, uint32_t i) {
     sc c, s;
     bool okc = load_scalar_be(c, a.c + 32 * (size_t)i), oks = load_scalar_be(s, a.s + 32 * (size_t)i);
     if (a.mode == PLUME_MODE_NON_ZK) { okc = sc_lt_n(c); oks = sc_lt_n(s); }
-    if (!okc || !oks) { if (a.eq1long) a.eq1long[i] = 1; return; }            // (the ingest stage rejects the item; its digit rows are never read)
+    if (!okc || !oks) { if (verify_eq1_short(a)) a.eq1fall[i] = 1; return; }            // (the ingest stage rejects the item; its digit rows are never read)
     bool lng = true;
     glv_half c1, c2;
     glv_split(c1, c2, c);                                                     // once: the half-GCD starts from it, the digits of -c are its
-    if (a.eq1long) {
+    if (verify_eq1_short(a)) {
         eis_short e;
         eis_half_gcd(e, c1, c2);
         lng = !e.ok || a.eq1force != 0 || !eis_consistent(e, c);
@@ -229,7 +234,7 @@ PLUME_HD void verify_scalars(const VerifyArgs& a, uint32_t i) {
             (void)eisd_store<PLUME_NPOS66, 3>(b, a.n, e.u[0], e.uneg[0] != 0, e.u[1], e.uneg[1] != 0, true);                                   // - upsilon
             (void)eisd_store<PLUME_NPOS66, 3>(b + (size_t)PLUME_NPOS66 * a.n, a.n, e.t[0], e.tneg[0] != 0, e.t[1], e.tneg[1] != 0, true);      // - (tau - 1)
         }
-        a.eq1long[i] = lng ? 1 : 0;
+        a.eq1fall[i] = lng ? 1 : 0;
     }
     verify_item_digits(a.digs + i, a.n, s, c1, c2, lng);
 }
@@ -250,7 +255,7 @@ PLUME_HD void verify_ingest_h2c(const VerifyArgs& a, uint32_t i) {
     // (The window digits of s and c are the scalar stage's work since round 5: verify_scalars.)
     // Short form of equation 1: R is a base of the multi-scalar chain, so it is validated HERE (an r_point that is no curve point rejects the item, as it does in the
     // finalize stage of the long form) and becomes job 3n + i of the table stage.
-    if (a.eq1long) {
+    if (verify_eq1_short(a)) {
         fe rx, ry;
         const uint32_t fr = load_affine_be(rx, ry, a.rpt + 64 * (size_t)i);
         if (fr == PLUME_JOB_INVALID && !err) { bad = true; a.itemflags[i] = (uint8_t)PLUME_ITEM_REJECT; }
@@ -297,7 +302,7 @@ PLUME_HD void verify_ingest_b1(const VerifyArgs& a, uint32_t i, ingest_xch& x) {
     jac p; p.inf = 0; p.z = fe_small(1); p.x = nx; p.y = ny;
     st_base(a.bases, 3 * (size_t)i + 2, p); a.jobflags[3 * (size_t)i + 2] = (uint8_t)(fnul | PLUME_JOB_AFFINE);
     bool okr = true;
-    if (a.eq1long) {                                                          // short form of equation 1: R is validated here and becomes job 3n + i (verify_ingest_h2c)
+    if (verify_eq1_short(a)) {                                                          // short form of equation 1: R is validated here and becomes job 3n + i (verify_ingest_h2c)
         fe rx, ry;
         const uint32_t fr = load_affine_be(rx, ry, a.rpt + 64 * (size_t)i);
         okr = fr != PLUME_JOB_INVALID;
@@ -348,16 +353,16 @@ PLUME_HD void verify_ingest_a3(const VerifyArgs& a, uint32_t i, const ingest_xch
 
 // task t = 2*item + eq;  eq 0: s*G - c*pk, eq 1: s*H - c*nul.   dig: this lane's digit area (LDS), element stride.
 // CHECKED = false: the hot form; a task whose chain met p == +-q is filed in a.redo and stores nothing.  CHECKED = true: the redo launch's form.
-// FORM: which forms of equation 1 the instantiation carries -- 0: the long form only (calls without a.eq1long), 1: the short form only (the hot kernel of a short-form call:
+// FORM: which forms of equation 1 the instantiation carries -- 0: the long form only (calls whose equation 1 runs in the long form), 1: the short form only (the hot kernel of a short-form call:
 // an item the scalar stage left in the long form is filed for the redo launch), 2: both (the redo launch, host harness)
 template <bool CHECKED, int FORM = 2>
 PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const uint32_t* gtab, int8_t* dig, uint32_t stride) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + eq;
     jac acc;
-    const bool short_call = FORM == 1 || (FORM == 2 && a.eq1long != nullptr);
+    const bool short_call = FORM == 1 || (FORM == 2 && verify_eq1_short(a));
     if (a.itemflags[item]) {
         acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
-    } else if (FORM != 0 && eq == 0 && short_call && !a.eq1long[item]) {
+    } else if (FORM != 0 && eq == 0 && short_call && !a.eq1fall[item]) {
         // Equation 1, short form (plume_eis.h): k G - upsilon pk - (tau - 1) R, to be compared with R by the finalize stage.  Two joint slots, pk and R, thirty-four positions
         // (66 doublings at most; leading all-zero positions are skipped); then the generator's term from the doubling-free comb, fifteen additions.
         const int8_t* db = a.digs + (size_t)PLUME_VDIG_SET * a.n + item;
