@@ -3,7 +3,7 @@
 // run by tests/test_sanitizers.py under AddressSanitizer + UBSan and under ThreadSanitizer: the contexts, lanes, staging slots, piece pipeline, chunk loop, shard worker
 // threads and their teardown then run for real, with every caller array sized exactly on the heap and the mock's lazy / random stream scheduler running whatever the
 // library did not order in the worst order.
-//   pipeline_driver <group> [seed]        groups: verify sign multi device misc devapi faults all
+//   pipeline_driver <group> [seed]        groups: verify sign multi benchseq device misc devapi faults all
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -90,6 +90,7 @@ static Batch make_batch(int version, size_t n, bool spoil) {
     b.msgs.resize(b.off[n]);
     for (auto& x : b.msgs) x = (uint8_t)rng();
     b.sk = random_scalar_bytes(n); b.r = random_scalar_bytes(n);
+    if (spoil) for (size_t i = 0; i < n; i++) if (rnd(0, 13) == 0) std::memset(&b.r[32 * i], 0, 32);      // nonce zero: R = Hr = identity, which the reference's verify ACCEPTS (both equations end at the identity)
     b.pk.assign(64 * n, 0); b.nul.assign(64 * n, 0); b.c.assign(32 * n, 0); b.s.assign(32 * n, 0); b.rpt.assign(64 * n, 0); b.hr.assign(64 * n, 0); b.h.assign(64 * n, 0); b.status.assign(n, 0);
     if (n) oracle_sign_batch(version, n, b.msgs.data(), b.off.data(), b.sk.data(), b.r.data(), nullptr, b.pk.data(), b.nul.data(), b.c.data(), b.s.data(), b.rpt.data(), b.hr.data(), b.h.data(), b.status.data(), 4);
     if (spoil)
@@ -351,6 +352,47 @@ static void group_multi(uint64_t seed) {
     REQUIRE(plume_init_multi(&ctx, bad, 2) != 0 && ctx == nullptr);
     REQUIRE(plume_init_multi(&ctx, ids, 0) != 0);
     REQUIRE(plume_init(&ctx, -1) != 0);
+}
+
+// bench.py --multi-ctx's call sequence, literally (bench.py multi_ctx_main): ONE plume_init_multi context over devices 0..7 with the library's DEFAULT knobs, the set-up sign
+// from pageable arrays, then warm-up + timed verify calls of the whole batch from the same page-locked arrays into the same page-locked verdict array, close.  What the first run
+// on a real 8-GPU node executes on the host side, with nothing left to discover there.
+static void group_benchseq(uint64_t seed) {
+    int ids[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    for (int ver : {1, 2}) {
+        plume_ctx* ctx = nullptr;
+        g_what = "bench.py --multi-ctx sequence";
+        REQUIRE(plume_init_multi(&ctx, ids, 8) == 0 && plume_num_shards(ctx) == 8);
+        const size_t n = 8 * 23 + 5 + seed % 7;
+        Batch b = make_batch(ver, n, false);
+        // the set-up pass: eng.sign_batch(ver, msgs, off, sk, r) on pageable arrays
+        std::vector<uint8_t> pk(64 * n), nul(64 * n), c(32 * n), s(32 * n), rpt(64 * n), hr(64 * n), st(n, 0xEE);
+        REQUIRE(plume_sign_batch(ctx, ver, n, b.msgs.data(), b.off.data(), b.sk.data(), b.r.data(), nullptr, pk.data(), nul.data(), c.data(), s.data(), rpt.data(), hr.data(), st.data()) == 0);
+        REQUIRE(pk == b.pk && nul == b.nul && c == b.c && s == b.s && rpt == b.rpt && hr == b.hr);
+        for (size_t i = 0; i < n; i++) REQUIRE(st[i] == 0);
+        // synth.corrupt_for_verify: items with i mod 16 == 5, kind (i div 16) mod 4
+        std::vector<uint8_t> msgs = b.msgs;
+        for (size_t i = 5; i < n; i += 16) {
+            switch ((i / 16) % 4) {
+                case 0: s[32 * i + 31] ^= 1; break;
+                case 1: c[32 * i + 31] ^= 1; break;
+                case 2: std::memcpy(&nul[64 * i], &b.nul[64 * (i - 1)], 64); break;
+                default: if (ver == 1) { std::memcpy(&rpt[64 * i], &b.hr[64 * i], 64); std::memcpy(&hr[64 * i], &b.rpt[64 * i], 64); } else if (b.off[i + 1] > b.off[i]) msgs[b.off[i]] ^= 1; break;
+            }
+        }
+        std::vector<uint8_t> want(n);
+        oracle_verify_batch(ver, n, msgs.data(), b.off.data(), pk.data(), nul.data(), c.data(), s.data(), rpt.data(), hr.data(), want.data(), 4);
+        // capi.pinned_copy of every array, capi.pinned_empty for the verdicts
+        Arr pm(msgs.size(), 1), po(8 * (n + 1), 1), ppk(64 * n, 1), pnul(64 * n, 1), pc(32 * n, 1), ps(32 * n, 1), prp(64 * n, 1), phr(64 * n, 1), pok(n, 1);
+        pm.set(msgs); std::memcpy(po.p, b.off.data(), 8 * (n + 1)); ppk.set(pk); pnul.set(nul); pc.set(c); ps.set(s); prp.set(rpt); phr.set(hr);
+        for (int step = 0; step < 1 + 3; step++) {                                // --warmup 1 --steps 3
+            std::memset(pok.p, 0xEE, n);
+            REQUIRE(plume_verify_batch(ctx, ver, n, (const uint8_t*)pm.p, (const uint64_t*)po.p, (const uint8_t*)ppk.p, (const uint8_t*)pnul.p, (const uint8_t*)pc.p, (const uint8_t*)ps.p,
+                                       ver == 1 ? (const uint8_t*)prp.p : nullptr, ver == 1 ? (const uint8_t*)phr.p : nullptr, (uint8_t*)pok.p) == 0);
+            REQUIRE(std::memcmp(pok.p, want.data(), n) == 0);
+        }
+        plume_destroy(ctx);
+    }
 }
 
 // device-resident calls: the caller owns the device arrays and the streams
@@ -639,6 +681,7 @@ int main(int argc, char** argv) {
     if (group == "verify" || group == "all") group_verify(seed);
     if (group == "sign" || group == "all") group_sign(seed);
     if (group == "multi" || group == "all") group_multi(seed);
+    if (group == "benchseq" || group == "all") group_benchseq(seed);
     if (group == "device" || group == "all") group_device(seed);
     if (group == "misc" || group == "all") group_misc(seed);
     if (group == "devapi" || group == "all") group_devapi(seed);

@@ -350,8 +350,22 @@ def test_crafted_items_are_redone_by_the_second_launch_and_cost_only_themselves(
     try:
         eng.set_eq1_short(0)                                  # the items are crafted against the LONG form of equation 1 (s G - c pk along one chain of 128 doublings)
         got, redone = run(v)
-        assert redone >= len(idx) // 4, (redone, len(idx))   # (rounds 3-4: every crafted item met p == +-q; with the Eisenstein digits of round 5 about half of these do -- the others'
-                                                             # digits of -c no longer mirror the generator's -- and whatever does is filed; the verdicts are the CPU's either way)
+        # How many of the crafted items meet p == +-q is a property of the digit recoding (rounds 3-4: all of them; with the Eisenstein digits of round 5 the digits of -c no
+        # longer mirror the generator's for every d), so the expected count comes from the SAME chain run on the CPU: the device headers compiled for the host
+        # (tests/devsim, ds_eq1 -> verify_msm<false>, which counts a fallback exactly when the unchecked chain collided).  The generator's wide digit of a scalar this small
+        # is its one bottom digit whatever the window width, so the host build's narrower window does not change the answer.  Equality, not a bound.
+        from tests import _devsim as D
+        g = O.pt_bytes(O.G)
+        hits = {}
+        for dd in range(1, 9):
+            for neg_s in (False, True):
+                before = D.fallback_count()
+                D.eq1(((N - dd) if neg_s else dd).to_bytes(32, "big"), dd.to_bytes(32, "big"), g)
+                hits[dd, neg_s] = D.fallback_count() - before
+                assert hits[dd, neg_s] in (0, 1)
+        is_minus = np.zeros(len(idx), dtype=bool); is_minus[::2] = True
+        expect = sum(hits[int(x), bool(m)] for x, m in zip(d, is_minus))
+        assert 0 < expect <= len(idx) and redone == expect, (redone, expect, len(idx), hits)
         assert np.array_equal(got, want) and int(got.sum()) == n - len(idx)
     finally:
         eng.set_eq1_short(1)

@@ -58,6 +58,30 @@ def test_two_rank_even_split(tmp_path):
     assert np.array_equal(ok, want)
 
 
+def test_eight_rank_even_split(tmp_path):
+    """the same run at world size 8 (the node BASELINE.json's metric is quoted on): eight gloo ranks, slices [floor(dN/8), floor((d+1)N/8)) of a batch that does not divide
+    evenly, every rank's verdicts and nullifiers landing in its slice"""
+    import bench
+    from tests import _oracle_c as OC
+    from tests import synth
+    total, world = 8 * 11 + 5, 8
+    bounds = [bench.shard_bounds(total, r, world) for r in range(world)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == total and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+    assert {hi - lo for lo, hi in bounds} == {11, 12}
+    OC.lib()
+    mp.start_processes(_worker, args=(world, 29617, total, str(tmp_path)), nprocs=world, start_method="fork")
+    ok = np.concatenate([np.load(tmp_path / f"ok_{r}.npy") for r in range(world)])
+    nul = np.concatenate([np.load(tmp_path / f"nul_{r}.npy") for r in range(world)])
+    b = synth.sign_inputs(total)
+    ref = OC.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+    assert np.array_equal(nul, ref["nullifier"])
+    want = synth.expected_ok(total).copy()
+    for lo, _ in bounds:                       # an item whose corruption is "the previous item's nullifier" and that opens a shard has no previous item there (like item 0 of a batch)
+        if lo % 16 == 5 and (lo // 16) % 4 == 2:
+            want[lo] = 1
+    assert np.array_equal(ok, want)
+
+
 def test_bench_plans_weak_strong_and_config4():
     """bench.py --scaling weak|strong and --config 4 (BASELINE.json configs[3]: 2^22 V2 verifies, even split): every rank's slice, for every world size the
     driver uses, is contiguous, disjoint, covers the batch, and differs by at most one item between ranks"""

@@ -37,6 +37,11 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 constexpr int kMaxSubBatches = 64;
+#if defined(PLUME_EXP_B8T)      // timing experiment (plume_ec.h tab_pass_b): room for eight more rows per H / nullifier job behind the tables
+#define PLUME_EXP_B8T_EXTRA(n) ((size_t)2 * (n) * 8 * PLUME_TAB_ENTRY_WORDS * 4)
+#else
+#define PLUME_EXP_B8T_EXTRA(n) ((size_t)0)
+#endif
 
 struct DevBuf {
     void* p = nullptr;
@@ -232,6 +237,9 @@ struct Route {
 // waits on it first.  Calls on one stream are ordered anyway; this makes calls on DIFFERENT streams of one context safe too.
 static int ws_acquire(plume_ctx* ctx, hipStream_t st) {
     // (the previous call on the SAME stream is ordered by the stream itself: no wait packet between two calls of a stream of small calls -- each one is a few us of idle GPU)
+    // The comparison is of stream HANDLES: a caller who destroys a stream and gets the same handle value back for a new one while this context's last call on the old
+    // one is still running would skip a wait it needs.  The header therefore asks that a caller-provided stream stay alive until the context's last call on it has
+    // finished (include/plume_hip.h, plume_init); the library's own streams live as long as the context.
     if (ctx->ws_used && ctx->ws_stream != st) HIPCHK(hipStreamWaitEvent(st, ctx->ws_free, 0));
     return 0;
 }
@@ -751,7 +759,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     const bool overlapped = nsub > 1;
     size_t scr_bytes = 0;
     for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, J * (cut[k + 1] - cut[k]), 3 * (cut[k + 1] - cut[k])));
-    if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * J * n) || ctx->jobflags.ensure(J * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * J * n) ||
+    if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * J * n) || ctx->jobflags.ensure(J * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * J * n + PLUME_EXP_B8T_EXTRA(n)) ||
         ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->redo.ensure((2 * n + nsub) * 4) || ctx->digs.ensure((size_t)PLUME_VDIG_ROWS * n) ||
         (eq1short && (ctx->eq1fall.ensure(n) || ctx->eq1k.ensure(32 * n))))

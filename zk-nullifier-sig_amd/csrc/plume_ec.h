@@ -590,6 +590,29 @@ PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jo
         aff_dbl(x2, y2, x, y, iy);
         fe_mul_k(b2, beta, x2);
         sink(rows + 2 * EW, x2, y2, b2);                        // row 2: 2P
+#if defined(PLUME_EXP_B8T)
+        // TIMING EXPERIMENT ONLY (round 6): the compute and the stores of eight more rows for the jobs that would carry base-8 tables (H and the nullifier: jobs 3i + 1,
+        // 3i + 2 of the first 3 * (njobs / 4) ... the caller passes the extra region behind the tables), with a stand-in for each row's inverse: an affine addition
+        // (one multiplication for the slope, a squaring, a multiplication), the Montgomery peel (two multiplications), beta * x
+        if (job < 3 * (njobs / 4) && job % 3 != 0) {
+            uint32_t* extra = tab + njobs * TW + ((job / 3) * 2 + (job % 3 - 1)) * (8 * EW);
+            fe inv2 = iy, xa = x2, ya = y2;
+            PLUME_NOUNROLL for (int r = 0; r < 8; r++) {
+                fe lam, t, d, x3, y3, b3;
+                fe_sub_lazy<2>(d, xa, x); fe_carry(d);
+                fe_mul(t, inv2, d); fe_mul(inv2, inv2, ix);           // the peel: two multiplications per row
+                fe_sub_lazy<2>(d, ya, y); fe_carry(d);
+                fe_mul(lam, d, t);
+                fe_add_lazy(d, xa, x);
+                fe_sqr_sub<3>(x3, lam, d);
+                fe_sub_lazy<2>(t, x, x3);
+                fe_mul_sub<2>(y3, lam, t, y);
+                fe_mul_k(b3, beta, x3);
+                sink(extra + (size_t)r * EW, x3, y3, b3);
+                xa = x3; ya = y3;
+            }
+        }
+#endif
     }
 }
 // carry[.] <- 1 / carry[.] for nl lane products: thread t of T takes lanes t, t + T, ..., t + (K-1) T and spends ONE inversion on their product
@@ -851,6 +874,22 @@ PLUME_HD bool msm_all_inf(const jac& acc) {
 template <bool CHECKED, int NP = PLUME_NPOS>
 PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, const int8_t* dig, uint32_t stride, bool wide0) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
+#if defined(PLUME_EXP_B8)
+    // TIMING EXPERIMENT ONLY (round 6, tests/gpu_debug/r06_exp_b8.py; results are garbage): what equation 2's chain would cost with base-8 Eisenstein digits -- 44 positions of
+    // three doublings, a digit at 63 of 64 positions -- with the existing base-4 digit codes standing in for the base-8 ones (same row gathers, same additions)
+    if (!CHECKED && NP == PLUME_NPOS && !wide0) {
+        PLUME_NOUNROLL for (int p = 43; p >= 0; p--) {
+            if (p != 43 && !msm_all_inf(acc)) { jac_dbl_neg(acc); jac_dbl_neg(acc); jac_dbl(acc); }
+            int c = tab0 ? dig[(uint32_t)p * stride] : 0;
+            if (c == 0 && (p & 3)) c = 1;
+            if (c != 0) { fe qx, qy; ld_tab_unit(qx, qy, tab0, c); jac_madd<CHECKED>(acc, qx, qy); }
+            c = tab1 ? dig[((uint32_t)NP + (uint32_t)p) * stride] : 0;
+            if (c == 0 && (p & 3)) c = 1;
+            if (c != 0) { fe qx, qy; ld_tab_unit(qx, qy, tab1, c); jac_madd<CHECKED>(acc, qx, qy); }
+        }
+        return;
+    }
+#endif
     const uint32_t r1 = wide0 ? 2u * PLUME_NDIG : (uint32_t)NP;        // first digit row of tab1's joint slot
     PLUME_NOUNROLL for (int p = NP - 1; p >= 0; p--) {
         if (p != NP - 1 && !msm_all_inf(acc)) { jac_dbl_neg(acc); jac_dbl_neg(acc); }      // (an even number of sign-flipping doublings)
