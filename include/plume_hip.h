@@ -88,8 +88,9 @@ int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
  * batches = 2 the calls go in turn to two lanes of the context (each with a workspace, streams and events of its own; the generator's fixed tables are shared), and calls the
  * caller issues on DIFFERENT streams run side by side: the memory-bound table passes and the ramps / tails of one batch's kernels fit beside the issue-bound multi-scalar
  * kernel of the other -- about 1 % per 2^20-item batch on the MI355X (17.95 against 18.14 ms, round 5), a third lane gains nothing more (1..4 accepted).  It pays for
- * LARGE calls only: since the small-call kernels of round 5 a 2^16-item call is latency-bound and two of them side by side measured 1.55 against 1.42 ms each, so device-resident
- * calls of fewer than 2^17 items (env PLUME_IN_FLIGHT_MIN) all run on the context's first lane, whatever `batches` is.
+ * LARGE calls only: calls of up to 2^16 items are latency-bound and two of them side by side gain nothing (round 6, one box, interleaved: -0.1 .. +0.6 % per call for 2^10 .. 2^16
+ * items, -3.8 % at 2^17), so device-resident calls of fewer than 2^17 items (env PLUME_IN_FLIGHT_MIN) all run on the context's first lane, whatever `batches` is, and never
+ * make it allocate the second workspace.
  * Results do not depend on it; calls on one stream keep that stream's order -- including NULL, which always means the stream of the context the caller holds,
  * whichever lane serves the call (so a sign followed by a verify of its outputs, both with stream = NULL, stay ordered).  Costs a second per-batch workspace.  Single-device contexts only (a multi-device context
  * already runs its shards side by side).  plume_last_stage_times / plume_last_redo_tasks then report the lane of the last device-resident call. */
@@ -135,7 +136,7 @@ int plume_get_eq1_short(const plume_ctx* ctx, size_t* min_items);
  *                            addition (default 16384; 0: never): on a machine a small call leaves empty, the kernel's time is one chain's latency
  *   PLUME_JOBS_PER_LANE      jobs per lane of the table passes (default: 3..6 by batch size)
  *   PLUME_SIGN_UNIFORM       default level of plume_set_sign_uniform (0, 1, 2; default 1)
- *   PLUME_EQ1_SHORT, PLUME_EQ1_SHORT_MIN   plume_set_eq1_short's mode and the smallest call that takes the short form (default 1, 131072)
+ *   PLUME_EQ1_SHORT, PLUME_EQ1_SHORT_MIN   plume_set_eq1_short's mode and the smallest call that takes the short form (default 1, 65536)
  *   PLUME_NO_AFFINITY        multi-device contexts: leave the shard threads' CPU affinity alone */
 /* Host-pointer calls only: a call is cut into pieces; piece k+1 uploads while piece k computes and piece k-1 downloads (an upload, a download and the compute streams,
  * four staging slots), so only the first upload and the last download are exposed.  The first piece is small (default 1<<16 items), each following piece up to three times

@@ -172,8 +172,11 @@ struct plume_ctx {
     plume_ctx* lane_last = nullptr;                               // the lane the last device-resident call went to (plume_last_stage_times, plume_last_redo_tasks)
     DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo, digs, eq1fall, eq1k, clk;
     int eq1_short = 1;                                             // verify calls that give R: equation 1 in its short form (plume_eis.h).  0 = long form always (A/B), 2 = test: every item takes the fallback
-    size_t eq1_short_min = (size_t)1 << 17;                        // ... for calls (slices) of at least this many items: below, the half-GCD's ~45 dependent steps are latency nothing hides
-                                                                   // (2^16 items: scalar stage +0.12 ms, multi-scalar kernel -0.09 ms; 2^20: +0.28 / -1.1 ms)
+    size_t eq1_short_min = (size_t)1 << 16;                        // ... for calls of at least this many items.  Round 6 sweep on one box, interleaved (profiles/r06_eq1_threshold.txt), now that the
+                                                                   // scalar stage -- half-GCD included -- of calls up to 2^16 runs in role B of the two-role ingest kernel: 2^16 items 1.385 -> 1.343 ms
+                                                                   // (-3.0 %), 2^17 -4.4 %, 2^18 -4.1 %; 2^15 +6.3 % (0.928 -> 0.987: one wavefront per SIMD, the chain's latency is the
+                                                                   // kernel's time and equation 2's chain is the long one either way), <= 2^14 +35 % (the half chains of k_verify_msm_pair
+                                                                   // need the long form).  Round 5's threshold, before the scalar stage moved: 2^17
     DevBuf dec[4], preflags;
     DevBuf agg[15];      // aggregate check (plume_aggregate.h): haff, scal, flags, gs, hash_ok, counters, count, sort tiles, sorted, bsum, bsuminf, red, redinf, ssum, perm + its histogram
     DevBuf agg_record;   // the running record of a host-pointer aggregate call (pieces of one batch)
@@ -650,8 +653,8 @@ extern "C" int plume_set_sub_batches(plume_ctx* ctx, int sub_batches) {
 // (each with its workspace, streams and events; the generator's fixed tables are shared) -- so that calls the caller issues on DIFFERENT streams run side by side instead
 // of queueing for one workspace: the memory-bound table passes and the ramps / tails of one batch's kernels fit beside the issue-bound multi-scalar kernel of another
 // (2^20 verifies: about 1 % per batch with two in flight; three gain nothing more).  Calls of fewer than in_flight_min items (2^17; env PLUME_IN_FLIGHT_MIN) stay on the
-// first lane: since round 5 they are latency-bound and two side by side measured SLOWER than one after the other (2^16: 1.55 against 1.42 ms each).  Results do not depend
-// on any of it.  Calls on ONE stream stay in that stream's order whatever k is.  Default 1.
+// first lane: they are latency-bound and two of them side by side gain nothing (round 6 sweep, 2^10 .. 2^16: -0.1 .. +0.6 % per call; 2^17: -3.8 %), so they do not
+// make the context allocate a second workspace either.  Results do not depend on any of it.  Calls on ONE stream stay in that stream's order whatever k is.  Default 1.
 extern "C" int plume_set_in_flight(plume_ctx* ctx, int batches) {
     if (!ctx || batches < 1 || batches > 4) return fail(PLUME_ERR_ARG, "plume_set_in_flight: bad argument");
     if (!ctx->shards.empty()) return fail(PLUME_ERR_ARG, "plume_set_in_flight: a multi-device context runs its shards side by side already");

@@ -8,8 +8,10 @@
 // (Antipa et al.'s accelerated verification, in the endomorphism ring: the four-dimensional form).  So
 //     k G - upsilon pk - tau R = O,   k = tau s mod n,
 // where pk and R carry 64-bit coefficients on (P, lambda P): a chain of 64 doublings instead of 128, and k G costs fifteen additions from the doubling-free comb the signer
-// already uses.  The multi-scalar kernel evaluates  k G - upsilon pk - (tau - 1) R  and the finalize stage compares it with R exactly as before -- for a valid signature the
-// accumulator ends at R, not at the identity, so the hot loop's unchecked additions never meet their exceptional case on honest inputs.
+// already uses.  The multi-scalar kernel evaluates  k G - upsilon pk - (tau - 1) R  and the finalize stage compares it with R exactly as before -- a valid signature's
+// accumulator ends at R, not at the identity, so the hot loop's unchecked additions meet no exceptional case on honest inputs.  (One valid input does end at the identity: the
+// signature with nonce r = 0, R = Hr = identity, which the reference accepts.  R's table is then absent, k G - upsilon pk closes at the identity in the comb's last addition, the
+// task is filed and the redo launch's checked chain returns the identity: tests/golden edge cases "r=0", tests/test_gpu_round6.py.)
 //
 // Quotients are ESTIMATED in double precision (any quotient gives a unimodular step, so the relation above holds whatever the estimates are; good estimates make the
 // coefficients short).  Measured over 10^5 random and 10^3 crafted c: coefficients <= 65 bits, 39 steps on average, 51 at most (tests/test_devsim.py).  The caller checks
