@@ -475,32 +475,13 @@ def small_batch_entry(eng, dev, log2n=16):
     dt, dt_ev = sorted(offs)[1], sorted(ons)[1]
     assert bool((ok.cpu() == torch.from_numpy(synth.expected_ok(n))).all())
     stages = {k: round(x, 4) for k, x in eng.last_stage_times()}
-    # The same calls with TWO batches in flight: two lanes of the context (plume_set_in_flight) on two streams, calls alternating.  A 2^16 batch leaves most SIMDs one or two
-    # wavefronts (the kernels run on latency, not on issue slots), so the validation / table kernels of one call fit beside the multi-scalar kernel of the other.
-    # A throughput figure for a server holding several small batches -- NOT the latency of one call, which is the entry above.
-    ok2 = torch.zeros(n, dtype=torch.uint8, device=dev)
-    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-    fn2 = lambda o, st: eng.verify_batch_device(1, n, d["msgs"], off, mb, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], o, stream=st)  # noqa: E731
-    torch.cuda.synchronize()
-    eng.set_in_flight(2)
-    try:
-        for _ in range(2):
-            fn2(ok, s1); fn2(ok2, s2)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn2(ok, s1); fn2(ok2, s2)
-        torch.cuda.synchronize()
-        dt2 = (time.perf_counter() - t0) / (2 * reps)
-    finally:
-        eng.set_in_flight(1)
-    assert bool((ok2.cpu() == torch.from_numpy(synth.expected_ok(n))).all()) and bool((ok.cpu() == torch.from_numpy(synth.expected_ok(n))).all())
     return {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "ms_per_batch_with_stage_events": round(dt_ev * 1e3, 4), "stage_ms": stages,
             "stage_events": "ms_per_batch: the library's default, no timing events inside the call; stage_ms and ms_per_batch_with_stage_events: plume_set_stage_timing(1), as everywhere else in this line",
             "workload": (f"BASELINE.json configs[1]: " if log2n == 16 else "") + f"2^{log2n} V1 verifies per call, inputs resident in HBM, {reps} calls back to back, median of 3 rounds",
             "rounds_ms": {"default": [round(x * 1e3, 4) for x in offs], "with_stage_events": [round(x * 1e3, 4) for x in ons]},
-            "two_batches_in_flight": {"items_per_s": round(n / dt2, 1), "ms_per_batch": round(dt2 * 1e3, 4),
-                                      "note": "plume_set_in_flight(2), two streams, calls alternating: throughput with two small batches in flight, not one call's latency"}}
+            "msm_kernel": eng.last_msm_kernel(),
+            "batches_in_flight": "not measured here since round 6: calls of fewer than 2^17 items stay on the context's first lane whatever plume_set_in_flight says (two of them side by side "
+                                 "gain nothing: profiles/r06_in_flight_small_calls.txt)"}
 
 
 def multi_ctx_main(a):
@@ -860,6 +841,30 @@ def main():
                                          "achieved_whole_path": round(whole, 1), "frac_whole_path": round(whole / mad_rate, 4),
                                          "msm_kernel_ms": msm_ms,
                                          "accounting": f"{FPMUL_SIGN_PER_ITEM if sign else FPMUL_PER_ITEM[ver]} Fp-mult/{op} x 72 MACs (SURVEY.md §8d, frozen in BASELINE.md §4)"}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(ver, sign)
+            except Exception as e:
+                line["cpu_baseline"] = {"error": str(e)}
+        # Everything the contract asks for is in `line` now.  The secondary sections below (other workloads, end-to-end host calls) add to it -- under a watchdog: should one of
+        # them ever stall (a GPU call that never returns cannot be interrupted from Python), the line is printed as it stands, says so, and the process ends, instead of the
+        # headline being lost with it.  (Round 6: one bench run on one box of the pool sat in a secondary section until its 900 s timeout; five later runs of the same command on other
+        # boxes took 12 s each and the cause was never seen again.)
+        import threading
+        done = threading.Event()
+
+        def _watchdog():
+            if not done.wait(float(os.environ.get("PLUME_BENCH_SECONDARY_TIMEOUT", "420"))):
+                line["watchdog"] = "the secondary sections (other_workloads / e2e_host_pinned) did not finish in time: this line carries what was measured before them"
+                for _ in range(5):                               # (the main thread may be adding a key just now)
+                    try:
+                        out = json.dumps(dict(line), default=str)
+                        break
+                    except RuntimeError:
+                        time.sleep(0.05)
+                print(out, flush=True)
+                os._exit(0)
+        threading.Thread(target=_watchdog, daemon=True).start()
         if world == 1 and not a.no_extras and a.scaling == "weak" and a.log2_batch == 20 and not sign:
             try:
                 line["other_workloads"] = extras(eng, dev, n, b, signed if ver == 1 else None)
@@ -885,11 +890,7 @@ def main():
                     line["e2e_host_pinned"] = {"error": str(e)}
                 finally:
                     eng.set_stage_timing(True)
-        if world == 1 and not a.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(ver, sign)
-            except Exception as e:
-                line["cpu_baseline"] = {"error": str(e)}
+        done.set()
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -365,6 +365,45 @@ PLUME_HD void eisd_store_glv(int8_t* dig, uint32_t stride, const glv_half& h1, c
     (void)eisd_store<PLUME_NPOS, 4>(dig, stride, h1.m, h1.neg != 0, h2.m, h2.neg != 0, flip);
 }
 
+// ---------------------------------------------------------------------------------- base-8 digits in the Eisenstein integers (round 6)
+// The same idea one size up: base 8, one digit per THREE doublings, from the 64 residues of Z[w] / 8.  Under the units they fall into ten orbits of six and one of three (the
+// class of 4), so ELEVEN rows serve every digit -- rows 0..2 are the base-4 table (P, theta P, 2P), rows 3..10 the multiples 3 + w, 3 + 2w, 3, 2 theta, 4 + w, 3 - w, 4,
+// 5 + 3w of P (gen_eis8.py: norms 7 7 9 12 13 13 16 19), built from rows 0..2 by one more round of inversions (tab8_* below).  A pair of 128-bit halves takes 44 positions
+// (43 x 3 = 129 doublings, an addition at 63 of 64 positions) where base 4 takes 65 (128 doublings, 15 of 16): 43 additions per joint slot instead of 61.  Used where the
+// eight extra rows per table cost less than the eighteen additions they save: the two slots of the verifier's second equation, s H - c nullifier (measured before it was
+// built, with stand-in digits: the multi-scalar kernel 13.95 -> 12.3 ms per 2^20 verifies; LABNOTES.md round 6).
+//   digit code: 0 = nothing to add, else 1 + 6 row + 2 j + neg = (-1)^neg w^j (row point) -- codes 1..18 mean what they mean in base 4.
+// Recoding: three bits per position, carries in {-1, 0, 1}, one lookup per position in a 256-entry table (gen_eis8.py -> plume_eis8.inc) indexed by the residues and signs of
+// t = sign chunk + carry.
+#define PLUME_NPOS8 44          // pairs of 128-bit halves
+#define PLUME_TAB8_ROWS 8       // rows 3..10 of a base-8 table: a second array, PLUME_TAB8_ROWS x PLUME_TAB_ENTRY_WORDS words per base-8 job
+PLUME_HD uint32_t eisd8_entry(int ta, int tb) {
+    static const uint16_t T8[256] = {
+#include "plume_eis8.inc"
+    };
+    return T8[(((uint32_t)ta & 7u) << 3) | ((uint32_t)tb & 7u) | (ta < 0 ? 64u : 0u) | (tb < 0 ? 128u : 0u)];
+}
+// NP base-8 digit codes of  +-(a + b w)  (arguments as eisd_store); false if a carry is left over
+template <int NP, int NW>
+PLUME_HD bool eisd8_store(int8_t* dig, uint32_t stride, const uint32_t (&am)[NW], bool aneg, const uint32_t (&bm)[NW], bool bneg, bool flip) {
+    const int sa = (aneg != flip) ? -1 : 1, sb = (bneg != flip) ? -1 : 1;
+    int ca = 0, cb = 0;
+    PLUME_UNROLL for (int i = 0; i < NP; i++) {
+        const int bit = 3 * i, w = bit >> 5, sh = bit & 31;
+        uint32_t xa = w < NW ? am[w < NW ? w : 0] >> sh : 0u, xb = w < NW ? bm[w < NW ? w : 0] >> sh : 0u;
+        if (sh > 29 && w + 1 < NW) { xa |= am[w + 1 < NW ? w + 1 : 0] << (32 - sh); xb |= bm[w + 1 < NW ? w + 1 : 0] << (32 - sh); }
+        const int ta = sa * (int)(xa & 7u) + ca, tb = sb * (int)(xb & 7u) + cb;
+        const uint32_t e = eisd8_entry(ta, tb);
+        dig[(uint32_t)i * stride] = (int8_t)(e & 127u);
+        ca = (ta - ((int)((e >> 7) & 15u) - 5)) >> 3;                  // exact: t = d (mod 8)
+        cb = (tb - ((int)((e >> 11) & 15u) - 5)) >> 3;
+    }
+    return ca == 0 && cb == 0;
+}
+PLUME_HD void eisd8_store_glv(int8_t* dig, uint32_t stride, const glv_half& h1, const glv_half& h2, bool flip) {
+    (void)eisd8_store<PLUME_NPOS8, 4>(dig, stride, h1.m, h1.neg != 0, h2.m, h2.neg != 0, flip);
+}
+
 // ------------------------------------------------------------------------------------------ window tables
 // One table = 3 rows x 32 words (128 B = one cache line): row 0 = P, row 1 = theta P = P - lambda P, row 2 = 2P, affine, as 29-bit limbs of tight field elements:
 //     [ x0..x7 | y0..y7 | b0..b7 | x8 y8 b8 0 | 0 0 0 0 ]        b = beta * x (the x of lambda * (row point))
@@ -549,22 +588,117 @@ PLUME_HD void tab_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t 
     }
     carry = acc;
 }
-// Pass B (jobs descending): carry = 1 / (the lane's product) in; rows P, theta P, 2P of every job out.
+// ------------------------------------------------------------------------------ rows 3..10 of a base-8 table (round 6)
+// Which jobs of a table stage carry base-8 tables, and where their rows 3..10 go (PLUME_TAB8_ROWS rows of PLUME_TAB_ENTRY_WORDS words per such job, a second array):
+//   kind 0: none;  kind 1: the verifier -- jobs [0, n3) come as (pk, H, nullifier) triples, H and the nullifier are base-8 jobs, array index 2 (job / 3) + job % 3 - 1
+struct Tab8Spec {
+    uint32_t* tab8;
+    size_t n3;
+    int kind;
+    PLUME_HD bool is8(size_t job) const { return kind == 1 && job < n3 && job % 3 != 0; }
+    PLUME_HD size_t index(size_t job) const { return (job / 3) * 2 + (job % 3) - 1; }
+};
+PLUME_HD Tab8Spec tab8_none() { Tab8Spec t; t.tab8 = nullptr; t.n3 = 0; t.kind = 0; return t; }
+struct tab_rows012 { fe x0, y0, b0, xt, yt, bt, x2, y2, b2; };        // rows 0..2 of a table: x, y, beta x of P, theta P, 2P (tight)
+// Rows 3..10 are sums of two points the rows 0..2 give for free (a unit multiple of a row is (x | beta x | beta^2 x, +-y)), or doubles:
+//     row 3 = (3 + w) P  = 2P + (-w^2) P          row 4 = (3 + 2w) P = 2P + w theta P         row 5 = 3 P     = 2P + P              row 6 = 2 theta P = dbl(theta P)
+//     row 7 = (4 + w) P  = 2P + (-w^2) theta P    row 8 = (3 - w) P  = 2P + theta P           row 9 = 4 P     = dbl(2P)             row 10 = (5 + 3w) P = row 4 + (-w^2) theta P
+// Each needs the inverse of one denominator (x_Q - x_A, or 2y): d3 .. d9 straight from rows 0..2, and row 10's, x_Q - x(row 4), from row 4 in fraction form --
+// x(row 4) = X4 / d4^2 with X4 = n4^2 - (x2 + beta xt) d4^2, so x_Q - x(row 4) = e / d4^2 with e = x_Q d4^2 - X4, and ONE inverse w = 1 / (d4 e) serves both: 1 / d4 = w e,
+// d4^2 / e = w d4^3.  Seven factors per job; their product joins the lane's second running product (Montgomery's trick, as for rows 1..2).  None of them vanishes for a
+// point of the group: x_Q = x_A means Q = +-A, i.e. (a +- q) P = O for Eisenstein integers a, q of norm <= 19 whose sum and difference are non-zero and of norm < n.
+// A zero factor (garbage fed by a test) is replaced by 1: that job's rows are garbage, its lane's other jobs are not.
+struct tab8_dens {
+    fe f[7];          // d3, d5, d6, d7, d8, d9, d4 e
+    fe d4, dd4, e;    // d4, d4^2, e
+    fe q0, qt;        // beta^2 x0, beta^2 xt (tight)
+};
+PLUME_HD void fe_beta2(fe& r, const fe& x, const fe& bx) { fe t; fe_add_lazy(t, x, bx); fe_neg(r, t); }       // beta^2 x = -(x + beta x)
+PLUME_HD void tab8_factors(tab8_dens& o, const tab_rows012& r) {
+    fe n4, nn, t, m, X4;
+    fe_beta2(o.q0, r.x0, r.b0); fe_beta2(o.qt, r.xt, r.bt);
+    fe_sub(o.f[0], o.q0, r.x2);                                 // d3 = beta^2 x0 - x2
+    fe_sub(o.f[1], r.x0, r.x2);                                 // d5 = x0 - x2
+    fe_dbl(o.f[2], r.yt);                                       // d6 = 2 yt
+    fe_sub(o.f[3], o.qt, r.x2);                                 // d7 = beta^2 xt - x2
+    fe_sub(o.f[4], r.xt, r.x2);                                 // d8 = xt - x2
+    fe_dbl(o.f[5], r.y2);                                       // d9 = 2 y2
+    fe_sub(o.d4, r.bt, r.x2);                                   // d4 = beta xt - x2
+    fe_sub(n4, r.yt, r.y2);
+    fe_sqr(o.dd4, o.d4); fe_sqr(nn, n4);
+    fe_add_lazy(t, r.x2, r.bt); fe_mul(m, t, o.dd4);
+    fe_sub(X4, nn, m);                                          // x(row 4) = X4 / d4^2
+    fe_mul(t, o.qt, o.dd4);
+    fe_sub(o.e, t, X4);                                         // e = beta^2 xt d4^2 - X4
+    fe_mul(o.f[6], o.d4, o.e);
+    PLUME_UNROLL for (int k = 0; k < 7; k++) guard_one(o.f[k], true);
+}
+PLUME_HD void tab8_product(fe& D, const tab8_dens& o) {
+    fe_mul(D, o.f[0], o.f[1]);
+    PLUME_UNROLL for (int k = 2; k < 7; k++) fe_mul(D, D, o.f[k]);
+}
+// A + Q for affine A = (xa, ya), Q = (xq, +-yq) (negq: the minus sign) and inv = 1 / (xq - xa); every operand tight
+PLUME_HD void aff_add(fe& x3, fe& y3, const fe& xa, const fe& ya, const fe& xq, const fe& yq, bool negq, const fe& inv) {
+    fe num, lam, s, t;
+    if (negq) { fe_add_lazy(t, yq, ya); fe_neg(num, t); } else fe_sub(num, yq, ya);
+    fe_mul(lam, num, inv);
+    fe_add_lazy(s, xa, xq);
+    fe_sqr_sub<3>(x3, lam, s);                                  // lambda^2 - xa - xq
+    fe_sub_lazy<2>(t, xa, x3);
+    fe_mul_sub<2>(y3, lam, t, ya);                              // lambda (xa - x3) - ya
+}
+// the eight rows from rows 0..2 and Dinv = 1 / (the product of the job's seven factors)
+template <class RowSink>
+PLUME_HD void tab8_rows(uint32_t* rows8, const tab_rows012& r, const tab8_dens& o, const fe& Dinv, const RowSink& sink) {
+    constexpr size_t EW = PLUME_TAB_ENTRY_WORDS;
+    const fe beta = fe_beta();
+    // the seven inverses from the one: prefix products up, peel down
+    fe pre[7], iv[7], inv = Dinv;
+    pre[0] = fe_small(1);
+    PLUME_UNROLL for (int k = 1; k < 7; k++) fe_mul(pre[k], pre[k - 1], o.f[k - 1]);
+    PLUME_UNROLL for (int k = 6; k >= 0; k--) { fe_mul(iv[k], inv, pre[k]); if (k) fe_mul(inv, inv, o.f[k]); }
+    fe i4, i10, t, x, y, b, x4, y4;
+    fe_mul(i4, iv[6], o.e);                                     // 1 / d4
+    fe_mul(t, o.dd4, o.d4); fe_mul(i10, iv[6], t);              // d4^2 / e = 1 / (x_Q - x(row 4))
+    aff_add(x, y, r.x2, r.y2, o.q0, r.y0, true, iv[0]);  fe_mul_k(b, beta, x); sink(rows8 + 0 * EW, x, y, b);          // row 3
+    aff_add(x4, y4, r.x2, r.y2, r.bt, r.yt, false, i4);  fe_mul_k(b, beta, x4); sink(rows8 + 1 * EW, x4, y4, b);       // row 4
+    aff_add(x, y, r.x2, r.y2, r.x0, r.y0, false, iv[1]); fe_mul_k(b, beta, x); sink(rows8 + 2 * EW, x, y, b);          // row 5
+    aff_dbl(x, y, r.xt, r.yt, iv[2]);                    fe_mul_k(b, beta, x); sink(rows8 + 3 * EW, x, y, b);          // row 6
+    aff_add(x, y, r.x2, r.y2, o.qt, r.yt, true, iv[3]);  fe_mul_k(b, beta, x); sink(rows8 + 4 * EW, x, y, b);          // row 7
+    aff_add(x, y, r.x2, r.y2, r.xt, r.yt, false, iv[4]); fe_mul_k(b, beta, x); sink(rows8 + 5 * EW, x, y, b);          // row 8
+    aff_dbl(x, y, r.x2, r.y2, iv[5]);                    fe_mul_k(b, beta, x); sink(rows8 + 6 * EW, x, y, b);          // row 9
+    aff_add(x, y, x4, y4, o.qt, r.yt, true, i10);        fe_mul_k(b, beta, x); sink(rows8 + 7 * EW, x, y, b);          // row 10
+}
+PLUME_HD void ld_rows012(tab_rows012& r, const uint32_t* t) {
+    const uint32_t *e0 = t, *e1 = t + PLUME_TAB_ENTRY_WORDS, *e2 = t + 2 * PLUME_TAB_ENTRY_WORDS;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) {
+        r.x0.v[i] = e0[i]; r.y0.v[i] = e0[8 + i]; r.b0.v[i] = e0[16 + i];
+        r.xt.v[i] = e1[i]; r.yt.v[i] = e1[8 + i]; r.bt.v[i] = e1[16 + i];
+        r.x2.v[i] = e2[i]; r.y2.v[i] = e2[8 + i]; r.b2.v[i] = e2[16 + i];
+    }
+    r.x0.v[8] = e0[24]; r.y0.v[8] = e0[25]; r.b0.v[8] = e0[26];
+    r.xt.v[8] = e1[24]; r.yt.v[8] = e1[25]; r.bt.v[8] = e1[26];
+    r.x2.v[8] = e2[24]; r.y2.v[8] = e2[25]; r.b2.v[8] = e2[26];
+}
+
+// Pass B (jobs descending): carry = 1 / (the lane's product) in; rows P, theta P, 2P of every job out.  For the base-8 jobs (t8) the product of the level-2 factors joins the
+// lane's SECOND running product, parked in scr2 like the first (carry2 = that product out; 1 where the lane holds no such job).
 template <class RowSink>
 PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, const uint32_t* scr, size_t sstride, size_t slane,
-                         const fe& carry, bool guard, const RowSink& sink) {
+                         const fe& carry, bool guard, const RowSink& sink, const Tab8Spec& t8 = tab8_none(), uint32_t* scr2 = nullptr, fe* carry2 = nullptr) {
     const fe beta = fe_beta();
     constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
-    fe inv = carry;
+    fe inv = carry, acc2 = fe_small(1);
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
         const size_t job = j0 + (size_t)jj;
         jac b;
         const bool zone = tab_base(b, bases, jobflags, njobs, job);
-        fe dy, dx, dz, pyx, D, Dinv, x, y, iy, ix;
+        fe dy, dx, dz, pyx, D, Dinv, iy, ix;
+        tab_rows012 r;
         tab_dens(dy, dx, dz, pyx, D, b, zone, guard);
         tab_unpark(Dinv, inv, scr, sstride, slane, (size_t)jj, D);
         if (zone) {
-            x = b.x; y = b.y;
+            r.x0 = b.x; r.y0 = b.y;
             fe_mul(iy, Dinv, dx);                               // 1 / (2y)
             fe_mul(ix, Dinv, dy);                               // 1 / ((beta - 1) x)
         } else {
@@ -573,46 +707,51 @@ PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jo
             fe zi, zi2, z2, t;
             fe_mul(zi, Dinv, pyx);
             fe_sqr(zi2, zi);
-            fe_mul(x, b.x, zi2);
-            fe_mul(t, zi2, zi); fe_mul(y, b.y, t);
+            fe_mul(r.x0, b.x, zi2);
+            fe_mul(t, zi2, zi); fe_mul(r.y0, b.y, t);
             fe_sqr(z2, dz);
             fe_mul(t, Dinv, dz);                                // 1 / (dy dx)
             fe_mul(iy, t, dx); fe_mul(iy, iy, z2); fe_mul(iy, iy, dz);      // Z^3 / (2Y)
             fe_mul(ix, t, dy); fe_mul(ix, ix, z2);                          // Z^2 / ((beta - 1) X)
         }
         uint32_t* rows = tab + job * TW;
-        fe bx, x2, y2, b2;
-        fe_mul_k(bx, beta, x);
-        sink(rows, x, y, bx);                                   // row 0: P
-        aff_theta(x2, y2, x, y, bx, ix);
-        fe_mul_k(b2, beta, x2);
-        sink(rows + EW, x2, y2, b2);                            // row 1: theta P = P - lambda P
-        aff_dbl(x2, y2, x, y, iy);
-        fe_mul_k(b2, beta, x2);
-        sink(rows + 2 * EW, x2, y2, b2);                        // row 2: 2P
-#if defined(PLUME_EXP_B8T)
-        // TIMING EXPERIMENT ONLY (round 6): the compute and the stores of eight more rows for the jobs that would carry base-8 tables (H and the nullifier: jobs 3i + 1,
-        // 3i + 2 of the first 3 * (njobs / 4) ... the caller passes the extra region behind the tables), with a stand-in for each row's inverse: an affine addition
-        // (one multiplication for the slope, a squaring, a multiplication), the Montgomery peel (two multiplications), beta * x
-        if (job < 3 * (njobs / 4) && job % 3 != 0) {
-            uint32_t* extra = tab + njobs * TW + ((job / 3) * 2 + (job % 3 - 1)) * (8 * EW);
-            fe inv2 = iy, xa = x2, ya = y2;
-            PLUME_NOUNROLL for (int r = 0; r < 8; r++) {
-                fe lam, t, d, x3, y3, b3;
-                fe_sub_lazy<2>(d, xa, x); fe_carry(d);
-                fe_mul(t, inv2, d); fe_mul(inv2, inv2, ix);           // the peel: two multiplications per row
-                fe_sub_lazy<2>(d, ya, y); fe_carry(d);
-                fe_mul(lam, d, t);
-                fe_add_lazy(d, xa, x);
-                fe_sqr_sub<3>(x3, lam, d);
-                fe_sub_lazy<2>(t, x, x3);
-                fe_mul_sub<2>(y3, lam, t, y);
-                fe_mul_k(b3, beta, x3);
-                sink(extra + (size_t)r * EW, x3, y3, b3);
-                xa = x3; ya = y3;
-            }
+        fe_mul_k(r.b0, beta, r.x0);
+        sink(rows, r.x0, r.y0, r.b0);                           // row 0: P
+        aff_theta(r.xt, r.yt, r.x0, r.y0, r.b0, ix);
+        fe_mul_k(r.bt, beta, r.xt);
+        sink(rows + EW, r.xt, r.yt, r.bt);                      // row 1: theta P = P - lambda P
+        aff_dbl(r.x2, r.y2, r.x0, r.y0, iy);
+        fe_mul_k(r.b2, beta, r.x2);
+        sink(rows + 2 * EW, r.x2, r.y2, r.b2);                  // row 2: 2P
+        if (t8.is8(job)) {
+            tab8_dens o;
+            fe D2;
+            tab8_factors(o, r);
+            tab8_product(D2, o);
+            tab_park(acc2, scr2, sstride, slane, (size_t)jj, D2);
         }
-#endif
+    }
+    if (carry2) *carry2 = acc2;
+}
+// Pass D (jobs ASCENDING: the reverse of the order pass B parked in): carry2 = 1 / (the lane's second product) in; rows 3..10 of every base-8 job out.  Rows 0..2 are read
+// back from the table (three lines), the factors recomputed from them.
+template <class RowSink>
+PLUME_HD void tab_pass_d(const uint32_t* tab, size_t njobs, size_t j0, int cnt, const uint32_t* scr2, size_t sstride, size_t slane, const fe& carry2, const RowSink& sink,
+                         const Tab8Spec& t8) {
+    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS;
+    (void)njobs;
+    fe inv = carry2;
+    PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
+        const size_t job = j0 + (size_t)jj;
+        if (!t8.is8(job)) continue;
+        tab_rows012 r;
+        ld_rows012(r, tab + job * TW);
+        tab8_dens o;
+        fe D2, D2inv;
+        tab8_factors(o, r);
+        tab8_product(D2, o);
+        tab_unpark(D2inv, inv, scr2, sstride, slane, (size_t)jj, D2);
+        tab8_rows(t8.tab8 + t8.index(job) * (size_t)PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS, r, o, D2inv, sink);
     }
 }
 // carry[.] <- 1 / carry[.] for nl lane products: thread t of T takes lanes t, t + T, ..., t + (K-1) T and spends ONE inversion on their product
@@ -634,15 +773,21 @@ PLUME_HD void tab_invert_group(uint32_t* carry, size_t nl, size_t T, size_t t) {
         if (l < nl) st_fe_soa(carry, nl, l, o);
     }
 }
-// Both passes in one function with the inversion in place: single-lane builds (the host harness holds the pass sequence to it).
+// All passes in one function with the inversions in place: single-lane builds (the host harness holds the pass sequence to it).  scr: two park regions of cnt entries when
+// the stage has base-8 jobs.
 template <class RowSink = DirectRowSinkSync>
 PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
-                          const RowSink& sink = RowSink()) {
-    fe carry, inv;
+                          const RowSink& sink = RowSink(), const Tab8Spec& t8 = tab8_none()) {
+    fe carry, inv, carry2;
     bool guard;
+    uint32_t* scr2 = scr + (size_t)cnt * PLUME_TAB_SCR_WORDS * sstride;
     tab_pass_a(bases, jobflags, njobs, j0, cnt, scr, sstride, slane, carry, guard);
     sink.inv(inv, carry, 1);
-    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr, sstride, slane, inv, guard, sink);
+    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr, sstride, slane, inv, guard, sink, t8, t8.kind ? scr2 : nullptr, &carry2);
+    if (t8.kind) {
+        sink.inv(inv, carry2, 1);
+        tab_pass_d(tab, njobs, j0, cnt, scr2, sstride, slane, inv, sink, t8);
+    }
 }
 
 // ------------------------------------------------------------------------------ the generator's fixed tables, one entry per lane (round 3)
@@ -874,22 +1019,6 @@ PLUME_HD bool msm_all_inf(const jac& acc) {
 template <bool CHECKED, int NP = PLUME_NPOS>
 PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, const int8_t* dig, uint32_t stride, bool wide0) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
-#if defined(PLUME_EXP_B8)
-    // TIMING EXPERIMENT ONLY (round 6, tests/gpu_debug/r06_exp_b8.py; results are garbage): what equation 2's chain would cost with base-8 Eisenstein digits -- 44 positions of
-    // three doublings, a digit at 63 of 64 positions -- with the existing base-4 digit codes standing in for the base-8 ones (same row gathers, same additions)
-    if (!CHECKED && NP == PLUME_NPOS && !wide0) {
-        PLUME_NOUNROLL for (int p = 43; p >= 0; p--) {
-            if (p != 43 && !msm_all_inf(acc)) { jac_dbl_neg(acc); jac_dbl_neg(acc); jac_dbl(acc); }
-            int c = tab0 ? dig[(uint32_t)p * stride] : 0;
-            if (c == 0 && (p & 3)) c = 1;
-            if (c != 0) { fe qx, qy; ld_tab_unit(qx, qy, tab0, c); jac_madd<CHECKED>(acc, qx, qy); }
-            c = tab1 ? dig[((uint32_t)NP + (uint32_t)p) * stride] : 0;
-            if (c == 0 && (p & 3)) c = 1;
-            if (c != 0) { fe qx, qy; ld_tab_unit(qx, qy, tab1, c); jac_madd<CHECKED>(acc, qx, qy); }
-        }
-        return;
-    }
-#endif
     const uint32_t r1 = wide0 ? 2u * PLUME_NDIG : (uint32_t)NP;        // first digit row of tab1's joint slot
     PLUME_NOUNROLL for (int p = NP - 1; p >= 0; p--) {
         if (p != NP - 1 && !msm_all_inf(acc)) { jac_dbl_neg(acc); jac_dbl_neg(acc); }      // (an even number of sign-flipping doublings)
@@ -913,6 +1042,46 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
         if (c != 0) { fe qx, qy; ld_tab_unit(qx, qy, tab1, c); jac_madd<CHECKED>(acc, qx, qy); }
     }
 }
+// ---- the chain over base-8 digits (round 6): two joint slots, PLUME_NPOS8 positions of three doublings.  A slot's table is its rows 0..2 (t3: the base-4 table, one line each)
+// and its rows 3..10 (t8: PLUME_TAB8_ROWS lines); digit rows [0, NP8) belong to slot A, [NP8, 2 NP8) to slot B.  A NULL t3 (a job flagged INF) contributes nothing.
+PLUME_HD void ld_tab_unit8(fe& qx, fe& qy, const uint32_t* t3, const uint32_t* t8, int code) {
+    const uint32_t c = (uint32_t)(code - 1), row = c / 6u, u = c - 6u * row, j = u >> 1;
+    const uint32_t* e = row < 3u ? t3 + row * PLUME_TAB_ENTRY_WORDS : t8 + (row - 3u) * PLUME_TAB_ENTRY_WORDS;
+    fe x, bx, s, t;
+    PLUME_UNROLL for (int i = 0; i < 8; i++) { x.v[i] = e[i]; qy.v[i] = e[8 + i]; bx.v[i] = e[16 + i]; }
+    x.v[8] = e[24]; qy.v[8] = e[25]; bx.v[8] = e[26];
+    fe_add_lazy(s, x, bx);
+    const fe z = fe_zero();
+    fe_sub_lazy<3>(t, z, s);
+    qx = x;
+    fe_cmov(qx, bx, j == 1u);
+    fe_cmov(qx, t, j == 2u);
+    if (u & 1u) fe_neg_lazy(qy, qy);
+}
+template <bool CHECKED>
+PLUME_HD void msm8_run_impl(jac& acc, const uint32_t* a3, const uint32_t* a8, const uint32_t* b3, const uint32_t* b8, const int8_t* dig, uint32_t stride) {
+    acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
+    // ONE doubling body and ONE addition body in the loop (rolled inner loops): the two equations' workgroups share a compute unit's instruction cache
+    PLUME_NOUNROLL for (int p = PLUME_NPOS8 - 1; p >= 0; p--) {
+        if (p != PLUME_NPOS8 - 1 && !msm_all_inf(acc)) { PLUME_NOUNROLL for (int d = 0; d < 3; d++) jac_dbl(acc); }
+        PLUME_NOUNROLL for (uint32_t sl = 0; sl < 2; sl++) {
+            const uint32_t* t3 = sl ? b3 : a3;
+            const uint32_t* t8 = sl ? b8 : a8;
+            const int c = t3 ? dig[(sl * (uint32_t)PLUME_NPOS8 + (uint32_t)p) * stride] : 0;
+            if (c != 0) { fe qx, qy; ld_tab_unit8(qx, qy, t3, t8, c); jac_madd<CHECKED>(acc, qx, qy); }
+        }
+    }
+}
+PLUME_HD void msm8_run_checked(jac& acc, const uint32_t* a3, const uint32_t* a8, const uint32_t* b3, const uint32_t* b8, const int8_t* dig, uint32_t stride) {
+    PLUME_COUNT_FALLBACK();
+    msm8_run_impl<true>(acc, a3, a8, b3, b8, dig, stride);
+}
+// false when the accumulator met p == +-q on the way (Z = 0 mod p: the task has to be redone with checked additions)
+PLUME_HD bool msm8_run_unchecked(jac& acc, const uint32_t* a3, const uint32_t* a8, const uint32_t* b3, const uint32_t* b8, const int8_t* dig, uint32_t stride) {
+    msm8_run_impl<false>(acc, a3, a8, b3, b8, dig, stride);
+    return acc.inf || !fe_is_zero(acc.z);
+}
+
 // One joint-slot addition of the UNIFORM schedule (the signer): the same instructions whatever the digit code is.  A zero code adds code 1's point to a copy that a masked
 // select drops; unit and sign are masked selects (ld_tab_unit's own, plus the sign here).  Level 1: the row's ADDRESS still depends on the code; SCAN (level 2): all three
 // rows are read and one is kept by masked selects.
