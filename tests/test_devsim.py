@@ -248,6 +248,11 @@ def test_base8_table_rows_are_the_multiples_they_stand_for():
         for (a, b), (x, y, bx) in zip(D.ROWS8, rows):
             want = O.pt_mul((a + b * lam) % N, pt)
             assert (x, y) == want and bx == beta * x % P, (a, b)
+        D.lib().ds_force_guard2(1)                 # pass D's slow path (a lane whose second product came out zero: every group inverted on its own) builds the same rows
+        try:
+            assert D.table8(O.pt_bytes(pt)) == rows
+        finally:
+            D.lib().ds_force_guard2(0)
 
 
 def test_eisenstein_digit_table():

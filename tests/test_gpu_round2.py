@@ -417,7 +417,8 @@ def test_bench_line_contract_on_a_small_preset():
                   "per_rank", "stage_ms"):
             assert k in d, k
         assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "verifies/s" and d["vs_baseline"] is None and f"V{ver}" in d["metric"]
-        assert d["roofline"]["bound"] == "int-valu" and d["roofline"]["kernel"] == "k_verify_msm" and 0.05 < d["roofline"]["frac"] < 1.0
+        # the kernel named is the one the context says it launched: equation 1's short form for the 2^16-item V1 call (since round 6: from 2^16 items up), the long form for V2
+        assert d["roofline"]["bound"] == "int-valu" and d["roofline"]["kernel"] == ("k_verify_msm_s" if ver == 1 else "k_verify_msm") and 0.05 < d["roofline"]["frac"] < 1.0
         assert d["hbm_view"]["bound"] == "hbm" and d["hbm_view"]["frac"] < 0.05
         assert abs(sum(d["per_rank"]["verifies_per_s"]) - d["value"]) / d["value"] < 1e-6
         assert d["value"] > 1e6

@@ -599,43 +599,39 @@ struct Tab8Spec {
     PLUME_HD size_t index(size_t job) const { return (job / 3) * 2 + (job % 3) - 1; }
 };
 PLUME_HD Tab8Spec tab8_none() { Tab8Spec t; t.tab8 = nullptr; t.n3 = 0; t.kind = 0; return t; }
-struct tab_rows012 { fe x0, y0, b0, xt, yt, bt, x2, y2, b2; };        // rows 0..2 of a table: x, y, beta x of P, theta P, 2P (tight)
 // Rows 3..10 are sums of two points the rows 0..2 give for free (a unit multiple of a row is (x | beta x | beta^2 x, +-y)), or doubles:
 //     row 3 = (3 + w) P  = 2P + (-w^2) P          row 4 = (3 + 2w) P = 2P + w theta P         row 5 = 3 P     = 2P + P              row 6 = 2 theta P = dbl(theta P)
 //     row 7 = (4 + w) P  = 2P + (-w^2) theta P    row 8 = (3 - w) P  = 2P + theta P           row 9 = 4 P     = dbl(2P)             row 10 = (5 + 3w) P = row 4 + (-w^2) theta P
 // Each needs the inverse of one denominator (x_Q - x_A, or 2y): d3 .. d9 straight from rows 0..2, and row 10's, x_Q - x(row 4), from row 4 in fraction form --
 // x(row 4) = X4 / d4^2 with X4 = n4^2 - (x2 + beta xt) d4^2, so x_Q - x(row 4) = e / d4^2 with e = x_Q d4^2 - X4, and ONE inverse w = 1 / (d4 e) serves both: 1 / d4 = w e,
-// d4^2 / e = w d4^3.  Seven factors per job; their product joins the lane's second running product (Montgomery's trick, as for rows 1..2).  None of them vanishes for a
-// point of the group: x_Q = x_A means Q = +-A, i.e. (a +- q) P = O for Eisenstein integers a, q of norm <= 19 whose sum and difference are non-zero and of norm < n.
-// A zero factor (garbage fed by a test) is replaced by 1: that job's rows are garbage, its lane's other jobs are not.
-struct tab8_dens {
-    fe f[7];          // d3, d5, d6, d7, d8, d9, d4 e
-    fe d4, dd4, e;    // d4, d4^2, e
-    fe q0, qt;        // beta^2 x0, beta^2 xt (tight)
-};
-PLUME_HD void fe_beta2(fe& r, const fe& x, const fe& bx) { fe t; fe_add_lazy(t, x, bx); fe_neg(r, t); }       // beta^2 x = -(x + beta x)
-PLUME_HD void tab8_factors(tab8_dens& o, const tab_rows012& r) {
-    fe n4, nn, t, m, X4;
-    fe_beta2(o.q0, r.x0, r.b0); fe_beta2(o.qt, r.xt, r.bt);
-    fe_sub(o.f[0], o.q0, r.x2);                                 // d3 = beta^2 x0 - x2
-    fe_sub(o.f[1], r.x0, r.x2);                                 // d5 = x0 - x2
-    fe_dbl(o.f[2], r.yt);                                       // d6 = 2 yt
-    fe_sub(o.f[3], o.qt, r.x2);                                 // d7 = beta^2 xt - x2
-    fe_sub(o.f[4], r.xt, r.x2);                                 // d8 = xt - x2
-    fe_dbl(o.f[5], r.y2);                                       // d9 = 2 y2
-    fe_sub(o.d4, r.bt, r.x2);                                   // d4 = beta xt - x2
-    fe_sub(n4, r.yt, r.y2);
-    fe_sqr(o.dd4, o.d4); fe_sqr(nn, n4);
-    fe_add_lazy(t, r.x2, r.bt); fe_mul(m, t, o.dd4);
-    fe_sub(X4, nn, m);                                          // x(row 4) = X4 / d4^2
-    fe_mul(t, o.qt, o.dd4);
-    fe_sub(o.e, t, X4);                                         // e = beta^2 xt d4^2 - X4
-    fe_mul(o.f[6], o.d4, o.e);
-    PLUME_UNROLL for (int k = 0; k < 7; k++) guard_one(o.f[k], true);
+// d4^2 / e = w d4^3.  The factors come in two groups, by the row of the table they need beside 2P -- group 0 (P): d3 d5 d9, group 1 (theta P): d6 d7 d8 (d4 e) -- and each
+// group's product joins the lane's second running product as an entry of its own (Montgomery's trick, as for rows 1..2): a pass then holds one group's operands at a time.
+// None of the factors vanishes for a point of the group: x_Q = x_A means Q = +-A, i.e. (a +- q) P = O for Eisenstein integers a, q of norm <= 19 whose sum and difference are
+// non-zero and of norm < n.  Should a lane's product come out zero all the same (garbage fed by a test), the lane is flagged and pass D inverts its groups one by one with zero
+// factors replaced by 1: that job's rows are garbage, the lane's other jobs are not.
+PLUME_HD void fe_beta2(fe& r, const fe& x, const fe& bx) { fe t; fe_add_lazy(t, x, bx); fe_neg(r, t); }       // beta^2 x = -(x + beta x), tight
+struct tab8_g0 { fe q0, d3, d5, d9; };                           // group 0: beta^2 x0; d3 = q0 - x2, d5 = x0 - x2, d9 = 2 y2
+struct tab8_g1 { fe qt, d6, d7, d8, d4, dd4, e, f4e; };          // group 1: beta^2 xt; d6 = 2 yt, d7 = qt - x2, d8 = xt - x2; d4 = beta xt - x2, d4^2, e, d4 e
+PLUME_HD void tab8_group0(tab8_g0& g, fe& A, const fe& x0, const fe& b0, const fe& x2, const fe& y2, bool guard, bool product = true) {
+    fe_beta2(g.q0, x0, b0);
+    fe_sub(g.d3, g.q0, x2); fe_sub(g.d5, x0, x2); fe_dbl(g.d9, y2);
+    guard_one(g.d3, guard); guard_one(g.d5, guard); guard_one(g.d9, guard);
+    if (product) { fe_mul(A, g.d3, g.d5); fe_mul(A, A, g.d9); }
 }
-PLUME_HD void tab8_product(fe& D, const tab8_dens& o) {
-    fe_mul(D, o.f[0], o.f[1]);
-    PLUME_UNROLL for (int k = 2; k < 7; k++) fe_mul(D, D, o.f[k]);
+PLUME_HD void tab8_group1(tab8_g1& g, fe& B, const fe& xt, const fe& yt, const fe& bt, const fe& x2, const fe& y2, bool guard, bool product = true) {
+    fe n4, nn, t, m, X4;
+    fe_beta2(g.qt, xt, bt);
+    fe_dbl(g.d6, yt); fe_sub(g.d7, g.qt, x2); fe_sub(g.d8, xt, x2);
+    fe_sub(g.d4, bt, x2);
+    fe_sub(n4, yt, y2);
+    fe_sqr(g.dd4, g.d4); fe_sqr(nn, n4);
+    fe_add_lazy(t, x2, bt); fe_mul(m, t, g.dd4);
+    fe_sub(X4, nn, m);                                          // x(row 4) = X4 / d4^2
+    fe_mul(t, g.qt, g.dd4);
+    fe_sub(g.e, t, X4);                                         // e = beta^2 xt d4^2 - X4
+    fe_mul(g.f4e, g.d4, g.e);
+    guard_one(g.d6, guard); guard_one(g.d7, guard); guard_one(g.d8, guard); guard_one(g.f4e, guard);
+    if (product) { fe_mul(B, g.d6, g.d7); fe_mul(t, g.d8, g.f4e); fe_mul(B, B, t); }
 }
 // A + Q for affine A = (xa, ya), Q = (xq, +-yq) (negq: the minus sign) and inv = 1 / (xq - xa); every operand tight
 PLUME_HD void aff_add(fe& x3, fe& y3, const fe& xa, const fe& ya, const fe& xq, const fe& yq, bool negq, const fe& inv) {
@@ -647,45 +643,42 @@ PLUME_HD void aff_add(fe& x3, fe& y3, const fe& xa, const fe& ya, const fe& xq, 
     fe_sub_lazy<2>(t, xa, x3);
     fe_mul_sub<2>(y3, lam, t, ya);                              // lambda (xa - x3) - ya
 }
-// the eight rows from rows 0..2 and Dinv = 1 / (the product of the job's seven factors)
+// rows 4, 6, 7, 8, 10 from theta P, 2P and Binv = 1 / (d6 d7 d8 (d4 e))
 template <class RowSink>
-PLUME_HD void tab8_rows(uint32_t* rows8, const tab_rows012& r, const tab8_dens& o, const fe& Dinv, const RowSink& sink) {
+PLUME_HD void tab8_rows_g1(uint32_t* rows8, const tab8_g1& g, const fe& Binv, const fe& xt, const fe& yt, const fe& bt, const fe& x2, const fe& y2, const RowSink& sink) {
     constexpr size_t EW = PLUME_TAB_ENTRY_WORDS;
     const fe beta = fe_beta();
-    // the seven inverses from the one: prefix products up, peel down
-    fe pre[7], iv[7], inv = Dinv;
-    pre[0] = fe_small(1);
-    PLUME_UNROLL for (int k = 1; k < 7; k++) fe_mul(pre[k], pre[k - 1], o.f[k - 1]);
-    PLUME_UNROLL for (int k = 6; k >= 0; k--) { fe_mul(iv[k], inv, pre[k]); if (k) fe_mul(inv, inv, o.f[k]); }
-    fe i4, i10, t, x, y, b, x4, y4;
-    fe_mul(i4, iv[6], o.e);                                     // 1 / d4
-    fe_mul(t, o.dd4, o.d4); fe_mul(i10, iv[6], t);              // d4^2 / e = 1 / (x_Q - x(row 4))
-    aff_add(x, y, r.x2, r.y2, o.q0, r.y0, true, iv[0]);  fe_mul_k(b, beta, x); sink(rows8 + 0 * EW, x, y, b);          // row 3
-    aff_add(x4, y4, r.x2, r.y2, r.bt, r.yt, false, i4);  fe_mul_k(b, beta, x4); sink(rows8 + 1 * EW, x4, y4, b);       // row 4
-    aff_add(x, y, r.x2, r.y2, r.x0, r.y0, false, iv[1]); fe_mul_k(b, beta, x); sink(rows8 + 2 * EW, x, y, b);          // row 5
-    aff_dbl(x, y, r.xt, r.yt, iv[2]);                    fe_mul_k(b, beta, x); sink(rows8 + 3 * EW, x, y, b);          // row 6
-    aff_add(x, y, r.x2, r.y2, o.qt, r.yt, true, iv[3]);  fe_mul_k(b, beta, x); sink(rows8 + 4 * EW, x, y, b);          // row 7
-    aff_add(x, y, r.x2, r.y2, r.xt, r.yt, false, iv[4]); fe_mul_k(b, beta, x); sink(rows8 + 5 * EW, x, y, b);          // row 8
-    aff_dbl(x, y, r.x2, r.y2, iv[5]);                    fe_mul_k(b, beta, x); sink(rows8 + 6 * EW, x, y, b);          // row 9
-    aff_add(x, y, x4, y4, o.qt, r.yt, true, i10);        fe_mul_k(b, beta, x); sink(rows8 + 7 * EW, x, y, b);          // row 10
+    fe C, E, iC, iE, iv, t, x, y, b, x4, y4;
+    fe_mul(C, g.d6, g.d7); fe_mul(E, g.d8, g.f4e);
+    fe_mul(iC, Binv, E); fe_mul(iE, Binv, C);                   // 1 / (d6 d7), 1 / (d8 d4 e)
+    fe_mul(iv, iC, g.d7); aff_dbl(x, y, xt, yt, iv);                         fe_mul_k(b, beta, x); sink(rows8 + 3 * EW, x, y, b);      // row 6 = 2 theta P
+    fe_mul(iv, iC, g.d6); aff_add(x, y, x2, y2, g.qt, yt, true, iv);         fe_mul_k(b, beta, x); sink(rows8 + 4 * EW, x, y, b);      // row 7
+    fe_mul(iv, iE, g.f4e); aff_add(x, y, x2, y2, xt, yt, false, iv);         fe_mul_k(b, beta, x); sink(rows8 + 5 * EW, x, y, b);      // row 8
+    fe_mul(C, iE, g.d8);                                                     // w = 1 / (d4 e)
+    fe_mul(iv, C, g.e); aff_add(x4, y4, x2, y2, bt, yt, false, iv);          fe_mul_k(b, beta, x4); sink(rows8 + 1 * EW, x4, y4, b);   // row 4 (1 / d4 = w e)
+    fe_mul(t, g.dd4, g.d4); fe_mul(iv, C, t); aff_add(x, y, x4, y4, g.qt, yt, true, iv); fe_mul_k(b, beta, x); sink(rows8 + 7 * EW, x, y, b);      // row 10 (d4^2 / e = w d4^3)
 }
-PLUME_HD void ld_rows012(tab_rows012& r, const uint32_t* t) {
-    const uint32_t *e0 = t, *e1 = t + PLUME_TAB_ENTRY_WORDS, *e2 = t + 2 * PLUME_TAB_ENTRY_WORDS;
-    PLUME_UNROLL for (int i = 0; i < 8; i++) {
-        r.x0.v[i] = e0[i]; r.y0.v[i] = e0[8 + i]; r.b0.v[i] = e0[16 + i];
-        r.xt.v[i] = e1[i]; r.yt.v[i] = e1[8 + i]; r.bt.v[i] = e1[16 + i];
-        r.x2.v[i] = e2[i]; r.y2.v[i] = e2[8 + i]; r.b2.v[i] = e2[16 + i];
-    }
-    r.x0.v[8] = e0[24]; r.y0.v[8] = e0[25]; r.b0.v[8] = e0[26];
-    r.xt.v[8] = e1[24]; r.yt.v[8] = e1[25]; r.bt.v[8] = e1[26];
-    r.x2.v[8] = e2[24]; r.y2.v[8] = e2[25]; r.b2.v[8] = e2[26];
+// rows 3, 5, 9 from P, 2P and Ainv = 1 / (d3 d5 d9)
+template <class RowSink>
+PLUME_HD void tab8_rows_g0(uint32_t* rows8, const tab8_g0& g, const fe& Ainv, const fe& x0, const fe& y0, const fe& x2, const fe& y2, const RowSink& sink) {
+    constexpr size_t EW = PLUME_TAB_ENTRY_WORDS;
+    const fe beta = fe_beta();
+    fe t, iv, x, y, b;
+    fe_mul(t, g.d5, g.d9); fe_mul(iv, Ainv, t); aff_add(x, y, x2, y2, g.q0, y0, true, iv);  fe_mul_k(b, beta, x); sink(rows8 + 0 * EW, x, y, b);      // row 3
+    fe_mul(t, g.d3, g.d9); fe_mul(iv, Ainv, t); aff_add(x, y, x2, y2, x0, y0, false, iv);   fe_mul_k(b, beta, x); sink(rows8 + 2 * EW, x, y, b);      // row 5
+    fe_mul(t, g.d3, g.d5); fe_mul(iv, Ainv, t); aff_dbl(x, y, x2, y2, iv);                  fe_mul_k(b, beta, x); sink(rows8 + 6 * EW, x, y, b);      // row 9 = 4P
+}
+PLUME_HD void ld_row_xyb(fe& x, fe& y, fe& b, const uint32_t* e) {
+    PLUME_UNROLL for (int i = 0; i < 8; i++) { x.v[i] = e[i]; y.v[i] = e[8 + i]; b.v[i] = e[16 + i]; }
+    x.v[8] = e[24]; y.v[8] = e[25]; b.v[8] = e[26];
 }
 
-// Pass B (jobs descending): carry = 1 / (the lane's product) in; rows P, theta P, 2P of every job out.  For the base-8 jobs (t8) the product of the level-2 factors joins the
-// lane's SECOND running product, parked in scr2 like the first (carry2 = that product out; 1 where the lane holds no such job).
+// Pass B (jobs descending): carry = 1 / (the lane's product) in; rows P, theta P, 2P of every job out.  For the base-8 jobs (t8) the products of the two level-2 groups join the
+// lane's SECOND running product; scr2 takes four entries per job -- 4 jj: the product so far, 4 jj + 1: group 0's own product, 4 jj + 2, 4 jj + 3: the same for group 1 --;
+// carry2 = the lane's product out (1 where the lane holds no such job), guard2 = it came out zero (carry2 is then 1 and pass C inverts the lane's groups one by one).
 template <class RowSink>
 PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, const uint32_t* scr, size_t sstride, size_t slane,
-                         const fe& carry, bool guard, const RowSink& sink, const Tab8Spec& t8 = tab8_none(), uint32_t* scr2 = nullptr, fe* carry2 = nullptr) {
+                         const fe& carry, bool guard, const RowSink& sink, const Tab8Spec& t8 = tab8_none(), uint32_t* scr2 = nullptr, fe* carry2 = nullptr, bool* guard2 = nullptr) {
     const fe beta = fe_beta();
     constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
     fe inv = carry, acc2 = fe_small(1);
@@ -693,12 +686,11 @@ PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jo
         const size_t job = j0 + (size_t)jj;
         jac b;
         const bool zone = tab_base(b, bases, jobflags, njobs, job);
-        fe dy, dx, dz, pyx, D, Dinv, iy, ix;
-        tab_rows012 r;
+        fe dy, dx, dz, pyx, D, Dinv, iy, ix, x0, y0, b0, xt, yt, bt, x2, y2, b2;
         tab_dens(dy, dx, dz, pyx, D, b, zone, guard);
         tab_unpark(Dinv, inv, scr, sstride, slane, (size_t)jj, D);
         if (zone) {
-            r.x0 = b.x; r.y0 = b.y;
+            x0 = b.x; y0 = b.y;
             fe_mul(iy, Dinv, dx);                               // 1 / (2y)
             fe_mul(ix, Dinv, dy);                               // 1 / ((beta - 1) x)
         } else {
@@ -707,51 +699,77 @@ PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jo
             fe zi, zi2, z2, t;
             fe_mul(zi, Dinv, pyx);
             fe_sqr(zi2, zi);
-            fe_mul(r.x0, b.x, zi2);
-            fe_mul(t, zi2, zi); fe_mul(r.y0, b.y, t);
+            fe_mul(x0, b.x, zi2);
+            fe_mul(t, zi2, zi); fe_mul(y0, b.y, t);
             fe_sqr(z2, dz);
             fe_mul(t, Dinv, dz);                                // 1 / (dy dx)
             fe_mul(iy, t, dx); fe_mul(iy, iy, z2); fe_mul(iy, iy, dz);      // Z^3 / (2Y)
             fe_mul(ix, t, dy); fe_mul(ix, ix, z2);                          // Z^2 / ((beta - 1) X)
         }
         uint32_t* rows = tab + job * TW;
-        fe_mul_k(r.b0, beta, r.x0);
-        sink(rows, r.x0, r.y0, r.b0);                           // row 0: P
-        aff_theta(r.xt, r.yt, r.x0, r.y0, r.b0, ix);
-        fe_mul_k(r.bt, beta, r.xt);
-        sink(rows + EW, r.xt, r.yt, r.bt);                      // row 1: theta P = P - lambda P
-        aff_dbl(r.x2, r.y2, r.x0, r.y0, iy);
-        fe_mul_k(r.b2, beta, r.x2);
-        sink(rows + 2 * EW, r.x2, r.y2, r.b2);                  // row 2: 2P
+        fe_mul_k(b0, beta, x0);
+        sink(rows, x0, y0, b0);                                 // row 0: P
+        aff_theta(xt, yt, x0, y0, b0, ix);
+        fe_mul_k(bt, beta, xt);
+        sink(rows + EW, xt, yt, bt);                            // row 1: theta P = P - lambda P
+        aff_dbl(x2, y2, x0, y0, iy);
+        fe_mul_k(b2, beta, x2);
+        sink(rows + 2 * EW, x2, y2, b2);                        // row 2: 2P
         if (t8.is8(job)) {
-            tab8_dens o;
-            fe D2;
-            tab8_factors(o, r);
-            tab8_product(D2, o);
-            tab_park(acc2, scr2, sstride, slane, (size_t)jj, D2);
+            fe A, B;
+            { tab8_g0 g; tab8_group0(g, A, x0, b0, x2, y2, false); }
+            pre_st(scr2, sstride, slane, 4 * (size_t)jj + 1, A);
+            tab_park(acc2, scr2, sstride, slane, 4 * (size_t)jj, A);
+            { tab8_g1 g; tab8_group1(g, B, xt, yt, bt, x2, y2, false); }
+            pre_st(scr2, sstride, slane, 4 * (size_t)jj + 3, B);
+            tab_park(acc2, scr2, sstride, slane, 4 * (size_t)jj + 2, B);
         }
     }
-    if (carry2) *carry2 = acc2;
+    const bool z2 = t8.kind != 0 && fe_is_zero(acc2);
+    if (guard2) *guard2 = z2;
+    if (carry2) { if (z2) acc2 = fe_small(1); *carry2 = acc2; }
 }
-// Pass D (jobs ASCENDING: the reverse of the order pass B parked in): carry2 = 1 / (the lane's second product) in; rows 3..10 of every base-8 job out.  Rows 0..2 are read
-// back from the table (three lines), the factors recomputed from them.
-template <class RowSink>
-PLUME_HD void tab_pass_d(const uint32_t* tab, size_t njobs, size_t j0, int cnt, const uint32_t* scr2, size_t sstride, size_t slane, const fe& carry2, const RowSink& sink,
-                         const Tab8Spec& t8) {
-    constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS;
-    (void)njobs;
+// Pass C (jobs ASCENDING, group 1 before group 0: the reverse of the order pass B parked in): carry2 = 1 / (the lane's second product) in; the inverse of every group's product
+// out -- ginv: two field elements per base-8 job, job-major, group 0 first.  No table row is touched: 36-byte reads and writes only.  guard2: the lane's product was zero -- every
+// group is inverted on its own (a zero group gets 0: that job's rows are garbage, the lane's other jobs are not).
+PLUME_HD void tab_pass_c(uint32_t* ginv, size_t j0, int cnt, const uint32_t* scr2, size_t sstride, size_t slane, const fe& carry2, bool guard2, const Tab8Spec& t8) {
     fe inv = carry2;
     PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
         const size_t job = j0 + (size_t)jj;
         if (!t8.is8(job)) continue;
-        tab_rows012 r;
-        ld_rows012(r, tab + job * TW);
-        tab8_dens o;
-        fe D2, D2inv;
-        tab8_factors(o, r);
-        tab8_product(D2, o);
-        tab_unpark(D2inv, inv, scr2, sstride, slane, (size_t)jj, D2);
-        tab8_rows(t8.tab8 + t8.index(job) * (size_t)PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS, r, o, D2inv, sink);
+        uint32_t* out = ginv + t8.index(job) * (size_t)(2 * PLUME_FE_WORDS);
+        PLUME_NOUNROLL for (int g = 1; g >= 0; g--) {
+            fe G, gi;
+            pre_ld(G, scr2, sstride, slane, 4 * (size_t)jj + 2 * (size_t)g + 1);
+            if (guard2) fe_inv(gi, G); else tab_unpark(gi, inv, scr2, sstride, slane, 4 * (size_t)jj + 2 * (size_t)g, G);
+            st_fe(out + g * PLUME_FE_WORDS, gi);
+        }
+    }
+}
+// rows 3..10 of ONE base-8 job from its rows 0..2 (t: the job's three-row table, read one group's operands at a time) and the two inverses pass C left for it.  Run by the lane
+// that is about to walk the job's digits -- the multi-scalar kernels' prologue (plume_stages.h verify_tab8): that kernel is bound by instruction issue and leaves HBM idle, so the
+// 1 KB of rows each job stores costs it the ~8 k instructions and nothing else, where a table pass of its own was bound by exactly those stores (round 6: 1.1 ms per 2^20
+// verifies as a pass, 0.45 ms inside the kernel).
+template <class RowSink>
+PLUME_HD void tab8_build_job(uint32_t* rows8, const uint32_t* t, const uint32_t* ginv2, const RowSink& sink) {
+    constexpr size_t EW = PLUME_TAB_ENTRY_WORDS;
+    fe x2, y2, b2;
+    ld_row_xyb(x2, y2, b2, t + 2 * EW);
+    {
+        fe xt, yt, bt, B, Binv;
+        ld_row_xyb(xt, yt, bt, t + EW);
+        ld_fe(Binv, ginv2 + PLUME_FE_WORDS);
+        tab8_g1 g;
+        tab8_group1(g, B, xt, yt, bt, x2, y2, false, false);
+        tab8_rows_g1(rows8, g, Binv, xt, yt, bt, x2, y2, sink);
+    }
+    {
+        fe x0, y0, b0, A, Ainv;
+        ld_row_xyb(x0, y0, b0, t);
+        ld_fe(Ainv, ginv2);
+        tab8_g0 g;
+        tab8_group0(g, A, x0, b0, x2, y2, false, false);
+        tab8_rows_g0(rows8, g, Ainv, x0, y0, x2, y2, sink);
     }
 }
 // carry[.] <- 1 / carry[.] for nl lane products: thread t of T takes lanes t, t + T, ..., t + (K-1) T and spends ONE inversion on their product
@@ -773,20 +791,24 @@ PLUME_HD void tab_invert_group(uint32_t* carry, size_t nl, size_t T, size_t t) {
         if (l < nl) st_fe_soa(carry, nl, l, o);
     }
 }
-// All passes in one function with the inversions in place: single-lane builds (the host harness holds the pass sequence to it).  scr: two park regions of cnt entries when
-// the stage has base-8 jobs.
+// All passes in one function with the inversions in place: single-lane builds (the host harness holds the pass sequence to it).  scr: the park region of the first level (cnt
+// entries) followed by the second level's (4 cnt entries) when the stage has base-8 jobs; ginv: 2 field elements per base-8 job (Tab8Spec::index).
 template <class RowSink = DirectRowSinkSync>
 PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
-                          const RowSink& sink = RowSink(), const Tab8Spec& t8 = tab8_none()) {
+                          const RowSink& sink = RowSink(), const Tab8Spec& t8 = tab8_none(), uint32_t* ginv = nullptr) {
     fe carry, inv, carry2;
-    bool guard;
+    bool guard, guard2 = false;
     uint32_t* scr2 = scr + (size_t)cnt * PLUME_TAB_SCR_WORDS * sstride;
     tab_pass_a(bases, jobflags, njobs, j0, cnt, scr, sstride, slane, carry, guard);
     sink.inv(inv, carry, 1);
-    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr, sstride, slane, inv, guard, sink, t8, t8.kind ? scr2 : nullptr, &carry2);
+    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr, sstride, slane, inv, guard, sink, t8, t8.kind ? scr2 : nullptr, &carry2, &guard2);
     if (t8.kind) {
         sink.inv(inv, carry2, 1);
-        tab_pass_d(tab, njobs, j0, cnt, scr2, sstride, slane, inv, sink, t8);
+        tab_pass_c(ginv, j0, cnt, scr2, sstride, slane, inv, guard2, t8);
+        for (int jj = 0; jj < cnt; jj++) {
+            const size_t job = j0 + (size_t)jj;
+            if (t8.is8(job)) tab8_build_job(t8.tab8 + t8.index(job) * (size_t)PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS, tab + job * (size_t)PLUME_TAB_WORDS, ginv + t8.index(job) * (size_t)(2 * PLUME_FE_WORDS), sink);
+        }
     }
 }
 

@@ -167,29 +167,23 @@ __global__ __launch_bounds__(kTabBlock, PLUME_TABPASS_WAVES_B) void k_tab_pass_b
     sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
     sink.full = __ballot(cnt == L) == ~0ull;
     const uint32_t* myscr = scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_SCR_WORDS * kTabBlock);
-    uint32_t* myscr2 = scr2 ? scr2 + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_SCR_WORDS * kTabBlock) : nullptr;
+    uint32_t* myscr2 = scr2 ? scr2 + (size_t)blockIdx.x * ((size_t)4 * L * PLUME_TAB_SCR_WORDS * kTabBlock) : nullptr;      // (four parked entries per job at the second level)
     fe c, c2;
+    bool g2 = false;
     ld_fe_soa(c, carry, nl, lane);
-    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, guardf[lane] != 0, sink, t8, myscr2, &c2);
-    if (carry2) st_fe_soa(carry2, nl, lane, c2);
+    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, guardf[lane] != 0, sink, t8, myscr2, &c2, &g2);
+    if (carry2) { st_fe_soa(carry2, nl, lane, c2); reinterpret_cast<uint8_t*>(carry2 + nl * PLUME_FE_WORDS)[lane] = g2 ? 1 : 0; }
 }
-// rows 3..10 of the base-8 jobs (plume_ec.h tab_pass_d): the lane -> jobs mapping of the passes before it, jobs ascending.  A wavefront whose lanes all walk whole triples
-// of (pk, H, nullifier) jobs stores through the row transposition; the one that straddles the end of the triples stores row by row.
-__global__ __launch_bounds__(kTabBlock, PLUME_TABPASS_WAVES_B) void k_tab_pass_d(const uint32_t* tab, size_t njobs, int L, const uint32_t* scr2, const uint32_t* carry2, Tab8Spec t8) {
-    __shared__ uint4 s_rows[kTabBlock * 8];
-    __shared__ uint32_t* s_ptrs[kTabBlock];
+// the inverses of the base-8 jobs' denominator groups (plume_ec.h tab_pass_c): the lane -> jobs mapping of the passes before it, jobs ascending; 36-byte reads and writes only
+__global__ __launch_bounds__(kTabBlock, 4) void k_tab_pass_c(uint32_t* ginv, size_t njobs, int L, const uint32_t* scr2, const uint32_t* carry2, Tab8Spec t8) {
     const size_t lane = (size_t)blockIdx.x * kTabBlock + threadIdx.x, nl = (size_t)gridDim.x * kTabBlock;
     const size_t j0 = lane * (size_t)L;
     const int cnt = j0 < njobs ? (int)((njobs - j0) < (size_t)L ? (njobs - j0) : (size_t)L) : 0;
     if (__ballot(j0 < t8.n3) == 0ull) return;                    // (wave-uniform: a wavefront with no base-8 job -- the R jobs behind the triples)
-    WaveRowSink sink;
-    sink.rows = s_rows + (threadIdx.x & ~63u) * 8;
-    sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
-    sink.full = __ballot(cnt == L && j0 + (size_t)L <= t8.n3 && L % 3 == 0) == ~0ull;
-    const uint32_t* myscr2 = scr2 + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_SCR_WORDS * kTabBlock);
+    const uint32_t* myscr2 = scr2 + (size_t)blockIdx.x * ((size_t)4 * L * PLUME_TAB_SCR_WORDS * kTabBlock);
     fe c2;
     ld_fe_soa(c2, carry2, nl, lane);
-    tab_pass_d(tab, njobs, j0, cnt, myscr2, (size_t)kTabBlock, threadIdx.x, c2, sink, t8);
+    tab_pass_c(ginv, j0, cnt, myscr2, (size_t)kTabBlock, threadIdx.x, c2, reinterpret_cast<const uint8_t*>(carry2 + nl * PLUME_FE_WORDS)[lane] != 0, t8);
 }
 // carry[.] <- 1 / carry[.] for the nl lane products: thread t takes lanes t, t + T, ..., t + (K-1) T (coalesced) and spends ONE inversion on their product.
 // The products are never zero (the passes' guard).
@@ -505,27 +499,27 @@ static size_t tables_park_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
     return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_SCR_WORDS * 4;          // one parked prefix product per job
 }
-// one level of the table stage's scratch: a parked prefix product per job, then the lanes' state between the passes (carry: 9 words; guard flag) -- a multiple of 16 bytes
-static size_t tables_level_bytes(size_t njobs, int L) {
+// one level of the table stage's scratch: `parks` parked prefix products per job, then the lanes' state between the passes (carry: 9 words; a flag byte) -- a multiple of 16 bytes
+static size_t tables_level_bytes(size_t njobs, int L, int parks) {
     const size_t lanes = (njobs + L - 1) / L;
-    return ((tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16 + 15) / 16) * 16;
+    return (((size_t)parks * tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16 + 15) / 16) * 16;
 }
-size_t tables_scratch_bytes(size_t njobs, int L, bool base8) { return tables_level_bytes(njobs, L) * (base8 ? 2 : 1); }
-void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st, const Tab8Spec& t8) {
+size_t tables_scratch_bytes(size_t njobs, int L, bool base8) { return tables_level_bytes(njobs, L, 1) + (base8 ? tables_level_bytes(njobs, L, 4) : 0); }
+void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st, const Tab8Spec& t8, uint32_t* ginv) {
     size_t lanes = (njobs + L - 1) / L;
     static_assert(kBlock % kTabBlock == 0, "the scratch regions are sized in units of kBlock lanes");
     const dim3 grid(nblocks(lanes) * (kBlock / kTabBlock)), block(kTabBlock);
     const size_t nl = (size_t)grid.x * kTabBlock, T = (nl + PLUME_TABINV_K - 1) / PLUME_TABINV_K;
     uint32_t* carry = scr + tables_park_bytes(njobs, L) / 4;
     uint8_t* guardf = reinterpret_cast<uint8_t*>(carry + nl * PLUME_FE_WORDS);
-    uint32_t* scr2 = t8.kind ? scr + tables_level_bytes(njobs, L) / 4 : nullptr;            // the second level's park area and lane products (base-8 jobs)
-    uint32_t* carry2 = t8.kind ? scr2 + tables_park_bytes(njobs, L) / 4 : nullptr;
+    uint32_t* scr2 = t8.kind ? scr + tables_level_bytes(njobs, L, 1) / 4 : nullptr;         // the second level's park area (two entries per job) and lane products + flags (base-8 jobs)
+    uint32_t* carry2 = t8.kind ? scr2 + 4 * tables_park_bytes(njobs, L) / 4 : nullptr;
     hipLaunchKernelGGL(k_tab_pass_a, grid, block, 0, st, bases, jobflags, njobs, L, scr, carry, guardf);
     hipLaunchKernelGGL(k_tab_invert, dim3(nblocks(T)), dim3(kBlock), 0, st, carry, nl, T);
     hipLaunchKernelGGL(k_tab_pass_b, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf, t8, scr2, carry2);
     if (t8.kind) {
         hipLaunchKernelGGL(k_tab_invert, dim3(nblocks(T)), dim3(kBlock), 0, st, carry2, nl, T);
-        hipLaunchKernelGGL(k_tab_pass_d, grid, block, 0, st, tab, njobs, L, scr2, carry2, t8);
+        hipLaunchKernelGGL(k_tab_pass_c, grid, block, 0, st, ginv, njobs, L, scr2, carry2, t8);
     }
 }
 const char* verify_msm_kernel_name(const VerifyArgs& a) { return a.msm_pair && !verify_eq1_short(a) ? "k_verify_msm_pair" : verify_eq1_short(a) ? "k_verify_msm_s" : "k_verify_msm"; }

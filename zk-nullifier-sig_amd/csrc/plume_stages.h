@@ -160,6 +160,8 @@ struct VerifyArgs {
     uint8_t* itemflags;   // n : 1 = rejected at ingest (bad scalar / invalid point)
     uint32_t* tab;        // 3n tables of PLUME_TAB_WORDS
     uint32_t* tab8;       // rows 3..10 of the base-8 tables (round 6): 2n blocks of PLUME_TAB8_ROWS rows -- H of item i at 2i, its nullifier at 2i + 1 (equation 2's two slots)
+    const uint32_t* ginv; // ... and what the table stage leaves for them: per block two field elements, the inverses of the block's two denominator groups (plume_ec.h tab_pass_c).  The rows
+                          //     themselves are built by the lane that walks the block's digits: verify_tab8 below, the multi-scalar kernels' prologue
     uint32_t* res;        // PLUME_JAC_WORDS x (2n) words, Jacobian SoA of R' (task 2i) and Hr' (task 2i+1)
     uint8_t* resinf;      // 2n
     const uint32_t* gtab; // wide table of G (PLUME_GTAB_WORDS): (1..2^(W-1))*G
@@ -363,6 +365,18 @@ PLUME_HD void verify_ingest_a3(const VerifyArgs& a, uint32_t i, const ingest_xch
     st_base(a.bases, 3 * (size_t)i + 1, h); a.jobflags[3 * (size_t)i + 1] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
 }
 
+// Rows 3..10 of one of the item's two base-8 tables (which 0: H, 1: the nullifier), by the lane about to use them (plume_ec.h tab8_build_job).  The rows go to HBM like any
+// table row -- the chain gathers them back by digit -- and the lane orders its own stores before its loads.
+struct DirectRowSink { PLUME_HD void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const { st_tab_entry(e, x, y, bx); } };
+PLUME_HD void verify_tab8(const VerifyArgs& a, uint32_t item, uint32_t which) {
+    const size_t job = 3 * (size_t)item + 1 + which, blk = 2 * (size_t)item + which;
+    tab8_build_job(a.tab8 + blk * (PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS), a.tab + job * PLUME_TAB_WORDS, a.ginv + blk * (2 * PLUME_FE_WORDS), DirectRowSink());
+}
+PLUME_HD void verify_tab8_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __threadfence();                 // the lane's row stores are visible to its own later gathers (which go through the vector cache)
+#endif
+}
 // task t = 2*item + eq;  eq 0: s*G - c*pk, eq 1: s*H - c*nul.   dig: this lane's digit area (LDS), element stride.
 // CHECKED = false: the hot form; a task whose chain met p == +-q is filed in a.redo and stores nothing.  CHECKED = true: the redo launch's form.
 // FORM: which forms of equation 1 the instantiation carries -- 0: the long form only (calls whose equation 1 runs in the long form), 1: the short form only (the hot kernel of a short-form call:
@@ -416,6 +430,7 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
             const uint32_t* n3 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
             const uint32_t* h8 = a.tab8 + (2 * (size_t)item) * (PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS);
             const uint32_t* n8 = h8 + PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS;
+            if (!CHECKED) { PLUME_NOUNROLL for (uint32_t w = 0; w < 2; w++) verify_tab8(a, item, w); verify_tab8_fence(); }      // (the redo launch finds the rows its task's first lane built)
             if (CHECKED) {
                 msm8_run_checked(acc, h3, h8, n3, n8, dig, stride);
             } else if (!msm8_run_unchecked(acc, h3, h8, n3, n8, dig, stride)) {
@@ -457,6 +472,7 @@ PLUME_HD bool verify_msm_half(const VerifyArgs& a, uint32_t item, uint32_t eq, u
     const uint32_t* n3 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
     const uint32_t* h8 = a.tab8 + (2 * (size_t)item) * (PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS);
     const uint32_t* n8 = h8 + PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS;
+    verify_tab8(a, item, half); verify_tab8_fence();           // each half builds the rows 3..10 of its own slot's table
     return msm8_run_unchecked(acc, half == 0 ? h3 : nullptr, h8, half == 1 ? n3 : nullptr, n8, dig, stride);
 }
 // the join, by half 0's lane: acc0 += acc1 with the checked Jacobian addition (the two halves may well meet in p == +-q: a valid equation 2 whose halves are H-multiples)
