@@ -90,47 +90,6 @@ def eis_digit(code):
     return (-a, -b) if neg else (a, b)
 
 
-NPOS8 = 44         # PLUME_NPOS8: positions of the BASE-8 Eisenstein digits of a pair of 128-bit halves (round 6)
-ROWS8 = [(1, 0), (1, -1), (2, 0), (3, 1), (3, 2), (3, 0), (2, -2), (4, 1), (3, -1), (4, 0), (5, 3)]      # the eleven rows of a base-8 table as multiples of P (csrc/gen_eis8.py)
-
-
-def eis_digit8(code):
-    """base-8 digit code -> (a, b): 0 -> 0; 1 + 6 row + 2 j + neg -> (-1)^neg w^j ROWS8[row]"""
-    if code == 0:
-        return (0, 0)
-    c = code - 1
-    row, j, neg = c // 6, (c % 6) >> 1, c & 1
-    a, b = ROWS8[row]
-    for _ in range(j):
-        a, b = -b, a - b
-    return (-a, -b) if neg else (a, b)
-
-
-def glv8(ks):
-    """k -> the 44 base-8 digit codes of its GLV pair k1 + k2 w"""
-    K = to_limbs(ks)
-    dig = np.zeros((len(ks), NPOS8), dtype=np.int8)
-    lib().ds_glv8(C.c_size_t(len(ks)), _p(K, u32p), dig.ctypes.data_as(C.POINTER(C.c_int8)))
-    return [dig[r].tolist() for r in range(len(ks))]
-
-
-def eisd8_64(a, b):
-    """the 22 base-8 digit codes of a + b w for |a|, |b| < 2^64 (the recoding alone), or None when a carry is left"""
-    am = np.array([abs(a) & 0xFFFFFFFF, abs(a) >> 32], dtype=np.uint32)
-    bm = np.array([abs(b) & 0xFFFFFFFF, abs(b) >> 32], dtype=np.uint32)
-    dig = np.zeros(22, dtype=np.int8)
-    ok = lib().ds_eisd8_64(_p(am, u32p), C.c_int(a < 0), _p(bm, u32p), C.c_int(b < 0), dig.ctypes.data_as(C.POINTER(C.c_int8)))
-    return dig.tolist() if ok else None
-
-
-def table8(pt: bytes):
-    """the eleven rows of the base-8 table of an affine point: list of (x, y, beta x) integers"""
-    out = (C.c_uint8 * (96 * 11))()
-    assert lib().ds_table8((C.c_uint8 * 64).from_buffer_copy(pt), out)
-    b = bytes(out)
-    return [tuple(int.from_bytes(b[96 * r + 32 * k:96 * r + 32 * k + 32], "big") for k in range(3)) for r in range(11)]
-
-
 def glv(ks):
     """k -> (|k1|, sign, |k2|, sign, the 65 digit codes of k1 + k2 w)"""
     K = to_limbs(ks)

@@ -126,47 +126,6 @@ void ds_glv(size_t count, const uint32_t* k, uint32_t* out, int8_t* digits) {
         eisd_store_glv(digits + PLUME_NPOS * i, 1, h1, h2, false);
     }
 }
-static void run_tables8(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, const Tab8Spec& t8, uint32_t* ginv);
-// the PLUME_NPOS8 base-8 Eisenstein digit codes of k's GLV pair (int8, rows of 44)
-void ds_glv8(size_t count, const uint32_t* k, int8_t* digits) {
-    for (size_t i = 0; i < count; i++) {
-        sc x; for (int j = 0; j < 8; j++) x.v[j] = k[8 * i + j];
-        glv_half h1, h2;
-        glv_split(h1, h2, x);
-        eisd8_store_glv(digits + PLUME_NPOS8 * i, 1, h1, h2, false);
-    }
-}
-uint32_t ds_npos8() { return PLUME_NPOS8; }
-// base-8 digits of a pair of 64-bit quarters given as magnitudes + signs (the recoding alone): 22 rows
-int ds_eisd8_64(const uint32_t am[2], int aneg, const uint32_t bm[2], int bneg, int8_t* digits) {
-    const uint32_t a[2] = {am[0], am[1]}, b[2] = {bm[0], bm[1]};
-    return eisd8_store<22, 2>(digits, 1, a, aneg != 0, b, bneg != 0, false) ? 1 : 0;
-}
-// the eleven rows of the base-8 table of one affine point (64 bytes big-endian): out = 11 x (x || y || beta x), 96 bytes each, canonical
-int ds_table8(const uint8_t pt[64], uint8_t* out) {
-    alignas(16) uint8_t pb[64]; memcpy(pb, pt, 64);
-    fe x, y;
-    if (load_affine_be(x, y, pb) != PLUME_JOB_OK) return 0;
-    std::vector<uint32_t> bases(PLUME_BASE_WORDS * 3), tab(3 * PLUME_TAB_WORDS), tab8(2 * PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS);
-    std::vector<uint8_t> jobflags(3);
-    jac p; p.x = x; p.y = y; p.z = fe_small(1); p.inf = 0;
-    for (int j = 0; j < 3; j++) { st_base(bases.data(), j, p); jobflags[j] = (uint8_t)(PLUME_JOB_OK | PLUME_JOB_AFFINE); }
-    Tab8Spec t8; t8.tab8 = tab8.data(); t8.n3 = 3; t8.kind = 1;
-    std::vector<uint32_t> ginv(2 * 2 * PLUME_FE_WORDS);
-    run_tables8(tab.data(), bases.data(), jobflags.data(), 3, 3, t8, ginv.data());
-    tab8_build_job(tab8.data(), tab.data() + PLUME_TAB_WORDS, ginv.data(), DirectRowSinkSync());       // job 1's rows 3..10, as the multi-scalar lane builds them
-    for (int r = 0; r < 11; r++) {
-        const uint32_t* e = r < 3 ? tab.data() + PLUME_TAB_WORDS + r * PLUME_TAB_ENTRY_WORDS : tab8.data() + (r - 3) * PLUME_TAB_ENTRY_WORDS;      // job 1 (the "H" of the triple)
-        fe rx, ry, rb;
-        for (int i = 0; i < 8; i++) { rx.v[i] = e[i]; ry.v[i] = e[8 + i]; rb.v[i] = e[16 + i]; }
-        rx.v[8] = e[24]; ry.v[8] = e[25]; rb.v[8] = e[26];
-        fe_normalize(rx); fe_normalize(ry); fe_normalize(rb);
-        alignas(16) uint8_t o[96];
-        fe_to_be_aligned(o, rx); fe_to_be_aligned(o + 32, ry); fe_to_be_aligned(o + 64, rb);
-        memcpy(out + 96 * r, o, 96);
-    }
-    return 1;
-}
 void ds_sha256(const uint8_t* data, uint32_t len, uint8_t out[32]) {
     uint32_t st[8];
     sha256_init(st);
@@ -212,13 +171,10 @@ static const std::vector<uint32_t>& shared_gcomb() {
 // lanes per pass, the lanes' running products in a word-major array, tab_invert_group between the two passes); a batch of one lane also runs the one-function form
 // (table_build) and the two must agree
 void ds_set_tables_small(int) {}                                  // (rounds 4's small-batch table path is gone: one path for every size)
-static int g_force_guard2 = 0;
-void ds_force_guard2(int on) { g_force_guard2 = on; }      // test hook: pass D then takes its slow path (every level-2 group inverted on its own) for every lane
-static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) { run_tables8(tab, bases, jobflags, njobs, L, tab8_none(), nullptr); }
-static void run_tables8(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, const Tab8Spec& t8, uint32_t* ginv) {
+static void run_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L, stride = ((lanes + 7) / 8) * 8;     // "grid" rounded up like the kernel's
-    std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_SCR_WORDS), carry(stride * PLUME_FE_WORDS), scr2(4 * stride * (size_t)L * PLUME_TAB_SCR_WORDS), carry2(stride * PLUME_FE_WORDS);
-    std::vector<uint8_t> guardf(stride, 0), guard2f(stride, 0);
+    std::vector<uint32_t> scr(stride * (size_t)L * PLUME_TAB_SCR_WORDS), carry(stride * PLUME_FE_WORDS);
+    std::vector<uint8_t> guardf(stride, 0);
     constexpr int K = 8;
     const size_t T = (stride + K - 1) / K;
     const DirectRowSinkSync sink;
@@ -232,29 +188,13 @@ static void run_tables8(uint32_t* tab, const uint32_t* bases, const uint8_t* job
     for (size_t t = 0; t < T; t++) tab_invert_group<K>(carry.data(), stride, T, t);
     for (size_t lane = 0; lane < stride; lane++) {
         size_t j0; int cnt; span(lane, j0, cnt);
-        fe c, c2; bool g2 = false; ld_fe_soa(c, carry.data(), stride, lane);
-        tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr.data(), stride, lane, c, guardf[lane] != 0, sink, t8, t8.kind ? scr2.data() : nullptr, &c2, &g2);
-        st_fe_soa(carry2.data(), stride, lane, c2); guard2f[lane] = (g2 || g_force_guard2) ? 1 : 0;
-    }
-    if (t8.kind) {                                                                 // the base-8 jobs: the second inversion, pass C (the groups' inverses); the rows themselves are the multi-scalar lanes' work
-        for (size_t t = 0; t < T; t++) tab_invert_group<K>(carry2.data(), stride, T, t);
-        for (size_t lane = 0; lane < stride; lane++) {
-            size_t j0; int cnt; span(lane, j0, cnt);
-            fe c2; ld_fe_soa(c2, carry2.data(), stride, lane);
-            tab_pass_c(ginv, j0, cnt, scr2.data(), stride, lane, c2, guard2f[lane] != 0, t8);
-        }
+        fe c; ld_fe_soa(c, carry.data(), stride, lane);
+        tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr.data(), stride, lane, c, guardf[lane] != 0, sink);
     }
     if (lanes == 1) {                                                              // the one-function form on the same input
-        std::vector<uint32_t> tabb((size_t)njobs * PLUME_TAB_WORDS), scrb(5 * (size_t)L * PLUME_TAB_SCR_WORDS), tab8b(2 * (njobs / 3 + 1) * PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS, 0),
-                              ginvb(2 * (njobs / 3 + 1) * 2 * PLUME_FE_WORDS, 0);
-        Tab8Spec tb = t8; tb.tab8 = tab8b.data();
-        table_build(tabb.data(), bases, jobflags, njobs, 0, (int)njobs, scrb.data(), 1, 0, sink, tb, ginvb.data());
-        if (memcmp(tabb.data(), tab, tabb.size() * 4) != 0) { fprintf(stderr, "devsim: table_build and the pass sequence disagree\n"); abort(); }
-        if (t8.kind) {
-            size_t n8 = 0;
-            for (size_t j = 0; j < njobs; j++) if (t8.is8(j)) n8 = t8.index(j) + 1;
-            if (!g_force_guard2 && memcmp(ginvb.data(), ginv, n8 * 2 * PLUME_FE_WORDS * 4) != 0) { fprintf(stderr, "devsim: table_build and the pass sequence disagree on the groups' inverses\n"); abort(); }
-        }
+        std::vector<uint32_t> tab2((size_t)njobs * PLUME_TAB_WORDS), scr2((size_t)L * PLUME_TAB_SCR_WORDS);
+        table_build(tab2.data(), bases, jobflags, njobs, 0, (int)njobs, scr2.data(), 1, 0);
+        if (memcmp(tab2.data(), tab, tab2.size() * 4) != 0) { fprintf(stderr, "devsim: table_build and the pass sequence disagree\n"); abort(); }
     }
 }
 
@@ -355,12 +295,7 @@ static int verify_impl(int version, uint32_t n, const uint8_t* msgs, const uint6
         for (uint32_t i = 0; i < n; i++) verify_scalars(a, i);
     }
     const size_t nj = J * (size_t)n;
-    std::vector<uint32_t> tab8(2 * (size_t)n * PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS + 1, 0);
-    a.tab8 = tab8.data();
-    std::vector<uint32_t> ginv(2 * (size_t)n * 2 * PLUME_FE_WORDS + 1, 0);
-    a.ginv = ginv.data();
-    Tab8Spec t8; t8.tab8 = a.tab8; t8.n3 = 3 * (size_t)n; t8.kind = 1;
-    run_tables8(a.tab, a.bases, a.jobflags, nj, L, t8, ginv.data());
+    run_tables(a.tab, a.bases, a.jobflags, nj, L);
     std::vector<int8_t> dig((2 * PLUME_NDIG + PLUME_NPOS) * B);
     std::vector<uint32_t> redo(2 * (size_t)n + 1, 0);
     a.redo = redo.data();

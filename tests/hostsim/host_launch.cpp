@@ -53,20 +53,16 @@ static size_t tables_park_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
     return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_SCR_WORDS * 4;
 }
-static size_t tables_level_bytes(size_t njobs, int L, int parks) {
+size_t tables_scratch_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
-    return (((size_t)parks * tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16 + 15) / 16) * 16;
+    return tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16;
 }
-size_t tables_scratch_bytes(size_t njobs, int L, bool base8) { return tables_level_bytes(njobs, L, 1) + (base8 ? tables_level_bytes(njobs, L, 4) : 0); }
-void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st, const Tab8Spec& t8, uint32_t* ginv) {
+void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st) {
     const size_t lanes = (njobs + L - 1) / L;
     const unsigned blocks = nblocks(lanes) * (kBlock / kTabBlock);
     const size_t nl = (size_t)blocks * kTabBlock, T = (nl + kTabInvK - 1) / kTabInvK;
     uint32_t* carry = scr + tables_park_bytes(njobs, L) / 4;
     uint8_t* guardf = reinterpret_cast<uint8_t*>(carry + nl * PLUME_FE_WORDS);
-    uint32_t* scr2 = t8.kind ? scr + tables_level_bytes(njobs, L, 1) / 4 : nullptr;
-    uint32_t* carry2 = t8.kind ? scr2 + 4 * tables_park_bytes(njobs, L) / 4 : nullptr;
-    uint8_t* guard2f = t8.kind ? reinterpret_cast<uint8_t*>(carry2 + nl * PLUME_FE_WORDS) : nullptr;
     auto span = [=](size_t lane, size_t& j0, int& cnt) { j0 = lane * (size_t)L; cnt = j0 < njobs ? (int)(njobs - j0 < (size_t)L ? njobs - j0 : (size_t)L) : 0; };
     mockhip::launch(st, [=] {
         grid(blocks, kTabBlock, [&](unsigned b, unsigned t) {
@@ -85,24 +81,12 @@ void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags
             const size_t lane = (size_t)b * kTabBlock + t;
             size_t j0; int cnt; span(lane, j0, cnt);
             const uint32_t* myscr = scr + (size_t)b * ((size_t)L * PLUME_TAB_SCR_WORDS * kTabBlock);
-            uint32_t* myscr2 = scr2 ? scr2 + (size_t)b * ((size_t)4 * L * PLUME_TAB_SCR_WORDS * kTabBlock) : nullptr;
-            fe c, c2; bool g2 = false; ld_fe_soa(c, carry, nl, lane);
-            tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, t, c, guardf[lane] != 0, sink, t8, myscr2, &c2, &g2);
-            if (carry2) { st_fe_soa(carry2, nl, lane, c2); guard2f[lane] = g2 ? 1 : 0; }
-        });
-    });
-    if (!t8.kind) return;
-    mockhip::launch(st, [=] { grid(nblocks(T), kBlock, [&](unsigned b, unsigned t) { const size_t k = (size_t)b * kBlock + t; if (k < T) tab_invert_group<kTabInvK>(carry2, nl, T, k); }); });
-    mockhip::launch(st, [=] {                                    // k_tab_pass_c: the inverses of the base-8 jobs' denominator groups
-        grid(blocks, kTabBlock, [&](unsigned b, unsigned t) {
-            const size_t lane = (size_t)b * kTabBlock + t;
-            size_t j0; int cnt; span(lane, j0, cnt);
-            const uint32_t* myscr2 = scr2 + (size_t)b * ((size_t)4 * L * PLUME_TAB_SCR_WORDS * kTabBlock);
-            fe c2; ld_fe_soa(c2, carry2, nl, lane);
-            tab_pass_c(ginv, j0, cnt, myscr2, (size_t)kTabBlock, t, c2, guard2f[lane] != 0, t8);
+            fe c; ld_fe_soa(c, carry, nl, lane);
+            tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, t, c, guardf[lane] != 0, sink);
         });
     });
 }
+
 #define PLUME_MSM_DIG_ROWS (2 * PLUME_NDIG + PLUME_NPOS)
 const char* verify_msm_kernel_name(const VerifyArgs& a) { return a.msm_pair && !verify_eq1_short(a) ? "k_verify_msm_pair" : verify_eq1_short(a) ? "k_verify_msm_s" : "k_verify_msm"; }
 void launch_verify_msm(const VerifyArgs& a0, hipStream_t st) {

@@ -192,69 +192,6 @@ def test_glv_and_booth():
     assert 0.92 < nonzero / total < 0.95                       # fifteen of the sixteen residues mod 4 are non-zero digits
 
 
-def test_eisenstein_base8_digits_and_table():
-    """Round 6, base-8 digits in Z[w] (plume_ec.h eisd8_store, csrc/gen_eis8.py): the eleven rows times the six units are a complete residue system of Z[w] / 8 (63 non-zero
-    classes; the class of 4 is its own negative), the committed table is the generator's, its every entry leaves a carry in {-1, 0, 1}^2, and the device recoding of GLV pairs
-    (44 positions) and of pairs of 64-bit quarters (22 positions) reconstructs the pair exactly, with a digit at about 63 of 64 positions."""
-    import importlib.util
-    import re
-    spec = importlib.util.spec_from_file_location("gen_eis8", Path(__file__).parent.parent / "zk-nullifier-sig_amd" / "csrc" / "gen_eis8.py")
-    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
-    vals = G.digit_values()
-    assert G.ROWS == D.ROWS8 and all(D.eis_digit8(c) == v for c, v in vals.items()) and [D.eis_digit8(c) for c in range(19)] == [D.eis_digit(c) for c in range(19)]
-    assert len(vals) == 66 and {(a % 8, b % 8) for a, b in vals.values()} | {(0, 0)} == {(a, b) for a in range(8) for b in range(8)}
-    assert max(a * a - a * b + b * b for a, b in vals.values()) == 19
-    tab = G.table()
-    inc = (Path(__file__).parent.parent / "zk-nullifier-sig_amd" / "csrc" / "plume_eis8.inc").read_text()
-    assert [int(x, 16) for x in re.findall(r"0x[0-9A-Fa-f]{4}", inc)] == tab
-    for idx, e in enumerate(tab):
-        ra, rb, na, nb = (idx >> 3) & 7, idx & 7, (idx >> 6) & 1, (idx >> 7) & 1
-        d = (((e >> 7) & 15) - 5, ((e >> 11) & 15) - 5)
-        assert (d[0] % 8, d[1] % 8) == (ra, rb) and d == ((0, 0) if (e & 127) == 0 else vals[e & 127])
-        for ta in [t for t in range(-8, 9) if t % 8 == ra and (t < 0) == bool(na)]:
-            for tb in [t for t in range(-8, 9) if t % 8 == rb and (t < 0) == bool(nb)]:
-                assert abs((ta - d[0]) // 8) <= 1 and abs((tb - d[1]) // 8) <= 1
-    rng = random.Random(8)
-    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
-    ks = [0, 1, 2, 7, 8, 9, N - 1, N - 2, lam, lam + 1, N - lam, (N - 1) // 2, 2**128, 2**128 - 1, 2**255 % N] + [rng.randrange(N) for _ in range(4000)]
-    nonzero = total = 0
-    for k, (m1, n1, m2, n2, _), codes in zip(ks, D.glv(ks), D.glv8(ks)):
-        k1, k2 = (-m1 if n1 else m1), (-m2 if n2 else m2)
-        assert len(codes) == D.NPOS8 and all(0 <= c <= 66 for c in codes)
-        va = vb = 0
-        for c in reversed(codes):
-            da, db = D.eis_digit8(c)
-            va, vb = 8 * va + da, 8 * vb + db
-        assert (va, vb) == (k1, k2), hex(k)
-        nonzero += sum(1 for c in codes[:42] if c); total += 42
-    assert 0.975 < nonzero / total < 0.992                       # sixty-three of the sixty-four residues are non-zero digits
-    for a, b in [(2**64 - 1, 2**64 - 1), (-(2**64 - 1), 2**64 - 1), (2**64 - 1, -(2**64 - 1)), (0, 0), (1, -1), (-(2**63), 2**63)] + [(rng.randrange(-2**64 + 1, 2**64), rng.randrange(-2**64 + 1, 2**64)) for _ in range(2000)]:
-        codes = D.eisd8_64(a, b)
-        assert codes is not None, (a, b)
-        va = vb = 0
-        for c in reversed(codes):
-            da, db = D.eis_digit8(c)
-            va, vb = 8 * va + da, 8 * vb + db
-        assert (va, vb) == (a, b)
-
-
-def test_base8_table_rows_are_the_multiples_they_stand_for():
-    """rows 0..10 of the base-8 table of P -- built by the pass sequence the kernels run (pass A, inversion, pass B, second inversion, pass D) and by the one-function form, which
-    must agree -- are (a + b lambda) P for the eleven Eisenstein integers a + b w of csrc/gen_eis8.py, each with its beta x; for G, a hash_to_curve point and a small multiple"""
-    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
-    beta = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
-    for pt in (O.G, O.hash_to_curve(b"base-8 rows", None), O.pt_mul(3, O.G), O.pt_mul(N - 5, O.G)):
-        rows = D.table8(O.pt_bytes(pt))
-        for (a, b), (x, y, bx) in zip(D.ROWS8, rows):
-            want = O.pt_mul((a + b * lam) % N, pt)
-            assert (x, y) == want and bx == beta * x % P, (a, b)
-        D.lib().ds_force_guard2(1)                 # pass D's slow path (a lane whose second product came out zero: every group inverted on its own) builds the same rows
-        try:
-            assert D.table8(O.pt_bytes(pt)) == rows
-        finally:
-            D.lib().ds_force_guard2(0)
-
-
 def test_eisenstein_digit_table():
     """the 64-entry table behind eisd_entry (plume_ec.h), regenerated from its definition: for t = (ta, tb), |t| <= 4, the digit is the representative of t mod 4 among
     0, the units, the associates of theta = 1 - w and of 2 that leaves a carry (t - d) / 4 in {-1, 0, 1}^2; and the header carries exactly this table"""

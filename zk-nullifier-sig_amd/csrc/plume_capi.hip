@@ -166,7 +166,7 @@ struct plume_ctx {
     size_t lane_next = 0;
     size_t in_flight_min = (size_t)1 << 17;                        // verify / sign calls of fewer items are not dealt out to the lanes (env PLUME_IN_FLIGHT_MIN): latency-bound calls side by side measured slower than one after the other
     plume_ctx* lane_last = nullptr;                               // the lane the last device-resident call went to (plume_last_stage_times, plume_last_redo_tasks)
-    DevBuf bases, jobflags, itemflags, tab, tab8, ginv, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo, digs, eq1fall, eq1k, clk;
+    DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo, digs, eq1fall, eq1k, clk;
     int eq1_short = 1;                                             // verify calls that give R: equation 1 in its short form (plume_eis.h).  0 = long form always (A/B), 2 = test: every item takes the fallback
     size_t eq1_short_min = (size_t)1 << 16;                        // ... for calls of at least this many items.  Round 6 sweep on one box, interleaved (profiles/r06_eq1_threshold.txt), now that the
                                                                    // scalar stage -- half-GCD included -- of calls up to 2^16 runs in role B of the two-role ingest kernel: 2^16 items 1.385 -> 1.343 ms
@@ -284,7 +284,7 @@ static void destroy_single(plume_ctx* ctx) {
     // for that event and for the context's own streams -- not for the whole device, which would also wait for every other framework's work in the process.
     if (ctx->ws_used && ctx->ws_free) (void)hipEventSynchronize(ctx->ws_free);
     for (hipStream_t q : {ctx->stream, ctx->up, ctx->down, ctx->side, ctx->pre}) if (q) (void)hipStreamSynchronize(q);
-    for (DevBuf* b : {&ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tab8, &ctx->ginv, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
+    for (DevBuf* b : {&ctx->bases, &ctx->jobflags, &ctx->itemflags, &ctx->tab, &ctx->tabscr, &ctx->res, &ctx->resinf, &ctx->res2, &ctx->res2inf, &ctx->pkaff,
                       &ctx->sink, &ctx->redo, &ctx->digs, &ctx->eq1fall, &ctx->eq1k, &ctx->clk, &ctx->dec[0], &ctx->dec[1], &ctx->dec[2], &ctx->dec[3], &ctx->preflags, &ctx->agg_record, &ctx->dslots, &ctx->dminid, &ctx->dmyslot, &ctx->dcount, &ctx->dblockcnt})
         b->release();
     for (DevBuf& b : ctx->agg) b.release();
@@ -717,12 +717,9 @@ static int pick_jobs_per_lane(const plume_ctx* ctx, size_t njobs, bool kinds_of_
 
 // nthrees: how many of the jobs, from the front, come as (pk, H, nullifier) triples (the verifier: 3 per item; its short first equation appends one more job per item behind
 // them; the signer: 0): the jobs per lane are then a multiple of three, so that the kinds line up across a wavefront (affine and Jacobian bases take different paths).
-// tab8 (the verifier): the H and nullifier jobs of the nthrees leading jobs carry base-8 tables, rows 3..10 in that array (plume_ec.h Tab8Spec)
-static size_t table_stage_scratch(const plume_ctx* ctx, size_t njobs, size_t nthrees, bool base8 = false) { return tables_scratch_bytes(njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0), base8); }
-static void table_stage(plume_ctx* ctx, uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t nthrees, hipStream_t st, uint32_t* tab8 = nullptr, uint32_t* ginv = nullptr) {
-    Tab8Spec t8 = tab8_none();
-    if (tab8) { t8.tab8 = tab8; t8.n3 = nthrees; t8.kind = 1; }
-    launch_tables(tab, bases, jobflags, njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0), ctx->tabscr.as<uint32_t>(), st, t8, ginv);
+static size_t table_stage_scratch(const plume_ctx* ctx, size_t njobs, size_t nthrees) { return tables_scratch_bytes(njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0)); }
+static void table_stage(plume_ctx* ctx, uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t nthrees, hipStream_t st) {
+    launch_tables(tab, bases, jobflags, njobs, pick_jobs_per_lane(ctx, njobs, nthrees != 0), ctx->tabscr.as<uint32_t>(), st);
 }
 
 // ------------------------------------------------------------------------------------------ device pipelines
@@ -760,9 +757,9 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
     const size_t nsub = cut.size() - 1;
     const bool overlapped = nsub > 1;
     size_t scr_bytes = 0;
-    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, J * (cut[k + 1] - cut[k]), 3 * (cut[k + 1] - cut[k]), true));
+    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, J * (cut[k + 1] - cut[k]), 3 * (cut[k + 1] - cut[k])));
     if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * J * n) || ctx->jobflags.ensure(J * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * J * n) ||
-        ctx->tab8.ensure((size_t)PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS * 4 * 2 * n) || ctx->ginv.ensure((size_t)2 * PLUME_FE_WORDS * 4 * 2 * n) || ctx->tabscr.ensure(scr_bytes) ||
+        ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->redo.ensure((2 * n + nsub) * 4) || ctx->digs.ensure((size_t)PLUME_VDIG_ROWS * n) ||
         (eq1short && (ctx->eq1fall.ensure(n) || ctx->eq1k.ensure(32 * n))))
         return PLUME_ERR_HIP;
@@ -782,7 +779,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         a.pk = pk + 64 * lo; a.nul = nul + 64 * lo; a.c = c + 32 * lo; a.s = s + 32 * lo; a.rpt = rpt ? rpt + 64 * lo : nullptr; a.hr = hr ? hr + 64 * lo : nullptr; a.ok = ok + lo;
         a.preflags = preflags ? preflags + lo : nullptr; a.rpt33 = rpt33 ? rpt33 + 33 * lo : nullptr; a.hr33 = hr33 ? hr33 + 33 * lo : nullptr;
         a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * J * lo; a.jobflags = ctx->jobflags.as<uint8_t>() + J * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo;
-        a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * J * lo; a.tab8 = ctx->tab8.as<uint32_t>() + (size_t)PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS * 2 * lo; a.ginv = ctx->ginv.as<uint32_t>() + (size_t)2 * PLUME_FE_WORDS * 2 * lo; a.res = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.resinf = ctx->resinf.as<uint8_t>() + 2 * lo;
+        a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * J * lo; a.res = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.resinf = ctx->resinf.as<uint8_t>() + 2 * lo;
         a.gtab = ctx->fixed->gtab.as<uint32_t>();
         a.redo = ctx->redo.as<uint32_t>() + 2 * lo + k;                      // the slice's redo list: counter + up to 2 * cnt tasks
         a.digs = ctx->digs.as<int8_t>() + (size_t)PLUME_VDIG_ROWS * lo;        // the slice's digit rows (row-major over the slice's cnt items)
@@ -797,7 +794,7 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
         a.scalars_in_ingest = two_roles && ctx->split_scalars ? 1 : 0;             // the small-batch ingest kernel runs the scalar stage in its idle role: one launch less
         launch_verify_ingest(a, pre, two_roles); if (!overlapped) t.stage(a.scalars_in_ingest ? "verify_ingest_h2c+scalars" : "verify_ingest_h2c", st);
         if (!a.scalars_in_ingest) { launch_verify_scalars(a, pre); if (!overlapped) t.stage("verify_scalars", st); }
-        table_stage(ctx, a.tab, a.bases, a.jobflags, J * cnt, 3 * cnt, pre, a.tab8, const_cast<uint32_t*>(a.ginv)); if (!overlapped) t.stage("tables", st);   // the table kernels of all sub-batches follow one another on one stream: one scratch
+        table_stage(ctx, a.tab, a.bases, a.jobflags, J * cnt, 3 * cnt, pre); if (!overlapped) t.stage("tables", st);   // the table kernels of all sub-batches follow one another on one stream: one scratch
         if (overlapped) {
             HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));
             HIPCHK(hipStreamWaitEvent(st, ctx->pre_ready[k], 0));

@@ -365,45 +365,6 @@ PLUME_HD void eisd_store_glv(int8_t* dig, uint32_t stride, const glv_half& h1, c
     (void)eisd_store<PLUME_NPOS, 4>(dig, stride, h1.m, h1.neg != 0, h2.m, h2.neg != 0, flip);
 }
 
-// ---------------------------------------------------------------------------------- base-8 digits in the Eisenstein integers (round 6)
-// The same idea one size up: base 8, one digit per THREE doublings, from the 64 residues of Z[w] / 8.  Under the units they fall into ten orbits of six and one of three (the
-// class of 4), so ELEVEN rows serve every digit -- rows 0..2 are the base-4 table (P, theta P, 2P), rows 3..10 the multiples 3 + w, 3 + 2w, 3, 2 theta, 4 + w, 3 - w, 4,
-// 5 + 3w of P (gen_eis8.py: norms 7 7 9 12 13 13 16 19), built from rows 0..2 by one more round of inversions (tab8_* below).  A pair of 128-bit halves takes 44 positions
-// (43 x 3 = 129 doublings, an addition at 63 of 64 positions) where base 4 takes 65 (128 doublings, 15 of 16): 43 additions per joint slot instead of 61.  Used where the
-// eight extra rows per table cost less than the eighteen additions they save: the two slots of the verifier's second equation, s H - c nullifier (measured before it was
-// built, with stand-in digits: the multi-scalar kernel 13.95 -> 12.3 ms per 2^20 verifies; LABNOTES.md round 6).
-//   digit code: 0 = nothing to add, else 1 + 6 row + 2 j + neg = (-1)^neg w^j (row point) -- codes 1..18 mean what they mean in base 4.
-// Recoding: three bits per position, carries in {-1, 0, 1}, one lookup per position in a 256-entry table (gen_eis8.py -> plume_eis8.inc) indexed by the residues and signs of
-// t = sign chunk + carry.
-#define PLUME_NPOS8 44          // pairs of 128-bit halves
-#define PLUME_TAB8_ROWS 8       // rows 3..10 of a base-8 table: a second array, PLUME_TAB8_ROWS x PLUME_TAB_ENTRY_WORDS words per base-8 job
-PLUME_HD uint32_t eisd8_entry(int ta, int tb) {
-    static const uint16_t T8[256] = {
-#include "plume_eis8.inc"
-    };
-    return T8[(((uint32_t)ta & 7u) << 3) | ((uint32_t)tb & 7u) | (ta < 0 ? 64u : 0u) | (tb < 0 ? 128u : 0u)];
-}
-// NP base-8 digit codes of  +-(a + b w)  (arguments as eisd_store); false if a carry is left over
-template <int NP, int NW>
-PLUME_HD bool eisd8_store(int8_t* dig, uint32_t stride, const uint32_t (&am)[NW], bool aneg, const uint32_t (&bm)[NW], bool bneg, bool flip) {
-    const int sa = (aneg != flip) ? -1 : 1, sb = (bneg != flip) ? -1 : 1;
-    int ca = 0, cb = 0;
-    PLUME_UNROLL for (int i = 0; i < NP; i++) {
-        const int bit = 3 * i, w = bit >> 5, sh = bit & 31;
-        uint32_t xa = w < NW ? am[w < NW ? w : 0] >> sh : 0u, xb = w < NW ? bm[w < NW ? w : 0] >> sh : 0u;
-        if (sh > 29 && w + 1 < NW) { xa |= am[w + 1 < NW ? w + 1 : 0] << (32 - sh); xb |= bm[w + 1 < NW ? w + 1 : 0] << (32 - sh); }
-        const int ta = sa * (int)(xa & 7u) + ca, tb = sb * (int)(xb & 7u) + cb;
-        const uint32_t e = eisd8_entry(ta, tb);
-        dig[(uint32_t)i * stride] = (int8_t)(e & 127u);
-        ca = (ta - ((int)((e >> 7) & 15u) - 5)) >> 3;                  // exact: t = d (mod 8)
-        cb = (tb - ((int)((e >> 11) & 15u) - 5)) >> 3;
-    }
-    return ca == 0 && cb == 0;
-}
-PLUME_HD void eisd8_store_glv(int8_t* dig, uint32_t stride, const glv_half& h1, const glv_half& h2, bool flip) {
-    (void)eisd8_store<PLUME_NPOS8, 4>(dig, stride, h1.m, h1.neg != 0, h2.m, h2.neg != 0, flip);
-}
-
 // ------------------------------------------------------------------------------------------ window tables
 // One table = 3 rows x 32 words (128 B = one cache line): row 0 = P, row 1 = theta P = P - lambda P, row 2 = 2P, affine, as 29-bit limbs of tight field elements:
 //     [ x0..x7 | y0..y7 | b0..b7 | x8 y8 b8 0 | 0 0 0 0 ]        b = beta * x (the x of lambda * (row point))
@@ -588,109 +549,22 @@ PLUME_HD void tab_pass_a(const uint32_t* bases, const uint8_t* jobflags, size_t 
     }
     carry = acc;
 }
-// ------------------------------------------------------------------------------ rows 3..10 of a base-8 table (round 6)
-// Which jobs of a table stage carry base-8 tables, and where their rows 3..10 go (PLUME_TAB8_ROWS rows of PLUME_TAB_ENTRY_WORDS words per such job, a second array):
-//   kind 0: none;  kind 1: the verifier -- jobs [0, n3) come as (pk, H, nullifier) triples, H and the nullifier are base-8 jobs, array index 2 (job / 3) + job % 3 - 1
-struct Tab8Spec {
-    uint32_t* tab8;
-    size_t n3;
-    int kind;
-    PLUME_HD bool is8(size_t job) const { return kind == 1 && job < n3 && job % 3 != 0; }
-    PLUME_HD size_t index(size_t job) const { return (job / 3) * 2 + (job % 3) - 1; }
-};
-PLUME_HD Tab8Spec tab8_none() { Tab8Spec t; t.tab8 = nullptr; t.n3 = 0; t.kind = 0; return t; }
-// Rows 3..10 are sums of two points the rows 0..2 give for free (a unit multiple of a row is (x | beta x | beta^2 x, +-y)), or doubles:
-//     row 3 = (3 + w) P  = 2P + (-w^2) P          row 4 = (3 + 2w) P = 2P + w theta P         row 5 = 3 P     = 2P + P              row 6 = 2 theta P = dbl(theta P)
-//     row 7 = (4 + w) P  = 2P + (-w^2) theta P    row 8 = (3 - w) P  = 2P + theta P           row 9 = 4 P     = dbl(2P)             row 10 = (5 + 3w) P = row 4 + (-w^2) theta P
-// Each needs the inverse of one denominator (x_Q - x_A, or 2y): d3 .. d9 straight from rows 0..2, and row 10's, x_Q - x(row 4), from row 4 in fraction form --
-// x(row 4) = X4 / d4^2 with X4 = n4^2 - (x2 + beta xt) d4^2, so x_Q - x(row 4) = e / d4^2 with e = x_Q d4^2 - X4, and ONE inverse w = 1 / (d4 e) serves both: 1 / d4 = w e,
-// d4^2 / e = w d4^3.  The factors come in two groups, by the row of the table they need beside 2P -- group 0 (P): d3 d5 d9, group 1 (theta P): d6 d7 d8 (d4 e) -- and each
-// group's product joins the lane's second running product as an entry of its own (Montgomery's trick, as for rows 1..2): a pass then holds one group's operands at a time.
-// None of the factors vanishes for a point of the group: x_Q = x_A means Q = +-A, i.e. (a +- q) P = O for Eisenstein integers a, q of norm <= 19 whose sum and difference are
-// non-zero and of norm < n.  Should a lane's product come out zero all the same (garbage fed by a test), the lane is flagged and pass D inverts its groups one by one with zero
-// factors replaced by 1: that job's rows are garbage, the lane's other jobs are not.
-PLUME_HD void fe_beta2(fe& r, const fe& x, const fe& bx) { fe t; fe_add_lazy(t, x, bx); fe_neg(r, t); }       // beta^2 x = -(x + beta x), tight
-struct tab8_g0 { fe q0, d3, d5, d9; };                           // group 0: beta^2 x0; d3 = q0 - x2, d5 = x0 - x2, d9 = 2 y2
-struct tab8_g1 { fe qt, d6, d7, d8, d4, dd4, e, f4e; };          // group 1: beta^2 xt; d6 = 2 yt, d7 = qt - x2, d8 = xt - x2; d4 = beta xt - x2, d4^2, e, d4 e
-PLUME_HD void tab8_group0(tab8_g0& g, fe& A, const fe& x0, const fe& b0, const fe& x2, const fe& y2, bool guard, bool product = true) {
-    fe_beta2(g.q0, x0, b0);
-    fe_sub(g.d3, g.q0, x2); fe_sub(g.d5, x0, x2); fe_dbl(g.d9, y2);
-    guard_one(g.d3, guard); guard_one(g.d5, guard); guard_one(g.d9, guard);
-    if (product) { fe_mul(A, g.d3, g.d5); fe_mul(A, A, g.d9); }
-}
-PLUME_HD void tab8_group1(tab8_g1& g, fe& B, const fe& xt, const fe& yt, const fe& bt, const fe& x2, const fe& y2, bool guard, bool product = true) {
-    fe n4, nn, t, m, X4;
-    fe_beta2(g.qt, xt, bt);
-    fe_dbl(g.d6, yt); fe_sub(g.d7, g.qt, x2); fe_sub(g.d8, xt, x2);
-    fe_sub(g.d4, bt, x2);
-    fe_sub(n4, yt, y2);
-    fe_sqr(g.dd4, g.d4); fe_sqr(nn, n4);
-    fe_add_lazy(t, x2, bt); fe_mul(m, t, g.dd4);
-    fe_sub(X4, nn, m);                                          // x(row 4) = X4 / d4^2
-    fe_mul(t, g.qt, g.dd4);
-    fe_sub(g.e, t, X4);                                         // e = beta^2 xt d4^2 - X4
-    fe_mul(g.f4e, g.d4, g.e);
-    guard_one(g.d6, guard); guard_one(g.d7, guard); guard_one(g.d8, guard); guard_one(g.f4e, guard);
-    if (product) { fe_mul(B, g.d6, g.d7); fe_mul(t, g.d8, g.f4e); fe_mul(B, B, t); }
-}
-// A + Q for affine A = (xa, ya), Q = (xq, +-yq) (negq: the minus sign) and inv = 1 / (xq - xa); every operand tight
-PLUME_HD void aff_add(fe& x3, fe& y3, const fe& xa, const fe& ya, const fe& xq, const fe& yq, bool negq, const fe& inv) {
-    fe num, lam, s, t;
-    if (negq) { fe_add_lazy(t, yq, ya); fe_neg(num, t); } else fe_sub(num, yq, ya);
-    fe_mul(lam, num, inv);
-    fe_add_lazy(s, xa, xq);
-    fe_sqr_sub<3>(x3, lam, s);                                  // lambda^2 - xa - xq
-    fe_sub_lazy<2>(t, xa, x3);
-    fe_mul_sub<2>(y3, lam, t, ya);                              // lambda (xa - x3) - ya
-}
-// rows 4, 6, 7, 8, 10 from theta P, 2P and Binv = 1 / (d6 d7 d8 (d4 e))
-template <class RowSink>
-PLUME_HD void tab8_rows_g1(uint32_t* rows8, const tab8_g1& g, const fe& Binv, const fe& xt, const fe& yt, const fe& bt, const fe& x2, const fe& y2, const RowSink& sink) {
-    constexpr size_t EW = PLUME_TAB_ENTRY_WORDS;
-    const fe beta = fe_beta();
-    fe C, E, iC, iE, iv, t, x, y, b, x4, y4;
-    fe_mul(C, g.d6, g.d7); fe_mul(E, g.d8, g.f4e);
-    fe_mul(iC, Binv, E); fe_mul(iE, Binv, C);                   // 1 / (d6 d7), 1 / (d8 d4 e)
-    fe_mul(iv, iC, g.d7); aff_dbl(x, y, xt, yt, iv);                         fe_mul_k(b, beta, x); sink(rows8 + 3 * EW, x, y, b);      // row 6 = 2 theta P
-    fe_mul(iv, iC, g.d6); aff_add(x, y, x2, y2, g.qt, yt, true, iv);         fe_mul_k(b, beta, x); sink(rows8 + 4 * EW, x, y, b);      // row 7
-    fe_mul(iv, iE, g.f4e); aff_add(x, y, x2, y2, xt, yt, false, iv);         fe_mul_k(b, beta, x); sink(rows8 + 5 * EW, x, y, b);      // row 8
-    fe_mul(C, iE, g.d8);                                                     // w = 1 / (d4 e)
-    fe_mul(iv, C, g.e); aff_add(x4, y4, x2, y2, bt, yt, false, iv);          fe_mul_k(b, beta, x4); sink(rows8 + 1 * EW, x4, y4, b);   // row 4 (1 / d4 = w e)
-    fe_mul(t, g.dd4, g.d4); fe_mul(iv, C, t); aff_add(x, y, x4, y4, g.qt, yt, true, iv); fe_mul_k(b, beta, x); sink(rows8 + 7 * EW, x, y, b);      // row 10 (d4^2 / e = w d4^3)
-}
-// rows 3, 5, 9 from P, 2P and Ainv = 1 / (d3 d5 d9)
-template <class RowSink>
-PLUME_HD void tab8_rows_g0(uint32_t* rows8, const tab8_g0& g, const fe& Ainv, const fe& x0, const fe& y0, const fe& x2, const fe& y2, const RowSink& sink) {
-    constexpr size_t EW = PLUME_TAB_ENTRY_WORDS;
-    const fe beta = fe_beta();
-    fe t, iv, x, y, b;
-    fe_mul(t, g.d5, g.d9); fe_mul(iv, Ainv, t); aff_add(x, y, x2, y2, g.q0, y0, true, iv);  fe_mul_k(b, beta, x); sink(rows8 + 0 * EW, x, y, b);      // row 3
-    fe_mul(t, g.d3, g.d9); fe_mul(iv, Ainv, t); aff_add(x, y, x2, y2, x0, y0, false, iv);   fe_mul_k(b, beta, x); sink(rows8 + 2 * EW, x, y, b);      // row 5
-    fe_mul(t, g.d3, g.d5); fe_mul(iv, Ainv, t); aff_dbl(x, y, x2, y2, iv);                  fe_mul_k(b, beta, x); sink(rows8 + 6 * EW, x, y, b);      // row 9 = 4P
-}
-PLUME_HD void ld_row_xyb(fe& x, fe& y, fe& b, const uint32_t* e) {
-    PLUME_UNROLL for (int i = 0; i < 8; i++) { x.v[i] = e[i]; y.v[i] = e[8 + i]; b.v[i] = e[16 + i]; }
-    x.v[8] = e[24]; y.v[8] = e[25]; b.v[8] = e[26];
-}
-
-// Pass B (jobs descending): carry = 1 / (the lane's product) in; rows P, theta P, 2P of every job out.  For the base-8 jobs (t8) the products of the two level-2 groups join the
-// lane's SECOND running product; scr2 takes four entries per job -- 4 jj: the product so far, 4 jj + 1: group 0's own product, 4 jj + 2, 4 jj + 3: the same for group 1 --;
-// carry2 = the lane's product out (1 where the lane holds no such job), guard2 = it came out zero (carry2 is then 1 and pass C inverts the lane's groups one by one).
+// Pass B (jobs descending): carry = 1 / (the lane's product) in; rows P, theta P, 2P of every job out.
 template <class RowSink>
 PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, const uint32_t* scr, size_t sstride, size_t slane,
-                         const fe& carry, bool guard, const RowSink& sink, const Tab8Spec& t8 = tab8_none(), uint32_t* scr2 = nullptr, fe* carry2 = nullptr, bool* guard2 = nullptr) {
+                         const fe& carry, bool guard, const RowSink& sink) {
     const fe beta = fe_beta();
     constexpr size_t TW = PLUME_TAB_ENTRIES * PLUME_TAB_ENTRY_WORDS, EW = PLUME_TAB_ENTRY_WORDS;
-    fe inv = carry, acc2 = fe_small(1);
+    fe inv = carry;
     PLUME_NOUNROLL for (int jj = cnt - 1; jj >= 0; jj--) {
         const size_t job = j0 + (size_t)jj;
         jac b;
         const bool zone = tab_base(b, bases, jobflags, njobs, job);
-        fe dy, dx, dz, pyx, D, Dinv, iy, ix, x0, y0, b0, xt, yt, bt, x2, y2, b2;
+        fe dy, dx, dz, pyx, D, Dinv, x, y, iy, ix;
         tab_dens(dy, dx, dz, pyx, D, b, zone, guard);
         tab_unpark(Dinv, inv, scr, sstride, slane, (size_t)jj, D);
         if (zone) {
-            x0 = b.x; y0 = b.y;
+            x = b.x; y = b.y;
             fe_mul(iy, Dinv, dx);                               // 1 / (2y)
             fe_mul(ix, Dinv, dy);                               // 1 / ((beta - 1) x)
         } else {
@@ -699,77 +573,23 @@ PLUME_HD void tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jo
             fe zi, zi2, z2, t;
             fe_mul(zi, Dinv, pyx);
             fe_sqr(zi2, zi);
-            fe_mul(x0, b.x, zi2);
-            fe_mul(t, zi2, zi); fe_mul(y0, b.y, t);
+            fe_mul(x, b.x, zi2);
+            fe_mul(t, zi2, zi); fe_mul(y, b.y, t);
             fe_sqr(z2, dz);
             fe_mul(t, Dinv, dz);                                // 1 / (dy dx)
             fe_mul(iy, t, dx); fe_mul(iy, iy, z2); fe_mul(iy, iy, dz);      // Z^3 / (2Y)
             fe_mul(ix, t, dy); fe_mul(ix, ix, z2);                          // Z^2 / ((beta - 1) X)
         }
         uint32_t* rows = tab + job * TW;
-        fe_mul_k(b0, beta, x0);
-        sink(rows, x0, y0, b0);                                 // row 0: P
-        aff_theta(xt, yt, x0, y0, b0, ix);
-        fe_mul_k(bt, beta, xt);
-        sink(rows + EW, xt, yt, bt);                            // row 1: theta P = P - lambda P
-        aff_dbl(x2, y2, x0, y0, iy);
+        fe bx, x2, y2, b2;
+        fe_mul_k(bx, beta, x);
+        sink(rows, x, y, bx);                                   // row 0: P
+        aff_theta(x2, y2, x, y, bx, ix);
+        fe_mul_k(b2, beta, x2);
+        sink(rows + EW, x2, y2, b2);                            // row 1: theta P = P - lambda P
+        aff_dbl(x2, y2, x, y, iy);
         fe_mul_k(b2, beta, x2);
         sink(rows + 2 * EW, x2, y2, b2);                        // row 2: 2P
-        if (t8.is8(job)) {
-            fe A, B;
-            { tab8_g0 g; tab8_group0(g, A, x0, b0, x2, y2, false); }
-            pre_st(scr2, sstride, slane, 4 * (size_t)jj + 1, A);
-            tab_park(acc2, scr2, sstride, slane, 4 * (size_t)jj, A);
-            { tab8_g1 g; tab8_group1(g, B, xt, yt, bt, x2, y2, false); }
-            pre_st(scr2, sstride, slane, 4 * (size_t)jj + 3, B);
-            tab_park(acc2, scr2, sstride, slane, 4 * (size_t)jj + 2, B);
-        }
-    }
-    const bool z2 = t8.kind != 0 && fe_is_zero(acc2);
-    if (guard2) *guard2 = z2;
-    if (carry2) { if (z2) acc2 = fe_small(1); *carry2 = acc2; }
-}
-// Pass C (jobs ASCENDING, group 1 before group 0: the reverse of the order pass B parked in): carry2 = 1 / (the lane's second product) in; the inverse of every group's product
-// out -- ginv: two field elements per base-8 job, job-major, group 0 first.  No table row is touched: 36-byte reads and writes only.  guard2: the lane's product was zero -- every
-// group is inverted on its own (a zero group gets 0: that job's rows are garbage, the lane's other jobs are not).
-PLUME_HD void tab_pass_c(uint32_t* ginv, size_t j0, int cnt, const uint32_t* scr2, size_t sstride, size_t slane, const fe& carry2, bool guard2, const Tab8Spec& t8) {
-    fe inv = carry2;
-    PLUME_NOUNROLL for (int jj = 0; jj < cnt; jj++) {
-        const size_t job = j0 + (size_t)jj;
-        if (!t8.is8(job)) continue;
-        uint32_t* out = ginv + t8.index(job) * (size_t)(2 * PLUME_FE_WORDS);
-        PLUME_NOUNROLL for (int g = 1; g >= 0; g--) {
-            fe G, gi;
-            pre_ld(G, scr2, sstride, slane, 4 * (size_t)jj + 2 * (size_t)g + 1);
-            if (guard2) fe_inv(gi, G); else tab_unpark(gi, inv, scr2, sstride, slane, 4 * (size_t)jj + 2 * (size_t)g, G);
-            st_fe(out + g * PLUME_FE_WORDS, gi);
-        }
-    }
-}
-// rows 3..10 of ONE base-8 job from its rows 0..2 (t: the job's three-row table, read one group's operands at a time) and the two inverses pass C left for it.  Run by the lane
-// that is about to walk the job's digits -- the multi-scalar kernels' prologue (plume_stages.h verify_tab8): that kernel is bound by instruction issue and leaves HBM idle, so the
-// 1 KB of rows each job stores costs it the ~8 k instructions and nothing else, where a table pass of its own was bound by exactly those stores (round 6: 1.1 ms per 2^20
-// verifies as a pass, 0.45 ms inside the kernel).
-template <class RowSink>
-PLUME_HD void tab8_build_job(uint32_t* rows8, const uint32_t* t, const uint32_t* ginv2, const RowSink& sink) {
-    constexpr size_t EW = PLUME_TAB_ENTRY_WORDS;
-    fe x2, y2, b2;
-    ld_row_xyb(x2, y2, b2, t + 2 * EW);
-    {
-        fe xt, yt, bt, B, Binv;
-        ld_row_xyb(xt, yt, bt, t + EW);
-        ld_fe(Binv, ginv2 + PLUME_FE_WORDS);
-        tab8_g1 g;
-        tab8_group1(g, B, xt, yt, bt, x2, y2, false, false);
-        tab8_rows_g1(rows8, g, Binv, xt, yt, bt, x2, y2, sink);
-    }
-    {
-        fe x0, y0, b0, A, Ainv;
-        ld_row_xyb(x0, y0, b0, t);
-        ld_fe(Ainv, ginv2);
-        tab8_g0 g;
-        tab8_group0(g, A, x0, b0, x2, y2, false, false);
-        tab8_rows_g0(rows8, g, Ainv, x0, y0, x2, y2, sink);
     }
 }
 // carry[.] <- 1 / carry[.] for nl lane products: thread t of T takes lanes t, t + T, ..., t + (K-1) T and spends ONE inversion on their product
@@ -791,25 +611,15 @@ PLUME_HD void tab_invert_group(uint32_t* carry, size_t nl, size_t T, size_t t) {
         if (l < nl) st_fe_soa(carry, nl, l, o);
     }
 }
-// All passes in one function with the inversions in place: single-lane builds (the host harness holds the pass sequence to it).  scr: the park region of the first level (cnt
-// entries) followed by the second level's (4 cnt entries) when the stage has base-8 jobs; ginv: 2 field elements per base-8 job (Tab8Spec::index).
+// Both passes in one function with the inversion in place: single-lane builds (the host harness holds the pass sequence to it).
 template <class RowSink = DirectRowSinkSync>
 PLUME_HD void table_build(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, size_t j0, int cnt, uint32_t* scr, size_t sstride, size_t slane,
-                          const RowSink& sink = RowSink(), const Tab8Spec& t8 = tab8_none(), uint32_t* ginv = nullptr) {
-    fe carry, inv, carry2;
-    bool guard, guard2 = false;
-    uint32_t* scr2 = scr + (size_t)cnt * PLUME_TAB_SCR_WORDS * sstride;
+                          const RowSink& sink = RowSink()) {
+    fe carry, inv;
+    bool guard;
     tab_pass_a(bases, jobflags, njobs, j0, cnt, scr, sstride, slane, carry, guard);
     sink.inv(inv, carry, 1);
-    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr, sstride, slane, inv, guard, sink, t8, t8.kind ? scr2 : nullptr, &carry2, &guard2);
-    if (t8.kind) {
-        sink.inv(inv, carry2, 1);
-        tab_pass_c(ginv, j0, cnt, scr2, sstride, slane, inv, guard2, t8);
-        for (int jj = 0; jj < cnt; jj++) {
-            const size_t job = j0 + (size_t)jj;
-            if (t8.is8(job)) tab8_build_job(t8.tab8 + t8.index(job) * (size_t)PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS, tab + job * (size_t)PLUME_TAB_WORDS, ginv + t8.index(job) * (size_t)(2 * PLUME_FE_WORDS), sink);
-        }
-    }
+    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, scr, sstride, slane, inv, guard, sink);
 }
 
 // ------------------------------------------------------------------------------ the generator's fixed tables, one entry per lane (round 3)
@@ -1064,46 +874,6 @@ PLUME_HD void msm_run_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1,
         if (c != 0) { fe qx, qy; ld_tab_unit(qx, qy, tab1, c); jac_madd<CHECKED>(acc, qx, qy); }
     }
 }
-// ---- the chain over base-8 digits (round 6): two joint slots, PLUME_NPOS8 positions of three doublings.  A slot's table is its rows 0..2 (t3: the base-4 table, one line each)
-// and its rows 3..10 (t8: PLUME_TAB8_ROWS lines); digit rows [0, NP8) belong to slot A, [NP8, 2 NP8) to slot B.  A NULL t3 (a job flagged INF) contributes nothing.
-PLUME_HD void ld_tab_unit8(fe& qx, fe& qy, const uint32_t* t3, const uint32_t* t8, int code) {
-    const uint32_t c = (uint32_t)(code - 1), row = c / 6u, u = c - 6u * row, j = u >> 1;
-    const uint32_t* e = row < 3u ? t3 + row * PLUME_TAB_ENTRY_WORDS : t8 + (row - 3u) * PLUME_TAB_ENTRY_WORDS;
-    fe x, bx, s, t;
-    PLUME_UNROLL for (int i = 0; i < 8; i++) { x.v[i] = e[i]; qy.v[i] = e[8 + i]; bx.v[i] = e[16 + i]; }
-    x.v[8] = e[24]; qy.v[8] = e[25]; bx.v[8] = e[26];
-    fe_add_lazy(s, x, bx);
-    const fe z = fe_zero();
-    fe_sub_lazy<3>(t, z, s);
-    qx = x;
-    fe_cmov(qx, bx, j == 1u);
-    fe_cmov(qx, t, j == 2u);
-    if (u & 1u) fe_neg_lazy(qy, qy);
-}
-template <bool CHECKED>
-PLUME_HD void msm8_run_impl(jac& acc, const uint32_t* a3, const uint32_t* a8, const uint32_t* b3, const uint32_t* b8, const int8_t* dig, uint32_t stride) {
-    acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
-    // ONE doubling body and ONE addition body in the loop (rolled inner loops): the two equations' workgroups share a compute unit's instruction cache
-    PLUME_NOUNROLL for (int p = PLUME_NPOS8 - 1; p >= 0; p--) {
-        if (p != PLUME_NPOS8 - 1 && !msm_all_inf(acc)) { PLUME_NOUNROLL for (int d = 0; d < 3; d++) jac_dbl(acc); }
-        PLUME_NOUNROLL for (uint32_t sl = 0; sl < 2; sl++) {
-            const uint32_t* t3 = sl ? b3 : a3;
-            const uint32_t* t8 = sl ? b8 : a8;
-            const int c = t3 ? dig[(sl * (uint32_t)PLUME_NPOS8 + (uint32_t)p) * stride] : 0;
-            if (c != 0) { fe qx, qy; ld_tab_unit8(qx, qy, t3, t8, c); jac_madd<CHECKED>(acc, qx, qy); }
-        }
-    }
-}
-PLUME_HD void msm8_run_checked(jac& acc, const uint32_t* a3, const uint32_t* a8, const uint32_t* b3, const uint32_t* b8, const int8_t* dig, uint32_t stride) {
-    PLUME_COUNT_FALLBACK();
-    msm8_run_impl<true>(acc, a3, a8, b3, b8, dig, stride);
-}
-// false when the accumulator met p == +-q on the way (Z = 0 mod p: the task has to be redone with checked additions)
-PLUME_HD bool msm8_run_unchecked(jac& acc, const uint32_t* a3, const uint32_t* a8, const uint32_t* b3, const uint32_t* b8, const int8_t* dig, uint32_t stride) {
-    msm8_run_impl<false>(acc, a3, a8, b3, b8, dig, stride);
-    return acc.inf || !fe_is_zero(acc.z);
-}
-
 // One joint-slot addition of the UNIFORM schedule (the signer): the same instructions whatever the digit code is.  A zero code adds code 1's point to a copy that a masked
 // select drops; unit and sign are masked selects (ld_tab_unit's own, plus the sign here).  Level 1: the row's ADDRESS still depends on the code; SCAN (level 2): all three
 // rows are read and one is kept by masked selects.

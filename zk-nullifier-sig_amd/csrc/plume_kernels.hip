@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kTabBlock, PLUME_TABPASS_WAVES_A) void k_tab_pass_a
     st_fe_soa(carry, nl, lane, c); guardf[lane] = g ? 1 : 0;
 }
 __global__ __launch_bounds__(kTabBlock, PLUME_TABPASS_WAVES_B) void k_tab_pass_b(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, const uint32_t* scr, const uint32_t* carry,
-                                                                                  const uint8_t* guardf, Tab8Spec t8, uint32_t* scr2, uint32_t* carry2) {
+                                                                                  const uint8_t* guardf) {
     __shared__ uint4 s_rows[kTabBlock * 8];
     __shared__ uint32_t* s_ptrs[kTabBlock];
     const size_t lane = (size_t)blockIdx.x * kTabBlock + threadIdx.x, nl = (size_t)gridDim.x * kTabBlock;
@@ -167,23 +167,9 @@ __global__ __launch_bounds__(kTabBlock, PLUME_TABPASS_WAVES_B) void k_tab_pass_b
     sink.ptrs = s_ptrs + (threadIdx.x & ~63u);
     sink.full = __ballot(cnt == L) == ~0ull;
     const uint32_t* myscr = scr + (size_t)blockIdx.x * ((size_t)L * PLUME_TAB_SCR_WORDS * kTabBlock);
-    uint32_t* myscr2 = scr2 ? scr2 + (size_t)blockIdx.x * ((size_t)4 * L * PLUME_TAB_SCR_WORDS * kTabBlock) : nullptr;      // (four parked entries per job at the second level)
-    fe c, c2;
-    bool g2 = false;
+    fe c;
     ld_fe_soa(c, carry, nl, lane);
-    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, guardf[lane] != 0, sink, t8, myscr2, &c2, &g2);
-    if (carry2) { st_fe_soa(carry2, nl, lane, c2); reinterpret_cast<uint8_t*>(carry2 + nl * PLUME_FE_WORDS)[lane] = g2 ? 1 : 0; }
-}
-// the inverses of the base-8 jobs' denominator groups (plume_ec.h tab_pass_c): the lane -> jobs mapping of the passes before it, jobs ascending; 36-byte reads and writes only
-__global__ __launch_bounds__(kTabBlock, 4) void k_tab_pass_c(uint32_t* ginv, size_t njobs, int L, const uint32_t* scr2, const uint32_t* carry2, Tab8Spec t8) {
-    const size_t lane = (size_t)blockIdx.x * kTabBlock + threadIdx.x, nl = (size_t)gridDim.x * kTabBlock;
-    const size_t j0 = lane * (size_t)L;
-    const int cnt = j0 < njobs ? (int)((njobs - j0) < (size_t)L ? (njobs - j0) : (size_t)L) : 0;
-    if (__ballot(j0 < t8.n3) == 0ull) return;                    // (wave-uniform: a wavefront with no base-8 job -- the R jobs behind the triples)
-    const uint32_t* myscr2 = scr2 + (size_t)blockIdx.x * ((size_t)4 * L * PLUME_TAB_SCR_WORDS * kTabBlock);
-    fe c2;
-    ld_fe_soa(c2, carry2, nl, lane);
-    tab_pass_c(ginv, j0, cnt, myscr2, (size_t)kTabBlock, threadIdx.x, c2, reinterpret_cast<const uint8_t*>(carry2 + nl * PLUME_FE_WORDS)[lane] != 0, t8);
+    tab_pass_b(tab, bases, jobflags, njobs, j0, cnt, myscr, (size_t)kTabBlock, threadIdx.x, c, guardf[lane] != 0, sink);
 }
 // carry[.] <- 1 / carry[.] for the nl lane products: thread t takes lanes t, t + T, ..., t + (K-1) T (coalesced) and spends ONE inversion on their product.
 // The products are never zero (the passes' guard).
@@ -499,28 +485,20 @@ static size_t tables_park_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
     return (size_t)nblocks(lanes) * kBlock * (size_t)L * PLUME_TAB_SCR_WORDS * 4;          // one parked prefix product per job
 }
-// one level of the table stage's scratch: `parks` parked prefix products per job, then the lanes' state between the passes (carry: 9 words; a flag byte) -- a multiple of 16 bytes
-static size_t tables_level_bytes(size_t njobs, int L, int parks) {
+size_t tables_scratch_bytes(size_t njobs, int L) {
     const size_t lanes = (njobs + L - 1) / L;
-    return (((size_t)parks * tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16 + 15) / 16) * 16;
+    return tables_park_bytes(njobs, L) + (size_t)nblocks(lanes) * kBlock * (PLUME_FE_WORDS * 4 + 1) + 16;   // ... + the lanes' state between the passes: carry (9 words) and guard flag per lane
 }
-size_t tables_scratch_bytes(size_t njobs, int L, bool base8) { return tables_level_bytes(njobs, L, 1) + (base8 ? tables_level_bytes(njobs, L, 4) : 0); }
-void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st, const Tab8Spec& t8, uint32_t* ginv) {
+void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int L, uint32_t* scr, hipStream_t st) {
     size_t lanes = (njobs + L - 1) / L;
     static_assert(kBlock % kTabBlock == 0, "the scratch regions are sized in units of kBlock lanes");
     const dim3 grid(nblocks(lanes) * (kBlock / kTabBlock)), block(kTabBlock);
     const size_t nl = (size_t)grid.x * kTabBlock, T = (nl + PLUME_TABINV_K - 1) / PLUME_TABINV_K;
     uint32_t* carry = scr + tables_park_bytes(njobs, L) / 4;
     uint8_t* guardf = reinterpret_cast<uint8_t*>(carry + nl * PLUME_FE_WORDS);
-    uint32_t* scr2 = t8.kind ? scr + tables_level_bytes(njobs, L, 1) / 4 : nullptr;         // the second level's park area (two entries per job) and lane products + flags (base-8 jobs)
-    uint32_t* carry2 = t8.kind ? scr2 + 4 * tables_park_bytes(njobs, L) / 4 : nullptr;
     hipLaunchKernelGGL(k_tab_pass_a, grid, block, 0, st, bases, jobflags, njobs, L, scr, carry, guardf);
     hipLaunchKernelGGL(k_tab_invert, dim3(nblocks(T)), dim3(kBlock), 0, st, carry, nl, T);
-    hipLaunchKernelGGL(k_tab_pass_b, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf, t8, scr2, carry2);
-    if (t8.kind) {
-        hipLaunchKernelGGL(k_tab_invert, dim3(nblocks(T)), dim3(kBlock), 0, st, carry2, nl, T);
-        hipLaunchKernelGGL(k_tab_pass_c, grid, block, 0, st, ginv, njobs, L, scr2, carry2, t8);
-    }
+    hipLaunchKernelGGL(k_tab_pass_b, grid, block, 0, st, tab, bases, jobflags, njobs, L, scr, carry, guardf);
 }
 const char* verify_msm_kernel_name(const VerifyArgs& a) { return a.msm_pair && !verify_eq1_short(a) ? "k_verify_msm_pair" : verify_eq1_short(a) ? "k_verify_msm_s" : "k_verify_msm"; }
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st) {      // (a.redo[0] was zeroed by k_verify_scalars, which every verify pipeline runs first)

@@ -12,11 +12,9 @@ constexpr int kTableJobsPerLane = 6;   // (measured r02, one box, final layout: 
 
 void launch_verify_scalars(const VerifyArgs& a, hipStream_t st);                           // window digits of s and c; the short first equation's coefficients (plume_eis.h)
 void launch_verify_ingest(const VerifyArgs& a, hipStream_t st, bool two_roles = false);   // two_roles: the small-batch form, two lanes per item (k_verify_ingest_split), which runs the scalar stage too when a.scalars_in_ingest is set: no launch_verify_scalars then
-// the window tables of njobs bases (plume_ec.h: rows P, theta P, 2P): pass A, one batched inversion, pass B; for the base-8 jobs t8 names, a second inversion and pass C
-// leave the inverses of their two denominator groups in ginv (2 x PLUME_FE_WORDS words per such job) -- their rows 3..10 are built by the multi-scalar kernels' prologue.
-// scr: tables_scratch_bytes(njobs, jobs_per_lane, t8.kind != 0) bytes
-size_t tables_scratch_bytes(size_t njobs, int jobs_per_lane, bool base8 = false);
-void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int jobs_per_lane, uint32_t* scr, hipStream_t st, const Tab8Spec& t8 = tab8_none(), uint32_t* ginv = nullptr);
+// the window tables of njobs bases (plume_ec.h: rows P, theta P, 2P): pass A, one batched inversion, pass B.  scr: tables_scratch_bytes(njobs, jobs_per_lane) bytes
+size_t tables_scratch_bytes(size_t njobs, int jobs_per_lane);
+void launch_tables(uint32_t* tab, const uint32_t* bases, const uint8_t* jobflags, size_t njobs, int jobs_per_lane, uint32_t* scr, hipStream_t st);
 void launch_verify_msm(const VerifyArgs& a, hipStream_t st);
 const char* verify_msm_kernel_name(const VerifyArgs& a);      // the kernel launch_verify_msm picks for this call
 void launch_verify_finalize(const VerifyArgs& a, hipStream_t st);

@@ -159,9 +159,6 @@ struct VerifyArgs {
     uint8_t* jobflags;    // 3n
     uint8_t* itemflags;   // n : 1 = rejected at ingest (bad scalar / invalid point)
     uint32_t* tab;        // 3n tables of PLUME_TAB_WORDS
-    uint32_t* tab8;       // rows 3..10 of the base-8 tables (round 6): 2n blocks of PLUME_TAB8_ROWS rows -- H of item i at 2i, its nullifier at 2i + 1 (equation 2's two slots)
-    const uint32_t* ginv; // ... and what the table stage leaves for them: per block two field elements, the inverses of the block's two denominator groups (plume_ec.h tab_pass_c).  The rows
-                          //     themselves are built by the lane that walks the block's digits: verify_tab8 below, the multi-scalar kernels' prologue
     uint32_t* res;        // PLUME_JAC_WORDS x (2n) words, Jacobian SoA of R' (task 2i) and Hr' (task 2i+1)
     uint8_t* resinf;      // 2n
     const uint32_t* gtab; // wide table of G (PLUME_GTAB_WORDS): (1..2^(W-1))*G
@@ -185,19 +182,11 @@ struct VerifyArgs {
 // across the lanes of the table passes and the last n are all of one kind (affine)
 PLUME_HD bool verify_eq1_short(const VerifyArgs& a) { return a.eq1fall != nullptr; }      // does this call run equation 1 in the short form?
 PLUME_HD size_t verify_njobs(const VerifyArgs& a) { return (verify_eq1_short(a) ? 4 : 3) * (size_t)a.n; }
-// the digit rows of an item, four sets (one byte per row and item, row-major):
-//   A   PLUME_NPOS8 rows        s in base-8 Eisenstein digits: H's slot of equation 2
-//   B   2 x PLUME_NPOS66 rows   equation 1's own rows: s in the generator's wide digits (2 x 33 rows: long form) OR the two coefficient pairs of the short form (2 x 34)
-//   C   PLUME_NPOS8 rows        -c in base-8 digits: the nullifier's slot of equation 2
-//   C4  PLUME_NPOS rows         -c in base-4 digits: pk's slot of equation 1 in its LONG form (pk keeps a three-row table) -- written for the items that run it
-#define PLUME_VDIG_SETA PLUME_NPOS8
-#define PLUME_VDIG_SETB (2 * PLUME_NPOS66)
-#define PLUME_VDIG_SETC PLUME_NPOS8
-#define PLUME_VDIG_SETC4 PLUME_NPOS
-#define PLUME_VDIG_OFFB PLUME_VDIG_SETA
-#define PLUME_VDIG_OFFC (PLUME_VDIG_SETA + PLUME_VDIG_SETB)
-#define PLUME_VDIG_OFFC4 (PLUME_VDIG_SETA + PLUME_VDIG_SETB + PLUME_VDIG_SETC)
-#define PLUME_VDIG_ROWS (PLUME_VDIG_SETA + PLUME_VDIG_SETB + PLUME_VDIG_SETC + PLUME_VDIG_SETC4)
+// the digit rows of an item: three sets of 2 x PLUME_NDIG rows (the two halves of a GLV split): s in 4-bit windows (equation 2), s with the generator's wide digits
+// (equation 1), -c in 4-bit windows (both equations)
+#define PLUME_VDIG_SET PLUME_NPOS                    // sets A and C: the Eisenstein digits of one GLV pair, one row per position
+#define PLUME_VDIG_SETB (2 * PLUME_NPOS66)          // set B: s in the generator's wide digits (2 x 33 rows: long form) OR the two coefficient pairs of the short form (2 x 34)
+#define PLUME_VDIG_ROWS (2 * PLUME_VDIG_SET + PLUME_VDIG_SETB)
 static_assert(PLUME_VDIG_SETB >= 2 * PLUME_NDIG, "set B holds either form");
 // One crafted item (pk = +-k G with small k, s = +-c, ...) steers its accumulator into p == +-q inside an UNCHECKED addition.  Rounds 1-2 redid such a lane on the spot with
 // the checked additions -- and its 63 neighbours waited: one crafted item per wavefront doubled the kernel.  Now the lane only files its task; a second,
@@ -214,17 +203,14 @@ PLUME_HD uint32_t redo_file(uint32_t* redo, uint32_t task) {
     return k;
 }
 
-// the digit rows of one item (d = the item's column of the row-major digit array, n = its row pitch): sets A and C always, the long form's set B and set C4 when the item's
-// equation 1 runs in the long form (long_b)
+// the digit rows of one item (d = the item's column of the row-major digit array, n = its row pitch): set A = the Eisenstein digits of s = k1 + k2 lambda (equation 2's H),
+// set B = equation 1's own rows (below), set C = the digits of -c (equation 2's nullifier, and pk in equation 1's long form)
 PLUME_HD void verify_item_digits(int8_t* d, uint32_t n, const sc& s, const glv_half& c1, const glv_half& c2, bool long_b) {
     glv_half h1, h2;
     glv_split(h1, h2, s);
-    eisd8_store_glv(d, n, h1, h2, false);
-    if (long_b) {
-        booth_store_wide(d + (size_t)PLUME_VDIG_OFFB * n, n, h1, false); booth_store_wide(d + (size_t)(PLUME_VDIG_OFFB + PLUME_NDIG) * n, n, h2, false);
-        eisd_store_glv(d + (size_t)PLUME_VDIG_OFFC4 * n, n, c1, c2, true);
-    }
-    eisd8_store_glv(d + (size_t)PLUME_VDIG_OFFC * n, n, c1, c2, true);
+    eisd_store_glv(d, n, h1, h2, false);
+    if (long_b) { booth_store_wide(d + (size_t)PLUME_VDIG_SET * n, n, h1, false); booth_store_wide(d + (size_t)(PLUME_VDIG_SET + PLUME_NDIG) * n, n, h2, false); }
+    eisd_store_glv(d + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * n, n, c1, c2, true);
 }
 // The scalar stage: every digit row the multi-scalar kernel reads, once per item.  Short form of equation 1 (verify_eq1_short(a); plume_eis.h): (tau, upsilon) from the
 // half-GCD of c, k = tau s mod n for the comb, and set B = the Eisenstein digits of -upsilon (pk's joint slot) and of -(tau - 1) (R's).
@@ -244,7 +230,7 @@ PLUME_HD void verify_scalars(const VerifyArgs& a, uint32_t i) {
             sc k;
             sc_mul(k, e.tau, s);
             PLUME_UNROLL for (int w = 0; w < 8; w++) a.eq1k[(size_t)w * a.n + i] = k.v[w];
-            int8_t* b = a.digs + (size_t)PLUME_VDIG_OFFB * a.n + i;
+            int8_t* b = a.digs + (size_t)PLUME_VDIG_SET * a.n + i;
             (void)eisd_store<PLUME_NPOS66, 3>(b, a.n, e.u[0], e.uneg[0] != 0, e.u[1], e.uneg[1] != 0, true);                                   // - upsilon
             (void)eisd_store<PLUME_NPOS66, 3>(b + (size_t)PLUME_NPOS66 * a.n, a.n, e.t[0], e.tneg[0] != 0, e.t[1], e.tneg[1] != 0, true);      // - (tau - 1)
         }
@@ -365,18 +351,6 @@ PLUME_HD void verify_ingest_a3(const VerifyArgs& a, uint32_t i, const ingest_xch
     st_base(a.bases, 3 * (size_t)i + 1, h); a.jobflags[3 * (size_t)i + 1] = (uint8_t)(h.inf ? PLUME_JOB_INF : PLUME_JOB_OK);
 }
 
-// Rows 3..10 of one of the item's two base-8 tables (which 0: H, 1: the nullifier), by the lane about to use them (plume_ec.h tab8_build_job).  The rows go to HBM like any
-// table row -- the chain gathers them back by digit -- and the lane orders its own stores before its loads.
-struct DirectRowSink { PLUME_HD void operator()(uint32_t* e, const fe& x, const fe& y, const fe& bx) const { st_tab_entry(e, x, y, bx); } };
-PLUME_HD void verify_tab8(const VerifyArgs& a, uint32_t item, uint32_t which) {
-    const size_t job = 3 * (size_t)item + 1 + which, blk = 2 * (size_t)item + which;
-    tab8_build_job(a.tab8 + blk * (PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS), a.tab + job * PLUME_TAB_WORDS, a.ginv + blk * (2 * PLUME_FE_WORDS), DirectRowSink());
-}
-PLUME_HD void verify_tab8_fence() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __threadfence();                 // the lane's row stores are visible to its own later gathers (which go through the vector cache)
-#endif
-}
 // task t = 2*item + eq;  eq 0: s*G - c*pk, eq 1: s*H - c*nul.   dig: this lane's digit area (LDS), element stride.
 // CHECKED = false: the hot form; a task whose chain met p == +-q is filed in a.redo and stores nothing.  CHECKED = true: the redo launch's form.
 // FORM: which forms of equation 1 the instantiation carries -- 0: the long form only (calls whose equation 1 runs in the long form), 1: the short form only (the hot kernel of a short-form call:
@@ -391,7 +365,7 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
     } else if (FORM != 0 && eq == 0 && short_call && !a.eq1fall[item]) {
         // Equation 1, short form (plume_eis.h): k G - upsilon pk - (tau - 1) R, to be compared with R by the finalize stage.  Two joint slots, pk and R, thirty-four positions
         // (66 doublings at most; leading all-zero positions are skipped); then the generator's term from the doubling-free comb, fifteen additions.
-        const int8_t* db = a.digs + (size_t)PLUME_VDIG_OFFB * a.n + item;
+        const int8_t* db = a.digs + (size_t)PLUME_VDIG_SET * a.n + item;
         PLUME_UNROLL for (int r = 0; r < PLUME_VDIG_SETB; r++) dig[(uint32_t)r * stride] = db[(size_t)r * a.n];
         const size_t jp = 3 * (size_t)item, jr = 3 * (size_t)a.n + item;
         const uint32_t* tabp = job_state(a.jobflags[jp]) == PLUME_JOB_OK ? a.tab + jp * PLUME_TAB_WORDS : nullptr;
@@ -406,37 +380,25 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
         return;
     } else {
         if (FORM == 2 && !CHECKED && eq == 0 && short_call) { redo_file(a.redo, (uint32_t)t); return; }
-        // the rows the scalar stage left for this item, into the lane's digit area.  Equation 1 (long form): s in its wide digits for the generator's table (2 x 33 rows), then
-        // the base-4 digits of -c for pk's three-row table (65 rows).  Equation 2: the base-8 digits of s for H (44 rows), then those of -c for the nullifier (44 rows).
+        // the rows the scalar stage left for this item, into the lane's digit area: s first (equation 1: its wide digits for the generator's table, 2 x 33 rows; equation 2: its
+        // Eisenstein digits for H, 65 rows), then the Eisenstein digits of -c (pk / the nullifier)
+        const int8_t* dc = a.digs + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * a.n + item;
         if (eq == 0) {
-            const int8_t* ds = a.digs + (size_t)PLUME_VDIG_OFFB * a.n + item;
-            const int8_t* dc = a.digs + (size_t)PLUME_VDIG_OFFC4 * a.n + item;
+            const int8_t* ds = a.digs + (size_t)PLUME_VDIG_SET * a.n + item;
             PLUME_UNROLL for (int r = 0; r < 2 * PLUME_NDIG; r++) dig[(uint32_t)r * stride] = ds[(size_t)r * a.n];
             PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) dig[(uint32_t)(2 * PLUME_NDIG + r) * stride] = dc[(size_t)r * a.n];
-            const size_t jb = 3 * (size_t)item;
-            const uint32_t* tab1 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
-            if (CHECKED) {
-                msm_run_checked(acc, gtab, tab1, dig, stride, true);
-            } else if (!msm_run_unchecked(acc, gtab, tab1, dig, stride, true)) {
-                redo_file(a.redo, (uint32_t)t);
-                return;
-            }
         } else {
             const int8_t* ds = a.digs + item;
-            const int8_t* dc = a.digs + (size_t)PLUME_VDIG_OFFC * a.n + item;
-            PLUME_UNROLL for (int r = 0; r < PLUME_NPOS8; r++) { dig[(uint32_t)r * stride] = ds[(size_t)r * a.n]; dig[(uint32_t)(PLUME_NPOS8 + r) * stride] = dc[(size_t)r * a.n]; }
-            const size_t ja = 3 * (size_t)item + 1, jb = 3 * (size_t)item + 2;
-            const uint32_t* h3 = job_state(a.jobflags[ja]) == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr;
-            const uint32_t* n3 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
-            const uint32_t* h8 = a.tab8 + (2 * (size_t)item) * (PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS);
-            const uint32_t* n8 = h8 + PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS;
-            if (!CHECKED) { PLUME_NOUNROLL for (uint32_t w = 0; w < 2; w++) verify_tab8(a, item, w); verify_tab8_fence(); }      // (the redo launch finds the rows its task's first lane built)
-            if (CHECKED) {
-                msm8_run_checked(acc, h3, h8, n3, n8, dig, stride);
-            } else if (!msm8_run_unchecked(acc, h3, h8, n3, n8, dig, stride)) {
-                redo_file(a.redo, (uint32_t)t);
-                return;
-            }
+            PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) { dig[(uint32_t)r * stride] = ds[(size_t)r * a.n]; dig[(uint32_t)(PLUME_NPOS + r) * stride] = dc[(size_t)r * a.n]; }
+        }
+        const size_t ja = 3 * (size_t)item + 1, jb = 3 * (size_t)item + (eq ? 2 : 0);
+        const uint32_t* tab0 = eq ? (job_state(a.jobflags[ja]) == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr) : gtab;
+        const uint32_t* tab1 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
+        if (CHECKED) {
+            msm_run_checked(acc, tab0, tab1, dig, stride, eq == 0);
+        } else if (!msm_run_unchecked(acc, tab0, tab1, dig, stride, eq == 0)) {
+            redo_file(a.redo, (uint32_t)t);
+            return;
         }
     }
     st_jac_soa(a.res, nt, t, acc);
@@ -452,28 +414,20 @@ PLUME_HD void verify_msm(const VerifyArgs& a, uint32_t item, uint32_t eq, const 
 PLUME_HD bool verify_msm_half(const VerifyArgs& a, uint32_t item, uint32_t eq, uint32_t half, const uint32_t* gtab, int8_t* dig, uint32_t stride, jac& acc) {
     acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
     if (a.itemflags[item]) return true;
-    if (eq == 0) {       // rows as verify_msm lays them out: s's wide digits first, then the base-4 digits of -c
-        if (half == 0) {
-            const int8_t* ds = a.digs + (size_t)PLUME_VDIG_OFFB * a.n + item;
-            PLUME_UNROLL for (int r = 0; r < 2 * PLUME_NDIG; r++) dig[(uint32_t)r * stride] = ds[(size_t)r * a.n];
-        } else {
-            const int8_t* dc = a.digs + (size_t)PLUME_VDIG_OFFC4 * a.n + item;
-            PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) dig[(uint32_t)(2 * PLUME_NDIG + r) * stride] = dc[(size_t)r * a.n];
-        }
-        const size_t jb = 3 * (size_t)item;
-        const uint32_t* tab1 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
-        return msm_run_unchecked(acc, half == 0 ? gtab : nullptr, half == 1 ? tab1 : nullptr, dig, stride, true);
+    const int8_t* dc = a.digs + (size_t)(PLUME_VDIG_SET + PLUME_VDIG_SETB) * a.n + item;
+    if (eq == 0) {       // rows as verify_msm lays them out: s's wide digits first, then the digits of -c
+        const int8_t* ds = a.digs + (size_t)PLUME_VDIG_SET * a.n + item;
+        if (half == 0) { PLUME_UNROLL for (int r = 0; r < 2 * PLUME_NDIG; r++) dig[(uint32_t)r * stride] = ds[(size_t)r * a.n]; }
+        else { PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) dig[(uint32_t)(2 * PLUME_NDIG + r) * stride] = dc[(size_t)r * a.n]; }
+    } else {
+        const int8_t* ds = a.digs + item;
+        if (half == 0) { PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) dig[(uint32_t)r * stride] = ds[(size_t)r * a.n]; }
+        else { PLUME_UNROLL for (int r = 0; r < PLUME_NPOS; r++) dig[(uint32_t)(PLUME_NPOS + r) * stride] = dc[(size_t)r * a.n]; }
     }
-    // equation 2: H's slot (base-8 digits of s) on half 0, the nullifier's (base-8 digits of -c) on half 1
-    const int8_t* ds = half == 0 ? a.digs + item : a.digs + (size_t)PLUME_VDIG_OFFC * a.n + item;
-    PLUME_UNROLL for (int r = 0; r < PLUME_NPOS8; r++) dig[(uint32_t)(half * PLUME_NPOS8 + r) * stride] = ds[(size_t)r * a.n];
-    const size_t ja = 3 * (size_t)item + 1, jb = 3 * (size_t)item + 2;
-    const uint32_t* h3 = job_state(a.jobflags[ja]) == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr;
-    const uint32_t* n3 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
-    const uint32_t* h8 = a.tab8 + (2 * (size_t)item) * (PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS);
-    const uint32_t* n8 = h8 + PLUME_TAB8_ROWS * PLUME_TAB_ENTRY_WORDS;
-    verify_tab8(a, item, half); verify_tab8_fence();           // each half builds the rows 3..10 of its own slot's table
-    return msm8_run_unchecked(acc, half == 0 ? h3 : nullptr, h8, half == 1 ? n3 : nullptr, n8, dig, stride);
+    const size_t ja = 3 * (size_t)item + 1, jb = 3 * (size_t)item + (eq ? 2 : 0);
+    const uint32_t* tab0 = eq ? (job_state(a.jobflags[ja]) == PLUME_JOB_OK ? a.tab + ja * PLUME_TAB_WORDS : nullptr) : gtab;
+    const uint32_t* tab1 = job_state(a.jobflags[jb]) == PLUME_JOB_OK ? a.tab + jb * PLUME_TAB_WORDS : nullptr;
+    return msm_run_unchecked(acc, half == 0 ? tab0 : nullptr, half == 1 ? tab1 : nullptr, dig, stride, eq == 0);
 }
 // the join, by half 0's lane: acc0 += acc1 with the checked Jacobian addition (the two halves may well meet in p == +-q: a valid equation 2 whose halves are H-multiples)
 PLUME_HD void verify_msm_join(const VerifyArgs& a, uint32_t item, uint32_t eq, jac& acc0, bool ok0, const jac& acc1, bool ok1) {
