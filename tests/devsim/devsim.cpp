@@ -443,8 +443,8 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     if (version != 1 && version != 2) return -1;
     // (the signer reads the comb only)
     const std::vector<uint32_t>& gcomb = shared_gcomb();
-    std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_BASE_WORDS * 2 * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab(2 * (size_t)n * PLUME_TAB_WORDS);
-    std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(2 * (size_t)n), itemflags(n);
+    std::vector<uint32_t> gres(PLUME_JAC_WORDS * 2 * (size_t)n), hres(PLUME_JAC_WORDS * 2 * (size_t)n), bases(PLUME_BASE_WORDS * PLUME_SIGN_K * (size_t)n), pkaff(2 * PLUME_FE_WORDS * (size_t)n), tab(PLUME_SIGN_K * (size_t)n * PLUME_TAB_WORDS);
+    std::vector<uint8_t> gresinf(2 * (size_t)n), hresinf(2 * (size_t)n), jobflags(PLUME_SIGN_K * (size_t)n), itemflags(n);
     SignArgs a; memset(&a, 0, sizeof a);
     a.version = version; a.n = n; a.msgs = msgs; a.msg_off = msg_off; a.msgs_bytes = msg_off[n]; a.sk = sk; a.r = r; a.pk_in = pk_in;
     a.pk = pk; a.nul = nul; a.c = c; a.s = s; a.rpt = rpt; a.hr = hr; a.status = status; a.h_out = h_out;
@@ -459,7 +459,7 @@ int ds_sign_batch(int version, uint32_t n, const uint8_t* msgs, const uint64_t* 
     }
     for (uint32_t i = 0; i < n; i++) sign_h2c(a, i);
     for (uint32_t i = 0; i < n; i++) sign_hdbl(a, i);
-    run_tables(a.tab, a.bases, a.jobflags, 2 * (size_t)n, L);
+    run_tables(a.tab, a.bases, a.jobflags, PLUME_SIGN_K * (size_t)n, L);
     for (uint32_t w = 0; w < 2; w++)
         for (uint32_t i = 0; i < n; i++) {
             int8_t* dg = dig.data() + (i % B);
@@ -636,7 +636,8 @@ int ds_point_mul(const uint8_t k_be[32], const uint8_t p_be[64], uint8_t out[64]
     glv_half h1, h2; glv_split(h1, h2, k);
     std::vector<int8_t> dig(2 * PLUME_NPOS);
     eisd_store_glv(dig.data(), 1, h1, h2, false);
-    jac acc; msm_run(acc, tab.data(), nullptr, dig.data(), 1);
+    jac acc;
+    if (!msm_run_unchecked(acc, tab.data(), nullptr, dig.data(), 1)) msm_run_checked(acc, tab.data(), nullptr, dig.data(), 1);
     fe ox = fe_zero(), oy = fe_zero();
     if (!acc.inf) { fe zi, zi2; fe_inv(zi, acc.z); fe_sqr(zi2, zi); fe_mul(ox, acc.x, zi2); fe_mul(zi2, zi2, zi); fe_mul(oy, acc.y, zi2); }
     store_affine_be(ob, ox, oy, acc.inf != 0);

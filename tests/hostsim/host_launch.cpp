@@ -145,7 +145,7 @@ void launch_sign_hdbl(const SignArgs& a0, hipStream_t st) {
 }
 void launch_sign_hmul(const SignArgs& a0, hipStream_t st) {
     mockhip::launch(st, [a = a0] {
-        std::vector<int8_t> s_dig((size_t)2 * PLUME_NPOS64 * kBlock);
+        std::vector<int8_t> s_dig((size_t)PLUME_SIGN_K * PLUME_NPOSK * kBlock);
         const uint32_t nb = nblocks(a.n);
         grid(2 * nb, kBlock, [&](unsigned b, unsigned t) {
             int8_t* dg = s_dig.data() + t;

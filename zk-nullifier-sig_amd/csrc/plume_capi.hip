@@ -826,9 +826,9 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
     const size_t nsub = cut.size() - 1;
     const bool overlapped = nsub > 1;
     size_t scr_bytes = 0;
-    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, 2 * (cut[k + 1] - cut[k]), 0));
-    // two table jobs per item: H and 2^64 H (the signer's chains are 64 doublings long)
-    if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * 2 * n) || ctx->jobflags.ensure(2 * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * 2 * n) ||
+    constexpr size_t SK = PLUME_SIGN_K;                                          // table jobs per item: H and its shifted copies 2^(j PLUME_SIGN_BITS) H (the signer's chains are PLUME_SIGN_BITS doublings long)
+    for (size_t k = 0; k < nsub; k++) scr_bytes = std::max(scr_bytes, table_stage_scratch(ctx, SK * (cut[k + 1] - cut[k]), 0));
+    if (ctx->bases.ensure((size_t)PLUME_BASE_WORDS * 4 * SK * n) || ctx->jobflags.ensure(SK * n) || ctx->itemflags.ensure(n) || ctx->tab.ensure((size_t)PLUME_TAB_WORDS * 4 * SK * n) ||
         ctx->tabscr.ensure(scr_bytes) ||
         ctx->res.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->resinf.ensure(2 * n) || ctx->res2.ensure((size_t)PLUME_JAC_WORDS * 4 * 2 * n) || ctx->res2inf.ensure(2 * n) || ctx->pkaff.ensure((size_t)2 * PLUME_FE_WORDS * 4 * n))
         return PLUME_ERR_HIP;
@@ -847,15 +847,15 @@ static int sign_device(plume_ctx* ctx, int version, size_t n, const uint8_t* msg
         a.version = version; a.n = (uint32_t)cnt; a.msgs = msgs; a.msg_off = msg_off + lo; a.msgs_bytes = msgs_bytes; a.sk = sk + 32 * lo; a.r = r + 32 * lo; a.pk_in = pk_in ? pk_in + 64 * lo : nullptr;
         a.pk = pk ? pk + P * lo : nullptr; a.nul = nul + P * lo; a.c = c + 32 * lo; a.s = s + 32 * lo; a.rpt = rpt + P * lo; a.hr = hr + P * lo; a.status = status + lo;
         a.h_out = h_out ? h_out + 64 * lo : nullptr; a.out33 = out33 ? 1 : 0;
-        a.gres = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.gresinf = ctx->resinf.as<uint8_t>() + 2 * lo; a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * 2 * lo;
-        a.jobflags = ctx->jobflags.as<uint8_t>() + 2 * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo; a.pkaff = ctx->pkaff.as<uint32_t>() + (size_t)2 * PLUME_FE_WORDS * lo;
-        a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * 2 * lo; a.hres = ctx->res2.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.hresinf = ctx->res2inf.as<uint8_t>() + 2 * lo;
+        a.gres = ctx->res.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.gresinf = ctx->resinf.as<uint8_t>() + 2 * lo; a.bases = ctx->bases.as<uint32_t>() + (size_t)PLUME_BASE_WORDS * SK * lo;
+        a.jobflags = ctx->jobflags.as<uint8_t>() + SK * lo; a.itemflags = ctx->itemflags.as<uint8_t>() + lo; a.pkaff = ctx->pkaff.as<uint32_t>() + (size_t)2 * PLUME_FE_WORDS * lo;
+        a.tab = ctx->tab.as<uint32_t>() + (size_t)PLUME_TAB_WORDS * SK * lo; a.hres = ctx->res2.as<uint32_t>() + (size_t)PLUME_JAC_WORDS * 2 * lo; a.hresinf = ctx->res2inf.as<uint8_t>() + 2 * lo;
         a.gcomb = ctx->fixed->gcomb.as<uint32_t>(); a.gscan = ctx->fixed->gscan.as<uint32_t>(); a.uniform = ctx->sign_uniform;
         launch_sign_gmul(a, pre); if (!overlapped) t.stage("sign_gmul", st);
         launch_normalize(a.gres, a.gresinf, 2 * cnt, pre); if (!overlapped) t.stage("to_affine_g", st);
         launch_sign_h2c(a, pre); if (!overlapped) t.stage("sign_h2c", st);
         launch_sign_hdbl(a, pre); if (!overlapped) t.stage("sign_hdbl", st);
-        table_stage(ctx, a.tab, a.bases, a.jobflags, 2 * cnt, 0, pre); if (!overlapped) t.stage("tables", st);
+        table_stage(ctx, a.tab, a.bases, a.jobflags, SK * cnt, 0, pre); if (!overlapped) t.stage("tables", st);
         if (overlapped) {
             HIPCHK(hipEventRecord(ctx->pre_ready[k], pre));
             HIPCHK(hipStreamWaitEvent(st, ctx->pre_ready[k], 0));

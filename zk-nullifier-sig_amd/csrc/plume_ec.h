@@ -42,6 +42,8 @@ PLUME_HD fe fe_off_c128_x() { return fe_set(0x8141C548u, 0xF0861E56u, 0xAE562CEC
 PLUME_HD fe fe_off_c128_y() { return fe_set(0xE429892Au, 0x9AB04F55u, 0xF3E86FE7u, 0xE225348Fu, 0xEF934040u, 0xDC585E87u, 0x1A3CC5BEu, 0x78194203u); }
 PLUME_HD fe fe_off_c64_x() { return fe_set(0x8C789E12u, 0x56849B1Eu, 0x66BB27D0u, 0x5BE6CDC5u, 0x043289AFu, 0xB56465A3u, 0xAF7D81E9u, 0xD0746A2Fu); }   // -(2^64 B): the signer's half-length chains
 PLUME_HD fe fe_off_c64_y() { return fe_set(0x951FAD83u, 0x6890A4BDu, 0x269416A6u, 0x5C972C30u, 0x9B5A23BDu, 0x5CBF67BDu, 0xB62C3867u, 0x3DBFF40Bu); }
+PLUME_HD fe fe_off_c32_x() { return fe_set(0x04C05939u, 0x040E182Au, 0x8B808086u, 0x5E66F4DEu, 0x60F9C236u, 0xEB2BF058u, 0x0469B3DAu, 0x11F0FCAEu); }   // -(2^32 B): the signer's chains of 32 doublings (round 6)
+PLUME_HD fe fe_off_c32_y() { return fe_set(0xF36744C1u, 0x473D51FAu, 0xF40D619Fu, 0xD4E1CF06u, 0xD5A12294u, 0x8CC33203u, 0x9C1D0738u, 0xDC827F44u); }
 PLUME_HD fe fe_off_neg_y() { return fe_set(0xEA51A88Cu, 0xE0506DCCu, 0x0FE9473Cu, 0x7B29D802u, 0x73083AFFu, 0xDD15495Eu, 0xD83C6AB3u, 0x75FE0F2Bu); }    // -B = (x(B), this)
 
 // y^2 == x^3 + 7 (curves/mod.rs:36-39)
@@ -325,6 +327,17 @@ PLUME_HD void booth_store_wide(int8_t* dig, uint32_t stride, const glv_half& h, 
 #define PLUME_NPOS 65        // pairs of 128-bit halves (the verifier)
 #define PLUME_NPOS64 33      // pairs of 64-bit quarters (the signer's chains of 64 doublings)
 #define PLUME_NPOS66 34      // pairs below 2^66 (the verifier's short first equation, plume_eis.h)
+// The signer's multiplications by H: each 128-bit GLV half is cut into PLUME_SIGN_K pieces of 128 / K bits, piece j on the table of 2^(128 j / K) H -- K joint slots along ONE
+// chain of 128 / K doublings, after 128 (K - 1) / K doublings spent once per item on the shifted bases, which serve both of its multiplications (sk H and r H).  Per item:
+// K = 1: 256 doublings; K = 2 (round 4, the default): 64 + 2 x 64 = 192; K = 4: 96 + 2 x 32 = 160 for two more three-row tables and 2 x 4 x 17 instead of 2 x 2 x 33 positions
+// -- built and measured in round 6 (profiles/r06_sign_cut32.txt, same box, uniform level 1): k_sign_hmul 9.33 -> 8.31 ms, but k_sign_hdbl 1.57 -> 2.43 and the table stage
+// 0.45 -> 0.83: a 2^20 sign 16.11 -> 16.49 ms (+2.4 %).  The doublings saved in the chains come back in the shifted bases and the tables: K stays 2.
+#ifndef PLUME_SIGN_K
+#define PLUME_SIGN_K 2
+#endif
+#define PLUME_SIGN_BITS (128 / PLUME_SIGN_K)                  // bits per piece = doublings per hop between the shifted bases = doublings of the chain
+#define PLUME_NPOSK (PLUME_SIGN_BITS / 2 + 1)                 // positions of a pair of pieces: 17 for K = 4, 33 for K = 2
+static_assert(PLUME_SIGN_K == 2 || PLUME_SIGN_K == 4, "pieces of 64 or 32 bits (whole words of the GLV halves)");
 PLUME_HD uint32_t eisd_entry_table(int ta, int tb) {
     // entry = code | (d0 + 2) << 5 | (d1 + 2) << 8 for t = (ta, tb), |ta|, |tb| <= 4; generated (and its invariants checked) by tests/test_devsim.py::test_eisenstein_digit_table
     static const uint16_t T[64] = {0x240, 0x343, 0x44F, 0x144, 0x261, 0x366, 0x469, 0x167, 0x28D, 0x38C, 0x492, 0x10B, 0x222, 0x328, 0x02A, 0x125,
@@ -906,27 +919,49 @@ PLUME_HD void msm_add_uniform(jac& acc, const uint32_t* tab, int code) {
     fe_cmov(qx, t, j == 2u);
     jac_madd_uniform<CHECKED>(acc, qx, y, zero ? 0 : ((u & 1u) ? -1 : 1));
 }
-// The chain with the UNIFORM schedule (the signer, levels 1 and 2): no position is skipped and no branch depends on a digit.  `live` false (the table's base was the
-// identity / invalid: a public fact) turns every digit into 0.  Starts at the offset point B; the caller takes 4^(NP - 1) B off again.
-template <bool CHECKED, int NP, bool SCAN>
-PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab0, const uint32_t* tab1, bool live, const int8_t* dig, uint32_t stride) {
+// The signer's chains: K joint slots -- slot j's table at tab + j * tstride words, its digit rows [j NP, (j + 1) NP) -- along NP positions of two doublings.  One addition body
+// in the loop (the slots are walked by a rolled inner loop).
+template <bool CHECKED, int NP, int K>
+PLUME_HD void msm_runk_impl(jac& acc, const uint32_t* tab, size_t tstride, const int8_t* dig, uint32_t stride) {
+    acc.x = fe_small(1); acc.y = fe_small(1); acc.z = fe_small(0); acc.inf = 1;
+    PLUME_NOUNROLL for (int p = NP - 1; p >= 0; p--) {
+        if (p != NP - 1 && !msm_all_inf(acc)) { jac_dbl_neg(acc); jac_dbl_neg(acc); }
+        PLUME_NOUNROLL for (uint32_t j = 0; j < (uint32_t)K; j++) {
+            const int c = tab ? dig[(j * (uint32_t)NP + (uint32_t)p) * stride] : 0;
+            if (c != 0) { fe qx, qy; ld_tab_unit(qx, qy, tab + j * tstride, c); jac_madd<CHECKED>(acc, qx, qy); }
+        }
+    }
+}
+template <int NP, int K>
+PLUME_HD void msm_runk(jac& acc, const uint32_t* tab, size_t tstride, const int8_t* dig, uint32_t stride) {
+    msm_runk_impl<false, NP, K>(acc, tab, tstride, dig, stride);
+    if (!acc.inf && fe_is_zero(acc.z)) {                        // met p == +-q inside an unchecked addition (Z = 0 mod p forever after, see jac_madd): redo that lane
+        PLUME_COUNT_FALLBACK();
+        msm_runk_impl<true, NP, K>(acc, tab, tstride, dig, stride);
+    }
+}
+// The same chain with the UNIFORM schedule (the signer, levels 1 and 2): no position is skipped and no branch depends on a digit.  `live` false (the table's base was the
+// identity / invalid: a public fact) turns every digit into 0.  Starts at the offset point B; 4^(NP - 1) B comes off again at the end.
+template <bool CHECKED, int NP, bool SCAN, int K>
+PLUME_HD void msm_run_uniform_impl(jac& acc, const uint32_t* tab, size_t tstride, bool live, const int8_t* dig, uint32_t stride) {
     acc.x = fe_off_x(); acc.y = fe_off_y(); acc.z = fe_small(1); acc.inf = 0;
     PLUME_NOUNROLL for (int p = NP - 1; p >= 0; p--) {
         if (p != NP - 1) { jac_dbl_neg(acc); jac_dbl_neg(acc); }
-        const int c0 = live ? dig[(uint32_t)p * stride] : 0, c1 = live ? dig[((uint32_t)NP + (uint32_t)p) * stride] : 0;
-        msm_add_uniform<CHECKED, SCAN>(acc, tab0, c0);
-        msm_add_uniform<CHECKED, SCAN>(acc, tab1, c1);
+        PLUME_NOUNROLL for (uint32_t j = 0; j < (uint32_t)K; j++) {
+            const int c = live ? dig[(j * (uint32_t)NP + (uint32_t)p) * stride] : 0;
+            msm_add_uniform<CHECKED, SCAN>(acc, tab + j * tstride, c);
+        }
     }
 }
-static_assert(2 * (PLUME_NPOS - 1) == 128 && 2 * (PLUME_NPOS64 - 1) == 64, "the uniform chains' offset constants are -(2^128 B) and -(2^64 B)");
-template <int NP, bool SCAN = false>
-PLUME_HD void msm_run_uniform(jac& acc, const uint32_t* tab0, const uint32_t* tab1, bool live, const int8_t* dig, uint32_t stride) {
-    msm_run_uniform_impl<false, NP, SCAN>(acc, tab0, tab1, live, dig, stride);
+static_assert(2 * (PLUME_NPOS - 1) == 128 && 2 * (PLUME_NPOS64 - 1) == 64 && (PLUME_NPOSK == PLUME_NPOS64 || 2 * (PLUME_NPOSK - 1) == 32), "the uniform chains' offset constants are -(2^128 B), -(2^64 B), -(2^32 B)");
+template <int NP, bool SCAN, int K>
+PLUME_HD void msm_run_uniform(jac& acc, const uint32_t* tab, size_t tstride, bool live, const int8_t* dig, uint32_t stride) {
+    msm_run_uniform_impl<false, NP, SCAN, K>(acc, tab, tstride, live, dig, stride);
     if (fe_is_zero(acc.z)) {
         PLUME_COUNT_FALLBACK();
-        msm_run_uniform_impl<true, NP, SCAN>(acc, tab0, tab1, live, dig, stride);
+        msm_run_uniform_impl<true, NP, SCAN, K>(acc, tab, tstride, live, dig, stride);
     }
-    const fe cx = NP == PLUME_NPOS64 ? fe_off_c64_x() : fe_off_c128_x(), cy = NP == PLUME_NPOS64 ? fe_off_c64_y() : fe_off_c128_y();     // - 4^(NP - 1) B
+    const fe cx = NP == 17 ? fe_off_c32_x() : NP == PLUME_NPOS64 ? fe_off_c64_x() : fe_off_c128_x(), cy = NP == 17 ? fe_off_c32_y() : NP == PLUME_NPOS64 ? fe_off_c64_y() : fe_off_c128_y();     // - 4^(NP - 1) B
     if (!acc.inf) jac_madd<true>(acc, cx, cy);
     else { acc.x = cx; acc.y = cy; acc.z = fe_small(1); acc.inf = 0; }              // (acc.inf: only after a checked redo that hit the identity)
 }
@@ -940,14 +975,4 @@ PLUME_HD bool msm_run_unchecked(jac& acc, const uint32_t* tab0, const uint32_t* 
     msm_run_impl<false>(acc, tab0, tab1, dig, stride, wide0);
     return acc.inf || !fe_is_zero(acc.z);
 }
-template <int NP = PLUME_NPOS>
-PLUME_HD void msm_run(jac& acc, const uint32_t* tab0, const uint32_t* tab1, const int8_t* dig, uint32_t stride, bool wide0 = false) {
-    msm_run_impl<false, NP>(acc, tab0, tab1, dig, stride, wide0);
-    // an accumulator that met p == +-q inside an unchecked addition has Z = 0 (mod p) forever after (see jac_madd): redo that lane
-    if (!acc.inf && fe_is_zero(acc.z)) {
-        PLUME_COUNT_FALLBACK();
-        msm_run_impl<true, NP>(acc, tab0, tab1, dig, stride, wide0);
-    }
-}
-
 }  // namespace plume

@@ -277,32 +277,32 @@ __global__ PLUME_H2C_BOUNDS void k_sign_h2c(SignArgs a) {
     if (i < a.n) sign_h2c(a, i);
 }
 
-// 2^64 H of every item (plume_stages.h sign_hdbl): 64 doublings, once per item, so that the item's two multiplications by H run along chains of half the length
+// the shifted bases 2^(j PLUME_SIGN_BITS) H of every item (plume_stages.h sign_hdbl), once per item, so that the item's two multiplications by H run along chains of PLUME_SIGN_BITS doublings
 __global__ PLUME_MSM_BOUNDS void k_sign_hdbl(SignArgs a) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < a.n) sign_hdbl(a, i);
 }
 
 __global__ PLUME_MSM_BOUNDS void k_sign_hmul(SignArgs a) {
-    __shared__ int8_t s_dig[2 * PLUME_NPOS64 * kBlock];
+    __shared__ int8_t s_dig[PLUME_SIGN_K * PLUME_NPOSK * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     const uint32_t which = blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
     if (i < a.n) sign_hmul(a, i, which, s_dig + threadIdx.x, kBlock);
-    wipe_digits<2 * PLUME_NPOS64>(s_dig);   // the rows are digits of sk and r: nothing derived from a secret stays in LDS when the workgroup retires
+    wipe_digits<PLUME_SIGN_K * PLUME_NPOSK>(s_dig);   // the rows are digits of sk and r: nothing derived from a secret stays in LDS when the workgroup retires
 }
 
 // the uniform-schedule forms of the two kernels that walk secret digits (plume_set_sign_uniform; LEVEL 1: no branch on a digit, LEVEL 2: no address from a digit
 // either): same grids, same outputs
 template <int LEVEL>
 __global__ PLUME_MSM_BOUNDS void k_sign_hmul_uniform(SignArgs a) {
-    __shared__ int8_t s_dig[2 * PLUME_NPOS64 * kBlock];
+    __shared__ int8_t s_dig[PLUME_SIGN_K * PLUME_NPOSK * kBlock];
     const uint32_t nb = (a.n + kBlock - 1) / kBlock;
     // level 2: the two tasks of an item (sk * H, r * H: the same two tables, every row of them read at every window) sit in ADJACENT lanes, so one fetch serves both
     const uint32_t which = LEVEL == 2 ? (threadIdx.x & 1u) : blockIdx.x >= nb ? 1u : 0u;
     const uint32_t i = LEVEL == 2 ? (blockIdx.x * kBlock + threadIdx.x) >> 1 : (which ? blockIdx.x - nb : blockIdx.x) * kBlock + threadIdx.x;
     if (i < a.n) sign_hmul<LEVEL>(a, i, which, s_dig + threadIdx.x, kBlock);
-    wipe_digits<2 * PLUME_NPOS64>(s_dig);
+    wipe_digits<PLUME_SIGN_K * PLUME_NPOSK>(s_dig);
 }
 template <int LEVEL>
 __global__ PLUME_MSM_BOUNDS void k_sign_gmul_uniform(SignArgs a) {

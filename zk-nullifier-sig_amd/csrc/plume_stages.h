@@ -559,10 +559,10 @@ struct SignArgs {
     int out33;              // 0: pk, nul, rpt, hr are 64-byte affine records; 1: 33-byte SEC1-compressed records (stride 33)
     // scratch
     uint32_t* gres;  uint8_t* gresinf;   // 2n tasks: sk*G, r*G (Jacobian SoA)
-    uint32_t* bases; uint8_t* jobflags;  // 2n jobs: H of item i at i, 2^64 H at n + i (round 4: the signer's chains are 64 doublings long, sign_hdbl)
+    uint32_t* bases; uint8_t* jobflags;  // PLUME_SIGN_K n jobs: H of item i at i, 2^(j PLUME_SIGN_BITS) H at j n + i (the signer's chains are PLUME_SIGN_BITS doublings long, sign_hdbl)
     uint8_t* itemflags;                  // n: status bits accumulated across stages
     uint32_t* pkaff;                     // 2 * PLUME_FE_WORDS x n words SoA: affine pk (x, y), canonical, for the final stage
-    uint32_t* tab;                       // 2n tables, same order
+    uint32_t* tab;                       // PLUME_SIGN_K n tables, same order
     uint32_t* hres;  uint8_t* hresinf;   // 2n tasks: sk*H, r*H
     const uint32_t* gcomb;               // fixed-base comb of G (PLUME_COMB_WORDS)
     const uint32_t* gscan;               // level 2 only: the small scanned table of G (PLUME_GSCAN_WORDS)
@@ -576,10 +576,10 @@ PLUME_HD uint32_t load_scalar_reduced(sc& k, const uint8_t* p) {
     sc_cond_sub_n(k);
     return ok ? 0u : PLUME_ST_BAD_SCALAR;
 }
-// task t = 2*item + which: which 0 -> sk, 1 -> r;  result = k * (table tab0)
-// k * H with the tables of H (tab0) and 2^64 H (tab1): k = k1 + k2 lambda (GLV), each 128-bit half = lo + hi 2^64 -- four 64-bit quarters on H, lambda H, 2^64 H,
-// lambda 2^64 H, one chain of 64 doublings (round 4; rounds 1-3: two halves, 128 doublings.  The 64 doublings that make 2^64 H are spent ONCE per item and serve both of
-// its multiplications, sk * H and r * H: sign_hdbl).
+// task t = 2*item + which: which 0 -> sk, 1 -> r;  result = k * H.
+// k = k1 + k2 lambda (GLV), each 128-bit half cut into PLUME_SIGN_K pieces of PLUME_SIGN_BITS bits: piece j of the pair on the table of 2^(j PLUME_SIGN_BITS) H (job j n + item)
+// -- K joint slots along one chain of PLUME_SIGN_BITS doublings (plume_ec.h; K = 2 in rounds 4-5, K = 4 since round 6.  The doublings that make the shifted bases are spent
+// ONCE per item and serve both of its multiplications, sk * H and r * H: sign_hdbl).
 template <int UNIFORM = 0>
 PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, bool live, uint32_t* res, uint8_t* resinf, int8_t* dig, uint32_t stride) {
     const size_t nt = 2 * (size_t)a.n, t = 2 * (size_t)item + which;
@@ -587,33 +587,34 @@ PLUME_HD void sign_mul(const SignArgs& a, uint32_t item, uint32_t which, bool li
     (void)load_scalar_reduced(k, (which ? a.r : a.sk) + 32 * (size_t)item);
     glv_half h1, h2;
     glv_split(h1, h2, k);
-    {   // k = (k1lo + k2lo lambda) + 2^64 (k1hi + k2hi lambda): the Eisenstein digits of the low pair for H's table, of the high pair for 2^64 H's
-        const uint32_t lo1[2] = {h1.m[0], h1.m[1]}, lo2[2] = {h2.m[0], h2.m[1]}, hi1[2] = {h1.m[2], h1.m[3]}, hi2[2] = {h2.m[2], h2.m[3]};
-        (void)eisd_store<PLUME_NPOS64, 2>(dig, stride, lo1, h1.neg != 0, lo2, h2.neg != 0, false);
-        (void)eisd_store<PLUME_NPOS64, 2>(dig + PLUME_NPOS64 * stride, stride, hi1, h1.neg != 0, hi2, h2.neg != 0, false);
+    constexpr int WPP = PLUME_SIGN_BITS / 32;                                           // words per piece
+    PLUME_UNROLL for (int j = 0; j < PLUME_SIGN_K; j++) {                              // the Eisenstein digits of piece j's pair, for the table of 2^(j PLUME_SIGN_BITS) H
+        uint32_t p1[WPP], p2[WPP];
+        PLUME_UNROLL for (int w = 0; w < WPP; w++) { p1[w] = h1.m[j * WPP + w]; p2[w] = h2.m[j * WPP + w]; }
+        (void)eisd_store<PLUME_NPOSK, WPP>(dig + (uint32_t)(j * PLUME_NPOSK) * stride, stride, p1, h1.neg != 0, p2, h2.neg != 0, false);
     }
     const uint32_t* t0 = a.tab + (size_t)item * PLUME_TAB_WORDS;                      // (every job has a table: a dummy one when its base was no usable point)
-    const uint32_t* t1 = a.tab + ((size_t)a.n + item) * PLUME_TAB_WORDS;
+    const size_t ts = (size_t)a.n * PLUME_TAB_WORDS;                                  // job j n + item: the next shifted base's table
     jac acc;
-    if (UNIFORM == 2) msm_run_uniform<PLUME_NPOS64, true>(acc, t0, t1, live, dig, stride);
-    else if (UNIFORM == 1) msm_run_uniform<PLUME_NPOS64>(acc, t0, t1, live, dig, stride);
-    else msm_run<PLUME_NPOS64>(acc, live ? t0 : nullptr, live ? t1 : nullptr, dig, stride, false);
+    if (UNIFORM == 2) msm_run_uniform<PLUME_NPOSK, true, PLUME_SIGN_K>(acc, t0, ts, live, dig, stride);
+    else if (UNIFORM == 1) msm_run_uniform<PLUME_NPOSK, false, PLUME_SIGN_K>(acc, t0, ts, live, dig, stride);
+    else msm_runk<PLUME_NPOSK, PLUME_SIGN_K>(acc, live ? t0 : nullptr, ts, dig, stride);
     st_jac_soa(res, nt, t, acc);
     resinf[t] = (uint8_t)acc.inf;
 }
-// 2^64 H of item i next to H (job n + i): 64 doublings of the Jacobian H, once per item.  A job whose H is no usable point (identity: a status bit, randomizedsigner.rs:61)
-// gets G under the same flag, like every other placeholder base.
+// The shifted bases of item i next to H (job i): 2^(j PLUME_SIGN_BITS) H at job j n + i, j = 1 .. K - 1 -- PLUME_SIGN_BITS doublings of the Jacobian point per hop, once per
+// item.  A job whose H is no usable point (identity: a status bit, randomizedsigner.rs:61) gets G under the same flag, like every other placeholder base.
 PLUME_HD void sign_hdbl(const SignArgs& a, uint32_t i) {
     const uint8_t f = a.jobflags[i];
     jac h;
-    if (job_state(f) == PLUME_JOB_OK) {
-        ld_base(h, a.bases, i, true); h.inf = 0;
-        PLUME_NOUNROLL for (int d = 0; d < 64; d++) jac_dbl_neg(h);               // an even number of sign-flipping doublings
-    } else {
-        h.x = fe_gx(); h.y = fe_gy(); h.z = fe_small(1); h.inf = 0;
+    const bool ok = job_state(f) == PLUME_JOB_OK;
+    if (ok) { ld_base(h, a.bases, i, true); h.inf = 0; }
+    else { h.x = fe_gx(); h.y = fe_gy(); h.z = fe_small(1); h.inf = 0; }
+    PLUME_NOUNROLL for (uint32_t j = 1; j < (uint32_t)PLUME_SIGN_K; j++) {
+        if (ok) { PLUME_NOUNROLL for (int d = 0; d < PLUME_SIGN_BITS; d++) jac_dbl_neg(h); }      // an even number of sign-flipping doublings
+        st_base(a.bases, (size_t)j * a.n + i, h);
+        a.jobflags[(size_t)j * a.n + i] = f;
     }
-    st_base(a.bases, (size_t)a.n + i, h);
-    a.jobflags[(size_t)a.n + i] = f;
 }
 // task t = 2*item + which: sk*G (which 0) or r*G (which 1) by the doubling-free comb
 template <int UNIFORM = 0>
