@@ -118,7 +118,7 @@ def pmc_issue(kernel: str, build: str):
 # frozen accounting per stage: Fp-multiplications per V1 / V2 verify, and the kernels each stage launches
 STAGE_FPMUL = {"verify_ingest_h2c": 634, "verify_scalars": 0, "tables": 381, "verify_msm": FPMUL_MSM_PER_ITEM, "to_affine": 0, "verify_finalize": 282}
 STAGE_KERNELS = {"verify_ingest_h2c": [("plume::k_verify_ingest", 1)], "verify_scalars": [("plume::k_verify_scalars", 1)],
-                 "tables": [("plume::k_tab_pass_a", 1), ("plume::k_tab_pass_b", 1), ("plume::k_tab_invert", 2), ("plume::k_tab_pass_d", 1)],      # (round 6: a second inversion + pass D build rows 3..10 of the base-8 tables)
+                 "tables": [("plume::k_tab_pass_a", 1), ("plume::k_tab_pass_b", 1), ("plume::k_tab_invert", 1)],
                  "verify_msm": [("plume::k_verify_msm", 1)], "verify_finalize": [("plume::k_verify_finalize", 1)]}
 
 

@@ -4,7 +4,7 @@
 # then, back in the container:  bash profiles/finish.sh r04       (copies the summaries into profiles/, regenerates the ISA mix, summarises the counter passes)
 # Counters go in their own passes, each with --kernel-trace only (never with sys/hip/hsa traces).  The profiled runs take --no-probe: the issue-rate probe kernels
 # (k_microbench) would otherwise be half of the trace.
-R=${1:-r05}
+R=${1:-r06}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python3 -c "import zk_nullifier_sig_amd as p; print(p.Engine(0).version())" > gpurun_out/build_$R.txt 2>/dev/null

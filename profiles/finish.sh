@@ -3,7 +3,7 @@
 # of the shipped build and summarise the counter passes.      bash profiles/finish.sh r04
 set -e
 shopt -s expand_aliases 2>/dev/null || true
-R=${1:-r05}
+R=${1:-r06}
 cd "$(dirname "$0")/.."
 cp gpurun_out/prof_$R/${R}_kernel_stats.csv gpurun_out/prof_$R/${R}_kernel_trace.csv profiles/
 cp gpurun_out/prof_${R}s/${R}s_kernel_stats.csv profiles/ 2>/dev/null || true
