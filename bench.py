@@ -36,6 +36,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the HIP runtime's hardware-queue pool: with the default 4 the two streams of the in-flight mode can land on ONE queue and run their kernels one after the other (round 6's trace;
+# include/plume_hip.h, plume_set_in_flight).  Read at the process's first HIP call; reported in config.form.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # Every context this script creates records the per-stage timing events (off by default in the library since 0.5: ~6 us of idle GPU each): roofline.kernel_ms is the
 # multi-scalar kernel's duration by HIP events over the timed region, as the contract asks -- so `value` carries their cost (0.2 % at 2^20: five events of ~6 us in a
 # step of 18 ms; the library's default, without them, is that much FASTER than `value`); the 2^16 entry also reports the default, event-free call
@@ -475,13 +478,36 @@ def small_batch_entry(eng, dev, log2n=16):
     dt, dt_ev = sorted(offs)[1], sorted(ons)[1]
     assert bool((ok.cpu() == torch.from_numpy(synth.expected_ok(n))).all())
     stages = {k: round(x, 4) for k, x in eng.last_stage_times()}
+    # The same calls with TWO batches in flight: two lanes of the context (plume_set_in_flight) on two caller streams, calls alternating (GPU_MAX_HW_QUEUES=8, set at the top of this
+    # script, so that the two streams sit on different hardware queues).  A 2^16 batch leaves most SIMDs two wavefronts: another call's kernels fit beside them.  A throughput figure for a
+    # server holding several small batches, NOT the latency of one call, which is the entry above.  Stage-timing events off, like the default entry.
+    ok2 = torch.zeros(n, dtype=torch.uint8, device=dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    fn2 = lambda o, st: eng.verify_batch_device(1, n, d["msgs"], off, mb, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], o, stream=st)  # noqa: E731
+    torch.cuda.synchronize()
+    eng.set_in_flight(2)
+    eng.set_stage_timing(False)
+    try:
+        for _ in range(4):
+            fn2(ok, s1); fn2(ok2, s2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn2(ok, s1); fn2(ok2, s2)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / (2 * reps)
+    finally:
+        eng.set_in_flight(1)
+        eng.set_stage_timing(True)
+    assert bool((ok2.cpu() == torch.from_numpy(synth.expected_ok(n))).all()) and bool((ok.cpu() == torch.from_numpy(synth.expected_ok(n))).all())
     return {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "ms_per_batch_with_stage_events": round(dt_ev * 1e3, 4), "stage_ms": stages,
             "stage_events": "ms_per_batch: the library's default, no timing events inside the call; stage_ms and ms_per_batch_with_stage_events: plume_set_stage_timing(1), as everywhere else in this line",
             "workload": (f"BASELINE.json configs[1]: " if log2n == 16 else "") + f"2^{log2n} V1 verifies per call, inputs resident in HBM, {reps} calls back to back, median of 3 rounds",
             "rounds_ms": {"default": [round(x * 1e3, 4) for x in offs], "with_stage_events": [round(x * 1e3, 4) for x in ons]},
             "msm_kernel": eng.last_msm_kernel(),
-            "batches_in_flight": "not measured here since round 6: calls of fewer than 2^17 items stay on the context's first lane whatever plume_set_in_flight says (two of them side by side "
-                                 "gain nothing: profiles/r06_in_flight_small_calls.txt)"}
+            "two_batches_in_flight": {"items_per_s": round(n / dt2, 1), "ms_per_batch": round(dt2 * 1e3, 4),
+                                      "note": "plume_set_in_flight(2), two caller streams on different hardware queues (GPU_MAX_HW_QUEUES=8), calls alternating: throughput with two small batches in "
+                                              "flight, not one call's latency"}}
 
 
 def multi_ctx_main(a):
@@ -703,6 +729,7 @@ def main():
                                    + ("" if sign else "1/16 corrupted, ") + "inputs resident in HBM; Fp arithmetic on 9x29-bit limbs through chains of v_mad_u64_u32 (32x32+64)",
                        "form": "one process per GPU (torch.distributed ranks), device-resident entry point plume_" + op + "_batch_device; " +
                                (f"{F} batches in flight per GPU (plume_set_in_flight): step i goes to lane i mod {F} of the context on stream i mod {F}, each call's launch order strictly serial (sub_batches = 1); "
+                                f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')} so that the streams sit on different hardware queues; "
                                 "stage_ms and roofline from a serial pass after the timed region (in_flight.serial)" if F > 1 else
                                 "one call after the other on torch's current stream, launch order strictly serial (sub_batches = 1)") + f"; library {eng.version()}",
                        "items_per_gpu": n, "global_items_per_step": total, "parallelism": f"shard x{world}, no collective on the data path",

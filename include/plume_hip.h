@@ -86,13 +86,17 @@ int plume_set_chunk(plume_ctx* ctx, size_t max_items_per_pass);
 int plume_set_sub_batches(plume_ctx* ctx, int sub_batches);
 /* Batches in flight (default 1).  A context runs its device-resident calls one at a time: they share its workspace, so calls issued on different streams queue.  With
  * batches = 2 the calls go in turn to two lanes of the context (each with a workspace, streams and events of its own; the generator's fixed tables are shared), and calls the
- * caller issues on DIFFERENT streams run side by side: the memory-bound table passes and the ramps / tails of one batch's kernels fit beside the issue-bound multi-scalar
- * kernel of the other -- about 1 % per 2^20-item batch on the MI355X (17.95 against 18.14 ms, round 5), a third lane gains nothing more (1..4 accepted).  It pays for
- * LARGE calls only: calls of up to 2^16 items are latency-bound and two of them side by side gain nothing (round 6, one box, interleaved: -0.1 .. +0.6 % per call for 2^10 .. 2^16
- * items, -3.8 % at 2^17), so device-resident calls of fewer than 2^17 items (env PLUME_IN_FLIGHT_MIN) all run on the context's first lane, whatever `batches` is, and never
- * make it allocate the second workspace.
- * Results do not depend on it; calls on one stream keep that stream's order -- including NULL, which always means the stream of the context the caller holds,
- * whichever lane serves the call (so a sign followed by a verify of its outputs, both with stream = NULL, stay ordered).  Costs a second per-batch workspace.  Single-device contexts only (a multi-device context
+ * caller issues on DIFFERENT streams can run side by side: every kernel of a 2^20 batch fills the chip, yet the memory-bound table passes and the ramps / tails of one batch's
+ * kernels fit beside the issue-bound multi-scalar kernel of the other (about 1 % per batch), and SMALL calls leave the chip mostly empty: two of them side by side take much less
+ * than one after the other -- on the MI355X, two lanes against one (profiles/r06_hw_queues_small_calls.txt): 2^10-item verifies -49 % per call, 2^12 -31 %, 2^14 -26 %,
+ * 2^16 -13.6 % (1.17 instead of 1.36 ms per call), 2^17 -6.5 %, 2^18 -2.3 %; 2^20 signs -3 %; a third lane gains nothing more (1..4 accepted).
+ * THE CALLER'S STREAMS MUST SIT ON DIFFERENT HARDWARE QUEUES for any of this: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware
+ * queues per priority level, and streams that share a queue run their kernels one after the other (round 6's kernel trace of two torch streams: every kernel of both on one
+ * queue, no gain at any size).  Set GPU_MAX_HW_QUEUES=8 in the environment of the process before its first HIP call (the Python package and bench.py do; the figures above are
+ * with it).  Do NOT give the two callers' streams different priorities instead: the command processor runs a high-priority queue's kernels alone.
+ * Results do not depend on any of it; calls on one stream keep that stream's order -- including NULL, which always means the stream of the context the caller holds,
+ * whichever lane serves the call (so a sign followed by a verify of its outputs, both with stream = NULL, stay ordered).  Costs a second per-batch workspace.  Env
+ * PLUME_IN_FLIGHT_MIN=<items> keeps smaller calls on the first lane (default 0: none).  Single-device contexts only (a multi-device context
  * already runs its shards side by side).  plume_last_stage_times / plume_last_redo_tasks then report the lane of the last device-resident call. */
 int plume_set_in_flight(plume_ctx* ctx, int batches);
 /* The signer's schedule.  k256's scalar multiplication is constant-time (call sites rust-k256/src/randomizedsigner.rs:51-70), so the DEFAULT here is level 1

@@ -8,6 +8,7 @@ ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the process's first HIP call: two caller streams on one hardware queue run one after the other (include/plume_hip.h, plume_set_in_flight)
 
 
 def pytest_configure(config):

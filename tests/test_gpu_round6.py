@@ -176,26 +176,41 @@ def test_the_context_says_which_form_and_kernel_ran(eng):
         fresh.close()
 
 
-def test_small_calls_stay_on_the_first_lane_with_batches_in_flight(eng):
-    """plume_set_in_flight(2): calls of fewer than 2^17 items are not dealt out to the second lane (they are latency-bound: side by side they gain nothing); the verdicts
-    are the same on two streams either way, and a large call still alternates"""
+def test_two_lanes_run_small_calls_side_by_side(eng):
+    """plume_set_in_flight(2) with the caller's two streams on different hardware queues (GPU_MAX_HW_QUEUES=8: the Python package sets it before the first HIP call, see
+    include/plume_hip.h).  Round 6's trace had shown two torch streams sharing ONE hardware queue under the default pool -- two batches in flight gaining nothing.  Calls of
+    2^12 items leave the chip nearly empty: on two streams they must take clearly less than one after the other (measured -31 %; asserted: -12 %), with the verdicts of one
+    stream, and every call allocates its lane's workspace (small calls are dealt out to the lanes like large ones)."""
+    import os
+    import time
     import torch
-    n = 1 << 14
+    if os.environ.get("GPU_MAX_HW_QUEUES") != "8":
+        pytest.skip("the process was started with another hardware-queue pool")
+    n = 1 << 12
     b = synth.sign_inputs(n, start=34_000_000)
     sg = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
     v = synth.corrupt_for_verify(1, b, sg, start=34_000_000)
     d = _dev(v, ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r"))
     exp = torch.from_numpy(synth.expected_ok(n, 34_000_000)).to("cuda:0")
-    oks = [torch.zeros(n, dtype=torch.uint8, device="cuda:0") for _ in range(4)]
+    oks = [torch.zeros(n, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
     st = [torch.cuda.Stream(device="cuda:0") for _ in range(2)]
-    free0, _ = torch.cuda.mem_get_info(0)
-    try:
-        eng.set_in_flight(2)
-        for k in range(4):
-            eng.verify_batch_device(1, n, d["msgs"], d["off"], int(v["off"][-1]), d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], oks[k], stream=st[k % 2])
+    call = lambda k: eng.verify_batch_device(1, n, d["msgs"], d["off"], int(v["off"][-1]), d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], oks[k], stream=st[k])  # noqa: E731
+
+    def per_call(both, reps=60):
+        for _ in range(6):
+            call(0); call(1 if both else 0)
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call(0); call(1 if both else 0)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (2 * reps)
+    try:
+        eng.set_in_flight(1)
+        one = min(per_call(False) for _ in range(3))
+        eng.set_in_flight(2)
+        two = min(per_call(True) for _ in range(3))
         assert all(bool((o == exp).all()) for o in oks)
-        free1, _ = torch.cuda.mem_get_info(0)
-        assert free0 - free1 < (16 << 20), "the second lane never allocated a workspace: the small calls all ran on the first"
+        assert two < 0.88 * one, (one, two)
     finally:
         eng.set_in_flight(1)

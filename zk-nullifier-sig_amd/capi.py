@@ -37,6 +37,9 @@ _lib = None
 
 
 def _load():
+    # The runtime's hardware-queue pool (4 per priority level by default): streams that share a queue run their kernels one after the other, which is what defeats
+    # plume_set_in_flight for callers with two streams (include/plume_hip.h).  Effective only if set before the process's first HIP call; harmless after it.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     global _lib
     if _lib is not None:
         return _lib

@@ -164,7 +164,7 @@ struct plume_ctx {
     // (workspace, streams, events; the fixed tables are shared), so that calls the caller issues on DIFFERENT streams run side by side instead of queueing for one workspace
     std::vector<plume_ctx*> lanes;
     size_t lane_next = 0;
-    size_t in_flight_min = (size_t)1 << 17;                        // verify / sign calls of fewer items are not dealt out to the lanes (env PLUME_IN_FLIGHT_MIN): latency-bound calls side by side measured slower than one after the other
+    size_t in_flight_min = 0;                                      // verify / sign calls of fewer items are not dealt out to the lanes (env PLUME_IN_FLIGHT_MIN; 0, the default: every call is)
     plume_ctx* lane_last = nullptr;                               // the lane the last device-resident call went to (plume_last_stage_times, plume_last_redo_tasks)
     DevBuf bases, jobflags, itemflags, tab, tabscr, res, resinf, res2, res2inf, pkaff, sink, redo, digs, eq1fall, eq1k, clk;
     int eq1_short = 1;                                             // verify calls that give R: equation 1 in its short form (plume_eis.h).  0 = long form always (A/B), 2 = test: every item takes the fallback
@@ -647,10 +647,13 @@ extern "C" int plume_set_sub_batches(plume_ctx* ctx, int sub_batches) {
 
 // Batches in flight: with k > 1 the device-resident calls of this context go in turn to k lanes -- the context itself and k - 1 further single-device contexts of its own
 // (each with its workspace, streams and events; the generator's fixed tables are shared) -- so that calls the caller issues on DIFFERENT streams run side by side instead
-// of queueing for one workspace: the memory-bound table passes and the ramps / tails of one batch's kernels fit beside the issue-bound multi-scalar kernel of another
-// (2^20 verifies: about 1 % per batch with two in flight; three gain nothing more).  Calls of fewer than in_flight_min items (2^17; env PLUME_IN_FLIGHT_MIN) stay on the
-// first lane: they are latency-bound and two of them side by side gain nothing (round 6 sweep, 2^10 .. 2^16: -0.1 .. +0.6 % per call; 2^17: -3.8 %), so they do not
-// make the context allocate a second workspace either.  Results do not depend on any of it.  Calls on ONE stream stay in that stream's order whatever k is.  Default 1.
+// of queueing for one workspace.  Whether they DO run side by side is the runtime's business: it multiplexes a process's streams onto GPU_MAX_HW_QUEUES (4 by default)
+// hardware queues per priority level, and two caller streams that land on one queue run their kernels one after the other -- round 6's kernel trace of two torch streams
+// showed every kernel of both on one queue, and round 5's "two small calls side by side gain nothing" was that.  With GPU_MAX_HW_QUEUES=8 in the process's environment
+// (profiles/r06_hw_queues_small_calls.txt, one box, two lanes against one): 2^10-item verifies -49 % per call, 2^12 -31 %, 2^14 -26 %, 2^16 -13.6 % (1.17 instead of 1.36 ms),
+// 2^17 -6.5 %, 2^18 -2.3 %, 2^20 within the spread; 2^20 signs -3 %; a third lane gains nothing more.  (Giving the second lane a high-priority stream of its own, tied to the
+// caller's by events, does not do it: the queues then differ, but the command processor runs a high-priority queue's kernels ALONE -- strict alternation in the trace.)
+// Results do not depend on any of it.  Calls on ONE stream stay in that stream's order whatever k is.  Default 1.
 extern "C" int plume_set_in_flight(plume_ctx* ctx, int batches) {
     if (!ctx || batches < 1 || batches > 4) return fail(PLUME_ERR_ARG, "plume_set_in_flight: bad argument");
     if (!ctx->shards.empty()) return fail(PLUME_ERR_ARG, "plume_set_in_flight: a multi-device context runs its shards side by side already");
