@@ -147,11 +147,13 @@ int plume_get_eq1_short(const plume_ctx* ctx, size_t* min_items);
  * the one before, up to the largest piece (default 1<<19, capped by the chunk size); calls with large outputs (the signer: 320 bytes down per item) taper instead -- a first
  * piece of twice the tail piece (default 1<<16), a body of pieces of at most half the largest, then 3, 2 and 1 tail pieces -- so that the last, unhidden download is short.
  * The pieces of a VERIFY call alternate between the context and a second lane of its own (workspace + stream, created on the first such call) when EVERY array of the call
- * is page-locked; the signer stays on one lane (measured: no gain from two).  The copy streams are created at high priority: the runtime multiplexes a process's streams onto
+ * is page-locked.  The signer under the same condition (round 6, now that two lanes' kernels really run side by side -- plume_set_in_flight's note on hardware queues): uniform
+ * pieces of the tail size dealt to the two lanes in turn (twice the tail size beyond 32 of them); 2^18..2^20 signs gain 2-7 %, 2^22 0.7 % over the tapered one-lane
+ * schedule, which pageable callers and PLUME_HOST_SIGN_LANES=1 still get.  The copy streams are created at high priority: the runtime multiplexes a process's streams onto
  * a few hardware queues per priority level, and a copy stream that shares a queue with a compute stream waits for its kernels (round 5: a finished piece's download started
  * 6 ms late).  Env PLUME_HOST_TRACE=1 prints every call's timeline to stderr (per piece: upload, kernels, download on the GPU's clock; no profiler needed -- and none should be
- * attached: rocprofv3's memory-copy trace turns the downloads into blit kernels).  2^20 items from page-locked arrays on the MI355X: verify 20.7-21.0 ms, sign 18.7-19.1 ms,
- * 0.89-0.91 of the device-resident rates.  Results do not depend on any of this. */
+ * attached: rocprofv3's memory-copy trace turns the downloads into blit kernels).  2^20 items from page-locked arrays on the MI355X: verify 19.3-19.6 ms, sign 17.9-18.1 ms
+ * (round 5: 20.7-21.0 and 18.7-19.1), 0.90-0.94 of the device-resident rates.  Results do not depend on any of this. */
 int plume_set_host_piece(plume_ctx* ctx, size_t largest_piece_items);
 int plume_set_host_first_piece(plume_ctx* ctx, size_t items);
 int plume_set_host_tail_piece(plume_ctx* ctx, size_t items);

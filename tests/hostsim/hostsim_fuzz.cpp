@@ -63,6 +63,7 @@ static void fuzz_pieces() {
     kn.host_first_piece = rnd(0, 3) ? ((size_t)1 << rnd(0, 20)) : any_size((size_t)1 << 26) + 1;
     kn.host_tail_piece = rnd(0, 3) ? ((size_t)1 << rnd(0, 20)) : any_size((size_t)1 << 26) + 1;
     if (rnd(0, 3) == 0) kn = PieceKnobs{(size_t)1 << 20, (size_t)1 << 19, (size_t)1 << 16, (size_t)1 << 16};     // the defaults
+    kn.out_lanes = (int)rnd(1, 2);
     const size_t cap0 = kn.host_piece < kn.chunk ? kn.host_piece : kn.chunk;
     size_t n = any_size(0x10000000u);
     if (n / cap0 > 3000) n = cap0 * rnd(1, 3000) + rnd(0, cap0 - 1);   // keep a case's piece count (and this harness's run time) bounded
@@ -95,7 +96,7 @@ static void fuzz_pieces() {
     }
     if (!listed) for (size_t c : s) REQUIRE(c <= cap);
     REQUIRE(s.size() <= n / 1 + 1 && (n == 0) == s.empty());
-    if (!listed && n) REQUIRE(s.size() <= 3 * (n / cap + 1) + 24);   // the number of pieces stays proportional to n / largest piece
+    if (!listed && n) REQUIRE(s.size() <= 8 * (n / cap + 1) + 24);   // (3 (n / cap + 1) + 24 for the growing and tapered rules; the signer's uniform two-lane pieces are never below cap / 8)   // the number of pieces stays proportional to n / largest piece
 }
 
 static void fuzz_offsets() {
@@ -169,6 +170,13 @@ int main(int argc, char** argv) {
     const size_t K = 1024;
     REQUIRE((piece_schedule(def, (size_t)1 << 20, false, nullptr) == std::vector<size_t>{64 * K, 192 * K, 512 * K, 256 * K}));
     REQUIRE((piece_schedule(def, (size_t)1 << 20, true, nullptr) == std::vector<size_t>{128 * K, 256 * K, 256 * K, 192 * K, 128 * K, 64 * K}));
+    PieceKnobs def2 = def; def2.out_lanes = 2;                     // the signer on two lanes: uniform 2^16-item pieces from 2^18 items up; verify calls do not change
+    REQUIRE((piece_schedule(def2, (size_t)1 << 20, true, nullptr) == std::vector<size_t>(16, 64 * K)));
+    REQUIRE((piece_schedule(def2, (size_t)1 << 21, true, nullptr) == std::vector<size_t>(32, 64 * K)));
+    REQUIRE((piece_schedule(def2, (size_t)1 << 22, true, nullptr) == std::vector<size_t>(32, 128 * K)));
+    REQUIRE((piece_schedule(def2, ((size_t)1 << 18) + 5, true, nullptr) == std::vector<size_t>{64 * K, 64 * K, 64 * K, 64 * K, 5}));
+    REQUIRE((piece_schedule(def2, ((size_t)1 << 18) - 1, true, nullptr) == piece_schedule(def, ((size_t)1 << 18) - 1, true, nullptr)));
+    REQUIRE((piece_schedule(def2, (size_t)1 << 20, false, nullptr) == std::vector<size_t>{64 * K, 192 * K, 512 * K, 256 * K}));
     REQUIRE((piece_schedule(def, (size_t)1 << 17, false, nullptr) == std::vector<size_t>{128 * K}));
     REQUIRE((piece_schedule(def, (size_t)1 << 19, true, nullptr) == std::vector<size_t>{64 * K, 192 * K, 192 * K, 64 * K}));
     std::printf("hostsim_fuzz: seed %llu, %ld cases of 6 fuzzers: ok\n", (unsigned long long)seed, cases);

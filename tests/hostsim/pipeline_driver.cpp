@@ -299,8 +299,9 @@ static void group_sign(uint64_t seed) {
     struct Case { const char* name; Knobs k; int mk; bool supply_pk; };
     const Case cases[] = {
         {"defaults (uniform level 1), pageable arrays", {}, 0, false},
-        {"tapered small pieces, page-locked arrays, level 0", {24, 0, 6, 0, 0, 0, -1, 0, 0}, 1, false},
-        {"tapered small pieces, registered arrays, level 2 (scanned tables), pk supplied", {24, 0, 6, 0, 0, 0, -1, 2, 0}, 2, true},
+        {"tapered small pieces on one lane (pageable arrays), level 0", {24, 0, 6, 0, 0, 0, -1, 0, 0}, 0, false},
+        {"uniform small pieces dealt to two lanes (page-locked arrays), level 0", {24, 0, 6, 0, 0, 0, -1, 0, 0}, 1, false},
+        {"uniform small pieces on two lanes, registered arrays, level 2 (scanned tables), pk supplied", {24, 0, 6, 0, 0, 0, -1, 2, 0}, 2, true},
         {"chunk smaller than the pieces, registration for the call, level 1", {32, 0, 8, 20, 1, 0, -1, 1, 0}, 0, true},
     };
     for (const Case& cs : cases) {

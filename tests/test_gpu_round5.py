@@ -162,7 +162,7 @@ def test_signer_default_is_the_uniform_schedule_level_1():
 def test_host_pipeline_lanes_share_the_contexts_knobs(eng):
     """the host pipeline's second lane did not inherit sign_uniform.  Now every derived context takes every knob from one helper (inherit_tunables).  A 2^19
     host-pointer sign from page-locked arrays at each level, with the context's host pipeline set to two lanes and to one (the signer itself runs on one lane by default:
-    two measured no gain; PLUME_HOST_SIGN_LANES=2 is the experiment's knob): identical bytes, = the C oracle on a sample."""
+    round 5: one lane; round 6: two lanes with uniform pieces, PLUME_HOST_SIGN_LANES=1 for the old schedule): identical bytes, = the C oracle on a sample."""
     from zk_nullifier_sig_amd import capi
     n = (1 << 19) + 4097
     b = synth.sign_inputs(n, start=24_000_000)

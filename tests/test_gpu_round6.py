@@ -214,3 +214,38 @@ def test_two_lanes_run_small_calls_side_by_side(eng):
         assert two < 0.88 * one, (one, two)
     finally:
         eng.set_in_flight(1)
+
+
+def test_signer_host_call_on_two_lanes_uniform_pieces():
+    """The signer's host-pointer call from page-locked arrays (round 6): uniform tail-sized pieces dealt to two lanes, twice that size beyond 32 pieces.  Small knobs bring
+    both rules within a quick batch (pieces of 2^12 items for 100 001 items, of 2^13 for 300 001, ragged last pieces); the bytes are those of the one-lane tapered call
+    and of the pageable call, = the C oracle on a sample."""
+    import zk_nullifier_sig_amd as plume
+    from zk_nullifier_sig_amd import capi
+    OUT = ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")
+    e = plume.Engine(0)
+    try:
+        e.set_host_piece(1 << 15); e.set_host_first_piece(1 << 12); e.set_host_tail_piece(1 << 12)
+        for n in (100_001, 300_001):
+            b = synth.sign_inputs(n, start=31_000_000 + n)
+            pin = {k: capi.pinned_copy(b[k]) for k in ("msgs", "off", "sk", "r")}
+            got = {}
+            for lanes in (2, 1):
+                e.set_host_lanes(lanes)
+                so = {k: capi.pinned_empty((n, w)) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
+                so["status"] = capi.pinned_empty(n)
+                so["status"][:] = 0xFF
+                r = e.sign_batch(1, pin["msgs"], pin["off"], pin["sk"], pin["r"], out=so)
+                assert not r["status"].any()
+                got[lanes] = {k: r[k].copy() for k in OUT}
+            pageable = e.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
+            for k in OUT:
+                assert np.array_equal(got[2][k], got[1][k]) and np.array_equal(got[2][k], pageable[k]), (n, k)
+            idx = np.unique(np.concatenate([np.arange(0, n, 997), np.arange(4090, 4100), np.arange(n - 5, n)]))
+            msgs = [b["msgs"][b["off"][i]:b["off"][i + 1]].tobytes() for i in idx]
+            mb, off = OC.pack_msgs(msgs)
+            want = OC.sign_batch(1, mb, off, np.ascontiguousarray(b["sk"][idx]), np.ascontiguousarray(b["r"][idx]), nthreads=8)
+            for k in OUT:
+                assert np.array_equal(got[2][k][idx], want[k]), (n, k)
+    finally:
+        e.close()

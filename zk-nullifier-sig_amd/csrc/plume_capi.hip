@@ -155,7 +155,7 @@ struct plume_ctx {
     int sign_uniform = 1;                                          // plume_set_sign_uniform: the signer's schedule (level 0, 1, 2).  Default 1 since round 5: no branch on a digit of sk or r
                                                                    // (k256's multiplication is constant-time, rust-k256/src/randomizedsigner.rs:51-70; measured price +2.5 % per signature)
     int host_lanes = 2;                                            // ... 1 = every piece on the context itself (rounds 1-3), 2 = pieces alternate between the context and host_lane
-    int host_sign_lanes = 1;                                       // ... the signer's host-pointer call: lanes it may use (env PLUME_HOST_SIGN_LANES; round-5 experiment)
+    int host_sign_lanes = 2;                                       // ... the signer's host-pointer call: lanes it may use (env PLUME_HOST_SIGN_LANES).  2 since round 6, with uniform 2^16-item pieces (plume_host_logic.h)
     bool host_lane_failed = false;                                 // ... the second lane could not be created once (out of memory): do not retry on every call
     int jobs_per_lane = kTableJobsPerLane;
     bool jobs_per_lane_forced = false;
@@ -1263,8 +1263,9 @@ struct ScopedPins {
 // Piece schedule: the first piece is small (nothing hides its upload), every following piece may be up to three times the one before it (an
 // upload runs at ~7 ns per item, the kernels at ~23 ns per item, so piece k+1's upload still hides behind piece k's kernels) up to the
 // largest piece; calls with large outputs (the signer: 320 bytes out per item) also end on a small piece, whose download nothing hides.
-static std::vector<size_t> piece_schedule(const plume_ctx* ctx, size_t n, bool out_heavy) {
-    const plume_host::PieceKnobs kn{ctx->chunk, ctx->host_piece, ctx->host_first_piece, ctx->host_tail_piece};
+static std::vector<size_t> piece_schedule(const plume_ctx* ctx, size_t n, bool out_heavy, int lanes) {
+    plume_host::PieceKnobs kn{ctx->chunk, ctx->host_piece, ctx->host_first_piece, ctx->host_tail_piece};
+    kn.out_lanes = lanes;
     return plume_host::piece_schedule(kn, n, out_heavy, std::getenv("PLUME_HOST_SCHEDULE"));     // the rules and the experiment knob: plume_host_logic.h
 }
 
@@ -1306,7 +1307,7 @@ static bool host_trace_on() { static const bool on = [] { const char* e = std::g
 
 template <class Up, class Run, class Down>
 static int host_pipeline(plume_ctx* ctx, size_t n, bool out_heavy, Up up, Run run, Down down, bool may_use_two_lanes = false) {
-    const std::vector<size_t> sched = piece_schedule(ctx, n, out_heavy);
+    const std::vector<size_t> sched = piece_schedule(ctx, n, out_heavy, (may_use_two_lanes && ctx->host_lanes > 1) ? 2 : 1);
     plume_ctx* lane2 = (may_use_two_lanes && ctx->host_lanes > 1 && sched.size() > 1) ? host_lane_of(ctx) : nullptr;
     const size_t nslots = lane2 ? 4 : 2;
     ctx->lane_last = nullptr;            // host-pointer calls report the stage timer of the lane their last piece ran on (set below)

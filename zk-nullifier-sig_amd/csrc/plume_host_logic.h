@@ -27,6 +27,7 @@ inline std::vector<size_t> sub_batch_bounds(size_t n, int sub_batches, size_t ov
 
 struct PieceKnobs {
     size_t chunk, host_piece, host_first_piece, host_tail_piece;
+    int out_lanes = 1;        // lanes a call with large outputs (the signer) may spread its pieces over
 };
 
 // Host-pointer calls: the pieces of an n-item call, in order.  Every piece is in [1, min(host_piece, chunk)] and they add up to n.
@@ -53,6 +54,17 @@ inline std::vector<size_t> piece_schedule(const PieceKnobs& kn, size_t n, bool o
         sched.clear();
     }
     const size_t tail = kn.host_tail_piece ? kn.host_tail_piece : 1;
+    if (out_heavy && kn.out_lanes > 1 && tail <= piece && piece <= 8 * tail && n >= 4 * tail) {          // (a tail knob far below the largest piece keeps the rules below: the piece count stays O(n / piece))
+        // The signer on TWO lanes (round 6): uniform pieces of the tail size (2^16), dealt out to the lanes in turn.  With the lanes' kernels really side by side (their streams on
+        // different hardware queues) a piece's fixed cost -- launches, three serial inversions, ramps and tails -- hides beside the other lane's kernels, every download but the
+        // last hides behind a kernel, and the last one is short: 2^20 signs from page-locked arrays 18.0 ms against 18.6-19.3 for the tapered one-lane schedule below on the same
+        // box (tests/gpu_debug/r06_host_sched.py; device-resident: 16.2).  Pieces of 2^15 or 3 * 2^14 items lose 25 %: 2^16 is where the small-call kernels still apply and the
+        // chip is half full.  (Verify calls, whose 1-byte-per-item downloads cost nothing, keep the growing schedule: 64k / 192k / 512k / 256k is still their best.)
+        // Beyond 32 such pieces (2^21 items) the pieces are twice as large: 2^22 signs 66.8 ms against 69.1 with 2^16-item pieces and 67.3 on one lane (r06_t.sh).
+        const size_t u = (n > 32 * tail && 2 * tail <= piece) ? 2 * tail : tail;
+        for (size_t rem = n; rem;) { const size_t c = rem < u ? rem : u; sched.push_back(c); rem -= c; }
+        return sched;
+    }
     if (out_heavy && tail <= piece / 8 && n / 12 >= tail && n >= 2 * piece) {
         // Calls with large outputs (the signer: 96 bytes up, 320 down per item): every piece's download hides behind the NEXT piece's kernels and the last one behind nothing, so
         // the pieces taper towards the end (3t, 2t, t with t = the tail piece, 2^16) after a body of pieces of at most half the largest piece (2^18) behind a first piece of 2t.
