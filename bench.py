@@ -370,8 +370,8 @@ def e2e_host_pinned(eng, n, b, signed_v1):
     except Exception as e:
         out["verify_v1_eight_shards_on_this_gpu"] = {"error": str(e)[:300]}
     eng.set_stage_timing(True)
-    out["note"] = ("median of 3 calls after one warm-up; stage-timing events off (the library's default); page-locked arrays from plume_host_alloc; pieces of up to 2^19 items (first 2^16, then x3 per piece; the signer's last piece 2^16); "
-                   "verify: pieces alternate between two lanes of the context, four staging slots (round 4); sign and pageable arrays: one lane")
+    out["note"] = ("median of 3 calls after one warm-up; stage-timing events off (the library's default); page-locked arrays from plume_host_alloc; verify: pieces of up to 2^19 items (first 2^16, then x3 per piece) alternating between two lanes of the context, four staging slots (round 4); "
+                   "sign: uniform 2^16-item pieces dealt to the two lanes in turn (round 6; one lane with tapered pieces before); pageable arrays: one lane")
     return out
 
 
