@@ -152,8 +152,8 @@ int plume_get_eq1_short(const plume_ctx* ctx, size_t* min_items);
  * schedule, which pageable callers and PLUME_HOST_SIGN_LANES=1 still get.  The copy streams are created at high priority: the runtime multiplexes a process's streams onto
  * a few hardware queues per priority level, and a copy stream that shares a queue with a compute stream waits for its kernels (round 5: a finished piece's download started
  * 6 ms late).  Env PLUME_HOST_TRACE=1 prints every call's timeline to stderr (per piece: upload, kernels, download on the GPU's clock; no profiler needed -- and none should be
- * attached: rocprofv3's memory-copy trace turns the downloads into blit kernels).  2^20 items from page-locked arrays on the MI355X: verify 19.3-19.6 ms, sign 17.9-18.1 ms
- * (round 5: 20.7-21.0 and 18.7-19.1), 0.90-0.94 of the device-resident rates.  Results do not depend on any of this. */
+ * attached: rocprofv3's memory-copy trace turns the downloads into blit kernels).  2^20 items from page-locked arrays on the MI355X: verify 19.3-20.5 ms, sign 17.9-18.7 ms
+ * over the boxes met (round 5: 20.4-21.1 and 18.7-19.1), 0.89-0.94 of the device-resident rates.  Results do not depend on any of this. */
 int plume_set_host_piece(plume_ctx* ctx, size_t largest_piece_items);
 int plume_set_host_first_piece(plume_ctx* ctx, size_t items);
 int plume_set_host_tail_piece(plume_ctx* ctx, size_t items);
