@@ -318,6 +318,17 @@ def cpu_baseline(version: int, sign: bool = False):
     return out
 
 
+_PROGRESS = {"section": None, "since": None}
+
+
+def _at(section: str):
+    """where the secondary sections are (the watchdog reports it should they stall)"""
+    _PROGRESS["section"] = section
+    _PROGRESS["since"] = time.time()
+    if os.environ.get("PLUME_BENCH_PROGRESS"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {section}", file=sys.stderr, flush=True)
+
+
 def e2e_host_pinned(eng, n, b, signed_v1):
     """whole-call rate of the host-pointer entry points with page-locked caller arrays: H2D + kernels + D2H, pipelined in pieces (SURVEY §8d 'secondary')"""
     import numpy as np
@@ -337,16 +348,19 @@ def e2e_host_pinned(eng, n, b, signed_v1):
             t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
         return min(ts), sorted(ts)[len(ts) // 2]
 
+    _at("e2e_host_pinned: sign_v1 from page-locked arrays")
     tb, tm = best(lambda: eng.sign_batch(1, pin["msgs"], pin["off"], pin["sk"], pin["r"], out=so))
     assert np.array_equal(so["s"], signed_v1["s"]) and not so["status"].any()
     out["sign_v1"] = {"items_per_s": round(n / tm, 1), "ms_per_call": round(tm * 1e3, 3), "best_ms": round(tb * 1e3, 3), "bytes_in": 96 * n, "bytes_out": 321 * n}
     v = synth.corrupt_for_verify(1, b, signed_v1)
     vp = {k: capi.pinned_copy(v[k]) for k in ("msgs", "pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
     ok = capi.pinned_empty(n)
+    _at("e2e_host_pinned: verify_v1 from page-locked arrays")
     tb, tm = best(lambda: eng.verify_batch(1, vp["msgs"], pin["off"], vp["pk"], vp["nullifier"], vp["c"], vp["s"], vp["r_point"], vp["hashed_to_curve_r"], out=ok))
     assert np.array_equal(ok, synth.expected_ok(n))
     out["verify_v1"] = {"items_per_s": round(n / tm, 1), "ms_per_call": round(tm * 1e3, 3), "best_ms": round(tb * 1e3, 3), "bytes_in": 352 * n, "bytes_out": n}
     # the same call with pageable caller arrays (the runtime stages them), for comparison
+    _at("e2e_host_pinned: verify_v1 from pageable arrays")
     tb, tm = best(lambda: eng.verify_batch(1, v["msgs"], b["off"], v["pk"], v["nullifier"], v["c"], v["s"], v["r_point"], v["hashed_to_curve_r"]), reps=2)
     out["verify_v1_pageable"] = {"items_per_s": round(n / tm, 1), "ms_per_call": round(tm * 1e3, 3)}
     # the same call through a plume_init_multi context of EIGHT shards that all sit on this one GPU (config 4's split in the library's own form), against the
@@ -355,10 +369,12 @@ def e2e_host_pinned(eng, n, b, signed_v1):
     try:
         import zk_nullifier_sig_amd as plume
         dev_id = eng.device_id if hasattr(eng, "device_id") else 0
+        _at("e2e_host_pinned: creating the eight-shard context")
         m = plume.Engine([dev_id] * 8)
         try:
             m.set_stage_timing(False)
             ok8 = capi.pinned_empty(n)
+            _at("e2e_host_pinned: verify_v1 through eight shards on this GPU")
             tb8, tm8 = best(lambda: m.verify_batch(1, vp["msgs"], pin["off"], vp["pk"], vp["nullifier"], vp["c"], vp["s"], vp["r_point"], vp["hashed_to_curve_r"], out=ok8))
             assert np.array_equal(ok8, synth.expected_ok(n))
             out["verify_v1_eight_shards_on_this_gpu"] = {"items_per_s": round(n / tm8, 1), "ms_per_call": round(tm8 * 1e3, 3), "best_ms": round(tb8 * 1e3, 3), "shards": m.num_shards(),
@@ -366,6 +382,7 @@ def e2e_host_pinned(eng, n, b, signed_v1):
                                                          "note": "plume_init_multi([d] * 8): eight worker threads, eight workspaces, 8 x 4 staging slots sharing ONE GPU; "
                                                                  "frac_of_one_context = this rate / verify_v1's (same arrays, same run)"}
         finally:
+            _at("e2e_host_pinned: closing the eight-shard context")
             m.close()
     except Exception as e:
         out["verify_v1_eight_shards_on_this_gpu"] = {"error": str(e)[:300]}
@@ -396,19 +413,23 @@ def extras(eng, dev, n, b, signed_v1):
     mbytes = int(b["off"][-1])
     o = {k: torch.zeros((n, w), dtype=torch.uint8, device=dev) for k, w in [("pk", 64), ("nullifier", 64), ("c", 32), ("s", 32), ("r_point", 64), ("hashed_to_curve_r", 64)]}
     st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    _at("other_workloads: sign_v1 / sign_v2 device-resident")
     for ver in (1, 2):
         dt = timed(lambda: eng.sign_batch_device(ver, n, msgs, off, mbytes, sk, r, None, o["pk"], o["nullifier"], o["c"], o["s"], o["r_point"], o["hashed_to_curve_r"], st))
         out[f"sign_v{ver}"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
     # V2 verify on the V2 signatures just produced (honest batch); the arkworks verification (verify_non_zk) of the same batch beside it
+    _at("other_workloads: verify_v2")
     ok = torch.zeros(n, dtype=torch.uint8, device=dev)
     dt = timed(lambda: eng.verify_batch_device(2, n, msgs, off, mbytes, o["pk"], o["nullifier"], o["c"], o["s"], None, None, ok))
     assert bool(ok.all())
     out["verify_v2"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
+    _at("other_workloads: verify_non_zk_v2")
     dt = timed(lambda: eng.verify_non_zk_batch_device(2, n, msgs, off, mbytes, o["pk"], o["nullifier"], o["s"], o["r_point"], o["hashed_to_curve_r"], o["c"], ok))
     assert bool((ok == 1).all())
     out["verify_non_zk_v2"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
     # V1 verify with SEC1-compressed points (decompression on the GPU)
     if signed_v1 is not None:
+        _at("other_workloads: verify_v1_sec1_compressed")
         c33 = {k: t(_sec1.compress(signed_v1[k])) for k in ("pk", "nullifier", "r_point", "hashed_to_curve_r")}
         cc, ss = t(signed_v1["c"]), t(signed_v1["s"])
         dt = timed(lambda: eng.verify_batch_sec1_device(1, n, msgs, off, mbytes, c33["pk"], c33["nullifier"], cc, ss, c33["r_point"], c33["hashed_to_curve_r"], ok))
@@ -416,6 +437,7 @@ def extras(eng, dev, n, b, signed_v1):
         out["verify_v1_sec1_compressed"] = {"items_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 3) for k, v in eng.last_stage_times()}}
     # aggregate random-linear-combination pre-filter over the V1 batch (all-or-nothing, probabilistic -- NOT the headline metric's semantics)
     if signed_v1 is not None:
+        _at("other_workloads: aggregate_check_v1")
         s1 = {k: t(signed_v1[k]) for k in ("pk", "nullifier", "c", "s", "r_point", "hashed_to_curve_r")}
         rec = torch.zeros(72, dtype=torch.uint8, device=dev)
         seed = os.urandom(32)
@@ -425,6 +447,7 @@ def extras(eng, dev, n, b, signed_v1):
                                      "semantics": "all-or-nothing pre-filter: exact per-item hash check + one 5n-point multi-scalar multiplication (bucket method, 16-bit windows)"}
     # nullifier-set post-processing on the nullifiers just produced: first occurrences among 2^20 records, 1/16 of them
     # made repeats of an earlier item; HBM view = 66 algorithmic bytes per item (64-byte record + live flag in, first flag out)
+    _at("other_workloads: nullifier_first_occurrence")
     nul = o["nullifier"].clone()
     nul[16::16] = nul[8::16][: nul[16::16].shape[0]]
     first = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -442,6 +465,7 @@ def small_batch_entry(eng, dev, log2n=16):
     import torch
 
     from tests import synth
+    _at("small_batch_entry: setting up")
     n = 1 << log2n
     b = synth.sign_inputs(n)
     signed = eng.sign_batch(1, b["msgs"], b["off"], b["sk"], b["r"])
@@ -462,11 +486,13 @@ def small_batch_entry(eng, dev, log2n=16):
             fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
+    _at(f"small_batch_entry 2^{log2n}: warm-up calls")
     for _ in range(60):                     # the GPU has idled through the host-side set-up above: ~90 ms of the same calls bring its clocks back (a first block of 20 calls right
         fn()                                # after the set-up read 5 % slower than the next one: profiles/r05_bench_line.json of build c8ce7f21, before this warm-up existed)
     torch.cuda.synchronize()
     # three interleaved rounds of: the library's default -- no timing events between the kernels (plume_set_stage_timing; each costs ~6 us of idle GPU, 2 % of a call this
     # size) -- and the same calls with the stage events this script reads everywhere else; the median round of each is reported
+    _at(f"small_batch_entry 2^{log2n}: timed rounds, one call after the other")
     offs, ons = [], []
     for _ in range(3):
         eng.set_stage_timing(False)
@@ -481,6 +507,7 @@ def small_batch_entry(eng, dev, log2n=16):
     # The same calls with TWO batches in flight: two lanes of the context (plume_set_in_flight) on two caller streams, calls alternating (GPU_MAX_HW_QUEUES=8, set at the top of this
     # script, so that the two streams sit on different hardware queues).  A 2^16 batch leaves most SIMDs two wavefronts: another call's kernels fit beside them.  A throughput figure for a
     # server holding several small batches, NOT the latency of one call, which is the entry above.  Stage-timing events off, like the default entry.
+    _at(f"small_batch_entry 2^{log2n}: two batches in flight on two streams")
     ok2 = torch.zeros(n, dtype=torch.uint8, device=dev)
     s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     fn2 = lambda o, st: eng.verify_batch_device(1, n, d["msgs"], off, mb, d["pk"], d["nullifier"], d["c"], d["s"], d["r_point"], d["hashed_to_curve_r"], o, stream=st)  # noqa: E731
@@ -883,6 +910,12 @@ def main():
         def _watchdog():
             if not done.wait(float(os.environ.get("PLUME_BENCH_SECONDARY_TIMEOUT", "420"))):
                 line["watchdog"] = "the secondary sections (other_workloads / e2e_host_pinned) did not finish in time: this line carries what was measured before them"
+                line["watchdog_stalled_in"] = {"section": _PROGRESS["section"], "for_s": round(time.time() - (_PROGRESS["since"] or time.time()), 1)}
+                try:                                             # ... and every thread's Python stack on stderr (the stalled call is a ctypes call into the library or a torch synchronize)
+                    import faulthandler
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                except Exception:
+                    pass
                 for _ in range(5):                               # (the main thread may be adding a key just now)
                     try:
                         out = json.dumps(dict(line), default=str)
