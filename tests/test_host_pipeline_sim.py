@@ -74,7 +74,7 @@ def _all_ok(results):
 def test_host_side_under_asan_ubsan_on_eight_devices(builds):
     exe = builds["asan"] / "pipeline_driver"
     jobs = [("faults", None, 1), ("multi", None, 1), ("benchseq", None, 1), ("benchseq", "random:6", 2), ("verify", None, 1), ("sign", None, 1), ("misc", None, 2), ("device", None, 1), ("device", "random:1", 1), ("device", "random:2", 2),
-            ("verify", "random:3", 3), ("sign", "eager", 1), ("devapi", None, 1), ("devapi", "random:4", 2)]
+            ("verify", "random:3", 3), ("sign", "eager", 1), ("sign", "random:7", 2), ("sign", "random:8", 3), ("devapi", None, 1), ("devapi", "random:4", 2)]      # (sign under the random scheduler: the two-lane uniform pieces of round 6)
     with ThreadPoolExecutor(4) as ex:
         res = list(ex.map(lambda j: (j, _run(exe, j[0], j[1], j[2])), jobs))
     _all_ok(res)
