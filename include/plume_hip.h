@@ -401,7 +401,7 @@ int plume_last_redo_tasks(plume_ctx* ctx, uint64_t* count);
 const char* plume_last_msm_kernel(const plume_ctx* ctx);
 /* Measurement hook: the shader clock (GHz) the multi-scalar kernel of the last verify call on this context ran at, sampled INSIDE that kernel -- one workgroup in 32 adds the
  * shader-clock cycles and the constant-rate wall-clock ticks it lived for to two counters.  kernel time x this clock = the kernel's duration in cycles, a figure that does not
- * move with the box's power / thermal state the way the time does.  Only with stage timing on (plume_set_stage_timing) before the call; PLUME_ERR_ARG otherwise. */
+ * move with the box's power / thermal state the way the time does.  Only when stage timing was on (plume_set_stage_timing) for THAT call; PLUME_ERR_ARG otherwise (an earlier call's sample is never handed out). */
 int plume_last_msm_clock(plume_ctx* ctx, double* ghz);
 /* VALU issue-rate microbenchmark (32 waves per CU, 8 independent chains per lane, `iters` x 8 instructions per lane):
  * returns operations per second chip-wide (<= 0 on error).  kind: 0 v_mad_u64_u32, 1 v_addc_co_u32, 2 v_mul_lo_u32,

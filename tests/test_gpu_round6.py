@@ -166,6 +166,8 @@ def test_the_context_says_which_form_and_kernel_ran(eng):
         eng.set_stage_timing(False)
         call(1 << 16)
         assert eng.last_msm_clock_ghz() is None                                  # sampled on request only
+        eng.set_stage_timing(True)
+        assert eng.last_msm_clock_ghz() is None                                  # ... and it is the LAST call's sample or nothing: an earlier call's counters are not handed out
     finally:
         eng.set_eq1_short(1)
         eng.set_stage_timing(False)

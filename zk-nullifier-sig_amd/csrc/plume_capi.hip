@@ -131,6 +131,7 @@ struct plume_ctx {
     hipEvent_t pre_begin = nullptr;                               // ... the caller's stream has reached the call (inputs are there, the workspace is free)
     std::vector<hipEvent_t> pre_ready;                            // ... sub-batch k's window tables are built
     const char* last_msm_kernel = nullptr;                         // the multi-scalar kernel the last verify call on this context launched (plume_last_msm_kernel)
+    bool last_msm_sampled = false;                                 // ... and whether that launch sampled its clocks (plume_last_msm_clock: stage timing was on for the call)
     std::vector<size_t> redo_counters;                            // word offsets (in `redo`) of the last verify call's redo counters, one per sub-batch (plume_last_redo_tasks)
     int sub_batches = 1;                                          // device-resident verify / sign: number of sub-batches; 1 = strictly serial launch order (the default: measured on the MI355X, r03, kernels of two
                                                                   // streams sharing the CUs cost MORE than the table kernel's idle issue slots give back -- 21.85 ms serial vs 22.1-22.4 ms for 2..16 sub-batches, LABNOTES.md §6)
@@ -803,10 +804,12 @@ static int verify_device(plume_ctx* ctx, int version, int mode, size_t n, const 
             HIPCHK(hipStreamWaitEvent(st, ctx->pre_ready[k], 0));
         }
         ctx->last_msm_kernel = verify_msm_kernel_name(a);
+        if (k == 0) ctx->last_msm_sampled = false;
         if (t.on && !overlapped && k == 0) {                                   // stage timing: the multi-scalar kernel also samples its clocks (plume_last_msm_clock)
             if (ctx->clk.ensure(16)) return PLUME_ERR_HIP;
             HIPCHK(hipMemsetAsync(ctx->clk.p, 0, 16, st));
             a.clk = ctx->clk.as<unsigned long long>();
+            ctx->last_msm_sampled = true;
         }
         launch_verify_msm(a, st); if (!overlapped) t.stage("verify_msm", st);
         if (version == 2 && mode == PLUME_MODE_VERIFY) { launch_normalize(a.res, a.resinf, 2 * cnt, st); if (!overlapped) t.stage("to_affine", st); }   // V2 hashes the computed R', Hr'
@@ -1744,7 +1747,7 @@ extern "C" int plume_last_msm_clock(plume_ctx* ctx, double* ghz) {
     if (ctx && ctx->lane_last) ctx = ctx->lane_last;
     if (int rc = bind(ctx)) return rc;
     if (!ghz) return fail(PLUME_ERR_ARG, "null argument");
-    if (!ctx->timer.on || !ctx->clk.p || !ctx->last_msm_kernel) return fail(PLUME_ERR_ARG, "plume_last_msm_clock: no verify call with stage timing on (plume_set_stage_timing) has run on this context");
+    if (!ctx->last_msm_sampled || !ctx->clk.p || !ctx->last_msm_kernel) return fail(PLUME_ERR_ARG, "plume_last_msm_clock: no verify call with stage timing on (plume_set_stage_timing) has run on this context");
     HIPCHK(hipDeviceSynchronize());
     unsigned long long c[2] = {0, 0};
     HIPCHK(hipMemcpy(c, ctx->clk.p, 16, hipMemcpyDeviceToHost));
